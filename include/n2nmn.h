@@ -1,0 +1,217 @@
+/*
+ * n2nmn.h -- C ABI of the MI355X-native N2NMN (CLEVR) forward hot path.
+ *
+ * This is the drop-in boundary.  The reference is pure Python on top of
+ * TensorFlow 1.0.0 + TensorFlow-Fold 0.0.1; the "FFI" it would bind for this path is the set of
+ * TF/Fold entry points listed below.  Each export names the reference interface it replaces
+ * (file:line relative to ronghanghu/n2nmn).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative N2NMN_E* code; no C++ exception crosses
+ *     the boundary; n2nmn_last_error() returns a thread-local message for the last failure.
+ *   - all tensor arguments are plain DEVICE pointers (fp32 / int32, layouts stated per argument)
+ *     unless the name ends in _host.  The caller owns every buffer it passes in; the library
+ *     only allocates inside n2nmn_ctx_create / n2nmn_program_create and frees in *_destroy.
+ *   - every launching function takes the HIP stream explicitly and never calls
+ *     hipDeviceSynchronize / hipStreamSynchronize (the only host sync on the path is the caller's
+ *     fetch of predicted_tokens between the two phases, exp_clevr/eval_clevr.py:111-125).
+ *   - one context may be used from one thread at a time; different contexts are independent.
+ *   - data layouts follow the reference: features NHWC, text time-major [T,N], attention maps
+ *     [Nb,H,W,1] row-major, fc/1x1 weights [in,out], conv weights [kh,kw,in,out], LSTM weights
+ *     [in+hidden, 4*hidden] with gate order i,j,f,o (TF BasicLSTMCell, forget_bias = 1).
+ */
+#ifndef N2NMN_H_
+#define N2NMN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define N2NMN_OK            0
+#define N2NMN_EINVAL       -1   /* bad argument (shape / null / out of range)            */
+#define N2NMN_EHIP         -2   /* a HIP runtime call failed (message has the HIP error) */
+#define N2NMN_ENOWEIGHT    -3   /* a required variable was never registered / committed  */
+#define N2NMN_ECAPACITY    -4   /* batch / program larger than the context was built for */
+#define N2NMN_EKEY         -5   /* unknown variable or module name                       */
+
+typedef void *n2nmn_stream;              /* a hipStream_t */
+typedef struct n2nmn_ctx n2nmn_ctx;      /* weights + workspace of one model on one device */
+typedef struct n2nmn_program n2nmn_program; /* packed, level-scheduled batch of layout trees */
+
+/* Module operator codes == CLEVR layout-token indices (exp_clevr/data/vocabulary_layout.txt;
+ * arity / output type tables: models_clevr/nmn3_assembler.py:9-41). */
+typedef enum {
+  N2NMN_OP_SCENE = 0, N2NMN_OP_FIND = 1, N2NMN_OP_FILTER = 2, N2NMN_OP_FIND_SAME_PROPERTY = 3,
+  N2NMN_OP_TRANSFORM = 4, N2NMN_OP_AND = 5, N2NMN_OP_OR = 6, N2NMN_OP_EXIST = 7,
+  N2NMN_OP_COUNT = 8, N2NMN_OP_EQUAL_NUM = 9, N2NMN_OP_MORE_NUM = 10, N2NMN_OP_LESS_NUM = 11,
+  N2NMN_OP_SAME_PROPERTY = 12, N2NMN_OP_DESCRIBE = 13, N2NMN_NUM_OPS = 14
+} n2nmn_op;
+
+/* Model dimensions (defaults of exp_clevr/eval_clevr.py:27-37 in comments). */
+typedef struct {
+  int32_t H, W, D;            /* 10, 15, 512   image feature grid                          */
+  int32_t map_dim;            /* 250           models_clevr/nmn3_modules.py map_dim         */
+  int32_t embed_dim_txt;      /* 300 */
+  int32_t embed_dim_nmn;      /* 300 */
+  int32_t lstm_dim;           /* 512 */
+  int32_t num_layers;         /* 2   (only 2 is supported) */
+  int32_t num_vocab_txt;      /* 82  */
+  int32_t num_vocab_nmn;      /* 15  (last index = <eos>) */
+  int32_t num_choices;        /* 28  */
+  int32_t T_encoder;          /* 45  maximum encoder length */
+  int32_t T_decoder;          /* 20  maximum decoder length */
+  int32_t N;                  /* 64  maximum batch size */
+  int32_t kernel_size;        /* 5   TransformModule conv kernel */
+} n2nmn_dims;
+
+const char *n2nmn_last_error(void);
+const char *n2nmn_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * (1) context, weights.   Replaces: tf.Session + tf.get_variable + tf.train.Saver.restore
+ *     (exp_clevr/eval_clevr.py:18-20,90-91; models_clevr/nmn3_modules.py:11-47).
+ * ---------------------------------------------------------------------------------------- */
+int n2nmn_ctx_create(const n2nmn_dims *dims, int device, n2nmn_ctx **out);
+int n2nmn_ctx_destroy(n2nmn_ctx *ctx);
+int n2nmn_ctx_dims(const n2nmn_ctx *ctx, n2nmn_dims *out);
+
+/* Register one variable by its reference (TF 1.0.0) name, e.g.
+ * "neural_module_network/layout_execution/module_variables/FindModule/conv_image/weights".
+ * `data` is a device pointer to contiguous fp32 in the reference's layout; it is only read
+ * during n2nmn_commit_weights.  shape is checked against the model dimensions. */
+int n2nmn_set_weight(n2nmn_ctx *ctx, const char *name, const float *data,
+                     const int64_t *shape, int ndim);
+/* Re-pack every registered variable into the kernels' HBM layouts (k-interleaved MFMA operand
+ * tiles, gate-interleaved LSTM column tiles).  Must be called after the
+ * variables change and before any forward.  Asynchronous on `stream`. */
+int n2nmn_commit_weights(n2nmn_ctx *ctx, n2nmn_stream stream);
+/* Validity automaton of the layout vocabulary: Assembler.P [V,3], Assembler.W [3,V,4],
+ * Assembler.b [V,4] (models_clevr/nmn3_assembler.py:50-119), which the reference hands to the
+ * decoder at models_clevr/nmn3_netgen_att.py:59-62.  HOST int32 pointers, copied synchronously. */
+int n2nmn_set_validity_tables(n2nmn_ctx *ctx, const int32_t *P_host, const int32_t *W_host,
+                              const int32_t *b_host);
+/* Number of expected variables and the i-th expected name/shape (introspection for loaders). */
+int n2nmn_num_variables(const n2nmn_ctx *ctx);
+int n2nmn_variable_info(const n2nmn_ctx *ctx, int i, const char **name, int64_t shape[4],
+                        int *ndim);
+
+/* ------------------------------------------------------------------------------------------
+ * (2) phase 1: layout generator.   Replaces AttentionSeq2Seq's graph
+ *     (models_clevr/nmn3_netgen_att.py:46-322: tf.nn.embedding_lookup, tf.nn.dynamic_rnn,
+ *     tf.nn.raw_rnn + loop_fn, util/cnn.py:87-119 fc) as run by the first sess.partial_run
+ *     (exp_clevr/eval_clevr.py:111-114).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  /* inputs */
+  const int32_t *input_seq;        /* [T_enc, N] time-major word indices, zero padded       */
+  const int32_t *seq_length;       /* [N]                                                   */
+  int32_t T_enc, N, T_dec;
+  int32_t use_gt_layout;           /* != 0: teacher forcing, all tokens valid (:204-207,239-241) */
+  const int32_t *gt_layout;        /* [T_dec, N] or NULL                                    */
+  const float *sample_uniforms;    /* [T_dec, N] in [0,1) -> decoder_sampling=True (:212-232,
+                                      inverse-CDF stand-in for tf.multinomial); NULL = greedy */
+  const int32_t *forced_tokens;    /* [T_dec, N] or NULL: parity hook, overrides the chosen token
+                                      without touching validity / probabilities            */
+  /* outputs (NULL = not wanted) */
+  int32_t *predicted_tokens;       /* [T_dec, N]                                            */
+  float *token_probs;              /* [T_dec, N]                                            */
+  float *neg_entropy;              /* [N]                                                   */
+  float *atts;                     /* [T_dec, T_enc, N] (the reference's trailing 1 dropped) */
+  float *word_vecs;                /* [T_dec, N, embed_dim_txt]                             */
+  float *token_scores;             /* [T_dec, N, num_vocab_nmn] pre-mask logits (debug/parity) */
+  float *encoder_outputs;          /* [T_enc, N, lstm_dim]                                  */
+  float *encoder_h_transformed;    /* [T_enc, N, lstm_dim]                                  */
+  float *encoder_states;           /* [2 layers][c,h][N, lstm_dim]                          */
+  float *log_seq_prob;             /* [N] sum_t log token_probs (models_clevr/nmn3_model.py:46) */
+} n2nmn_seq2seq_io;
+
+int n2nmn_encoder_forward(n2nmn_ctx *ctx, const n2nmn_seq2seq_io *io, n2nmn_stream stream);
+/* decoder uses the encoder results held in the context by the preceding encoder call */
+int n2nmn_decoder_forward(n2nmn_ctx *ctx, const n2nmn_seq2seq_io *io, n2nmn_stream stream);
+/* encoder + decoder in one call */
+int n2nmn_seq2seq_forward(n2nmn_ctx *ctx, const n2nmn_seq2seq_io *io, n2nmn_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * (3) host: RPN tokens -> packed program.   Replaces Assembler.assemble
+ *     (models_clevr/nmn3_assembler.py:153-222) + td.Compiler.build_feed_dict / Loom's
+ *     serialisation and per-depth batching (models_clevr/nmn3_model.py:55-159;
+ *     exp_clevr/eval_clevr.py:125-128).  Pure host code, no GPU needed.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t op;          /* n2nmn_op */
+  int32_t time_idx;    /* RPN position t: text parameter row t*N_full + batch_idx            */
+  int32_t batch_idx;   /* question / image index                                             */
+  int32_t in0, in1;    /* node ids of input_0 / input_1 (input_1 = most recently pushed), -1 */
+  int32_t level;       /* dependency level assigned by the scheduler                          */
+  int32_t out_row;     /* answer nodes: row of `scores`; attention nodes: -1                  */
+  int32_t reserved;
+} n2nmn_node;
+
+/* assembly error kinds, in the order the reference checks them (nmn3_assembler.py:172-211) */
+#define N2NMN_ASM_OK            0
+#define N2NMN_ASM_NO_EOS        1  /* 'cannot find <eos>'                                  */
+#define N2NMN_ASM_NOT_ENOUGH    2  /* 'not enough input for <module>'                      */
+#define N2NMN_ASM_INCOMPATIBLE  3  /* 'input incompatible for <module>'                    */
+#define N2NMN_ASM_STACK_SIZE    4  /* 'final stack size not equal to 1 (<k> remains)'      */
+#define N2NMN_ASM_NOT_ANS       5  /* 'result type must be ans, not att'                   */
+
+int n2nmn_program_create(n2nmn_program **out);
+int n2nmn_program_destroy(n2nmn_program *p);
+/* tokens_host [T,N] int32 (host).  token_op_host[V]: op code of each layout token, or -1 for
+ * <eos>.  validity_host[N] receives 1/0 like expr_validity_array.  Never fails on invalid
+ * layouts -- they are data (INVALID_EXPR -> zero logits, nmn3_model.py:146,155). */
+int n2nmn_assemble(n2nmn_program *p, const int32_t *tokens_host, int T, int N,
+                   const int32_t *token_op_host, int V, uint8_t *validity_host);
+/* Build a program from explicit nodes (the dict-walking build_feed_dict path).  `nodes_host`
+ * must be topologically ordered (inputs before consumers); level / reserved are ignored and
+ * recomputed.  num_rows = number of score rows (len(expr_list)). */
+int n2nmn_program_from_nodes(n2nmn_program *p, const n2nmn_node *nodes_host, int num_nodes,
+                             int num_rows);
+int n2nmn_program_num_nodes(const n2nmn_program *p);
+int n2nmn_program_num_rows(const n2nmn_program *p);
+int n2nmn_program_num_levels(const n2nmn_program *p);
+int n2nmn_program_get_nodes(const n2nmn_program *p, n2nmn_node *out_host, int capacity);
+/* per-example assembly status: kind (N2NMN_ASM_*), offending op (or -1), remaining stack size */
+int n2nmn_program_status(const n2nmn_program *p, int example, int32_t *kind, int32_t *op,
+                         int32_t *remains);
+/* number of kernel launches execute_program will issue for this program (scheduler metric) */
+int n2nmn_program_num_launches(const n2nmn_program *p);
+
+/* ------------------------------------------------------------------------------------------
+ * (4) phase 2: module-network execution.   Replaces compiler.loom_input_tensor ->
+ *     compiler.output_tensors[0] (models_clevr/nmn3_model.py:158-159), i.e. Loom's depth-wise
+ *     dynamic batching of the Modules.* operators, as run by the second sess.partial_run
+ *     (exp_clevr/eval_clevr.py:132).
+ *     image_feat [N_full,H,W,D]; word_vecs [T_dec,N_full,E]; scores [num_rows, num_choices].
+ * ---------------------------------------------------------------------------------------- */
+int n2nmn_execute_program(n2nmn_ctx *ctx, n2nmn_program *p, const float *image_feat,
+                          const float *word_vecs, int N_full, float *scores,
+                          n2nmn_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * (5) one direct entry per module operator, mirroring Modules.<X>Module(input_0[, input_1],
+ *     time_idx, batch_idx) (models_clevr/nmn3_modules.py:60-495; used directly by
+ *     exp_shapes/visualize_shapes.ipynb).  input_0 / input_1: [Nb,H,W] attention logits or NULL
+ *     according to the op's arity; time_idx_host / batch_idx_host: [Nb] int32 on the HOST;
+ *     out: [Nb,H,W] (attention modules) or [Nb,num_choices] (answer modules).
+ * ---------------------------------------------------------------------------------------- */
+int n2nmn_module_forward(n2nmn_ctx *ctx, int op, int Nb, const float *input_0,
+                         const float *input_1, const int32_t *time_idx_host,
+                         const int32_t *batch_idx_host, const float *image_feat,
+                         const float *word_vecs, int N_full, float *out, n2nmn_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * (7) introspection used by the roofline report: algorithmic bytes / flops of one launch of a
+ *     kernel family (SURVEY.md section 8d figures), and a plain GEMM entry for unit parity.
+ * ---------------------------------------------------------------------------------------- */
+/* C[M,N] = A[M,K] . B[K,N] + bias[N]   (row-major fp32; B is packed internally) */
+int n2nmn_debug_gemm(n2nmn_ctx *ctx, const float *A, const float *B, const float *bias,
+                     float *C, int M, int N, int K, n2nmn_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* N2NMN_H_ */

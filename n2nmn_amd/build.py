@@ -1,0 +1,80 @@
+"""In-tree build of the gfx950 shared library (hipcc cross-compiles without a GPU).
+
+    python -m n2nmn_amd.build [--force]
+
+Produces n2nmn_amd/lib/libn2nmn_hip.so from csrc/*.hip + csrc/*.cpp.  The .so is git-ignored but
+travels to the GPU box with the gpurun snapshot.
+"""
+from __future__ import annotations
+
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIBDIR = os.path.join(HERE, 'lib')
+LIB = os.path.join(LIBDIR, 'libn2nmn_hip.so')
+ARCH = 'gfx950'
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, '*.hip')) + glob.glob(os.path.join(CSRC, '*.cpp')))
+
+
+def _deps():
+    return sources() + glob.glob(os.path.join(CSRC, '*.h')) + \
+        [os.path.join(HERE, '..', 'include', 'n2nmn.h')]
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(p) > t for p in _deps())
+
+
+def hipcc() -> str:
+    exe = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(exe):
+        raise RuntimeError('hipcc not found: the HIP extension cannot be built')
+    return exe
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not is_stale():
+        return LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    objs = []
+    procs = []
+    objdir = os.path.join(LIBDIR, 'obj')
+    os.makedirs(objdir, exist_ok=True)
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src) + '.o')
+        objs.append(obj)
+        cmd = [hipcc(), '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-x', 'hip',
+               '-Wall', '-Wno-unused-function', '-c', src, '-o', obj]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    failed = False
+    for src, p in procs:
+        out, _ = p.communicate()
+        if out and verbose:
+            sys.stdout.write(out.decode(errors='replace'))
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write('FAILED: %s\n%s\n' % (src, out.decode(errors='replace')))
+    if failed:
+        raise RuntimeError('hipcc failed')
+    cmd = [hipcc(), '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

@@ -1,0 +1,706 @@
+// C ABI of the N2NMN hot path (include/n2nmn.h): context / weight store, phase-1 and phase-2
+// launch orchestration.  Host code only; the kernels live in the .hip files.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "kernels.h"
+#include "program.h"
+
+namespace n2nmn {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& s) { g_last_error = s; }
+
+#define N2_HIP(expr)                                                                     \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      set_last_error(std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+      return N2NMN_EHIP;                                                                 \
+    }                                                                                    \
+  } while (0)
+
+#define N2_REQUIRE(cond, code, msg)                                                      \
+  do {                                                                                   \
+    if (!(cond)) {                                                                       \
+      set_last_error(msg);                                                               \
+      return code;                                                                       \
+    }                                                                                    \
+  } while (0)
+
+struct Var {
+  std::string name;
+  std::vector<int64_t> shape;
+  size_t numel = 0;
+  float* mirror = nullptr;   // context-owned copy in the reference layout
+  bool set = false;
+};
+
+// indices into Ctx::vars (order of build_vars)
+enum VarId {
+  V_ENC_EMB, V_ENC_W0, V_ENC_B0, V_ENC_W1, V_ENC_B1, V_EHT_W, V_EHT_B,
+  V_DEC_EMB, V_DEC_GO, V_ATT_V, V_ATT_W, V_ATT_B, V_TOK_W, V_TOK_B,
+  V_DEC_W0, V_DEC_B0, V_DEC_W1, V_DEC_B1,
+  V_FIND_IMG_W, V_FIND_IMG_B, V_FIND_TXT_W, V_FIND_TXT_B, V_FIND_E_W, V_FIND_E_B,
+  V_FSP_IMG_W, V_FSP_IMG_B, V_FSP_TXT_W, V_FSP_TXT_B, V_FSP_ATT_W, V_FSP_ATT_B, V_FSP_E_W,
+  V_FSP_E_B,
+  V_TR_MAPS_W, V_TR_MAPS_B, V_TR_TXT_W, V_TR_TXT_B, V_TR_E_W, V_TR_E_B,
+  V_EXIST_W, V_EXIST_B, V_COUNT_W, V_COUNT_B, V_EQ_W, V_EQ_B, V_MORE_W, V_MORE_B, V_LESS_W,
+  V_LESS_B,
+  V_SP_TXT_W, V_SP_TXT_B, V_SP_ATT0_W, V_SP_ATT0_B, V_SP_ATT1_W, V_SP_ATT1_B, V_SP_E_W, V_SP_E_B,
+  V_DE_TXT_W, V_DE_TXT_B, V_DE_ATT_W, V_DE_ATT_B, V_DE_E_W, V_DE_E_B,
+  V_COUNT_
+};
+
+}  // namespace n2nmn
+
+using namespace n2nmn;
+
+struct n2nmn_ctx {
+  n2nmn_dims d{};
+  int device = 0;
+  std::vector<Var> vars;
+  std::unordered_map<std::string, int> index;
+  bool committed = false;
+  bool have_tables = false;
+
+  char* base = nullptr;
+  size_t bytes = 0;
+
+  int Mp = 0, HWp = 0, KpE = 0, KpL = 0, KpD = 0;
+  int max_nodes = 0, max_text = 0, max_pool = 0;
+
+  // packed weights / derived tables
+  float *enc_W0x_p = nullptr, *dec_W0x_p = nullptr, *enc_xtab = nullptr, *dec_xtab = nullptr;
+  float *enc_W0h_t = nullptr, *enc_W1_t = nullptr, *dec_W0h_t = nullptr, *dec_W1_t = nullptr;
+  float *eht_W_p = nullptr, *att_W_t = nullptr, *find_img_p = nullptr, *fsp_img_p = nullptr;
+  float* dec_emb_cat = nullptr;
+  float* we_pad[3] = {nullptr, nullptr, nullptr};
+  float* batt_pad[4] = {nullptr, nullptr, nullptr, nullptr};
+  int32_t *P = nullptr, *Wv = nullptr, *bv = nullptr;
+
+  // seq2seq workspace
+  float *eh0[2] = {nullptr, nullptr}, *eh1[2] = {nullptr, nullptr}, *ec0 = nullptr, *ec1 = nullptr;
+  float *dh0[2] = {nullptr, nullptr}, *dh1[2] = {nullptr, nullptr}, *dc0 = nullptr, *dc1 = nullptr;
+  float *enc_out = nullptr, *eht = nullptr, *qbuf = nullptr;
+  int32_t *state = nullptr, *next_idx = nullptr, *tokens = nullptr;
+  float *tprobs = nullptr, *negent = nullptr, *atts = nullptr, *word_vecs = nullptr;
+  int enc_T = 0, enc_N = 0;            // shape of the encoder results currently held
+  const int32_t* enc_seq = nullptr;    // input_seq of the last encoder call (for word_vecs)
+  const int32_t* enc_len = nullptr;
+
+  // module workspace
+  float *arena = nullptr, *tmap = nullptr, *pfc = nullptr, *mfind = nullptr, *mfsp = nullptr;
+  DevNode* dev_nodes = nullptr;
+  int32_t* dev_tab = nullptr;
+  int max_tab = 0;
+
+  n2nmn_program* scratch_prog = nullptr;   // used by n2nmn_module_forward
+};
+
+namespace n2nmn {
+
+static void add_var(n2nmn_ctx* c, const std::string& name, std::vector<int64_t> shape) {
+  Var v;
+  v.name = name;
+  v.shape = std::move(shape);
+  v.numel = 1;
+  for (auto s : v.shape) v.numel *= (size_t)s;
+  c->index[name] = (int)c->vars.size();
+  c->vars.push_back(std::move(v));
+}
+
+// Variable names follow TF 1.0.0 scoping of the reference graph (SURVEY.md Appendix A.6;
+// models_clevr/nmn3_model.py:22-49, nmn3_netgen_att.py:82-86,102-103,139-156,
+// nmn3_modules.py scope= arguments, util/cnn.py:19-25,104-109).  Order must match enum VarId.
+static void build_vars(n2nmn_ctx* c) {
+  const n2nmn_dims& d = c->d;
+  const int64_t L = d.lstm_dim, E = d.embed_dim_txt, En = d.embed_dim_nmn, M = d.map_dim,
+                C = d.num_choices, D = d.D, HW = (int64_t)d.H * d.W, ks = d.kernel_size;
+  const std::string enc = "neural_module_network/layout_generation/encoder_decoder/encoder/";
+  const std::string dec = "neural_module_network/layout_generation/encoder_decoder/decoder/";
+  const std::string mod = "neural_module_network/layout_execution/module_variables/";
+  auto lstm = [&](const std::string& base, int layer, const char* kind) {
+    return base + "lstm/multi_rnn_cell/cell_" + std::to_string(layer) + "/basic_lstm_cell/" + kind;
+  };
+  add_var(c, enc + "embedding_mat", {d.num_vocab_txt, E});
+  add_var(c, lstm(enc, 0, "weights"), {E + L, 4 * L});
+  add_var(c, lstm(enc, 0, "biases"), {4 * L});
+  add_var(c, lstm(enc, 1, "weights"), {2 * L, 4 * L});
+  add_var(c, lstm(enc, 1, "biases"), {4 * L});
+  add_var(c, enc + "encoder_h_transform/weights", {L, L});
+  add_var(c, enc + "encoder_h_transform/biases", {L});
+  add_var(c, dec + "embedding_mat", {d.num_vocab_nmn, En});
+  add_var(c, dec + "go_embedding", {1, En});
+  add_var(c, dec + "att_prediction/v", {L});
+  add_var(c, dec + "att_prediction/weights", {L, L});
+  add_var(c, dec + "att_prediction/biases", {L});
+  add_var(c, dec + "token_prediction/weights", {2 * L, d.num_vocab_nmn});
+  add_var(c, dec + "token_prediction/biases", {d.num_vocab_nmn});
+  add_var(c, lstm(dec, 0, "weights"), {En + L, 4 * L});
+  add_var(c, lstm(dec, 0, "biases"), {4 * L});
+  add_var(c, lstm(dec, 1, "weights"), {2 * L, 4 * L});
+  add_var(c, lstm(dec, 1, "biases"), {4 * L});
+  auto layer = [&](const char* scope, const char* name, std::vector<int64_t> shape) {
+    const int64_t out = shape.back();
+    add_var(c, mod + scope + "/" + name + "/weights", shape);
+    add_var(c, mod + scope + "/" + name + "/biases", {out});
+  };
+  layer("FindModule", "conv_image", {D, M});
+  layer("FindModule", "fc_text", {E, M});
+  layer("FindModule", "conv_eltwise", {M, 1});
+  layer("FindSamePropertyModule", "conv_image", {D, M});
+  layer("FindSamePropertyModule", "fc_text", {E, M});
+  layer("FindSamePropertyModule", "fc_att", {D, M});
+  layer("FindSamePropertyModule", "conv_eltwise", {M, 1});
+  layer("TransformModule", "conv_maps", {ks, ks, 1, M});
+  layer("TransformModule", "text_fc", {E, M});
+  layer("TransformModule", "conv_eltwise", {M, 1});
+  layer("ExistModule", "fc_scores", {3, C});
+  layer("CountModule", "fc_scores", {HW + 2, C});
+  layer("EqualNumModule", "fc_scores", {2 * HW + 4, C});
+  layer("MoreNumModule", "fc_scores", {2 * HW + 4, C});
+  layer("LessNumModule", "fc_scores", {2 * HW + 4, C});
+  layer("SamePropertyModule", "fc_text", {E, M});
+  layer("SamePropertyModule", "fc_att_0", {D, M});
+  layer("SamePropertyModule", "fc_att_1", {D, M});
+  layer("SamePropertyModule", "fc_eltwise", {M, C});
+  layer("DescribeModule", "fc_text", {E, M});
+  layer("DescribeModule", "fc_att", {D, M});
+  layer("DescribeModule", "fc_eltwise", {M, C});
+}
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(char* b) : base(b) {}
+  template <typename T>
+  T* take(size_t count) {
+    off = align_up(off, 256);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += count * sizeof(T);
+    return p;
+  }
+};
+
+// lays out every buffer of the context; with base == nullptr only computes the size
+static size_t carve(n2nmn_ctx* c, char* base) {
+  const n2nmn_dims& d = c->d;
+  const size_t L = d.lstm_dim, E = d.embed_dim_txt, N = d.N, T = d.T_encoder, Td = d.T_decoder,
+               V = d.num_vocab_nmn, Vt = d.num_vocab_txt, D = d.D, HW = (size_t)d.H * d.W;
+  const size_t Mp = c->Mp, HWp = c->HWp;
+  Carver k(base);
+  for (auto& v : c->vars) v.mirror = k.take<float>(v.numel);
+  c->enc_W0x_p = k.take<float>((size_t)c->KpE * 4 * L);
+  c->dec_W0x_p = k.take<float>((size_t)c->KpE * 4 * L);
+  c->enc_xtab = k.take<float>(Vt * 4 * L);
+  c->dec_xtab = k.take<float>((V + 1) * 4 * L);
+  c->enc_W0h_t = k.take<float>(L * 4 * L);
+  c->enc_W1_t = k.take<float>(2 * L * 4 * L);
+  c->dec_W0h_t = k.take<float>(L * 4 * L);
+  c->dec_W1_t = k.take<float>(2 * L * 4 * L);
+  c->eht_W_p = k.take<float>((size_t)c->KpL * L);
+  c->att_W_t = k.take<float>(L * L);
+  c->find_img_p = k.take<float>((size_t)c->KpD * Mp);
+  c->fsp_img_p = k.take<float>((size_t)c->KpD * Mp);
+  c->dec_emb_cat = k.take<float>((V + 1) * (size_t)d.embed_dim_nmn);
+  for (int i = 0; i < 3; ++i) c->we_pad[i] = k.take<float>(Mp);
+  for (int i = 0; i < 4; ++i) c->batt_pad[i] = k.take<float>(Mp);
+  c->P = k.take<int32_t>(V * 3);
+  c->Wv = k.take<int32_t>(3 * V * 4);
+  c->bv = k.take<int32_t>(V * 4);
+  // recurrent state: one contiguous block so the encoder can clear it with one memset
+  float* st = k.take<float>(6 * N * L);
+  c->eh0[0] = st; c->eh0[1] = st + N * L; c->eh1[0] = st + 2 * N * L; c->eh1[1] = st + 3 * N * L;
+  c->ec0 = st + 4 * N * L; c->ec1 = st + 5 * N * L;
+  float* ds = k.take<float>(6 * N * L);
+  c->dh0[0] = ds; c->dh0[1] = ds + N * L; c->dh1[0] = ds + 2 * N * L; c->dh1[1] = ds + 3 * N * L;
+  c->dc0 = ds + 4 * N * L; c->dc1 = ds + 5 * N * L;
+  c->enc_out = k.take<float>(T * N * L);
+  c->eht = k.take<float>(T * N * L);
+  c->qbuf = k.take<float>(N * L);
+  c->state = k.take<int32_t>(N * 3);
+  c->next_idx = k.take<int32_t>(N);
+  c->tokens = k.take<int32_t>(Td * N);
+  c->tprobs = k.take<float>(Td * N);
+  c->negent = k.take<float>(N);
+  c->atts = k.take<float>(Td * T * N);
+  c->word_vecs = k.take<float>(Td * N * E);
+  // module workspace
+  c->arena = k.take<float>((size_t)c->max_nodes * HWp);
+  c->tmap = k.take<float>((size_t)c->max_text * Mp);
+  c->pfc = k.take<float>((size_t)c->max_pool * 2 * POOL_PARTS * Mp);
+  c->mfind = k.take<float>(N * HW * Mp);
+  c->mfsp = k.take<float>(N * HW * Mp);
+  c->dev_nodes = k.take<DevNode>(c->max_nodes);
+  c->dev_tab = k.take<int32_t>(c->max_tab);
+  (void)D;
+  return align_up(k.off, 256);
+}
+
+static hipStream_t S(n2nmn_stream s) { return reinterpret_cast<hipStream_t>(s); }
+
+static int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_last_error(std::string(what) + ": " + hipGetErrorString(e));
+    return N2NMN_EHIP;
+  }
+  return N2NMN_OK;
+}
+
+static ModuleWeights module_weights(const n2nmn_ctx* c) {
+  ModuleWeights w{};
+  auto m = [&](int id) { return (const float*)c->vars[id].mirror; };
+  const int txtw[5] = {V_FIND_TXT_W, V_FSP_TXT_W, V_TR_TXT_W, V_SP_TXT_W, V_DE_TXT_W};
+  for (int i = 0; i < 5; ++i) { w.Wtxt[i] = m(txtw[i]); w.btxt[i] = m(txtw[i] + 1); }
+  for (int i = 0; i < 3; ++i) w.we[i] = c->we_pad[i];
+  w.be[0] = m(V_FIND_E_B); w.be[1] = m(V_FSP_E_B); w.be[2] = m(V_TR_E_B);
+  w.Kt = m(V_TR_MAPS_W); w.bt = m(V_TR_MAPS_B);
+  const int attw[4] = {V_FSP_ATT_W, V_SP_ATT0_W, V_SP_ATT1_W, V_DE_ATT_W};
+  for (int i = 0; i < 4; ++i) { w.Watt[i] = m(attw[i]); w.batt[i] = c->batt_pad[i]; }
+  const int answ[7] = {V_EXIST_W, V_COUNT_W, V_EQ_W, V_MORE_W, V_LESS_W, V_SP_E_W, V_DE_E_W};
+  for (int i = 0; i < 7; ++i) { w.Wans[i] = m(answ[i]); w.bans[i] = m(answ[i] + 1); }
+  return w;
+}
+
+static int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s) {
+  const n2nmn_dims& d = c->d;
+  N2_REQUIRE(c->committed, N2NMN_ENOWEIGHT, "encoder_forward: weights not committed");
+  N2_REQUIRE(io && io->input_seq && io->seq_length, N2NMN_EINVAL, "encoder_forward: null input");
+  const int T = io->T_enc, N = io->N, L = d.lstm_dim;
+  N2_REQUIRE(T >= 1 && T <= d.T_encoder && N >= 1 && N <= d.N, N2NMN_ECAPACITY,
+             "encoder_forward: T_enc / N exceed the context capacity");
+  N2_HIP(hipMemsetAsync(c->eh0[0], 0, sizeof(float) * 6 * (size_t)d.N * L, s));
+  const float* W0x_bias_table = c->enc_xtab;
+  // software-pipelined over time: launch k runs layer-0 step k and layer-1 step k-1
+  for (int k = 0; k <= T; ++k) {
+    LstmJob jobs[2];
+    LstmJob& j0 = jobs[0];
+    j0 = LstmJob{};
+    j0.active = k < T;
+    j0.A0 = c->eh0[(k + 1) & 1]; j0.A1 = nullptr; j0.K = L; j0.Wp = c->enc_W0h_t;
+    j0.xtab = W0x_bias_table; j0.xidx = io->input_seq + (size_t)k * N; j0.xidx_const = 0;
+    j0.bias = nullptr; j0.c_in = c->ec0; j0.c_out = c->ec0; j0.ntiles = L / 4;
+    j0.h_old = c->eh0[(k + 1) & 1]; j0.h_new = c->eh0[k & 1];
+    j0.out_seq = nullptr; j0.seq_len = io->seq_length; j0.t = k;
+    LstmJob& j1 = jobs[1];
+    j1 = LstmJob{};
+    const int st = k - 1;
+    j1.active = st >= 0;
+    j1.A0 = c->eh0[st & 1]; j1.A1 = c->eh1[(st + 1) & 1]; j1.K = 2 * L; j1.Wp = c->enc_W1_t;
+    j1.xtab = nullptr; j1.xidx = nullptr; j1.bias = c->vars[V_ENC_B1].mirror;
+    j1.c_in = c->ec1; j1.c_out = c->ec1; j1.ntiles = L / 4;
+    j1.h_old = c->eh1[(st + 1) & 1]; j1.h_new = c->eh1[st & 1];
+    j1.out_seq = st >= 0 ? c->enc_out + (size_t)st * N * L : nullptr;
+    j1.seq_len = io->seq_length; j1.t = st;
+    launch_lstm_step(jobs, 2, N, L, s);
+  }
+  // encoder_h_transformed = fc(encoder_outputs)          (nmn3_netgen_att.py:102-106)
+  GemmArgs g{};
+  g.A = c->enc_out; g.lda = L; g.M = T * N; g.K = L; g.group_idx = nullptr; g.group_size = 1;
+  g.Bp = c->eht_W_p; g.Np = L; g.Kp = c->KpL; g.bias = c->vars[V_EHT_B].mirror; g.N = L;
+  g.C = c->eht; g.ldc = L; g.n_store = L;
+  launch_gemm_pk(g, s);
+  c->enc_T = T; c->enc_N = N; c->enc_seq = io->input_seq; c->enc_len = io->seq_length;
+  const size_t nl = sizeof(float) * (size_t)N * L;
+  if (io->encoder_outputs)
+    N2_HIP(hipMemcpyAsync(io->encoder_outputs, c->enc_out, nl * T, hipMemcpyDeviceToDevice, s));
+  if (io->encoder_h_transformed)
+    N2_HIP(hipMemcpyAsync(io->encoder_h_transformed, c->eht, nl * T, hipMemcpyDeviceToDevice, s));
+  if (io->encoder_states) {
+    const int pe = (T - 1) & 1;
+    const float* src[4] = {c->ec0, c->eh0[pe], c->ec1, c->eh1[pe]};
+    for (int i = 0; i < 4; ++i)
+      N2_HIP(hipMemcpyAsync(io->encoder_states + (size_t)i * N * L, src[i], nl,
+                            hipMemcpyDeviceToDevice, s));
+  }
+  return check_launch("encoder_forward");
+}
+
+static int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s) {
+  const n2nmn_dims& d = c->d;
+  N2_REQUIRE(c->committed, N2NMN_ENOWEIGHT, "decoder_forward: weights not committed");
+  N2_REQUIRE(c->have_tables, N2NMN_ENOWEIGHT,
+             "decoder_forward: validity tables (assembler P/W/b) not set");
+  N2_REQUIRE(io, N2NMN_EINVAL, "decoder_forward: null io");
+  N2_REQUIRE(c->enc_T > 0 && io->N == c->enc_N && io->T_enc == c->enc_T, N2NMN_EINVAL,
+             "decoder_forward: no matching encoder results in the context");
+  const int T = c->enc_T, N = c->enc_N, L = d.lstm_dim, Td = io->T_dec, V = d.num_vocab_nmn;
+  N2_REQUIRE(Td >= 1 && Td <= d.T_decoder, N2NMN_ECAPACITY, "decoder_forward: T_dec too large");
+  N2_REQUIRE(!io->use_gt_layout || io->gt_layout, N2NMN_EINVAL,
+             "decoder_forward: use_gt_layout without gt_layout");
+  int32_t* tokens = io->predicted_tokens ? io->predicted_tokens : c->tokens;
+  float* tprobs = io->token_probs ? io->token_probs : c->tprobs;
+  float* negent = io->neg_entropy ? io->neg_entropy : c->negent;
+  float* atts = io->atts ? io->atts : c->atts;
+  float* wv = io->word_vecs ? io->word_vecs : c->word_vecs;
+  launch_dec_init(c->state, negent, N, Td, s);
+  const int pe = (T - 1) & 1;
+  for (int t = 0; t < Td; ++t) {
+    LstmJob j0{};
+    j0.active = 1;
+    j0.A0 = t == 0 ? c->eh0[pe] : c->dh0[(t + 1) & 1]; j0.K = L; j0.Wp = c->dec_W0h_t;
+    j0.xtab = c->dec_xtab; j0.xidx = t == 0 ? nullptr : c->next_idx; j0.xidx_const = V;  // <go>
+    j0.c_in = t == 0 ? c->ec0 : c->dc0; j0.c_out = c->dc0; j0.ntiles = L / 4;
+    j0.h_old = j0.A0; j0.h_new = c->dh0[t & 1];
+    launch_lstm_step(&j0, 1, N, L, s);
+    LstmJob j1{};
+    j1.active = 1;
+    j1.A0 = c->dh0[t & 1]; j1.A1 = t == 0 ? c->eh1[pe] : c->dh1[(t + 1) & 1]; j1.K = 2 * L;
+    j1.Wp = c->dec_W1_t; j1.bias = c->vars[V_DEC_B1].mirror;
+    j1.c_in = t == 0 ? c->ec1 : c->dc1; j1.c_out = c->dc1; j1.ntiles = L / 4;
+    j1.h_old = j1.A1; j1.h_new = c->dh1[t & 1];
+    launch_lstm_step(&j1, 1, N, L, s);
+    LstmJob jq{};                      // q = out . W_a + b_a            (nmn3_netgen_att.py:185)
+    jq.active = 1; jq.mode = 1; jq.A0 = c->dh1[t & 1]; jq.K = L; jq.Wp = c->att_W_t;
+    jq.ntiles = L / 16; jq.bias = c->vars[V_ATT_B].mirror; jq.h_new = c->qbuf; jq.ldo = L;
+    launch_lstm_step(&jq, 1, N, L, s);
+    DecStepArgs a{};
+    a.q = c->qbuf; a.out = c->dh1[t & 1]; a.eht = c->eht; a.eout = c->enc_out;
+    a.seq_len = c->enc_len; a.v = c->vars[V_ATT_V].mirror; a.Wy = c->vars[V_TOK_W].mirror;
+    a.by = c->vars[V_TOK_B].mirror; a.P = c->P; a.Wv = c->Wv; a.bv = c->bv;
+    a.gt = io->gt_layout ? io->gt_layout + (size_t)t * N : nullptr;
+    a.uni = io->sample_uniforms ? io->sample_uniforms + (size_t)t * N : nullptr;
+    a.forced = io->forced_tokens ? io->forced_tokens + (size_t)t * N : nullptr;
+    a.use_gt = io->use_gt_layout; a.t = t; a.T = T; a.N = N; a.L = L; a.V = V;
+    a.state = c->state; a.tokens = tokens + (size_t)t * N; a.tprobs = tprobs + (size_t)t * N;
+    a.neg_entropy = negent; a.atts = atts + (size_t)t * T * N;
+    a.scores = io->token_scores ? io->token_scores + (size_t)t * N * V : nullptr;
+    a.next_idx = c->next_idx;
+    launch_dec_step(a, s);
+  }
+  launch_word_vecs(atts, c->enc_seq, c->vars[V_ENC_EMB].mirror, Td, T, N, d.embed_dim_txt, wv,
+                   tprobs, io->log_seq_prob, s);
+  return check_launch("decoder_forward");
+}
+
+static int run_program(n2nmn_ctx* c, Program& p, const float* feat, const float* word_vecs,
+                       int N_full, float* scores, const float* ext0, const float* ext1,
+                       float* att_out, int att_out_first, int att_out_count, hipStream_t s) {
+  const n2nmn_dims& d = c->d;
+  N2_REQUIRE(c->committed, N2NMN_ENOWEIGHT, "execute_program: weights not committed");
+  N2_REQUIRE(N_full >= 1 && N_full <= d.N, N2NMN_ECAPACITY, "execute_program: N_full > capacity");
+  const int nn = (int)p.dev_nodes.size();
+  N2_REQUIRE(nn <= c->max_nodes && p.num_text <= c->max_text && p.num_pool <= c->max_pool &&
+                 (int)p.tab.size() <= c->max_tab,
+             N2NMN_ECAPACITY, "execute_program: program larger than the context workspace");
+  for (const DevNode& nd : p.dev_nodes)
+    N2_REQUIRE(nd.op == OP_INPUT || (nd.n < N_full && nd.t < d.T_decoder), N2NMN_EINVAL,
+               "execute_program: batch_idx / time_idx out of range");
+  const int HW = d.H * d.W, C = d.num_choices;
+  if (scores && p.num_rows > 0)
+    N2_HIP(hipMemsetAsync(scores, 0, sizeof(float) * (size_t)p.num_rows * C, s));  // INVALID_EXPR
+  if (nn == 0) return N2NMN_OK;
+  N2_HIP(hipMemcpyAsync(c->dev_nodes, p.dev_nodes.data(), sizeof(DevNode) * nn,
+                        hipMemcpyHostToDevice, s));
+  if (!p.tab.empty())
+    N2_HIP(hipMemcpyAsync(c->dev_tab, p.tab.data(), sizeof(int32_t) * p.tab.size(),
+                          hipMemcpyHostToDevice, s));
+  // externally supplied attention maps (module_forward): node i <- ext[time_idx][batch_idx]
+  for (int i = 0; i < nn; ++i) {
+    const DevNode& nd = p.dev_nodes[i];
+    if (nd.op != OP_INPUT) continue;
+    const float* src = (nd.t == 0 ? ext0 : ext1);
+    N2_REQUIRE(src, N2NMN_EINVAL, "module_forward: missing attention input");
+    N2_HIP(hipMemcpyAsync(c->arena + (size_t)i * c->HWp, src + (size_t)nd.n * HW,
+                          sizeof(float) * HW, hipMemcpyDeviceToDevice, s));
+  }
+  ModuleWeights w = module_weights(c);
+  ModuleBuffers b{};
+  b.nodes = c->dev_nodes; b.tab = c->dev_tab; b.arena = c->arena; b.tmap = c->tmap;
+  b.pfc = c->pfc; b.mfind = c->mfind; b.mfsp = c->mfsp; b.feat = feat; b.word_vecs = word_vecs;
+  b.scores = scores; b.N_full = N_full; b.H = d.H; b.W = d.W; b.D = d.D; b.M = d.map_dim;
+  b.Mp = c->Mp; b.E = d.embed_dim_txt; b.C = C; b.HWp = c->HWp; b.ksize = d.kernel_size;
+  for (const Launch& l : p.launches) {
+    switch (l.kind) {
+      case LK_TEXTMAP: launch_textmap(w, b, l.offset, l.count, s); break;
+      case LK_CONV_FIND:
+      case LK_CONV_FSP: {
+        const bool fsp = l.kind == LK_CONV_FSP;
+        GemmArgs g{};
+        g.A = feat; g.lda = d.D; g.M = l.count * HW; g.K = d.D;
+        g.group_idx = c->dev_tab + l.offset; g.group_size = HW;
+        g.Bp = fsp ? c->fsp_img_p : c->find_img_p; g.Np = c->Mp; g.Kp = c->KpD;
+        g.bias = c->vars[fsp ? V_FSP_IMG_B : V_FIND_IMG_B].mirror; g.N = d.map_dim;
+        g.C = fsp ? c->mfsp : c->mfind; g.ldc = c->Mp; g.n_store = c->Mp;
+        launch_gemm_pk(g, s);
+        break;
+      }
+      case LK_ATT: launch_att_ops(w, b, l.offset, l.count, s); break;
+      case LK_POOL: launch_pool(w, b, l.offset, l.count, s); break;
+      case LK_HEAD: launch_heads(w, b, l.offset, l.count, s); break;
+      default: break;
+    }
+  }
+  if (att_out && att_out_count > 0) {
+    N2_HIP(hipMemcpy2DAsync(att_out, sizeof(float) * HW,
+                            c->arena + (size_t)att_out_first * c->HWp, sizeof(float) * c->HWp,
+                            sizeof(float) * HW, att_out_count, hipMemcpyDeviceToDevice, s));
+  }
+  return check_launch("execute_program");
+}
+
+}  // namespace n2nmn
+
+// =============================================================================================
+extern "C" {
+
+const char* n2nmn_last_error(void) { return g_last_error.c_str(); }
+const char* n2nmn_version(void) { return "n2nmn-mi355x 0.1 (gfx950)"; }
+
+int n2nmn_ctx_create(const n2nmn_dims* dims, int device, n2nmn_ctx** out) {
+  N2_REQUIRE(dims && out, N2NMN_EINVAL, "ctx_create: null argument");
+  const n2nmn_dims& d = *dims;
+  N2_REQUIRE(d.num_layers == 2, N2NMN_EINVAL, "ctx_create: only num_layers == 2 is supported");
+  N2_REQUIRE(d.lstm_dim > 0 && d.lstm_dim % 128 == 0, N2NMN_EINVAL,
+             "ctx_create: lstm_dim must be a multiple of 128");
+  N2_REQUIRE(d.embed_dim_txt % 4 == 0 && d.embed_dim_nmn == d.embed_dim_txt, N2NMN_EINVAL,
+             "ctx_create: embed dims must be equal multiples of 4");
+  N2_REQUIRE(d.D % (4 * POOL_PARTS) == 0 && (256 % (d.D / POOL_PARTS / 4)) == 0, N2NMN_EINVAL,
+             "ctx_create: D must be a multiple of 16 with D/16 dividing 256");
+  N2_REQUIRE(d.kernel_size == 3 || d.kernel_size == 5, N2NMN_EINVAL,
+             "ctx_create: kernel_size must be 3 or 5");
+  N2_REQUIRE(d.num_vocab_nmn >= 2 && d.num_vocab_nmn <= 16, N2NMN_EINVAL,
+             "ctx_create: num_vocab_nmn must be in [2, 16]");
+  N2_REQUIRE(d.H > 0 && d.W > 0 && d.map_dim > 0 && d.num_choices > 0 && d.N > 0 &&
+                 d.T_encoder > 0 && d.T_decoder > 0 && d.num_vocab_txt > 0,
+             N2NMN_EINVAL, "ctx_create: non-positive dimension");
+  N2_REQUIRE((size_t)d.T_encoder * d.embed_dim_txt + (size_t)d.T_decoder * d.T_encoder <= 16000,
+             N2NMN_EINVAL, "ctx_create: T_encoder*embed_dim_txt too large for the LDS staging");
+  n2nmn_ctx* c = new (std::nothrow) n2nmn_ctx();
+  N2_REQUIRE(c, N2NMN_EINVAL, "ctx_create: out of host memory");
+  c->d = d; c->device = device;
+  build_vars(c);
+  c->Mp = round_up(d.map_dim, 64);
+  c->HWp = round_up(d.H * d.W, 32);
+  c->KpE = round_up(d.embed_dim_txt, 32);
+  c->KpL = round_up(d.lstm_dim, 32);
+  c->KpD = round_up(d.D, 32);
+  c->max_nodes = d.N * std::max(d.T_decoder, 4);
+  c->max_text = c->max_nodes;
+  c->max_pool = c->max_nodes;
+  c->max_tab = c->max_nodes * 16 + 4096;
+  c->bytes = carve(c, nullptr);
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->base), c->bytes);
+  if (e != hipSuccess) {
+    set_last_error(std::string("ctx_create: hipMalloc of ") + std::to_string(c->bytes) +
+                   " bytes failed: " + hipGetErrorString(e));
+    delete c;
+    return N2NMN_EHIP;
+  }
+  carve(c, c->base);
+  if (n2nmn_program_create(&c->scratch_prog) != N2NMN_OK) {
+    (void)hipFree(c->base);
+    delete c;
+    return N2NMN_EINVAL;
+  }
+  *out = c;
+  return N2NMN_OK;
+}
+
+int n2nmn_ctx_destroy(n2nmn_ctx* ctx) {
+  if (!ctx) return N2NMN_OK;
+  if (ctx->base) (void)hipFree(ctx->base);
+  n2nmn_program_destroy(ctx->scratch_prog);
+  delete ctx;
+  return N2NMN_OK;
+}
+
+int n2nmn_ctx_dims(const n2nmn_ctx* ctx, n2nmn_dims* out) {
+  N2_REQUIRE(ctx && out, N2NMN_EINVAL, "ctx_dims: null argument");
+  *out = ctx->d;
+  return N2NMN_OK;
+}
+
+int n2nmn_num_variables(const n2nmn_ctx* ctx) { return ctx ? (int)ctx->vars.size() : N2NMN_EINVAL; }
+
+int n2nmn_variable_info(const n2nmn_ctx* ctx, int i, const char** name, int64_t shape[4],
+                        int* ndim) {
+  N2_REQUIRE(ctx && i >= 0 && i < (int)ctx->vars.size(), N2NMN_EINVAL, "variable_info: bad index");
+  const Var& v = ctx->vars[i];
+  if (name) *name = v.name.c_str();
+  if (ndim) *ndim = (int)v.shape.size();
+  if (shape)
+    for (size_t k = 0; k < 4; ++k) shape[k] = k < v.shape.size() ? v.shape[k] : 1;
+  return N2NMN_OK;
+}
+
+int n2nmn_set_weight(n2nmn_ctx* ctx, const char* name, const float* data, const int64_t* shape,
+                     int ndim) {
+  N2_REQUIRE(ctx && name && data && shape, N2NMN_EINVAL, "set_weight: null argument");
+  auto it = ctx->index.find(name);
+  if (it == ctx->index.end()) {
+    set_last_error(std::string("set_weight: unknown variable '") + name + "'");
+    return N2NMN_EKEY;
+  }
+  Var& v = ctx->vars[it->second];
+  bool ok = ndim == (int)v.shape.size();
+  for (int k = 0; ok && k < ndim; ++k) ok = shape[k] == v.shape[k];
+  if (!ok) {
+    set_last_error(std::string("set_weight: shape mismatch for '") + name + "'");
+    return N2NMN_EINVAL;
+  }
+  // the copy into the context-owned mirror is issued here on the NULL stream so the caller's
+  // buffer is only referenced during this call
+  N2_HIP(hipMemcpy(v.mirror, data, sizeof(float) * v.numel, hipMemcpyDeviceToDevice));
+  v.set = true;
+  ctx->committed = false;
+  return N2NMN_OK;
+}
+
+/* validity automaton of the layout vocabulary: Assembler.P [V,3], .W [3,V,4], .b [V,4]
+ * (models_clevr/nmn3_assembler.py:50-119 -> nmn3_netgen_att.py:59-62), host int32 pointers */
+int n2nmn_set_validity_tables(n2nmn_ctx* ctx, const int32_t* P_host, const int32_t* W_host,
+                              const int32_t* b_host) {
+  N2_REQUIRE(ctx && P_host && W_host && b_host, N2NMN_EINVAL, "set_validity_tables: null argument");
+  const int V = ctx->d.num_vocab_nmn;
+  N2_HIP(hipMemcpy(ctx->P, P_host, sizeof(int32_t) * V * 3, hipMemcpyHostToDevice));
+  N2_HIP(hipMemcpy(ctx->Wv, W_host, sizeof(int32_t) * 3 * V * 4, hipMemcpyHostToDevice));
+  N2_HIP(hipMemcpy(ctx->bv, b_host, sizeof(int32_t) * V * 4, hipMemcpyHostToDevice));
+  ctx->have_tables = true;
+  return N2NMN_OK;
+}
+
+int n2nmn_commit_weights(n2nmn_ctx* c, n2nmn_stream stream) {
+  N2_REQUIRE(c, N2NMN_EINVAL, "commit_weights: null context");
+  for (const Var& v : c->vars)
+    if (!v.set) {
+      set_last_error("commit_weights: variable never set: " + v.name);
+      return N2NMN_ENOWEIGHT;
+    }
+  hipStream_t s = S(stream);
+  const n2nmn_dims& d = c->d;
+  const int L = d.lstm_dim, E = d.embed_dim_txt, M = d.map_dim, V = d.num_vocab_nmn, Mp = c->Mp;
+  auto m = [&](int id) { return c->vars[id].mirror; };
+  // layer-0 input projections (rows [0,E) of the LSTM weights) -> PK, then the tables
+  launch_pack_pk(m(V_ENC_W0), 4 * L, E, 4 * L, c->enc_W0x_p, c->KpE, 4 * L, s);
+  launch_pack_pk(m(V_DEC_W0), 4 * L, E, 4 * L, c->dec_W0x_p, c->KpE, 4 * L, s);
+  // recurrent parts -> gate-interleaved column tiles
+  launch_pack_tiles(m(V_ENC_W0), 4 * L, E, L, L / 4, L, c->enc_W0h_t, s);
+  launch_pack_tiles(m(V_ENC_W1), 4 * L, 0, 2 * L, L / 4, L, c->enc_W1_t, s);
+  launch_pack_tiles(m(V_DEC_W0), 4 * L, E, L, L / 4, L, c->dec_W0h_t, s);
+  launch_pack_tiles(m(V_DEC_W1), 4 * L, 0, 2 * L, L / 4, L, c->dec_W1_t, s);
+  launch_pack_pk(m(V_EHT_W), L, L, L, c->eht_W_p, c->KpL, L, s);
+  launch_pack_tiles(m(V_ATT_W), L, 0, L, L / 16, 0, c->att_W_t, s);
+  launch_pack_pk(m(V_FIND_IMG_W), M, d.D, M, c->find_img_p, c->KpD, Mp, s);
+  launch_pack_pk(m(V_FSP_IMG_W), M, d.D, M, c->fsp_img_p, c->KpD, Mp, s);
+  N2_HIP(hipMemcpyAsync(c->dec_emb_cat, m(V_DEC_EMB), sizeof(float) * (size_t)V * E,
+                        hipMemcpyDeviceToDevice, s));
+  N2_HIP(hipMemcpyAsync(c->dec_emb_cat + (size_t)V * E, m(V_DEC_GO), sizeof(float) * E,
+                        hipMemcpyDeviceToDevice, s));
+  // xtab[v] = emb[v] . W_x + b : the whole input half of the layer-0 gate pre-activations
+  GemmArgs g{};
+  g.A = m(V_ENC_EMB); g.lda = E; g.M = d.num_vocab_txt; g.K = E; g.group_size = 1;
+  g.Bp = c->enc_W0x_p; g.Np = 4 * L; g.Kp = c->KpE; g.bias = m(V_ENC_B0); g.N = 4 * L;
+  g.C = c->enc_xtab; g.ldc = 4 * L; g.n_store = 4 * L;
+  launch_gemm_pk(g, s);
+  g.A = c->dec_emb_cat; g.M = V + 1; g.Bp = c->dec_W0x_p; g.bias = m(V_DEC_B0); g.C = c->dec_xtab;
+  launch_gemm_pk(g, s);
+  // zero-padded copies of the [M] vectors read with float4 lanes
+  const int wes[3] = {V_FIND_E_W, V_FSP_E_W, V_TR_E_W};
+  for (int i = 0; i < 3; ++i) {
+    N2_HIP(hipMemsetAsync(c->we_pad[i], 0, sizeof(float) * Mp, s));
+    N2_HIP(hipMemcpyAsync(c->we_pad[i], m(wes[i]), sizeof(float) * M, hipMemcpyDeviceToDevice, s));
+  }
+  const int bas[4] = {V_FSP_ATT_B, V_SP_ATT0_B, V_SP_ATT1_B, V_DE_ATT_B};
+  for (int i = 0; i < 4; ++i) {
+    N2_HIP(hipMemsetAsync(c->batt_pad[i], 0, sizeof(float) * Mp, s));
+    N2_HIP(hipMemcpyAsync(c->batt_pad[i], m(bas[i]), sizeof(float) * M, hipMemcpyDeviceToDevice, s));
+  }
+  c->committed = true;
+  c->enc_T = 0;
+  return check_launch("commit_weights");
+}
+
+int n2nmn_encoder_forward(n2nmn_ctx* ctx, const n2nmn_seq2seq_io* io, n2nmn_stream stream) {
+  N2_REQUIRE(ctx, N2NMN_EINVAL, "encoder_forward: null context");
+  return encoder_impl(ctx, io, S(stream));
+}
+
+int n2nmn_decoder_forward(n2nmn_ctx* ctx, const n2nmn_seq2seq_io* io, n2nmn_stream stream) {
+  N2_REQUIRE(ctx, N2NMN_EINVAL, "decoder_forward: null context");
+  return decoder_impl(ctx, io, S(stream));
+}
+
+int n2nmn_seq2seq_forward(n2nmn_ctx* ctx, const n2nmn_seq2seq_io* io, n2nmn_stream stream) {
+  N2_REQUIRE(ctx, N2NMN_EINVAL, "seq2seq_forward: null context");
+  const int rc = encoder_impl(ctx, io, S(stream));
+  if (rc != N2NMN_OK) return rc;
+  return decoder_impl(ctx, io, S(stream));
+}
+
+int n2nmn_execute_program(n2nmn_ctx* ctx, n2nmn_program* p, const float* image_feat,
+                          const float* word_vecs, int N_full, float* scores,
+                          n2nmn_stream stream) {
+  N2_REQUIRE(ctx && p && image_feat && word_vecs && scores, N2NMN_EINVAL,
+             "execute_program: null argument");
+  return run_program(ctx, p->prog, image_feat, word_vecs, N_full, scores, nullptr, nullptr,
+                     nullptr, 0, 0, S(stream));
+}
+
+int n2nmn_module_forward(n2nmn_ctx* ctx, int op, int Nb, const float* input_0,
+                         const float* input_1, const int32_t* time_idx_host,
+                         const int32_t* batch_idx_host, const float* image_feat,
+                         const float* word_vecs, int N_full, float* out, n2nmn_stream stream) {
+  N2_REQUIRE(ctx && out && time_idx_host && batch_idx_host, N2NMN_EINVAL,
+             "module_forward: null argument");
+  const int k = op_arity(op);
+  N2_REQUIRE(k >= 0 && op != OP_INPUT, N2NMN_EKEY, "module_forward: unknown module operator");
+  N2_REQUIRE(Nb >= 0, N2NMN_EINVAL, "module_forward: negative batch");
+  if (Nb == 0) return N2NMN_OK;          // Fold's zero-size batches need no work at all
+  N2_REQUIRE((k < 1 || input_0) && (k < 2 || input_1), N2NMN_EINVAL,
+             "module_forward: missing attention input for this operator");
+  N2_REQUIRE(image_feat && word_vecs, N2NMN_EINVAL, "module_forward: null feature / word_vecs");
+  std::vector<n2nmn_node> nodes;
+  nodes.reserve((size_t)Nb * (k + 1));
+  for (int j = 0; j < k; ++j)
+    for (int i = 0; i < Nb; ++i) {
+      n2nmn_node nd{};
+      nd.op = OP_INPUT; nd.time_idx = j; nd.batch_idx = i; nd.in0 = nd.in1 = -1; nd.out_row = -1;
+      nodes.push_back(nd);
+    }
+  const bool ans = op_is_answer(op);
+  for (int i = 0; i < Nb; ++i) {
+    n2nmn_node nd{};
+    nd.op = op; nd.time_idx = time_idx_host[i]; nd.batch_idx = batch_idx_host[i];
+    nd.in0 = k >= 1 ? i : -1; nd.in1 = k >= 2 ? Nb + i : -1;
+    nd.out_row = ans ? i : -1;
+    nodes.push_back(nd);
+  }
+  Program& p = ctx->scratch_prog->prog;
+  int rc = from_nodes(p, nodes.data(), (int)nodes.size(), ans ? Nb : 0);
+  if (rc != N2NMN_OK) { set_last_error(p.error); return rc; }
+  return run_program(ctx, p, image_feat, word_vecs, N_full, ans ? out : nullptr, input_0, input_1,
+                     ans ? nullptr : out, k * Nb, ans ? 0 : Nb, S(stream));
+}
+
+int n2nmn_debug_gemm(n2nmn_ctx* ctx, const float* A, const float* B, const float* bias, float* C,
+                     int M, int N, int K, n2nmn_stream stream) {
+  N2_REQUIRE(ctx && A && B && C, N2NMN_EINVAL, "debug_gemm: null argument");
+  N2_REQUIRE(M > 0 && N > 0 && K > 0 && K % 4 == 0, N2NMN_EINVAL,
+             "debug_gemm: K must be a positive multiple of 4");
+  const int Kp = round_up(K, 32), Np = round_up(N, 64);
+  float* Bp = nullptr;
+  N2_HIP(hipMalloc(reinterpret_cast<void**>(&Bp), sizeof(float) * (size_t)Kp * Np));
+  hipStream_t s = S(stream);
+  launch_pack_pk(B, N, K, N, Bp, Kp, Np, s);
+  GemmArgs g{};
+  g.A = A; g.lda = K; g.M = M; g.K = K; g.group_size = 1; g.Bp = Bp; g.Np = Np; g.Kp = Kp;
+  g.bias = bias; g.N = N; g.C = C; g.ldc = N; g.n_store = N;
+  launch_gemm_pk(g, s);
+  N2_HIP(hipStreamSynchronize(s));       // debug entry only: Bp is freed right away
+  N2_HIP(hipFree(Bp));
+  return check_launch("debug_gemm");
+}
+
+}  // extern "C"

@@ -1,0 +1,180 @@
+// fp32 MFMA GEMM with bias for the dense contractions of the path, plus the operand packers.
+//
+//   C[M,N] = A[M,K] . B[K,N] + bias           (exact fp32: v_mfma_f32_32x32x2_f32)
+//
+// Used for: the input-projection tables of the LSTMs (emb . W_x + b), encoder_h_transform
+// (models_clevr/nmn3_netgen_att.py:102-106), the hoisted conv_image 1x1 convolution of
+// Find / FindSameProperty (util/empty_safe_conv.py:17,29-30 <- nmn3_modules.py:98-99,158-159)
+// and the decoder's W_a projection (nmn3_netgen_att.py:185).
+//
+// CDNA4 mapping
+//   * 64x64 block tile, 4 waves (2x2), each wave one 32x32 accumulator (16 VGPR).
+//   * Both operands live in LDS in a k-interleaved layout [k/4][row][4]: one ds_read_b128 feeds
+//     FOUR consecutive MFMAs.  The MFMA k index is a summation index, so the two half-waves may
+//     take any disjoint k's as long as A and B agree: lanes 0-31 take k = 8q..8q+3, lanes 32-63
+//     take k = 8q+4..8q+7.
+//   * B (weights) is pre-packed in HBM as [Kp/4][Np][4], so its global->LDS copy is a straight,
+//     fully coalesced float4 stream; A is read with float4 loads along K (its contiguous axis).
+//   * k4-stride in LDS is padded by one float4 so the 8-lane groups of ds_write_b128 (same row,
+//     8 different k4) land on 8 distinct bank quads.
+//   * register-staged double buffering: global loads of tile t+1 are in flight during the MFMAs
+//     of tile t; one barrier per k-tile.
+#include <algorithm>
+
+#include "device_utils.h"
+#include "kernels.h"
+
+namespace n2nmn {
+
+namespace {
+constexpr int BM = 64, BN = 64, BK = 32;
+constexpr int LDS_STRIDE = BM + 1;   // in float4 units
+
+__global__ __launch_bounds__(256) void gemm_pk_kernel(GemmArgs a) {
+  __shared__ float4 As[2][BK / 4][LDS_STRIDE];
+  __shared__ float4 Bs[2][BK / 4][LDS_STRIDE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+  // ---- global load assignment: 2 float4 of A and 2 of B per thread -----------------------
+  // A: float4 index i = tid + 256 j -> row = i >> 3, k4 = i & 7 (8 lanes cover 128 contiguous B)
+  const float* a_ptr[2];
+  bool a_ok[2];
+  int a_row[2], a_k4[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = tid + 256 * j;
+    a_row[j] = i >> 3; a_k4[j] = i & 7;
+    const int r = m0 + a_row[j];
+    a_ok[j] = r < a.M;
+    int src = r < a.M ? r : 0;
+    if (a.group_idx) {
+      const int g = src / a.group_size;
+      src = a.group_idx[g] * a.group_size + (src - g * a.group_size);
+    }
+    a_ptr[j] = a.A + (size_t)src * a.lda + 4 * a_k4[j];
+  }
+  // B: float4 index i -> k4 = i >> 6, n = i & 63 (one contiguous KiB per k4)
+  const float4* b_ptr[2];
+  int b_k4[2], b_n[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = tid + 256 * j;
+    b_k4[j] = i >> 6; b_n[j] = i & 63;
+    b_ptr[j] = reinterpret_cast<const float4*>(a.Bp) + (size_t)b_k4[j] * a.Np + n0 + b_n[j];
+  }
+
+  const int nkt = a.Kp / BK;
+  float4 ra[2], rb[2];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = kt * BK + 4 * a_k4[j];
+      if (a_ok[j] && k < a.K) ra[j] = *reinterpret_cast<const float4*>(a_ptr[j] + kt * BK);
+      else ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      rb[j] = b_ptr[j][(size_t)kt * (BK / 4) * a.Np];
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      As[buf][a_k4[j]][a_row[j]] = ra[j];
+      Bs[buf][b_k4[j]][b_n[j]] = rb[j];
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int li = lane & 31, kh = lane >> 5;
+  int cur = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt) gload(kt + 1);
+#pragma unroll
+    for (int kq = 0; kq < BK / 8; ++kq) {
+      const float4 av = As[cur][2 * kq + kh][wm * 32 + li];
+      const float4 bv = Bs[cur][2 * kq + kh][wn * 32 + li];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+    }
+    if (kt + 1 < nkt) lstore(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int col = n0 + wn * 32 + li;
+  if (col < a.n_store) {
+    const float bias = (a.bias && col < a.N) ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      if (row < a.M) a.C[(size_t)row * a.ldc + col] = (col < a.N) ? acc[r] + bias : 0.f;
+    }
+  }
+}
+
+__global__ void pack_pk_kernel(const float* __restrict__ src, int ld, int K, int N,
+                               float* __restrict__ dst, int Kp, int Np) {
+  const size_t total = (size_t)Kp * Np;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int kk = (int)(i & 3);
+    const size_t r = i >> 2;
+    const int n = (int)(r % Np);
+    const int k = (int)(r / Np) * 4 + kk;
+    dst[i] = (k < K && n < N) ? src[(size_t)k * ld + n] : 0.f;
+  }
+}
+
+// dst[tile j][k/4][c][k%4] = W[row0 + k][col(j, c)],  c = 0..15
+//   gate_L > 0: col = (c>>2)*gate_L + 4j + (c&3)   (i,j,f,o gates of hidden units 4j..4j+3)
+//   gate_L == 0: col = 16j + c
+__global__ void pack_tiles_kernel(const float* __restrict__ W, int ld, int row0, int K, int ntiles,
+                                  int gate_L, float* __restrict__ dst) {
+  const size_t total = (size_t)ntiles * K * 16;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int kk = (int)(i & 3);
+    const int c = (int)((i >> 2) & 15);
+    const size_t r = i >> 6;
+    const int k4 = (int)(r % (K / 4));
+    const int j = (int)(r / (K / 4));
+    const int k = 4 * k4 + kk;
+    const int col = gate_L > 0 ? (c >> 2) * gate_L + 4 * j + (c & 3) : 16 * j + c;
+    dst[i] = W[(size_t)(row0 + k) * ld + col];
+  }
+}
+}  // namespace
+
+void launch_gemm_pk(const GemmArgs& a, hipStream_t s) {
+  dim3 grid((a.n_store + BN - 1) / BN, (a.M + BM - 1) / BM);
+  if (a.M <= 0) return;
+  hipLaunchKernelGGL(gemm_pk_kernel, grid, dim3(256), 0, s, a);
+}
+
+void launch_pack_pk(const float* src, int ld, int K, int N, float* dst, int Kp, int Np,
+                    hipStream_t s) {
+  const size_t total = (size_t)Kp * Np;
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
+  hipLaunchKernelGGL(pack_pk_kernel, dim3(blocks), dim3(256), 0, s, src, ld, K, N, dst, Kp, Np);
+}
+
+void launch_pack_tiles(const float* W, int ld, int row0, int K, int ntiles, int gate_L, float* dst,
+                       hipStream_t s) {
+  const size_t total = (size_t)ntiles * K * 16;
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
+  hipLaunchKernelGGL(pack_tiles_kernel, dim3(blocks), dim3(256), 0, s, W, ld, row0, K, ntiles,
+                     gate_L, dst);
+}
+
+}  // namespace n2nmn

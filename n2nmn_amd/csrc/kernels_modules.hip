@@ -1,0 +1,458 @@
+// Module-operator kernels (models_clevr/nmn3_modules.py:60-495), batched per level stage by the
+// scheduler in schedule.cpp instead of per (module type, depth) like TensorFlow-Fold.
+//
+//   textmap  : fc_text / text_fc of every node with a text parameter           (:101,161,209,424,479)
+//   att_ops  : Scene, Find / Filter / FindSameProperty epilogues (l2-normalise + conv_eltwise on
+//              the hoisted conv_image map), Transform, And, Or, Exist, Count, Equal/More/LessNum
+//   pool     : spatial softmax + attention-weighted feature sum + partial fc_att
+//              (FindSameProperty :170-176, SameProperty :432-446, Describe :482-490)
+//   heads    : Describe / SameProperty  l2-normalise + fc_eltwise               (:448-450,492-493)
+//
+// Data layout: image features stay in the reference's NHWC [N, H*W, D] fp32 and are indexed in
+// place by batch_idx (Fold's tf.gather copy of [Nb,H,W,D], nmn3_modules.py:49-51, never exists);
+// attention maps live in an arena [node][HWp] in HBM/L2; text maps [tslot][Mp] and conv_image
+// maps [image slot][HW][Mp] are zero padded to Mp = round_up(map_dim, 64) so float4 lanes need no
+// tail handling.
+#include "device_utils.h"
+#include "kernels.h"
+
+namespace n2nmn {
+
+namespace {
+
+constexpr int MT = 256;   // threads per workgroup for every module kernel
+
+// out[j] = b[j] + sum_f x[f] * Wm[f*C + j]   (x in LDS).  256 threads = nsl slices x C columns.
+// `partial` needs >= 256 floats of LDS.  All threads must call.
+__device__ void fc_small(const float* x, int F, const float* __restrict__ Wm,
+                         const float* __restrict__ b, int C, float* __restrict__ out,
+                         float* partial) {
+  const int tid = threadIdx.x;
+  if (C <= MT) {
+    const int nsl = MT / C;
+    const int j = tid % C, sl = tid / C;
+    float s = 0.f;
+    if (sl < nsl)
+      for (int f = sl; f < F; f += nsl) s += x[f] * Wm[(size_t)f * C + j];
+    __syncthreads();
+    if (sl < nsl) partial[sl * C + j] = s;
+    __syncthreads();
+    if (tid < C) {
+      float r = b[tid];
+      for (int q = 0; q < nsl; ++q) r += partial[q * C + tid];
+      out[tid] = r;
+    }
+  } else {
+    for (int j = tid; j < C; j += MT) {
+      float s = b[j];
+      for (int f = 0; f < F; ++f) s += x[f] * Wm[(size_t)f * C + j];
+      out[j] = s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// text maps: tmap[tslot, :] = word_vecs[t*N_full + n, :] . W_txt + b_txt
+// A workgroup handles up to TM_GROUP nodes that share a weight set, so the [E, M] weight stream
+// is read once per group.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MT) void textmap_kernel(ModuleWeights w, ModuleBuffers b,
+                                                     int tab_off) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int* tab = b.tab + tab_off + blockIdx.x * (2 + TM_GROUP);
+  const int ws = tab[0], cnt = tab[1];
+  const int E = b.E, M = b.M, Mp = b.Mp;
+  float* wv = smem;   // [TM_GROUP][E]
+  for (int i = threadIdx.x; i < TM_GROUP * E; i += MT) {
+    const int g = i / E, e = i - g * E;
+    float v = 0.f;
+    if (g < cnt) {
+      const DevNode& nd = b.nodes[tab[2 + g]];
+      v = b.word_vecs[((size_t)nd.t * b.N_full + nd.n) * E + e];   // nmn3_modules.py:53-57
+    }
+    wv[i] = v;
+  }
+  __syncthreads();
+  const float* Wm = w.Wtxt[ws];
+  const float* bm = w.btxt[ws];
+  for (int c = threadIdx.x; c < Mp; c += MT) {
+    float acc[TM_GROUP];
+#pragma unroll
+    for (int g = 0; g < TM_GROUP; ++g) acc[g] = 0.f;
+    if (c < M) {
+#pragma unroll 4
+      for (int e = 0; e < E; ++e) {
+        const float wt = Wm[(size_t)e * M + c];
+#pragma unroll
+        for (int g = 0; g < TM_GROUP; ++g) acc[g] += wv[g * E + e] * wt;
+      }
+      const float bb = bm[c];
+#pragma unroll
+      for (int g = 0; g < TM_GROUP; ++g) acc[g] += bb;
+    }
+#pragma unroll
+    for (int g = 0; g < TM_GROUP; ++g)
+      if (g < cnt) b.tmap[(size_t)b.nodes[tab[2 + g]].tslot * Mp + c] = acc[g];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Find-type epilogue on a hoisted conv_image map:
+//   att[r] = l2norm_c( M[r, c] * tmap[c] (* amap[c]) ) . w_e + b_e   [ min with input_0 for Filter ]
+// (nmn3_modules.py:104-108 Find, :129-130 Filter, :178-180 FindSameProperty)
+// one wave per row, float4 lanes over the Mp channels; rows [r0, r1) of the map.
+// ---------------------------------------------------------------------------------------------
+__device__ void find_epilogue(const ModuleWeights& w, const ModuleBuffers& b, const DevNode& nd,
+                              int node_id, int part, int nparts) {
+  const int HW = b.H * b.W, Mp = b.Mp;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const bool fsp = nd.op == N2NMN_OP_FIND_SAME_PROPERTY;
+  const int wsel = fsp ? 1 : 0;
+  const float* Mbuf = (fsp ? b.mfsp : b.mfind) + (size_t)nd.mslot * HW * Mp;
+  const float* tm = b.tmap + (size_t)nd.tslot * Mp;
+  const float be = w.be[wsel][0];
+  const int rpp = (HW + nparts - 1) / nparts;
+  const int r0 = part * rpp, r1 = min(HW, r0 + rpp);
+  const float* in0 = (nd.op == N2NMN_OP_FILTER) ? b.arena + (size_t)nd.in0 * b.HWp : nullptr;
+  float* outp = b.arena + (size_t)node_id * b.HWp;
+
+  for (int r = r0 + wid; r < r1; r += MT / 64) {
+    float ss = 0.f, dot = 0.f;
+    for (int c = 4 * lane; c < Mp; c += 256) {
+      float4 t4 = *reinterpret_cast<const float4*>(tm + c);
+      if (fsp) {   // amap = fc_att(att_feat): bias + the POOL_PARTS partial sums of stage B
+        float4 a4 = *reinterpret_cast<const float4*>(w.batt[0] + c);   // padded to Mp
+        const float* pf = b.pfc + (size_t)nd.pslot * 2 * POOL_PARTS * Mp + c;
+#pragma unroll
+        for (int p = 0; p < POOL_PARTS; ++p) {
+          const float4 q = *reinterpret_cast<const float4*>(pf + p * Mp);
+          a4.x += q.x; a4.y += q.y; a4.z += q.z; a4.w += q.w;
+        }
+        t4.x *= a4.x; t4.y *= a4.y; t4.z *= a4.z; t4.w *= a4.w;
+      }
+      const float4 m4 = *reinterpret_cast<const float4*>(Mbuf + (size_t)r * Mp + c);
+      const float4 e4 = *reinterpret_cast<const float4*>(w.we[wsel] + c);   // padded to Mp
+      const float p0 = m4.x * t4.x, p1 = m4.y * t4.y, p2 = m4.z * t4.z, p3 = m4.w * t4.w;
+      ss += p0 * p0 + p1 * p1 + p2 * p2 + p3 * p3;
+      dot += p0 * e4.x + p1 * e4.y + p2 * e4.z + p3 * e4.w;
+    }
+    ss = wave_sum(ss);
+    dot = wave_sum(dot);
+    if (lane == 0) {
+      float att = dot / sqrtf(fmaxf(ss, 1e-12f)) + be;   // tf.nn.l2_normalize eps (A.4)
+      if (in0) att = fminf(in0[r], att);                 // Filter = And(input_0, Find)
+      outp[r] = att;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Transform (nmn3_modules.py:185-216): conv KSxKS SAME of the 1-channel attention map to M
+// channels, times the text map, l2-normalise over channels, dot with w_e.  The text map is folded
+// into the filter taps (K'[tap,c] = K[tap,c]*t[c]) which each lane keeps in registers for its 4
+// channels; the zero-padded input map sits in LDS; one wave per output pixel.
+// ---------------------------------------------------------------------------------------------
+template <int KS>
+__device__ void transform_op(const ModuleWeights& w, const ModuleBuffers& b, const DevNode& nd,
+                             int node_id, int part, int nparts, float* smem) {
+  const int H = b.H, W = b.W, HW = H * W, M = b.M, Mp = b.Mp;
+  constexpr int PAD = KS / 2;
+  const int PW = W + 2 * PAD, PH = H + 2 * PAD;
+  float* xin = smem;                 // [PH][PW]
+  float* sss = xin + PH * PW;        // [HW] sum of squares
+  float* sdot = sss + HW;            // [HW]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const float* in0 = b.arena + (size_t)nd.in0 * b.HWp;
+  for (int i = threadIdx.x; i < PH * PW; i += MT) {
+    const int y = i / PW - PAD, x = i % PW - PAD;
+    xin[i] = (y >= 0 && y < H && x >= 0 && x < W) ? in0[y * W + x] : 0.f;
+  }
+  const int ppp = (HW + nparts - 1) / nparts;
+  const int p0 = part * ppp, p1 = min(HW, p0 + ppp);
+  for (int i = p0 + threadIdx.x; i < p1; i += MT) { sss[i] = 0.f; sdot[i] = 0.f; }
+  __syncthreads();
+  const float* tm = b.tmap + (size_t)nd.tslot * Mp;
+  for (int cbase = 0; cbase < Mp; cbase += 256) {
+    float kreg[KS * KS][4], breg[4], ereg[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = cbase + lane + 64 * q;
+      const bool ok = c < M;
+      const float t = ok ? tm[c] : 0.f;
+      breg[q] = ok ? w.bt[c] * t : 0.f;
+      ereg[q] = ok ? w.we[2][c] : 0.f;
+#pragma unroll
+      for (int tap = 0; tap < KS * KS; ++tap) kreg[tap][q] = ok ? w.Kt[tap * M + c] * t : 0.f;
+    }
+    for (int p = p0 + wid; p < p1; p += MT / 64) {
+      const int y = p / W, x = p - y * W;
+      float v[4] = {breg[0], breg[1], breg[2], breg[3]};
+#pragma unroll
+      for (int dy = 0; dy < KS; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < KS; ++dx) {
+          const float xv = xin[(y + dy) * PW + x + dx];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] += kreg[dy * KS + dx][q] * xv;
+        }
+      float ss = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+      float dot = v[0] * ereg[0] + v[1] * ereg[1] + v[2] * ereg[2] + v[3] * ereg[3];
+      ss = wave_sum(ss);
+      dot = wave_sum(dot);
+      if (lane == 0) { sss[p] += ss; sdot[p] += dot; }   // same wave owns p in every chunk
+    }
+  }
+  __syncthreads();
+  const float be = w.be[2][0];
+  float* outp = b.arena + (size_t)node_id * b.HWp;
+  for (int p = p0 + threadIdx.x; p < p1; p += MT)
+    outp[p] = sdot[p] / sqrtf(fmaxf(sss[p], 1e-12f)) + be;
+}
+
+// ---------------------------------------------------------------------------------------------
+// answer heads on raw attention maps: Exist (:258-280), Count (:282-304),
+// EqualNum / MoreNum / LessNum (:306-400)
+// ---------------------------------------------------------------------------------------------
+__device__ void light_answer(const ModuleWeights& w, const ModuleBuffers& b, const DevNode& nd,
+                             float* smem) {
+  const int HW = b.H * b.W, C = b.C;
+  float* x = smem;                    // up to 2*HW + 4 features
+  float* scratch = x + 2 * HW + 4;    // 16 floats for block reductions
+  float* partial = scratch + 16;      // 256 floats
+  const int nin = (nd.op == N2NMN_OP_EXIST || nd.op == N2NMN_OP_COUNT) ? 1 : 2;
+  const int tid = threadIdx.x;
+  float mn[2], mx[2], sm[2];
+  for (int i = 0; i < nin; ++i) {
+    const float* src = b.arena + (size_t)(i == 0 ? nd.in0 : nd.in1) * b.HWp;
+    float lmn = INFINITY, lmx = -INFINITY, lsm = 0.f;
+    for (int r = tid; r < HW; r += MT) {
+      const float v = src[r];
+      x[i * (HW + 2) + r] = v;        // row-major y*W + x flatten (:297)
+      lmn = fminf(lmn, v); lmx = fmaxf(lmx, v); lsm += v;
+    }
+    mn[i] = block_reduce<2>(lmn, scratch);
+    mx[i] = block_reduce<1>(lmx, scratch);
+    sm[i] = block_reduce<0>(lsm, scratch);
+  }
+  __syncthreads();
+  int F, wi;
+  if (nd.op == N2NMN_OP_EXIST) {
+    if (tid == 0) { x[0] = mn[0]; x[1] = sm[0] / (float)HW; x[2] = mx[0]; }
+    F = 3; wi = 0;
+  } else if (nd.op == N2NMN_OP_COUNT) {
+    if (tid == 0) { x[HW] = mn[0]; x[HW + 1] = mx[0]; }
+    F = HW + 2; wi = 1;
+  } else {
+    if (tid == 0) {
+      x[HW] = mn[0]; x[HW + 1] = mx[0];
+      x[2 * HW + 2] = mn[1]; x[2 * HW + 3] = mx[1];
+    }
+    F = 2 * HW + 4;
+    wi = nd.op == N2NMN_OP_EQUAL_NUM ? 2 : (nd.op == N2NMN_OP_MORE_NUM ? 3 : 4);
+  }
+  __syncthreads();
+  fc_small(x, F, w.Wans[wi], w.bans[wi], C, b.scores + (size_t)nd.out_row * C, partial);
+}
+
+__global__ __launch_bounds__(MT) void att_ops_kernel(ModuleWeights w, ModuleBuffers b,
+                                                     int tab_off) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int* e = b.tab + tab_off + blockIdx.x * 4;
+  const int node_id = e[0], part = e[1], nparts = e[2];
+  const DevNode nd = b.nodes[node_id];
+  const int HW = b.H * b.W;
+  float* outp = b.arena + (size_t)node_id * b.HWp;
+  switch (nd.op) {
+    case N2NMN_OP_SCENE:                                   // :60-72  att = 3.0 everywhere
+      for (int r = threadIdx.x; r < HW; r += MT) outp[r] = 3.0f;
+      break;
+    case N2NMN_OP_FIND:
+    case N2NMN_OP_FILTER:
+    case N2NMN_OP_FIND_SAME_PROPERTY:
+      find_epilogue(w, b, nd, node_id, part, nparts);
+      break;
+    case N2NMN_OP_TRANSFORM:
+      if (b.ksize == 5) transform_op<5>(w, b, nd, node_id, part, nparts, smem);
+      else transform_op<3>(w, b, nd, node_id, part, nparts, smem);
+      break;
+    case N2NMN_OP_AND:                                     // :218-236
+    case N2NMN_OP_OR: {                                    // :238-256
+      const float* a0 = b.arena + (size_t)nd.in0 * b.HWp;
+      const float* a1 = b.arena + (size_t)nd.in1 * b.HWp;
+      for (int r = threadIdx.x; r < HW; r += MT)
+        outp[r] = nd.op == N2NMN_OP_AND ? fminf(a0[r], a1[r]) : fmaxf(a0[r], a1[r]);
+      break;
+    }
+    default:
+      light_answer(w, b, nd, smem);
+      break;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pool: a = softmax_HW(att logits);  f = sum_hw a[hw] * feat[n, hw, :]  (the HBM-bound read of
+// the [H*W, D] feature map), then this part's slice of fc_att:  pfc[part, c] = f[c0:c0+Dp] .
+// W_att[c0:c0+Dp, c].  One workgroup per (node, channel part): POOL_PARTS x nodes workgroups fill
+// the chip; SameProperty pools both inputs from ONE feature read.  Each thread owns a float4
+// channel column and strides over rows (8 rows in flight per workgroup -> ~19 independent 16-B
+// loads per thread).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MT) void pool_kernel(ModuleWeights w, ModuleBuffers b, int tab_off) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int* e = b.tab + tab_off + blockIdx.x * 2;
+  const int node_id = e[0], part = e[1];
+  const DevNode nd = b.nodes[node_id];
+  const int HW = b.H * b.W, D = b.D, M = b.M, Mp = b.Mp;
+  const int Dp = D / POOL_PARTS, c0 = part * Dp;
+  const int tid = threadIdx.x;
+  const int nin = nd.op == N2NMN_OP_SAME_PROPERTY ? 2 : 1;
+  float* a0 = smem;                    // [HW]
+  float* a1 = a0 + ((HW + 3) & ~3);    // [HW]
+  float* scratch = a1 + ((HW + 3) & ~3);   // [16]
+  float* pooled = scratch + 16;        // [2][Dp]
+  float* stage = pooled + 2 * Dp;      // [rows in flight][2][Dp]
+
+  for (int i = 0; i < nin; ++i) {      // softmax over the H*W logits (:170-172,432-437,482-484)
+    const float* src = b.arena + (size_t)(i == 0 ? nd.in0 : nd.in1) * b.HWp;
+    float* dst = i == 0 ? a0 : a1;
+    float lm = -INFINITY;
+    for (int r = tid; r < HW; r += MT) lm = fmaxf(lm, src[r]);
+    const float mx = block_reduce<1>(lm, scratch);
+    float ls = 0.f;
+    for (int r = tid; r < HW; r += MT) {
+      const float ex = expf(src[r] - mx);
+      dst[r] = ex;
+      ls += ex;
+    }
+    const float sum = block_reduce<0>(ls, scratch);
+    for (int r = tid; r < HW; r += MT) dst[r] = dst[r] / sum;
+  }
+  __syncthreads();
+
+  const int ncol = Dp / 4;             // float4 columns of this part
+  const int nrow = MT / ncol;          // rows in flight
+  const int lc = tid % ncol, lr = tid / ncol;
+  float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
+  if (lr < nrow) {
+    const float* fp = b.feat + (size_t)nd.n * HW * D + c0 + 4 * lc;
+    if (nin == 1) {
+#pragma unroll 4
+      for (int r = lr; r < HW; r += nrow) {
+        const float4 f4 = *reinterpret_cast<const float4*>(fp + (size_t)r * D);
+        const float w0 = a0[r];
+        acc0.x += w0 * f4.x; acc0.y += w0 * f4.y; acc0.z += w0 * f4.z; acc0.w += w0 * f4.w;
+      }
+    } else {
+#pragma unroll 4
+      for (int r = lr; r < HW; r += nrow) {
+        const float4 f4 = *reinterpret_cast<const float4*>(fp + (size_t)r * D);
+        const float w0 = a0[r], w1 = a1[r];
+        acc0.x += w0 * f4.x; acc0.y += w0 * f4.y; acc0.z += w0 * f4.z; acc0.w += w0 * f4.w;
+        acc1.x += w1 * f4.x; acc1.y += w1 * f4.y; acc1.z += w1 * f4.z; acc1.w += w1 * f4.w;
+      }
+    }
+    *reinterpret_cast<float4*>(stage + (size_t)(lr * 2 + 0) * Dp + 4 * lc) = acc0;
+    *reinterpret_cast<float4*>(stage + (size_t)(lr * 2 + 1) * Dp + 4 * lc) = acc1;
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * Dp; i += MT) {
+    float s = 0.f;
+    for (int q = 0; q < nrow; ++q) s += stage[(size_t)q * 2 * Dp + i];
+    pooled[i] = s;
+  }
+  __syncthreads();
+
+  // partial fc_att over this part's channels
+  for (int i = 0; i < nin; ++i) {
+    int wi;
+    if (nd.op == N2NMN_OP_FIND_SAME_PROPERTY) wi = 0;
+    else if (nd.op == N2NMN_OP_SAME_PROPERTY) wi = 1 + i;
+    else wi = 3;
+    const float* Wm = w.Watt[wi] + (size_t)c0 * M;
+    const float* pv = pooled + i * Dp;
+    float* dst = b.pfc + (((size_t)nd.pslot * 2 + i) * POOL_PARTS + part) * Mp;
+    for (int c = tid; c < Mp; c += MT) {
+      float s = 0.f;
+      if (c < M) {
+#pragma unroll 8
+        for (int k = 0; k < Dp; ++k) s += pv[k] * Wm[(size_t)k * M + c];
+      }
+      dst[c] = s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// heads: Describe  scores = l2norm(tmap * a) . W_e + b          (:479-493)
+//        SameProperty  scores = l2norm(a0 * tmap * a1) . W_e + b (:424-450)
+// a = b_att + sum of the POOL_PARTS partial fc_att rows of stage B.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MT) void heads_kernel(ModuleWeights w, ModuleBuffers b, int tab_off) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int node_id = b.tab[tab_off + blockIdx.x];
+  const DevNode nd = b.nodes[node_id];
+  const int M = b.M, Mp = b.Mp, C = b.C;
+  float* ev = smem;                 // [Mp]
+  float* scratch = ev + Mp;         // [16]
+  float* partial = scratch + 16;    // [256]
+  const bool same = nd.op == N2NMN_OP_SAME_PROPERTY;
+  const float* tm = b.tmap + (size_t)nd.tslot * Mp;
+  const float* pf = b.pfc + (size_t)nd.pslot * 2 * POOL_PARTS * Mp;
+  float lss = 0.f;
+  for (int c = threadIdx.x; c < Mp; c += MT) {
+    float v = 0.f;
+    if (c < M) {
+      float a0 = w.batt[same ? 1 : 3][c];
+      for (int p = 0; p < POOL_PARTS; ++p) a0 += pf[p * Mp + c];
+      v = a0 * tm[c];
+      if (same) {
+        float a1 = w.batt[2][c];
+        for (int p = 0; p < POOL_PARTS; ++p) a1 += pf[(POOL_PARTS + p) * Mp + c];
+        v *= a1;
+      }
+    }
+    ev[c] = v;
+    lss += v * v;
+  }
+  const float ss = block_reduce<0>(lss, scratch);
+  const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+  for (int c = threadIdx.x; c < Mp; c += MT) ev[c] *= inv;
+  __syncthreads();
+  const int wi = same ? 5 : 6;
+  fc_small(ev, M, w.Wans[wi], w.bans[wi], C, b.scores + (size_t)nd.out_row * C, partial);
+}
+
+}  // namespace
+
+void launch_textmap(const ModuleWeights& w, const ModuleBuffers& b, int tab_off, int count,
+                    hipStream_t s) {
+  const size_t smem = sizeof(float) * TM_GROUP * b.E;
+  hipLaunchKernelGGL(textmap_kernel, dim3(count), dim3(MT), smem, s, w, b, tab_off);
+}
+
+void launch_att_ops(const ModuleWeights& w, const ModuleBuffers& b, int tab_off, int count,
+                    hipStream_t s) {
+  const int HW = b.H * b.W;
+  const int pad = b.ksize / 2;
+  const size_t tr = (size_t)(b.H + 2 * pad) * (b.W + 2 * pad) + 2 * HW;
+  const size_t la = (size_t)2 * HW + 4 + 16 + 256;
+  const size_t smem = sizeof(float) * (tr > la ? tr : la);
+  hipLaunchKernelGGL(att_ops_kernel, dim3(count), dim3(MT), smem, s, w, b, tab_off);
+}
+
+void launch_pool(const ModuleWeights& w, const ModuleBuffers& b, int tab_off, int count,
+                 hipStream_t s) {
+  const int HW = b.H * b.W, Dp = b.D / POOL_PARTS;
+  const int nrow = MT / (Dp / 4);
+  const size_t smem =
+      sizeof(float) * (2 * (size_t)((HW + 3) & ~3) + 16 + 2 * Dp + (size_t)nrow * 2 * Dp);
+  hipLaunchKernelGGL(pool_kernel, dim3(count), dim3(MT), smem, s, w, b, tab_off);
+}
+
+void launch_heads(const ModuleWeights& w, const ModuleBuffers& b, int tab_off, int count,
+                  hipStream_t s) {
+  const size_t smem = sizeof(float) * ((size_t)b.Mp + 16 + 256);
+  hipLaunchKernelGGL(heads_kernel, dim3(count), dim3(MT), smem, s, w, b, tab_off);
+}
+
+}  // namespace n2nmn

@@ -1,0 +1,218 @@
+"""Thin host-side engine over the C-ABI: one context (weights + workspace) on one GPU.
+
+PyTorch is used only as plumbing here: device memory (`torch.empty(..., device='cuda')`), the current
+HIP stream and D2H copies.  All arithmetic runs in libn2nmn_hip.so; there is no fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import _lib
+from .nmn3_assembler import Assembler, PackedLayouts
+from .spec import Dims, OP_CODE, MODULE_INPUT_NUM, MODULE_OUTPUT_TYPE
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class Engine:
+    def __init__(self, dims: Dims, assembler: Assembler, device: int = 0):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise RuntimeError('n2nmn_amd.Engine needs a HIP device (no CPU fallback exists)')
+        if assembler.num_vocab_nmn != dims.num_vocab_nmn:
+            raise ValueError('assembler vocabulary size != dims.num_vocab_nmn')
+        self.dims = dims
+        self.assembler = assembler
+        self.device = torch.device('cuda', device)
+        self._lib = _lib.lib()
+        cd = _lib.Dims(**{k: int(v) for k, v in dims.asdict().items()})
+        self._ctx = C.c_void_p()
+        _lib.check(self._lib.n2nmn_ctx_create(C.byref(cd), device, C.byref(self._ctx)))
+        P = np.ascontiguousarray(assembler.P, np.int32)
+        W = np.ascontiguousarray(assembler.W, np.int32)
+        b = np.ascontiguousarray(assembler.b, np.int32)
+        _lib.check(self._lib.n2nmn_set_validity_tables(self._ctx, P.ctypes.data, W.ctypes.data,
+                                                       b.ctypes.data))
+        self._bufs: Dict[tuple, object] = {}
+
+    def __del__(self):
+        ctx, self._ctx = getattr(self, '_ctx', None), None
+        if ctx:
+            try:
+                self._lib.n2nmn_ctx_destroy(ctx)
+            except Exception:
+                pass
+
+    # ------------------------------------------------------------------------------------
+    def stream(self) -> int:
+        return _torch().cuda.current_stream(self.device).cuda_stream
+
+    def variable_names(self):
+        out = {}
+        n = _lib.check(self._lib.n2nmn_num_variables(self._ctx))
+        for i in range(n):
+            name = C.c_char_p()
+            shape = (C.c_int64 * 4)()
+            nd = C.c_int()
+            _lib.check(self._lib.n2nmn_variable_info(self._ctx, i, C.byref(name), shape,
+                                                     C.byref(nd)))
+            out[name.value.decode()] = tuple(int(shape[k]) for k in range(nd.value))
+        return out
+
+    def load_weights(self, weights: Dict[str, object]):
+        """weights: reference variable name -> numpy array or torch tensor (any device)."""
+        torch = _torch()
+        for name, w in weights.items():
+            t = torch.as_tensor(w).to(device=self.device, dtype=torch.float32).contiguous()
+            shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+            _lib.check(self._lib.n2nmn_set_weight(self._ctx, name.encode(), t.data_ptr(), shape,
+                                                  t.dim()))
+        torch.cuda.synchronize(self.device)
+        _lib.check(self._lib.n2nmn_commit_weights(self._ctx, self.stream()))
+
+    # ------------------------------------------------------------------------------------
+    def _buf(self, key, shape, dtype):
+        torch = _torch()
+        k = (key, tuple(shape), dtype)
+        t = self._bufs.get(k)
+        if t is None:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._bufs[k] = t
+        return t
+
+    def _dev(self, x, dtype):
+        torch = _torch()
+        if x is None:
+            return None
+        t = torch.as_tensor(x)
+        if t.device != self.device or t.dtype != dtype or not t.is_contiguous():
+            t = t.to(device=self.device, dtype=dtype).contiguous()
+        return t
+
+    def seq2seq(self, input_seq, seq_len, T_dec: Optional[int] = None, use_gt_layout: bool = False,
+                gt_layout=None, sample_uniforms=None, forced_tokens=None, debug: bool = False,
+                reuse_buffers: bool = True, phase: str = 'both'):
+        """Phase 1.  input_seq [T,N] int32, seq_len [N] int32 (device tensors or anything
+        convertible).  Returns a dict of device tensors named like the reference attributes
+        (models_clevr/nmn3_netgen_att.py:305-322).  With reuse_buffers the outputs are views of
+        engine-owned buffers that the next call overwrites."""
+        torch = _torch()
+        d = self.dims
+        seq = self._dev(input_seq, torch.int32)
+        lens = self._dev(seq_len, torch.int32)
+        T, N = seq.shape
+        Td = d.T_decoder if T_dec is None else int(T_dec)
+        mk = (lambda k, s, dt: self._buf(k, s, dt)) if reuse_buffers else \
+            (lambda k, s, dt: torch.empty(s, dtype=dt, device=self.device))
+        out = {
+            'predicted_tokens': mk('tok', (Td, N), torch.int32),
+            'token_probs': mk('tp', (Td, N), torch.float32),
+            'neg_entropy': mk('ne', (N,), torch.float32),
+            'atts': mk('att', (Td, T, N), torch.float32),
+            'word_vecs': mk('wv', (Td, N, d.embed_dim_txt), torch.float32),
+            'log_seq_prob': mk('lsp', (N,), torch.float32),
+        }
+        if debug:
+            out['token_scores'] = mk('ts', (Td, N, d.num_vocab_nmn), torch.float32)
+            out['encoder_outputs'] = mk('eo', (T, N, d.lstm_dim), torch.float32)
+            out['encoder_h_transformed'] = mk('eh', (T, N, d.lstm_dim), torch.float32)
+            out['encoder_states'] = mk('es', (2, 2, N, d.lstm_dim), torch.float32)
+        gt = self._dev(gt_layout, torch.int32)
+        uni = self._dev(sample_uniforms, torch.float32)
+        forced = self._dev(forced_tokens, torch.int32)
+        io = _lib.Seq2SeqIO()
+        io.input_seq = seq.data_ptr(); io.seq_length = lens.data_ptr()
+        io.T_enc = T; io.N = N; io.T_dec = Td
+        io.use_gt_layout = 1 if use_gt_layout else 0
+        io.gt_layout = gt.data_ptr() if gt is not None else None
+        io.sample_uniforms = uni.data_ptr() if uni is not None else None
+        io.forced_tokens = forced.data_ptr() if forced is not None else None
+        for k, t in out.items():
+            setattr(io, k, t.data_ptr())
+        fn = {'both': self._lib.n2nmn_seq2seq_forward, 'encoder': self._lib.n2nmn_encoder_forward,
+              'decoder': self._lib.n2nmn_decoder_forward}[phase]
+        _lib.check(fn(self._ctx, C.byref(io), self.stream()))
+        out['_keepalive'] = (seq, lens, gt, uni, forced)
+        return out
+
+    def execute(self, packed: PackedLayouts, image_feat, word_vecs, reuse_buffers: bool = True):
+        """Phase 2: scores [num_rows, num_choices] (device tensor) for a packed program."""
+        torch = _torch()
+        feat = self._dev(image_feat, torch.float32)
+        wv = self._dev(word_vecs, torch.float32)
+        n_full = feat.shape[0]
+        if wv.shape[1] != n_full:
+            raise ValueError('word_vecs [T_dec, N, E] and image_feat [N, H, W, D] disagree on N')
+        rows = packed.num_rows
+        shape = (rows, self.dims.num_choices)
+        scores = self._buf('scores', shape, torch.float32) if reuse_buffers else \
+            torch.empty(shape, dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.n2nmn_execute_program(self._ctx, packed.handle, feat.data_ptr(),
+                                                   wv.data_ptr(), n_full, scores.data_ptr(),
+                                                   self.stream()))
+        return scores
+
+    def module_forward(self, name: str, inputs, time_idx, batch_idx, image_feat, word_vecs):
+        """One module operator on explicit inputs (Modules.<X>Module)."""
+        torch = _torch()
+        if name not in OP_CODE:
+            raise KeyError(name)
+        arity = MODULE_INPUT_NUM[name]
+        if len(inputs) != arity:
+            raise ValueError('%s takes %d attention input(s)' % (name, arity))
+        t_idx = np.ascontiguousarray(np.asarray(_to_host(time_idx)).reshape(-1), np.int32)
+        b_idx = np.ascontiguousarray(np.asarray(_to_host(batch_idx)).reshape(-1), np.int32)
+        nb = t_idx.shape[0]
+        if b_idx.shape[0] != nb:
+            raise ValueError('time_idx and batch_idx must have the same length')
+        d = self.dims
+        feat = self._dev(image_feat, torch.float32)
+        wv = self._dev(word_vecs, torch.float32)
+        ins = [self._dev(x, torch.float32).reshape(nb, d.H * d.W) for x in inputs]
+        if MODULE_OUTPUT_TYPE[name] == 'att':
+            out = torch.empty((nb, d.H, d.W, 1), dtype=torch.float32, device=self.device)
+        else:
+            out = torch.empty((nb, d.num_choices), dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.n2nmn_module_forward(
+            self._ctx, OP_CODE[name], nb,
+            ins[0].data_ptr() if arity >= 1 else None, ins[1].data_ptr() if arity >= 2 else None,
+            t_idx.ctypes.data, b_idx.ctypes.data, feat.data_ptr(), wv.data_ptr(), feat.shape[0],
+            out.data_ptr(), self.stream()))
+        return out
+
+    def gemm(self, A, B, bias=None):
+        torch = _torch()
+        A = self._dev(A, torch.float32); B = self._dev(B, torch.float32)
+        bias = self._dev(bias, torch.float32)
+        M, K = A.shape
+        N = B.shape[1]
+        Cm = torch.empty((M, N), dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.n2nmn_debug_gemm(self._ctx, A.data_ptr(), B.data_ptr(),
+                                              bias.data_ptr() if bias is not None else None,
+                                              Cm.data_ptr(), M, N, K, self.stream()))
+        return Cm
+
+    # ------------------------------------------------------------------------------------
+    def forward(self, batch, T_dec: Optional[int] = None, use_gt_layout: bool = False,
+                gt_layout=None, sample_uniforms=None):
+        """The whole hot path of exp_clevr/eval_clevr.py:103-135 for one batch:
+        phase 1 -> token fetch (the one host sync) -> C++ assemble/pack -> phase 2.
+        Returns (scores device tensor, tokens numpy [T_dec,N], validity numpy [N])."""
+        s2s = self.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], T_dec,
+                           use_gt_layout, gt_layout, sample_uniforms)
+        tokens = s2s['predicted_tokens'].cpu().numpy()
+        packed, validity = self.assembler.assemble_packed(tokens)
+        scores = self.execute(packed, batch['image_feat_batch'], s2s['word_vecs'])
+        return scores, tokens, validity
+
+
+def _to_host(x):
+    if hasattr(x, 'detach'):
+        return x.detach().cpu().numpy()
+    return x
