@@ -652,12 +652,13 @@ int n2nmn_module_forward(n2nmn_ctx* ctx, int op, int Nb, const float* input_0,
                          const float* input_1, const int32_t* time_idx_host,
                          const int32_t* batch_idx_host, const float* image_feat,
                          const float* word_vecs, int N_full, float* out, n2nmn_stream stream) {
-  N2_REQUIRE(ctx && out && time_idx_host && batch_idx_host, N2NMN_EINVAL,
-             "module_forward: null argument");
+  N2_REQUIRE(ctx, N2NMN_EINVAL, "module_forward: null context");
   const int k = op_arity(op);
   N2_REQUIRE(k >= 0 && op != OP_INPUT, N2NMN_EKEY, "module_forward: unknown module operator");
   N2_REQUIRE(Nb >= 0, N2NMN_EINVAL, "module_forward: negative batch");
   if (Nb == 0) return N2NMN_OK;          // Fold's zero-size batches need no work at all
+  N2_REQUIRE(out && time_idx_host && batch_idx_host, N2NMN_EINVAL,
+             "module_forward: null argument");
   N2_REQUIRE((k < 1 || input_0) && (k < 2 || input_1), N2NMN_EINVAL,
              "module_forward: missing attention input for this operator");
   N2_REQUIRE(image_feat && word_vecs, N2NMN_EINVAL, "module_forward: null feature / word_vecs");
