@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Benchmark of the N2NMN CLEVR forward hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = one pass of the hot path over one batch of 64 questions (BASELINE.json configs[1]:
+CLEVR forward, fixed ground-truth layouts, 10x15x512 synthetic pool5 features): phase 1 (LSTM
+encoder + teacher-forced attentional decoder) -> predicted_tokens fetched to the host (the sync the
+reference's API mandates, exp_clevr/eval_clevr.py:111-125) -> C++ assemble/pack -> phase 2 (module
+network) -> answer logits in HBM.  Inputs are resident in HBM before the timed region.
+Multi-GPU: the path shards by question with no data-path collective (weak scaling: every rank runs
+its own batch-64 stream); timing = barrier + synchronize on both sides, max over ranks.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TF = 157.3    # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+MFMA_FAMILIES = ('lstm_step', 'gemm_pk')
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--config', type=int, default=2, choices=(2, 3),
+                    help='2: fixed gt layouts (metric config); 3: greedy decoder layouts')
+    ap.add_argument('--batch', type=int, default=64)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-profile', action='store_true')
+    return ap.parse_args()
+
+
+def cpu_baseline(d, w, batch, gt, names, use_gt):
+    """fp32 numpy oracle (the CPU restatement of the reference; the reference's TF1 path cannot
+    run here) on a bounded sample: whole batches until ~10 s have passed (max 3)."""
+    import numpy as np
+    from oracle import n2nmn_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    nb = 0
+    while nb < 3 and (nb == 0 or time.perf_counter() - t0 < 10.0):
+        O.forward(w, names, batch, d.T_decoder, d.num_choices, np.float32,
+                  use_gt_layout=use_gt, gt_layout=gt)
+        nb += 1
+    dt = time.perf_counter() - t0
+    return {'value': round(nb * d.N / dt, 2), 'unit': 'questions/sec', 'cores': int(threads),
+            'kind': 'port',
+            'sample': '%d batch(es) of %d questions, same synthetic inputs, fp32 numpy oracle '
+                      '(oracle/n2nmn_oracle.py; BLAS threads=%d of %d host cores); the reference '
+                      'TF1/Fold CPU path is not runnable here' % (nb, d.N, threads,
+                                                                   os.cpu_count() or 0)}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=torch.device('cuda', local_rank))
+
+    from n2nmn_amd import synth
+    from n2nmn_amd.engine import Engine
+    from n2nmn_amd.nmn3_assembler import Assembler
+    from n2nmn_amd.spec import Dims, CLEVR_MODULE_NAMES
+
+    d = Dims(N=args.batch)
+    names = list(CLEVR_MODULE_NAMES)
+    asm = Assembler(names)
+    eng = Engine(d, asm, device=local_rank)
+    w = synth.make_weights(d, seed=0)
+    eng.load_weights(w)
+    dev = eng.device
+    # every rank streams its own questions (weak scaling); a few distinct batches are cycled so
+    # the feature maps of a step are not the ones the previous step left in the caches
+    n_batches = 4
+    batches, gts = [], []
+    for i in range(n_batches):
+        b = synth.make_inputs(d, seed=rank * 1000 + i)
+        batches.append({k: torch.as_tensor(v).to(dev) for k, v in b.items()})
+        gts.append(torch.as_tensor(synth.template_layout_batch(d, offset=i)).to(dev))
+    use_gt = args.config == 2
+
+    def step(i):
+        b = batches[i % n_batches]
+        return eng.forward(b, use_gt_layout=use_gt, gt_layout=gts[i % n_batches] if use_gt else None)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(i)
+    sync_all()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    out = None
+    if rank == 0:
+        qps = world * d.N * args.steps / elapsed
+        out = {
+            'metric': 'questions/sec (forward) on CLEVR 10x15x512 feats, batch 64',
+            'value': round(qps, 1), 'unit': 'questions/sec', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1e3 * elapsed / args.steps, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE.json configs[%d]: CLEVR forward, %s, batch %d per GPU, '
+                                   '10x15x512 synthetic pool5, T_enc=45, T_dec=20' %
+                                   (args.config - 1,
+                                    'fixed ground-truth layouts (10-template mix, teacher-forced '
+                                    'decoder)' if use_gt else 'layouts sampled by the greedy seq2seq '
+                                    'decoder', d.N),
+                       'global_batch': world * d.N, 'parallelism': 'dp%d (question-sharded, no '
+                       'data-path collective)' % world, 'streams_per_gpu': 1,
+                       'host_sync': 'predicted_tokens D2H between phase 1 and phase 2'},
+        }
+
+    # ---- per-kernel roofline: HIP events around every launch, separate pass of the same steps
+    if rank == 0 and not args.no_profile:
+        ksteps = min(args.steps, 50)
+        eng.profile_begin()
+        for i in range(ksteps):
+            step(i)
+        fams = eng.profile_end()
+        rows = []
+        for f in fams:
+            if f['launches'] == 0:
+                continue
+            bound = 'mfma' if f['name'].startswith(MFMA_FAMILIES) else 'hbm'
+            avg_s = f['total_ms'] * 1e-3 / f['launches']
+            if bound == 'mfma':
+                ach = f['flops'] / f['launches'] / avg_s / 1e12
+                peak, unit = MFMA_F32_PEAK_TF, 'TFLOP/s'
+            else:
+                ach = f['bytes'] / f['launches'] / avg_s / 1e9
+                peak, unit = HBM_PEAK_GBS, 'GB/s'
+            rows.append({'kernel': f['name'], 'bound': bound, 'launches_per_step':
+                         round(f['launches'] / ksteps, 2), 'avg_us': round(avg_s * 1e6, 3),
+                         'us_per_step': round(f['total_ms'] * 1e3 / ksteps, 2),
+                         'achieved': round(ach, 3), 'peak': peak, 'unit': unit,
+                         'frac': round(ach / peak, 4)})
+        rows.sort(key=lambda r: -r['us_per_step'])
+        dom = rows[0]
+        out['roofline'] = {'kernel': dom['kernel'], 'bound': dom['bound'],
+                           'achieved': dom['achieved'], 'peak': dom['peak'], 'unit': dom['unit'],
+                           'frac': dom['frac'], 'traffic': None, 'avg_us': dom['avg_us'],
+                           'measured': 'hipEvent pairs around each launch on the launch stream, '
+                                       'separate pass of %d steps right after the timed region'
+                                       % ksteps}
+        out['kernels'] = rows
+        out['gpu_us_per_step'] = round(sum(r['us_per_step'] for r in rows), 1)
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        b0 = synth.make_inputs(d, seed=0)
+        gt0 = synth.template_layout_batch(d) if use_gt else None
+        out['cpu_baseline'] = cpu_baseline(d, w, b0, gt0, names, use_gt)
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -207,6 +207,17 @@ int n2nmn_module_forward(n2nmn_ctx *ctx, int op, int Nb, const float *input_0,
  * (7) introspection used by the roofline report: algorithmic bytes / flops of one launch of a
  *     kernel family (SURVEY.md section 8d figures), and a plain GEMM entry for unit parity.
  * ---------------------------------------------------------------------------------------- */
+/* Per-kernel-family profiler: between profile_begin and profile_end every kernel launch of the
+ * context is bracketed by HIP events on its launch stream; profile_end synchronises the stream and
+ * accumulates, per family, launches / total duration / ALGORITHMIC flops and bytes (the figures
+ * of SURVEY.md section 8(d), stated per kernel in DESIGN.md section 4).  Returns the number of
+ * launches recorded. */
+int n2nmn_profile_begin(n2nmn_ctx *ctx);
+int n2nmn_profile_end(n2nmn_ctx *ctx, n2nmn_stream stream);
+int n2nmn_profile_num_families(void);
+int n2nmn_profile_get(const n2nmn_ctx *ctx, int family, const char **name, int64_t *launches,
+                      double *total_ms, double *flops, double *bytes);
+
 /* C[M,N] = A[M,K] . B[K,N] + bias[N]   (row-major fp32; B is packed internally) */
 int n2nmn_debug_gemm(n2nmn_ctx *ctx, const float *A, const float *B, const float *bias,
                      float *C, int M, int N, int K, n2nmn_stream stream);

@@ -72,6 +72,12 @@ SYMBOLS = [
     ('n2nmn_program_num_launches', _I, [_P]),
     ('n2nmn_execute_program', _I, [_P, _P, _P, _P, _I, _P, _P]),
     ('n2nmn_module_forward', _I, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    ('n2nmn_profile_begin', _I, [_P]),
+    ('n2nmn_profile_end', _I, [_P, _P]),
+    ('n2nmn_profile_num_families', _I, []),
+    ('n2nmn_profile_get', _I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_int64),
+                               C.POINTER(C.c_double), C.POINTER(C.c_double),
+                               C.POINTER(C.c_double)]),
     ('n2nmn_debug_gemm', _I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
 ]
 

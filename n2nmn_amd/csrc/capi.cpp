@@ -102,6 +102,14 @@ struct n2nmn_ctx {
   int max_tab = 0;
 
   n2nmn_program* scratch_prog = nullptr;   // used by n2nmn_module_forward
+
+  // per-kernel-family HIP-event profiler (n2nmn_profile_*)
+  bool prof_on = false;
+  std::vector<hipEvent_t> prof_events;      // pairs
+  struct ProfRec { int fam; double flops, bytes; };
+  std::vector<ProfRec> prof_recs;
+  double prof_ms[16] = {0}, prof_flops[16] = {0}, prof_bytes[16] = {0};
+  long prof_launches[16] = {0};
 };
 
 namespace n2nmn {
@@ -246,6 +254,35 @@ static size_t carve(n2nmn_ctx* c, char* base) {
   return align_up(k.off, 256);
 }
 
+enum Family {
+  F_LSTM_ENC = 0, F_LSTM_DEC0, F_LSTM_DEC1, F_LINEAR_Q, F_DEC_STEP, F_GEMM_EHT, F_WORD_VECS,
+  F_TEXTMAP, F_CONV_IMAGE, F_ATT_OPS, F_POOL, F_HEADS, F_COUNT
+};
+static const char* kFamilyNames[F_COUNT] = {
+  "lstm_step(enc L0+L1)", "lstm_step(dec L0)", "lstm_step(dec L1)", "lstm_step(linear q)",
+  "dec_step", "gemm_pk(encoder_h_transform)", "word_vecs", "textmap", "gemm_pk(conv_image)",
+  "att_ops", "pool", "heads"};
+
+// Brackets one launch with HIP events on the launch stream when profiling is enabled.
+struct ProfScope {
+  n2nmn_ctx* c; hipStream_t s; bool on;
+  ProfScope(n2nmn_ctx* c_, int fam, double flops, double bytes, hipStream_t s_)
+      : c(c_), s(s_), on(c_->prof_on) {
+    if (!on) return;
+    const size_t i = c->prof_recs.size();
+    while (c->prof_events.size() < 2 * (i + 1)) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) { on = false; return; }
+      c->prof_events.push_back(e);
+    }
+    c->prof_recs.push_back({fam, flops, bytes});
+    (void)hipEventRecord(c->prof_events[2 * i], s);
+  }
+  ~ProfScope() {
+    if (on) (void)hipEventRecord(c->prof_events[2 * (c->prof_recs.size() - 1) + 1], s);
+  }
+};
+
 static hipStream_t S(n2nmn_stream s) { return reinterpret_cast<hipStream_t>(s); }
 
 static int check_launch(const char* what) {
@@ -302,14 +339,23 @@ static int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s)
     j1.h_old = c->eh1[(st + 1) & 1]; j1.h_new = c->eh1[st & 1];
     j1.out_seq = st >= 0 ? c->enc_out + (size_t)st * N * L : nullptr;
     j1.seq_len = io->seq_length; j1.t = st;
-    launch_lstm_step(jobs, 2, N, L, s);
+    {
+      const double fl = 2.0 * N * 4 * L * ((j0.active ? L : 0) + (j1.active ? 2 * L : 0));
+      const double by = 4.0 * ((j0.active ? (double)L * 4 * L + 3.0 * N * L : 0) +
+                               (j1.active ? 2.0 * L * 4 * L + 5.0 * N * L : 0));
+      ProfScope ps(c, F_LSTM_ENC, fl, by, s);
+      launch_lstm_step(jobs, 2, N, L, s);
+    }
   }
   // encoder_h_transformed = fc(encoder_outputs)          (nmn3_netgen_att.py:102-106)
   GemmArgs g{};
   g.A = c->enc_out; g.lda = L; g.M = T * N; g.K = L; g.group_idx = nullptr; g.group_size = 1;
   g.Bp = c->eht_W_p; g.Np = L; g.Kp = c->KpL; g.bias = c->vars[V_EHT_B].mirror; g.N = L;
   g.C = c->eht; g.ldc = L; g.n_store = L;
-  launch_gemm_pk(g, s);
+  {
+    ProfScope ps(c, F_GEMM_EHT, 2.0 * T * N * L * L, 4.0 * (2.0 * T * N * L + (double)L * L), s);
+    launch_gemm_pk(g, s);
+  }
   c->enc_T = T; c->enc_N = N; c->enc_seq = io->input_seq; c->enc_len = io->seq_length;
   const size_t nl = sizeof(float) * (size_t)N * L;
   if (io->encoder_outputs)
@@ -352,18 +398,28 @@ static int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s)
     j0.xtab = c->dec_xtab; j0.xidx = t == 0 ? nullptr : c->next_idx; j0.xidx_const = V;  // <go>
     j0.c_in = t == 0 ? c->ec0 : c->dc0; j0.c_out = c->dc0; j0.ntiles = L / 4;
     j0.h_old = j0.A0; j0.h_new = c->dh0[t & 1];
-    launch_lstm_step(&j0, 1, N, L, s);
+    {
+      ProfScope ps(c, F_LSTM_DEC0, 2.0 * N * L * 4 * L, 4.0 * ((double)L * 4 * L + 3.0 * N * L), s);
+      launch_lstm_step(&j0, 1, N, L, s);
+    }
     LstmJob j1{};
     j1.active = 1;
     j1.A0 = c->dh0[t & 1]; j1.A1 = t == 0 ? c->eh1[pe] : c->dh1[(t + 1) & 1]; j1.K = 2 * L;
     j1.Wp = c->dec_W1_t; j1.bias = c->vars[V_DEC_B1].mirror;
     j1.c_in = t == 0 ? c->ec1 : c->dc1; j1.c_out = c->dc1; j1.ntiles = L / 4;
     j1.h_old = j1.A1; j1.h_new = c->dh1[t & 1];
-    launch_lstm_step(&j1, 1, N, L, s);
+    {
+      ProfScope ps(c, F_LSTM_DEC1, 2.0 * N * 2 * L * 4 * L,
+                   4.0 * (2.0 * L * 4 * L + 5.0 * N * L), s);
+      launch_lstm_step(&j1, 1, N, L, s);
+    }
     LstmJob jq{};                      // q = out . W_a + b_a            (nmn3_netgen_att.py:185)
     jq.active = 1; jq.mode = 1; jq.A0 = c->dh1[t & 1]; jq.K = L; jq.Wp = c->att_W_t;
     jq.ntiles = L / 16; jq.bias = c->vars[V_ATT_B].mirror; jq.h_new = c->qbuf; jq.ldo = L;
-    launch_lstm_step(&jq, 1, N, L, s);
+    {
+      ProfScope ps(c, F_LINEAR_Q, 2.0 * N * L * L, 4.0 * ((double)L * L + 2.0 * N * L), s);
+      launch_lstm_step(&jq, 1, N, L, s);
+    }
     DecStepArgs a{};
     a.q = c->qbuf; a.out = c->dh1[t & 1]; a.eht = c->eht; a.eout = c->enc_out;
     a.seq_len = c->enc_len; a.v = c->vars[V_ATT_V].mirror; a.Wy = c->vars[V_TOK_W].mirror;
@@ -376,10 +432,19 @@ static int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s)
     a.neg_entropy = negent; a.atts = atts + (size_t)t * T * N;
     a.scores = io->token_scores ? io->token_scores + (size_t)t * N * V : nullptr;
     a.next_idx = c->next_idx;
-    launch_dec_step(a, s);
+    {
+      // eht + eout rows of every question, q, out, W_y; tanh / exp counted as 1 flop
+      ProfScope ps(c, F_DEC_STEP, (double)N * (4.0 * T * L + 2.0 * 2 * L * V),
+                   4.0 * N * (2.0 * T * L + 2.0 * L + T + V) + 4.0 * 2 * L * V, s);
+      launch_dec_step(a, s);
+    }
   }
-  launch_word_vecs(atts, c->enc_seq, c->vars[V_ENC_EMB].mirror, Td, T, N, d.embed_dim_txt, wv,
-                   tprobs, io->log_seq_prob, s);
+  {
+    const double E = d.embed_dim_txt;
+    ProfScope ps(c, F_WORD_VECS, 2.0 * Td * T * N * E, 4.0 * N * (T * E + Td * T + Td * E), s);
+    launch_word_vecs(atts, c->enc_seq, c->vars[V_ENC_EMB].mirror, Td, T, N, d.embed_dim_txt, wv,
+                     tprobs, io->log_seq_prob, s);
+  }
   return check_launch("decoder_forward");
 }
 
@@ -420,9 +485,16 @@ static int run_program(n2nmn_ctx* c, Program& p, const float* feat, const float*
   b.pfc = c->pfc; b.mfind = c->mfind; b.mfsp = c->mfsp; b.feat = feat; b.word_vecs = word_vecs;
   b.scores = scores; b.N_full = N_full; b.H = d.H; b.W = d.W; b.D = d.D; b.M = d.map_dim;
   b.Mp = c->Mp; b.E = d.embed_dim_txt; b.C = C; b.HWp = c->HWp; b.ksize = d.kernel_size;
+  const double dE = d.embed_dim_txt, dM = d.map_dim, dD = d.D, dHW = HW, dC = C, dMp = c->Mp;
   for (const Launch& l : p.launches) {
     switch (l.kind) {
-      case LK_TEXTMAP: launch_textmap(w, b, l.offset, l.count, s); break;
+      case LK_TEXTMAP: {
+        // groups of <= TM_GROUP nodes; one [E,M] weight stream per group
+        ProfScope ps(c, F_TEXTMAP, 2.0 * p.num_text * dE * dM,
+                     4.0 * (l.count * dE * dM + p.num_text * (dE + dMp)), s);
+        launch_textmap(w, b, l.offset, l.count, s);
+        break;
+      }
       case LK_CONV_FIND:
       case LK_CONV_FSP: {
         const bool fsp = l.kind == LK_CONV_FSP;
@@ -432,12 +504,52 @@ static int run_program(n2nmn_ctx* c, Program& p, const float* feat, const float*
         g.Bp = fsp ? c->fsp_img_p : c->find_img_p; g.Np = c->Mp; g.Kp = c->KpD;
         g.bias = c->vars[fsp ? V_FSP_IMG_B : V_FIND_IMG_B].mirror; g.N = d.map_dim;
         g.C = fsp ? c->mfsp : c->mfind; g.ldc = c->Mp; g.n_store = c->Mp;
+        ProfScope ps(c, F_CONV_IMAGE, 2.0 * l.count * dHW * dD * dM,
+                     4.0 * (l.count * dHW * (dD + dMp) + dD * dM), s);
         launch_gemm_pk(g, s);
         break;
       }
-      case LK_ATT: launch_att_ops(w, b, l.offset, l.count, s); break;
-      case LK_POOL: launch_pool(w, b, l.offset, l.count, s); break;
-      case LK_HEAD: launch_heads(w, b, l.offset, l.count, s); break;
+      case LK_ATT: {
+        // algorithmic bytes: conv_image map read by the Find-type epilogues + attention maps
+        double by = 0, fl = 0;
+        for (int i = 0; i < l.count; ++i) {
+          const int* e = p.tab.data() + l.offset + 4 * i;
+          const DevNode& nd = p.dev_nodes[e[0]];
+          const double part = 1.0 / e[2];
+          if (nd.op == N2NMN_OP_FIND || nd.op == N2NMN_OP_FILTER ||
+              nd.op == N2NMN_OP_FIND_SAME_PROPERTY) {
+            by += part * 4.0 * (dHW * dMp + 2 * dMp + dHW); fl += part * 5.0 * dHW * dM;
+          } else if (nd.op == N2NMN_OP_TRANSFORM) {
+            by += part * 4.0 * (2 * dHW) + 4.0 * (d.kernel_size * d.kernel_size + 3) * dM;
+            fl += part * dHW * dM * (2.0 * d.kernel_size * d.kernel_size + 5);
+          } else {
+            by += 4.0 * 3 * dHW; fl += 2.0 * (2 * dHW + 4) * dC;
+          }
+        }
+        ProfScope ps(c, F_ATT_OPS, fl, by, s);
+        launch_att_ops(w, b, l.offset, l.count, s);
+        break;
+      }
+      case LK_POOL: {
+        // per job: the [HW, D] feature map once (shared by both inputs of SameProperty),
+        // the attention logits, the partial fc_att rows; fc_att weights once per launch
+        double by = 4.0 * dD * dM, fl = 0;
+        for (int i = 0; i < l.count; i += POOL_PARTS) {
+          const DevNode& nd = p.dev_nodes[p.tab[l.offset + 2 * i]];
+          const double nin = nd.op == N2NMN_OP_SAME_PROPERTY ? 2 : 1;
+          by += 4.0 * (dHW * dD + nin * dHW + nin * POOL_PARTS * dMp);
+          fl += nin * (2.0 * dHW * dD + 2.0 * dD * dM + 3.0 * dHW);
+        }
+        ProfScope ps(c, F_POOL, fl, by, s);
+        launch_pool(w, b, l.offset, l.count, s);
+        break;
+      }
+      case LK_HEAD: {
+        ProfScope ps(c, F_HEADS, l.count * (2.0 * dM * dC + 8.0 * dM),
+                     4.0 * (l.count * (2.0 * POOL_PARTS * dMp + dMp + dC) + dM * dC), s);
+        launch_heads(w, b, l.offset, l.count, s);
+        break;
+      }
       default: break;
     }
   }
@@ -511,6 +623,7 @@ int n2nmn_ctx_create(const n2nmn_dims* dims, int device, n2nmn_ctx** out) {
 int n2nmn_ctx_destroy(n2nmn_ctx* ctx) {
   if (!ctx) return N2NMN_OK;
   if (ctx->base) (void)hipFree(ctx->base);
+  for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
   n2nmn_program_destroy(ctx->scratch_prog);
   delete ctx;
   return N2NMN_OK;
@@ -683,6 +796,44 @@ int n2nmn_module_forward(n2nmn_ctx* ctx, int op, int Nb, const float* input_0,
   if (rc != N2NMN_OK) { set_last_error(p.error); return rc; }
   return run_program(ctx, p, image_feat, word_vecs, N_full, ans ? out : nullptr, input_0, input_1,
                      ans ? nullptr : out, k * Nb, ans ? 0 : Nb, S(stream));
+}
+
+int n2nmn_profile_begin(n2nmn_ctx* ctx) {
+  N2_REQUIRE(ctx, N2NMN_EINVAL, "profile_begin: null context");
+  ctx->prof_recs.clear();
+  for (int i = 0; i < 16; ++i) {
+    ctx->prof_ms[i] = ctx->prof_flops[i] = ctx->prof_bytes[i] = 0;
+    ctx->prof_launches[i] = 0;
+  }
+  ctx->prof_on = true;
+  return N2NMN_OK;
+}
+
+int n2nmn_profile_end(n2nmn_ctx* ctx, n2nmn_stream stream) {
+  N2_REQUIRE(ctx, N2NMN_EINVAL, "profile_end: null context");
+  ctx->prof_on = false;
+  N2_HIP(hipStreamSynchronize(S(stream)));
+  for (size_t i = 0; i < ctx->prof_recs.size(); ++i) {
+    float ms = 0.f;
+    N2_HIP(hipEventElapsedTime(&ms, ctx->prof_events[2 * i], ctx->prof_events[2 * i + 1]));
+    const auto& r = ctx->prof_recs[i];
+    ctx->prof_ms[r.fam] += ms; ctx->prof_flops[r.fam] += r.flops;
+    ctx->prof_bytes[r.fam] += r.bytes; ctx->prof_launches[r.fam] += 1;
+  }
+  return (int)ctx->prof_recs.size();
+}
+
+int n2nmn_profile_num_families(void) { return F_COUNT; }
+
+int n2nmn_profile_get(const n2nmn_ctx* ctx, int family, const char** name, int64_t* launches,
+                      double* total_ms, double* flops, double* bytes) {
+  N2_REQUIRE(ctx && family >= 0 && family < F_COUNT, N2NMN_EINVAL, "profile_get: bad family");
+  if (name) *name = kFamilyNames[family];
+  if (launches) *launches = ctx->prof_launches[family];
+  if (total_ms) *total_ms = ctx->prof_ms[family];
+  if (flops) *flops = ctx->prof_flops[family];
+  if (bytes) *bytes = ctx->prof_bytes[family];
+  return N2NMN_OK;
 }
 
 int n2nmn_debug_gemm(n2nmn_ctx* ctx, const float* A, const float* B, const float* bias, float* C,

@@ -186,6 +186,22 @@ class Engine:
             out.data_ptr(), self.stream()))
         return out
 
+    def profile_begin(self):
+        _lib.check(self._lib.n2nmn_profile_begin(self._ctx))
+
+    def profile_end(self):
+        """-> list of dicts {name, launches, total_ms, flops, bytes} per kernel family."""
+        _lib.check(self._lib.n2nmn_profile_end(self._ctx, self.stream()))
+        out = []
+        for i in range(self._lib.n2nmn_profile_num_families()):
+            name = C.c_char_p(); n = C.c_int64()
+            ms, fl, by = C.c_double(), C.c_double(), C.c_double()
+            _lib.check(self._lib.n2nmn_profile_get(self._ctx, i, C.byref(name), C.byref(n),
+                                                   C.byref(ms), C.byref(fl), C.byref(by)))
+            out.append(dict(name=name.value.decode(), launches=n.value, total_ms=ms.value,
+                            flops=fl.value, bytes=by.value))
+        return out
+
     def gemm(self, A, B, bias=None):
         torch = _torch()
         A = self._dev(A, torch.float32); B = self._dev(B, torch.float32)
