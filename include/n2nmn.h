@@ -218,6 +218,10 @@ int n2nmn_profile_num_families(void);
 int n2nmn_profile_get(const n2nmn_ctx *ctx, int family, const char **name, int64_t *launches,
                       double *total_ms, double *flops, double *bytes);
 
+/* Kernel-variant microbenchmark of the fused LSTM step (see csrc/capi.cpp); debugging aid. */
+int n2nmn_debug_lstm_bench(n2nmn_ctx *ctx, int variant, int rows_per_wg, int njobs, int N,
+                           int iters, double *us, n2nmn_stream stream);
+
 /* C[M,N] = A[M,K] . B[K,N] + bias[N]   (row-major fp32; B is packed internally) */
 int n2nmn_debug_gemm(n2nmn_ctx *ctx, const float *A, const float *B, const float *bias,
                      float *C, int M, int N, int K, n2nmn_stream stream);

@@ -78,6 +78,7 @@ SYMBOLS = [
     ('n2nmn_profile_get', _I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_int64),
                                C.POINTER(C.c_double), C.POINTER(C.c_double),
                                C.POINTER(C.c_double)]),
+    ('n2nmn_debug_lstm_bench', _I, [_P, _I, _I, _I, _I, _I, C.POINTER(C.c_double), _P]),
     ('n2nmn_debug_gemm', _I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
 ]
 

@@ -81,6 +81,9 @@ struct n2nmn_ctx {
   float *enc_W0h_t = nullptr, *enc_W1_t = nullptr, *dec_W0h_t = nullptr, *dec_W1_t = nullptr;
   float *eht_W_p = nullptr, *att_W_t = nullptr, *find_img_p = nullptr, *fsp_img_p = nullptr;
   float* dec_emb_cat = nullptr;
+  float* wtxt_pad[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  float* btxt_pad[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  float* watt_pad[4] = {nullptr, nullptr, nullptr, nullptr};
   float* we_pad[3] = {nullptr, nullptr, nullptr};
   float* batt_pad[4] = {nullptr, nullptr, nullptr, nullptr};
   int32_t *P = nullptr, *Wv = nullptr, *bv = nullptr;
@@ -88,7 +91,7 @@ struct n2nmn_ctx {
   // seq2seq workspace
   float *eh0[2] = {nullptr, nullptr}, *eh1[2] = {nullptr, nullptr}, *ec0 = nullptr, *ec1 = nullptr;
   float *dh0[2] = {nullptr, nullptr}, *dh1[2] = {nullptr, nullptr}, *dc0 = nullptr, *dc1 = nullptr;
-  float *enc_out = nullptr, *eht = nullptr, *qbuf = nullptr;
+  float *enc_out = nullptr, *eht = nullptr, *qbuf = nullptr, *dec_h1_all = nullptr, *ent_t = nullptr, *dh1_rm = nullptr;
   int32_t *state = nullptr, *next_idx = nullptr, *tokens = nullptr;
   float *tprobs = nullptr, *negent = nullptr, *atts = nullptr, *word_vecs = nullptr;
   int enc_T = 0, enc_N = 0;            // shape of the encoder results currently held
@@ -220,6 +223,9 @@ static size_t carve(n2nmn_ctx* c, char* base) {
   c->find_img_p = k.take<float>((size_t)c->KpD * Mp);
   c->fsp_img_p = k.take<float>((size_t)c->KpD * Mp);
   c->dec_emb_cat = k.take<float>((V + 1) * (size_t)d.embed_dim_nmn);
+  for (int i = 0; i < 5; ++i) c->wtxt_pad[i] = k.take<float>(E * Mp);
+  for (int i = 0; i < 5; ++i) c->btxt_pad[i] = k.take<float>(Mp);
+  for (int i = 0; i < 4; ++i) c->watt_pad[i] = k.take<float>(D * Mp);
   for (int i = 0; i < 3; ++i) c->we_pad[i] = k.take<float>(Mp);
   for (int i = 0; i < 4; ++i) c->batt_pad[i] = k.take<float>(Mp);
   c->P = k.take<int32_t>(V * 3);
@@ -234,7 +240,10 @@ static size_t carve(n2nmn_ctx* c, char* base) {
   c->dc0 = ds + 4 * N * L; c->dc1 = ds + 5 * N * L;
   c->enc_out = k.take<float>(T * N * L);
   c->eht = k.take<float>(T * N * L);
-  c->qbuf = k.take<float>(N * L);
+  c->qbuf = k.take<float>(Td * N * L);
+  c->dec_h1_all = k.take<float>(Td * N * L);
+  c->ent_t = k.take<float>(Td * N);
+  c->dh1_rm = k.take<float>(N * L);
   c->state = k.take<int32_t>(N * 3);
   c->next_idx = k.take<int32_t>(N);
   c->tokens = k.take<int32_t>(Td * N);
@@ -259,8 +268,8 @@ enum Family {
   F_TEXTMAP, F_CONV_IMAGE, F_ATT_OPS, F_POOL, F_HEADS, F_COUNT
 };
 static const char* kFamilyNames[F_COUNT] = {
-  "lstm_step(enc L0+L1)", "lstm_step(dec L0)", "lstm_step(dec L1)", "lstm_step(linear q)",
-  "dec_step", "gemm_pk(encoder_h_transform)", "word_vecs", "textmap", "gemm_pk(conv_image)",
+  "lstm_step(enc L0+L1)", "lstm_step(dec L0 | pipelined L0+L1)", "lstm_step(dec L1)",
+  "lstm_step(linear q)", "dec_attn", "gemm_pk(encoder_h_transform)", "word_vecs", "textmap", "gemm_pk(conv_image)",
   "att_ops", "pool", "heads"};
 
 // Brackets one launch with HIP events on the launch stream when profiling is enabled.
@@ -298,15 +307,25 @@ static ModuleWeights module_weights(const n2nmn_ctx* c) {
   ModuleWeights w{};
   auto m = [&](int id) { return (const float*)c->vars[id].mirror; };
   const int txtw[5] = {V_FIND_TXT_W, V_FSP_TXT_W, V_TR_TXT_W, V_SP_TXT_W, V_DE_TXT_W};
-  for (int i = 0; i < 5; ++i) { w.Wtxt[i] = m(txtw[i]); w.btxt[i] = m(txtw[i] + 1); }
+  (void)txtw;
+  for (int i = 0; i < 5; ++i) { w.Wtxt[i] = c->wtxt_pad[i]; w.btxt[i] = c->btxt_pad[i]; }
   for (int i = 0; i < 3; ++i) w.we[i] = c->we_pad[i];
   w.be[0] = m(V_FIND_E_B); w.be[1] = m(V_FSP_E_B); w.be[2] = m(V_TR_E_B);
   w.Kt = m(V_TR_MAPS_W); w.bt = m(V_TR_MAPS_B);
   const int attw[4] = {V_FSP_ATT_W, V_SP_ATT0_W, V_SP_ATT1_W, V_DE_ATT_W};
-  for (int i = 0; i < 4; ++i) { w.Watt[i] = m(attw[i]); w.batt[i] = c->batt_pad[i]; }
+  (void)attw;
+  for (int i = 0; i < 4; ++i) { w.Watt[i] = c->watt_pad[i]; w.batt[i] = c->batt_pad[i]; }
   const int answ[7] = {V_EXIST_W, V_COUNT_W, V_EQ_W, V_MORE_W, V_LESS_W, V_SP_E_W, V_DE_E_W};
   for (int i = 0; i < 7; ++i) { w.Wans[i] = m(answ[i]); w.bans[i] = m(answ[i] + 1); }
   return w;
+}
+
+// state buffers (eh0/eh1/dh0/dh1) are k-interleaved [L/4][R][4] with R = capacity N
+static void packed_state(const n2nmn_ctx* c, LstmJob& j) {
+  j.a_rs = 4; j.a_ks = 4 * c->d.N; j.hp_R = c->d.N;
+}
+static void rowmajor_a(const n2nmn_ctx* c, LstmJob& j) {
+  j.a_rs = c->d.lstm_dim; j.a_ks = 4; j.hp_R = 0;
 }
 
 static int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s) {
@@ -324,6 +343,7 @@ static int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s)
     LstmJob& j0 = jobs[0];
     j0 = LstmJob{};
     j0.active = k < T;
+    packed_state(c, j0);
     j0.A0 = c->eh0[(k + 1) & 1]; j0.A1 = nullptr; j0.K = L; j0.Wp = c->enc_W0h_t;
     j0.xtab = W0x_bias_table; j0.xidx = io->input_seq + (size_t)k * N; j0.xidx_const = 0;
     j0.bias = nullptr; j0.c_in = c->ec0; j0.c_out = c->ec0; j0.ntiles = L / 4;
@@ -333,6 +353,7 @@ static int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s)
     j1 = LstmJob{};
     const int st = k - 1;
     j1.active = st >= 0;
+    packed_state(c, j1);
     j1.A0 = c->eh0[st & 1]; j1.A1 = c->eh1[(st + 1) & 1]; j1.K = 2 * L; j1.Wp = c->enc_W1_t;
     j1.xtab = nullptr; j1.xidx = nullptr; j1.bias = c->vars[V_ENC_B1].mirror;
     j1.c_in = c->ec1; j1.c_out = c->ec1; j1.ntiles = L / 4;
@@ -344,7 +365,7 @@ static int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s)
       const double by = 4.0 * ((j0.active ? (double)L * 4 * L + 3.0 * N * L : 0) +
                                (j1.active ? 2.0 * L * 4 * L + 5.0 * N * L : 0));
       ProfScope ps(c, F_LSTM_ENC, fl, by, s);
-      launch_lstm_step(jobs, 2, N, L, s);
+      launch_lstm_step(jobs, 2, N, L, 64, s);
     }
   }
   // encoder_h_transformed = fc(encoder_outputs)          (nmn3_netgen_att.py:102-106)
@@ -364,10 +385,11 @@ static int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s)
     N2_HIP(hipMemcpyAsync(io->encoder_h_transformed, c->eht, nl * T, hipMemcpyDeviceToDevice, s));
   if (io->encoder_states) {
     const int pe = (T - 1) & 1;
-    const float* src[4] = {c->ec0, c->eh0[pe], c->ec1, c->eh1[pe]};
-    for (int i = 0; i < 4; ++i)
-      N2_HIP(hipMemcpyAsync(io->encoder_states + (size_t)i * N * L, src[i], nl,
-                            hipMemcpyDeviceToDevice, s));
+    N2_HIP(hipMemcpyAsync(io->encoder_states, c->ec0, nl, hipMemcpyDeviceToDevice, s));
+    launch_unpack_h(c->eh0[pe], io->encoder_states + (size_t)N * L, N, L, d.N, s);
+    N2_HIP(hipMemcpyAsync(io->encoder_states + (size_t)2 * N * L, c->ec1, nl,
+                          hipMemcpyDeviceToDevice, s));
+    launch_unpack_h(c->eh1[pe], io->encoder_states + (size_t)3 * N * L, N, L, d.N, s);
   }
   return check_launch("encoder_forward");
 }
@@ -389,61 +411,116 @@ static int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s)
   float* negent = io->neg_entropy ? io->neg_entropy : c->negent;
   float* atts = io->atts ? io->atts : c->atts;
   float* wv = io->word_vecs ? io->word_vecs : c->word_vecs;
-  launch_dec_init(c->state, negent, N, Td, s);
   const int pe = (T - 1) & 1;
-  for (int t = 0; t < Td; ++t) {
-    LstmJob j0{};
-    j0.active = 1;
-    j0.A0 = t == 0 ? c->eh0[pe] : c->dh0[(t + 1) & 1]; j0.K = L; j0.Wp = c->dec_W0h_t;
-    j0.xtab = c->dec_xtab; j0.xidx = t == 0 ? nullptr : c->next_idx; j0.xidx_const = V;  // <go>
-    j0.c_in = t == 0 ? c->ec0 : c->dc0; j0.c_out = c->dc0; j0.ntiles = L / 4;
-    j0.h_old = j0.A0; j0.h_new = c->dh0[t & 1];
-    {
-      ProfScope ps(c, F_LSTM_DEC0, 2.0 * N * L * 4 * L, 4.0 * ((double)L * 4 * L + 3.0 * N * L), s);
-      launch_lstm_step(&j0, 1, N, L, s);
+  const double fl0 = 2.0 * N * L * 4 * L, by0 = 4.0 * ((double)L * 4 * L + 3.0 * N * L);
+  const double fl1 = 2.0 * N * 2 * L * 4 * L, by1 = 4.0 * (2.0 * L * 4 * L + 5.0 * N * L);
+  DecStepArgs a{};
+  a.eht = c->eht; a.eout = c->enc_out; a.seq_len = c->enc_len; a.v = c->vars[V_ATT_V].mirror;
+  a.Wy = c->vars[V_TOK_W].mirror; a.by = c->vars[V_TOK_B].mirror; a.P = c->P; a.Wv = c->Wv;
+  a.bv = c->bv; a.use_gt = io->use_gt_layout; a.T = T; a.N = N; a.L = L; a.V = V;
+  a.state = c->state;
+  const double att_fl = (double)N * (4.0 * T * L + 2.0 * 2 * L * V);
+  const double att_by = 4.0 * N * (2.0 * T * L + 2.0 * L + T + V) + 4.0 * 2 * L * V;
+  // Teacher forcing knows every token up front: the LSTM no longer waits for the attention /
+  // token step, so the two layers pipeline over time like the encoder and the attention of ALL
+  // T_dec steps runs as one launch.
+  const bool batched = io->use_gt_layout && !io->forced_tokens && !io->sample_uniforms;
+  if (batched) {
+    for (int k = 0; k <= Td; ++k) {
+      LstmJob jobs[2];
+      LstmJob& j0 = jobs[0];
+      j0 = LstmJob{};
+      j0.active = k < Td;
+      packed_state(c, j0);
+      j0.A0 = k == 0 ? c->eh0[pe] : c->dh0[(k + 1) & 1]; j0.K = L; j0.Wp = c->dec_W0h_t;
+      j0.ntiles = L / 4; j0.xtab = c->dec_xtab;
+      j0.xidx = k == 0 ? nullptr : io->gt_layout + (size_t)(k - 1) * N; j0.xidx_const = V;
+      j0.c_in = k == 0 ? c->ec0 : c->dc0; j0.c_out = c->dc0;
+      j0.h_old = j0.A0; j0.h_new = c->dh0[k & 1];
+      LstmJob& j1 = jobs[1];
+      j1 = LstmJob{};
+      const int st = k - 1;
+      j1.active = st >= 0;
+      packed_state(c, j1);
+      j1.A0 = c->dh0[st & 1]; j1.A1 = st == 0 ? c->eh1[pe] : c->dh1[(st + 1) & 1];
+      j1.K = 2 * L; j1.Wp = c->dec_W1_t; j1.ntiles = L / 4; j1.bias = c->vars[V_DEC_B1].mirror;
+      j1.c_in = st == 0 ? c->ec1 : c->dc1; j1.c_out = c->dc1;
+      j1.h_old = j1.A1; j1.h_new = c->dh1[st & 1];
+      j1.out_seq = st >= 0 ? c->dec_h1_all + (size_t)st * N * L : nullptr;
+      ProfScope ps(c, F_LSTM_DEC0, (j0.active ? fl0 : 0) + (j1.active ? fl1 : 0),
+                   (j0.active ? by0 : 0) + (j1.active ? by1 : 0), s);
+      launch_lstm_step(jobs, 2, N, L, 64, s);
     }
-    LstmJob j1{};
-    j1.active = 1;
-    j1.A0 = c->dh0[t & 1]; j1.A1 = t == 0 ? c->eh1[pe] : c->dh1[(t + 1) & 1]; j1.K = 2 * L;
-    j1.Wp = c->dec_W1_t; j1.bias = c->vars[V_DEC_B1].mirror;
-    j1.c_in = t == 0 ? c->ec1 : c->dc1; j1.c_out = c->dc1; j1.ntiles = L / 4;
-    j1.h_old = j1.A1; j1.h_new = c->dh1[t & 1];
-    {
-      ProfScope ps(c, F_LSTM_DEC1, 2.0 * N * 2 * L * 4 * L,
-                   4.0 * (2.0 * L * 4 * L + 5.0 * N * L), s);
-      launch_lstm_step(&j1, 1, N, L, s);
-    }
-    LstmJob jq{};                      // q = out . W_a + b_a            (nmn3_netgen_att.py:185)
-    jq.active = 1; jq.mode = 1; jq.A0 = c->dh1[t & 1]; jq.K = L; jq.Wp = c->att_W_t;
+    LstmJob jq{};                      // q = out . W_a + b_a for all steps  (nmn3_netgen_att.py:185)
+    rowmajor_a(c, jq);
+    jq.active = 1; jq.mode = 1; jq.A0 = c->dec_h1_all; jq.K = L; jq.Wp = c->att_W_t;
     jq.ntiles = L / 16; jq.bias = c->vars[V_ATT_B].mirror; jq.h_new = c->qbuf; jq.ldo = L;
     {
-      ProfScope ps(c, F_LINEAR_Q, 2.0 * N * L * L, 4.0 * ((double)L * L + 2.0 * N * L), s);
-      launch_lstm_step(&jq, 1, N, L, s);
+      ProfScope ps(c, F_LINEAR_Q, 2.0 * Td * N * L * L, 4.0 * ((double)L * L + 2.0 * Td * N * L), s);
+      launch_lstm_step(&jq, 1, Td * N, L, 64, s);
     }
-    DecStepArgs a{};
-    a.q = c->qbuf; a.out = c->dh1[t & 1]; a.eht = c->eht; a.eout = c->enc_out;
-    a.seq_len = c->enc_len; a.v = c->vars[V_ATT_V].mirror; a.Wy = c->vars[V_TOK_W].mirror;
-    a.by = c->vars[V_TOK_B].mirror; a.P = c->P; a.Wv = c->Wv; a.bv = c->bv;
-    a.gt = io->gt_layout ? io->gt_layout + (size_t)t * N : nullptr;
-    a.uni = io->sample_uniforms ? io->sample_uniforms + (size_t)t * N : nullptr;
-    a.forced = io->forced_tokens ? io->forced_tokens + (size_t)t * N : nullptr;
-    a.use_gt = io->use_gt_layout; a.t = t; a.T = T; a.N = N; a.L = L; a.V = V;
-    a.state = c->state; a.tokens = tokens + (size_t)t * N; a.tprobs = tprobs + (size_t)t * N;
-    a.neg_entropy = negent; a.atts = atts + (size_t)t * T * N;
-    a.scores = io->token_scores ? io->token_scores + (size_t)t * N * V : nullptr;
-    a.next_idx = c->next_idx;
+    a.q = c->qbuf; a.out = c->dec_h1_all; a.gt = io->gt_layout; a.uni = nullptr; a.forced = nullptr;
+    a.tokens = tokens; a.tprobs = tprobs; a.ent_t = c->ent_t; a.atts = atts;
+    a.scores = io->token_scores; a.next_idx = nullptr;
     {
-      // eht + eout rows of every question, q, out, W_y; tanh / exp counted as 1 flop
-      ProfScope ps(c, F_DEC_STEP, (double)N * (4.0 * T * L + 2.0 * 2 * L * V),
-                   4.0 * N * (2.0 * T * L + 2.0 * L + T + V) + 4.0 * 2 * L * V, s);
-      launch_dec_step(a, s);
+      ProfScope ps(c, F_DEC_STEP, Td * att_fl, Td * att_by, s);
+      launch_dec_attn(a, Td, s);
+    }
+  } else {
+    launch_dec_init(c->state, N, Td, s);
+    for (int t = 0; t < Td; ++t) {
+      LstmJob j0{};
+      j0.active = 1;
+      packed_state(c, j0);
+      j0.A0 = t == 0 ? c->eh0[pe] : c->dh0[(t + 1) & 1]; j0.K = L; j0.Wp = c->dec_W0h_t;
+      j0.ntiles = L / 4;
+      j0.xtab = c->dec_xtab; j0.xidx = t == 0 ? nullptr : c->next_idx; j0.xidx_const = V;  // <go>
+      j0.c_in = t == 0 ? c->ec0 : c->dc0; j0.c_out = c->dc0;
+      j0.h_old = j0.A0; j0.h_new = c->dh0[t & 1];
+      {
+        ProfScope ps(c, F_LSTM_DEC0, fl0, by0, s);
+        launch_lstm_step(&j0, 1, N, L, 32, s);
+      }
+      LstmJob j1{};
+      j1.active = 1;
+      packed_state(c, j1);
+      j1.out_seq = c->dh1_rm;          // row-major copy of the top-layer h for dec_attn
+      j1.A0 = c->dh0[t & 1]; j1.A1 = t == 0 ? c->eh1[pe] : c->dh1[(t + 1) & 1]; j1.K = 2 * L;
+      j1.Wp = c->dec_W1_t; j1.ntiles = L / 4; j1.bias = c->vars[V_DEC_B1].mirror;
+      j1.c_in = t == 0 ? c->ec1 : c->dc1; j1.c_out = c->dc1;
+      j1.h_old = j1.A1; j1.h_new = c->dh1[t & 1];
+      {
+        ProfScope ps(c, F_LSTM_DEC1, fl1, by1, s);
+        launch_lstm_step(&j1, 1, N, L, 32, s);
+      }
+      LstmJob jq{};                    // q = out . W_a + b_a            (nmn3_netgen_att.py:185)
+      packed_state(c, jq);
+      jq.hp_R = 0;
+      jq.active = 1; jq.mode = 1; jq.A0 = c->dh1[t & 1]; jq.K = L; jq.Wp = c->att_W_t;
+      jq.ntiles = L / 16; jq.bias = c->vars[V_ATT_B].mirror; jq.h_new = c->qbuf; jq.ldo = L;
+      {
+        ProfScope ps(c, F_LINEAR_Q, 2.0 * N * L * L, 4.0 * ((double)L * L + 2.0 * N * L), s);
+        launch_lstm_step(&jq, 1, N, L, 32, s);
+      }
+      a.q = c->qbuf; a.out = c->dh1_rm;
+      a.gt = io->gt_layout ? io->gt_layout + (size_t)t * N : nullptr;
+      a.uni = io->sample_uniforms ? io->sample_uniforms + (size_t)t * N : nullptr;
+      a.forced = io->forced_tokens ? io->forced_tokens + (size_t)t * N : nullptr;
+      a.tokens = tokens + (size_t)t * N; a.tprobs = tprobs + (size_t)t * N;
+      a.ent_t = c->ent_t + (size_t)t * N; a.atts = atts + (size_t)t * T * N;
+      a.scores = io->token_scores ? io->token_scores + (size_t)t * N * V : nullptr;
+      a.next_idx = c->next_idx;
+      {
+        ProfScope ps(c, F_DEC_STEP, att_fl, att_by, s);
+        launch_dec_attn(a, 1, s);
+      }
     }
   }
   {
     const double E = d.embed_dim_txt;
     ProfScope ps(c, F_WORD_VECS, 2.0 * Td * T * N * E, 4.0 * N * (T * E + Td * T + Td * E), s);
     launch_word_vecs(atts, c->enc_seq, c->vars[V_ENC_EMB].mirror, Td, T, N, d.embed_dim_txt, wv,
-                     tprobs, io->log_seq_prob, s);
+                     tprobs, c->ent_t, negent, io->log_seq_prob, s);
   }
   return check_launch("decoder_forward");
 }
@@ -484,7 +561,7 @@ static int run_program(n2nmn_ctx* c, Program& p, const float* feat, const float*
   b.nodes = c->dev_nodes; b.tab = c->dev_tab; b.arena = c->arena; b.tmap = c->tmap;
   b.pfc = c->pfc; b.mfind = c->mfind; b.mfsp = c->mfsp; b.feat = feat; b.word_vecs = word_vecs;
   b.scores = scores; b.N_full = N_full; b.H = d.H; b.W = d.W; b.D = d.D; b.M = d.map_dim;
-  b.Mp = c->Mp; b.E = d.embed_dim_txt; b.C = C; b.HWp = c->HWp; b.ksize = d.kernel_size;
+  b.Mp = c->Mp; b.wl_cap = d.map_dim * C <= 10240 ? d.map_dim * C : 0; b.E = d.embed_dim_txt; b.C = C; b.HWp = c->HWp; b.ksize = d.kernel_size;
   const double dE = d.embed_dim_txt, dM = d.map_dim, dD = d.D, dHW = HW, dC = C, dMp = c->Mp;
   for (const Launch& l : p.launches) {
     switch (l.kind) {
@@ -725,6 +802,13 @@ int n2nmn_commit_weights(n2nmn_ctx* c, n2nmn_stream stream) {
     N2_HIP(hipMemsetAsync(c->we_pad[i], 0, sizeof(float) * Mp, s));
     N2_HIP(hipMemcpyAsync(c->we_pad[i], m(wes[i]), sizeof(float) * M, hipMemcpyDeviceToDevice, s));
   }
+  const int txs[5] = {V_FIND_TXT_W, V_FSP_TXT_W, V_TR_TXT_W, V_SP_TXT_W, V_DE_TXT_W};
+  for (int i = 0; i < 5; ++i) {
+    launch_pad_rows(m(txs[i]), E, M, c->wtxt_pad[i], Mp, s);
+    launch_pad_rows(m(txs[i] + 1), 1, M, c->btxt_pad[i], Mp, s);
+  }
+  const int ats[4] = {V_FSP_ATT_W, V_SP_ATT0_W, V_SP_ATT1_W, V_DE_ATT_W};
+  for (int i = 0; i < 4; ++i) launch_pad_rows(m(ats[i]), d.D, M, c->watt_pad[i], Mp, s);
   const int bas[4] = {V_FSP_ATT_B, V_SP_ATT0_B, V_SP_ATT1_B, V_DE_ATT_B};
   for (int i = 0; i < 4; ++i) {
     N2_HIP(hipMemsetAsync(c->batt_pad[i], 0, sizeof(float) * Mp, s));
@@ -834,6 +918,52 @@ int n2nmn_profile_get(const n2nmn_ctx* ctx, int family, const char** name, int64
   if (flops) *flops = ctx->prof_flops[family];
   if (bytes) *bytes = ctx->prof_bytes[family];
   return N2NMN_OK;
+}
+
+/* Times `iters` back-to-back encoder-style LSTM launches (layer-0 step + layer-1 step per launch,
+ * N rows) of a kernel variant with one HIP event pair; returns the average microseconds per
+ * launch in *us.  variant: 0 shipped kernel, 1 loads pinned before MFMAs, 2 loads only,
+ * 3 MFMA only, 4 neither (LDS reduce + epilogue only), 5 empty kernel.  jobs: 2 = L0+L1, 1 = L1. */
+int n2nmn_debug_lstm_bench(n2nmn_ctx* c, int variant, int rows_per_wg, int njobs, int N, int iters,
+                           double* us, n2nmn_stream stream) {
+  const int layout = variant < 10;       // variant >= 10: row-major h (A/B against the packed state)
+  variant %= 10;
+  N2_REQUIRE(c && us && c->committed, N2NMN_EINVAL, "debug_lstm_bench: bad argument");
+  N2_REQUIRE(N >= 1 && N <= c->d.N && iters >= 1, N2NMN_EINVAL, "debug_lstm_bench: bad size");
+  hipStream_t s = S(stream);
+  const int L = c->d.lstm_dim;
+  hipEvent_t e0, e1;
+  N2_HIP(hipEventCreate(&e0));
+  N2_HIP(hipEventCreate(&e1));
+  N2_HIP(hipMemsetAsync(c->eh0[0], 0, sizeof(float) * 6 * (size_t)c->d.N * L, s));
+  for (int rep = 0; rep < 2; ++rep) {
+    if (rep == 1) N2_HIP(hipEventRecord(e0, s));
+    for (int k = 0; k < (rep == 0 ? 5 : iters); ++k) {
+      LstmJob jobs[2];
+      LstmJob& j0 = jobs[njobs == 2 ? 0 : 1];
+      j0 = LstmJob{};
+      if (layout) packed_state(c, j0); else rowmajor_a(c, j0);
+      j0.active = 1; j0.A0 = c->eh0[(k + 1) & 1]; j0.K = L; j0.Wp = c->enc_W0h_t;
+      j0.ntiles = L / 4; j0.xtab = c->enc_xtab; j0.xidx = nullptr; j0.xidx_const = 1;
+      j0.c_in = c->ec0; j0.c_out = c->ec0; j0.h_old = j0.A0; j0.h_new = c->eh0[k & 1];
+      LstmJob& j1 = jobs[njobs == 2 ? 1 : 0];
+      j1 = LstmJob{};
+      if (layout) packed_state(c, j1); else rowmajor_a(c, j1);
+      j1.active = 1; j1.A0 = c->eh0[(k + 1) & 1]; j1.A1 = c->eh1[(k + 1) & 1]; j1.K = 2 * L;
+      j1.Wp = c->enc_W1_t; j1.ntiles = L / 4; j1.bias = c->vars[V_ENC_B1].mirror;
+      j1.c_in = c->ec1; j1.c_out = c->ec1; j1.h_old = j1.A1; j1.h_new = c->eh1[k & 1];
+      j1.out_seq = c->enc_out;
+      launch_lstm_step_dbg(jobs, njobs, N, L, rows_per_wg, variant, s);
+    }
+  }
+  N2_HIP(hipEventRecord(e1, s));
+  N2_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  N2_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *us = 1e3 * ms / iters;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return check_launch("debug_lstm_bench");
 }
 
 int n2nmn_debug_gemm(n2nmn_ctx* ctx, const float* A, const float* B, const float* bias, float* C,

@@ -28,6 +28,8 @@ void launch_gemm_pk(const GemmArgs& a, hipStream_t s);
 // generic packer: dst PK layout <- src[k*ld + n] (k < K, n < N), zero padded
 void launch_pack_pk(const float* src, int ld, int K, int N, float* dst, int Kp, int Np,
                     hipStream_t s);
+// dst[r][0..Mp) = src[r][0..M) zero padded
+void launch_pad_rows(const float* src, int R, int M, float* dst, int Mp, hipStream_t s);
 // column-tile packer: src rows [row0, row0+K) of a [*, ld] matrix -> [tile][K/4][16][4].
 // gate_L > 0: LSTM gate interleave, tile j column c <- source column (c>>2)*gate_L + 4j + (c&3)
 // gate_L == 0: plain, tile j column c <- source column 16j + c
@@ -40,6 +42,10 @@ void launch_pack_tiles(const float* W, int ld, int row0, int K, int ntiles, int 
 struct LstmJob {
   const float* A0;        // [N][L] source of k in [0, L)
   const float* A1;        // [N][L] source of k in [L, 2L) (layer-1 jobs), else nullptr
+  int a_rs, a_ks;         // A addressing in floats: element (row, k) at row*a_rs + (k/4)*a_ks + k%4
+                          //   row-major [rows][L]: a_rs = L, a_ks = 4
+                          //   k-interleaved state layout [L/4][R][4]: a_rs = 4, a_ks = 4*R
+  int hp_R;               // > 0: h_old / h_new use the k-interleaved layout with R rows per k4
   int K;                  // L or 2L
   const float* Wp;        // packed tiles for this job
   int ntiles;             // number of 16-column tiles (LSTM: L/4; linear: Ncols/16)
@@ -58,12 +64,21 @@ struct LstmJob {
   int t;                  // time step compared against seq_len
   int active;             // 0: skip this job entirely (pipeline fill / drain)
 };
-void launch_lstm_step(const LstmJob* jobs, int njobs, int N, int L, hipStream_t s);
+// rows_per_wg: 64 (4 M-tiles per workgroup) or 32 (2 M-tiles; doubles the workgroups of a launch)
+void launch_lstm_step(const LstmJob* jobs, int njobs, int N, int L, int rows_per_wg,
+                      hipStream_t s);
+
+// Arguments of dec_attn_kernel.  Every per-step pointer is the slice of the FIRST step of the
+// launch; workgroup (n, ts) addresses element ts*N + n of it.
+// k-interleaved state [L/4][R][4] -> row-major [N][L]
+void launch_unpack_h(const float* src, float* dst, int N, int L, int R, hipStream_t s);
+void launch_lstm_step_dbg(const LstmJob* jobs, int njobs, int N, int L, int rows_per_wg,
+                          int variant, hipStream_t s);
 
 struct DecStepArgs {
   // inputs
-  const float* q;          // [N][L]   out . W_a + b_a
-  const float* out;        // [N][L]   top-layer h
+  const float* q;          // [steps][N][L]   out . W_a + b_a
+  const float* out;        // [steps][N][L]   top-layer h
   const float* eht;        // [T][N][L]
   const float* eout;       // [T][N][L]
   const int32_t* seq_len;  // [N]
@@ -73,40 +88,41 @@ struct DecStepArgs {
   const int32_t* P;        // [V][3]
   const int32_t* Wv;       // [3][V][4]
   const int32_t* bv;       // [V][4]
-  const int32_t* gt;       // [N] tokens of this step or nullptr
-  const float* uni;        // [N] uniforms of this step or nullptr
-  const int32_t* forced;   // [N] or nullptr
+  const int32_t* gt;       // [steps][N] teacher-forcing tokens or nullptr
+  const float* uni;        // [steps][N] uniforms or nullptr
+  const int32_t* forced;   // [steps][N] or nullptr
   int use_gt;
-  int t, T, N, L, V;
+  int T, N, L, V;
   // state / outputs
-  int32_t* state;          // [N][3]
-  int32_t* tokens;         // [N] slice
-  float* tprobs;           // [N] slice
-  float* neg_entropy;      // [N] accumulated
-  float* atts;             // [T][N] slice of atts[t]
-  float* scores;           // [N][V] slice or nullptr
-  int32_t* next_idx;       // [N] row of the decoder x-table for the next step (= token)
+  int32_t* state;          // [N][3]   (sequential decoding only)
+  int32_t* tokens;         // [steps][N]
+  float* tprobs;           // [steps][N]
+  float* ent_t;            // [steps][N] per-step entropy terms (summed by word_vecs_kernel)
+  float* atts;             // [steps][T][N]
+  float* scores;           // [steps][N][V] or nullptr
+  int32_t* next_idx;       // [N] row of the decoder x-table for the next step (= token) or nullptr
 };
-void launch_dec_step(const DecStepArgs& a, hipStream_t s);
+// nsteps == 1: one sequential step (1024-thread workgroups); nsteps > 1: all steps in one launch
+void launch_dec_attn(const DecStepArgs& a, int nsteps, hipStream_t s);
 
-void launch_dec_init(int32_t* state, float* neg_entropy, int N, int T_dec, hipStream_t s);
+void launch_dec_init(int32_t* state, int N, int T_dec, hipStream_t s);
 
 // word_vecs[t][n][:] = sum_tau atts[t][tau][n] * emb[seq[tau][n]][:];  log_seq_prob
 void launch_word_vecs(const float* atts, const int32_t* seq, const float* emb, int T_dec,
                       int T_enc, int N, int E, float* word_vecs, const float* tprobs,
-                      float* log_seq_prob, hipStream_t s);
+                      const float* ent_t, float* neg_entropy, float* log_seq_prob, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // module network
 // ---------------------------------------------------------------------------------------------
 struct ModuleWeights {     // device pointers into the context's packed weight store
-  // text maps: [ws][E][M] row-major + bias [ws][M]; ws = Find, FSP, Transform, SameProperty, Describe
+  // text maps: zero-padded [E][Mp] + bias [Mp]; ws = Find, FSP, Transform, SameProperty, Describe
   const float* Wtxt[5]; const float* btxt[5];
   // conv_eltwise of Find / FSP / Transform: w [M], b scalar (device)
   const float* we[3]; const float* be[3];
   // Transform conv_maps [k*k][M], bias [M]
   const float* Kt; const float* bt;
-  // fc_att of FSP, SameProperty(0,1), Describe: [D][M] + bias
+  // fc_att of FSP, SameProperty(0,1), Describe: zero-padded [D][Mp] + bias [Mp]
   const float* Watt[4]; const float* batt[4];
   // answer FCs: Exist [3][C], Count [HW+2][C], Equal/More/Less [2HW+4][C], SameProp/Describe [M][C]
   const float* Wans[7]; const float* bans[7];
@@ -124,6 +140,7 @@ struct ModuleBuffers {
   const float* word_vecs; // [T_dec][N_full][E]
   float* scores;          // [rows][C]
   int N_full, H, W, D, M, Mp, E, C, HWp, ksize;
+  int wl_cap;             // floats of LDS the answer heads may use to stage fc weights
 };
 
 void launch_textmap(const ModuleWeights& w, const ModuleBuffers& b, int tab_off, int count,

@@ -41,75 +41,89 @@ __global__ __launch_bounds__(256) void gemm_pk_kernel(GemmArgs a) {
 
   // ---- global load assignment: 2 float4 of A and 2 of B per thread -----------------------
   // A: float4 index i = tid + 256 j -> row = i >> 3, k4 = i & 7 (8 lanes cover 128 contiguous B)
-  const float* a_ptr[2];
-  bool a_ok[2];
-  int a_row[2], a_k4[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int i = tid + 256 * j;
-    a_row[j] = i >> 3; a_k4[j] = i & 7;
-    const int r = m0 + a_row[j];
-    a_ok[j] = r < a.M;
+  // B: float4 index i -> k4 = i >> 6, n = i & 63 (one contiguous KiB per k4)
+  const int a_row0 = tid >> 3, a_row1 = (tid + 256) >> 3;
+  const int a_k40 = tid & 7, a_k41 = a_k40;
+  auto src_row = [&](int r) {
     int src = r < a.M ? r : 0;
     if (a.group_idx) {
       const int g = src / a.group_size;
       src = a.group_idx[g] * a.group_size + (src - g * a.group_size);
     }
-    a_ptr[j] = a.A + (size_t)src * a.lda + 4 * a_k4[j];
-  }
-  // B: float4 index i -> k4 = i >> 6, n = i & 63 (one contiguous KiB per k4)
-  const float4* b_ptr[2];
-  int b_k4[2], b_n[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int i = tid + 256 * j;
-    b_k4[j] = i >> 6; b_n[j] = i & 63;
-    b_ptr[j] = reinterpret_cast<const float4*>(a.Bp) + (size_t)b_k4[j] * a.Np + n0 + b_n[j];
-  }
+    return src;
+  };
+  const bool a_ok0 = m0 + a_row0 < a.M, a_ok1 = m0 + a_row1 < a.M;
+  const float* a_ptr0 = a.A + (size_t)src_row(m0 + a_row0) * a.lda;
+  const float* a_ptr1 = a.A + (size_t)src_row(m0 + a_row1) * a.lda;
+  const int b_k40 = tid >> 6, b_k41 = (tid + 256) >> 6, b_n0 = tid & 63, b_n1 = b_n0;
+  const float4* b_ptr0 = reinterpret_cast<const float4*>(a.Bp) + (size_t)b_k40 * a.Np + n0 + b_n0;
+  const float4* b_ptr1 = reinterpret_cast<const float4*>(a.Bp) + (size_t)b_k41 * a.Np + n0 + b_n1;
 
   const int nkt = a.Kp / BK;
-  float4 ra[2], rb[2];
-  auto gload = [&](int kt) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int k = kt * BK + 4 * a_k4[j];
-      if (a_ok[j] && k < a.K) ra[j] = *reinterpret_cast<const float4*>(a_ptr[j] + kt * BK);
-      else ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      rb[j] = b_ptr[j][(size_t)kt * (BK / 4) * a.Np];
-    }
-  };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      As[buf][a_k4[j]][a_row[j]] = ra[j];
-      Bs[buf][b_k4[j]][b_n[j]] = rb[j];
-    }
-  };
+  const size_t bstep = (size_t)(BK / 4) * a.Np;     // float4 stride of one k-tile in packed B
+  // register-staged pipeline, two k-tiles deep: tile kt+2 is being fetched while tile kt+1 sits
+  // in registers and tile kt is consumed from LDS (a global round trip spans two MFMA phases)
+  float4 ra0, ra1, rb0, rb1;     // staging set X
+  float4 sa0, sa1, sb0, sb1;     // staging set Y
+// loads are unconditional from a clamped (always valid) address and masked afterwards: a
+// conditional load would be lowered to a flat load through a select with a scratch zero
+#define N2_GLOAD(KT, A0, A1, B0, B1)                                                        \
+  do {                                                                                      \
+    const int kk0 = (KT) * BK + 4 * a_k40, kk1 = (KT) * BK + 4 * a_k41;                     \
+    const float4 t0 = *reinterpret_cast<const float4*>(a_ptr0 + (kk0 < a.K ? kk0 : a.K - 4)); \
+    const float4 t1 = *reinterpret_cast<const float4*>(a_ptr1 + (kk1 < a.K ? kk1 : a.K - 4)); \
+    const bool k0 = a_ok0 && kk0 < a.K, k1 = a_ok1 && kk1 < a.K;                            \
+    A0.x = k0 ? t0.x : 0.f; A0.y = k0 ? t0.y : 0.f; A0.z = k0 ? t0.z : 0.f; A0.w = k0 ? t0.w : 0.f; \
+    A1.x = k1 ? t1.x : 0.f; A1.y = k1 ? t1.y : 0.f; A1.z = k1 ? t1.z : 0.f; A1.w = k1 ? t1.w : 0.f; \
+    B0 = b_ptr0[(size_t)(KT) * bstep];                                                      \
+    B1 = b_ptr1[(size_t)(KT) * bstep];                                                      \
+  } while (0)
+#define N2_LSTORE(BUF, A0, A1, B0, B1)                                                      \
+  do {                                                                                      \
+    As[BUF][a_k40][a_row0] = A0; As[BUF][a_k41][a_row1] = A1;                       \
+    Bs[BUF][b_k40][b_n0] = B0; Bs[BUF][b_k41][b_n1] = B1;                           \
+  } while (0)
 
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-
-  gload(0);
-  lstore(0);
-  __syncthreads();
   const int li = lane & 31, kh = lane >> 5;
-  int cur = 0;
-  for (int kt = 0; kt < nkt; ++kt) {
-    if (kt + 1 < nkt) gload(kt + 1);
+
+  N2_GLOAD(0, ra0, ra1, rb0, rb1);
+  if (nkt > 1) N2_GLOAD(1, sa0, sa1, sb0, sb1);
+  N2_LSTORE(0, ra0, ra1, rb0, rb1);
+  __syncthreads();
+  // invariant at the top of iteration kt (cur = kt & 1): LDS[cur] holds tile kt; set Y holds
+  // tile kt+1 (if any); set X is free
+  for (int kt = 0; kt < nkt; kt += 2) {
+    if (kt + 2 < nkt) N2_GLOAD(kt + 2, ra0, ra1, rb0, rb1);
 #pragma unroll
     for (int kq = 0; kq < BK / 8; ++kq) {
-      const float4 av = As[cur][2 * kq + kh][wm * 32 + li];
-      const float4 bv = Bs[cur][2 * kq + kh][wn * 32 + li];
+      const float4 av = As[0][2 * kq + kh][wm * 32 + li];
+      const float4 bv = Bs[0][2 * kq + kh][wn * 32 + li];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
     }
-    if (kt + 1 < nkt) lstore(cur ^ 1);
+    if (kt + 1 < nkt) N2_LSTORE(1, sa0, sa1, sb0, sb1);
     __syncthreads();
-    cur ^= 1;
+    if (kt + 1 >= nkt) break;
+    if (kt + 3 < nkt) N2_GLOAD(kt + 3, sa0, sa1, sb0, sb1);
+#pragma unroll
+    for (int kq = 0; kq < BK / 8; ++kq) {
+      const float4 av = As[1][2 * kq + kh][wm * 32 + li];
+      const float4 bv = Bs[1][2 * kq + kh][wn * 32 + li];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+    }
+    if (kt + 2 < nkt) N2_LSTORE(0, ra0, ra1, rb0, rb1);
+    __syncthreads();
   }
+#undef N2_GLOAD
+#undef N2_LSTORE
 
   // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int col = n0 + wn * 32 + li;
@@ -154,7 +168,23 @@ __global__ void pack_tiles_kernel(const float* __restrict__ W, int ld, int row0,
     dst[i] = W[(size_t)(row0 + k) * ld + col];
   }
 }
+__global__ void pad_rows_kernel(const float* __restrict__ src, int R, int M,
+                                float* __restrict__ dst, int Mp) {
+  const size_t total = (size_t)R * Mp;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Mp);
+    const size_t r = i / Mp;
+    dst[i] = c < M ? src[r * M + c] : 0.f;
+  }
+}
 }  // namespace
+
+void launch_pad_rows(const float* src, int R, int M, float* dst, int Mp, hipStream_t s) {
+  const size_t total = (size_t)R * Mp;
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
+  hipLaunchKernelGGL(pad_rows_kernel, dim3(blocks), dim3(256), 0, s, src, R, M, dst, Mp);
+}
 
 void launch_gemm_pk(const GemmArgs& a, hipStream_t s) {
   dim3 grid((a.n_store + BN - 1) / BN, (a.M + BM - 1) / BM);

@@ -13,6 +13,8 @@
 // attention maps live in an arena [node][HWp] in HBM/L2; text maps [tslot][Mp] and conv_image
 // maps [image slot][HW][Mp] are zero padded to Mp = round_up(map_dim, 64) so float4 lanes need no
 // tail handling.
+#include <algorithm>
+
 #include "device_utils.h"
 #include "kernels.h"
 
@@ -31,11 +33,18 @@ __device__ void fc_small(const float* x, int F, const float* __restrict__ Wm,
   if (C <= MT) {
     const int nsl = MT / C;
     const int j = tid % C, sl = tid / C;
-    float s = 0.f;
-    if (sl < nsl)
-      for (int f = sl; f < F; f += nsl) s += x[f] * Wm[(size_t)f * C + j];
+    float s0 = 0.f, s1 = 0.f;
+    if (sl < nsl) {
+      int f = sl;
+#pragma unroll 4
+      for (; f + nsl < F; f += 2 * nsl) {         // two independent chains, loads unrolled
+        s0 += x[f] * Wm[(size_t)f * C + j];
+        s1 += x[f + nsl] * Wm[(size_t)(f + nsl) * C + j];
+      }
+      if (f < F) s0 += x[f] * Wm[(size_t)f * C + j];
+    }
     __syncthreads();
-    if (sl < nsl) partial[sl * C + j] = s;
+    if (sl < nsl) partial[sl * C + j] = s0 + s1;
     __syncthreads();
     if (tid < C) {
       float r = b[tid];
@@ -45,9 +54,49 @@ __device__ void fc_small(const float* x, int F, const float* __restrict__ Wm,
   } else {
     for (int j = tid; j < C; j += MT) {
       float s = b[j];
+#pragma unroll 8
       for (int f = 0; f < F; ++f) s += x[f] * Wm[(size_t)f * C + j];
       out[j] = s;
     }
+  }
+}
+
+// Same contraction with the [F][C] weight matrix first staged into LDS by the whole workgroup
+// (independent 16-B loads: one or two memory round trips instead of F/nsl dependent ones).
+// wl needs F*C floats.  Falls back to fc_small when the matrix does not fit `wl_cap` floats.
+__device__ void fc_lds(const float* x, int F, const float* __restrict__ Wm,
+                       const float* __restrict__ b, int C, float* __restrict__ out,
+                       float* partial, float* wl, int wl_cap) {
+  const int tid = threadIdx.x;
+  const int tot = F * C;
+  if (tot > wl_cap || C > MT) {
+    fc_small(x, F, Wm, b, C, out, partial);
+    return;
+  }
+  const int n4 = tot >> 2;
+  const float4* W4 = reinterpret_cast<const float4*>(Wm);
+  float4* wl4 = reinterpret_cast<float4*>(wl);
+#pragma unroll 4
+  for (int i = tid; i < n4; i += MT) wl4[i] = W4[i];
+  for (int i = 4 * n4 + tid; i < tot; i += MT) wl[i] = Wm[i];
+  __syncthreads();
+  const int nsl = MT / C;
+  const int j = tid % C, sl = tid / C;
+  float s0 = 0.f, s1 = 0.f;
+  if (sl < nsl) {
+    int f = sl;
+    for (; f + nsl < F; f += 2 * nsl) {
+      s0 += x[f] * wl[f * C + j];
+      s1 += x[f + nsl] * wl[(f + nsl) * C + j];
+    }
+    if (f < F) s0 += x[f] * wl[f * C + j];
+    partial[sl * C + j] = s0 + s1;
+  }
+  __syncthreads();
+  if (tid < C) {
+    float r = b[tid];
+    for (int q = 0; q < nsl; ++q) r += partial[q * C + tid];
+    out[tid] = r;
   }
 }
 
@@ -61,9 +110,11 @@ __global__ __launch_bounds__(MT) void textmap_kernel(ModuleWeights w, ModuleBuff
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int* tab = b.tab + tab_off + blockIdx.x * (2 + TM_GROUP);
   const int ws = tab[0], cnt = tab[1];
-  const int E = b.E, M = b.M, Mp = b.Mp;
-  float* wv = smem;   // [TM_GROUP][E]
-  for (int i = threadIdx.x; i < TM_GROUP * E; i += MT) {
+  const int E = b.E, Mp = b.Mp;
+  float* wv = smem;                       // [TM_GROUP][E]
+  float* part = wv + TM_GROUP * E;        // [4 waves][TM_GROUP][256]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  for (int i = tid; i < TM_GROUP * E; i += MT) {
     const int g = i / E, e = i - g * E;
     float v = 0.f;
     if (g < cnt) {
@@ -73,26 +124,40 @@ __global__ __launch_bounds__(MT) void textmap_kernel(ModuleWeights w, ModuleBuff
     wv[i] = v;
   }
   __syncthreads();
-  const float* Wm = w.Wtxt[ws];
+  // K-split over the 4 waves, float4 columns over the lanes: every lane streams its slice of
+  // the padded [E][Mp] weight matrix with independent 16-B loads.
+  const float4* Wp4 = reinterpret_cast<const float4*>(w.Wtxt[ws]);
   const float* bm = w.btxt[ws];
-  for (int c = threadIdx.x; c < Mp; c += MT) {
-    float acc[TM_GROUP];
+  const int eper = (E + 3) / 4;
+  const int e0 = wid * eper, e1 = min(E, e0 + eper);
+  for (int cb = 0; cb < Mp; cb += 256) {
+    float4 acc[TM_GROUP];
 #pragma unroll
-    for (int g = 0; g < TM_GROUP; ++g) acc[g] = 0.f;
-    if (c < M) {
-#pragma unroll 4
-      for (int e = 0; e < E; ++e) {
-        const float wt = Wm[(size_t)e * M + c];
+    for (int g = 0; g < TM_GROUP; ++g) acc[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* wp = Wp4 + (cb >> 2) + lane;
+#pragma unroll 5
+    for (int e = e0; e < e1; ++e) {
+      const float4 w4 = wp[(size_t)e * (Mp >> 2)];
 #pragma unroll
-        for (int g = 0; g < TM_GROUP; ++g) acc[g] += wv[g * E + e] * wt;
+      for (int g = 0; g < TM_GROUP; ++g) {
+        const float x = wv[g * E + e];
+        acc[g].x += x * w4.x; acc[g].y += x * w4.y; acc[g].z += x * w4.z; acc[g].w += x * w4.w;
       }
-      const float bb = bm[c];
-#pragma unroll
-      for (int g = 0; g < TM_GROUP; ++g) acc[g] += bb;
     }
+    __syncthreads();
 #pragma unroll
     for (int g = 0; g < TM_GROUP; ++g)
-      if (g < cnt) b.tmap[(size_t)b.nodes[tab[2 + g]].tslot * Mp + c] = acc[g];
+      *reinterpret_cast<float4*>(part + ((size_t)(wid * TM_GROUP + g) * 256) + 4 * lane) = acc[g];
+    __syncthreads();
+    for (int i = tid; i < TM_GROUP * 256; i += MT) {
+      const int g = i >> 8, c = i & 255;
+      if (g < cnt && cb + c < Mp) {
+        float r = bm[cb + c];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r += part[(size_t)(q * TM_GROUP + g) * 256 + c];
+        b.tmap[(size_t)b.nodes[tab[2 + g]].tslot * Mp + cb + c] = r;
+      }
+    }
   }
 }
 
@@ -104,6 +169,7 @@ __global__ __launch_bounds__(MT) void textmap_kernel(ModuleWeights w, ModuleBuff
 // ---------------------------------------------------------------------------------------------
 __device__ void find_epilogue(const ModuleWeights& w, const ModuleBuffers& b, const DevNode& nd,
                               int node_id, int part, int nparts) {
+  constexpr int MAXCI = 4;                 // Mp <= 1024
   const int HW = b.H * b.W, Mp = b.Mp;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const bool fsp = nd.op == N2NMN_OP_FIND_SAME_PROPERTY;
@@ -116,10 +182,14 @@ __device__ void find_epilogue(const ModuleWeights& w, const ModuleBuffers& b, co
   const float* in0 = (nd.op == N2NMN_OP_FILTER) ? b.arena + (size_t)nd.in0 * b.HWp : nullptr;
   float* outp = b.arena + (size_t)node_id * b.HWp;
 
-  for (int r = r0 + wid; r < r1; r += MT / 64) {
-    float ss = 0.f, dot = 0.f;
-    for (int c = 4 * lane; c < Mp; c += 256) {
-      float4 t4 = *reinterpret_cast<const float4*>(tm + c);
+  // row-invariant per-lane vectors: text map (times fc_att(att_feat) for FindSameProperty) and w_e
+  float4 t4[MAXCI], e4[MAXCI];
+#pragma unroll
+  for (int i = 0; i < MAXCI; ++i) {
+    const int c = 4 * lane + 256 * i;
+    if (c < Mp) {
+      t4[i] = *reinterpret_cast<const float4*>(tm + c);
+      e4[i] = *reinterpret_cast<const float4*>(w.we[wsel] + c);   // padded to Mp
       if (fsp) {   // amap = fc_att(att_feat): bias + the POOL_PARTS partial sums of stage B
         float4 a4 = *reinterpret_cast<const float4*>(w.batt[0] + c);   // padded to Mp
         const float* pf = b.pfc + (size_t)nd.pslot * 2 * POOL_PARTS * Mp + c;
@@ -128,85 +198,120 @@ __device__ void find_epilogue(const ModuleWeights& w, const ModuleBuffers& b, co
           const float4 q = *reinterpret_cast<const float4*>(pf + p * Mp);
           a4.x += q.x; a4.y += q.y; a4.z += q.z; a4.w += q.w;
         }
-        t4.x *= a4.x; t4.y *= a4.y; t4.z *= a4.z; t4.w *= a4.w;
+        t4[i].x *= a4.x; t4[i].y *= a4.y; t4[i].z *= a4.z; t4[i].w *= a4.w;
       }
-      const float4 m4 = *reinterpret_cast<const float4*>(Mbuf + (size_t)r * Mp + c);
-      const float4 e4 = *reinterpret_cast<const float4*>(w.we[wsel] + c);   // padded to Mp
-      const float p0 = m4.x * t4.x, p1 = m4.y * t4.y, p2 = m4.z * t4.z, p3 = m4.w * t4.w;
-      ss += p0 * p0 + p1 * p1 + p2 * p2 + p3 * p3;
-      dot += p0 * e4.x + p1 * e4.y + p2 * e4.z + p3 * e4.w;
     }
-    ss = wave_sum(ss);
-    dot = wave_sum(dot);
-    if (lane == 0) {
-      float att = dot / sqrtf(fmaxf(ss, 1e-12f)) + be;   // tf.nn.l2_normalize eps (A.4)
-      if (in0) att = fminf(in0[r], att);                 // Filter = And(input_0, Find)
-      outp[r] = att;
+  }
+  constexpr int UNR = 5;
+  for (int rb = r0 + wid; rb < r1; rb += UNR * (MT / 64)) {
+    float ss[UNR], dot[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int r = rb + u * (MT / 64);
+      ss[u] = 0.f; dot[u] = 0.f;
+      if (r < r1) {
+#pragma unroll
+        for (int i = 0; i < MAXCI; ++i) {
+          const int c = 4 * lane + 256 * i;
+          if (c < Mp) {
+            const float4 m4 = *reinterpret_cast<const float4*>(Mbuf + (size_t)r * Mp + c);
+            const float p0 = m4.x * t4[i].x, p1 = m4.y * t4[i].y, p2 = m4.z * t4[i].z,
+                        p3 = m4.w * t4[i].w;
+            ss[u] += p0 * p0 + p1 * p1 + p2 * p2 + p3 * p3;
+            dot[u] += p0 * e4[i].x + p1 * e4[i].y + p2 * e4[i].z + p3 * e4[i].w;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int r = rb + u * (MT / 64);
+      const float s2 = wave_sum(ss[u]);
+      const float d2 = wave_sum(dot[u]);
+      if (lane == 0 && r < r1) {
+        float att = d2 / sqrtf(fmaxf(s2, 1e-12f)) + be;    // tf.nn.l2_normalize eps (A.4)
+        if (in0) att = fminf(in0[r], att);                 // Filter = And(input_0, Find)
+        outp[r] = att;
+      }
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Transform (nmn3_modules.py:185-216): conv KSxKS SAME of the 1-channel attention map to M
-// channels, times the text map, l2-normalise over channels, dot with w_e.  The text map is folded
-// into the filter taps (K'[tap,c] = K[tap,c]*t[c]) which each lane keeps in registers for its 4
-// channels; the zero-padded input map sits in LDS; one wave per output pixel.
+// channels, times the text map, l2-normalise over channels, dot with w_e.
+// Lanes = output pixels (each lane keeps its KSxKS input window in registers), waves = channel
+// quarters; the filter taps, pre-multiplied by the text map (K'[c][tap] = K[tap][c]*t[c], with
+// b'[c] and w_e[c] appended), sit in LDS and are read with wave-uniform (broadcast) 16-B reads.
+// The channel reduction is lane-local, so there is no cross-lane traffic in the hot loop.
 // ---------------------------------------------------------------------------------------------
 template <int KS>
 __device__ void transform_op(const ModuleWeights& w, const ModuleBuffers& b, const DevNode& nd,
                              int node_id, int part, int nparts, float* smem) {
-  const int H = b.H, W = b.W, HW = H * W, M = b.M, Mp = b.Mp;
+  constexpr int KK = KS * KS;
+  constexpr int RS = (KK + 2 + 3) & ~3;      // row stride of the tap table (floats, 16-B multiple)
   constexpr int PAD = KS / 2;
+  const int H = b.H, W = b.W, HW = H * W, M = b.M, Mp = b.Mp;
   const int PW = W + 2 * PAD, PH = H + 2 * PAD;
-  float* xin = smem;                 // [PH][PW]
-  float* sss = xin + PH * PW;        // [HW] sum of squares
-  float* sdot = sss + HW;            // [HW]
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float* Kl = smem;                            // [M][RS]
+  float* xin = Kl + (size_t)M * RS;            // [PH][PW]
+  float* red = xin + ((PH * PW + 3) & ~3);     // [4 waves][64][2]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const float* in0 = b.arena + (size_t)nd.in0 * b.HWp;
-  for (int i = threadIdx.x; i < PH * PW; i += MT) {
+  const float* tm = b.tmap + (size_t)nd.tslot * Mp;
+  for (int i = tid; i < PH * PW; i += MT) {
     const int y = i / PW - PAD, x = i % PW - PAD;
     xin[i] = (y >= 0 && y < H && x >= 0 && x < W) ? in0[y * W + x] : 0.f;
   }
-  const int ppp = (HW + nparts - 1) / nparts;
-  const int p0 = part * ppp, p1 = min(HW, p0 + ppp);
-  for (int i = p0 + threadIdx.x; i < p1; i += MT) { sss[i] = 0.f; sdot[i] = 0.f; }
-  __syncthreads();
-  const float* tm = b.tmap + (size_t)nd.tslot * Mp;
-  for (int cbase = 0; cbase < Mp; cbase += 256) {
-    float kreg[KS * KS][4], breg[4], ereg[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c = cbase + lane + 64 * q;
-      const bool ok = c < M;
-      const float t = ok ? tm[c] : 0.f;
-      breg[q] = ok ? w.bt[c] * t : 0.f;
-      ereg[q] = ok ? w.we[2][c] : 0.f;
-#pragma unroll
-      for (int tap = 0; tap < KS * KS; ++tap) kreg[tap][q] = ok ? w.Kt[tap * M + c] * t : 0.f;
-    }
-    for (int p = p0 + wid; p < p1; p += MT / 64) {
-      const int y = p / W, x = p - y * W;
-      float v[4] = {breg[0], breg[1], breg[2], breg[3]};
-#pragma unroll
-      for (int dy = 0; dy < KS; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < KS; ++dx) {
-          const float xv = xin[(y + dy) * PW + x + dx];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] += kreg[dy * KS + dx][q] * xv;
-        }
-      float ss = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-      float dot = v[0] * ereg[0] + v[1] * ereg[1] + v[2] * ereg[2] + v[3] * ereg[3];
-      ss = wave_sum(ss);
-      dot = wave_sum(dot);
-      if (lane == 0) { sss[p] += ss; sdot[p] += dot; }   // same wave owns p in every chunk
-    }
+#pragma unroll 4
+  for (int i = tid; i < KK * M; i += MT) {     // coalesced over c, independent loads
+    const int tap = i / M, c = i - tap * M;
+    Kl[c * RS + tap] = w.Kt[i] * tm[c];
+  }
+  for (int c = tid; c < M; c += MT) {
+    Kl[c * RS + KK] = w.bt[c] * tm[c];
+    Kl[c * RS + KK + 1] = w.we[2][c];
   }
   __syncthreads();
   const float be = w.be[2][0];
   float* outp = b.arena + (size_t)node_id * b.HWp;
-  for (int p = p0 + threadIdx.x; p < p1; p += MT)
-    outp[p] = sdot[p] / sqrtf(fmaxf(sss[p], 1e-12f)) + be;
+  const int ppp = (HW + nparts - 1) / nparts;
+  const int p0 = part * ppp, p1 = min(HW, p0 + ppp);
+  for (int pb = p0; pb < p1; pb += 64) {
+    const int p = pb + lane;
+    const bool on = p < p1;
+    const int y = on ? p / W : 0, x = on ? p - (p / W) * W : 0;
+    float win[KK];
+#pragma unroll
+    for (int dy = 0; dy < KS; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < KS; ++dx) win[dy * KS + dx] = xin[(y + dy) * PW + x + dx];
+    float ss = 0.f, dot = 0.f;
+    for (int c = wid; c < M; c += MT / 64) {
+      const float4* kr = reinterpret_cast<const float4*>(Kl + (size_t)c * RS);
+      float k[RS];
+#pragma unroll
+      for (int q = 0; q < RS / 4; ++q) {
+        const float4 t = kr[q];
+        k[4 * q] = t.x; k[4 * q + 1] = t.y; k[4 * q + 2] = t.z; k[4 * q + 3] = t.w;
+      }
+      float v = k[KK];
+#pragma unroll
+      for (int tap = 0; tap < KK; ++tap) v += k[tap] * win[tap];
+      ss += v * v;
+      dot += v * k[KK + 1];
+    }
+    __syncthreads();
+    red[(wid * 64 + lane) * 2] = ss;
+    red[(wid * 64 + lane) * 2 + 1] = dot;
+    __syncthreads();
+    if (wid == 0 && on) {
+      float s2 = 0.f, d2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < MT / 64; ++q) { s2 += red[(q * 64 + lane) * 2]; d2 += red[(q * 64 + lane) * 2 + 1]; }
+      outp[p] = d2 / sqrtf(fmaxf(s2, 1e-12f)) + be;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -217,8 +322,9 @@ __device__ void light_answer(const ModuleWeights& w, const ModuleBuffers& b, con
                              float* smem) {
   const int HW = b.H * b.W, C = b.C;
   float* x = smem;                    // up to 2*HW + 4 features
-  float* scratch = x + 2 * HW + 4;    // 16 floats for block reductions
+  float* scratch = x + ((2 * HW + 4 + 3) & ~3);    // 16 floats for block reductions
   float* partial = scratch + 16;      // 256 floats
+  float* wl = partial + 256;          // staged fc weights
   const int nin = (nd.op == N2NMN_OP_EXIST || nd.op == N2NMN_OP_COUNT) ? 1 : 2;
   const int tid = threadIdx.x;
   float mn[2], mx[2], sm[2];
@@ -251,7 +357,8 @@ __device__ void light_answer(const ModuleWeights& w, const ModuleBuffers& b, con
     wi = nd.op == N2NMN_OP_EQUAL_NUM ? 2 : (nd.op == N2NMN_OP_MORE_NUM ? 3 : 4);
   }
   __syncthreads();
-  fc_small(x, F, w.Wans[wi], w.bans[wi], C, b.scores + (size_t)nd.out_row * C, partial);
+  fc_lds(x, F, w.Wans[wi], w.bans[wi], C, b.scores + (size_t)nd.out_row * C, partial, wl,
+         (2 * HW + 4) * C);
 }
 
 __global__ __launch_bounds__(MT) void att_ops_kernel(ModuleWeights w, ModuleBuffers b,
@@ -302,7 +409,7 @@ __global__ __launch_bounds__(MT) void pool_kernel(ModuleWeights w, ModuleBuffers
   const int* e = b.tab + tab_off + blockIdx.x * 2;
   const int node_id = e[0], part = e[1];
   const DevNode nd = b.nodes[node_id];
-  const int HW = b.H * b.W, D = b.D, M = b.M, Mp = b.Mp;
+  const int HW = b.H * b.W, D = b.D, Mp = b.Mp;
   const int Dp = D / POOL_PARTS, c0 = part * Dp;
   const int tid = threadIdx.x;
   const int nin = nd.op == N2NMN_OP_SAME_PROPERTY ? 2 : 1;
@@ -311,6 +418,25 @@ __global__ __launch_bounds__(MT) void pool_kernel(ModuleWeights w, ModuleBuffers
   float* scratch = a1 + ((HW + 3) & ~3);   // [16]
   float* pooled = scratch + 16;        // [2][Dp]
   float* stage = pooled + 2 * Dp;      // [rows in flight][2][Dp]
+
+  const int ncol = Dp / 4;             // float4 columns of this part
+  const int nrow = MT / ncol;          // rows in flight
+  const int lc = tid % ncol, lr = tid / ncol;
+  // The feature rows of this thread do not depend on the softmax: issue all of their 16-B loads
+  // first so the HBM round trip overlaps the softmax prologue (register path for <= PR rows).
+  constexpr int PR = 20;
+  const int myrows = lr < nrow ? (HW - lr + nrow - 1) / nrow : 0;
+  const bool regpath = (HW + nrow - 1) / nrow <= PR;
+  const float* fp = b.feat + (size_t)nd.n * HW * D + c0 + 4 * lc;
+  float4 fr[PR];
+  if (regpath) {
+#pragma unroll
+    for (int q = 0; q < PR; ++q) {
+      const int r = lr + q * nrow;
+      fr[q] = *reinterpret_cast<const float4*>(fp + (size_t)(q < myrows ? r : lr) * D);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
 
   for (int i = 0; i < nin; ++i) {      // softmax over the H*W logits (:170-172,432-437,482-484)
     const float* src = b.arena + (size_t)(i == 0 ? nd.in0 : nd.in1) * b.HWp;
@@ -329,24 +455,23 @@ __global__ __launch_bounds__(MT) void pool_kernel(ModuleWeights w, ModuleBuffers
   }
   __syncthreads();
 
-  const int ncol = Dp / 4;             // float4 columns of this part
-  const int nrow = MT / ncol;          // rows in flight
-  const int lc = tid % ncol, lr = tid / ncol;
   float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
   if (lr < nrow) {
-    const float* fp = b.feat + (size_t)nd.n * HW * D + c0 + 4 * lc;
-    if (nin == 1) {
-#pragma unroll 4
-      for (int r = lr; r < HW; r += nrow) {
-        const float4 f4 = *reinterpret_cast<const float4*>(fp + (size_t)r * D);
-        const float w0 = a0[r];
-        acc0.x += w0 * f4.x; acc0.y += w0 * f4.y; acc0.z += w0 * f4.z; acc0.w += w0 * f4.w;
+    if (regpath) {
+#pragma unroll
+      for (int q = 0; q < PR; ++q) {
+        if (q < myrows) {
+          const int r = lr + q * nrow;
+          const float w0 = a0[r], w1 = nin == 2 ? a1[r] : 0.f;
+          acc0.x += w0 * fr[q].x; acc0.y += w0 * fr[q].y; acc0.z += w0 * fr[q].z; acc0.w += w0 * fr[q].w;
+          acc1.x += w1 * fr[q].x; acc1.y += w1 * fr[q].y; acc1.z += w1 * fr[q].z; acc1.w += w1 * fr[q].w;
+        }
       }
     } else {
-#pragma unroll 4
+#pragma unroll 8
       for (int r = lr; r < HW; r += nrow) {
         const float4 f4 = *reinterpret_cast<const float4*>(fp + (size_t)r * D);
-        const float w0 = a0[r], w1 = a1[r];
+        const float w0 = a0[r], w1 = nin == 2 ? a1[r] : 0.f;
         acc0.x += w0 * f4.x; acc0.y += w0 * f4.y; acc0.z += w0 * f4.z; acc0.w += w0 * f4.w;
         acc1.x += w1 * f4.x; acc1.y += w1 * f4.y; acc1.z += w1 * f4.z; acc1.w += w1 * f4.w;
       }
@@ -362,22 +487,34 @@ __global__ __launch_bounds__(MT) void pool_kernel(ModuleWeights w, ModuleBuffers
   }
   __syncthreads();
 
-  // partial fc_att over this part's channels
+  // partial fc_att over this part's channels: K-split over the 4 waves, float4 columns over
+  // the lanes of the padded [D][Mp] weight matrix
+  float* fpart = stage;                // [4 waves][256] (stage is free again)
+  const int lane = tid & 63, wid = tid >> 6;
+  const int kper = (Dp + 3) / 4;
+  const int k0 = wid * kper, k1 = min(Dp, k0 + kper);
   for (int i = 0; i < nin; ++i) {
     int wi;
     if (nd.op == N2NMN_OP_FIND_SAME_PROPERTY) wi = 0;
     else if (nd.op == N2NMN_OP_SAME_PROPERTY) wi = 1 + i;
     else wi = 3;
-    const float* Wm = w.Watt[wi] + (size_t)c0 * M;
+    const float4* Wp4 = reinterpret_cast<const float4*>(w.Watt[wi] + (size_t)c0 * Mp);
     const float* pv = pooled + i * Dp;
     float* dst = b.pfc + (((size_t)nd.pslot * 2 + i) * POOL_PARTS + part) * Mp;
-    for (int c = tid; c < Mp; c += MT) {
-      float s = 0.f;
-      if (c < M) {
-#pragma unroll 8
-        for (int k = 0; k < Dp; ++k) s += pv[k] * Wm[(size_t)k * M + c];
+    for (int cb = 0; cb < Mp; cb += 256) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4* wp = Wp4 + (cb >> 2) + lane;
+#pragma unroll 16
+      for (int k = k0; k < k1; ++k) {
+        const float4 w4 = wp[(size_t)k * (Mp >> 2)];
+        const float x = pv[k];
+        acc.x += x * w4.x; acc.y += x * w4.y; acc.z += x * w4.z; acc.w += x * w4.w;
       }
-      dst[c] = s;
+      __syncthreads();
+      *reinterpret_cast<float4*>(fpart + wid * 256 + 4 * lane) = acc;
+      __syncthreads();
+      if (cb + tid < Mp)
+        dst[cb + tid] = fpart[tid] + fpart[256 + tid] + fpart[512 + tid] + fpart[768 + tid];
     }
   }
 }
@@ -395,6 +532,7 @@ __global__ __launch_bounds__(MT) void heads_kernel(ModuleWeights w, ModuleBuffer
   float* ev = smem;                 // [Mp]
   float* scratch = ev + Mp;         // [16]
   float* partial = scratch + 16;    // [256]
+  float* wl = partial + 256;        // staged fc_eltwise weights
   const bool same = nd.op == N2NMN_OP_SAME_PROPERTY;
   const float* tm = b.tmap + (size_t)nd.tslot * Mp;
   const float* pf = b.pfc + (size_t)nd.pslot * 2 * POOL_PARTS * Mp;
@@ -419,14 +557,15 @@ __global__ __launch_bounds__(MT) void heads_kernel(ModuleWeights w, ModuleBuffer
   for (int c = threadIdx.x; c < Mp; c += MT) ev[c] *= inv;
   __syncthreads();
   const int wi = same ? 5 : 6;
-  fc_small(ev, M, w.Wans[wi], w.bans[wi], C, b.scores + (size_t)nd.out_row * C, partial);
+  fc_lds(ev, M, w.Wans[wi], w.bans[wi], C, b.scores + (size_t)nd.out_row * C, partial, wl,
+         b.wl_cap);
 }
 
 }  // namespace
 
 void launch_textmap(const ModuleWeights& w, const ModuleBuffers& b, int tab_off, int count,
                     hipStream_t s) {
-  const size_t smem = sizeof(float) * TM_GROUP * b.E;
+  const size_t smem = sizeof(float) * ((size_t)TM_GROUP * b.E + 4 * TM_GROUP * 256);
   hipLaunchKernelGGL(textmap_kernel, dim3(count), dim3(MT), smem, s, w, b, tab_off);
 }
 
@@ -434,8 +573,11 @@ void launch_att_ops(const ModuleWeights& w, const ModuleBuffers& b, int tab_off,
                     hipStream_t s) {
   const int HW = b.H * b.W;
   const int pad = b.ksize / 2;
-  const size_t tr = (size_t)(b.H + 2 * pad) * (b.W + 2 * pad) + 2 * HW;
-  const size_t la = (size_t)2 * HW + 4 + 16 + 256;
+  const int KK = b.ksize * b.ksize;
+  const int RS = (KK + 2 + 3) & ~3;
+  const size_t tr = (size_t)b.M * RS + (((size_t)(b.H + 2 * pad) * (b.W + 2 * pad) + 3) & ~3) +
+                    4 * 64 * 2;
+  const size_t la = (size_t)((2 * HW + 4 + 3) & ~3) + 16 + 256 + (size_t)(2 * HW + 4) * b.C;
   const size_t smem = sizeof(float) * (tr > la ? tr : la);
   hipLaunchKernelGGL(att_ops_kernel, dim3(count), dim3(MT), smem, s, w, b, tab_off);
 }
@@ -444,14 +586,14 @@ void launch_pool(const ModuleWeights& w, const ModuleBuffers& b, int tab_off, in
                  hipStream_t s) {
   const int HW = b.H * b.W, Dp = b.D / POOL_PARTS;
   const int nrow = MT / (Dp / 4);
-  const size_t smem =
-      sizeof(float) * (2 * (size_t)((HW + 3) & ~3) + 16 + 2 * Dp + (size_t)nrow * 2 * Dp);
+  const size_t stage = std::max<size_t>((size_t)nrow * 2 * Dp, 1024);
+  const size_t smem = sizeof(float) * (2 * (size_t)((HW + 3) & ~3) + 16 + 2 * Dp + stage);
   hipLaunchKernelGGL(pool_kernel, dim3(count), dim3(MT), smem, s, w, b, tab_off);
 }
 
 void launch_heads(const ModuleWeights& w, const ModuleBuffers& b, int tab_off, int count,
                   hipStream_t s) {
-  const size_t smem = sizeof(float) * ((size_t)b.Mp + 16 + 256);
+  const size_t smem = sizeof(float) * ((size_t)b.Mp + 16 + 256 + (size_t)b.wl_cap);
   hipLaunchKernelGGL(heads_kernel, dim3(count), dim3(MT), smem, s, w, b, tab_off);
 }
 

@@ -9,6 +9,16 @@ namespace n2nmn {
 
 namespace {
 
+// tanh / sigmoid on the hardware exp (v_exp_f32): tanh(x) = 1 - 2/(e^{2x}+1).  Absolute error
+// <= ~2e-7 over the whole range (saturates cleanly to +-1), far inside the 1e-4 logit budget.
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float t = __expf(2.0f * x);
+  return 1.0f - __fdividef(2.0f, t + 1.0f);
+}
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __fdividef(1.0f, 1.0f + __expf(-x));
+}
+
 // ---------------------------------------------------------------------------------------------
 // lstm_step_kernel: one LSTM layer step (or two independent ones: grid.y = job).
 //
@@ -20,12 +30,15 @@ namespace {
 // over the recurrent K = L (layer 0) or K = 2L (layer 1: [h_below, h_own]).
 //
 // CDNA4 mapping: a workgroup owns 4 hidden units = 16 gate columns (one 16x16x4 fp32 MFMA
-// N-tile, columns ordered gate-major in the packed weights) for 64 batch rows (4 M-tiles).
+// N-tile, columns ordered gate-major in the packed weights) for 16*MT batch rows (MT M-tiles).
 // Its 8 waves split K; each wave streams its K-slice of the weight tile (contiguous float4s of
 // the k-interleaved pack) and of h straight from L2 into MFMA operand registers -- no LDS staging,
-// because nothing is reused inside the workgroup.  The 8 partial 64x16 tiles are reduced through
-// LDS and the gate nonlinearities + state update run in the same kernel, so z never exists in HBM.
-// grid = (L/4 column tiles, jobs, row blocks of 64): 128..256 workgroups per launch.
+// because nothing is reused inside the workgroup.  The K-slice is a compile-time number of
+// 16-wide chunks so that ALL operand loads of a wave are in flight before its first MFMA (one
+// L2 round trip per step instead of one per chunk), and the operands of the pointwise epilogue
+// (c, x-table row, bias, h_old) are fetched at kernel entry as well.  The 8 partial tiles are
+// reduced through LDS and the gate nonlinearities + state update run in the same kernel, so z
+// never exists in HBM.  grid = (column tiles, jobs, row blocks).
 // ---------------------------------------------------------------------------------------------
 constexpr int LSTM_WAVES = 8;
 constexpr int LSTM_THREADS = LSTM_WAVES * 64;
@@ -34,147 +47,249 @@ struct LstmJobs {
   LstmJob j[2];
 };
 
+// DBG: 0 normal, 1 = pin all loads before the MFMAs (sched_barrier), 2 = loads only (no MFMA),
+// 3 = MFMA only (no loads), 4 = neither   -- variants 2..4 exist for n2nmn_debug_lstm_bench
+template <int NCH, int MT, int DBG = 0>
+__device__ __forceinline__ void lstm_mma(const LstmJob& jb, int N, int L, int tile, int row0,
+                                         f32x4 (&acc)[MT]) {
+  const int lane = threadIdx.x & 63;
+  // stagger: neighbouring column tiles walk the K slices and chunks in rotated order, so the
+  // 128 workgroups that all read the same h rows do not hit the same L2 channel at the same time
+  const int w = ((threadIdx.x >> 6) + tile) & (LSTM_WAVES - 1);
+  const int rot = (tile >> 3) & (NCH - 1);
+  const int ci = lane & 15, kg = lane >> 4;
+  const int K = jb.K;
+  const int kbeg = w * (NCH * 16);
+  const float* Asrc = (kbeg < L) ? jb.A0 : jb.A1;
+  const int kloc = (kbeg < L) ? kbeg : kbeg - L;
+  const float4* Wp4 = reinterpret_cast<const float4*>(jb.Wp) + (size_t)tile * (K / 4) * 16 +
+                      (size_t)((kbeg >> 2) + kg) * 16 + ci;
+  float4 bq[NCH];
+  float4 aq[NCH][MT];
+  if (DBG == 3 || DBG == 4) {
+    const float f = (float)lane * 1e-3f;
+#pragma unroll
+    for (int kc = 0; kc < NCH; ++kc) {
+      bq[kc] = make_float4(f, f + 1.f, f + 2.f, f + 3.f);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) aq[kc][m] = make_float4(f, f - 1.f, f - 2.f, f - 3.f);
+    }
+  } else {
+#pragma unroll
+    for (int kc = 0; kc < NCH; ++kc) bq[kc] = Wp4[(size_t)((kc + rot) & (NCH - 1)) * 64];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      int r = row0 + 16 * m + ci;
+      r = r < N ? r : N - 1;
+      const float* ar = Asrc + (size_t)r * jb.a_rs + (size_t)((kloc >> 2) + kg) * jb.a_ks;
+#pragma unroll
+      for (int kc = 0; kc < NCH; ++kc)
+        aq[kc][m] = *reinterpret_cast<const float4*>(
+            ar + (size_t)(4 * ((kc + rot) & (NCH - 1))) * jb.a_ks);
+    }
+  }
+  if (DBG == 1) __builtin_amdgcn_sched_barrier(0);   // all loads issued before the first MFMA
+  if (DBG == 2 || DBG == 4) {                        // no MFMA: fold the operands so they stay live
+#pragma unroll
+    for (int kc = 0; kc < NCH; ++kc)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        acc[m][0] += aq[kc][m].x * bq[kc].x; acc[m][1] += aq[kc][m].y * bq[kc].y;
+        acc[m][2] += aq[kc][m].z * bq[kc].z; acc[m][3] += aq[kc][m].w * bq[kc].w;
+      }
+    return;
+  }
+#pragma unroll
+  for (int kc = 0; kc < NCH; ++kc) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[kc][m].x, bq[kc].x, acc[m], 0, 0, 0);
+      acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[kc][m].y, bq[kc].y, acc[m], 0, 0, 0);
+      acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[kc][m].z, bq[kc].z, acc[m], 0, 0, 0);
+      acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[kc][m].w, bq[kc].w, acc[m], 0, 0, 0);
+    }
+  }
+}
+
+template <int MT, int DBG = 0>
 __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_kernel(LstmJobs jobs, int N, int L) {
   const LstmJob& jb = jobs.j[blockIdx.y];
   if (!jb.active) return;
-  __shared__ float part[LSTM_WAVES][64][17];
-
   const int tile = blockIdx.x;
   if (tile >= jb.ntiles) return;
-  const int row0 = blockIdx.z * 64;
+  __shared__ float part[LSTM_WAVES][16 * MT][17];
+
+  constexpr int ROWS = 16 * MT;
+  const int row0 = blockIdx.z * ROWS;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int ci = lane & 15, kg = lane >> 4;
-  const int K = jb.K;
-  const int kslice = K / LSTM_WAVES;
-  const int kbeg = w * kslice;
-  const float* Asrc = (kbeg < L) ? jb.A0 : jb.A1;
-  const int kloc = (kbeg < L) ? kbeg : kbeg - L;
-  const float4* Wp4 = reinterpret_cast<const float4*>(jb.Wp) + (size_t)tile * (K / 4) * 16;
 
-  const float* arow[4];
+  // ---- epilogue operands, fetched up front (thread = (row, unit) for tid < 4*ROWS) ----------
+  const int erow = tid >> 2, ul = tid & 3;
+  const int gr = row0 + erow;
+  const bool eact = tid < 4 * ROWS && gr < N;
+  float add[4] = {0.f, 0.f, 0.f, 0.f};
+  float c_old = 0.f, h_prev = 0.f;
+  bool masked = false;
+  if (eact) {
+    if (jb.mode == 1) {
 #pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    int r = row0 + 16 * m + ci;
-    r = r < N ? r : N - 1;
-    arow[m] = Asrc + (size_t)r * L + kloc + 4 * kg;
-  }
-
-  f32x4 acc[4];
-#pragma unroll
-  for (int m = 0; m < 4; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nchunk = kslice / 16;
-#pragma unroll 4
-  for (int kc = 0; kc < nchunk; ++kc) {
-    const float4 bq = Wp4[(size_t)((kbeg >> 2) + 4 * kc + kg) * 16 + ci];
-    float4 aq[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) aq[m] = *reinterpret_cast<const float4*>(arow[m] + 16 * kc);
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[m].x, bq.x, acc[m], 0, 0, 0);
-      acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[m].y, bq.y, acc[m], 0, 0, 0);
-      acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[m].z, bq.z, acc[m], 0, 0, 0);
-      acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[m].w, bq.w, acc[m], 0, 0, 0);
-    }
-  }
-  // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
-#pragma unroll
-  for (int m = 0; m < 4; ++m)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) part[w][16 * m + 4 * kg + r][ci] = acc[m][r];
-  __syncthreads();
-
-  if (tid < 256) {
-    const int row = tid >> 2, ul = tid & 3;
-    const int gr = row0 + row;
-    if (gr < N) {
-      float z[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float s = 0.f;
-#pragma unroll
-        for (int ww = 0; ww < LSTM_WAVES; ++ww) s += part[ww][row][g * 4 + ul];
-        z[g] = s;
-      }
-      if (jb.mode == 1) {                       // plain linear: out = z + bias
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int col = 16 * tile + g * 4 + ul;
-          jb.h_new[(size_t)gr * jb.ldo + col] = z[g] + (jb.bias ? jb.bias[col] : 0.f);
-        }
-        return;
-      }
+      for (int g = 0; g < 4; ++g) add[g] = jb.bias ? jb.bias[16 * tile + g * 4 + ul] : 0.f;
+    } else {
       const int u = 4 * tile + ul;
       if (jb.xtab) {
         const int xi = jb.xidx ? jb.xidx[gr] : jb.xidx_const;
         const float* xr = jb.xtab + (size_t)xi * 4 * L + u;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) z[g] += xr[g * L];
+        for (int g = 0; g < 4; ++g) add[g] = xr[g * L];
       } else {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) z[g] += jb.bias[g * L + u];
+        for (int g = 0; g < 4; ++g) add[g] = jb.bias[g * L + u];
       }
       const size_t idx = (size_t)gr * L + u;
-      const float c_old = jb.c_in[idx];
-      float c_new = c_old * sigmoidf_(z[2] + 1.0f) + sigmoidf_(z[0]) * tanhf(z[1]);
-      float h_new = tanhf(c_new) * sigmoidf_(z[3]);
-      float o = h_new;
+      c_old = jb.c_in[idx];
       if (jb.seq_len && jb.t >= jb.seq_len[gr]) {   // dynamic_rnn past the length (A.2)
-        c_new = c_old;
-        h_new = jb.h_old[idx];
-        o = 0.f;
+        masked = true;
+        h_prev = jb.h_old[jb.hp_R > 0 ? ((size_t)tile * jb.hp_R + gr) * 4 + ul : idx];
       }
-      jb.c_out[idx] = c_new;
-      jb.h_new[idx] = h_new;
-      if (jb.out_seq) jb.out_seq[idx] = o;
     }
+  }
+
+  // ---- K-split MFMA ------------------------------------------------------------------------
+  f32x4 acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nch = jb.K / (LSTM_WAVES * 16);
+  if (nch == 4) lstm_mma<4, MT, DBG>(jb, N, L, tile, row0, acc);
+  else if (nch == 8) lstm_mma<8, MT, DBG>(jb, N, L, tile, row0, acc);
+  else {
+    for (int q = 0; q < nch; ++q) {               // generic K: one chunk at a time
+      const int kbeg = w * nch * 16 + 16 * q;
+      const float* Asrc = (kbeg < L) ? jb.A0 : jb.A1;
+      const int kloc = (kbeg < L) ? kbeg : kbeg - L;
+      const float4 bq = (reinterpret_cast<const float4*>(jb.Wp) +
+                         (size_t)tile * (jb.K / 4) * 16)[(size_t)((kbeg >> 2) + kg) * 16 + ci];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        int r = row0 + 16 * m + ci;
+        r = r < N ? r : N - 1;
+        const float4 aq = *reinterpret_cast<const float4*>(
+            Asrc + (size_t)r * jb.a_rs + (size_t)((kloc >> 2) + kg) * jb.a_ks);
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.x, bq.x, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.y, bq.y, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.z, bq.z, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.w, bq.w, acc[m], 0, 0, 0);
+      }
+    }
+  }
+  // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[w][16 * m + 4 * kg + r][ci] = acc[m][r];
+  __syncthreads();
+
+  if (eact) {
+    float z[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float s = add[g];
+#pragma unroll
+      for (int ww = 0; ww < LSTM_WAVES; ++ww) s += part[ww][erow][g * 4 + ul];
+      z[g] = s;
+    }
+    if (jb.mode == 1) {                           // plain linear: out = z + bias
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        jb.h_new[(size_t)gr * jb.ldo + 16 * tile + g * 4 + ul] = z[g];
+      return;
+    }
+    const size_t idx = (size_t)gr * L + 4 * tile + ul;
+    float c_new = c_old * fast_sigmoid(z[2] + 1.0f) + fast_sigmoid(z[0]) * fast_tanh(z[1]);
+    float h_new = fast_tanh(c_new) * fast_sigmoid(z[3]);
+    float o = h_new;
+    if (masked) { c_new = c_old; h_new = h_prev; o = 0.f; }
+    jb.c_out[idx] = c_new;
+    jb.h_new[jb.hp_R > 0 ? ((size_t)tile * jb.hp_R + gr) * 4 + ul : idx] = h_new;
+    if (jb.out_seq) jb.out_seq[idx] = o;
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// dec_step_kernel: everything of one decoder step after the LSTM cell, one workgroup per
-// question (nmn3_netgen_att.py:184-268):
+// dec_attn_kernel: everything of a decoder step after the LSTM cell, one workgroup per
+// (question n, step t = blockIdx.y) (nmn3_netgen_att.py:184-268):
 //   additive attention over the encoder steps, masked renormalised softmax, context vector,
 //   token logits, validity automaton (int32), greedy / sampled / teacher-forced choice,
 //   token probability, entropy term, automaton update.
-// q = out . W_a + b_a comes from gemm_pk.  eht / eout rows of this question (2 x T x L fp32) are
-// streamed with float4 loads; v, q, out, the attention row and the context live in LDS.
+// Sequential decoding launches it with grid.y = 1 per step (NT = 1024 threads to cut the
+// per-step latency); teacher-forced decoding knows every token up front, so ALL T_dec steps run
+// in ONE launch (grid.y = T_dec, NT = 256).  q = out . W_a + b_a comes from the linear mode of
+// lstm_step_kernel.  eht / eout rows of the question are streamed with float4 loads (several
+// encoder steps in flight per wave); v, q, out, the attention row and the context live in
+// registers / LDS.
 // ---------------------------------------------------------------------------------------------
-constexpr int DEC_THREADS = 256;
 constexpr int MAXV = 16;
+constexpr int MAXKI = 4;      // lstm_dim <= 1024
 
-__global__ __launch_bounds__(DEC_THREADS) void dec_step_kernel(DecStepArgs a) {
+template <int NT>
+__global__ __launch_bounds__(NT) void dec_attn_kernel(DecStepArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NW = NT / 64;
   const int L = a.L, T = a.T, N = a.N, V = a.V;
-  float* qs = smem;             // [L]
-  float* outs = qs + L;         // [L]
+  float* outs = smem;           // [L]
   float* ctx = outs + L;        // [L]
-  float* ctxp = ctx + L;        // [2][L] partial contexts
-  float* es = ctxp + 2 * L;     // [T] logits -> attention
-  float* red = es + ((T + 3) & ~3);   // [4][MAXV] + scratch
-  const int n = blockIdx.x;
+  float* ctxp = ctx + L;        // [NSPLIT][L] partial contexts
+  const int ncol = L / 4;
+  const int nsplit = NT / ncol > 0 ? (NT / ncol < 8 ? NT / ncol : 8) : 1;
+  float* es = ctxp + (size_t)nsplit * L;      // [T] logits -> attention
+  float* red = es + ((T + 3) & ~3);           // [NW][MAXV]
+  const int n = blockIdx.x, ts = blockIdx.y;  // ts: step offset inside this launch
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int len = a.seq_len[n];
+  const size_t tn = (size_t)ts * N + n;
+  const float* qrow = a.q + tn * L;
+  const float* orow = a.out + tn * L;
 
-  for (int k = tid; k < L; k += DEC_THREADS) {
-    qs[k] = a.q[(size_t)n * L + k];
-    outs[k] = a.out[(size_t)n * L + k];
-  }
-  __syncthreads();
+  for (int k = tid; k < L; k += NT) outs[k] = orow[k];
 
   // ---- e[tau] = sum_k v_k tanh(q_k + eht[tau, n, k])                               (:184-187)
-  for (int tau = w; tau < T; tau += DEC_THREADS / 64) {
-    const float* er = a.eht + ((size_t)tau * N + n) * L;
-    float s = 0.f;
-    for (int k = 4 * lane; k < L; k += 256) {
-      const float4 e4 = *reinterpret_cast<const float4*>(er + k);
-      const float4 v4 = *reinterpret_cast<const float4*>(a.v + k);
-      s += v4.x * tanhf(qs[k] + e4.x) + v4.y * tanhf(qs[k + 1] + e4.y) +
-           v4.z * tanhf(qs[k + 2] + e4.z) + v4.w * tanhf(qs[k + 3] + e4.w);
+  {
+    float4 v4[MAXKI], q4[MAXKI];
+#pragma unroll
+    for (int i = 0; i < MAXKI; ++i) {
+      const int k = 4 * lane + 256 * i;
+      if (k < L) {
+        v4[i] = *reinterpret_cast<const float4*>(a.v + k);
+        q4[i] = *reinterpret_cast<const float4*>(qrow + k);
+      }
     }
-    s = wave_sum(s);
-    if (lane == 0) es[tau] = s;
+    constexpr int UNR = 4;
+    for (int j0 = 0; j0 * NW + w < T; j0 += UNR) {
+      float s[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int tau = w + NW * (j0 + u);
+        s[u] = 0.f;
+        if (tau < T) {
+          const float* er = a.eht + ((size_t)tau * N + n) * L;
+#pragma unroll
+          for (int i = 0; i < MAXKI; ++i) {
+            const int k = 4 * lane + 256 * i;
+            if (k < L) {
+              const float4 e4 = *reinterpret_cast<const float4*>(er + k);
+              s[u] += v4[i].x * fast_tanh(q4[i].x + e4.x) + v4[i].y * fast_tanh(q4[i].y + e4.y) +
+                      v4[i].z * fast_tanh(q4[i].z + e4.z) + v4[i].w * fast_tanh(q4[i].w + e4.w);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int tau = w + NW * (j0 + u);
+        const float r = wave_sum(s[u]);
+        if (lane == 0 && tau < T) es[tau] = r;
+      }
+    }
   }
   __syncthreads();
 
@@ -194,32 +309,35 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_step_kernel(DecStepArgs a) {
       s2 += p;
     }
     s2 = wave_sum(s2);
+    float* arow = a.atts + (size_t)ts * T * N;
     for (int tau = lane; tau < T; tau += 64) {
       const float att = es[tau] / s2;
       es[tau] = att;
-      a.atts[(size_t)tau * N + n] = att;
+      arow[(size_t)tau * N + n] = att;
     }
   }
   __syncthreads();
 
   // ---- ctx = sum_tau att[tau] * eout[tau, n, :]                                     (:193)
   {
-    const int ncol = L / 4;
-    const int nsplit = (2 * ncol <= DEC_THREADS) ? 2 : 1;
-    for (int c = tid; c < ncol * nsplit; c += DEC_THREADS) {
+    for (int c = tid; c < ncol * nsplit; c += NT) {
       const int col = c % ncol, sp = c / ncol;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float* ob = a.eout + (size_t)n * L + 4 * col;
+#pragma unroll 4
       for (int tau = sp; tau < len; tau += nsplit) {
         const float at = es[tau];
-        const float4 o4 =
-            *reinterpret_cast<const float4*>(a.eout + ((size_t)tau * N + n) * L + 4 * col);
+        const float4 o4 = *reinterpret_cast<const float4*>(ob + (size_t)tau * N * L);
         acc.x += at * o4.x; acc.y += at * o4.y; acc.z += at * o4.z; acc.w += at * o4.w;
       }
-      *reinterpret_cast<float4*>(ctxp + sp * L + 4 * col) = acc;
+      *reinterpret_cast<float4*>(ctxp + (size_t)sp * L + 4 * col) = acc;
     }
     __syncthreads();
-    for (int k = tid; k < L; k += DEC_THREADS)
-      ctx[k] = (nsplit == 2) ? ctxp[k] + ctxp[L + k] : ctxp[k];
+    for (int k = tid; k < L; k += NT) {
+      float s = 0.f;
+      for (int sp = 0; sp < nsplit; ++sp) s += ctxp[(size_t)sp * L + k];
+      ctx[k] = s;
+    }
     __syncthreads();
   }
 
@@ -228,7 +346,8 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_step_kernel(DecStepArgs a) {
     float ps[MAXV];
 #pragma unroll
     for (int s = 0; s < MAXV; ++s) ps[s] = 0.f;
-    for (int k = tid; k < 2 * L; k += DEC_THREADS) {
+#pragma unroll 2
+    for (int k = tid; k < 2 * L; k += NT) {
       const float x = k < L ? outs[k] : ctx[k - L];
       const float* wr = a.Wy + (size_t)k * V;
 #pragma unroll
@@ -249,20 +368,21 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_step_kernel(DecStepArgs a) {
     float sc = -INFINITY;
     if (on) {
       sc = a.by[lane];
-      for (int ww = 0; ww < DEC_THREADS / 64; ++ww) sc += red[ww * MAXV + lane];
-      if (a.scores) a.scores[(size_t)n * V + lane] = sc;
+      for (int ww = 0; ww < NW; ++ww) sc += red[ww * MAXV + lane];
+      if (a.scores) a.scores[tn * V + lane] = sc;
     }
-    const int x0 = a.state[n * 3 + 0], x1 = a.state[n * 3 + 1], x2 = a.state[n * 3 + 2];
-    bool valid = false;
-    if (on) {
-      valid = true;
-      for (int c = 0; c < 4; ++c) {          // all_c( X . W[:, s, c] - b[s, c] >= 0 )   (:8-11)
-        const int val = x0 * a.Wv[(0 * V + lane) * 4 + c] + x1 * a.Wv[(1 * V + lane) * 4 + c] +
-                        x2 * a.Wv[(2 * V + lane) * 4 + c] - a.bv[lane * 4 + c];
-        valid = valid && (val >= 0);
+    int x0 = 0, x1 = 0, x2 = 0;
+    bool valid = on;
+    if (!a.use_gt) {
+      x0 = a.state[n * 3 + 0]; x1 = a.state[n * 3 + 1]; x2 = a.state[n * 3 + 2];
+      if (on) {
+        for (int c = 0; c < 4; ++c) {        // all_c( X . W[:, s, c] - b[s, c] >= 0 )   (:8-11)
+          const int val = x0 * a.Wv[(0 * V + lane) * 4 + c] + x1 * a.Wv[(1 * V + lane) * 4 + c] +
+                          x2 * a.Wv[(2 * V + lane) * 4 + c] - a.bv[lane * 4 + c];
+          valid = valid && (val >= 0);
+        }
       }
-      if (a.use_gt) valid = true;            // logical_or(valid, use_gt_layout)         (:204-207)
-    }
+    }                                        // use_gt: logical_or(valid, True)          (:204-207)
     // greedy: first index of the maximum over valid tokens (invalid ones sit at min-1)  (:234-238)
     const float key = (on && valid) ? sc : -INFINITY;
     const float kmax = wave_max(key);
@@ -274,22 +394,21 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_step_kernel(DecStepArgs a) {
       const float ex = on ? expf(sv - mx) : 0.f;
       const float den = wave_sum(ex);
       const float ps = ex / den;
-      // inclusive scan over V <= 16 lanes, sequential order
-      float cdf = 0.f, tot = 0.f;
+      float cdf = 0.f, tot = 0.f;            // inclusive scan over V <= 16 lanes, in order
       for (int s = 0; s < V; ++s) {
         const float v = __shfl(ps, s, 64);
         tot += v;
         if (s == lane) cdf = tot;
       }
-      const float thr = a.uni[n] * tot;
+      const float thr = a.uni[tn] * tot;
       const unsigned long long le = __ballot(on && cdf <= thr);
       int samp = __builtin_popcountll(le);
       samp = samp < V - 1 ? samp : V - 1;
       const bool ok = (__ballot(on && valid) >> samp) & 1ull;
       tok = ok ? samp : tok;
     }
-    if (a.use_gt && a.gt) tok = a.gt[n];     // (:239-241)
-    if (a.forced) tok = a.forced[n];
+    if (a.use_gt && a.gt) tok = a.gt[tn];    // (:239-241)
+    if (a.forced) tok = a.forced[tn];
     // robust softmax restricted to valid tokens                                        (:245-260)
     const float mx = wave_max(sc);
     const float ex = on ? expf(sc - mx) : 0.f;
@@ -301,54 +420,78 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_step_kernel(DecStepArgs a) {
     float ent = on ? p * logf(fmaxf(1e-5f, p + (valid ? 0.f : 1.f))) : 0.f;
     ent = wave_sum(ent);
     if (lane == 0) {
-      a.tokens[n] = tok;
-      a.tprobs[n] = tp;
-      a.neg_entropy[n] += ent;
-      a.next_idx[n] = tok;
-      a.state[n * 3 + 0] = x0 + a.P[tok * 3 + 0];          // X += P[token]            (:13-15)
-      a.state[n * 3 + 1] = x1 + a.P[tok * 3 + 1];
-      a.state[n * 3 + 2] = x2 + a.P[tok * 3 + 2];
+      a.tokens[tn] = tok;
+      a.tprobs[tn] = tp;
+      a.ent_t[tn] = ent;
+      if (!a.use_gt) {
+        a.next_idx[n] = tok;
+        a.state[n * 3 + 0] = x0 + a.P[tok * 3 + 0];        // X += P[token]            (:13-15)
+        a.state[n * 3 + 1] = x1 + a.P[tok * 3 + 1];
+        a.state[n * 3 + 2] = x2 + a.P[tok * 3 + 2];
+      } else if (a.next_idx) {
+        a.next_idx[n] = tok;
+      }
     }
   }
 }
 
-__global__ void dec_init_kernel(int32_t* state, float* neg_entropy, int N, int T_dec) {
+__global__ void dec_init_kernel(int32_t* state, int N, int T_dec) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n < N) {
     state[n * 3 + 0] = 0; state[n * 3 + 1] = 0; state[n * 3 + 2] = T_dec;     // (:284)
-    neg_entropy[n] = 0.f;
   }
 }
 
 // word_vecs[t, n, :] = sum_tau atts[t, tau, n] * emb[seq[tau, n], :]   (nmn3_netgen_att.py:312)
-// one workgroup per question: the question's T_enc embedding rows are staged once in LDS.
+// one workgroup per question: the question's T_enc embedding rows are staged once in LDS (the
+// row index comes from LDS so the global loads of different tau are independent), then every
+// thread owns output elements.  Also finishes neg_entropy = sum_t ent_t and log_seq_prob.
+constexpr int WV_TGROUPS = 4;
 __global__ __launch_bounds__(256) void word_vecs_kernel(const float* __restrict__ atts,
                                                         const int32_t* __restrict__ seq,
                                                         const float* __restrict__ emb, int T_dec,
                                                         int T_enc, int N, int E,
                                                         float* __restrict__ wv,
                                                         const float* __restrict__ tprobs,
+                                                        const float* __restrict__ ent_t,
+                                                        float* __restrict__ neg_entropy,
                                                         float* __restrict__ log_seq_prob) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* rows = smem;                       // [T_enc][E]
-  float* at = rows + (size_t)T_enc * E;     // [T_dec][T_enc]
+  float* at = rows + (size_t)T_enc * E;     // [tper][T_enc]
+  int* idx = reinterpret_cast<int*>(at + (size_t)T_dec * T_enc);   // [T_enc]
   const int n = blockIdx.x, tid = threadIdx.x;
-  for (int i = tid; i < T_enc * E; i += 256) {
-    const int tau = i / E, e = i - tau * E;
-    rows[i] = emb[(size_t)seq[tau * N + n] * E + e];
-  }
-  for (int i = tid; i < T_dec * T_enc; i += 256) {
+  const int tper = (T_dec + WV_TGROUPS - 1) / WV_TGROUPS;
+  const int t0 = blockIdx.y * tper, t1 = min(T_dec, t0 + tper);
+  for (int tau = tid; tau < T_enc; tau += 256) idx[tau] = seq[tau * N + n];
+  for (int i = tid; i < (t1 - t0) * T_enc; i += 256) {
     const int t = i / T_enc, tau = i - t * T_enc;
-    at[i] = atts[((size_t)t * T_enc + tau) * N + n];
+    at[i] = atts[((size_t)(t0 + t) * T_enc + tau) * N + n];
   }
   __syncthreads();
-  for (int i = tid; i < T_dec * E; i += 256) {
+  {   // the question's embedding rows, 16-B loads, all independent
+    const int e4n = E >> 2;
+    float4* rows4 = reinterpret_cast<float4*>(rows);
+#pragma unroll 4
+    for (int i = tid; i < T_enc * e4n; i += 256) {
+      const int tau = i / e4n, e4 = i - tau * e4n;
+      rows4[i] = reinterpret_cast<const float4*>(emb + (size_t)idx[tau] * E)[e4];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < (t1 - t0) * E; i += 256) {
     const int t = i / E, e = i - t * E;
     float s = 0.f;
+#pragma unroll 5
     for (int tau = 0; tau < T_enc; ++tau) s += at[t * T_enc + tau] * rows[tau * E + e];
-    wv[((size_t)t * N + n) * E + e] = s;
+    wv[((size_t)(t0 + t) * N + n) * E + e] = s;
   }
-  if (log_seq_prob && tid == 0) {           // models_clevr/nmn3_model.py:46
+  if (blockIdx.y == 0 && tid == 0) {
+    float s = 0.f;
+    for (int t = 0; t < T_dec; ++t) s += ent_t[t * N + n];
+    neg_entropy[n] = s;                      // loop_state[3] + neg_entropy  (:297)
+  }
+  if (blockIdx.y == 0 && log_seq_prob && tid == 64) {   // models_clevr/nmn3_model.py:46
     float s = 0.f;
     for (int t = 0; t < T_dec; ++t) s += logf(tprobs[t * N + n]);
     log_seq_prob[n] = s;
@@ -357,7 +500,8 @@ __global__ __launch_bounds__(256) void word_vecs_kernel(const float* __restrict_
 
 }  // namespace
 
-void launch_lstm_step(const LstmJob* jobs, int njobs, int N, int L, hipStream_t s) {
+void launch_lstm_step(const LstmJob* jobs, int njobs, int N, int L, int rows_per_wg,
+                      hipStream_t s) {
   LstmJobs js;
   for (int i = 0; i < 2; ++i) {
     if (i < njobs) js.j[i] = jobs[i];
@@ -365,26 +509,87 @@ void launch_lstm_step(const LstmJob* jobs, int njobs, int N, int L, hipStream_t 
   }
   int nt = 0;
   for (int i = 0; i < njobs; ++i) nt = jobs[i].ntiles > nt ? jobs[i].ntiles : nt;
-  dim3 grid(nt, njobs, (N + 63) / 64);
-  hipLaunchKernelGGL(lstm_step_kernel, grid, dim3(LSTM_THREADS), 0, s, js, N, L);
+  if (rows_per_wg == 32) {
+    dim3 grid(nt, njobs, (N + 31) / 32);
+    hipLaunchKernelGGL((lstm_step_kernel<2, 0>), grid, dim3(LSTM_THREADS), 0, s, js, N, L);
+  } else {
+    dim3 grid(nt, njobs, (N + 63) / 64);
+    hipLaunchKernelGGL((lstm_step_kernel<4, 0>), grid, dim3(LSTM_THREADS), 0, s, js, N, L);
+  }
 }
 
-void launch_dec_step(const DecStepArgs& a, hipStream_t s) {
-  const size_t smem = sizeof(float) * (5 * (size_t)a.L + ((a.T + 3) & ~3) + 4 * MAXV + 16);
-  hipLaunchKernelGGL(dec_step_kernel, dim3(a.N), dim3(DEC_THREADS), smem, s, a);
+__global__ void empty_kernel(int) {}
+
+__global__ void unpack_h_kernel(const float* __restrict__ src, float* __restrict__ dst, int N,
+                                int L, int R) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N * L) {
+    const int n = i / L, k = i - n * L;
+    dst[i] = src[((size_t)(k >> 2) * R + n) * 4 + (k & 3)];
+  }
 }
 
-void launch_dec_init(int32_t* state, float* neg_entropy, int N, int T_dec, hipStream_t s) {
-  hipLaunchKernelGGL(dec_init_kernel, dim3((N + 63) / 64), dim3(64), 0, s, state, neg_entropy, N,
-                     T_dec);
+// debug: the same launch with a kernel variant (see lstm_mma DBG); variant 5 = empty kernel
+void launch_lstm_step_dbg(const LstmJob* jobs, int njobs, int N, int L, int rows_per_wg,
+                          int variant, hipStream_t s) {
+  LstmJobs js;
+  for (int i = 0; i < 2; ++i) {
+    if (i < njobs) js.j[i] = jobs[i];
+    else { js.j[i] = LstmJob{}; js.j[i].active = 0; }
+  }
+  int nt = 0;
+  for (int i = 0; i < njobs; ++i) nt = jobs[i].ntiles > nt ? jobs[i].ntiles : nt;
+  dim3 g4(nt, njobs, (N + 63) / 64), g2(nt, njobs, (N + 31) / 32), b(LSTM_THREADS);
+  if (variant == 5) { hipLaunchKernelGGL(empty_kernel, g4, b, 0, s, 0); return; }
+  if (rows_per_wg == 32) {
+    switch (variant) {
+      case 1: hipLaunchKernelGGL((lstm_step_kernel<2, 1>), g2, b, 0, s, js, N, L); break;
+      case 2: hipLaunchKernelGGL((lstm_step_kernel<2, 2>), g2, b, 0, s, js, N, L); break;
+      case 3: hipLaunchKernelGGL((lstm_step_kernel<2, 3>), g2, b, 0, s, js, N, L); break;
+      case 4: hipLaunchKernelGGL((lstm_step_kernel<2, 4>), g2, b, 0, s, js, N, L); break;
+      default: hipLaunchKernelGGL((lstm_step_kernel<2, 0>), g2, b, 0, s, js, N, L); break;
+    }
+  } else {
+    switch (variant) {
+      case 1: hipLaunchKernelGGL((lstm_step_kernel<4, 1>), g4, b, 0, s, js, N, L); break;
+      case 2: hipLaunchKernelGGL((lstm_step_kernel<4, 2>), g4, b, 0, s, js, N, L); break;
+      case 3: hipLaunchKernelGGL((lstm_step_kernel<4, 3>), g4, b, 0, s, js, N, L); break;
+      case 4: hipLaunchKernelGGL((lstm_step_kernel<4, 4>), g4, b, 0, s, js, N, L); break;
+      default: hipLaunchKernelGGL((lstm_step_kernel<4, 0>), g4, b, 0, s, js, N, L); break;
+    }
+  }
+}
+
+void launch_unpack_h(const float* src, float* dst, int N, int L, int R, hipStream_t s) {
+  hipLaunchKernelGGL(unpack_h_kernel, dim3((N * L + 255) / 256), dim3(256), 0, s, src, dst, N, L,
+                     R);
+}
+
+void launch_dec_attn(const DecStepArgs& a, int nsteps, hipStream_t s) {
+  const int nt = nsteps > 1 ? 256 : 1024;
+  const int ncol = a.L / 4;
+  int nsplit = nt / ncol;
+  nsplit = nsplit < 1 ? 1 : (nsplit > 8 ? 8 : nsplit);
+  const size_t smem = sizeof(float) * ((2 + (size_t)nsplit) * a.L + ((a.T + 3) & ~3) +
+                                       (size_t)(nt / 64) * MAXV + 16);
+  if (nsteps > 1)
+    hipLaunchKernelGGL(dec_attn_kernel<256>, dim3(a.N, nsteps), dim3(256), smem, s, a);
+  else
+    hipLaunchKernelGGL(dec_attn_kernel<1024>, dim3(a.N, 1), dim3(1024), smem, s, a);
+}
+
+void launch_dec_init(int32_t* state, int N, int T_dec, hipStream_t s) {
+  hipLaunchKernelGGL(dec_init_kernel, dim3((N + 63) / 64), dim3(64), 0, s, state, N, T_dec);
 }
 
 void launch_word_vecs(const float* atts, const int32_t* seq, const float* emb, int T_dec,
                       int T_enc, int N, int E, float* word_vecs, const float* tprobs,
-                      float* log_seq_prob, hipStream_t s) {
-  const size_t smem = sizeof(float) * ((size_t)T_enc * E + (size_t)T_dec * T_enc);
-  hipLaunchKernelGGL(word_vecs_kernel, dim3(N), dim3(256), smem, s, atts, seq, emb, T_dec, T_enc,
-                     N, E, word_vecs, tprobs, log_seq_prob);
+                      const float* ent_t, float* neg_entropy, float* log_seq_prob,
+                      hipStream_t s) {
+  const size_t smem =
+      sizeof(float) * ((size_t)T_enc * E + (size_t)T_dec * T_enc + (size_t)T_enc + 4);
+  hipLaunchKernelGGL(word_vecs_kernel, dim3(N, WV_TGROUPS), dim3(256), smem, s, atts, seq, emb, T_dec, T_enc,
+                     N, E, word_vecs, tprobs, ent_t, neg_entropy, log_seq_prob);
 }
 
 }  // namespace n2nmn

@@ -41,7 +41,7 @@ struct Launch {
 
 constexpr int TM_GROUP = 8;        // nodes per text-map workgroup (share one weight stream)
 constexpr int FIND_PARTS = 4;      // row split of a Find-type epilogue
-constexpr int TRANSFORM_PARTS = 2; // pixel split of a Transform node
+constexpr int TRANSFORM_PARTS = 3; // pixel split of a Transform node (<= 64 pixels per pass)
 constexpr int POOL_PARTS = 4;      // channel split of an attention-pooling job
 
 struct Program {
