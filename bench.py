@@ -37,6 +37,9 @@ def parse():
     ap.add_argument('--config', type=int, default=2, choices=(2, 3),
                     help='2: fixed gt layouts (metric config); 3: greedy decoder layouts')
     ap.add_argument('--batch', type=int, default=64)
+    ap.add_argument('--streams', type=int, default=1,
+                    help='independent batches in flight per GPU (one host thread + HIP stream + '
+                         'forked context each; weights shared)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     return ap.parse_args()
@@ -106,22 +109,51 @@ def main():
         gts.append(torch.as_tensor(synth.template_layout_batch(d, offset=i)).to(dev))
     use_gt = args.config == 2
 
-    def step(i):
+    S = max(1, args.streams)
+    engines = [eng] + [eng.fork() for _ in range(S - 1)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [None]
+
+    def step(i, e=eng):
         b = batches[i % n_batches]
-        return eng.forward(b, use_gt_layout=use_gt, gt_layout=gts[i % n_batches] if use_gt else None)
+        return e.forward(b, use_gt_layout=use_gt, gt_layout=gts[i % n_batches] if use_gt else None)
 
     def sync_all():
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
 
-    for i in range(args.warmup):
-        step(i)
+    def run_steps(first, count):
+        """`count` steps starting at global index `first`, spread round-robin over S workers."""
+        if S == 1:
+            for i in range(first, first + count):
+                step(i)
+            return
+        import threading
+        errs = []
+
+        def worker(k):
+            try:
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(streams[k]):
+                    for i in range(first + k, first + count, S):
+                        step(i, engines[k])
+                    streams[k].synchronize()
+            except Exception as ex:   # surface worker failures instead of hanging
+                errs.append(ex)
+
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(S)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errs:
+            raise errs[0]
+
+    run_steps(0, args.warmup)
     sync_all()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    run_steps(args.warmup, args.steps)
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -147,7 +179,7 @@ def main():
                                     'decoder)' if use_gt else 'layouts sampled by the greedy seq2seq '
                                     'decoder', d.N),
                        'global_batch': world * d.N, 'parallelism': 'dp%d (question-sharded, no '
-                       'data-path collective)' % world, 'streams_per_gpu': 1,
+                       'data-path collective)' % world, 'streams_per_gpu': S,
                        'host_sync': 'predicted_tokens D2H between phase 1 and phase 2'},
         }
 

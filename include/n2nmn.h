@@ -75,6 +75,10 @@ const char *n2nmn_version(void);
  *     (exp_clevr/eval_clevr.py:18-20,90-91; models_clevr/nmn3_modules.py:11-47).
  * ---------------------------------------------------------------------------------------- */
 int n2nmn_ctx_create(const n2nmn_dims *dims, int device, n2nmn_ctx **out);
+/* A second context on the same device that SHARES the weight store of `parent` (committed through
+ * the parent) and owns only its workspace: several batches in flight on different streams / host
+ * threads without duplicating the weights in HBM and L2.  The parent must outlive its forks. */
+int n2nmn_ctx_fork(n2nmn_ctx *parent, n2nmn_ctx **out);
 int n2nmn_ctx_destroy(n2nmn_ctx *ctx);
 int n2nmn_ctx_dims(const n2nmn_ctx *ctx, n2nmn_dims *out);
 

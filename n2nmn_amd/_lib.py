@@ -48,6 +48,7 @@ SYMBOLS = [
     ('n2nmn_last_error', C.c_char_p, []),
     ('n2nmn_version', C.c_char_p, []),
     ('n2nmn_ctx_create', _I, [C.POINTER(Dims), _I, C.POINTER(_P)]),
+    ('n2nmn_ctx_fork', _I, [_P, C.POINTER(_P)]),
     ('n2nmn_ctx_destroy', _I, [_P]),
     ('n2nmn_ctx_dims', _I, [_P, C.POINTER(Dims)]),
     ('n2nmn_set_weight', _I, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), _I]),

@@ -70,8 +70,17 @@ struct n2nmn_ctx {
   bool committed = false;
   bool have_tables = false;
 
-  char* base = nullptr;
+  char* base = nullptr;        // weight store (owned by the root context only)
   size_t bytes = 0;
+  char* ws_base = nullptr;     // workspace (every context owns its own)
+  size_t ws_bytes = 0;
+  n2nmn_ctx* parent = nullptr; // forked contexts share the parent's weight store
+  // pinned staging ring for the program upload (nodes + tables)
+  static constexpr int kStage = 4;
+  char* stage[kStage] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t stage_ev[kStage] = {nullptr, nullptr, nullptr, nullptr};
+  size_t stage_bytes = 0;
+  int stage_next = 0;
 
   int Mp = 0, HWp = 0, KpE = 0, KpL = 0, KpD = 0;
   int max_nodes = 0, max_text = 0, max_pool = 0;
@@ -116,6 +125,10 @@ struct n2nmn_ctx {
 };
 
 namespace n2nmn {
+
+static const n2nmn_ctx* root(const n2nmn_ctx* c) { return c->parent ? c->parent : c; }
+static bool is_committed(const n2nmn_ctx* c) { return root(c)->committed; }
+static bool has_tables(const n2nmn_ctx* c) { return root(c)->have_tables; }
 
 static void add_var(n2nmn_ctx* c, const std::string& name, std::vector<int64_t> shape) {
   Var v;
@@ -202,8 +215,8 @@ struct Carver {
   }
 };
 
-// lays out every buffer of the context; with base == nullptr only computes the size
-static size_t carve(n2nmn_ctx* c, char* base) {
+// lays out the weight store (mirrors, packed operands, tables); base == nullptr: size only
+static size_t carve_weights(n2nmn_ctx* c, char* base) {
   const n2nmn_dims& d = c->d;
   const size_t L = d.lstm_dim, E = d.embed_dim_txt, N = d.N, T = d.T_encoder, Td = d.T_decoder,
                V = d.num_vocab_nmn, Vt = d.num_vocab_txt, D = d.D, HW = (size_t)d.H * d.W;
@@ -231,6 +244,17 @@ static size_t carve(n2nmn_ctx* c, char* base) {
   c->P = k.take<int32_t>(V * 3);
   c->Wv = k.take<int32_t>(3 * V * 4);
   c->bv = k.take<int32_t>(V * 4);
+  (void)N; (void)T; (void)Td; (void)HW; (void)HWp;
+  return align_up(k.off, 256);
+}
+
+// lays out the per-context workspace (activations, module arena, program tables)
+static size_t carve_workspace(n2nmn_ctx* c, char* base) {
+  const n2nmn_dims& d = c->d;
+  const size_t L = d.lstm_dim, E = d.embed_dim_txt, N = d.N, T = d.T_encoder, Td = d.T_decoder,
+               HW = (size_t)d.H * d.W;
+  const size_t Mp = c->Mp, HWp = c->HWp;
+  Carver k(base);
   // recurrent state: one contiguous block so the encoder can clear it with one memset
   float* st = k.take<float>(6 * N * L);
   c->eh0[0] = st; c->eh0[1] = st + N * L; c->eh1[0] = st + 2 * N * L; c->eh1[1] = st + 3 * N * L;
@@ -259,7 +283,6 @@ static size_t carve(n2nmn_ctx* c, char* base) {
   c->mfsp = k.take<float>(N * HW * Mp);
   c->dev_nodes = k.take<DevNode>(c->max_nodes);
   c->dev_tab = k.take<int32_t>(c->max_tab);
-  (void)D;
   return align_up(k.off, 256);
 }
 
@@ -330,7 +353,7 @@ static void rowmajor_a(const n2nmn_ctx* c, LstmJob& j) {
 
 static int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s) {
   const n2nmn_dims& d = c->d;
-  N2_REQUIRE(c->committed, N2NMN_ENOWEIGHT, "encoder_forward: weights not committed");
+  N2_REQUIRE(is_committed(c), N2NMN_ENOWEIGHT, "encoder_forward: weights not committed");
   N2_REQUIRE(io && io->input_seq && io->seq_length, N2NMN_EINVAL, "encoder_forward: null input");
   const int T = io->T_enc, N = io->N, L = d.lstm_dim;
   N2_REQUIRE(T >= 1 && T <= d.T_encoder && N >= 1 && N <= d.N, N2NMN_ECAPACITY,
@@ -396,8 +419,8 @@ static int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s)
 
 static int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s) {
   const n2nmn_dims& d = c->d;
-  N2_REQUIRE(c->committed, N2NMN_ENOWEIGHT, "decoder_forward: weights not committed");
-  N2_REQUIRE(c->have_tables, N2NMN_ENOWEIGHT,
+  N2_REQUIRE(is_committed(c), N2NMN_ENOWEIGHT, "decoder_forward: weights not committed");
+  N2_REQUIRE(has_tables(c), N2NMN_ENOWEIGHT,
              "decoder_forward: validity tables (assembler P/W/b) not set");
   N2_REQUIRE(io, N2NMN_EINVAL, "decoder_forward: null io");
   N2_REQUIRE(c->enc_T > 0 && io->N == c->enc_N && io->T_enc == c->enc_T, N2NMN_EINVAL,
@@ -529,7 +552,7 @@ static int run_program(n2nmn_ctx* c, Program& p, const float* feat, const float*
                        int N_full, float* scores, const float* ext0, const float* ext1,
                        float* att_out, int att_out_first, int att_out_count, hipStream_t s) {
   const n2nmn_dims& d = c->d;
-  N2_REQUIRE(c->committed, N2NMN_ENOWEIGHT, "execute_program: weights not committed");
+  N2_REQUIRE(is_committed(c), N2NMN_ENOWEIGHT, "execute_program: weights not committed");
   N2_REQUIRE(N_full >= 1 && N_full <= d.N, N2NMN_ECAPACITY, "execute_program: N_full > capacity");
   const int nn = (int)p.dev_nodes.size();
   N2_REQUIRE(nn <= c->max_nodes && p.num_text <= c->max_text && p.num_pool <= c->max_pool &&
@@ -542,11 +565,21 @@ static int run_program(n2nmn_ctx* c, Program& p, const float* feat, const float*
   if (scores && p.num_rows > 0)
     N2_HIP(hipMemsetAsync(scores, 0, sizeof(float) * (size_t)p.num_rows * C, s));  // INVALID_EXPR
   if (nn == 0) return N2NMN_OK;
-  N2_HIP(hipMemcpyAsync(c->dev_nodes, p.dev_nodes.data(), sizeof(DevNode) * nn,
-                        hipMemcpyHostToDevice, s));
-  if (!p.tab.empty())
-    N2_HIP(hipMemcpyAsync(c->dev_tab, p.tab.data(), sizeof(int32_t) * p.tab.size(),
-                          hipMemcpyHostToDevice, s));
+  {
+    // nodes + tables travel through a pinned staging slot so the upload is truly asynchronous;
+    // a slot is reused only after the copy that last read it has completed
+    const size_t nb = sizeof(DevNode) * nn, tb = sizeof(int32_t) * p.tab.size();
+    const int slot = c->stage_next;
+    c->stage_next = (slot + 1) % n2nmn_ctx::kStage;
+    N2_HIP(hipEventSynchronize(c->stage_ev[slot]));
+    std::memcpy(c->stage[slot], p.dev_nodes.data(), nb);
+    if (tb) std::memcpy(c->stage[slot] + align_up(nb, 256), p.tab.data(), tb);
+    N2_HIP(hipMemcpyAsync(c->dev_nodes, c->stage[slot], nb, hipMemcpyHostToDevice, s));
+    if (tb)
+      N2_HIP(hipMemcpyAsync(c->dev_tab, c->stage[slot] + align_up(nb, 256), tb,
+                            hipMemcpyHostToDevice, s));
+    N2_HIP(hipEventRecord(c->stage_ev[slot], s));
+  }
   // externally supplied attention maps (module_forward): node i <- ext[time_idx][batch_idx]
   for (int i = 0; i < nn; ++i) {
     const DevNode& nd = p.dev_nodes[i];
@@ -638,6 +671,42 @@ static int run_program(n2nmn_ctx* c, Program& p, const float* feat, const float*
   return check_launch("execute_program");
 }
 
+static int finish_create(n2nmn_ctx* c, n2nmn_ctx* parent) {
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) { set_last_error(std::string("hipSetDevice: ") + hipGetErrorString(e)); return N2NMN_EHIP; }
+  if (parent) {
+    c->parent = parent;
+    carve_weights(c, parent->base);           // same layout -> same pointers as the parent
+    for (size_t i = 0; i < c->vars.size(); ++i) c->vars[i].set = true;
+  } else {
+    c->bytes = carve_weights(c, nullptr);
+    e = hipMalloc(reinterpret_cast<void**>(&c->base), c->bytes);
+    if (e != hipSuccess) {
+      set_last_error(std::string("ctx_create: hipMalloc of ") + std::to_string(c->bytes) +
+                     " bytes failed: " + hipGetErrorString(e));
+      return N2NMN_EHIP;
+    }
+    carve_weights(c, c->base);
+  }
+  c->ws_bytes = carve_workspace(c, nullptr);
+  e = hipMalloc(reinterpret_cast<void**>(&c->ws_base), c->ws_bytes);
+  if (e != hipSuccess) {
+    set_last_error(std::string("ctx_create: hipMalloc of ") + std::to_string(c->ws_bytes) +
+                   " bytes failed: " + hipGetErrorString(e));
+    if (!parent && c->base) (void)hipFree(c->base);
+    return N2NMN_EHIP;
+  }
+  carve_workspace(c, c->ws_base);
+  c->stage_bytes = align_up(sizeof(DevNode) * (size_t)c->max_nodes, 256) +
+                   sizeof(int32_t) * (size_t)c->max_tab;
+  for (int i = 0; i < n2nmn_ctx::kStage; ++i) {
+    N2_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->stage[i]), c->stage_bytes, 0));
+    N2_HIP(hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming));
+  }
+  if (n2nmn_program_create(&c->scratch_prog) != N2NMN_OK) return N2NMN_EINVAL;
+  return N2NMN_OK;
+}
+
 }  // namespace n2nmn
 
 // =============================================================================================
@@ -678,28 +747,40 @@ int n2nmn_ctx_create(const n2nmn_dims* dims, int device, n2nmn_ctx** out) {
   c->max_text = c->max_nodes;
   c->max_pool = c->max_nodes;
   c->max_tab = c->max_nodes * 16 + 4096;
-  c->bytes = carve(c, nullptr);
-  hipError_t e = hipSetDevice(device);
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->base), c->bytes);
-  if (e != hipSuccess) {
-    set_last_error(std::string("ctx_create: hipMalloc of ") + std::to_string(c->bytes) +
-                   " bytes failed: " + hipGetErrorString(e));
-    delete c;
-    return N2NMN_EHIP;
-  }
-  carve(c, c->base);
-  if (n2nmn_program_create(&c->scratch_prog) != N2NMN_OK) {
-    (void)hipFree(c->base);
-    delete c;
-    return N2NMN_EINVAL;
-  }
+  int rc = finish_create(c, nullptr);
+  if (rc != N2NMN_OK) { delete c; return rc; }
+  *out = c;
+  return N2NMN_OK;
+}
+
+/* A second context on the same device that SHARES the weight store of `parent` (mirrors, packed
+ * operands, validity tables: committed through the parent) and owns only its workspace.  Lets
+ * several batches be in flight on different streams / host threads without duplicating the
+ * weights in HBM and L2.  The parent must outlive its forks. */
+int n2nmn_ctx_fork(n2nmn_ctx* parent, n2nmn_ctx** out) {
+  N2_REQUIRE(parent && out, N2NMN_EINVAL, "ctx_fork: null argument");
+  N2_REQUIRE(!parent->parent, N2NMN_EINVAL, "ctx_fork: fork the root context");
+  n2nmn_ctx* c = new (std::nothrow) n2nmn_ctx();
+  N2_REQUIRE(c, N2NMN_EINVAL, "ctx_fork: out of host memory");
+  c->d = parent->d; c->device = parent->device;
+  build_vars(c);
+  c->Mp = parent->Mp; c->HWp = parent->HWp; c->KpE = parent->KpE; c->KpL = parent->KpL;
+  c->KpD = parent->KpD; c->max_nodes = parent->max_nodes; c->max_text = parent->max_text;
+  c->max_pool = parent->max_pool; c->max_tab = parent->max_tab;
+  int rc = finish_create(c, parent);
+  if (rc != N2NMN_OK) { delete c; return rc; }
   *out = c;
   return N2NMN_OK;
 }
 
 int n2nmn_ctx_destroy(n2nmn_ctx* ctx) {
   if (!ctx) return N2NMN_OK;
-  if (ctx->base) (void)hipFree(ctx->base);
+  if (ctx->base && !ctx->parent) (void)hipFree(ctx->base);
+  if (ctx->ws_base) (void)hipFree(ctx->ws_base);
+  for (int i = 0; i < n2nmn_ctx::kStage; ++i) {
+    if (ctx->stage[i]) (void)hipHostFree(ctx->stage[i]);
+    if (ctx->stage_ev[i]) (void)hipEventDestroy(ctx->stage_ev[i]);
+  }
   for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
   n2nmn_program_destroy(ctx->scratch_prog);
   delete ctx;
@@ -728,6 +809,7 @@ int n2nmn_variable_info(const n2nmn_ctx* ctx, int i, const char** name, int64_t 
 int n2nmn_set_weight(n2nmn_ctx* ctx, const char* name, const float* data, const int64_t* shape,
                      int ndim) {
   N2_REQUIRE(ctx && name && data && shape, N2NMN_EINVAL, "set_weight: null argument");
+  N2_REQUIRE(!ctx->parent, N2NMN_EINVAL, "set_weight: forked contexts share the parent's weights");
   auto it = ctx->index.find(name);
   if (it == ctx->index.end()) {
     set_last_error(std::string("set_weight: unknown variable '") + name + "'");
@@ -753,6 +835,7 @@ int n2nmn_set_weight(n2nmn_ctx* ctx, const char* name, const float* data, const 
 int n2nmn_set_validity_tables(n2nmn_ctx* ctx, const int32_t* P_host, const int32_t* W_host,
                               const int32_t* b_host) {
   N2_REQUIRE(ctx && P_host && W_host && b_host, N2NMN_EINVAL, "set_validity_tables: null argument");
+  N2_REQUIRE(!ctx->parent, N2NMN_EINVAL, "set_validity_tables: set them on the root context");
   const int V = ctx->d.num_vocab_nmn;
   N2_HIP(hipMemcpy(ctx->P, P_host, sizeof(int32_t) * V * 3, hipMemcpyHostToDevice));
   N2_HIP(hipMemcpy(ctx->Wv, W_host, sizeof(int32_t) * 3 * V * 4, hipMemcpyHostToDevice));
@@ -763,6 +846,7 @@ int n2nmn_set_validity_tables(n2nmn_ctx* ctx, const int32_t* P_host, const int32
 
 int n2nmn_commit_weights(n2nmn_ctx* c, n2nmn_stream stream) {
   N2_REQUIRE(c, N2NMN_EINVAL, "commit_weights: null context");
+  N2_REQUIRE(!c->parent, N2NMN_EINVAL, "commit_weights: commit through the root context");
   for (const Var& v : c->vars)
     if (!v.set) {
       set_last_error("commit_weights: variable never set: " + v.name);
@@ -928,7 +1012,7 @@ int n2nmn_debug_lstm_bench(n2nmn_ctx* c, int variant, int rows_per_wg, int njobs
                            double* us, n2nmn_stream stream) {
   const int layout = variant < 10;       // variant >= 10: row-major h (A/B against the packed state)
   variant %= 10;
-  N2_REQUIRE(c && us && c->committed, N2NMN_EINVAL, "debug_lstm_bench: bad argument");
+  N2_REQUIRE(c && us && is_committed(c), N2NMN_EINVAL, "debug_lstm_bench: bad argument");
   N2_REQUIRE(N >= 1 && N <= c->d.N && iters >= 1, N2NMN_EINVAL, "debug_lstm_bench: bad size");
   hipStream_t s = S(stream);
   const int L = c->d.lstm_dim;

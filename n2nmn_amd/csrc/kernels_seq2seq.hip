@@ -66,7 +66,27 @@ __device__ __forceinline__ void lstm_mma(const LstmJob& jb, int N, int L, int ti
                       (size_t)((kbeg >> 2) + kg) * 16 + ci;
   float4 bq[NCH];
   float4 aq[NCH][MT];
-  if (DBG == 3 || DBG == 4) {
+  if (DBG == 6 || DBG == 7) {            // 6: weight (B) loads only; 7: state (A) loads only
+    const float f = (float)lane * 1e-3f;
+#pragma unroll
+    for (int kc = 0; kc < NCH; ++kc) {
+      bq[kc] = DBG == 6 ? Wp4[(size_t)((kc + rot) & (NCH - 1)) * 64] : make_float4(f, f, f, f);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) aq[kc][m] = make_float4(f, f - 1.f, f - 2.f, f - 3.f);
+    }
+    if (DBG == 7) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        int r = row0 + 16 * m + ci;
+        r = r < N ? r : N - 1;
+        const float* ar = Asrc + (size_t)r * jb.a_rs + (size_t)((kloc >> 2) + kg) * jb.a_ks;
+#pragma unroll
+        for (int kc = 0; kc < NCH; ++kc)
+          aq[kc][m] = *reinterpret_cast<const float4*>(
+              ar + (size_t)(4 * ((kc + rot) & (NCH - 1))) * jb.a_ks);
+      }
+    }
+  } else if (DBG == 3 || DBG == 4) {
     const float f = (float)lane * 1e-3f;
 #pragma unroll
     for (int kc = 0; kc < NCH; ++kc) {
@@ -75,21 +95,26 @@ __device__ __forceinline__ void lstm_mma(const LstmJob& jb, int N, int L, int ti
       for (int m = 0; m < MT; ++m) aq[kc][m] = make_float4(f, f - 1.f, f - 2.f, f - 3.f);
     }
   } else {
-#pragma unroll
-    for (int kc = 0; kc < NCH; ++kc) bq[kc] = Wp4[(size_t)((kc + rot) & (NCH - 1)) * 64];
+    // chunk-major issue order: the five operand loads of chunk 0 go first, so its MFMAs can start
+    // after one round trip while the later chunks are still in flight
+    const float* ar[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       int r = row0 + 16 * m + ci;
       r = r < N ? r : N - 1;
-      const float* ar = Asrc + (size_t)r * jb.a_rs + (size_t)((kloc >> 2) + kg) * jb.a_ks;
+      ar[m] = Asrc + (size_t)r * jb.a_rs + (size_t)((kloc >> 2) + kg) * jb.a_ks;
+    }
 #pragma unroll
-      for (int kc = 0; kc < NCH; ++kc)
-        aq[kc][m] = *reinterpret_cast<const float4*>(
-            ar + (size_t)(4 * ((kc + rot) & (NCH - 1))) * jb.a_ks);
+    for (int kc = 0; kc < NCH; ++kc) {
+      const int kq = (kc + rot) & (NCH - 1);
+      bq[kc] = Wp4[(size_t)kq * 64];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        aq[kc][m] = *reinterpret_cast<const float4*>(ar[m] + (size_t)(4 * kq) * jb.a_ks);
     }
   }
   if (DBG == 1) __builtin_amdgcn_sched_barrier(0);   // all loads issued before the first MFMA
-  if (DBG == 2 || DBG == 4) {                        // no MFMA: fold the operands so they stay live
+  if (DBG == 2 || DBG == 4 || DBG == 6 || DBG == 7) {  // no MFMA: fold the operands so they stay live
 #pragma unroll
     for (int kc = 0; kc < NCH; ++kc)
 #pragma unroll
@@ -555,6 +580,8 @@ void launch_lstm_step_dbg(const LstmJob* jobs, int njobs, int N, int L, int rows
       case 2: hipLaunchKernelGGL((lstm_step_kernel<4, 2>), g4, b, 0, s, js, N, L); break;
       case 3: hipLaunchKernelGGL((lstm_step_kernel<4, 3>), g4, b, 0, s, js, N, L); break;
       case 4: hipLaunchKernelGGL((lstm_step_kernel<4, 4>), g4, b, 0, s, js, N, L); break;
+      case 6: hipLaunchKernelGGL((lstm_step_kernel<4, 6>), g4, b, 0, s, js, N, L); break;
+      case 7: hipLaunchKernelGGL((lstm_step_kernel<4, 7>), g4, b, 0, s, js, N, L); break;
       default: hipLaunchKernelGGL((lstm_step_kernel<4, 0>), g4, b, 0, s, js, N, L); break;
     }
   }

@@ -21,7 +21,7 @@ def _torch():
 
 
 class Engine:
-    def __init__(self, dims: Dims, assembler: Assembler, device: int = 0):
+    def __init__(self, dims: Dims, assembler: Assembler, device: int = 0, _parent=None):
         torch = _torch()
         if not torch.cuda.is_available():
             raise RuntimeError('n2nmn_amd.Engine needs a HIP device (no CPU fallback exists)')
@@ -33,6 +33,11 @@ class Engine:
         self._lib = _lib.lib()
         cd = _lib.Dims(**{k: int(v) for k, v in dims.asdict().items()})
         self._ctx = C.c_void_p()
+        self._bufs: Dict[tuple, object] = {}
+        self._parent = _parent
+        if _parent is not None:
+            _lib.check(self._lib.n2nmn_ctx_fork(_parent._ctx, C.byref(self._ctx)))
+            return
         _lib.check(self._lib.n2nmn_ctx_create(C.byref(cd), device, C.byref(self._ctx)))
         P = np.ascontiguousarray(assembler.P, np.int32)
         W = np.ascontiguousarray(assembler.W, np.int32)
@@ -48,6 +53,11 @@ class Engine:
                 self._lib.n2nmn_ctx_destroy(ctx)
             except Exception:
                 pass
+
+    def fork(self) -> 'Engine':
+        """A sibling engine sharing this engine's weights with its own workspace, for running
+        another batch concurrently on another stream / host thread."""
+        return Engine(self.dims, self.assembler, self.device.index, _parent=self)
 
     # ------------------------------------------------------------------------------------
     def stream(self) -> int:
