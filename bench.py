@@ -37,12 +37,33 @@ def parse():
     ap.add_argument('--config', type=int, default=2, choices=(2, 3),
                     help='2: fixed gt layouts (metric config); 3: greedy decoder layouts')
     ap.add_argument('--batch', type=int, default=64)
-    ap.add_argument('--streams', type=int, default=1,
+    ap.add_argument('--streams', type=int, default=4,
                     help='independent batches in flight per GPU (one host thread + HIP stream + '
                          'forked context each; weights shared)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     return ap.parse_args()
+
+
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+PMC_KERNEL = {'lstm_step': 'lstm_step_kernel<4, 0>', 'dec_attn': 'dec_attn_kernel<256>',
+              'gemm_pk': 'gemm_pk_kernel', 'att_ops': 'att_ops_kernel', 'pool': 'pool_kernel',
+              'textmap': 'textmap_kernel', 'heads': 'heads_kernel', 'word_vecs': 'word_vecs_kernel'}
+
+
+def pmc_traffic(family):
+    """HBM bytes per launch of the kernel behind a profiler family, from the committed rocprofv3
+    PMC passes (tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE runs of this same bench
+    command, gfx950 x2 read correction).  PMC counters cannot be read inside the timed run."""
+    try:
+        data = json.load(open(PMC_FILE))['kernels']
+        for prefix, kname in PMC_KERNEL.items():
+            if family.startswith(prefix) and kname in data:
+                return data[kname]['hbm_bytes_per_launch'], \
+                    'profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)'
+    except Exception:
+        pass
+    return None, None
 
 
 def cpu_baseline(d, w, batch, gt, names, use_gt):
@@ -74,18 +95,12 @@ def main():
     args = parse()
     import numpy as np
     import torch
-    import torch.distributed as dist
 
-    rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local_rank))
+    from n2nmn_amd.dp import DataParallel
+    dp = DataParallel(backend='nccl', device=torch.device('cuda', local_rank))
+    rank, world = dp.rank, dp.world
 
     from n2nmn_amd import synth
     from n2nmn_amd.engine import Engine
@@ -104,7 +119,7 @@ def main():
     n_batches = 4
     batches, gts = [], []
     for i in range(n_batches):
-        b = synth.make_inputs(d, seed=rank * 1000 + i)
+        b = synth.make_inputs(d, seed=dp.batch_seed(i))
         batches.append({k: torch.as_tensor(v).to(dev) for k, v in b.items()})
         gts.append(torch.as_tensor(synth.template_layout_batch(d, offset=i)).to(dev))
     use_gt = args.config == 2
@@ -116,11 +131,6 @@ def main():
     def step(i, e=eng):
         b = batches[i % n_batches]
         return e.forward(b, use_gt_layout=use_gt, gt_layout=gts[i % n_batches] if use_gt else None)
-
-    def sync_all():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
 
     def run_steps(first, count):
         """`count` steps starting at global index `first`, spread round-robin over S workers."""
@@ -150,21 +160,13 @@ def main():
             raise errs[0]
 
     run_steps(0, args.warmup)
-    sync_all()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    run_steps(args.warmup, args.steps)
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # barrier + synchronize on both sides of EXACTLY `steps` steps; max over ranks
+    elapsed = dp.timed(lambda: run_steps(args.warmup, args.steps),
+                       sync=lambda: torch.cuda.synchronize(dev))
 
     out = None
     if rank == 0:
-        qps = world * d.N * args.steps / elapsed
+        qps = dp.throughput(d.N * args.steps, elapsed)
         out = {
             'metric': 'questions/sec (forward) on CLEVR 10x15x512 feats, batch 64',
             'value': round(qps, 1), 'unit': 'questions/sec', 'n_gpus': world,
@@ -182,6 +184,20 @@ def main():
                        'data-path collective)' % world, 'streams_per_gpu': S,
                        'host_sync': 'predicted_tokens D2H between phase 1 and phase 2'},
         }
+
+    # ---- the same workload with ONE batch in flight (latency-oriented number)
+    if rank == 0 and S > 1:
+        S_saved, S = S, 1
+        n1 = min(args.steps, 100)
+        run_steps(0, 10)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        run_steps(10, n1)
+        torch.cuda.synchronize(dev)
+        e1 = time.perf_counter() - t0
+        S = S_saved
+        out['single_stream'] = {'value': round(d.N * n1 / e1, 1), 'unit': 'questions/sec',
+                                'ms_per_step': round(1e3 * e1 / n1, 4), 'steps': n1}
 
     # ---- per-kernel roofline: HIP events around every launch, separate pass of the same steps
     if rank == 0 and not args.no_profile:
@@ -209,9 +225,11 @@ def main():
                          'frac': round(ach / peak, 4)})
         rows.sort(key=lambda r: -r['us_per_step'])
         dom = rows[0]
+        traffic, traffic_src = pmc_traffic(dom['kernel'])
         out['roofline'] = {'kernel': dom['kernel'], 'bound': dom['bound'],
                            'achieved': dom['achieved'], 'peak': dom['peak'], 'unit': dom['unit'],
-                           'frac': dom['frac'], 'traffic': None, 'avg_us': dom['avg_us'],
+                           'frac': dom['frac'], 'traffic': traffic, 'traffic_source': traffic_src,
+                           'avg_us': dom['avg_us'],
                            'measured': 'hipEvent pairs around each launch on the launch stream, '
                                        'separate pass of %d steps right after the timed region'
                                        % ksteps}
@@ -225,9 +243,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    dp.close()
 
 
 if __name__ == '__main__':
