@@ -100,6 +100,8 @@ struct n2nmn_ctx {
   // seq2seq workspace
   float *eh0[2] = {nullptr, nullptr}, *eh1[2] = {nullptr, nullptr}, *ec0 = nullptr, *ec1 = nullptr;
   float *dh0[2] = {nullptr, nullptr}, *dh1[2] = {nullptr, nullptr}, *dc0 = nullptr, *dc1 = nullptr;
+  float *fc0 = nullptr, *fh0 = nullptr, *fc1 = nullptr, *fh1 = nullptr;
+  int32_t *perm = nullptr, *nact = nullptr;
   float *enc_out = nullptr, *eht = nullptr, *qbuf = nullptr, *dec_h1_all = nullptr, *ent_t = nullptr, *dh1_rm = nullptr;
   int32_t *state = nullptr, *next_idx = nullptr, *tokens = nullptr;
   float *tprobs = nullptr, *negent = nullptr, *atts = nullptr, *word_vecs = nullptr;
@@ -256,9 +258,13 @@ static size_t carve_workspace(n2nmn_ctx* c, char* base) {
   const size_t Mp = c->Mp, HWp = c->HWp;
   Carver k(base);
   // recurrent state: one contiguous block so the encoder can clear it with one memset
-  float* st = k.take<float>(6 * N * L);
+  float* st = k.take<float>(10 * N * L);
   c->eh0[0] = st; c->eh0[1] = st + N * L; c->eh1[0] = st + 2 * N * L; c->eh1[1] = st + 3 * N * L;
   c->ec0 = st + 4 * N * L; c->ec1 = st + 5 * N * L;
+  // final encoder state in ORIGINAL row order (written at each row's last valid step)
+  c->fc0 = st + 6 * N * L; c->fh0 = st + 7 * N * L; c->fc1 = st + 8 * N * L; c->fh1 = st + 9 * N * L;
+  c->perm = k.take<int32_t>(N);
+  c->nact = k.take<int32_t>(T + 1);
   float* ds = k.take<float>(6 * N * L);
   c->dh0[0] = ds; c->dh0[1] = ds + N * L; c->dh1[0] = ds + 2 * N * L; c->dh1[1] = ds + 3 * N * L;
   c->dc0 = ds + 4 * N * L; c->dc1 = ds + 5 * N * L;
@@ -358,7 +364,8 @@ static int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s)
   const int T = io->T_enc, N = io->N, L = d.lstm_dim;
   N2_REQUIRE(T >= 1 && T <= d.T_encoder && N >= 1 && N <= d.N, N2NMN_ECAPACITY,
              "encoder_forward: T_enc / N exceed the context capacity");
-  N2_HIP(hipMemsetAsync(c->eh0[0], 0, sizeof(float) * 6 * (size_t)d.N * L, s));
+  N2_HIP(hipMemsetAsync(c->eh0[0], 0, sizeof(float) * 10 * (size_t)d.N * L, s));
+  launch_enc_prepare(io->seq_length, N, T, c->perm, c->nact, s);
   const float* W0x_bias_table = c->enc_xtab;
   // software-pipelined over time: launch k runs layer-0 step k and layer-1 step k-1
   for (int k = 0; k <= T; ++k) {
@@ -372,6 +379,7 @@ static int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s)
     j0.bias = nullptr; j0.c_in = c->ec0; j0.c_out = c->ec0; j0.ntiles = L / 4;
     j0.h_old = c->eh0[(k + 1) & 1]; j0.h_new = c->eh0[k & 1];
     j0.out_seq = nullptr; j0.seq_len = io->seq_length; j0.t = k;
+    j0.perm = c->perm; j0.n_active = c->nact + (k < T ? k : T - 1); j0.fin_c = c->fc0; j0.fin_h = c->fh0;
     LstmJob& j1 = jobs[1];
     j1 = LstmJob{};
     const int st = k - 1;
@@ -383,6 +391,7 @@ static int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s)
     j1.h_old = c->eh1[(st + 1) & 1]; j1.h_new = c->eh1[st & 1];
     j1.out_seq = st >= 0 ? c->enc_out + (size_t)st * N * L : nullptr;
     j1.seq_len = io->seq_length; j1.t = st;
+    j1.perm = c->perm; j1.n_active = c->nact + (st >= 0 ? st : 0); j1.fin_c = c->fc1; j1.fin_h = c->fh1;
     {
       const double fl = 2.0 * N * 4 * L * ((j0.active ? L : 0) + (j1.active ? 2 * L : 0));
       const double by = 4.0 * ((j0.active ? (double)L * 4 * L + 3.0 * N * L : 0) +
@@ -407,12 +416,11 @@ static int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s)
   if (io->encoder_h_transformed)
     N2_HIP(hipMemcpyAsync(io->encoder_h_transformed, c->eht, nl * T, hipMemcpyDeviceToDevice, s));
   if (io->encoder_states) {
-    const int pe = (T - 1) & 1;
-    N2_HIP(hipMemcpyAsync(io->encoder_states, c->ec0, nl, hipMemcpyDeviceToDevice, s));
-    launch_unpack_h(c->eh0[pe], io->encoder_states + (size_t)N * L, N, L, d.N, s);
-    N2_HIP(hipMemcpyAsync(io->encoder_states + (size_t)2 * N * L, c->ec1, nl,
+    N2_HIP(hipMemcpyAsync(io->encoder_states, c->fc0, nl, hipMemcpyDeviceToDevice, s));
+    launch_unpack_h(c->fh0, io->encoder_states + (size_t)N * L, N, L, d.N, s);
+    N2_HIP(hipMemcpyAsync(io->encoder_states + (size_t)2 * N * L, c->fc1, nl,
                           hipMemcpyDeviceToDevice, s));
-    launch_unpack_h(c->eh1[pe], io->encoder_states + (size_t)3 * N * L, N, L, d.N, s);
+    launch_unpack_h(c->fh1, io->encoder_states + (size_t)3 * N * L, N, L, d.N, s);
   }
   return check_launch("encoder_forward");
 }
@@ -434,7 +442,6 @@ static int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s)
   float* negent = io->neg_entropy ? io->neg_entropy : c->negent;
   float* atts = io->atts ? io->atts : c->atts;
   float* wv = io->word_vecs ? io->word_vecs : c->word_vecs;
-  const int pe = (T - 1) & 1;
   const double fl0 = 2.0 * N * L * 4 * L, by0 = 4.0 * ((double)L * 4 * L + 3.0 * N * L);
   const double fl1 = 2.0 * N * 2 * L * 4 * L, by1 = 4.0 * (2.0 * L * 4 * L + 5.0 * N * L);
   DecStepArgs a{};
@@ -455,19 +462,19 @@ static int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s)
       j0 = LstmJob{};
       j0.active = k < Td;
       packed_state(c, j0);
-      j0.A0 = k == 0 ? c->eh0[pe] : c->dh0[(k + 1) & 1]; j0.K = L; j0.Wp = c->dec_W0h_t;
+      j0.A0 = k == 0 ? c->fh0 : c->dh0[(k + 1) & 1]; j0.K = L; j0.Wp = c->dec_W0h_t;
       j0.ntiles = L / 4; j0.xtab = c->dec_xtab;
       j0.xidx = k == 0 ? nullptr : io->gt_layout + (size_t)(k - 1) * N; j0.xidx_const = V;
-      j0.c_in = k == 0 ? c->ec0 : c->dc0; j0.c_out = c->dc0;
+      j0.c_in = k == 0 ? c->fc0 : c->dc0; j0.c_out = c->dc0;
       j0.h_old = j0.A0; j0.h_new = c->dh0[k & 1];
       LstmJob& j1 = jobs[1];
       j1 = LstmJob{};
       const int st = k - 1;
       j1.active = st >= 0;
       packed_state(c, j1);
-      j1.A0 = c->dh0[st & 1]; j1.A1 = st == 0 ? c->eh1[pe] : c->dh1[(st + 1) & 1];
+      j1.A0 = c->dh0[st & 1]; j1.A1 = st == 0 ? c->fh1 : c->dh1[(st + 1) & 1];
       j1.K = 2 * L; j1.Wp = c->dec_W1_t; j1.ntiles = L / 4; j1.bias = c->vars[V_DEC_B1].mirror;
-      j1.c_in = st == 0 ? c->ec1 : c->dc1; j1.c_out = c->dc1;
+      j1.c_in = st == 0 ? c->fc1 : c->dc1; j1.c_out = c->dc1;
       j1.h_old = j1.A1; j1.h_new = c->dh1[st & 1];
       j1.out_seq = st >= 0 ? c->dec_h1_all + (size_t)st * N * L : nullptr;
       ProfScope ps(c, F_LSTM_DEC0, (j0.active ? fl0 : 0) + (j1.active ? fl1 : 0),
@@ -495,10 +502,10 @@ static int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s)
       LstmJob j0{};
       j0.active = 1;
       packed_state(c, j0);
-      j0.A0 = t == 0 ? c->eh0[pe] : c->dh0[(t + 1) & 1]; j0.K = L; j0.Wp = c->dec_W0h_t;
+      j0.A0 = t == 0 ? c->fh0 : c->dh0[(t + 1) & 1]; j0.K = L; j0.Wp = c->dec_W0h_t;
       j0.ntiles = L / 4;
       j0.xtab = c->dec_xtab; j0.xidx = t == 0 ? nullptr : c->next_idx; j0.xidx_const = V;  // <go>
-      j0.c_in = t == 0 ? c->ec0 : c->dc0; j0.c_out = c->dc0;
+      j0.c_in = t == 0 ? c->fc0 : c->dc0; j0.c_out = c->dc0;
       j0.h_old = j0.A0; j0.h_new = c->dh0[t & 1];
       {
         ProfScope ps(c, F_LSTM_DEC0, fl0, by0, s);
@@ -508,9 +515,9 @@ static int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s)
       j1.active = 1;
       packed_state(c, j1);
       j1.out_seq = c->dh1_rm;          // row-major copy of the top-layer h for dec_attn
-      j1.A0 = c->dh0[t & 1]; j1.A1 = t == 0 ? c->eh1[pe] : c->dh1[(t + 1) & 1]; j1.K = 2 * L;
+      j1.A0 = c->dh0[t & 1]; j1.A1 = t == 0 ? c->fh1 : c->dh1[(t + 1) & 1]; j1.K = 2 * L;
       j1.Wp = c->dec_W1_t; j1.ntiles = L / 4; j1.bias = c->vars[V_DEC_B1].mirror;
-      j1.c_in = t == 0 ? c->ec1 : c->dc1; j1.c_out = c->dc1;
+      j1.c_in = t == 0 ? c->fc1 : c->dc1; j1.c_out = c->dc1;
       j1.h_old = j1.A1; j1.h_new = c->dh1[t & 1];
       {
         ProfScope ps(c, F_LSTM_DEC1, fl1, by1, s);

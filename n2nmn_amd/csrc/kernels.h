@@ -60,8 +60,14 @@ struct LstmJob {
   float* h_new;           // [N][L]  (linear mode: output [N][ldo])
   int ldo;                // linear mode: row stride of the output
   float* out_seq;         // [N][L] slice of encoder_outputs (zeros when masked) or nullptr
-  const int32_t* seq_len; // [N] or nullptr (no masking)
+  const int32_t* seq_len; // [N] or nullptr (no masking); indexed by ORIGINAL row
   int t;                  // time step compared against seq_len
+  // length-sorted encoder: state row r holds original row perm[r]; rows >= *n_active are past
+  // their length (whole 16-row tiles beyond it skip their loads and MFMAs)
+  const int32_t* perm;    // [N] or nullptr (identity)
+  const int32_t* n_active;// device scalar for this step or nullptr (= N)
+  float* fin_c;           // [N][L] row-major, ORIGINAL order: c of a row at the step it finishes
+  float* fin_h;           // k-interleaved [L/4][R][4], ORIGINAL order (or nullptr)
   int active;             // 0: skip this job entirely (pipeline fill / drain)
 };
 // rows_per_wg: 64 (4 M-tiles per workgroup) or 32 (2 M-tiles; doubles the workgroups of a launch)
@@ -106,6 +112,9 @@ struct DecStepArgs {
 void launch_dec_attn(const DecStepArgs& a, int nsteps, hipStream_t s);
 
 void launch_dec_init(int32_t* state, int N, int T_dec, hipStream_t s);
+// perm = rows sorted by decreasing length (stable); n_active[t] = #{n : seq_len[n] > t}, t < T
+void launch_enc_prepare(const int32_t* seq_len, int N, int T, int32_t* perm, int32_t* n_active,
+                        hipStream_t s);
 
 // word_vecs[t][n][:] = sum_tau atts[t][tau][n] * emb[seq[tau][n]][:];  log_seq_prob
 void launch_word_vecs(const float* atts, const int32_t* seq, const float* emb, int T_dec,

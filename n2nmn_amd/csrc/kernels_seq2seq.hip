@@ -48,10 +48,14 @@ struct LstmJobs {
 };
 
 // DBG: 0 normal, 1 = pin all loads before the MFMAs (sched_barrier), 2 = loads only (no MFMA),
-// 3 = MFMA only (no loads), 4 = neither   -- variants 2..4 exist for n2nmn_debug_lstm_bench
-template <int NCH, int MT, int DBG = 0>
+// 3 = MFMA only (no loads), 4 = neither, 6 = weight loads only, 7 = state loads only
+// -- variants 1..7 exist for n2nmn_debug_lstm_bench.
+// NA = number of leading 16-row M-tiles of this workgroup that hold active rows (the length-sorted
+// encoder skips the rest); the code for a given NA is straight-line so the scheduler can interleave
+// the chunk-major loads with the MFMAs.
+template <int NCH, int NA, int DBG = 0>
 __device__ __forceinline__ void lstm_mma(const LstmJob& jb, int N, int L, int tile, int row0,
-                                         f32x4 (&acc)[MT]) {
+                                         f32x4* acc) {
   const int lane = threadIdx.x & 63;
   // stagger: neighbouring column tiles walk the K slices and chunks in rotated order, so the
   // 128 workgroups that all read the same h rows do not hit the same L2 channel at the same time
@@ -65,52 +69,26 @@ __device__ __forceinline__ void lstm_mma(const LstmJob& jb, int N, int L, int ti
   const float4* Wp4 = reinterpret_cast<const float4*>(jb.Wp) + (size_t)tile * (K / 4) * 16 +
                       (size_t)((kbeg >> 2) + kg) * 16 + ci;
   float4 bq[NCH];
-  float4 aq[NCH][MT];
-  if (DBG == 6 || DBG == 7) {            // 6: weight (B) loads only; 7: state (A) loads only
-    const float f = (float)lane * 1e-3f;
+  float4 aq[NCH][NA];
+  const float* ar[NA];
 #pragma unroll
-    for (int kc = 0; kc < NCH; ++kc) {
-      bq[kc] = DBG == 6 ? Wp4[(size_t)((kc + rot) & (NCH - 1)) * 64] : make_float4(f, f, f, f);
+  for (int m = 0; m < NA; ++m) {
+    int r = row0 + 16 * m + ci;
+    r = r < N ? r : N - 1;
+    ar[m] = Asrc + (size_t)r * jb.a_rs + (size_t)((kloc >> 2) + kg) * jb.a_ks;
+  }
+  const float f = (float)lane * 1e-3f;
+  // chunk-major issue order: the operand loads of chunk 0 go first, so its MFMAs can start after
+  // one round trip while the later chunks are still in flight
 #pragma unroll
-      for (int m = 0; m < MT; ++m) aq[kc][m] = make_float4(f, f - 1.f, f - 2.f, f - 3.f);
-    }
-    if (DBG == 7) {
+  for (int kc = 0; kc < NCH; ++kc) {
+    const int kq = (kc + rot) & (NCH - 1);
+    if (DBG == 3 || DBG == 4 || DBG == 7) bq[kc] = make_float4(f, f + 1.f, f + 2.f, f + 3.f);
+    else bq[kc] = Wp4[(size_t)kq * 64];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        int r = row0 + 16 * m + ci;
-        r = r < N ? r : N - 1;
-        const float* ar = Asrc + (size_t)r * jb.a_rs + (size_t)((kloc >> 2) + kg) * jb.a_ks;
-#pragma unroll
-        for (int kc = 0; kc < NCH; ++kc)
-          aq[kc][m] = *reinterpret_cast<const float4*>(
-              ar + (size_t)(4 * ((kc + rot) & (NCH - 1))) * jb.a_ks);
-      }
-    }
-  } else if (DBG == 3 || DBG == 4) {
-    const float f = (float)lane * 1e-3f;
-#pragma unroll
-    for (int kc = 0; kc < NCH; ++kc) {
-      bq[kc] = make_float4(f, f + 1.f, f + 2.f, f + 3.f);
-#pragma unroll
-      for (int m = 0; m < MT; ++m) aq[kc][m] = make_float4(f, f - 1.f, f - 2.f, f - 3.f);
-    }
-  } else {
-    // chunk-major issue order: the five operand loads of chunk 0 go first, so its MFMAs can start
-    // after one round trip while the later chunks are still in flight
-    const float* ar[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      int r = row0 + 16 * m + ci;
-      r = r < N ? r : N - 1;
-      ar[m] = Asrc + (size_t)r * jb.a_rs + (size_t)((kloc >> 2) + kg) * jb.a_ks;
-    }
-#pragma unroll
-    for (int kc = 0; kc < NCH; ++kc) {
-      const int kq = (kc + rot) & (NCH - 1);
-      bq[kc] = Wp4[(size_t)kq * 64];
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-        aq[kc][m] = *reinterpret_cast<const float4*>(ar[m] + (size_t)(4 * kq) * jb.a_ks);
+    for (int m = 0; m < NA; ++m) {
+      if (DBG == 3 || DBG == 4 || DBG == 6) aq[kc][m] = make_float4(f, f - 1.f, f - 2.f, f - 3.f);
+      else aq[kc][m] = *reinterpret_cast<const float4*>(ar[m] + (size_t)(4 * kq) * jb.a_ks);
     }
   }
   if (DBG == 1) __builtin_amdgcn_sched_barrier(0);   // all loads issued before the first MFMA
@@ -118,7 +96,7 @@ __device__ __forceinline__ void lstm_mma(const LstmJob& jb, int N, int L, int ti
 #pragma unroll
     for (int kc = 0; kc < NCH; ++kc)
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
+      for (int m = 0; m < NA; ++m) {
         acc[m][0] += aq[kc][m].x * bq[kc].x; acc[m][1] += aq[kc][m].y * bq[kc].y;
         acc[m][2] += aq[kc][m].z * bq[kc].z; acc[m][3] += aq[kc][m].w * bq[kc].w;
       }
@@ -127,11 +105,31 @@ __device__ __forceinline__ void lstm_mma(const LstmJob& jb, int N, int L, int ti
 #pragma unroll
   for (int kc = 0; kc < NCH; ++kc) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
+    for (int m = 0; m < NA; ++m) {
       acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[kc][m].x, bq[kc].x, acc[m], 0, 0, 0);
       acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[kc][m].y, bq[kc].y, acc[m], 0, 0, 0);
       acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[kc][m].z, bq[kc].z, acc[m], 0, 0, 0);
       acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[kc][m].w, bq[kc].w, acc[m], 0, 0, 0);
+    }
+  }
+}
+
+template <int NCH, int MT, int DBG>
+__device__ __forceinline__ void lstm_mma_dispatch(const LstmJob& jb, int N, int L, int tile,
+                                                  int row0, int na, f32x4* acc) {
+  if (MT == 4) {
+    switch (na) {
+      case 4: lstm_mma<NCH, 4, DBG>(jb, N, L, tile, row0, acc); break;
+      case 3: lstm_mma<NCH, 3, DBG>(jb, N, L, tile, row0, acc); break;
+      case 2: lstm_mma<NCH, 2, DBG>(jb, N, L, tile, row0, acc); break;
+      case 1: lstm_mma<NCH, 1, DBG>(jb, N, L, tile, row0, acc); break;
+      default: break;
+    }
+  } else {
+    switch (na) {
+      case 2: lstm_mma<NCH, 2, DBG>(jb, N, L, tile, row0, acc); break;
+      case 1: lstm_mma<NCH, 1, DBG>(jb, N, L, tile, row0, acc); break;
+      default: break;
     }
   }
 }
@@ -149,10 +147,12 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_kernel(LstmJobs jobs, 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int ci = lane & 15, kg = lane >> 4;
 
+  const int nact = jb.n_active ? *jb.n_active : N;   // rows [nact, N) are past their length
   // ---- epilogue operands, fetched up front (thread = (row, unit) for tid < 4*ROWS) ----------
   const int erow = tid >> 2, ul = tid & 3;
   const int gr = row0 + erow;
   const bool eact = tid < 4 * ROWS && gr < N;
+  const int orow = (eact && jb.perm) ? jb.perm[gr] : gr;   // original row of state row gr
   float add[4] = {0.f, 0.f, 0.f, 0.f};
   float c_old = 0.f, h_prev = 0.f;
   bool masked = false;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_kernel(LstmJobs jobs, 
     } else {
       const int u = 4 * tile + ul;
       if (jb.xtab) {
-        const int xi = jb.xidx ? jb.xidx[gr] : jb.xidx_const;
+        const int xi = jb.xidx ? jb.xidx[orow] : jb.xidx_const;
         const float* xr = jb.xtab + (size_t)xi * 4 * L + u;
 #pragma unroll
         for (int g = 0; g < 4; ++g) add[g] = xr[g * L];
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_kernel(LstmJobs jobs, 
       }
       const size_t idx = (size_t)gr * L + u;
       c_old = jb.c_in[idx];
-      if (jb.seq_len && jb.t >= jb.seq_len[gr]) {   // dynamic_rnn past the length (A.2)
+      if (jb.seq_len && jb.t >= jb.seq_len[orow]) { // dynamic_rnn past the length (A.2)
         masked = true;
         h_prev = jb.h_old[jb.hp_R > 0 ? ((size_t)tile * jb.hp_R + gr) * 4 + ul : idx];
       }
@@ -185,8 +185,11 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_kernel(LstmJobs jobs, 
 #pragma unroll
   for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int nch = jb.K / (LSTM_WAVES * 16);
-  if (nch == 4) lstm_mma<4, MT, DBG>(jb, N, L, tile, row0, acc);
-  else if (nch == 8) lstm_mma<8, MT, DBG>(jb, N, L, tile, row0, acc);
+  // leading M-tiles with at least one active row (wave-uniform)
+  int na = (nact - row0 + 15) >> 4;
+  na = na < 0 ? 0 : (na > MT ? MT : na);
+  if (nch == 4) lstm_mma_dispatch<4, MT, DBG>(jb, N, L, tile, row0, na, acc);
+  else if (nch == 8) lstm_mma_dispatch<8, MT, DBG>(jb, N, L, tile, row0, na, acc);
   else {
     for (int q = 0; q < nch; ++q) {               // generic K: one chunk at a time
       const int kbeg = w * nch * 16 + 16 * q;
@@ -236,7 +239,12 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_kernel(LstmJobs jobs, 
     if (masked) { c_new = c_old; h_new = h_prev; o = 0.f; }
     jb.c_out[idx] = c_new;
     jb.h_new[jb.hp_R > 0 ? ((size_t)tile * jb.hp_R + gr) * 4 + ul : idx] = h_new;
-    if (jb.out_seq) jb.out_seq[idx] = o;
+    const size_t oidx = (size_t)orow * L + 4 * tile + ul;
+    if (jb.out_seq) jb.out_seq[oidx] = o;
+    if (jb.fin_c && jb.seq_len && jb.t == jb.seq_len[orow] - 1) {   // the row's last valid step
+      jb.fin_c[oidx] = c_new;
+      jb.fin_h[((size_t)tile * jb.hp_R + orow) * 4 + ul] = h_new;
+    }
   }
 }
 
@@ -460,6 +468,26 @@ __global__ __launch_bounds__(NT) void dec_attn_kernel(DecStepArgs a) {
   }
 }
 
+// perm[rank] = n with rows ranked by decreasing length (ties by index); n_active[t] = #{len > t}
+__global__ void enc_prepare_kernel(const int32_t* __restrict__ seq_len, int N, int T,
+                                   int32_t* __restrict__ perm, int32_t* __restrict__ n_active) {
+  const int tid = threadIdx.x;
+  for (int i = tid; i < N; i += blockDim.x) {
+    const int li = seq_len[i];
+    int rank = 0;
+    for (int j = 0; j < N; ++j) {
+      const int lj = seq_len[j];
+      rank += (lj > li) || (lj == li && j < i);
+    }
+    perm[rank] = i;
+  }
+  for (int t = tid; t < T; t += blockDim.x) {
+    int c = 0;
+    for (int j = 0; j < N; ++j) c += seq_len[j] > t;
+    n_active[t] = c;
+  }
+}
+
 __global__ void dec_init_kernel(int32_t* state, int N, int T_dec) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n < N) {
@@ -603,6 +631,11 @@ void launch_dec_attn(const DecStepArgs& a, int nsteps, hipStream_t s) {
     hipLaunchKernelGGL(dec_attn_kernel<256>, dim3(a.N, nsteps), dim3(256), smem, s, a);
   else
     hipLaunchKernelGGL(dec_attn_kernel<1024>, dim3(a.N, 1), dim3(1024), smem, s, a);
+}
+
+void launch_enc_prepare(const int32_t* seq_len, int N, int T, int32_t* perm, int32_t* n_active,
+                        hipStream_t s) {
+  hipLaunchKernelGGL(enc_prepare_kernel, dim3(1), dim3(256), 0, s, seq_len, N, T, perm, n_active);
 }
 
 void launch_dec_init(int32_t* state, int N, int T_dec, hipStream_t s) {
