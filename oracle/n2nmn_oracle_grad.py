@@ -1,0 +1,337 @@
+"""CPU ORACLE for the N2NMN CLEVR *training step* (config 4) -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+What it is: the forward of oracle/n2nmn_oracle.py restated on torch-CPU float64 tensors so that
+torch.autograd yields d(total_loss)/d(variable) for every trainable variable of the reference's
+behavioural-cloning objective (exp_clevr/train_clevr_gt_layout.py:104-124):
+
+    total_loss = mean_n(-log_seq_prob[n]) + mean_n(softmax_CE(scores[n], label[n]))
+                 + weight_decay * sum_{v name ends with 'weights'} 0.5*||v||^2
+                                                    (models_clevr/nmn3_model.py:161-166)
+
+with teacher-forced decoding (use_gt_layout=True: every token valid, token_prob =
+softmax(token_scores)[gt], models_clevr/nmn3_netgen_att.py:204-207,239-256), followed by the
+reference's optimiser: per-tensor tf.clip_by_norm(g, 10) and tf.train.AdamOptimizer() with its
+TF 1.0.0 defaults (train_clevr_gt_layout.py:112-120).
+
+The forward VALUES of this module are checked against the numpy oracle in
+tests/test_oracle_grad.py (same weights/inputs, fp64 round-off); the gradients are checked there
+against central finite differences of the numpy oracle's loss.  PARITY STATUS is the numpy
+oracle's: "parity unpinned" at the TensorFlow boundary (TF 1.0.0 / Fold 0.0.1 un-vendored, no
+golden gradients in the reference tree).
+
+TF gradient conventions restated here (TF 1.0.0 math_grad.py):
+  * tf.minimum / tf.maximum (And / Or / Filter): ties send the gradient to the FIRST argument
+    (xmask = x <= y for minimum, x >= y for maximum).
+  * tf.reduce_min / reduce_max (Exist / Count / *Num): the gradient is split equally between all
+    positions equal to the extremum.
+  * tf.nn.l2_normalize(x, dim, eps): x * rsqrt(max(sum x^2, eps)) -- differentiated as written.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import n2nmn_oracle as O
+
+_ENC, _DEC, _MOD = O._ENC, O._DEC, O._MOD
+F64 = torch.float64
+
+
+def _t(x):
+    return torch.as_tensor(np.asarray(x), dtype=F64)
+
+
+class _MinMax2(torch.autograd.Function):
+    """tf.minimum / tf.maximum with TF's tie rule (first argument wins)."""
+
+    @staticmethod
+    def forward(ctx, x, y, is_min):
+        mask = (x <= y) if is_min else (x >= y)
+        ctx.save_for_backward(mask)
+        return torch.where(mask, x, y)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        z = torch.zeros_like(g)
+        return torch.where(mask, g, z), torch.where(mask, z, g), None
+
+
+def tf_minimum(x, y):
+    return _MinMax2.apply(x, y, True)
+
+
+def tf_maximum(x, y):
+    return _MinMax2.apply(x, y, False)
+
+
+class _ReduceExt(torch.autograd.Function):
+    """tf.reduce_min / reduce_max over the last axis; gradient split between tied positions."""
+
+    @staticmethod
+    def forward(ctx, x, is_min):
+        y = x.min(dim=-1, keepdim=True).values if is_min else x.max(dim=-1, keepdim=True).values
+        ind = (x == y).to(x.dtype)
+        ctx.save_for_backward(ind)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (ind,) = ctx.saved_tensors
+        return g * ind / ind.sum(dim=-1, keepdim=True), None
+
+
+def tf_reduce_min(x):
+    return _ReduceExt.apply(x, True)
+
+
+def tf_reduce_max(x):
+    return _ReduceExt.apply(x, False)
+
+
+def _l2n(x, dim):
+    ss = torch.sum(x * x, dim=dim, keepdim=True)
+    return x * torch.rsqrt(torch.clamp(ss, min=1e-12))
+
+
+def _lstm_cell(x, c, h, Wm, bm):
+    z = torch.cat([x, h], dim=1) @ Wm + bm                     # Appendix A.1
+    i, j, f, o = torch.chunk(z, 4, dim=1)
+    c2 = c * torch.sigmoid(f + 1.0) + torch.sigmoid(i) * torch.tanh(j)
+    h2 = torch.tanh(c2) * torch.sigmoid(o)
+    return c2, h2
+
+
+def _lstm_w(w, which, layer):
+    base = (_ENC if which == 'encoder' else _DEC) + 'lstm/multi_rnn_cell/cell_%d/basic_lstm_cell/' % layer
+    return w[base + 'weights'], w[base + 'biases']
+
+
+def encoder_forward(w, input_seq, seq_len):
+    """models_clevr/nmn3_netgen_att.py:73-113 (dynamic_rnn with sequence_length, Appendix A.2)."""
+    T, N = input_seq.shape
+    seq = torch.as_tensor(np.asarray(input_seq)).long()
+    lens = torch.as_tensor(np.asarray(seq_len)).long()
+    E = w[_ENC + 'embedding_mat'][seq]                          # [T, N, E]
+    L = w[_ENC + 'encoder_h_transform/weights'].shape[0]
+    W0, b0 = _lstm_w(w, 'encoder', 0)
+    W1, b1 = _lstm_w(w, 'encoder', 1)
+    z = torch.zeros(N, L, dtype=F64)
+    c0, h0, c1, h1 = z, z, z, z
+    outs = []
+    for t in range(T):
+        act = (t < lens)[:, None]
+        nc0, nh0 = _lstm_cell(E[t], c0, h0, W0, b0)
+        nc1, nh1 = _lstm_cell(nh0, c1, h1, W1, b1)
+        outs.append(torch.where(act, nh1, torch.zeros_like(nh1)))
+        c0 = torch.where(act, nc0, c0); h0 = torch.where(act, nh0, h0)
+        c1 = torch.where(act, nc1, c1); h1 = torch.where(act, nh1, h1)
+    outs = torch.stack(outs)
+    eht = (outs.reshape(T * N, L) @ w[_ENC + 'encoder_h_transform/weights']
+           + w[_ENC + 'encoder_h_transform/biases']).reshape(T, N, L)
+    nf = (torch.arange(T)[:, None] < lens[None, :]).to(F64)[:, :, None]
+    return dict(embedded=E, outputs=outs, h_transformed=eht, not_finished=nf,
+                states=((c0, h0), (c1, h1)))
+
+
+def decoder_forward_gt(w, enc, T_dec, gt_layout):
+    """Teacher-forced decoder (nmn3_netgen_att.py:175-312 with use_gt_layout=True): all tokens
+    valid, predicted_token = gt, token_prob = softmax(token_scores)[gt]."""
+    (c0, h0), (c1, h1) = enc['states']
+    N = h0.shape[0]
+    gt = torch.as_tensor(np.asarray(gt_layout)).long()
+    demb = w[_DEC + 'embedding_mat']
+    x = w[_DEC + 'go_embedding'].expand(N, -1)
+    v = w[_DEC + 'att_prediction/v']
+    Wa, ba = w[_DEC + 'att_prediction/weights'], w[_DEC + 'att_prediction/biases']
+    Wy, by = w[_DEC + 'token_prediction/weights'], w[_DEC + 'token_prediction/biases']
+    W0, b0 = _lstm_w(w, 'decoder', 0)
+    W1, b1 = _lstm_w(w, 'decoder', 1)
+    eht, eout, nf = enc['h_transformed'], enc['outputs'], enc['not_finished']
+    tprobs, atts, scores = [], [], []
+    for t in range(T_dec):
+        c0, h0 = _lstm_cell(x, c0, h0, W0, b0)
+        c1, h1 = _lstm_cell(h0, c1, h1, W1, b1)
+        out = h1
+        q = out @ Wa + ba
+        e = torch.sum(torch.tanh(q[None] + eht) * v, dim=2, keepdim=True)
+        att = torch.softmax(e, dim=0) * nf                       # :190
+        att = att / torch.sum(att, dim=0, keepdim=True)          # :191
+        ctx = torch.sum(att * eout, dim=0)
+        sc = torch.cat([out, ctx], dim=1) @ Wy + by
+        p = torch.softmax(sc, dim=1)                             # validity_mult == 1 everywhere
+        p = p / torch.sum(p, dim=1, keepdim=True)
+        tprobs.append(p[torch.arange(N), gt[t]])
+        x = demb[gt[t]]
+        atts.append(att); scores.append(sc)
+    atts = torch.stack(atts)                                     # [T_dec, T_enc, N, 1]
+    word_vecs = torch.sum(atts * enc['embedded'][None], dim=1)   # :312
+    return dict(token_probs=torch.stack(tprobs), atts=atts, word_vecs=word_vecs,
+                token_scores=torch.stack(scores))
+
+
+# ---- module operators (models_clevr/nmn3_modules.py) on torch tensors ---------------------
+def _fc(w, scope, x):
+    return x @ w[_MOD + scope + '/weights'] + w[_MOD + scope + '/biases']
+
+
+def _conv1x1(w, scope, x):
+    shp = x.shape
+    y = x.reshape(-1, shp[-1]) @ w[_MOD + scope + '/weights'] + w[_MOD + scope + '/biases']
+    return y.reshape(tuple(shp[:-1]) + (y.shape[-1],))
+
+
+def _conv_same(w, scope, x):
+    K = w[_MOD + scope + '/weights']                             # [kh, kw, cin, cout]
+    y = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), K.permute(3, 2, 0, 1),
+                                   padding=(K.shape[0] // 2, K.shape[1] // 2))
+    return y.permute(0, 2, 3, 1) + w[_MOD + scope + '/biases']
+
+
+def _att_pool(feat, att):
+    n, H, Wd, _ = att.shape
+    a = torch.softmax(att.reshape(n, H * Wd), dim=1).reshape(n, H, Wd, 1)
+    return torch.sum(feat * a, dim=(1, 2))
+
+
+def _flat_ext(in0):
+    f = in0.reshape(in0.shape[0], -1)
+    return f, tf_reduce_min(f), tf_reduce_max(f)
+
+
+def _compare(w, scope, in0, in1):
+    f0, mn0, mx0 = _flat_ext(in0)
+    f1, mn1, mx1 = _flat_ext(in1)
+    return _fc(w, scope + '/fc_scores', torch.cat([f0, mn0, mx0, f1, mn1, mx1], dim=1))
+
+
+def eval_expr(w, expr, image_feat, word_vecs, num_choices):
+    if expr['module'] == O.INVALID:
+        return torch.zeros(num_choices, dtype=F64)
+    N_full = word_vecs.shape[1]
+    flat = word_vecs.reshape(-1, word_vecs.shape[-1])
+    H, Wd = image_feat.shape[1:3]
+
+    def find(scope, feat, txt, extra=None):
+        img = _conv1x1(w, scope + 'conv_image', feat)
+        t = _fc(w, scope + 'fc_text', txt)[:, None, None, :]
+        el = img * t if extra is None else img * t * extra
+        return _conv1x1(w, scope + 'conv_eltwise', _l2n(el, 3))
+
+    def rec(e):
+        t, n = e['time_idx'], e['batch_idx']
+        feat = image_feat[n:n + 1]
+        txt = flat[t * N_full + n][None]
+        ins = [rec(e[k]) for k in ('input_0', 'input_1') if k in e]
+        m = e['module']
+        if m == '_Scene':
+            return torch.full((1, H, Wd, 1), 3.0, dtype=F64)
+        if m == '_Find':
+            return find('FindModule/', feat, txt)
+        if m == '_Filter':                                       # And(input_0, Find(...))  :129-130
+            return tf_minimum(ins[0], find('FindModule/', feat, txt))
+        if m == '_FindSameProperty':
+            s = 'FindSamePropertyModule/'
+            a = _fc(w, s + 'fc_att', _att_pool(feat, ins[0]))[:, None, None, :]
+            return find(s, feat, txt, a)
+        if m == '_Transform':
+            s = 'TransformModule/'
+            maps = _conv_same(w, s + 'conv_maps', ins[0])
+            tt = _fc(w, s + 'text_fc', txt)[:, None, None, :]
+            return _conv1x1(w, s + 'conv_eltwise', _l2n(maps * tt, 3))
+        if m == '_And':
+            return tf_minimum(ins[0], ins[1])
+        if m == '_Or':
+            return tf_maximum(ins[0], ins[1])
+        if m == '_Exist':
+            f, mn, mx = _flat_ext(ins[0])
+            return _fc(w, 'ExistModule/fc_scores',
+                       torch.cat([mn, f.mean(dim=1, keepdim=True), mx], dim=1))
+        if m == '_Count':
+            f, mn, mx = _flat_ext(ins[0])
+            return _fc(w, 'CountModule/fc_scores', torch.cat([f, mn, mx], dim=1))
+        if m == '_EqualNum':
+            return _compare(w, 'EqualNumModule', ins[0], ins[1])
+        if m == '_MoreNum':
+            return _compare(w, 'MoreNumModule', ins[0], ins[1])
+        if m == '_LessNum':
+            return _compare(w, 'LessNumModule', ins[0], ins[1])
+        if m == '_SameProperty':
+            s = 'SamePropertyModule/'
+            tt = _fc(w, s + 'fc_text', txt)
+            a0 = _fc(w, s + 'fc_att_0', _att_pool(feat, ins[0]))
+            a1 = _fc(w, s + 'fc_att_1', _att_pool(feat, ins[1]))
+            return _fc(w, s + 'fc_eltwise', _l2n(a0 * tt * a1, 1))
+        if m == '_Describe':
+            s = 'DescribeModule/'
+            tt = _fc(w, s + 'fc_text', txt)
+            a = _fc(w, s + 'fc_att', _att_pool(feat, ins[0]))
+            return _fc(w, s + 'fc_eltwise', _l2n(tt * a, 1))
+        raise KeyError(m)
+
+    return rec(expr)[0]
+
+
+def train_forward(wt, module_names, batch, T_dec, num_choices, gt_layout, weight_decay=5e-6):
+    """wt: name -> torch fp64 tensor (requires_grad as the caller wishes).  Returns dict of torch
+    scalars / tensors incl. the intermediates whose gradients the GPU tests compare."""
+    enc = encoder_forward(wt, batch['input_seq_batch'], batch['seq_length_batch'])
+    dec = decoder_forward_gt(wt, enc, T_dec, gt_layout)
+    exprs, validity = O.assemble(module_names, np.asarray(gt_layout))
+    feat = _t(batch['image_feat_batch'])
+    scores = torch.stack([eval_expr(wt, e, feat, dec['word_vecs'], num_choices) for e in exprs])
+    labels = torch.as_tensor(np.asarray(batch['answer_label_batch'])).long()
+    log_seq_prob = torch.sum(torch.log(dec['token_probs']), dim=0)     # nmn3_model.py:46
+    ce = torch.logsumexp(scores, dim=1) - scores[torch.arange(len(labels)), labels]
+    avg_sample_loss = ce.mean()                                        # :110
+    seq_likelihood_loss = torch.mean(-log_seq_prob)                    # :111
+    l2 = sum(0.5 * torch.sum(v * v) for k, v in wt.items() if k.endswith('weights'))
+    total = seq_likelihood_loss + avg_sample_loss + weight_decay * l2   # :113-114
+    return dict(enc=enc, dec=dec, expr_list=exprs, validity=validity, scores=scores,
+                log_seq_prob=log_seq_prob, avg_sample_loss=avg_sample_loss,
+                seq_likelihood_loss=seq_likelihood_loss, l2_reg=l2, total_loss=total)
+
+
+def loss_and_grads(w, module_names, batch, T_dec, num_choices, gt_layout, weight_decay=5e-6):
+    """numpy in / numpy out.  Returns (losses dict of floats, grads name -> ndarray fp64,
+    extras: gradients w.r.t. intermediates + forward scores)."""
+    wt = {k: _t(v).clone().requires_grad_(True) for k, v in w.items()}
+    r = train_forward(wt, module_names, batch, T_dec, num_choices, gt_layout, weight_decay)
+    inter = dict(word_vecs=r['dec']['word_vecs'], token_scores=r['dec']['token_scores'],
+                 scores=r['scores'], encoder_outputs=r['enc']['outputs'],
+                 encoder_h_transformed=r['enc']['h_transformed'], atts=r['dec']['atts'])
+    for v in inter.values():
+        if v.requires_grad:
+            v.retain_grad()
+    r['total_loss'].backward()
+    grads = {k: (v.grad.numpy().copy() if v.grad is not None else np.zeros(tuple(v.shape)))
+             for k, v in wt.items()}
+    losses = {k: float(r[k].detach()) for k in ('avg_sample_loss', 'seq_likelihood_loss', 'l2_reg',
+                                       'total_loss')}
+    extras = {'d_' + k: (v.grad.numpy().copy() if v.grad is not None else None)
+              for k, v in inter.items()}
+    extras['scores'] = r['scores'].detach().numpy().copy()
+    extras['log_seq_prob'] = r['log_seq_prob'].detach().numpy().copy()
+    return losses, grads, extras
+
+
+# ---- optimiser: exp_clevr/train_clevr_gt_layout.py:112-120 -------------------------------
+def clip_by_norm(g, c):
+    """tf.clip_by_norm(g, c) = g * c / max(||g||_2, c)  (Appendix A.4)."""
+    return g * (c / max(float(np.sqrt(np.sum(np.asarray(g, np.float64) ** 2))), c))
+
+
+def adam_step(w, grads, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8,
+              max_grad_l2_norm=10.0):
+    """One tf.train.AdamOptimizer() step (TF 1.0.0 defaults) on per-tensor clipped gradients.
+    step = 1 for the first update.  All dicts name -> ndarray; returns (w', m', v')."""
+    lr_t = lr * np.sqrt(1.0 - beta2 ** step) / (1.0 - beta1 ** step)
+    w2, m2, v2 = {}, {}, {}
+    for k in w:
+        g = clip_by_norm(np.asarray(grads[k], np.float64), max_grad_l2_norm)
+        m2[k] = beta1 * m[k] + (1.0 - beta1) * g
+        v2[k] = beta2 * v[k] + (1.0 - beta2) * g * g
+        w2[k] = np.asarray(w[k], np.float64) - lr_t * m2[k] / (np.sqrt(v2[k]) + eps)
+    return w2, m2, v2
