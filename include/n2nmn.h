@@ -208,6 +208,70 @@ int n2nmn_module_forward(n2nmn_ctx *ctx, int op, int Nb, const float *input_0,
                          const float *word_vecs, int N_full, float *out, n2nmn_stream stream);
 
 /* ------------------------------------------------------------------------------------------
+ * (6) training step.   Replaces the graph built by exp_clevr/train_clevr_gt_layout.py:104-130:
+ *     tf.nn.sparse_softmax_cross_entropy_with_logits + seq_likelihood_loss + weight_decay*l2_reg
+ *     (models_clevr/nmn3_model.py:161-166), tf.train.AdamOptimizer().compute_gradients,
+ *     tf.clip_by_norm(g, max_grad_l2_norm) per tensor, apply_gradients.  Teacher-forced layouts
+ *     (use_gt_layout = True).  Data parallelism is NEW relative to the reference:
+ *     the gradient lives in ONE caller-owned flat fp32 buffer so that a single all-reduce per
+ *     bucket (RCCL through torch.distributed, or any other collective) can run between
+ *     n2nmn_train_backward and n2nmn_adam_step.
+ *
+ *     Flat layout: variable i (order of n2nmn_variable_info) occupies
+ *     [offset_i, offset_i + numel_i) in the reference's own element order, contiguous, no padding.
+ *     Encoder variables come first, so the buffer splits into two buckets:
+ *       bucket "late"  = [n2nmn_grad_split(), n2nmn_grad_numel())  decoder + module variables,
+ *                        final after phase 0 of n2nmn_train_backward
+ *       bucket "early" = [0, n2nmn_grad_split())                   encoder variables, final after phase 1
+ *     which lets the all-reduce of the late bucket overlap the encoder's backward pass.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  /* inputs (device pointers) */
+  const int32_t *input_seq;        /* [T_enc, N]                                             */
+  const int32_t *seq_length;       /* [N]                                                    */
+  int32_t T_enc, N, T_dec;
+  const int32_t *gt_layout;        /* [T_dec, N] ground-truth layout tokens                  */
+  const float *image_feat;         /* [N, H, W, D]                                           */
+  const int32_t *answer_labels;    /* [N]                                                    */
+  float weight_decay;              /* 5e-6 (train_clevr_gt_layout.py:39)                     */
+  /* outputs */
+  float *scores;                   /* [N, num_choices] answer logits                         */
+  float *losses;                   /* [4]: avg_sample_loss, seq_likelihood_loss, l2_reg, total_loss
+                                      (l2_reg / total_loss are complete after backward phase 1) */
+  float *grads;                    /* flat [n2nmn_grad_numel]: d total_loss / d variable     */
+} n2nmn_train_io;
+
+/* Allocates the training workspace of a ROOT context (saved activations, backward scratch, Adam
+ * moments: ~0.5 GB at CLEVR dimensions).  Idempotent. */
+int n2nmn_train_enable(n2nmn_ctx *ctx);
+int64_t n2nmn_grad_numel(const n2nmn_ctx *ctx);
+int64_t n2nmn_grad_split(const n2nmn_ctx *ctx);
+int n2nmn_grad_layout(const n2nmn_ctx *ctx, int variable, int64_t *offset, int64_t *numel);
+/* forward of the objective; `p` = program assembled from the SAME gt_layout (n2nmn_assemble);
+ * keeps every activation the backward pass needs inside the context */
+int n2nmn_train_forward(n2nmn_ctx *ctx, const n2nmn_train_io *io, n2nmn_program *p,
+                        n2nmn_stream stream);
+/* phase 0: module network + decoder (zeroes io->grads first); phase 1: encoder.  Must follow
+ * n2nmn_train_forward with the same io / program, in this order, on the same stream. */
+int n2nmn_train_backward(n2nmn_ctx *ctx, const n2nmn_train_io *io, n2nmn_program *p, int phase,
+                         n2nmn_stream stream);
+/* g = grads * grad_scale (1/world_size after a sum all-reduce); per-tensor tf.clip_by_norm(g,
+ * max_grad_l2_norm); Adam update (TF 1.0.0: lr_t = lr*sqrt(1-b2^step)/(1-b1^step)) of the
+ * registered variables in place; re-packs the weights (n2nmn_commit_weights).  step = 1 first. */
+int n2nmn_adam_step(n2nmn_ctx *ctx, const float *grads, float grad_scale, float lr, float beta1,
+                    float beta2, float eps, float max_grad_l2_norm, int64_t step,
+                    n2nmn_stream stream);
+/* zero the Adam moments (a fresh tf.train.AdamOptimizer) */
+int n2nmn_train_reset_optimizer(n2nmn_ctx *ctx, n2nmn_stream stream);
+/* copies variable `name` (current value, reference layout) into `out` (device) */
+int n2nmn_get_weight(n2nmn_ctx *ctx, const char *name, float *out, n2nmn_stream stream);
+/* debug / parity: copy an internal gradient tensor ("d_word_vecs" [T_dec,N,E], "d_token_scores"
+ * [T_dec,N,16], "d_encoder_outputs" [T_enc,N,L], "d_encoder_h_transformed" [T_enc,N,L],
+ * "d_scores" [N,C]) into `out` (device, capacity in floats); returns the element count */
+int64_t n2nmn_train_debug_tensor(n2nmn_ctx *ctx, const char *name, float *out, int64_t capacity,
+                                 n2nmn_stream stream);
+
+/* ------------------------------------------------------------------------------------------
  * (7) introspection used by the roofline report: algorithmic bytes / flops of one launch of a
  *     kernel family (SURVEY.md section 8d figures), and a plain GEMM entry for unit parity.
  * ---------------------------------------------------------------------------------------- */

@@ -33,6 +33,15 @@ class Seq2SeqIO(C.Structure):
         ('encoder_states', C.c_void_p), ('log_seq_prob', C.c_void_p)]
 
 
+class TrainIO(C.Structure):
+    _fields_ = [
+        ('input_seq', C.c_void_p), ('seq_length', C.c_void_p),
+        ('T_enc', C.c_int32), ('N', C.c_int32), ('T_dec', C.c_int32),
+        ('gt_layout', C.c_void_p), ('image_feat', C.c_void_p), ('answer_labels', C.c_void_p),
+        ('weight_decay', C.c_float),
+        ('scores', C.c_void_p), ('losses', C.c_void_p), ('grads', C.c_void_p)]
+
+
 class Node(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'op', 'time_idx', 'batch_idx', 'in0', 'in1', 'level', 'out_row', 'reserved')]
@@ -73,6 +82,17 @@ SYMBOLS = [
     ('n2nmn_program_num_launches', _I, [_P]),
     ('n2nmn_execute_program', _I, [_P, _P, _P, _P, _I, _P, _P]),
     ('n2nmn_module_forward', _I, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    ('n2nmn_train_enable', _I, [_P]),
+    ('n2nmn_grad_numel', C.c_int64, [_P]),
+    ('n2nmn_grad_split', C.c_int64, [_P]),
+    ('n2nmn_grad_layout', _I, [_P, _I, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ('n2nmn_train_forward', _I, [_P, C.POINTER(TrainIO), _P, _P]),
+    ('n2nmn_train_backward', _I, [_P, C.POINTER(TrainIO), _P, _I, _P]),
+    ('n2nmn_adam_step', _I, [_P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                             C.c_float, C.c_int64, _P]),
+    ('n2nmn_train_reset_optimizer', _I, [_P, _P]),
+    ('n2nmn_get_weight', _I, [_P, C.c_char_p, _P, _P]),
+    ('n2nmn_train_debug_tensor', C.c_int64, [_P, C.c_char_p, _P, C.c_int64, _P]),
     ('n2nmn_profile_begin', _I, [_P]),
     ('n2nmn_profile_end', _I, [_P, _P]),
     ('n2nmn_profile_num_families', _I, []),

@@ -12,125 +12,20 @@
 #include "kernels.h"
 #include "program.h"
 
-namespace n2nmn {
+#include "ctx.h"
 
+namespace n2nmn {
 static thread_local std::string g_last_error;
 void set_last_error(const std::string& s) { g_last_error = s; }
-
-#define N2_HIP(expr)                                                                     \
-  do {                                                                                   \
-    hipError_t _e = (expr);                                                              \
-    if (_e != hipSuccess) {                                                              \
-      set_last_error(std::string(#expr) + ": " + hipGetErrorString(_e));                 \
-      return N2NMN_EHIP;                                                                 \
-    }                                                                                    \
-  } while (0)
-
-#define N2_REQUIRE(cond, code, msg)                                                      \
-  do {                                                                                   \
-    if (!(cond)) {                                                                       \
-      set_last_error(msg);                                                               \
-      return code;                                                                       \
-    }                                                                                    \
-  } while (0)
-
-struct Var {
-  std::string name;
-  std::vector<int64_t> shape;
-  size_t numel = 0;
-  float* mirror = nullptr;   // context-owned copy in the reference layout
-  bool set = false;
-};
-
-// indices into Ctx::vars (order of build_vars)
-enum VarId {
-  V_ENC_EMB, V_ENC_W0, V_ENC_B0, V_ENC_W1, V_ENC_B1, V_EHT_W, V_EHT_B,
-  V_DEC_EMB, V_DEC_GO, V_ATT_V, V_ATT_W, V_ATT_B, V_TOK_W, V_TOK_B,
-  V_DEC_W0, V_DEC_B0, V_DEC_W1, V_DEC_B1,
-  V_FIND_IMG_W, V_FIND_IMG_B, V_FIND_TXT_W, V_FIND_TXT_B, V_FIND_E_W, V_FIND_E_B,
-  V_FSP_IMG_W, V_FSP_IMG_B, V_FSP_TXT_W, V_FSP_TXT_B, V_FSP_ATT_W, V_FSP_ATT_B, V_FSP_E_W,
-  V_FSP_E_B,
-  V_TR_MAPS_W, V_TR_MAPS_B, V_TR_TXT_W, V_TR_TXT_B, V_TR_E_W, V_TR_E_B,
-  V_EXIST_W, V_EXIST_B, V_COUNT_W, V_COUNT_B, V_EQ_W, V_EQ_B, V_MORE_W, V_MORE_B, V_LESS_W,
-  V_LESS_B,
-  V_SP_TXT_W, V_SP_TXT_B, V_SP_ATT0_W, V_SP_ATT0_B, V_SP_ATT1_W, V_SP_ATT1_B, V_SP_E_W, V_SP_E_B,
-  V_DE_TXT_W, V_DE_TXT_B, V_DE_ATT_W, V_DE_ATT_B, V_DE_E_W, V_DE_E_B,
-  V_COUNT_
-};
-
 }  // namespace n2nmn
 
 using namespace n2nmn;
 
-struct n2nmn_ctx {
-  n2nmn_dims d{};
-  int device = 0;
-  std::vector<Var> vars;
-  std::unordered_map<std::string, int> index;
-  bool committed = false;
-  bool have_tables = false;
-
-  char* base = nullptr;        // weight store (owned by the root context only)
-  size_t bytes = 0;
-  char* ws_base = nullptr;     // workspace (every context owns its own)
-  size_t ws_bytes = 0;
-  n2nmn_ctx* parent = nullptr; // forked contexts share the parent's weight store
-  // pinned staging ring for the program upload (nodes + tables)
-  static constexpr int kStage = 4;
-  char* stage[kStage] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t stage_ev[kStage] = {nullptr, nullptr, nullptr, nullptr};
-  size_t stage_bytes = 0;
-  int stage_next = 0;
-
-  int Mp = 0, HWp = 0, KpE = 0, KpL = 0, KpD = 0;
-  int max_nodes = 0, max_text = 0, max_pool = 0;
-
-  // packed weights / derived tables
-  float *enc_W0x_p = nullptr, *dec_W0x_p = nullptr, *enc_xtab = nullptr, *dec_xtab = nullptr;
-  float *enc_W0h_t = nullptr, *enc_W1_t = nullptr, *dec_W0h_t = nullptr, *dec_W1_t = nullptr;
-  float *eht_W_p = nullptr, *att_W_t = nullptr, *find_img_p = nullptr, *fsp_img_p = nullptr;
-  float* dec_emb_cat = nullptr;
-  float* wtxt_pad[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  float* btxt_pad[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  float* watt_pad[4] = {nullptr, nullptr, nullptr, nullptr};
-  float* we_pad[3] = {nullptr, nullptr, nullptr};
-  float* batt_pad[4] = {nullptr, nullptr, nullptr, nullptr};
-  int32_t *P = nullptr, *Wv = nullptr, *bv = nullptr;
-
-  // seq2seq workspace
-  float *eh0[2] = {nullptr, nullptr}, *eh1[2] = {nullptr, nullptr}, *ec0 = nullptr, *ec1 = nullptr;
-  float *dh0[2] = {nullptr, nullptr}, *dh1[2] = {nullptr, nullptr}, *dc0 = nullptr, *dc1 = nullptr;
-  float *fc0 = nullptr, *fh0 = nullptr, *fc1 = nullptr, *fh1 = nullptr;
-  int32_t *perm = nullptr, *nact = nullptr;
-  float *enc_out = nullptr, *eht = nullptr, *qbuf = nullptr, *dec_h1_all = nullptr, *ent_t = nullptr, *dh1_rm = nullptr;
-  int32_t *state = nullptr, *next_idx = nullptr, *tokens = nullptr;
-  float *tprobs = nullptr, *negent = nullptr, *atts = nullptr, *word_vecs = nullptr;
-  int enc_T = 0, enc_N = 0;            // shape of the encoder results currently held
-  const int32_t* enc_seq = nullptr;    // input_seq of the last encoder call (for word_vecs)
-  const int32_t* enc_len = nullptr;
-
-  // module workspace
-  float *arena = nullptr, *tmap = nullptr, *pfc = nullptr, *mfind = nullptr, *mfsp = nullptr;
-  DevNode* dev_nodes = nullptr;
-  int32_t* dev_tab = nullptr;
-  int max_tab = 0;
-
-  n2nmn_program* scratch_prog = nullptr;   // used by n2nmn_module_forward
-
-  // per-kernel-family HIP-event profiler (n2nmn_profile_*)
-  bool prof_on = false;
-  std::vector<hipEvent_t> prof_events;      // pairs
-  struct ProfRec { int fam; double flops, bytes; };
-  std::vector<ProfRec> prof_recs;
-  double prof_ms[16] = {0}, prof_flops[16] = {0}, prof_bytes[16] = {0};
-  long prof_launches[16] = {0};
-};
-
 namespace n2nmn {
 
-static const n2nmn_ctx* root(const n2nmn_ctx* c) { return c->parent ? c->parent : c; }
-static bool is_committed(const n2nmn_ctx* c) { return root(c)->committed; }
-static bool has_tables(const n2nmn_ctx* c) { return root(c)->have_tables; }
+const n2nmn_ctx* root(const n2nmn_ctx* c) { return c->parent ? c->parent : c; }
+bool is_committed(const n2nmn_ctx* c) { return root(c)->committed; }
+bool has_tables(const n2nmn_ctx* c) { return root(c)->have_tables; }
 
 static void add_var(n2nmn_ctx* c, const std::string& name, std::vector<int64_t> shape) {
   Var v;
@@ -202,20 +97,7 @@ static void build_vars(n2nmn_ctx* c) {
   layer("DescribeModule", "fc_eltwise", {M, C});
 }
 
-static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-struct Carver {
-  char* base;
-  size_t off = 0;
-  explicit Carver(char* b) : base(b) {}
-  template <typename T>
-  T* take(size_t count) {
-    off = align_up(off, 256);
-    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
-    off += count * sizeof(T);
-    return p;
-  }
-};
 
 // lays out the weight store (mirrors, packed operands, tables); base == nullptr: size only
 static size_t carve_weights(n2nmn_ctx* c, char* base) {
@@ -292,38 +174,17 @@ static size_t carve_workspace(n2nmn_ctx* c, char* base) {
   return align_up(k.off, 256);
 }
 
-enum Family {
-  F_LSTM_ENC = 0, F_LSTM_DEC0, F_LSTM_DEC1, F_LINEAR_Q, F_DEC_STEP, F_GEMM_EHT, F_WORD_VECS,
-  F_TEXTMAP, F_CONV_IMAGE, F_ATT_OPS, F_POOL, F_HEADS, F_COUNT
-};
-static const char* kFamilyNames[F_COUNT] = {
+const char* kFamilyNames[F_COUNT] = {
   "lstm_step(enc L0+L1)", "lstm_step(dec L0 | pipelined L0+L1)", "lstm_step(dec L1)",
   "lstm_step(linear q)", "dec_attn", "gemm_pk(encoder_h_transform)", "word_vecs", "textmap", "gemm_pk(conv_image)",
-  "att_ops", "pool", "heads"};
+  "att_ops", "pool", "heads",
+  "lstm_bwd_step", "gemm_tn(weight grads)", "backward misc (modules/attention/gemm_nt)",
+  "optimiser"};
 
-// Brackets one launch with HIP events on the launch stream when profiling is enabled.
-struct ProfScope {
-  n2nmn_ctx* c; hipStream_t s; bool on;
-  ProfScope(n2nmn_ctx* c_, int fam, double flops, double bytes, hipStream_t s_)
-      : c(c_), s(s_), on(c_->prof_on) {
-    if (!on) return;
-    const size_t i = c->prof_recs.size();
-    while (c->prof_events.size() < 2 * (i + 1)) {
-      hipEvent_t e;
-      if (hipEventCreate(&e) != hipSuccess) { on = false; return; }
-      c->prof_events.push_back(e);
-    }
-    c->prof_recs.push_back({fam, flops, bytes});
-    (void)hipEventRecord(c->prof_events[2 * i], s);
-  }
-  ~ProfScope() {
-    if (on) (void)hipEventRecord(c->prof_events[2 * (c->prof_recs.size() - 1) + 1], s);
-  }
-};
 
-static hipStream_t S(n2nmn_stream s) { return reinterpret_cast<hipStream_t>(s); }
+hipStream_t S(n2nmn_stream s) { return reinterpret_cast<hipStream_t>(s); }
 
-static int check_launch(const char* what) {
+int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_last_error(std::string(what) + ": " + hipGetErrorString(e));
@@ -332,7 +193,7 @@ static int check_launch(const char* what) {
   return N2NMN_OK;
 }
 
-static ModuleWeights module_weights(const n2nmn_ctx* c) {
+ModuleWeights module_weights(const n2nmn_ctx* c) {
   ModuleWeights w{};
   auto m = [&](int id) { return (const float*)c->vars[id].mirror; };
   const int txtw[5] = {V_FIND_TXT_W, V_FSP_TXT_W, V_TR_TXT_W, V_SP_TXT_W, V_DE_TXT_W};
@@ -350,14 +211,14 @@ static ModuleWeights module_weights(const n2nmn_ctx* c) {
 }
 
 // state buffers (eh0/eh1/dh0/dh1) are k-interleaved [L/4][R][4] with R = capacity N
-static void packed_state(const n2nmn_ctx* c, LstmJob& j) {
+void packed_state(const n2nmn_ctx* c, LstmJob& j) {
   j.a_rs = 4; j.a_ks = 4 * c->d.N; j.hp_R = c->d.N;
 }
-static void rowmajor_a(const n2nmn_ctx* c, LstmJob& j) {
+void rowmajor_a(const n2nmn_ctx* c, LstmJob& j) {
   j.a_rs = c->d.lstm_dim; j.a_ks = 4; j.hp_R = 0;
 }
 
-static int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s) {
+int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s) {
   const n2nmn_dims& d = c->d;
   N2_REQUIRE(is_committed(c), N2NMN_ENOWEIGHT, "encoder_forward: weights not committed");
   N2_REQUIRE(io && io->input_seq && io->seq_length, N2NMN_EINVAL, "encoder_forward: null input");
@@ -392,6 +253,17 @@ static int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s)
     j1.out_seq = st >= 0 ? c->enc_out + (size_t)st * N * L : nullptr;
     j1.seq_len = io->seq_length; j1.t = st;
     j1.perm = c->perm; j1.n_active = c->nact + (st >= 0 ? st : 0); j1.fin_c = c->fc1; j1.fin_h = c->fh1;
+    if (c->rec) {                      // training: keep gates / cell / hidden sequences
+      const size_t nl = (size_t)N * L;
+      if (j0.active) {
+        j0.save_gates = c->rec->eg0 + (size_t)k * nl; j0.save_c = c->rec->ec0s + (size_t)(k + 1) * nl;
+        j0.save_h = c->rec->eh0s + (size_t)(k + 1) * nl;
+      }
+      if (j1.active) {
+        j1.save_gates = c->rec->eg1 + (size_t)st * nl; j1.save_c = c->rec->ec1s + (size_t)(st + 1) * nl;
+        j1.save_h = c->rec->eh1s + (size_t)(st + 1) * nl;
+      }
+    }
     {
       const double fl = 2.0 * N * 4 * L * ((j0.active ? L : 0) + (j1.active ? 2 * L : 0));
       const double by = 4.0 * ((j0.active ? (double)L * 4 * L + 3.0 * N * L : 0) +
@@ -425,7 +297,7 @@ static int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s)
   return check_launch("encoder_forward");
 }
 
-static int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s) {
+int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s) {
   const n2nmn_dims& d = c->d;
   N2_REQUIRE(is_committed(c), N2NMN_ENOWEIGHT, "decoder_forward: weights not committed");
   N2_REQUIRE(has_tables(c), N2NMN_ENOWEIGHT,
@@ -477,6 +349,17 @@ static int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s)
       j1.c_in = st == 0 ? c->fc1 : c->dc1; j1.c_out = c->dc1;
       j1.h_old = j1.A1; j1.h_new = c->dh1[st & 1];
       j1.out_seq = st >= 0 ? c->dec_h1_all + (size_t)st * N * L : nullptr;
+      if (c->rec) {
+        const size_t nl = (size_t)N * L;
+        if (j0.active) {
+          j0.save_gates = c->rec->dg0 + (size_t)k * nl; j0.save_c = c->rec->dc0s + (size_t)(k + 1) * nl;
+          j0.save_h = c->rec->dh0s + (size_t)(k + 1) * nl;
+        }
+        if (j1.active) {
+          j1.save_gates = c->rec->dg1 + (size_t)st * nl; j1.save_c = c->rec->dc1s + (size_t)(st + 1) * nl;
+          j1.save_h = c->rec->dh1s + (size_t)(st + 1) * nl;
+        }
+      }
       ProfScope ps(c, F_LSTM_DEC0, (j0.active ? fl0 : 0) + (j1.active ? fl1 : 0),
                    (j0.active ? by0 : 0) + (j1.active ? by1 : 0), s);
       launch_lstm_step(jobs, 2, N, L, 64, s);
@@ -492,6 +375,10 @@ static int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s)
     a.q = c->qbuf; a.out = c->dec_h1_all; a.gt = io->gt_layout; a.uni = nullptr; a.forced = nullptr;
     a.tokens = tokens; a.tprobs = tprobs; a.ent_t = c->ent_t; a.atts = atts;
     a.scores = io->token_scores; a.next_idx = nullptr;
+    if (c->rec) {
+      a.ctx_out = c->rec->ctx;
+      if (!a.scores) a.scores = c->rec->tscores;
+    }
     {
       ProfScope ps(c, F_DEC_STEP, Td * att_fl, Td * att_by, s);
       launch_dec_attn(a, Td, s);
@@ -550,12 +437,13 @@ static int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s)
     const double E = d.embed_dim_txt;
     ProfScope ps(c, F_WORD_VECS, 2.0 * Td * T * N * E, 4.0 * N * (T * E + Td * T + Td * E), s);
     launch_word_vecs(atts, c->enc_seq, c->vars[V_ENC_EMB].mirror, Td, T, N, d.embed_dim_txt, wv,
-                     tprobs, c->ent_t, negent, io->log_seq_prob, s);
+                     tprobs, c->ent_t, negent,
+                     io->log_seq_prob ? io->log_seq_prob : (c->rec ? c->rec->lsp : nullptr), s);
   }
   return check_launch("decoder_forward");
 }
 
-static int run_program(n2nmn_ctx* c, Program& p, const float* feat, const float* word_vecs,
+int run_program(n2nmn_ctx* c, Program& p, const float* feat, const float* word_vecs,
                        int N_full, float* scores, const float* ext0, const float* ext1,
                        float* att_out, int att_out_first, int att_out_count, hipStream_t s) {
   const n2nmn_dims& d = c->d;
@@ -601,6 +489,7 @@ static int run_program(n2nmn_ctx* c, Program& p, const float* feat, const float*
   b.nodes = c->dev_nodes; b.tab = c->dev_tab; b.arena = c->arena; b.tmap = c->tmap;
   b.pfc = c->pfc; b.mfind = c->mfind; b.mfsp = c->mfsp; b.feat = feat; b.word_vecs = word_vecs;
   b.scores = scores; b.N_full = N_full; b.H = d.H; b.W = d.W; b.D = d.D; b.M = d.map_dim;
+  b.pooled = c->rec ? c->rec->pooled : nullptr;
   b.Mp = c->Mp; b.wl_cap = d.map_dim * C <= 10240 ? d.map_dim * C : 0; b.E = d.embed_dim_txt; b.C = C; b.HWp = c->HWp; b.ksize = d.kernel_size;
   const double dE = d.embed_dim_txt, dM = d.map_dim, dD = d.D, dHW = HW, dC = C, dMp = c->Mp;
   for (const Launch& l : p.launches) {
@@ -789,6 +678,7 @@ int n2nmn_ctx_destroy(n2nmn_ctx* ctx) {
     if (ctx->stage_ev[i]) (void)hipEventDestroy(ctx->stage_ev[i]);
   }
   for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
+  if (ctx->train) train_state_destroy(ctx->train);
   n2nmn_program_destroy(ctx->scratch_prog);
   delete ctx;
   return N2NMN_OK;
@@ -906,6 +796,7 @@ int n2nmn_commit_weights(n2nmn_ctx* c, n2nmn_stream stream) {
     N2_HIP(hipMemcpyAsync(c->batt_pad[i], m(bas[i]), sizeof(float) * M, hipMemcpyDeviceToDevice, s));
   }
   c->committed = true;
+  c->commit_epoch++;
   c->enc_T = 0;
   return check_launch("commit_weights");
 }

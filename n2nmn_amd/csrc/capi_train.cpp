@@ -1,0 +1,693 @@
+// C ABI of the training step (include/n2nmn.h section 6): forward of the behavioural-cloning
+// objective with activations kept, backward in two phases (module network + decoder, then encoder)
+// into ONE caller-owned flat gradient buffer, per-tensor clip + Adam.
+// Reference: exp_clevr/train_clevr_gt_layout.py:104-130, models_clevr/nmn3_model.py:46,161-166.
+// Host code only; kernels live in kernels_train.hip / kernels_train_modules.hip.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ctx.h"
+
+namespace n2nmn {
+
+struct TrainState {
+  char* base = nullptr;
+  size_t bytes = 0;
+  TrainRec rec;
+  // forward results kept inside the context
+  float* scores = nullptr;            // [N][C] (when the caller passes no buffer)
+  // backward scratch
+  float *dscores = nullptr, *dsc = nullptr, *garena = nullptr, *dtmap = nullptr, *dpfc = nullptr,
+        *dmfind = nullptr, *dmfsp = nullptr, *dwv = nullptr, *datts_wv = nullptr, *de = nullptr,
+        *dctx = nullptr, *dq = nullptr, *dout = nullptr, *dvp = nullptr, *deht = nullptr,
+        *denc_out = nullptr;
+  float *dz0_all = nullptr, *dz1_all = nullptr;
+  float *dzk0[2] = {nullptr, nullptr}, *dzk1[2] = {nullptr, nullptr};
+  float *dH0 = nullptr, *dH1 = nullptr, *dC0 = nullptr, *dC1 = nullptr;
+  float *dxtab_enc = nullptr, *dxtab_dec = nullptr;
+  int32_t* dec_xidx = nullptr;
+  // transposed operand packs (rebuilt after every weight commit)
+  float *enc_Wt1 = nullptr, *enc_Wt0 = nullptr, *dec_Wt1 = nullptr, *dec_Wt0 = nullptr;
+  float *eht_WT_p = nullptr, *att_WT_p = nullptr, *enc_W0xT_p = nullptr, *dec_W0xT_p = nullptr;
+  uint64_t pack_epoch = 0;
+  // per-program tables (text slot -> word_vecs row / weight set; pooling slot -> fc_att set)
+  int32_t *tslot_row = nullptr, *tslot_ws = nullptr, *pool_sel = nullptr;
+  int32_t* tab_host = nullptr;        // pinned staging for the three tables
+  hipEvent_t tab_ev = nullptr;
+  // optimiser
+  float *m = nullptr, *v = nullptr, *norm2 = nullptr;
+  float** mirrors_dev = nullptr;
+  int64_t* var_off_dev = nullptr;
+  int32_t* decay_dev = nullptr;
+  ParamSeg* segs_dev = nullptr;
+  int nsegs = 0, nsegs_early = 0;     // segments of the encoder variables come first
+  std::vector<int64_t> var_off;
+  int64_t total = 0, split = 0;
+  int KpL4 = 0;                       // round_up(4L, 32)
+  int last_N = 0, last_T = 0, last_Td = 0;   // shape of the forward currently held
+};
+
+void train_state_destroy(TrainState* t) {
+  if (!t) return;
+  if (t->base) (void)hipFree(t->base);
+  if (t->tab_host) (void)hipHostFree(t->tab_host);
+  if (t->tab_ev) (void)hipEventDestroy(t->tab_ev);
+  delete t;
+}
+
+namespace {
+
+constexpr int SEG_ELEMS = 4096;
+
+size_t carve_train(n2nmn_ctx* c, TrainState* t, char* base) {
+  const n2nmn_dims& d = c->d;
+  const size_t L = d.lstm_dim, E = d.embed_dim_txt, N = d.N, T = d.T_encoder, Td = d.T_decoder,
+               V = d.num_vocab_nmn, Vt = d.num_vocab_txt, D = d.D, HW = (size_t)d.H * d.W,
+               C = d.num_choices;
+  const size_t Mp = c->Mp, HWp = c->HWp;
+  const size_t Tm = std::max(T, Td);
+  Carver k(base);
+  TrainRec& r = t->rec;
+  r.eg0 = k.take<float4>(T * N * L); r.eg1 = k.take<float4>(T * N * L);
+  r.dg0 = k.take<float4>(Td * N * L); r.dg1 = k.take<float4>(Td * N * L);
+  r.ec0s = k.take<float>((T + 1) * N * L); r.ec1s = k.take<float>((T + 1) * N * L);
+  r.eh0s = k.take<float>((T + 1) * N * L); r.eh1s = k.take<float>((T + 1) * N * L);
+  r.dc0s = k.take<float>((Td + 1) * N * L); r.dc1s = k.take<float>((Td + 1) * N * L);
+  r.dh0s = k.take<float>((Td + 1) * N * L); r.dh1s = k.take<float>((Td + 1) * N * L);
+  r.ctx = k.take<float>(Td * N * L);
+  r.tscores = k.take<float>(Td * N * V);
+  r.lsp = k.take<float>(N);
+  r.pooled = k.take<float>((size_t)c->max_pool * 2 * D);
+  t->scores = k.take<float>(N * C);
+  t->dscores = k.take<float>(N * C + 4);
+  t->dsc = k.take<float>(Td * N * 16);
+  t->garena = k.take<float>((size_t)c->max_nodes * HWp);
+  t->dtmap = k.take<float>((size_t)c->max_text * Mp);
+  t->dpfc = k.take<float>((size_t)c->max_pool * 2 * Mp);
+  t->dmfind = k.take<float>(N * HW * Mp);
+  t->dmfsp = k.take<float>(N * HW * Mp);
+  t->dwv = k.take<float>(Td * N * E);
+  t->datts_wv = k.take<float>(Td * T * N);
+  t->de = k.take<float>(Td * T * N);
+  t->dctx = k.take<float>(Td * N * L);
+  t->dq = k.take<float>(Td * N * L);
+  t->dout = k.take<float>(Td * N * L);
+  t->dvp = k.take<float>(Td * N * L);
+  t->deht = k.take<float>(T * N * L);
+  t->denc_out = k.take<float>(T * N * L);
+  t->dz0_all = k.take<float>(Tm * N * 4 * L);
+  t->dz1_all = k.take<float>(Tm * N * 4 * L);
+  for (int i = 0; i < 2; ++i) {
+    t->dzk0[i] = k.take<float>(4 * L * N);
+    t->dzk1[i] = k.take<float>(4 * L * N);
+  }
+  t->dH0 = k.take<float>(N * L); t->dH1 = k.take<float>(N * L);
+  t->dC0 = k.take<float>(N * L); t->dC1 = k.take<float>(N * L);
+  t->dxtab_enc = k.take<float>(Vt * 4 * L);
+  t->dxtab_dec = k.take<float>((V + 1) * 4 * L);
+  t->dec_xidx = k.take<int32_t>(Td * N);
+  t->enc_Wt1 = k.take<float>(L * 4 * L); t->enc_Wt0 = k.take<float>(L * 8 * L);
+  t->dec_Wt1 = k.take<float>(L * 4 * L); t->dec_Wt0 = k.take<float>(L * 8 * L);
+  t->eht_WT_p = k.take<float>((size_t)c->KpL * L);
+  t->att_WT_p = k.take<float>((size_t)c->KpL * L);
+  const size_t Ep = round_up((int)E, 64);
+  t->enc_W0xT_p = k.take<float>((size_t)t->KpL4 * Ep);
+  t->dec_W0xT_p = k.take<float>((size_t)t->KpL4 * Ep);
+  t->tslot_row = k.take<int32_t>(c->max_text);
+  t->tslot_ws = k.take<int32_t>(c->max_text);
+  t->pool_sel = k.take<int32_t>((size_t)c->max_pool * 2);
+  t->m = k.take<float>((size_t)t->total);
+  t->v = k.take<float>((size_t)t->total);
+  t->norm2 = k.take<float>(V_COUNT_);
+  t->mirrors_dev = k.take<float*>(V_COUNT_);
+  t->var_off_dev = k.take<int64_t>(V_COUNT_);
+  t->decay_dev = k.take<int32_t>(V_COUNT_);
+  t->segs_dev = k.take<ParamSeg>(t->nsegs);
+  return align_up(k.off, 256);
+}
+
+bool ends_with(const std::string& s, const char* suf) {
+  const size_t n = std::strlen(suf);
+  return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+// operand packs of the backward GEMMs: W^T views of the committed weights
+int repack_transposed(n2nmn_ctx* c, hipStream_t s) {
+  TrainState* t = c->train;
+  const n2nmn_dims& d = c->d;
+  const int L = d.lstm_dim, E = d.embed_dim_txt;
+  auto m = [&](int id) { return c->vars[id].mirror; };
+  // layer 1: rec = dz1 . W1[L:2L, :]^T ; layer 0: rec = [dz1 ; dz0] . [W1[0:L, :] ; W0[E:E+L, :]]^T
+  launch_pack_tiles_t(m(V_ENC_W1), 4 * L, L, L, t->enc_Wt1, 4 * L, 0, s);
+  launch_pack_tiles_t(m(V_ENC_W1), 4 * L, 0, L, t->enc_Wt0, 8 * L, 0, s);
+  launch_pack_tiles_t(m(V_ENC_W0), 4 * L, E, L, t->enc_Wt0, 8 * L, 4 * L, s);
+  launch_pack_tiles_t(m(V_DEC_W1), 4 * L, L, L, t->dec_Wt1, 4 * L, 0, s);
+  launch_pack_tiles_t(m(V_DEC_W1), 4 * L, 0, L, t->dec_Wt0, 8 * L, 0, s);
+  launch_pack_tiles_t(m(V_DEC_W0), 4 * L, E, L, t->dec_Wt0, 8 * L, 4 * L, s);
+  launch_pack_pk_t(m(V_EHT_W), L, L, L, t->eht_WT_p, c->KpL, L, s);
+  launch_pack_pk_t(m(V_ATT_W), L, L, L, t->att_WT_p, c->KpL, L, s);
+  const int Ep = round_up(E, 64);
+  // B[k][n] = W0[n][k], k < 4L (gate pre-activations), n < E (embedding dims)
+  launch_pack_pk_t(m(V_ENC_W0), 4 * L, 4 * L, E, t->enc_W0xT_p, t->KpL4, Ep, s);
+  launch_pack_pk_t(m(V_DEC_W0), 4 * L, 4 * L, E, t->dec_W0xT_p, t->KpL4, Ep, s);
+  t->pack_epoch = c->commit_epoch;
+  return check_launch("train: repack_transposed");
+}
+
+float* gptr(const n2nmn_ctx* c, const n2nmn_train_io* io, int var) {
+  return io->grads + c->train->var_off[var];
+}
+
+int gemm_tn(n2nmn_ctx* c, hipStream_t s, const float* A, int lda, int M, const float* B, int ldb,
+            int N, int R, float* C, int ldc, const int32_t* a_idx = nullptr, int a_gs = 1,
+            const int32_t* b_sel = nullptr, int b_val = 0) {
+  if (R <= 0) return N2NMN_OK;
+  GemmTnArgs g{};
+  g.A = A; g.lda = lda; g.M = M; g.a_group_idx = a_idx; g.a_group_size = a_gs;
+  g.B = B; g.ldb = ldb; g.N = N; g.b_sel = b_sel; g.b_sel_val = b_val; g.R = R; g.C = C; g.ldc = ldc;
+  ProfScope ps(c, F_GEMM_TN, 2.0 * M * N * R, 4.0 * ((double)R * (M + N) + (double)M * N), s);
+  launch_gemm_tn(g, s);
+  return N2NMN_OK;
+}
+
+// C (+)= A[M,K] . Bp   (NT GEMMs of the backward pass go through the forward gemm_pk kernel)
+void gemm_nt(n2nmn_ctx* c, hipStream_t s, const float* A, int lda, int M, int K, const float* Bp,
+             int Np, int Kp, int N, float* C, int ldc, bool accumulate) {
+  if (M <= 0) return;
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.M = M; g.K = K; g.group_size = 1; g.Bp = Bp; g.Np = Np; g.Kp = Kp;
+  g.bias = nullptr; g.N = N; g.C = C; g.ldc = ldc; g.n_store = N; g.accumulate = accumulate ? 1 : 0;
+  ProfScope ps(c, F_BWD_MISC, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)K * N + 2.0 * M * N), s);
+  launch_gemm_pk(g, s);
+}
+
+void colsum(n2nmn_ctx* c, hipStream_t s, const float* src, int R, int ncols, int ld, float* dst,
+            const int32_t* sel = nullptr, int val = 0) {
+  if (R <= 0) return;
+  ProfScope ps(c, F_BWD_MISC, (double)R * ncols, 4.0 * R * ncols, s);
+  launch_colsum(src, R, ncols, ld, sel, val, dst, s);
+}
+
+// reverse-time recurrence of a 2-layer LSTM stack; layer 1 runs one launch ahead of layer 0
+struct BpttArgs {
+  int T, N;
+  bool want_init_grad;          // also produce dH of the initial state (decoder)
+  const int32_t* seq_len;
+  const float4 *g0, *g1;        // gates [T][N][L]
+  const float *c0s, *c1s;       // [(T+1)][N][L]
+  const float* dout;            // [T][N][L] gradient arriving at the top layer's outputs
+  const float *Wt0, *Wt1;
+};
+
+int run_bptt(n2nmn_ctx* c, const BpttArgs& a, hipStream_t s) {
+  TrainState* t = c->train;
+  const int L = c->d.lstm_dim, R = c->d.N, N = a.N;
+  const size_t nl = (size_t)N * L;
+  N2_HIP(hipMemsetAsync(t->dzk0[0], 0, sizeof(float) * 4 * (size_t)L * R, s));
+  const int last = a.T + (a.want_init_grad ? 1 : 0);
+  for (int k = 0; k <= last; ++k) {
+    LstmBwdJob jobs[2];
+    const int t1 = a.T - 1 - k, t0 = t1 + 1;
+    LstmBwdJob& j1 = jobs[0];
+    j1 = LstmBwdJob{};
+    j1.active = (t1 >= 0) || (t1 == -1 && a.want_init_grad);
+    j1.A0 = t->dzk1[(k + 1) & 1]; j1.A1 = nullptr; j1.K = 4 * L; j1.R = R; j1.Wt = a.Wt1;
+    j1.gemm = k > 0; j1.cell = t1 >= 0; j1.t = t1; j1.T = a.T; j1.seq_len = a.seq_len;
+    j1.dH = t->dH1; j1.dC = t->dC1; j1.dz_k = t->dzk1[k & 1];
+    if (t1 >= 0) {
+      j1.gates = a.g1 + (size_t)t1 * nl; j1.c_new = a.c1s + (size_t)(t1 + 1) * nl;
+      j1.c_prev = a.c1s + (size_t)t1 * nl; j1.dout = a.dout + (size_t)t1 * nl;
+      j1.dz_rm = t->dz1_all + (size_t)t1 * N * 4 * L;
+    }
+    LstmBwdJob& j0 = jobs[1];
+    j0 = LstmBwdJob{};
+    j0.active = k >= 1 && ((t0 >= 0) || (t0 == -1 && a.want_init_grad));
+    j0.A0 = t->dzk1[(k + 1) & 1]; j0.A1 = t->dzk0[(k + 1) & 1]; j0.K = 8 * L; j0.R = R;
+    j0.Wt = a.Wt0; j0.gemm = 1; j0.cell = t0 >= 0; j0.t = t0; j0.T = a.T; j0.seq_len = a.seq_len;
+    j0.dH = t->dH0; j0.dC = t->dC0; j0.dz_k = t->dzk0[k & 1];
+    if (t0 >= 0 && t0 < a.T) {
+      j0.gates = a.g0 + (size_t)t0 * nl; j0.c_new = a.c0s + (size_t)(t0 + 1) * nl;
+      j0.c_prev = a.c0s + (size_t)t0 * nl; j0.dout = nullptr;
+      j0.dz_rm = t->dz0_all + (size_t)t0 * N * 4 * L;
+    }
+    const double fl = 2.0 * N * L * ((j1.active && j1.gemm ? 4.0 * L : 0) + (j0.active ? 8.0 * L : 0));
+    const double by = 4.0 * ((j1.active && j1.gemm ? 4.0 * L * L + 4.0 * N * L : 0) +
+                             (j0.active ? 8.0 * L * L + 8.0 * N * L : 0) + 20.0 * N * L);
+    ProfScope ps(c, F_LSTM_BWD, fl, by, s);
+    launch_lstm_bwd_step(jobs, 2, N, L, s);
+  }
+  return check_launch("train: bptt");
+}
+
+}  // namespace
+}  // namespace n2nmn
+
+using namespace n2nmn;
+
+extern "C" {
+
+int n2nmn_train_enable(n2nmn_ctx* c) {
+  N2_REQUIRE(c, N2NMN_EINVAL, "train_enable: null context");
+  N2_REQUIRE(!c->parent, N2NMN_EINVAL, "train_enable: train on the root context");
+  if (c->train) return N2NMN_OK;
+  N2_REQUIRE(c->d.num_vocab_nmn <= 15, N2NMN_EINVAL,
+             "train_enable: num_vocab_nmn + <go> must fit 16 x-table rows");
+  N2_HIP(hipSetDevice(c->device));
+  TrainState* t = new (std::nothrow) TrainState();
+  N2_REQUIRE(t, N2NMN_EINVAL, "train_enable: out of host memory");
+  t->KpL4 = round_up(4 * c->d.lstm_dim, 32);
+  // flat parameter vector: variables in registration order, contiguous
+  t->var_off.resize(c->vars.size());
+  int64_t off = 0;
+  std::vector<ParamSeg> segs;
+  for (size_t i = 0; i < c->vars.size(); ++i) {
+    if ((int)i == V_DEC_EMB) { t->split = off; t->nsegs_early = (int)segs.size(); }
+    t->var_off[i] = off;
+    const int64_t n = (int64_t)c->vars[i].numel;
+    for (int64_t b = 0; b < n; b += SEG_ELEMS) {
+      ParamSeg sg{};
+      sg.var = (int32_t)i; sg.begin = off + b; sg.end = off + std::min<int64_t>(n, b + SEG_ELEMS);
+      segs.push_back(sg);
+    }
+    off += n;
+  }
+  t->total = off;
+  t->nsegs = (int)segs.size();
+  c->train = t;
+  t->bytes = carve_train(c, t, nullptr);
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&t->base), t->bytes);
+  if (e != hipSuccess) {
+    set_last_error(std::string("train_enable: hipMalloc of ") + std::to_string(t->bytes) +
+                   " bytes failed: " + hipGetErrorString(e));
+    c->train = nullptr;
+    delete t;
+    return N2NMN_EHIP;
+  }
+  carve_train(c, t, t->base);
+  N2_HIP(hipMemset(t->base, 0, t->bytes));
+  std::vector<float*> mir(c->vars.size());
+  std::vector<int32_t> decay(c->vars.size());
+  for (size_t i = 0; i < c->vars.size(); ++i) {
+    mir[i] = c->vars[i].mirror;
+    decay[i] = ends_with(c->vars[i].name, "weights") ? 1 : 0;      // nmn3_model.py:163-165
+  }
+  N2_HIP(hipMemcpy(t->mirrors_dev, mir.data(), sizeof(float*) * mir.size(), hipMemcpyHostToDevice));
+  N2_HIP(hipMemcpy(t->var_off_dev, t->var_off.data(), sizeof(int64_t) * t->var_off.size(),
+                   hipMemcpyHostToDevice));
+  N2_HIP(hipMemcpy(t->decay_dev, decay.data(), sizeof(int32_t) * decay.size(), hipMemcpyHostToDevice));
+  N2_HIP(hipMemcpy(t->segs_dev, segs.data(), sizeof(ParamSeg) * segs.size(), hipMemcpyHostToDevice));
+  const size_t tabn = 2 * (size_t)c->max_text + 2 * (size_t)c->max_pool;
+  N2_HIP(hipHostMalloc(reinterpret_cast<void**>(&t->tab_host), sizeof(int32_t) * tabn, 0));
+  N2_HIP(hipEventCreateWithFlags(&t->tab_ev, hipEventDisableTiming));
+  return N2NMN_OK;
+}
+
+int64_t n2nmn_grad_numel(const n2nmn_ctx* c) { return (c && c->train) ? c->train->total : N2NMN_EINVAL; }
+int64_t n2nmn_grad_split(const n2nmn_ctx* c) { return (c && c->train) ? c->train->split : N2NMN_EINVAL; }
+
+int n2nmn_grad_layout(const n2nmn_ctx* c, int variable, int64_t* offset, int64_t* numel) {
+  N2_REQUIRE(c && c->train, N2NMN_EINVAL, "grad_layout: training not enabled");
+  N2_REQUIRE(variable >= 0 && variable < (int)c->vars.size(), N2NMN_EINVAL, "grad_layout: bad index");
+  if (offset) *offset = c->train->var_off[variable];
+  if (numel) *numel = (int64_t)c->vars[variable].numel;
+  return N2NMN_OK;
+}
+
+int n2nmn_get_weight(n2nmn_ctx* c, const char* name, float* out, n2nmn_stream stream) {
+  N2_REQUIRE(c && name && out, N2NMN_EINVAL, "get_weight: null argument");
+  const n2nmn_ctx* r = root(c);
+  auto it = r->index.find(name);
+  if (it == r->index.end()) {
+    set_last_error(std::string("get_weight: unknown variable '") + name + "'");
+    return N2NMN_EKEY;
+  }
+  const Var& v = r->vars[it->second];
+  N2_HIP(hipMemcpyAsync(out, v.mirror, sizeof(float) * v.numel, hipMemcpyDeviceToDevice, S(stream)));
+  return N2NMN_OK;
+}
+
+static int check_train_io(const n2nmn_ctx* c, const n2nmn_train_io* io, const n2nmn_program* p,
+                          const char* what) {
+  N2_REQUIRE(c && io && p, N2NMN_EINVAL, std::string(what) + ": null argument");
+  N2_REQUIRE(c->train, N2NMN_EINVAL, std::string(what) + ": call n2nmn_train_enable first");
+  N2_REQUIRE(io->input_seq && io->seq_length && io->gt_layout && io->image_feat &&
+                 io->answer_labels && io->losses && io->grads,
+             N2NMN_EINVAL, std::string(what) + ": null tensor in n2nmn_train_io");
+  N2_REQUIRE(io->N >= 1 && io->N <= c->d.N && io->T_enc >= 1 && io->T_enc <= c->d.T_encoder &&
+                 io->T_dec >= 1 && io->T_dec <= c->d.T_decoder,
+             N2NMN_ECAPACITY, std::string(what) + ": N / T_enc / T_dec exceed the context capacity");
+  N2_REQUIRE(p->prog.num_rows == io->N, N2NMN_EINVAL,
+             std::string(what) + ": program was not assembled from this batch");
+  return N2NMN_OK;
+}
+
+int n2nmn_train_forward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* p,
+                        n2nmn_stream stream) {
+  int rc = check_train_io(c, io, p, "train_forward");
+  if (rc != N2NMN_OK) return rc;
+  N2_REQUIRE(is_committed(c), N2NMN_ENOWEIGHT, "train_forward: weights not committed");
+  TrainState* t = c->train;
+  hipStream_t s = S(stream);
+  const n2nmn_dims& d = c->d;
+  const int N = io->N, L = d.lstm_dim;
+  const size_t nl = (size_t)N * L;
+  if (t->pack_epoch != c->commit_epoch) {
+    rc = repack_transposed(c, s);
+    if (rc != N2NMN_OK) return rc;
+  }
+  // initial state slots of the kept sequences: zeros for the encoder
+  N2_HIP(hipMemsetAsync(t->rec.ec0s, 0, sizeof(float) * nl, s));
+  N2_HIP(hipMemsetAsync(t->rec.ec1s, 0, sizeof(float) * nl, s));
+  N2_HIP(hipMemsetAsync(t->rec.eh0s, 0, sizeof(float) * nl, s));
+  N2_HIP(hipMemsetAsync(t->rec.eh1s, 0, sizeof(float) * nl, s));
+  n2nmn_seq2seq_io sio{};
+  sio.input_seq = io->input_seq; sio.seq_length = io->seq_length; sio.T_enc = io->T_enc; sio.N = N;
+  sio.T_dec = io->T_dec; sio.use_gt_layout = 1; sio.gt_layout = io->gt_layout;
+  t->last_N = N; t->last_T = io->T_enc; t->last_Td = io->T_dec;
+  c->rec = &t->rec;
+  rc = encoder_impl(c, &sio, s);
+  if (rc == N2NMN_OK) {
+    // the decoder starts from the encoder's final state (nmn3_netgen_att.py:177)
+    (void)hipMemcpyAsync(t->rec.dc0s, c->fc0, sizeof(float) * nl, hipMemcpyDeviceToDevice, s);
+    (void)hipMemcpyAsync(t->rec.dc1s, c->fc1, sizeof(float) * nl, hipMemcpyDeviceToDevice, s);
+    launch_unpack_h(c->fh0, t->rec.dh0s, N, L, d.N, s);
+    launch_unpack_h(c->fh1, t->rec.dh1s, N, L, d.N, s);
+    rc = decoder_impl(c, &sio, s);
+  }
+  float* scores = io->scores ? io->scores : t->scores;
+  if (rc == N2NMN_OK)
+    rc = run_program(c, p->prog, io->image_feat, c->word_vecs, N, scores, nullptr, nullptr, nullptr,
+                     0, 0, s);
+  c->rec = nullptr;
+  if (rc != N2NMN_OK) return rc;
+  if (scores != t->scores)
+    N2_HIP(hipMemcpyAsync(t->scores, scores, sizeof(float) * (size_t)N * d.num_choices,
+                          hipMemcpyDeviceToDevice, s));
+  N2_HIP(hipMemsetAsync(io->losses, 0, sizeof(float) * 4, s));
+  {
+    ProfScope ps(c, F_BWD_MISC, 6.0 * N * d.num_choices, 4.0 * 2 * N * d.num_choices, s);
+    launch_loss(t->scores, io->answer_labels, t->rec.lsp, N, d.num_choices, t->dscores, io->losses, s);
+  }
+  return check_launch("train_forward");
+}
+
+int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* pp, int phase,
+                         n2nmn_stream stream) {
+  int rc = check_train_io(c, io, pp, "train_backward");
+  if (rc != N2NMN_OK) return rc;
+  N2_REQUIRE(phase == 0 || phase == 1, N2NMN_EINVAL, "train_backward: phase must be 0 or 1");
+  TrainState* t = c->train;
+  Program& p = pp->prog;
+  hipStream_t s = S(stream);
+  const n2nmn_dims& d = c->d;
+  const int N = io->N, L = d.lstm_dim, E = d.embed_dim_txt, T = io->T_enc, Td = io->T_dec,
+            V = d.num_vocab_nmn, Vt = d.num_vocab_txt, M = d.map_dim, Mp = c->Mp, D = d.D,
+            HW = d.H * d.W, C = d.num_choices;
+  const int Ep = round_up(E, 64);
+  auto G = [&](int var) { return gptr(c, io, var); };
+  auto mir = [&](int var) { return (const float*)c->vars[var].mirror; };
+
+  if (phase == 0) {
+    N2_HIP(hipMemsetAsync(io->grads, 0, sizeof(float) * (size_t)t->total, s));
+    // ------------------------------- module network ---------------------------------------
+    const int nn = (int)p.dev_nodes.size();
+    N2_HIP(hipMemsetAsync(t->dwv, 0, sizeof(float) * (size_t)Td * N * E, s));
+    if (nn > 0) {
+      N2_HIP(hipMemsetAsync(t->dtmap, 0, sizeof(float) * (size_t)std::max(p.num_text, 1) * Mp, s));
+      N2_HIP(hipMemsetAsync(t->dpfc, 0, sizeof(float) * (size_t)std::max(p.num_pool, 1) * 2 * Mp, s));
+      if (p.num_find_img)
+        N2_HIP(hipMemsetAsync(t->dmfind, 0, sizeof(float) * (size_t)p.num_find_img * HW * Mp, s));
+      if (p.num_fsp_img)
+        N2_HIP(hipMemsetAsync(t->dmfsp, 0, sizeof(float) * (size_t)p.num_fsp_img * HW * Mp, s));
+      // tables: text slot -> (word_vecs row, weight set); pooling slot/input -> fc_att weight set
+      {
+        N2_HIP(hipEventSynchronize(t->tab_ev));
+        int32_t* row = t->tab_host;
+        int32_t* ws = row + c->max_text;
+        int32_t* sel = ws + c->max_text;
+        for (int i = 0; i < 2 * p.num_pool; ++i) sel[i] = -1;
+        for (const DevNode& nd : p.dev_nodes) {
+          if (nd.tslot >= 0) {
+            row[nd.tslot] = nd.t * N + nd.n;
+            int w5;
+            switch (nd.op) {
+              case N2NMN_OP_FIND: case N2NMN_OP_FILTER: w5 = 0; break;
+              case N2NMN_OP_FIND_SAME_PROPERTY: w5 = 1; break;
+              case N2NMN_OP_TRANSFORM: w5 = 2; break;
+              case N2NMN_OP_SAME_PROPERTY: w5 = 3; break;
+              default: w5 = 4; break;
+            }
+            ws[nd.tslot] = w5;
+          }
+          if (nd.pslot >= 0) {
+            if (nd.op == N2NMN_OP_FIND_SAME_PROPERTY) sel[2 * nd.pslot] = 0;
+            else if (nd.op == N2NMN_OP_SAME_PROPERTY) { sel[2 * nd.pslot] = 1; sel[2 * nd.pslot + 1] = 2; }
+            else sel[2 * nd.pslot] = 3;
+          }
+        }
+        if (p.num_text) {
+          N2_HIP(hipMemcpyAsync(t->tslot_row, row, sizeof(int32_t) * p.num_text, hipMemcpyHostToDevice, s));
+          N2_HIP(hipMemcpyAsync(t->tslot_ws, ws, sizeof(int32_t) * p.num_text, hipMemcpyHostToDevice, s));
+        }
+        if (p.num_pool)
+          N2_HIP(hipMemcpyAsync(t->pool_sel, sel, sizeof(int32_t) * 2 * p.num_pool, hipMemcpyHostToDevice, s));
+        N2_HIP(hipEventRecord(t->tab_ev, s));
+      }
+      ModuleWeights w = module_weights(c);
+      ModuleBuffers b{};
+      b.nodes = c->dev_nodes; b.tab = c->dev_tab; b.arena = c->arena; b.tmap = c->tmap;
+      b.pfc = c->pfc; b.mfind = c->mfind; b.mfsp = c->mfsp; b.feat = io->image_feat;
+      b.word_vecs = c->word_vecs; b.scores = nullptr; b.N_full = N; b.H = d.H; b.W = d.W; b.D = D;
+      b.M = M; b.Mp = Mp; b.wl_cap = 0; b.E = E; b.C = C; b.HWp = c->HWp; b.ksize = d.kernel_size;
+      b.pooled = t->rec.pooled;
+      ModuleGrads g{};
+      g.garena = t->garena; g.dtmap = t->dtmap; g.dpfc = t->dpfc; g.dmfind = t->dmfind;
+      g.dmfsp = t->dmfsp; g.dscores = t->dscores; g.dwv = t->dwv;
+      g.gwe[0] = G(V_FIND_E_W); g.gbe[0] = G(V_FIND_E_B);
+      g.gwe[1] = G(V_FSP_E_W); g.gbe[1] = G(V_FSP_E_B);
+      g.gwe[2] = G(V_TR_E_W); g.gbe[2] = G(V_TR_E_B);
+      g.gKt = G(V_TR_MAPS_W); g.gbt = G(V_TR_MAPS_B);
+      const int attb[4] = {V_FSP_ATT_B, V_SP_ATT0_B, V_SP_ATT1_B, V_DE_ATT_B};
+      for (int i = 0; i < 4; ++i) g.gbatt[i] = G(attb[i]);
+      const int answ[7] = {V_EXIST_W, V_COUNT_W, V_EQ_W, V_MORE_W, V_LESS_W, V_SP_E_W, V_DE_E_W};
+      for (int i = 0; i < 7; ++i) { g.gWans[i] = G(answ[i]); g.gbans[i] = G(answ[i] + 1); }
+      bool att_done = false;
+      for (int li = (int)p.launches.size() - 1; li >= 0; --li) {
+        const Launch& l = p.launches[li];
+        switch (l.kind) {
+          case LK_HEAD: {
+            ProfScope ps(c, F_BWD_MISC, l.count * 4.0 * M * C, 4.0 * l.count * (8.0 * Mp + C), s);
+            launch_heads_bwd(w, b, g, l.offset, l.count, s);
+            break;
+          }
+          case LK_POOL: {
+            const int jobs = l.count / POOL_PARTS;
+            ProfScope ps(c, F_BWD_MISC, jobs * (2.0 * HW * D + 2.0 * D * M),
+                         4.0 * (jobs * ((double)HW * D + 2.0 * HW) + (double)D * M), s);
+            launch_pool_bwd(w, b, g, l.offset, jobs, 2 * POOL_PARTS, s);
+            break;
+          }
+          case LK_ATT: {
+            ProfScope ps(c, F_BWD_MISC, l.count * 8.0 * HW * M / FIND_PARTS,
+                         4.0 * l.count * 2.0 * HW * Mp / FIND_PARTS, s);
+            launch_att_bwd(w, b, g, l.offset, l.count, s);
+            break;
+          }
+          case LK_CONV_FIND:
+          case LK_CONV_FSP: {
+            const bool fsp = l.kind == LK_CONV_FSP;
+            if (!att_done) {            // fc_att weight gradients from the kept pooled features
+              att_done = true;
+              const int attw[4] = {V_FSP_ATT_W, V_SP_ATT0_W, V_SP_ATT1_W, V_DE_ATT_W};
+              for (int i = 0; i < 4; ++i)
+                gemm_tn(c, s, t->rec.pooled, D, D, t->dpfc, Mp, M, 2 * p.num_pool, G(attw[i]), M,
+                        nullptr, 1, t->pool_sel, i);
+            }
+            gemm_tn(c, s, io->image_feat, D, D, fsp ? t->dmfsp : t->dmfind, Mp, M, l.count * HW,
+                    G(fsp ? V_FSP_IMG_W : V_FIND_IMG_W), M, c->dev_tab + l.offset, HW);
+            colsum(c, s, fsp ? t->dmfsp : t->dmfind, l.count * HW, M, Mp,
+                   G(fsp ? V_FSP_IMG_B : V_FIND_IMG_B));
+            break;
+          }
+          case LK_TEXTMAP: {
+            if (!att_done) {
+              att_done = true;
+              const int attw[4] = {V_FSP_ATT_W, V_SP_ATT0_W, V_SP_ATT1_W, V_DE_ATT_W};
+              for (int i = 0; i < 4; ++i)
+                gemm_tn(c, s, t->rec.pooled, D, D, t->dpfc, Mp, M, 2 * p.num_pool, G(attw[i]), M,
+                        nullptr, 1, t->pool_sel, i);
+            }
+            {
+              ProfScope ps(c, F_BWD_MISC, 2.0 * p.num_text * E * M,
+                           4.0 * (l.count * (double)E * Mp + p.num_text * (double)(E + Mp)), s);
+              launch_textmap_bwd(w, b, g, l.offset, l.count, s);
+            }
+            const int txw[5] = {V_FIND_TXT_W, V_FSP_TXT_W, V_TR_TXT_W, V_SP_TXT_W, V_DE_TXT_W};
+            for (int i = 0; i < 5; ++i) {
+              gemm_tn(c, s, c->word_vecs, E, E, t->dtmap, Mp, M, p.num_text, G(txw[i]), M,
+                      t->tslot_row, 1, t->tslot_ws, i);
+              colsum(c, s, t->dtmap, p.num_text, M, Mp, G(txw[i] + 1), t->tslot_ws, i);
+            }
+            break;
+          }
+          default: break;
+        }
+      }
+    }
+    // ------------------------------- decoder ----------------------------------------------
+    {
+      ProfScope ps(c, F_BWD_MISC, 4.0 * Td * T * N * E, 4.0 * N * (double)(T * E + 2 * Td * E + 2 * Td * T), s);
+      launch_word_vecs_bwd(t->dwv, c->atts, io->input_seq, io->seq_length, mir(V_ENC_EMB), Td, T, N,
+                           E, t->datts_wv, G(V_ENC_EMB), s);
+    }
+    DecBwdArgs a{};
+    a.scores = t->rec.tscores; a.gt = io->gt_layout; a.q = c->qbuf; a.eht = c->eht;
+    a.eout = c->enc_out; a.atts = c->atts; a.datts_wv = t->datts_wv; a.seq_len = io->seq_length;
+    a.v = mir(V_ATT_V); a.Wy = mir(V_TOK_W); a.T = T; a.N = N; a.L = L; a.V = V; a.Td = Td;
+    a.inv_n = 1.0f / (float)N;
+    a.dsc = t->dsc; a.dout = t->dout; a.dctx = t->dctx; a.de = t->de; a.dq = t->dq; a.dvp = t->dvp;
+    a.deht = t->deht; a.deout = t->denc_out;
+    {
+      ProfScope ps(c, F_BWD_MISC, (double)Td * N * (8.0 * T * L + 4.0 * L * V),
+                   4.0 * Td * N * (2.0 * T * L + 4.0 * L), s);
+      launch_dec_bwd_a(a, s);
+    }
+    {
+      ProfScope ps(c, F_BWD_MISC, (double)Td * T * N * 8.0 * L,
+                   4.0 * ((double)T * N * 3 * L + (double)Td * N * 2 * L), s);
+      launch_dec_bwd_b(a, s);
+    }
+    const int RT = Td * N;
+    gemm_tn(c, s, c->dec_h1_all, L, L, t->dsc, 16, V, RT, G(V_TOK_W), V);
+    gemm_tn(c, s, t->rec.ctx, L, L, t->dsc, 16, V, RT, G(V_TOK_W) + (size_t)L * V, V);
+    colsum(c, s, t->dsc, RT, V, 16, G(V_TOK_B));
+    colsum(c, s, t->dvp, RT, L, L, G(V_ATT_V));
+    gemm_tn(c, s, c->dec_h1_all, L, L, t->dq, L, L, RT, G(V_ATT_W), L);
+    colsum(c, s, t->dq, RT, L, L, G(V_ATT_B));
+    gemm_nt(c, s, t->dq, L, RT, L, t->att_WT_p, L, c->KpL, L, t->dout, L, true);
+    // BPTT through the decoder LSTM stack; its initial state is the encoder's final state
+    N2_HIP(hipMemsetAsync(t->dH0, 0, sizeof(float) * 4 * (size_t)d.N * L, s));   // dH0,dH1,dC0,dC1
+    BpttArgs ba{};
+    ba.T = Td; ba.N = N; ba.want_init_grad = true; ba.seq_len = nullptr;
+    ba.g0 = t->rec.dg0; ba.g1 = t->rec.dg1; ba.c0s = t->rec.dc0s; ba.c1s = t->rec.dc1s;
+    ba.dout = t->dout; ba.Wt0 = t->dec_Wt0; ba.Wt1 = t->dec_Wt1;
+    rc = run_bptt(c, ba, s);
+    if (rc != N2NMN_OK) return rc;
+    launch_dec_xidx(io->gt_layout, Td, N, V, t->dec_xidx, s);
+    {
+      ProfScope ps(c, F_BWD_MISC, (double)RT * 4 * L, 4.0 * RT * 4.0 * L, s);
+      launch_xtab_grad(t->dz0_all, t->dec_xidx, RT, 4 * L, V + 1, t->dxtab_dec, s);
+    }
+    gemm_tn(c, s, c->dec_emb_cat, E, E, t->dxtab_dec, 4 * L, 4 * L, V + 1, G(V_DEC_W0), 4 * L);
+    colsum(c, s, t->dxtab_dec, V + 1, 4 * L, 4 * L, G(V_DEC_B0));
+    gemm_nt(c, s, t->dxtab_dec, 4 * L, V, 4 * L, t->dec_W0xT_p, Ep, t->KpL4, E, G(V_DEC_EMB), E, true);
+    gemm_nt(c, s, t->dxtab_dec + (size_t)V * 4 * L, 4 * L, 1, 4 * L, t->dec_W0xT_p, Ep, t->KpL4, E,
+            G(V_DEC_GO), E, true);
+    gemm_tn(c, s, t->rec.dh0s, L, L, t->dz0_all, 4 * L, 4 * L, RT, G(V_DEC_W0) + (size_t)E * 4 * L, 4 * L);
+    gemm_tn(c, s, t->rec.dh0s + (size_t)N * L, L, L, t->dz1_all, 4 * L, 4 * L, RT, G(V_DEC_W1), 4 * L);
+    gemm_tn(c, s, t->rec.dh1s, L, L, t->dz1_all, 4 * L, 4 * L, RT, G(V_DEC_W1) + (size_t)L * 4 * L, 4 * L);
+    colsum(c, s, t->dz1_all, RT, 4 * L, 4 * L, G(V_DEC_B1));
+    {
+      ProfScope ps(c, F_OPTIMISER, 3.0 * (t->total - t->split), 4.0 * 3 * (t->total - t->split), s);
+      launch_grad_finish(io->grads, (const float* const*)t->mirrors_dev, t->var_off_dev, t->decay_dev,
+                         t->segs_dev + t->nsegs_early, t->nsegs - t->nsegs_early, 1.0f,
+                         io->weight_decay, io->losses + 2, s);
+    }
+    return check_launch("train_backward(0)");
+  }
+
+  // ------------------------------- phase 1: encoder -----------------------------------------
+  const int RT = T * N;
+  // d encoder_outputs = (through the context vectors, already in denc_out) + deht . W_eht^T
+  gemm_nt(c, s, t->deht, L, RT, L, t->eht_WT_p, L, c->KpL, L, t->denc_out, L, true);
+  gemm_tn(c, s, c->enc_out, L, L, t->deht, L, L, RT, G(V_EHT_W), L);
+  colsum(c, s, t->deht, RT, L, L, G(V_EHT_B));
+  BpttArgs ba{};
+  ba.T = T; ba.N = N; ba.want_init_grad = false; ba.seq_len = io->seq_length;
+  ba.g0 = t->rec.eg0; ba.g1 = t->rec.eg1; ba.c0s = t->rec.ec0s; ba.c1s = t->rec.ec1s;
+  ba.dout = t->denc_out; ba.Wt0 = t->enc_Wt0; ba.Wt1 = t->enc_Wt1;
+  rc = run_bptt(c, ba, s);
+  if (rc != N2NMN_OK) return rc;
+  {
+    ProfScope ps(c, F_BWD_MISC, (double)RT * 4 * L, 4.0 * RT * 4.0 * L, s);
+    launch_xtab_grad(t->dz0_all, io->input_seq, RT, 4 * L, Vt, t->dxtab_enc, s);
+  }
+  gemm_tn(c, s, mir(V_ENC_EMB), E, E, t->dxtab_enc, 4 * L, 4 * L, Vt, G(V_ENC_W0), 4 * L);
+  colsum(c, s, t->dxtab_enc, Vt, 4 * L, 4 * L, G(V_ENC_B0));
+  gemm_nt(c, s, t->dxtab_enc, 4 * L, Vt, 4 * L, t->enc_W0xT_p, Ep, t->KpL4, E, G(V_ENC_EMB), E, true);
+  gemm_tn(c, s, t->rec.eh0s, L, L, t->dz0_all, 4 * L, 4 * L, RT, G(V_ENC_W0) + (size_t)E * 4 * L, 4 * L);
+  gemm_tn(c, s, t->rec.eh0s + (size_t)N * L, L, L, t->dz1_all, 4 * L, 4 * L, RT, G(V_ENC_W1), 4 * L);
+  gemm_tn(c, s, t->rec.eh1s, L, L, t->dz1_all, 4 * L, 4 * L, RT, G(V_ENC_W1) + (size_t)L * 4 * L, 4 * L);
+  colsum(c, s, t->dz1_all, RT, 4 * L, 4 * L, G(V_ENC_B1));
+  {
+    ProfScope ps(c, F_OPTIMISER, 3.0 * t->split, 4.0 * 3 * t->split, s);
+    launch_grad_finish(io->grads, (const float* const*)t->mirrors_dev, t->var_off_dev, t->decay_dev,
+                       t->segs_dev, t->nsegs_early, 1.0f, io->weight_decay, io->losses + 2, s);
+  }
+  launch_loss_total(io->losses, io->weight_decay, s);
+  return check_launch("train_backward(1)");
+}
+
+int n2nmn_adam_step(n2nmn_ctx* c, const float* grads, float grad_scale, float lr, float beta1,
+                    float beta2, float eps, float max_grad_l2_norm, int64_t step,
+                    n2nmn_stream stream) {
+  N2_REQUIRE(c && grads, N2NMN_EINVAL, "adam_step: null argument");
+  N2_REQUIRE(c->train, N2NMN_EINVAL, "adam_step: call n2nmn_train_enable first");
+  N2_REQUIRE(step >= 1, N2NMN_EINVAL, "adam_step: step counts from 1");
+  TrainState* t = c->train;
+  hipStream_t s = S(stream);
+  N2_HIP(hipMemsetAsync(t->norm2, 0, sizeof(float) * V_COUNT_, s));
+  const double lr_t = (double)lr * std::sqrt(1.0 - std::pow((double)beta2, (double)step)) /
+                      (1.0 - std::pow((double)beta1, (double)step));
+  {
+    ProfScope ps(c, F_OPTIMISER, 2.0 * t->total, 4.0 * t->total, s);
+    launch_grad_sqnorm(grads, t->segs_dev, t->nsegs, grad_scale, t->norm2, s);
+  }
+  {
+    ProfScope ps(c, F_OPTIMISER, 12.0 * t->total, 4.0 * 7 * t->total, s);
+    launch_adam(grads, t->mirrors_dev, t->var_off_dev, t->segs_dev, t->nsegs, t->norm2, grad_scale,
+                max_grad_l2_norm, (float)lr_t, beta1, beta2, eps, t->m, t->v, s);
+  }
+  int rc = check_launch("adam_step");
+  if (rc != N2NMN_OK) return rc;
+  return n2nmn_commit_weights(c, stream);
+}
+
+int n2nmn_train_reset_optimizer(n2nmn_ctx* c, n2nmn_stream stream) {
+  N2_REQUIRE(c && c->train, N2NMN_EINVAL, "train_reset_optimizer: training not enabled");
+  N2_HIP(hipMemsetAsync(c->train->m, 0, sizeof(float) * (size_t)c->train->total, S(stream)));
+  N2_HIP(hipMemsetAsync(c->train->v, 0, sizeof(float) * (size_t)c->train->total, S(stream)));
+  return N2NMN_OK;
+}
+
+int64_t n2nmn_train_debug_tensor(n2nmn_ctx* c, const char* name, float* out, int64_t capacity,
+                                 n2nmn_stream stream) {
+  N2_REQUIRE(c && c->train && name && out, N2NMN_EINVAL, "train_debug_tensor: bad argument");
+  TrainState* t = c->train;
+  const n2nmn_dims& d = c->d;
+  const int64_t N = t->last_N, T = t->last_T, Td = t->last_Td, L = d.lstm_dim;
+  const std::string k(name);
+  const float* src = nullptr;
+  int64_t n = 0;
+  if (k == "d_word_vecs") { src = t->dwv; n = Td * N * d.embed_dim_txt; }
+  else if (k == "d_token_scores") { src = t->dsc; n = Td * N * 16; }
+  else if (k == "d_encoder_outputs") { src = t->denc_out; n = T * N * L; }
+  else if (k == "d_encoder_h_transformed") { src = t->deht; n = T * N * L; }
+  else if (k == "d_scores") { src = t->dscores; n = N * d.num_choices; }
+  else if (k == "d_dec_out") { src = t->dout; n = Td * N * L; }
+  else if (k == "d_state") { src = t->dH0; n = 4 * (int64_t)d.N * L; }
+  else {
+    set_last_error("train_debug_tensor: unknown tensor '" + k + "'");
+    return N2NMN_EKEY;
+  }
+  N2_REQUIRE(n <= capacity, N2NMN_ECAPACITY, "train_debug_tensor: capacity too small");
+  N2_HIP(hipMemcpyAsync(out, src, sizeof(float) * n, hipMemcpyDeviceToDevice, S(stream)));
+  return n;
+}
+
+}  // extern "C"

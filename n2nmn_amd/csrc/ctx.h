@@ -1,0 +1,206 @@
+// Internal definition of the context shared by capi.cpp (forward path) and capi_train.cpp
+// (training step).  Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "kernels.h"
+#include "program.h"
+
+namespace n2nmn {
+
+void set_last_error(const std::string& s);
+
+#define N2_HIP(expr)                                                                     \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      set_last_error(std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+      return N2NMN_EHIP;                                                                 \
+    }                                                                                    \
+  } while (0)
+
+#define N2_REQUIRE(cond, code, msg)                                                      \
+  do {                                                                                   \
+    if (!(cond)) {                                                                       \
+      set_last_error(msg);                                                               \
+      return code;                                                                       \
+    }                                                                                    \
+  } while (0)
+
+struct Var {
+  std::string name;
+  std::vector<int64_t> shape;
+  size_t numel = 0;
+  float* mirror = nullptr;   // context-owned copy in the reference layout
+  bool set = false;
+};
+
+// indices into Ctx::vars (order of build_vars)
+enum VarId {
+  V_ENC_EMB, V_ENC_W0, V_ENC_B0, V_ENC_W1, V_ENC_B1, V_EHT_W, V_EHT_B,
+  V_DEC_EMB, V_DEC_GO, V_ATT_V, V_ATT_W, V_ATT_B, V_TOK_W, V_TOK_B,
+  V_DEC_W0, V_DEC_B0, V_DEC_W1, V_DEC_B1,
+  V_FIND_IMG_W, V_FIND_IMG_B, V_FIND_TXT_W, V_FIND_TXT_B, V_FIND_E_W, V_FIND_E_B,
+  V_FSP_IMG_W, V_FSP_IMG_B, V_FSP_TXT_W, V_FSP_TXT_B, V_FSP_ATT_W, V_FSP_ATT_B, V_FSP_E_W,
+  V_FSP_E_B,
+  V_TR_MAPS_W, V_TR_MAPS_B, V_TR_TXT_W, V_TR_TXT_B, V_TR_E_W, V_TR_E_B,
+  V_EXIST_W, V_EXIST_B, V_COUNT_W, V_COUNT_B, V_EQ_W, V_EQ_B, V_MORE_W, V_MORE_B, V_LESS_W,
+  V_LESS_B,
+  V_SP_TXT_W, V_SP_TXT_B, V_SP_ATT0_W, V_SP_ATT0_B, V_SP_ATT1_W, V_SP_ATT1_B, V_SP_E_W, V_SP_E_B,
+  V_DE_TXT_W, V_DE_TXT_B, V_DE_ATT_W, V_DE_ATT_B, V_DE_E_W, V_DE_E_B,
+  V_COUNT_
+};
+
+}  // namespace n2nmn
+
+using namespace n2nmn;
+
+namespace n2nmn {
+// Where the forward pass keeps the activations the backward pass needs (set while a training
+// forward runs; see capi_train.cpp).  Strides use the ACTUAL batch size N of the call.
+struct TrainRec {
+  float4 *eg0 = nullptr, *eg1 = nullptr, *dg0 = nullptr, *dg1 = nullptr;   // gates [T][N][L]
+  float *ec0s = nullptr, *ec1s = nullptr, *eh0s = nullptr, *eh1s = nullptr; // [(T+1)][N][L]
+  float *dc0s = nullptr, *dc1s = nullptr, *dh0s = nullptr, *dh1s = nullptr; // [(Td+1)][N][L]
+  float *ctx = nullptr;        // [Td][N][L]
+  float *tscores = nullptr;    // [Td][N][V]
+  float *lsp = nullptr;        // [N] log_seq_prob
+  float *pooled = nullptr;     // [max_pool][2][D]
+};
+struct TrainState;
+}  // namespace n2nmn
+
+struct n2nmn_ctx {
+  n2nmn_dims d{};
+  int device = 0;
+  std::vector<Var> vars;
+  std::unordered_map<std::string, int> index;
+  bool committed = false;
+  bool have_tables = false;
+
+  char* base = nullptr;        // weight store (owned by the root context only)
+  size_t bytes = 0;
+  char* ws_base = nullptr;     // workspace (every context owns its own)
+  size_t ws_bytes = 0;
+  n2nmn_ctx* parent = nullptr; // forked contexts share the parent's weight store
+  // pinned staging ring for the program upload (nodes + tables)
+  static constexpr int kStage = 4;
+  char* stage[kStage] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t stage_ev[kStage] = {nullptr, nullptr, nullptr, nullptr};
+  size_t stage_bytes = 0;
+  int stage_next = 0;
+
+  int Mp = 0, HWp = 0, KpE = 0, KpL = 0, KpD = 0;
+  int max_nodes = 0, max_text = 0, max_pool = 0;
+
+  // packed weights / derived tables
+  float *enc_W0x_p = nullptr, *dec_W0x_p = nullptr, *enc_xtab = nullptr, *dec_xtab = nullptr;
+  float *enc_W0h_t = nullptr, *enc_W1_t = nullptr, *dec_W0h_t = nullptr, *dec_W1_t = nullptr;
+  float *eht_W_p = nullptr, *att_W_t = nullptr, *find_img_p = nullptr, *fsp_img_p = nullptr;
+  float* dec_emb_cat = nullptr;
+  float* wtxt_pad[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  float* btxt_pad[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  float* watt_pad[4] = {nullptr, nullptr, nullptr, nullptr};
+  float* we_pad[3] = {nullptr, nullptr, nullptr};
+  float* batt_pad[4] = {nullptr, nullptr, nullptr, nullptr};
+  int32_t *P = nullptr, *Wv = nullptr, *bv = nullptr;
+
+  // seq2seq workspace
+  float *eh0[2] = {nullptr, nullptr}, *eh1[2] = {nullptr, nullptr}, *ec0 = nullptr, *ec1 = nullptr;
+  float *dh0[2] = {nullptr, nullptr}, *dh1[2] = {nullptr, nullptr}, *dc0 = nullptr, *dc1 = nullptr;
+  float *fc0 = nullptr, *fh0 = nullptr, *fc1 = nullptr, *fh1 = nullptr;
+  int32_t *perm = nullptr, *nact = nullptr;
+  float *enc_out = nullptr, *eht = nullptr, *qbuf = nullptr, *dec_h1_all = nullptr, *ent_t = nullptr, *dh1_rm = nullptr;
+  int32_t *state = nullptr, *next_idx = nullptr, *tokens = nullptr;
+  float *tprobs = nullptr, *negent = nullptr, *atts = nullptr, *word_vecs = nullptr;
+  int enc_T = 0, enc_N = 0;            // shape of the encoder results currently held
+  const int32_t* enc_seq = nullptr;    // input_seq of the last encoder call (for word_vecs)
+  const int32_t* enc_len = nullptr;
+
+  // module workspace
+  float *arena = nullptr, *tmap = nullptr, *pfc = nullptr, *mfind = nullptr, *mfsp = nullptr;
+  DevNode* dev_nodes = nullptr;
+  int32_t* dev_tab = nullptr;
+  int max_tab = 0;
+
+  n2nmn_program* scratch_prog = nullptr;   // used by n2nmn_module_forward
+
+  // training step (capi_train.cpp)
+  uint64_t commit_epoch = 0;               // bumped by every n2nmn_commit_weights
+  const TrainRec* rec = nullptr;           // != nullptr while a training forward records
+  TrainState* train = nullptr;             // owned; created by n2nmn_train_enable
+
+  // per-kernel-family HIP-event profiler (n2nmn_profile_*)
+  bool prof_on = false;
+  std::vector<hipEvent_t> prof_events;      // pairs
+  struct ProfRec { int fam; double flops, bytes; };
+  std::vector<ProfRec> prof_recs;
+  double prof_ms[16] = {0}, prof_flops[16] = {0}, prof_bytes[16] = {0};
+  long prof_launches[16] = {0};
+};
+
+
+namespace n2nmn {
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(char* b) : base(b) {}
+  template <typename T>
+  T* take(size_t count) {
+    off = align_up(off, 256);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += count * sizeof(T);
+    return p;
+  }
+};
+
+enum Family {
+  F_LSTM_ENC = 0, F_LSTM_DEC0, F_LSTM_DEC1, F_LINEAR_Q, F_DEC_STEP, F_GEMM_EHT, F_WORD_VECS,
+  F_TEXTMAP, F_CONV_IMAGE, F_ATT_OPS, F_POOL, F_HEADS,
+  F_LSTM_BWD, F_GEMM_TN, F_BWD_MISC, F_OPTIMISER, F_COUNT
+};
+extern const char* kFamilyNames[F_COUNT];
+
+// Brackets one launch with HIP events on the launch stream when profiling is enabled.
+struct ProfScope {
+  n2nmn_ctx* c; hipStream_t s; bool on;
+  ProfScope(n2nmn_ctx* c_, int fam, double flops, double bytes, hipStream_t s_)
+      : c(c_), s(s_), on(c_->prof_on) {
+    if (!on) return;
+    const size_t i = c->prof_recs.size();
+    while (c->prof_events.size() < 2 * (i + 1)) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) { on = false; return; }
+      c->prof_events.push_back(e);
+    }
+    c->prof_recs.push_back({fam, flops, bytes});
+    (void)hipEventRecord(c->prof_events[2 * i], s);
+  }
+  ~ProfScope() {
+    if (on) (void)hipEventRecord(c->prof_events[2 * (c->prof_recs.size() - 1) + 1], s);
+  }
+};
+
+const n2nmn_ctx* root(const n2nmn_ctx* c);
+bool is_committed(const n2nmn_ctx* c);
+bool has_tables(const n2nmn_ctx* c);
+hipStream_t S(n2nmn_stream s);
+int check_launch(const char* what);
+ModuleWeights module_weights(const n2nmn_ctx* c);
+void packed_state(const n2nmn_ctx* c, LstmJob& j);
+void rowmajor_a(const n2nmn_ctx* c, LstmJob& j);
+int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s);
+int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s);
+void train_state_destroy(TrainState* t);
+int run_program(n2nmn_ctx* c, Program& p, const float* feat, const float* word_vecs, int N_full,
+                float* scores, const float* ext0, const float* ext1, float* att_out,
+                int att_out_first, int att_out_count, hipStream_t s);
+
+}  // namespace n2nmn

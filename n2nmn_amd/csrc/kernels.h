@@ -22,6 +22,7 @@ struct GemmArgs {
   const float* Bp; int Np; int Kp;
   const float* bias; int N;
   float* C; int ldc; int n_store;
+  int accumulate;                             // != 0: C += A.B (+ bias) instead of C = ...
 };
 void launch_gemm_pk(const GemmArgs& a, hipStream_t s);
 
@@ -69,6 +70,10 @@ struct LstmJob {
   float* fin_c;           // [N][L] row-major, ORIGINAL order: c of a row at the step it finishes
   float* fin_h;           // k-interleaved [L/4][R][4], ORIGINAL order (or nullptr)
   int active;             // 0: skip this job entirely (pipeline fill / drain)
+  // training: activations kept for the backward pass (ORIGINAL row order), or nullptr
+  float4* save_gates;     // [N][L] (i, j, f, o) after their nonlinearities, this step
+  float* save_c;          // [N][L] cell state after this step
+  float* save_h;          // [N][L] hidden state after this step (row-major)
 };
 // rows_per_wg: 64 (4 M-tiles per workgroup) or 32 (2 M-tiles; doubles the workgroups of a launch)
 void launch_lstm_step(const LstmJob* jobs, int njobs, int N, int L, int rows_per_wg,
@@ -107,6 +112,7 @@ struct DecStepArgs {
   float* atts;             // [steps][T][N]
   float* scores;           // [steps][N][V] or nullptr
   int32_t* next_idx;       // [N] row of the decoder x-table for the next step (= token) or nullptr
+  float* ctx_out;          // [steps][N][L] context vectors kept for the backward pass, or nullptr
 };
 // nsteps == 1: one sequential step (1024-thread workgroups); nsteps > 1: all steps in one launch
 void launch_dec_attn(const DecStepArgs& a, int nsteps, hipStream_t s);
@@ -150,6 +156,7 @@ struct ModuleBuffers {
   float* scores;          // [rows][C]
   int N_full, H, W, D, M, Mp, E, C, HWp, ksize;
   int wl_cap;             // floats of LDS the answer heads may use to stage fc weights
+  float* pooled;          // [max_pool][2][D] attention-pooled features kept for backward, or nullptr
 };
 
 void launch_textmap(const ModuleWeights& w, const ModuleBuffers& b, int tab_off, int count,
@@ -160,5 +167,134 @@ void launch_pool(const ModuleWeights& w, const ModuleBuffers& b, int tab_off, in
                  hipStream_t s);
 void launch_heads(const ModuleWeights& w, const ModuleBuffers& b, int tab_off, int count,
                   hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// training step (exp_clevr/train_clevr_gt_layout.py:104-130): kernels_train.hip
+// Every gradient writer ACCUMULATES into the zeroed flat gradient buffer.
+// ---------------------------------------------------------------------------------------------
+// C[m][n] += sum_r A[row(r)][m] * B[r][n]   (weight gradients: both operands have the reduction
+// index as their slow axis).  fp32 MFMA, split over r across blockIdx.z, atomicAdd epilogue.
+struct GemmTnArgs {
+  const float* A; int lda; int M;              // m < M; M % 4 == 0; rows readable up to M
+  const int32_t* a_group_idx; int a_group_size; // source row of r = group_idx[r/gs]*gs + r%gs
+  const float* B; int ldb; int N;              // n < N; rows readable up to round_up(N, 4)
+  const int32_t* b_sel; int b_sel_val;         // optional: row r contributes iff b_sel[r] == val
+  int R;
+  float* C; int ldc;
+};
+void launch_gemm_tn(const GemmTnArgs& a, hipStream_t s);
+// dst[c] += sum_r src[r*ld + c] (rows filtered by sel[r] == sel_val when sel != nullptr)
+void launch_colsum(const float* src, int R, int ncols, int ld, const int32_t* sel, int sel_val,
+                   float* dst, hipStream_t s);
+// PK layout of the TRANSPOSE: dst <- B[k][n] = src[n*ld + k]
+void launch_pack_pk_t(const float* src, int ld, int K, int N, float* dst, int Kp, int Np,
+                      hipStream_t s);
+// backward recurrent operand: tile j, k = 4u+g (unit u, gate g) -> W[(row0 + 16j + c)*ld + g*L + u]
+// written at k offset k_off of tiles holding Ktot k's: dst [L/16][Ktot/4][16][4]
+void launch_pack_tiles_t(const float* W, int ld, int row0, int L, float* dst, int Ktot, int k_off,
+                         hipStream_t s);
+
+// One reverse-time step of one LSTM layer: rec = dz_next . W^T (MFMA, K = 4L or 8L), then the cell
+// backward of step t in the epilogue (Appendix A.1 differentiated; masking as dynamic_rnn A.2).
+struct LstmBwdJob {
+  int active;
+  const float* A0;        // dz operand, k-interleaved [L][R][4] (k = 4u+g), first 4L k's
+  const float* A1;        // second 4L k's (layer 0: its own dz of step t+1) or nullptr
+  int K, R;
+  const float* Wt;        // packed tiles [L/16][K/4][16][4]
+  int gemm;               // 0: dz operands are all zero (first launch), skip the contraction
+  int cell;               // 0: only produce dH (gradient of the initial state), no cell backward
+  int t, T;
+  const int32_t* seq_len; // [N] or nullptr
+  const float4* gates;    // [N][L] saved (i,j,f,o) of step t
+  const float* c_new;     // [N][L] cell state after step t
+  const float* c_prev;    // [N][L] cell state before step t
+  const float* dout;      // [N][L] gradient arriving at this layer's output of step t, or nullptr
+  float* dH;              // [N][L] carried gradient of the hidden state (in/out)
+  float* dC;              // [N][L] carried gradient of the cell state (in/out)
+  float* dz_k;            // out: k-interleaved [L][R][4]
+  float* dz_rm;           // out: row-major [N][4L], reference column order g*L+u
+};
+void launch_lstm_bwd_step(const LstmBwdJob* jobs, int njobs, int N, int L, hipStream_t s);
+
+// dxtab[v][c] = sum_{r : idx[r] == v} dz[r][c]     (gradient of the input-projection tables)
+void launch_xtab_grad(const float* dz, const int32_t* idx, int R, int ncols, int V, float* dxtab,
+                      hipStream_t s);
+// idx[t*N+n] = t == 0 ? go_row : gt[(t-1)*N+n]
+void launch_dec_xidx(const int32_t* gt, int Td, int N, int go_row, int32_t* idx, hipStream_t s);
+
+struct DecBwdArgs {
+  const float* scores;     // [Td][N][V] token logits of the forward pass
+  const int32_t* gt;       // [Td][N]
+  const float* q;          // [Td][N][L]
+  const float* eht;        // [T][N][L]
+  const float* eout;       // [T][N][L]
+  const float* atts;       // [Td][T][N]
+  const float* datts_wv;   // [Td][T][N] gradient arriving through word_vecs
+  const int32_t* seq_len;  // [N]
+  const float* v;          // [L]
+  const float* Wy;         // [2L][V]
+  int T, N, L, V, Td;
+  float inv_n;             // 1/N of the batch mean
+  float* dsc;              // [Td][N][16] d token logits (zero padded)
+  float* dout;             // [Td][N][L] direct part of d(top-layer h)
+  float* dctx;             // [Td][N][L]
+  float* de;               // [Td][T][N]
+  float* dq;               // [Td][N][L]
+  float* dvp;              // [Td*N][L] per-(t,n) partial of d v
+  float* deht;             // [T][N][L]
+  float* deout;            // [T][N][L]
+};
+void launch_dec_bwd_a(const DecBwdArgs& a, hipStream_t s);   // per (n, t)
+void launch_dec_bwd_b(const DecBwdArgs& a, hipStream_t s);   // per (tau, n)
+
+// word_vecs = sum_tau atts * emb[seq]: datts_wv and the embedding gradient (atomic)
+void launch_word_vecs_bwd(const float* dwv, const float* atts, const int32_t* seq,
+                          const int32_t* seq_len, const float* emb, int T_dec, int T_enc, int N,
+                          int E, float* datts_wv, float* gemb, hipStream_t s);
+
+// losses[0] = mean CE(scores, labels), losses[1] = mean(-log_seq_prob); dscores = (p - onehot)/N
+void launch_loss(const float* scores, const int32_t* labels, const float* log_seq_prob, int N,
+                 int C, float* dscores, float* losses, hipStream_t s);
+
+void launch_loss_total(float* losses, float wd, hipStream_t s);
+
+struct ModuleGrads {
+  float* garena;          // [max_nodes][HWp]   d loss / d attention map of a node
+  float* dtmap;           // [max_text][Mp]     (zeroed; Find-type parts add atomically)
+  float* dpfc;            // [max_pool][2][Mp]  d fc_att output (zeroed)
+  float* dmfind;          // [N][HW][Mp]        d conv_image map, FindModule weights (zeroed)
+  float* dmfsp;
+  const float* dscores;   // [rows][C]
+  float* dwv;             // [T_dec][N_full][E] (zeroed)
+  // destinations inside the flat gradient buffer (reference layouts)
+  float* gwe[3]; float* gbe[3];        // conv_eltwise of Find / FSP / Transform
+  float* gKt; float* gbt;              // Transform conv_maps
+  float* gbatt[4];                     // fc_att biases: FSP, SameProperty(0,1), Describe
+  float* gWans[7]; float* gbans[7];    // answer FCs (order of ModuleWeights::Wans)
+};
+void launch_heads_bwd(const ModuleWeights& w, const ModuleBuffers& b, const ModuleGrads& g,
+                      int tab_off, int count, hipStream_t s);
+// tab entries of a node are `stride` int32 apart (forward pooling table: 2*POOL_PARTS)
+void launch_pool_bwd(const ModuleWeights& w, const ModuleBuffers& b, const ModuleGrads& g,
+                     int tab_off, int count, int stride, hipStream_t s);
+void launch_att_bwd(const ModuleWeights& w, const ModuleBuffers& b, const ModuleGrads& g,
+                    int tab_off, int count, hipStream_t s);
+void launch_textmap_bwd(const ModuleWeights& w, const ModuleBuffers& b, const ModuleGrads& g,
+                        int tab_off, int count, hipStream_t s);
+
+// Optimiser.  Segment table: seg[i] = {var, begin, end} over the flat parameter vector.
+struct ParamSeg { int32_t var; int32_t pad; int64_t begin, end; };
+// g[i] = g[i]*scale + wd*w[i] (only where decay[var] != 0); l2 += 0.5*w^2 over decayed vars
+void launch_grad_finish(float* grads, const float* const* mirrors, const int64_t* var_off,
+                        const int32_t* decay, const ParamSeg* segs, int nsegs, float scale, float wd,
+                        float* l2_out, hipStream_t s);
+void launch_grad_sqnorm(const float* grads, const ParamSeg* segs, int nsegs, float scale,
+                        float* norm2, hipStream_t s);
+// per-tensor tf.clip_by_norm then Adam (TF 1.0.0 formula) on the mirrors
+void launch_adam(const float* grads, float* const* mirrors, const int64_t* var_off,
+                 const ParamSeg* segs, int nsegs, const float* norm2, float scale, float clip,
+                 float lr_t, float beta1, float beta2, float eps, float* m, float* v,
+                 hipStream_t s);
 
 }  // namespace n2nmn

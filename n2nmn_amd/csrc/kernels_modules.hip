@@ -484,6 +484,8 @@ __global__ __launch_bounds__(MT) void pool_kernel(ModuleWeights w, ModuleBuffers
     float s = 0.f;
     for (int q = 0; q < nrow; ++q) s += stage[(size_t)q * 2 * Dp + i];
     pooled[i] = s;
+    if (b.pooled)                        // training: [pslot][input][D]
+      b.pooled[((size_t)nd.pslot * 2 + i / Dp) * D + c0 + (i % Dp)] = s;
   }
   __syncthreads();
 

@@ -233,13 +233,20 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_kernel(LstmJobs jobs, 
       return;
     }
     const size_t idx = (size_t)gr * L + 4 * tile + ul;
-    float c_new = c_old * fast_sigmoid(z[2] + 1.0f) + fast_sigmoid(z[0]) * fast_tanh(z[1]);
-    float h_new = fast_tanh(c_new) * fast_sigmoid(z[3]);
+    const float gi = fast_sigmoid(z[0]), gj = fast_tanh(z[1]), gf = fast_sigmoid(z[2] + 1.0f),
+                go = fast_sigmoid(z[3]);
+    float c_new = c_old * gf + gi * gj;
+    float h_new = fast_tanh(c_new) * go;
     float o = h_new;
     if (masked) { c_new = c_old; h_new = h_prev; o = 0.f; }
     jb.c_out[idx] = c_new;
     jb.h_new[jb.hp_R > 0 ? ((size_t)tile * jb.hp_R + gr) * 4 + ul : idx] = h_new;
     const size_t oidx = (size_t)orow * L + 4 * tile + ul;
+    if (jb.save_gates) {          // training: keep what the cell backward needs (masked rows keep
+      jb.save_gates[oidx] = make_float4(gi, gj, gf, go);   // finite values; their dz is zero)
+      jb.save_c[oidx] = c_new;
+      jb.save_h[oidx] = h_new;
+    }
     if (jb.out_seq) jb.out_seq[oidx] = o;
     if (jb.fin_c && jb.seq_len && jb.t == jb.seq_len[orow] - 1) {   // the row's last valid step
       jb.fin_c[oidx] = c_new;
@@ -370,6 +377,7 @@ __global__ __launch_bounds__(NT) void dec_attn_kernel(DecStepArgs a) {
       float s = 0.f;
       for (int sp = 0; sp < nsplit; ++sp) s += ctxp[(size_t)sp * L + k];
       ctx[k] = s;
+      if (a.ctx_out) a.ctx_out[tn * L + k] = s;
     }
     __syncthreads();
   }

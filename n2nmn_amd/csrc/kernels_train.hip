@@ -1,0 +1,757 @@
+// Backward-pass kernels of the training step (exp_clevr/train_clevr_gt_layout.py:104-130):
+// gradients of the behavioural-cloning objective through the layout generator
+// (models_clevr/nmn3_netgen_att.py) -- the module-network backward lives in
+// kernels_train_modules.hip.  TensorFlow computes these with its registered op gradients; here
+// each is a hand-written gfx950 kernel, and every gradient writer ACCUMULATES into the zeroed flat
+// gradient buffer.
+//
+//   gemm_tn        : all weight gradients  dW = X^T . dY          (MFMA 32x32x2 fp32, split-R)
+//   colsum         : bias gradients        db = sum_r dY[r, :]
+//   lstm_bwd_step  : one reverse-time step of an LSTM layer: dz_{t+1} . W^T on MFMA with the cell
+//                    backward of step t fused in the epilogue (BPTT; two layers pipelined per launch)
+//   xtab_grad      : gradient of the input-projection tables (the layer-0 x.W_x+b lookup)
+//   dec_bwd_a/b    : token-logit loss, additive attention, masked softmax backward
+//   word_vecs_bwd  : gradient of the text-attention word vectors
+//   loss, grad_finish, grad_sqnorm, adam : objective and optimiser (clip_by_norm + Adam)
+#include <algorithm>
+
+#include "device_utils.h"
+#include "kernels.h"
+
+namespace n2nmn {
+
+namespace {
+
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float t = __expf(2.0f * x);
+  return 1.0f - __fdividef(2.0f, t + 1.0f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// gemm_tn: C[m][n] += sum_r A[row(r)][m] * B[r][n]
+// 64x64 output tile, 4 waves (2x2) of one 32x32x2 fp32 MFMA accumulator each; the reduction runs
+// over rows r in k-tiles of 32.  Both operands arrive with r as the slow axis, so each loading
+// thread fetches a 4(r) x 4(m) block with four 16-B loads (coalesced along m), transposes it in
+// registers and writes the k-interleaved LDS layout [r/4][m][4] that lets one ds_read_b128 feed
+// four MFMAs (same compute loop as gemm_pk).  Threads 0..127 load A, 128..255 load B.
+// ---------------------------------------------------------------------------------------------
+constexpr int TBM = 64, TBN = 64, TBK = 32;
+constexpr int TLDS = TBM + 1;   // float4 units
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a, int r_per_split) {
+  __shared__ float4 As[2][TBK / 4][TLDS];
+  __shared__ float4 Bs[2][TBK / 4][TLDS];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int m0 = blockIdx.y * TBM, n0 = blockIdx.x * TBN;
+  const int rbeg = blockIdx.z * r_per_split;
+  const int rend = min(a.R, rbeg + r_per_split);
+  if (rbeg >= rend) return;
+
+  const bool isB = tid >= 128;
+  const int lt = tid & 127;
+  const int k4 = lt >> 4;            // 0..7: which group of 4 r-rows inside the k-tile
+  const int c4 = lt & 15;            // which float4 column (4 consecutive m or n)
+  const float* base = isB ? a.B : a.A;
+  const int ld = isB ? a.ldb : a.lda;
+  const int cbeg = (isB ? n0 : m0) + 4 * c4;
+  const int clim = isB ? a.N : a.M;                 // columns >= clim read as zero
+  // a float4 load is issued when its first column is inside the (4-padded) row
+  const bool col_ok = cbeg < ((clim + 3) & ~3);
+  const int ccl = col_ok ? cbeg : 0;
+
+  float4 reg[4];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = rbeg + kt * TBK + 4 * k4 + j;
+      const bool rok = r < rend;
+      int src = rok ? r : rbeg;
+      bool sel_ok = true;
+      if (isB) {
+        if (a.b_sel) sel_ok = a.b_sel[src] == a.b_sel_val;
+      } else if (a.a_group_idx) {
+        const int g = src / a.a_group_size;
+        src = a.a_group_idx[g] * a.a_group_size + (src - g * a.a_group_size);
+      }
+      const float4 t = *reinterpret_cast<const float4*>(base + (size_t)src * ld + ccl);
+      const bool ok = rok && col_ok && sel_ok;
+      reg[j].x = (ok && cbeg + 0 < clim) ? t.x : 0.f;
+      reg[j].y = (ok && cbeg + 1 < clim) ? t.y : 0.f;
+      reg[j].z = (ok && cbeg + 2 < clim) ? t.z : 0.f;
+      reg[j].w = (ok && cbeg + 3 < clim) ? t.w : 0.f;
+    }
+  };
+  auto lstore = [&](int buf) {
+    float4(*dst)[TLDS] = isB ? Bs[buf] : As[buf];
+    dst[k4][4 * c4 + 0] = make_float4(reg[0].x, reg[1].x, reg[2].x, reg[3].x);
+    dst[k4][4 * c4 + 1] = make_float4(reg[0].y, reg[1].y, reg[2].y, reg[3].y);
+    dst[k4][4 * c4 + 2] = make_float4(reg[0].z, reg[1].z, reg[2].z, reg[3].z);
+    dst[k4][4 * c4 + 3] = make_float4(reg[0].w, reg[1].w, reg[2].w, reg[3].w);
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int li = lane & 31, kh = lane >> 5;
+  const int nkt = (rend - rbeg + TBK - 1) / TBK;
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nkt) gload(kt + 1);          // in flight during the MFMAs of tile kt
+#pragma unroll
+    for (int kq = 0; kq < TBK / 8; ++kq) {
+      const float4 av = As[cur][2 * kq + kh][wm * 32 + li];
+      const float4 bv = Bs[cur][2 * kq + kh][wn * 32 + li];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+    }
+    if (kt + 1 < nkt) lstore(cur ^ 1);        // the other buffer was last read in iteration kt-1
+    __syncthreads();
+  }
+  // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int col = n0 + wn * 32 + li;
+  if (col < a.N) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      if (row < a.M) atomicAdd(a.C + (size_t)row * a.ldc + col, acc[r]);
+    }
+  }
+}
+
+// dst[c] += sum_r src[r*ld + c]; lanes own consecutive columns, waves / blockIdx.y split the rows
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ src, int R,
+                                                     int ncols, int ld,
+                                                     const int32_t* __restrict__ sel, int sel_val,
+                                                     float* __restrict__ dst, int r_per_block) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int r0 = blockIdx.y * r_per_block, r1 = min(R, r0 + r_per_block);
+  float s0 = 0.f, s1 = 0.f;
+  if (c < ncols) {
+    int r = r0 + w;
+    for (; r + 4 < r1; r += 8) {
+      const bool k0 = !sel || sel[r] == sel_val, k1 = !sel || sel[r + 4] == sel_val;
+      const float v0 = src[(size_t)r * ld + c], v1 = src[(size_t)(r + 4) * ld + c];
+      s0 += k0 ? v0 : 0.f;
+      s1 += k1 ? v1 : 0.f;
+    }
+    if (r < r1 && (!sel || sel[r] == sel_val)) s0 += src[(size_t)r * ld + c];
+  }
+  part[w][lane] = s0 + s1;
+  __syncthreads();
+  if (w == 0 && c < ncols)
+    atomicAdd(dst + c, part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);
+}
+
+__global__ void pack_pk_t_kernel(const float* __restrict__ src, int ld, int K, int N,
+                                 float* __restrict__ dst, int Kp, int Np) {
+  const size_t total = (size_t)Kp * Np;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int kk = (int)(i & 3);
+    const size_t r = i >> 2;
+    const int n = (int)(r % Np);
+    const int k = (int)(r / Np) * 4 + kk;
+    dst[i] = (k < K && n < N) ? src[(size_t)n * ld + k] : 0.f;
+  }
+}
+
+// dst[((j*(Ktot/4) + k_off/4 + u)*16 + c)*4 + g] = W[(row0 + 16j + c)*ld + g*L + u]
+__global__ void pack_tiles_t_kernel(const float* __restrict__ W, int ld, int row0, int L,
+                                    float* __restrict__ dst, int Ktot, int k_off) {
+  const size_t total = (size_t)(L / 16) * L * 64;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i & 3);
+    const int c = (int)((i >> 2) & 15);
+    const size_t r = i >> 6;
+    const int u = (int)(r % L);
+    const int j = (int)(r / L);
+    dst[(((size_t)j * (Ktot / 4) + k_off / 4 + u) * 16 + c) * 4 + g] =
+        W[(size_t)(row0 + 16 * j + c) * ld + (size_t)g * L + u];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// lstm_bwd_step_kernel.  Reverse-time recurrence of one layer (grid.y = job):
+//
+//   rec[n, u]  = sum_k dz_next[n, k] * Wt[k, u]          k = 4*unit + gate over K = 4L or 8L
+//   dh         = rec + (step t+1 masked ? dH[n,u] : 0) + dout[n,u]
+//   tc = tanh(c_t);  dc = dC + dh*o*(1-tc^2)
+//   dz_i = dc*j*i(1-i)  dz_j = dc*i*(1-j^2)  dz_f = dc*c_{t-1}*f(1-f)  dz_o = dh*tc*o(1-o)
+//   dC <- dc*f
+//
+// (gates saved after their nonlinearities; f already contains the +1 forget bias).  A row past
+// its length at step t (dynamic_rnn carries the state through, Appendix A.2) emits dz = 0 and
+// leaves dH / dC untouched; "step T" counts as masked for every row so the initial carry (the
+// decoder's gradient of the encoder state) enters through dH / dC.
+//
+// CDNA4 mapping mirrors lstm_step_kernel: a workgroup owns 16 hidden units (one 16x16x4 MFMA
+// N-tile) x 32 batch rows; its 8 waves split K and stream dz (k-interleaved [unit][row][4 gates],
+// so an A fragment is 4 x 256-B contiguous) and the pre-transposed weight tile straight from L2
+// into MFMA registers; partial tiles are reduced through LDS and the cell backward runs in the
+// same kernel.  Layer 0's job contracts over [dz1_{t}; dz0_{t+1}] (K = 8L) so that the gradient
+// from the layer above and the recurrent gradient come out of ONE accumulation.
+// ---------------------------------------------------------------------------------------------
+constexpr int BW_WAVES = 8;
+constexpr int BW_THREADS = BW_WAVES * 64;
+constexpr int BW_MT = 2;                 // 16-row M tiles per workgroup
+
+struct LstmBwdJobs {
+  LstmBwdJob j[2];
+};
+
+__global__ __launch_bounds__(BW_THREADS) void lstm_bwd_step_kernel(LstmBwdJobs jobs, int N,
+                                                                   int L) {
+  const LstmBwdJob& jb = jobs.j[blockIdx.y];
+  if (!jb.active) return;
+  __shared__ float part[BW_WAVES][16 * BW_MT][17];
+  constexpr int ROWS = 16 * BW_MT;
+  const int tile = blockIdx.x;
+  const int row0 = blockIdx.z * ROWS;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int ci = lane & 15, kg = lane >> 4;
+
+  f32x4 acc[BW_MT];
+#pragma unroll
+  for (int m = 0; m < BW_MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (jb.gemm) {
+    const int K = jb.K, R = jb.R;
+    const int kper = K / BW_WAVES;                 // k's of this wave (multiple of 16)
+    const int kbeg = w * kper;
+    const int K1 = 4 * L;                          // k's held by A0
+    const float* Asrc = (kbeg < K1) ? jb.A0 : jb.A1;
+    const int kloc = (kbeg < K1) ? kbeg : kbeg - K1;
+    const float4* Wp4 = reinterpret_cast<const float4*>(jb.Wt) + (size_t)tile * (K / 4) * 16 +
+                        (size_t)((kbeg >> 2) + kg) * 16 + ci;
+    const float* ar[BW_MT];
+#pragma unroll
+    for (int m = 0; m < BW_MT; ++m) {
+      int r = row0 + 16 * m + ci;
+      r = r < N ? r : N - 1;
+      ar[m] = Asrc + ((size_t)((kloc >> 2) + kg) * R + r) * 4;
+    }
+    const int nch = kper / 16;
+    constexpr int UN = 8;                          // chunks in flight
+    for (int q0 = 0; q0 < nch; q0 += UN) {
+      float4 bq[UN];
+      float4 aq[UN][BW_MT];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int q = q0 + u < nch ? q0 + u : nch - 1;
+        bq[u] = Wp4[(size_t)q * 64];
+#pragma unroll
+        for (int m = 0; m < BW_MT; ++m)
+          aq[u][m] = *reinterpret_cast<const float4*>(ar[m] + (size_t)(4 * q) * R * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        if (q0 + u < nch) {
+#pragma unroll
+          for (int m = 0; m < BW_MT; ++m) {
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[u][m].x, bq[u].x, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[u][m].y, bq[u].y, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[u][m].z, bq[u].z, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[u][m].w, bq[u].w, acc[m], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+  for (int m = 0; m < BW_MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[w][16 * m + 4 * kg + r][ci] = acc[m][r];
+  __syncthreads();
+
+  // ---- epilogue: thread = (row, unit) ---------------------------------------------------------
+  const int erow = tid >> 4, ul = tid & 15;
+  const int n = row0 + erow;
+  if (erow >= ROWS || n >= N) return;
+  const int u = 16 * tile + ul;
+  float rec = 0.f;
+#pragma unroll
+  for (int ww = 0; ww < BW_WAVES; ++ww) rec += part[ww][erow][ul];
+  const size_t idx = (size_t)n * L + u;
+  const int len = jb.seq_len ? jb.seq_len[n] : jb.T;
+  const bool m_next = jb.t + 1 >= len;            // step t+1 carried the state through
+  const float dh_state = rec + (m_next ? jb.dH[idx] : 0.f);
+  if (!jb.cell) {                                 // gradient of the initial hidden state
+    jb.dH[idx] = dh_state;                        // (there is no step -1: its dz operand is zero)
+    *reinterpret_cast<float4*>(jb.dz_k + ((size_t)u * jb.R + n) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+  float4 dz = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (jb.t < len) {
+    const float dh = dh_state + (jb.dout ? jb.dout[idx] : 0.f);
+    const float4 g = jb.gates[idx];               // i, j, f, o
+    const float tc = fast_tanh(jb.c_new[idx]);
+    const float dc = jb.dC[idx] + dh * g.w * (1.f - tc * tc);
+    dz.x = dc * g.y * g.x * (1.f - g.x);
+    dz.y = dc * g.x * (1.f - g.y * g.y);
+    dz.z = dc * jb.c_prev[idx] * g.z * (1.f - g.z);
+    dz.w = dh * tc * g.w * (1.f - g.w);
+    jb.dC[idx] = dc * g.z;
+  }                                               // masked: dH / dC keep carrying
+  *reinterpret_cast<float4*>(jb.dz_k + ((size_t)u * jb.R + n) * 4) = dz;
+  float* zr = jb.dz_rm + (size_t)n * 4 * L + u;
+  zr[0] = dz.x; zr[L] = dz.y; zr[2 * L] = dz.z; zr[3 * L] = dz.w;
+}
+
+// dxtab[v][c] = sum_{r: idx[r]==v} dz[r][c]; grid (V, ncols/256).  No atomics: the row indices are
+// scanned from LDS in ascending order by every thread (uniform branch), so the sum is deterministic.
+__global__ __launch_bounds__(256) void xtab_grad_kernel(const float* __restrict__ dz,
+                                                        const int32_t* __restrict__ idx, int R,
+                                                        int ncols, float* __restrict__ dxtab) {
+  __shared__ int32_t lidx[256];
+  const int v = blockIdx.x;
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  const int cc = c < ncols ? c : 0;
+  float s = 0.f;
+  for (int rb = 0; rb < R; rb += 256) {
+    const int r = rb + threadIdx.x;
+    lidx[threadIdx.x] = r < R ? idx[r] : -1;
+    __syncthreads();
+    const int lim = min(256, R - rb);
+    for (int i = 0; i < lim; ++i)
+      if (lidx[i] == v) s += dz[(size_t)(rb + i) * ncols + cc];
+    __syncthreads();
+  }
+  if (c < ncols) dxtab[(size_t)v * ncols + c] = s;
+}
+
+__global__ void dec_xidx_kernel(const int32_t* __restrict__ gt, int Td, int N, int go_row,
+                                int32_t* __restrict__ idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < Td * N) idx[i] = i < N ? go_row : gt[i - N];
+}
+
+// ---------------------------------------------------------------------------------------------
+// dec_bwd_a: one workgroup per (question n, decoder step t).  Backward of everything after the
+// LSTM cell of that step (nmn3_netgen_att.py:184-256 with use_gt_layout: all tokens valid):
+//   dsc   = (softmax(token_scores) - onehot(gt)) / N              d(-mean log_seq_prob)
+//   dout  = W_y[:L] . dsc ;  dctx = W_y[L:] . dsc
+//   datt  = dctx . eout[tau] + datts_wv ;  de = att * (datt - sum att*datt)   (masked softmax)
+//   dq_k  = sum_tau de[tau] v_k (1 - th^2) ;  dv_k partial = sum_tau de[tau] th,
+//   th = tanh(q_k + eht[tau,n,k])
+// ---------------------------------------------------------------------------------------------
+constexpr int DB_MAXKI = 4;     // lstm_dim <= 1024
+__global__ __launch_bounds__(256) void dec_bwd_a_kernel(DecBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int L = a.L, T = a.T, N = a.N, V = a.V;
+  float* dctx = smem;                 // [L]
+  float* des = dctx + L;              // [T]  datt -> de
+  float* ats = des + ((T + 3) & ~3);  // [T]
+  float* dscs = ats + ((T + 3) & ~3); // [16]
+  float* red = dscs + 16;             // [4 waves][2][L] partial dq / dv
+  const int n = blockIdx.x, t = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const size_t tn = (size_t)t * N + n;
+  const int len = a.seq_len[n];
+
+  if (w == 0) {                       // softmax of the token logits
+    const bool on = lane < V;
+    const float sc = on ? a.scores[tn * V + lane] : -INFINITY;
+    const float mx = wave_max(sc);
+    const float ex = on ? expf(sc - mx) : 0.f;
+    const float den = wave_sum(ex);
+    if (lane < 16) {
+      const float d = on ? (ex / den - (lane == a.gt[tn] ? 1.f : 0.f)) * a.inv_n : 0.f;
+      dscs[lane] = d;
+      a.dsc[tn * 16 + lane] = d;
+    }
+  }
+  for (int tau = tid; tau < T; tau += 256) ats[tau] = a.atts[((size_t)t * T + tau) * N + n];
+  __syncthreads();
+  for (int k = tid; k < 2 * L; k += 256) {
+    const float* wr = a.Wy + (size_t)k * V;
+    float s = 0.f;
+    for (int sI = 0; sI < V; ++sI) s += wr[sI] * dscs[sI];
+    if (k < L) a.dout[tn * L + k] = s;
+    else { dctx[k - L] = s; a.dctx[tn * L + (k - L)] = s; }
+  }
+  __syncthreads();
+  // datt[tau] = dctx . eout[tau, n, :] + datts_wv     (wave per tau)
+  for (int tau = w; tau < T; tau += 4) {
+    float s = 0.f;
+    if (tau < len) {
+      const float* er = a.eout + ((size_t)tau * N + n) * L;
+      for (int k = 4 * lane; k < L; k += 256) {
+        const float4 e4 = *reinterpret_cast<const float4*>(er + k);
+        const float4 d4 = *reinterpret_cast<const float4*>(dctx + k);
+        s += e4.x * d4.x + e4.y * d4.y + e4.z * d4.z + e4.w * d4.w;
+      }
+    }
+    s = wave_sum(s);
+    if (lane == 0) des[tau] = s + a.datts_wv[((size_t)t * T + tau) * N + n];
+  }
+  __syncthreads();
+  {
+    float ls = 0.f;
+    for (int tau = tid; tau < T; tau += 256) ls += ats[tau] * des[tau];
+    const float sad = block_reduce<0>(ls, dscs);       // dscs no longer needed
+    for (int tau = tid; tau < T; tau += 256) {
+      const float d = ats[tau] * (des[tau] - sad);      // att == 0 past the length
+      des[tau] = d;
+      a.de[((size_t)t * T + tau) * N + n] = d;
+    }
+  }
+  __syncthreads();
+  // dq / dv partials: lanes own k (float4), waves stride over tau
+  {
+    float4 v4[DB_MAXKI], q4[DB_MAXKI], dq4[DB_MAXKI], dv4[DB_MAXKI];
+    const float* qrow = a.q + tn * L;
+#pragma unroll
+    for (int i = 0; i < DB_MAXKI; ++i) {
+      const int k = 4 * lane + 256 * i;
+      dq4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      dv4[i] = dq4[i];
+      if (k < L) {
+        v4[i] = *reinterpret_cast<const float4*>(a.v + k);
+        q4[i] = *reinterpret_cast<const float4*>(qrow + k);
+      }
+    }
+    for (int tau = w; tau < len && tau < T; tau += 4) {
+      const float d = des[tau];
+      const float* er = a.eht + ((size_t)tau * N + n) * L;
+#pragma unroll
+      for (int i = 0; i < DB_MAXKI; ++i) {
+        const int k = 4 * lane + 256 * i;
+        if (k < L) {
+          const float4 e4 = *reinterpret_cast<const float4*>(er + k);
+          const float t0 = fast_tanh(q4[i].x + e4.x), t1 = fast_tanh(q4[i].y + e4.y),
+                      t2 = fast_tanh(q4[i].z + e4.z), t3 = fast_tanh(q4[i].w + e4.w);
+          dv4[i].x += d * t0; dv4[i].y += d * t1; dv4[i].z += d * t2; dv4[i].w += d * t3;
+          dq4[i].x += d * v4[i].x * (1.f - t0 * t0); dq4[i].y += d * v4[i].y * (1.f - t1 * t1);
+          dq4[i].z += d * v4[i].z * (1.f - t2 * t2); dq4[i].w += d * v4[i].w * (1.f - t3 * t3);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < DB_MAXKI; ++i) {
+      const int k = 4 * lane + 256 * i;
+      if (k < L) {
+        *reinterpret_cast<float4*>(red + (size_t)(w * 2 + 0) * L + k) = dq4[i];
+        *reinterpret_cast<float4*>(red + (size_t)(w * 2 + 1) * L + k) = dv4[i];
+      }
+    }
+  }
+  __syncthreads();
+  for (int k = tid; k < L; k += 256) {
+    float sq = 0.f, sv = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) { sq += red[(size_t)(ww * 2) * L + k]; sv += red[(size_t)(ww * 2 + 1) * L + k]; }
+    a.dq[tn * L + k] = sq;
+    a.dvp[tn * L + k] = sv;
+  }
+}
+
+// dec_bwd_b: one workgroup per (encoder step tau, question n), lanes over k:
+//   deht[tau,n,k]  = sum_t de[t,tau,n] v_k (1 - tanh^2(q[t,n,k] + eht[tau,n,k]))
+//   deout[tau,n,k] = sum_t att[t,tau,n] dctx[t,n,k]
+__global__ __launch_bounds__(128) void dec_bwd_b_kernel(DecBwdArgs a) {
+  const int L = a.L, T = a.T, N = a.N;
+  const int tau = blockIdx.x, n = blockIdx.y;
+  const int len = a.seq_len[n];
+  const size_t row = ((size_t)tau * N + n) * L;
+  for (int k = 4 * threadIdx.x; k < L; k += 512) {
+    float4 dh = make_float4(0.f, 0.f, 0.f, 0.f), dob = dh;
+    if (tau < len) {
+      const float4 e4 = *reinterpret_cast<const float4*>(a.eht + row + k);
+      const float4 v4 = *reinterpret_cast<const float4*>(a.v + k);
+      for (int t = 0; t < a.Td; ++t) {
+        const size_t tn = (size_t)t * N + n;
+        const float d = a.de[((size_t)t * T + tau) * N + n];
+        const float at = a.atts[((size_t)t * T + tau) * N + n];
+        const float4 q4 = *reinterpret_cast<const float4*>(a.q + tn * L + k);
+        const float4 c4 = *reinterpret_cast<const float4*>(a.dctx + tn * L + k);
+        const float t0 = fast_tanh(q4.x + e4.x), t1 = fast_tanh(q4.y + e4.y),
+                    t2 = fast_tanh(q4.z + e4.z), t3 = fast_tanh(q4.w + e4.w);
+        dh.x += d * v4.x * (1.f - t0 * t0); dh.y += d * v4.y * (1.f - t1 * t1);
+        dh.z += d * v4.z * (1.f - t2 * t2); dh.w += d * v4.w * (1.f - t3 * t3);
+        dob.x += at * c4.x; dob.y += at * c4.y; dob.z += at * c4.z; dob.w += at * c4.w;
+      }
+    }
+    *reinterpret_cast<float4*>(a.deht + row + k) = dh;
+    *reinterpret_cast<float4*>(a.deout + row + k) = dob;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// word_vecs_bwd: word_vecs[t,n,:] = sum_tau atts[t,tau,n] * emb[seq[tau,n],:]
+//   datts_wv[t,tau,n] = dwv[t,n,:] . emb[seq[tau,n],:]
+//   gemb[seq[tau,n],:] += sum_t atts[t,tau,n] * dwv[t,n,:]        (atomic; tau < len only)
+// one workgroup per question; its embedding rows and dwv rows are staged in LDS.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void word_vecs_bwd_kernel(
+    const float* __restrict__ dwv, const float* __restrict__ atts, const int32_t* __restrict__ seq,
+    const int32_t* __restrict__ seq_len, const float* __restrict__ emb, int T_dec, int T_enc,
+    int N, int E, float* __restrict__ datts_wv, float* __restrict__ gemb) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* rows = smem;                          // [T_enc][E]
+  float* dw = rows + (size_t)T_enc * E;        // [T_dec][E]
+  float* at = dw + (size_t)T_dec * E;          // [T_dec][T_enc]
+  int* idx = reinterpret_cast<int*>(at + (size_t)T_dec * T_enc);
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int len = seq_len[n];
+  for (int tau = tid; tau < T_enc; tau += 256) idx[tau] = seq[tau * N + n];
+  for (int i = tid; i < T_dec * T_enc; i += 256) {
+    const int t = i / T_enc, tau = i - t * T_enc;
+    at[i] = atts[((size_t)t * T_enc + tau) * N + n];
+  }
+  for (int i = tid; i < T_dec * E; i += 256) {
+    const int t = i / E, e = i - t * E;
+    dw[i] = dwv[((size_t)t * N + n) * E + e];
+  }
+  __syncthreads();
+  for (int i = tid; i < T_enc * E; i += 256) {
+    const int tau = i / E, e = i - tau * E;
+    rows[i] = emb[(size_t)idx[tau] * E + e];
+  }
+  __syncthreads();
+  for (int p = w; p < T_dec * T_enc; p += 4) {           // wave per (t, tau)
+    const int t = p / T_enc, tau = p - t * T_enc;
+    float s = 0.f;
+    for (int e = lane; e < E; e += 64) s += dw[t * E + e] * rows[tau * E + e];
+    s = wave_sum(s);
+    if (lane == 0) datts_wv[((size_t)t * T_enc + tau) * N + n] = s;
+  }
+  for (int i = tid; i < T_enc * E; i += 256) {
+    const int tau = i / E, e = i - tau * E;
+    if (tau < len) {
+      float s = 0.f;
+      for (int t = 0; t < T_dec; ++t) s += at[t * T_enc + tau] * dw[t * E + e];
+      atomicAdd(gemb + (size_t)idx[tau] * E + e, s);
+    }
+  }
+}
+
+// losses[0] = mean_n CE(scores[n], label[n]);  losses[1] = mean_n(-log_seq_prob[n])
+// dscores[n][c] = (softmax(scores[n])[c] - [c == label]) / N
+// (tf.nn.sparse_softmax_cross_entropy_with_logits + reduce_mean, train_clevr_gt_layout.py:104-111)
+__global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ scores,
+                                                   const int32_t* __restrict__ labels,
+                                                   const float* __restrict__ log_seq_prob, int N,
+                                                   int C, float* __restrict__ dscores,
+                                                   float* __restrict__ losses) {
+  __shared__ float scratch[16];
+  float ce = 0.f, nl = 0.f;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const float* z = scores + (size_t)n * C;
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, z[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(z[c] - mx);
+    const int lab = labels[n];
+    ce += logf(s) + mx - z[lab];
+    for (int c = 0; c < C; ++c)
+      dscores[(size_t)n * C + c] = (expf(z[c] - mx) / s - (c == lab ? 1.f : 0.f)) / (float)N;
+    nl -= log_seq_prob[n];
+  }
+  const float tce = block_reduce<0>(ce, scratch);
+  const float tnl = block_reduce<0>(nl, scratch);
+  if (threadIdx.x == 0) {
+    losses[0] = tce / (float)N;
+    losses[1] = tnl / (float)N;
+  }
+}
+
+// total_loss = seq_likelihood_loss + avg_sample_loss + weight_decay * l2_reg   (:113-114)
+__global__ void loss_total_kernel(float* __restrict__ losses, float wd) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) losses[3] = losses[0] + losses[1] + wd * losses[2];
+}
+
+// ---------------------------------------------------------------------------------------------
+// optimiser (train_clevr_gt_layout.py:112-120): total_loss includes weight_decay * l2_reg over the
+// variables named '.../weights' (nmn3_model.py:161-166); per-tensor tf.clip_by_norm(g, 10);
+// tf.train.AdamOptimizer() with its TF 1.0.0 defaults.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void grad_finish_kernel(float* __restrict__ grads,
+                                                          const float* const* __restrict__ mirrors,
+                                                          const int64_t* __restrict__ var_off,
+                                                          const int32_t* __restrict__ decay,
+                                                          const ParamSeg* __restrict__ segs,
+                                                          float scale, float wd,
+                                                          float* __restrict__ l2_out) {
+  __shared__ float scratch[16];
+  const ParamSeg sg = segs[blockIdx.x];
+  const bool dec = decay[sg.var] != 0;
+  const float* wsrc = mirrors[sg.var] - var_off[sg.var];
+  float l2 = 0.f;
+  for (int64_t i = sg.begin + threadIdx.x; i < sg.end; i += 256) {
+    float g = grads[i] * scale;
+    if (dec) {
+      const float wv = wsrc[i];
+      g += wd * wv;
+      l2 += 0.5f * wv * wv;
+    }
+    grads[i] = g;
+  }
+  const float t = block_reduce<0>(l2, scratch);
+  if (dec && threadIdx.x == 0) atomicAdd(l2_out, t);
+}
+
+__global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* __restrict__ grads,
+                                                          const ParamSeg* __restrict__ segs,
+                                                          float scale, float* __restrict__ norm2) {
+  __shared__ float scratch[16];
+  const ParamSeg sg = segs[blockIdx.x];
+  float s = 0.f;
+  for (int64_t i = sg.begin + threadIdx.x; i < sg.end; i += 256) {
+    const float g = grads[i] * scale;
+    s += g * g;
+  }
+  const float t = block_reduce<0>(s, scratch);
+  if (threadIdx.x == 0) atomicAdd(norm2 + sg.var, t);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(const float* __restrict__ grads,
+                                                   float* const* __restrict__ mirrors,
+                                                   const int64_t* __restrict__ var_off,
+                                                   const ParamSeg* __restrict__ segs,
+                                                   const float* __restrict__ norm2, float scale,
+                                                   float clip, float lr_t, float beta1, float beta2,
+                                                   float eps, float* __restrict__ m,
+                                                   float* __restrict__ v) {
+  const ParamSeg sg = segs[blockIdx.x];
+  // tf.clip_by_norm: g * clip / max(||g||, clip)
+  const float cs = scale * clip / fmaxf(sqrtf(norm2[sg.var]), clip);
+  float* wdst = mirrors[sg.var] - var_off[sg.var];
+  for (int64_t i = sg.begin + threadIdx.x; i < sg.end; i += 256) {
+    const float g = grads[i] * cs;
+    const float mi = beta1 * m[i] + (1.f - beta1) * g;
+    const float vi = beta2 * v[i] + (1.f - beta2) * g * g;
+    m[i] = mi;
+    v[i] = vi;
+    wdst[i] -= lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+void launch_gemm_tn(const GemmTnArgs& a, hipStream_t s) {
+  if (a.M <= 0 || a.N <= 0 || a.R <= 0) return;
+  const int gx = (a.N + TBN - 1) / TBN, gy = (a.M + TBM - 1) / TBM;
+  // split the reduction until the launch has ~2 workgroups per CU (k-tiles of 32 rows)
+  int splits = 1;
+  const int nkt = (a.R + TBK - 1) / TBK;
+  while (gx * gy * splits < 512 && splits * 2 <= nkt / 4) splits *= 2;
+  int r_per = ((nkt + splits - 1) / splits) * TBK;
+  splits = (a.R + r_per - 1) / r_per;
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(gx, gy, splits), dim3(256), 0, s, a, r_per);
+}
+
+void launch_colsum(const float* src, int R, int ncols, int ld, const int32_t* sel, int sel_val,
+                   float* dst, hipStream_t s) {
+  if (R <= 0 || ncols <= 0) return;
+  const int gx = (ncols + 63) / 64;
+  int gy = 1;
+  while (gx * gy < 256 && R / (gy * 2) >= 32) gy *= 2;
+  const int r_per = (R + gy - 1) / gy;
+  hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(256), 0, s, src, R, ncols, ld, sel, sel_val,
+                     dst, r_per);
+}
+
+void launch_pack_pk_t(const float* src, int ld, int K, int N, float* dst, int Kp, int Np,
+                      hipStream_t s) {
+  const size_t total = (size_t)Kp * Np;
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
+  hipLaunchKernelGGL(pack_pk_t_kernel, dim3(blocks), dim3(256), 0, s, src, ld, K, N, dst, Kp, Np);
+}
+
+void launch_pack_tiles_t(const float* W, int ld, int row0, int L, float* dst, int Ktot, int k_off,
+                         hipStream_t s) {
+  const size_t total = (size_t)(L / 16) * L * 64;
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
+  hipLaunchKernelGGL(pack_tiles_t_kernel, dim3(blocks), dim3(256), 0, s, W, ld, row0, L, dst, Ktot,
+                     k_off);
+}
+
+void launch_lstm_bwd_step(const LstmBwdJob* jobs, int njobs, int N, int L, hipStream_t s) {
+  LstmBwdJobs js;
+  for (int i = 0; i < 2; ++i) {
+    if (i < njobs) js.j[i] = jobs[i];
+    else { js.j[i] = LstmBwdJob{}; js.j[i].active = 0; }
+  }
+  dim3 grid(L / 16, njobs, (N + 16 * BW_MT - 1) / (16 * BW_MT));
+  hipLaunchKernelGGL(lstm_bwd_step_kernel, grid, dim3(BW_THREADS), 0, s, js, N, L);
+}
+
+void launch_xtab_grad(const float* dz, const int32_t* idx, int R, int ncols, int V, float* dxtab,
+                      hipStream_t s) {
+  hipLaunchKernelGGL(xtab_grad_kernel, dim3(V, (ncols + 255) / 256), dim3(256), 0, s, dz, idx, R,
+                     ncols, dxtab);
+}
+
+void launch_dec_xidx(const int32_t* gt, int Td, int N, int go_row, int32_t* idx, hipStream_t s) {
+  hipLaunchKernelGGL(dec_xidx_kernel, dim3((Td * N + 255) / 256), dim3(256), 0, s, gt, Td, N,
+                     go_row, idx);
+}
+
+void launch_dec_bwd_a(const DecBwdArgs& a, hipStream_t s) {
+  const size_t smem = sizeof(float) * ((size_t)a.L + 2 * ((a.T + 3) & ~3) + 16 + 8 * (size_t)a.L);
+  hipLaunchKernelGGL(dec_bwd_a_kernel, dim3(a.N, a.Td), dim3(256), smem, s, a);
+}
+
+void launch_dec_bwd_b(const DecBwdArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(dec_bwd_b_kernel, dim3(a.T, a.N), dim3(128), 0, s, a);
+}
+
+void launch_word_vecs_bwd(const float* dwv, const float* atts, const int32_t* seq,
+                          const int32_t* seq_len, const float* emb, int T_dec, int T_enc, int N,
+                          int E, float* datts_wv, float* gemb, hipStream_t s) {
+  const size_t smem = sizeof(float) * ((size_t)T_enc * E + (size_t)T_dec * E +
+                                       (size_t)T_dec * T_enc + (size_t)T_enc + 4);
+  if (smem > 64 * 1024)      // a workgroup may use the whole 160 KiB LDS of a gfx950 CU
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(word_vecs_bwd_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(word_vecs_bwd_kernel, dim3(N), dim3(256), smem, s, dwv, atts, seq, seq_len,
+                     emb, T_dec, T_enc, N, E, datts_wv, gemb);
+}
+
+void launch_loss(const float* scores, const int32_t* labels, const float* log_seq_prob, int N,
+                 int C, float* dscores, float* losses, hipStream_t s) {
+  hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(256), 0, s, scores, labels, log_seq_prob, N, C,
+                     dscores, losses);
+}
+
+void launch_loss_total(float* losses, float wd, hipStream_t s) {
+  hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(64), 0, s, losses, wd);
+}
+
+void launch_grad_finish(float* grads, const float* const* mirrors, const int64_t* var_off,
+                        const int32_t* decay, const ParamSeg* segs, int nsegs, float scale,
+                        float wd, float* l2_out, hipStream_t s) {
+  if (nsegs <= 0) return;
+  hipLaunchKernelGGL(grad_finish_kernel, dim3(nsegs), dim3(256), 0, s, grads, mirrors, var_off,
+                     decay, segs, scale, wd, l2_out);
+}
+
+void launch_grad_sqnorm(const float* grads, const ParamSeg* segs, int nsegs, float scale,
+                        float* norm2, hipStream_t s) {
+  if (nsegs <= 0) return;
+  hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(nsegs), dim3(256), 0, s, grads, segs, scale, norm2);
+}
+
+void launch_adam(const float* grads, float* const* mirrors, const int64_t* var_off,
+                 const ParamSeg* segs, int nsegs, const float* norm2, float scale, float clip,
+                 float lr_t, float beta1, float beta2, float eps, float* m, float* v,
+                 hipStream_t s) {
+  if (nsegs <= 0) return;
+  hipLaunchKernelGGL(adam_kernel, dim3(nsegs), dim3(256), 0, s, grads, mirrors, var_off, segs,
+                     norm2, scale, clip, lr_t, beta1, beta2, eps, m, v);
+}
+
+}  // namespace n2nmn

@@ -1,0 +1,174 @@
+"""Host side of the training step (BASELINE.json configs[3]): the loop body of
+exp_clevr/train_clevr_gt_layout.py:150-200 -- forward of the behavioural-cloning objective with
+ground-truth layouts, backward, per-tensor clip-by-norm, Adam -- on top of the C-ABI
+(include/n2nmn.h section 6), plus the data-parallel gradient exchange the reference does not have
+(SURVEY.md 8e): one flat fp32 gradient buffer, all-reduced in two buckets so that the decoder +
+module bucket travels over RCCL while the encoder's backward pass is still running.
+
+PyTorch is plumbing only (device buffers, streams, torch.distributed); all arithmetic is in
+libn2nmn_hip.so and there is no fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import _lib
+from .engine import Engine
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class GradBuckets:
+    """Two-bucket all-reduce of a flat gradient vector (sum over ranks; the optimiser applies the
+    1/world scale).  `late` = [split, numel) is ready first (decoder + modules), `early` =
+    [0, split) (encoder) last.  Works on any torch.distributed backend (RCCL on GPUs, gloo in
+    the CPU tests); world size 1 is a no-op."""
+
+    def __init__(self, flat, split: int, dist=None):
+        self.flat = flat
+        self.split = int(split)
+        self.dist = dist
+        self._pending = []
+
+    @property
+    def world(self) -> int:
+        return self.dist.get_world_size() if self.dist is not None else 1
+
+    def reduce_late(self):
+        if self.dist is not None and self.world > 1:
+            self._pending.append(self.dist.all_reduce(self.flat[self.split:], async_op=True))
+
+    def reduce_early(self):
+        if self.dist is not None and self.world > 1:
+            self._pending.append(self.dist.all_reduce(self.flat[:self.split], async_op=True))
+
+    def wait(self) -> float:
+        """Blocks the current stream on both collectives; returns the scale that turns the sum into
+        the mean over ranks."""
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+        return 1.0 / self.world
+
+
+class Trainer:
+    """One model replica on one GPU.  `step(batch, gt_layout)` = one iteration of
+    train_clevr_gt_layout.py: returns the losses of that iteration (device tensor of 4 floats:
+    avg_sample_loss, seq_likelihood_loss, l2_reg, total_loss)."""
+
+    def __init__(self, engine: Engine, weight_decay: float = 5e-6, lr: float = 1e-3,
+                 beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
+                 max_grad_l2_norm: float = 10.0, dist=None):
+        torch = _torch()
+        if engine._parent is not None:
+            raise ValueError('train on the root engine, not on a fork')
+        self.engine = engine
+        self._lib = engine._lib
+        self._ctx = engine._ctx
+        _lib.check(self._lib.n2nmn_train_enable(self._ctx))
+        self.numel = int(self._lib.n2nmn_grad_numel(self._ctx))
+        self.split = int(self._lib.n2nmn_grad_split(self._ctx))
+        self.weight_decay = float(weight_decay)
+        self.hyper = dict(lr=float(lr), beta1=float(beta1), beta2=float(beta2), eps=float(eps),
+                          max_grad_l2_norm=float(max_grad_l2_norm))
+        self.grads = torch.zeros(self.numel, dtype=torch.float32, device=engine.device)
+        self.losses = torch.zeros(4, dtype=torch.float32, device=engine.device)
+        self.scores = None
+        self.buckets = GradBuckets(self.grads, self.split, dist)
+        self.iteration = 0
+        _lib.check(self._lib.n2nmn_train_reset_optimizer(self._ctx, engine.stream()))
+        self.layout: Dict[str, tuple] = {}
+        names = list(engine.variable_names().items())
+        for i, (name, shape) in enumerate(names):
+            off, n = C.c_int64(), C.c_int64()
+            _lib.check(self._lib.n2nmn_grad_layout(self._ctx, i, C.byref(off), C.byref(n)))
+            self.layout[name] = (int(off.value), int(n.value), shape)
+        self._keep = None
+
+    # ------------------------------------------------------------------------------------
+    def _io(self, batch, gt_layout):
+        torch = _torch()
+        e = self.engine
+        d = e.dims
+        seq = e._dev(batch['input_seq_batch'], torch.int32)
+        lens = e._dev(batch['seq_length_batch'], torch.int32)
+        feat = e._dev(batch['image_feat_batch'], torch.float32)
+        labels = e._dev(batch['answer_label_batch'], torch.int32)
+        gt_host = np.ascontiguousarray(np.asarray(
+            gt_layout.cpu().numpy() if hasattr(gt_layout, 'cpu') else gt_layout), np.int32)
+        gt = e._dev(gt_host, torch.int32)
+        T, N = seq.shape
+        Td = gt.shape[0]
+        # teacher forcing: the layout is known before the forward, so the program is assembled
+        # up front and there is no host sync inside the step
+        packed, validity = e.assembler.assemble_packed(gt_host)
+        if self.scores is None or tuple(self.scores.shape) != (N, d.num_choices):
+            self.scores = torch.empty((N, d.num_choices), dtype=torch.float32, device=e.device)
+        io = _lib.TrainIO()
+        io.input_seq = seq.data_ptr(); io.seq_length = lens.data_ptr()
+        io.T_enc = T; io.N = N; io.T_dec = Td
+        io.gt_layout = gt.data_ptr(); io.image_feat = feat.data_ptr()
+        io.answer_labels = labels.data_ptr(); io.weight_decay = self.weight_decay
+        io.scores = self.scores.data_ptr(); io.losses = self.losses.data_ptr()
+        io.grads = self.grads.data_ptr()
+        self._keep = (seq, lens, feat, labels, gt, packed)
+        return io, packed, validity
+
+    def forward_backward(self, batch, gt_layout, reduce: bool = True) -> float:
+        """Forward + both backward phases (+ the bucketed all-reduce).  Afterwards self.grads is
+        d total_loss / d variables summed over ranks; returns the 1/world scale."""
+        io, packed, _ = self._io(batch, gt_layout)
+        s = self.engine.stream()
+        _lib.check(self._lib.n2nmn_train_forward(self._ctx, C.byref(io), packed.handle, s))
+        _lib.check(self._lib.n2nmn_train_backward(self._ctx, C.byref(io), packed.handle, 0, s))
+        if reduce:
+            self.buckets.reduce_late()       # overlaps the encoder's backward pass
+        _lib.check(self._lib.n2nmn_train_backward(self._ctx, C.byref(io), packed.handle, 1, s))
+        if reduce:
+            self.buckets.reduce_early()
+            return self.buckets.wait()
+        return 1.0
+
+    def apply(self, scale: float = 1.0):
+        self.iteration += 1
+        h = self.hyper
+        _lib.check(self._lib.n2nmn_adam_step(self._ctx, self.grads.data_ptr(), scale, h['lr'],
+                                             h['beta1'], h['beta2'], h['eps'],
+                                             h['max_grad_l2_norm'], self.iteration,
+                                             self.engine.stream()))
+
+    def step(self, batch, gt_layout):
+        scale = self.forward_backward(batch, gt_layout)
+        self.apply(scale)
+        return self.losses
+
+    # ------------------------------------------------------------------------------------
+    def gradients(self) -> Dict[str, object]:
+        """name -> view of the flat gradient buffer in the variable's reference shape."""
+        return {name: self.grads[off:off + n].view(shape)
+                for name, (off, n, shape) in self.layout.items()}
+
+    def get_weights(self) -> Dict[str, object]:
+        torch = _torch()
+        out = {}
+        for name, (off, n, shape) in self.layout.items():
+            t = torch.empty(shape, dtype=torch.float32, device=self.engine.device)
+            _lib.check(self._lib.n2nmn_get_weight(self._ctx, name.encode(), t.data_ptr(),
+                                                  self.engine.stream()))
+            out[name] = t
+        return out
+
+    def debug_tensor(self, name: str, shape):
+        torch = _torch()
+        n = int(np.prod(shape))
+        t = torch.empty(n, dtype=torch.float32, device=self.engine.device)
+        got = self._lib.n2nmn_train_debug_tensor(self._ctx, name.encode(), t.data_ptr(), n,
+                                                 self.engine.stream())
+        _lib.check(int(got))
+        return t[:int(got)].view(shape) if int(got) == n else t[:int(got)]

@@ -43,12 +43,29 @@ def _t(x):
     return torch.as_tensor(np.asarray(x), dtype=F64)
 
 
+# Discrete selections (which argument of a min/max wins, which pixel is the extremum) make the
+# gradient discontinuous: when two candidates are closer than fp32 round-off, an fp32
+# implementation may legitimately route the gradient to the other candidate.  The oracle records,
+# per example, the smallest gap it saw, so that parity tests can apply the same rule SURVEY.md 8(c)
+# states for the decoder's argmax (compare only where the oracle's margin is clear).
+_MARGIN = {'example': None, 'min_gap': {}}
+
+
+def _note_gap(gap: float):
+    n = _MARGIN['example']
+    if n is not None:
+        _MARGIN['min_gap'][n] = min(_MARGIN['min_gap'].get(n, float('inf')), float(gap))
+
+
 class _MinMax2(torch.autograd.Function):
     """tf.minimum / tf.maximum with TF's tie rule (first argument wins)."""
 
     @staticmethod
     def forward(ctx, x, y, is_min):
         mask = (x <= y) if is_min else (x >= y)
+        d = (x - y).abs()
+        if d.numel() and bool((d > 0).any()):
+            _note_gap(float(d[d > 0].min()))
         ctx.save_for_backward(mask)
         return torch.where(mask, x, y)
 
@@ -74,6 +91,9 @@ class _ReduceExt(torch.autograd.Function):
     def forward(ctx, x, is_min):
         y = x.min(dim=-1, keepdim=True).values if is_min else x.max(dim=-1, keepdim=True).values
         ind = (x == y).to(x.dtype)
+        d = (x - y).abs()
+        if bool((d > 0).any()):
+            _note_gap(float(d[d > 0].min()))          # runner-up vs extremum
         ctx.save_for_backward(ind)
         return y
 
@@ -150,7 +170,7 @@ def decoder_forward_gt(w, enc, T_dec, gt_layout):
     W0, b0 = _lstm_w(w, 'decoder', 0)
     W1, b1 = _lstm_w(w, 'decoder', 1)
     eht, eout, nf = enc['h_transformed'], enc['outputs'], enc['not_finished']
-    tprobs, atts, scores = [], [], []
+    atts, scores = [], []
     for t in range(T_dec):
         c0, h0 = _lstm_cell(x, c0, h0, W0, b0)
         c1, h1 = _lstm_cell(h0, c1, h1, W1, b1)
@@ -161,15 +181,15 @@ def decoder_forward_gt(w, enc, T_dec, gt_layout):
         att = att / torch.sum(att, dim=0, keepdim=True)          # :191
         ctx = torch.sum(att * eout, dim=0)
         sc = torch.cat([out, ctx], dim=1) @ Wy + by
-        p = torch.softmax(sc, dim=1)                             # validity_mult == 1 everywhere
-        p = p / torch.sum(p, dim=1, keepdim=True)
-        tprobs.append(p[torch.arange(N), gt[t]])
         x = demb[gt[t]]
         atts.append(att); scores.append(sc)
     atts = torch.stack(atts)                                     # [T_dec, T_enc, N, 1]
+    scores = torch.stack(scores)                                 # [T_dec, N, V]
+    p = torch.softmax(scores, dim=2)                             # validity_mult == 1 everywhere
+    p = p / torch.sum(p, dim=2, keepdim=True)                    # :245-247
+    tprobs = torch.gather(p, 2, gt[:, :, None])[:, :, 0]         # :251-256
     word_vecs = torch.sum(atts * enc['embedded'][None], dim=1)   # :312
-    return dict(token_probs=torch.stack(tprobs), atts=atts, word_vecs=word_vecs,
-                token_scores=torch.stack(scores))
+    return dict(token_probs=tprobs, atts=atts, word_vecs=word_vecs, token_scores=scores)
 
 
 # ---- module operators (models_clevr/nmn3_modules.py) on torch tensors ---------------------
@@ -281,7 +301,13 @@ def train_forward(wt, module_names, batch, T_dec, num_choices, gt_layout, weight
     dec = decoder_forward_gt(wt, enc, T_dec, gt_layout)
     exprs, validity = O.assemble(module_names, np.asarray(gt_layout))
     feat = _t(batch['image_feat_batch'])
-    scores = torch.stack([eval_expr(wt, e, feat, dec['word_vecs'], num_choices) for e in exprs])
+    _MARGIN['min_gap'] = {}
+    rows = []
+    for n, e in enumerate(exprs):
+        _MARGIN['example'] = n
+        rows.append(eval_expr(wt, e, feat, dec['word_vecs'], num_choices))
+    _MARGIN['example'] = None
+    scores = torch.stack(rows)
     labels = torch.as_tensor(np.asarray(batch['answer_label_batch'])).long()
     log_seq_prob = torch.sum(torch.log(dec['token_probs']), dim=0)     # nmn3_model.py:46
     ce = torch.logsumexp(scores, dim=1) - scores[torch.arange(len(labels)), labels]
@@ -313,6 +339,9 @@ def loss_and_grads(w, module_names, batch, T_dec, num_choices, gt_layout, weight
     extras = {'d_' + k: (v.grad.numpy().copy() if v.grad is not None else None)
               for k, v in inter.items()}
     extras['scores'] = r['scores'].detach().numpy().copy()
+    # smallest min/max selection gap per example (inf: no discrete selection in its layout)
+    extras['selection_gap'] = np.array([_MARGIN['min_gap'].get(n, np.inf)
+                                        for n in range(len(r['expr_list']))])
     extras['log_seq_prob'] = r['log_seq_prob'].detach().numpy().copy()
     return losses, grads, extras
 

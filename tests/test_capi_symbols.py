@@ -39,3 +39,5 @@ def test_struct_sizes_match_header():
     assert ctypes.sizeof(_lib.Node) == 8 * 4
     # 2 ptr + 4 int32 + 13 ptr
     assert ctypes.sizeof(_lib.Seq2SeqIO) == 2 * 8 + 4 * 4 + 13 * 8
+    # 2 ptr + 3 int32 (+4 pad) + 3 ptr + float (+4 pad) + 3 ptr
+    assert ctypes.sizeof(_lib.TrainIO) == 2 * 8 + 16 + 3 * 8 + 8 + 3 * 8

@@ -1,0 +1,167 @@
+"""Training step (BASELINE.json configs[3], exp_clevr/train_clevr_gt_layout.py:104-130) on the GPU
+against the autograd oracle (oracle/n2nmn_oracle_grad.py, fp64): losses, answer logits, EVERY
+variable's gradient of total_loss, the gradients of the intermediates, and the Adam update.
+
+Tolerances (fp32 kernels vs an fp64 oracle):
+  * forward values: 1e-4 absolute (the forward bar of the north star)
+  * gradients: max|got - want| <= GRAD_RTOL * max|want| + GRAD_ATOL per tensor -- gradients are
+    sums over up to T*N = 2880 fp32 products, so the bar is relative to the tensor's scale
+  * discrete min/max selections: per-node gradients are compared where the oracle's selection gap
+    is >= SELECTION_GAP (see _check)
+  * Adam: the update applied to the SAME (GPU) gradient must match the fp64 formula to 2e-6
+"""
+import numpy as np
+import pytest
+
+from oracle import n2nmn_oracle_grad as G
+from n2nmn_amd import synth
+from n2nmn_amd.spec import CLEVR_MODULE_NAMES, Dims
+from util import assert_close, t2n
+
+pytestmark = pytest.mark.gpu
+NAMES = list(CLEVR_MODULE_NAMES)
+GRAD_RTOL = 2e-4
+GRAD_ATOL = 1e-7
+WD = 5e-6
+SELECTION_GAP = 1e-5
+
+
+def grad_report(got: dict, want: dict):
+    """per tensor: (name, max|want|, max|diff|, ok)"""
+    rows = []
+    for k in sorted(want):
+        w = np.asarray(want[k], np.float64)
+        g = np.asarray(got[k], np.float64).reshape(w.shape)
+        scale = float(np.max(np.abs(w))) if w.size else 0.0
+        diff = float(np.max(np.abs(g - w))) if w.size else 0.0
+        ok = np.isfinite(g).all() and diff <= GRAD_RTOL * scale + GRAD_ATOL
+        rows.append((k, scale, diff, bool(ok)))
+    return rows
+
+
+def format_report(rows):
+    return '\n'.join('%-100s scale %.3e diff %.3e %s' % (k[-100:], s, d, 'ok' if ok else 'FAIL')
+                     for k, s, d, ok in rows)
+
+
+@pytest.fixture(scope='module')
+def trainer_setup():
+    from n2nmn_amd.nmn3_assembler import Assembler
+    from n2nmn_amd.engine import Engine
+    from n2nmn_amd.train import Trainer
+    d = Dims(T_decoder=10)                      # train_clevr_gt_layout.py:35
+    asm = Assembler(NAMES)
+    eng = Engine(d, asm)
+    w = synth.make_weights(d, seed=0)
+    eng.load_weights(w)
+    tr = Trainer(eng, weight_decay=WD)
+    return tr, eng, d, asm, w
+
+
+def _run(tr, d, w, batch, gt):
+    tr.engine.load_weights(w)
+    tr.forward_backward(batch, gt, reduce=False)
+    losses = t2n(tr.losses)
+    grads = {k: t2n(v) for k, v in tr.gradients().items()}
+    ref_l, ref_g, ex = G.loss_and_grads(w, NAMES, batch, gt.shape[0], d.num_choices, gt, WD)
+    return losses, grads, ref_l, ref_g, ex
+
+
+def _check(tr, d, w, batch, gt):
+    losses, grads, ref_l, ref_g, ex = _run(tr, d, w, batch, gt)
+    N = batch['input_seq_batch'].shape[1]
+    assert_close('scores', t2n(tr.scores), ex['scores'], 1e-4)
+    for i, k in enumerate(('avg_sample_loss', 'seq_likelihood_loss', 'l2_reg', 'total_loss')):
+        assert abs(losses[i] - ref_l[k]) <= 1e-4 * max(1.0, abs(ref_l[k])), (k, losses[i], ref_l[k])
+    Td, T, L, E = gt.shape[0], batch['input_seq_batch'].shape[0], d.lstm_dim, d.embed_dim_txt
+    inter_got = {
+        'd_word_vecs': t2n(tr.debug_tensor('d_word_vecs', (Td, N, E))),
+        'd_token_scores': t2n(tr.debug_tensor('d_token_scores', (Td, N, 16)))[:, :, :d.num_vocab_nmn],
+        'd_encoder_outputs': t2n(tr.debug_tensor('d_encoder_outputs', (T, N, L))),
+        'd_encoder_h_transformed': t2n(tr.debug_tensor('d_encoder_h_transformed', (T, N, L))),
+        'd_scores': t2n(tr.debug_tensor('d_scores', (N, d.num_choices))),
+    }
+    inter_want = {k: ex[k] for k in inter_got}
+    # Discrete selections (tf.minimum/maximum branch, reduce_min/max pixel) are discontinuous: where
+    # the oracle's two candidates are closer than fp32 can resolve, the fp32 kernels may route a
+    # pixel's gradient to the other candidate (with the synthetic weights, And/Or inputs of one
+    # question nearly coincide).  Same protocol as the decoder's argmax: the
+    # per-node gradient d_word_vecs is compared on the examples whose smallest selection gap is
+    # clear; the variable gradients (sums over all nodes) are compared in full.
+    clear = ex['selection_gap'] >= SELECTION_GAP
+    assert clear.mean() >= 0.5
+    inter_got['d_word_vecs'] = inter_got['d_word_vecs'][:, clear]
+    inter_want['d_word_vecs'] = inter_want['d_word_vecs'][:, clear]
+    rows = grad_report(inter_got, inter_want) + grad_report(grads, ref_g)
+    bad = [r for r in rows if not r[3]]
+    assert not bad, 'gradient mismatch:\n' + format_report(rows)
+    return rows
+
+
+def test_gradients_template_layouts(trainer_setup):
+    """config 4 inputs: the 10-template layout mix, T_dec = 10, N = 64."""
+    tr, eng, d, asm, w = trainer_setup
+    batch = synth.make_inputs(d, seed=0)
+    gt = synth.template_layout_batch(d)
+    _check(tr, d, w, batch, gt)
+
+
+@pytest.mark.parametrize('seed', [1, 2])
+def test_gradients_random_trees(trainer_setup, seed):
+    """random valid layouts: every operator incl. And/Or/Scene/EqualNum..., deep trees, images
+    shared by several Find-type nodes."""
+    tr, eng, d, asm, w = trainer_setup
+    batch = synth.make_inputs(d, seed=40 + seed, min_len=1)
+    gt = synth.random_valid_layouts(d, asm.P, asm.W, asm.b, seed=seed, max_len=[3, 7][seed - 1])
+    _check(tr, d, w, batch, gt)
+
+
+def test_gradients_ragged_small_batch(trainer_setup):
+    """N below the context capacity, shorter T_enc, length-1 questions."""
+    tr, eng, d, asm, w = trainer_setup
+    small = Dims(T_decoder=10, N=37, T_encoder=17)
+    batch = synth.make_inputs(small, seed=7, min_len=1)
+    gt = synth.template_layout_batch(small, offset=3)
+    _check(tr, d, w, batch, gt)
+
+
+def test_flat_layout_and_buckets(trainer_setup):
+    tr, eng, d, asm, w = trainer_setup
+    from n2nmn_amd.spec import num_parameters
+    assert tr.numel == num_parameters(d)
+    offs = sorted((o, n, k) for k, (o, n, s) in tr.layout.items())
+    pos = 0
+    for o, n, k in offs:
+        assert o == pos, k
+        pos += n
+    assert pos == tr.numel
+    enc = [k for k in tr.layout if '/encoder/' in k]
+    assert tr.split == max(tr.layout[k][0] + tr.layout[k][1] for k in enc)
+    assert all(tr.layout[k][0] >= tr.split for k in tr.layout if '/encoder/' not in k)
+
+
+def test_adam_steps_match_oracle_formula(trainer_setup):
+    """three optimiser steps: each update equals clip_by_norm + Adam (fp64) applied to the gradient
+    the GPU produced at that step; moments carry over."""
+    tr, eng, d, asm, w = trainer_setup
+    from n2nmn_amd.train import Trainer
+    eng.load_weights(w)
+    tr2 = Trainer(eng, weight_decay=WD)          # a new Trainer resets the Adam moments
+    assert tr2.iteration == 0
+    batch = synth.make_inputs(d, seed=3)
+    gt = synth.template_layout_batch(d, offset=1)
+    cur = {k: np.asarray(v, np.float64) for k, v in w.items()}
+    m = {k: np.zeros_like(v) for k, v in cur.items()}
+    v = {k: np.zeros_like(x) for k, x in cur.items()}
+    first_loss = None
+    for step in range(1, 4):
+        scale = tr2.forward_backward(batch, gt, reduce=False)
+        g = {k: t2n(t).astype(np.float64) for k, t in tr2.gradients().items()}
+        loss = float(t2n(tr2.losses)[3])
+        first_loss = loss if first_loss is None else first_loss
+        tr2.apply(scale)
+        cur, m, v = G.adam_step(cur, g, m, v, step)
+        got = {k: t2n(t) for k, t in tr2.get_weights().items()}
+        for k in cur:
+            assert_close('adam[%d] %s' % (step, k), got[k], cur[k], 2e-6)
+    assert loss < first_loss          # the objective goes down on a repeated batch
