@@ -26,7 +26,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3    # MI355X_MICROARCH.md: fp32-input MFMA dense peak
-MFMA_FAMILIES = ('lstm_step', 'gemm_pk')
+MFMA_FAMILIES = ('lstm_step', 'gemm_pk', 'lstm_bwd_step', 'gemm_tn')
 
 
 def parse():
@@ -34,8 +34,9 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--config', type=int, default=2, choices=(2, 3),
-                    help='2: fixed gt layouts (metric config); 3: greedy decoder layouts')
+    ap.add_argument('--config', type=int, default=2, choices=(2, 3, 4),
+                    help='2: fixed gt layouts (metric config); 3: greedy decoder layouts; '
+                         '4: training step (forward + backward + RCCL all-reduce + Adam)')
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--streams', type=int, default=4,
                     help='independent batches in flight per GPU (one host thread + HIP stream + '
@@ -91,6 +92,110 @@ def cpu_baseline(d, w, batch, gt, names, use_gt):
                                                                    os.cpu_count() or 0)}
 
 
+def kernel_rows(fams, ksteps):
+    rows = []
+    for f in fams:
+        if f['launches'] == 0:
+            continue
+        bound = 'mfma' if f['name'].startswith(MFMA_FAMILIES) else 'hbm'
+        avg_s = f['total_ms'] * 1e-3 / f['launches']
+        if bound == 'mfma':
+            ach = f['flops'] / f['launches'] / avg_s / 1e12
+            peak, unit = MFMA_F32_PEAK_TF, 'TFLOP/s'
+        else:
+            ach = f['bytes'] / f['launches'] / avg_s / 1e9
+            peak, unit = HBM_PEAK_GBS, 'GB/s'
+        rows.append({'kernel': f['name'], 'bound': bound, 'launches_per_step':
+                     round(f['launches'] / ksteps, 2), 'avg_us': round(avg_s * 1e6, 3),
+                     'us_per_step': round(f['total_ms'] * 1e3 / ksteps, 2),
+                     'achieved': round(ach, 3), 'peak': peak, 'unit': unit,
+                     'frac': round(ach / peak, 4)})
+    rows.sort(key=lambda r: -r['us_per_step'])
+    return rows
+
+
+def bench_train(args, dp, local_rank):
+    """BASELINE.json configs[3]: exp_clevr/train_clevr_gt_layout.py loop body -- forward + backward
+    + gradient all-reduce (RCCL, two buckets, the late one overlapping the encoder's backward) +
+    per-tensor clip + Adam -- batch 64 per GPU, T_dec = 10, gt layouts.  One step = one iteration."""
+    import numpy as np
+    import torch
+    from n2nmn_amd import synth
+    from n2nmn_amd.engine import Engine
+    from n2nmn_amd.nmn3_assembler import Assembler
+    from n2nmn_amd.spec import Dims, CLEVR_MODULE_NAMES
+    from n2nmn_amd.train import Trainer
+
+    rank, world = dp.rank, dp.world
+    d = Dims(N=args.batch, T_decoder=10)
+    names = list(CLEVR_MODULE_NAMES)
+    eng = Engine(d, Assembler(names), device=local_rank)
+    w = synth.make_weights(d, seed=0)          # identical replicas on every rank
+    eng.load_weights(w)
+    dev = eng.device
+    tr = Trainer(eng, dist=dp._dist)
+    n_batches = 4
+    batches, gts = [], []
+    for i in range(n_batches):
+        b = synth.make_inputs(d, seed=dp.batch_seed(i))
+        batches.append({k: torch.as_tensor(v).to(dev) for k, v in b.items()})
+        gts.append(synth.template_layout_batch(d, offset=i))      # host: assembled per step
+
+    def run_steps(first, count):
+        for i in range(first, first + count):
+            tr.step(batches[i % n_batches], gts[i % n_batches])
+
+    run_steps(0, args.warmup)
+    elapsed = dp.timed(lambda: run_steps(args.warmup, args.steps),
+                       sync=lambda: torch.cuda.synchronize(dev))
+    out = None
+    if rank == 0:
+        out = {
+            'metric': 'questions/sec (training step: forward + backward + all-reduce + Adam) on '
+                      'CLEVR 10x15x512 feats, batch 64 per GPU',
+            'value': round(dp.throughput(d.N * args.steps, elapsed), 1), 'unit': 'questions/sec',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE.json configs[3]: CLEVR train_clevr_gt_layout.py step, '
+                                   'gt layouts (10-template mix), batch %d per GPU, T_enc=45, '
+                                   'T_dec=10, weight_decay 5e-6, clip 10, Adam' % d.N,
+                       'global_batch': world * d.N,
+                       'parallelism': 'dp%d: flat fp32 gradient (%d floats), 2 RCCL all-reduce '
+                                      'buckets per step' % (world, tr.numel)},
+            'final_total_loss': float(tr.losses[3].item()),
+        }
+    if rank == 0 and not args.no_profile and world == 1:
+        ksteps = min(args.steps, 20)
+        eng.profile_begin()
+        run_steps(0, ksteps)
+        rows = kernel_rows(eng.profile_end(), ksteps)
+        dom = rows[0]
+        out['roofline'] = {'kernel': dom['kernel'], 'bound': dom['bound'],
+                           'achieved': dom['achieved'], 'peak': dom['peak'], 'unit': dom['unit'],
+                           'frac': dom['frac'], 'traffic': None, 'avg_us': dom['avg_us'],
+                           'measured': 'hipEvent pairs around each launch, separate pass of %d '
+                                       'steps' % ksteps}
+        out['kernels'] = rows
+        out['gpu_us_per_step'] = round(sum(r['us_per_step'] for r in rows), 1)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import n2nmn_oracle_grad as G
+        b0 = synth.make_inputs(d, seed=0)
+        t0 = time.perf_counter()
+        G.loss_and_grads(w, names, b0, d.T_decoder, d.num_choices,
+                         synth.template_layout_batch(d), 5e-6)
+        dt = time.perf_counter() - t0
+        out['cpu_baseline'] = {'value': round(d.N / dt, 2), 'unit': 'questions/sec',
+                               'cores': int(torch.get_num_threads()), 'kind': 'port',
+                               'sample': '1 batch of %d questions, forward+backward of the torch-'
+                                         'autograd fp64 oracle (oracle/n2nmn_oracle_grad.py), no '
+                                         'optimiser step; the reference TF1/Fold path is not '
+                                         'runnable here' % d.N}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    dp.close()
+
+
 def main():
     args = parse()
     import numpy as np
@@ -101,6 +206,8 @@ def main():
     from n2nmn_amd.dp import DataParallel
     dp = DataParallel(backend='nccl', device=torch.device('cuda', local_rank))
     rank, world = dp.rank, dp.world
+    if args.config == 4:
+        return bench_train(args, dp, local_rank)
 
     from n2nmn_amd import synth
     from n2nmn_amd.engine import Engine
@@ -205,25 +312,7 @@ def main():
         eng.profile_begin()
         for i in range(ksteps):
             step(i)
-        fams = eng.profile_end()
-        rows = []
-        for f in fams:
-            if f['launches'] == 0:
-                continue
-            bound = 'mfma' if f['name'].startswith(MFMA_FAMILIES) else 'hbm'
-            avg_s = f['total_ms'] * 1e-3 / f['launches']
-            if bound == 'mfma':
-                ach = f['flops'] / f['launches'] / avg_s / 1e12
-                peak, unit = MFMA_F32_PEAK_TF, 'TFLOP/s'
-            else:
-                ach = f['bytes'] / f['launches'] / avg_s / 1e9
-                peak, unit = HBM_PEAK_GBS, 'GB/s'
-            rows.append({'kernel': f['name'], 'bound': bound, 'launches_per_step':
-                         round(f['launches'] / ksteps, 2), 'avg_us': round(avg_s * 1e6, 3),
-                         'us_per_step': round(f['total_ms'] * 1e3 / ksteps, 2),
-                         'achieved': round(ach, 3), 'peak': peak, 'unit': unit,
-                         'frac': round(ach / peak, 4)})
-        rows.sort(key=lambda r: -r['us_per_step'])
+        rows = kernel_rows(eng.profile_end(), ksteps)
         dom = rows[0]
         traffic, traffic_src = pmc_traffic(dom['kernel'])
         out['roofline'] = {'kernel': dom['kernel'], 'bound': dom['bound'],

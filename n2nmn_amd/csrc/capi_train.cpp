@@ -182,6 +182,9 @@ void gemm_nt(n2nmn_ctx* c, hipStream_t s, const float* A, int lda, int M, int K,
   GemmArgs g{};
   g.A = A; g.lda = lda; g.M = M; g.K = K; g.group_size = 1; g.Bp = Bp; g.Np = Np; g.Kp = Kp;
   g.bias = nullptr; g.N = N; g.C = C; g.ldc = ldc; g.n_store = N; g.accumulate = accumulate ? 1 : 0;
+  // skinny outputs (a few 64x64 tiles) with a long K: split K so the launch covers the chip
+  const int tiles = ((N + 63) / 64) * ((M + 63) / 64), nkt = Kp / 32;
+  if (accumulate && tiles < 64 && nkt >= 16) g.ksplit = std::min(nkt / 4, std::max(1, 256 / tiles));
   ProfScope ps(c, F_BWD_MISC, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)K * N + 2.0 * M * N), s);
   launch_gemm_pk(g, s);
 }
@@ -360,11 +363,8 @@ int n2nmn_train_forward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* p
     rc = repack_transposed(c, s);
     if (rc != N2NMN_OK) return rc;
   }
-  // initial state slots of the kept sequences: zeros for the encoder
-  N2_HIP(hipMemsetAsync(t->rec.ec0s, 0, sizeof(float) * nl, s));
-  N2_HIP(hipMemsetAsync(t->rec.ec1s, 0, sizeof(float) * nl, s));
-  N2_HIP(hipMemsetAsync(t->rec.eh0s, 0, sizeof(float) * nl, s));
-  N2_HIP(hipMemsetAsync(t->rec.eh1s, 0, sizeof(float) * nl, s));
+  // slot 0 of the kept encoder sequences (the zero initial state) was cleared by train_enable and
+  // is never written again
   n2nmn_seq2seq_io sio{};
   sio.input_seq = io->input_seq; sio.seq_length = io->seq_length; sio.T_enc = io->T_enc; sio.N = N;
   sio.T_dec = io->T_dec; sio.use_gt_layout = 1; sio.gt_layout = io->gt_layout;
@@ -579,9 +579,14 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
     rc = run_bptt(c, ba, s);
     if (rc != N2NMN_OK) return rc;
     launch_dec_xidx(io->gt_layout, Td, N, V, t->dec_xidx, s);
+    // gradient of the input-projection table: dxtab = onehot(idx)^T . dz0  (one-hot gemm_tn)
+    N2_HIP(hipMemsetAsync(t->dxtab_dec, 0, sizeof(float) * (size_t)(V + 1) * 4 * L, s));
     {
-      ProfScope ps(c, F_BWD_MISC, (double)RT * 4 * L, 4.0 * RT * 4.0 * L, s);
-      launch_xtab_grad(t->dz0_all, t->dec_xidx, RT, 4 * L, V + 1, t->dxtab_dec, s);
+      GemmTnArgs g1{};
+      g1.A = nullptr; g1.lda = 0; g1.M = V + 1; g1.a_onehot = t->dec_xidx;
+      g1.B = t->dz0_all; g1.ldb = 4 * L; g1.N = 4 * L; g1.R = RT; g1.C = t->dxtab_dec; g1.ldc = 4 * L;
+      ProfScope ps(c, F_GEMM_TN, 2.0 * (V + 1) * 4.0 * L * RT, 4.0 * ((double)RT * 4 * L + (V + 1) * 4.0 * L), s);
+      launch_gemm_tn(g1, s);
     }
     gemm_tn(c, s, c->dec_emb_cat, E, E, t->dxtab_dec, 4 * L, 4 * L, V + 1, G(V_DEC_W0), 4 * L);
     colsum(c, s, t->dxtab_dec, V + 1, 4 * L, 4 * L, G(V_DEC_B0));
@@ -613,9 +618,13 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
   ba.dout = t->denc_out; ba.Wt0 = t->enc_Wt0; ba.Wt1 = t->enc_Wt1;
   rc = run_bptt(c, ba, s);
   if (rc != N2NMN_OK) return rc;
+  N2_HIP(hipMemsetAsync(t->dxtab_enc, 0, sizeof(float) * (size_t)Vt * 4 * L, s));
   {
-    ProfScope ps(c, F_BWD_MISC, (double)RT * 4 * L, 4.0 * RT * 4.0 * L, s);
-    launch_xtab_grad(t->dz0_all, io->input_seq, RT, 4 * L, Vt, t->dxtab_enc, s);
+    GemmTnArgs g1{};
+    g1.A = nullptr; g1.lda = 0; g1.M = Vt; g1.a_onehot = io->input_seq;
+    g1.B = t->dz0_all; g1.ldb = 4 * L; g1.N = 4 * L; g1.R = RT; g1.C = t->dxtab_enc; g1.ldc = 4 * L;
+    ProfScope ps(c, F_GEMM_TN, 2.0 * Vt * 4.0 * L * RT, 4.0 * ((double)RT * 4 * L + Vt * 4.0 * L), s);
+    launch_gemm_tn(g1, s);
   }
   gemm_tn(c, s, mir(V_ENC_EMB), E, E, t->dxtab_enc, 4 * L, 4 * L, Vt, G(V_ENC_W0), 4 * L);
   colsum(c, s, t->dxtab_enc, Vt, 4 * L, 4 * L, G(V_ENC_B0));

@@ -23,6 +23,7 @@ struct GemmArgs {
   const float* bias; int N;
   float* C; int ldc; int n_store;
   int accumulate;                             // != 0: C += A.B (+ bias) instead of C = ...
+  int ksplit;                                 // > 1: K split over blockIdx.z, atomic C += (needs accumulate)
 };
 void launch_gemm_pk(const GemmArgs& a, hipStream_t s);
 
@@ -177,6 +178,7 @@ void launch_heads(const ModuleWeights& w, const ModuleBuffers& b, int tab_off, i
 struct GemmTnArgs {
   const float* A; int lda; int M;              // m < M; M % 4 == 0; rows readable up to M
   const int32_t* a_group_idx; int a_group_size; // source row of r = group_idx[r/gs]*gs + r%gs
+  const int32_t* a_onehot;                     // != nullptr: A[r][m] = (a_onehot[r] == m), A unused
   const float* B; int ldb; int N;              // n < N; rows readable up to round_up(N, 4)
   const int32_t* b_sel; int b_sel_val;         // optional: row r contributes iff b_sel[r] == val
   int R;
@@ -217,9 +219,6 @@ struct LstmBwdJob {
 };
 void launch_lstm_bwd_step(const LstmBwdJob* jobs, int njobs, int N, int L, hipStream_t s);
 
-// dxtab[v][c] = sum_{r : idx[r] == v} dz[r][c]     (gradient of the input-projection tables)
-void launch_xtab_grad(const float* dz, const int32_t* idx, int R, int ncols, int V, float* dxtab,
-                      hipStream_t s);
 // idx[t*N+n] = t == 0 ? go_row : gt[(t-1)*N+n]
 void launch_dec_xidx(const int32_t* gt, int Td, int N, int go_row, int32_t* idx, hipStream_t s);
 

@@ -59,7 +59,15 @@ __global__ __launch_bounds__(256) void gemm_pk_kernel(GemmArgs a) {
   const float4* b_ptr0 = reinterpret_cast<const float4*>(a.Bp) + (size_t)b_k40 * a.Np + n0 + b_n0;
   const float4* b_ptr1 = reinterpret_cast<const float4*>(a.Bp) + (size_t)b_k41 * a.Np + n0 + b_n1;
 
-  const int nkt = a.Kp / BK;
+  // split-K (ksplit > 1, accumulate only): blockIdx.z owns a contiguous range of k-tiles and adds
+  // its partial tile atomically -- for the skinny NT products of the backward pass ([V,4L].[4L,E])
+  int ktb = 0, nkt = a.Kp / BK;
+  if (a.ksplit > 1) {
+    const int per = (nkt + a.ksplit - 1) / a.ksplit;
+    ktb = blockIdx.z * per;
+    nkt = min(per, nkt - ktb);
+    if (nkt <= 0) return;
+  }
   const size_t bstep = (size_t)(BK / 4) * a.Np;     // float4 stride of one k-tile in packed B
   // register-staged pipeline, two k-tiles deep: tile kt+2 is being fetched while tile kt+1 sits
   // in registers and tile kt is consumed from LDS (a global round trip spans two MFMA phases)
@@ -69,14 +77,14 @@ __global__ __launch_bounds__(256) void gemm_pk_kernel(GemmArgs a) {
 // conditional load would be lowered to a flat load through a select with a scratch zero
 #define N2_GLOAD(KT, A0, A1, B0, B1)                                                        \
   do {                                                                                      \
-    const int kk0 = (KT) * BK + 4 * a_k40, kk1 = (KT) * BK + 4 * a_k41;                     \
+    const int kk0 = (ktb + (KT)) * BK + 4 * a_k40, kk1 = (ktb + (KT)) * BK + 4 * a_k41;     \
     const float4 t0 = *reinterpret_cast<const float4*>(a_ptr0 + (kk0 < a.K ? kk0 : a.K - 4)); \
     const float4 t1 = *reinterpret_cast<const float4*>(a_ptr1 + (kk1 < a.K ? kk1 : a.K - 4)); \
     const bool k0 = a_ok0 && kk0 < a.K, k1 = a_ok1 && kk1 < a.K;                            \
     A0.x = k0 ? t0.x : 0.f; A0.y = k0 ? t0.y : 0.f; A0.z = k0 ? t0.z : 0.f; A0.w = k0 ? t0.w : 0.f; \
     A1.x = k1 ? t1.x : 0.f; A1.y = k1 ? t1.y : 0.f; A1.z = k1 ? t1.z : 0.f; A1.w = k1 ? t1.w : 0.f; \
-    B0 = b_ptr0[(size_t)(KT) * bstep];                                                      \
-    B1 = b_ptr1[(size_t)(KT) * bstep];                                                      \
+    B0 = b_ptr0[(size_t)(ktb + (KT)) * bstep];                                              \
+    B1 = b_ptr1[(size_t)(ktb + (KT)) * bstep];                                              \
   } while (0)
 #define N2_LSTORE(BUF, A0, A1, B0, B1)                                                      \
   do {                                                                                      \
@@ -128,14 +136,15 @@ __global__ __launch_bounds__(256) void gemm_pk_kernel(GemmArgs a) {
   // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int col = n0 + wn * 32 + li;
   if (col < a.n_store) {
-    const float bias = (a.bias && col < a.N) ? a.bias[col] : 0.f;
+    const float bias = (a.bias && col < a.N && blockIdx.z == 0) ? a.bias[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
       if (row < a.M) {
         const float val = (col < a.N) ? acc[r] + bias : 0.f;
         float* dst = a.C + (size_t)row * a.ldc + col;
-        *dst = a.accumulate ? *dst + val : val;
+        if (a.ksplit > 1) atomicAdd(dst, val);
+        else *dst = a.accumulate ? *dst + val : val;
       }
     }
   }
@@ -191,7 +200,7 @@ void launch_pad_rows(const float* src, int R, int M, float* dst, int Mp, hipStre
 }
 
 void launch_gemm_pk(const GemmArgs& a, hipStream_t s) {
-  dim3 grid((a.n_store + BN - 1) / BN, (a.M + BM - 1) / BM);
+  dim3 grid((a.n_store + BN - 1) / BN, (a.M + BM - 1) / BM, a.ksplit > 1 ? a.ksplit : 1);
   if (a.M <= 0) return;
   hipLaunchKernelGGL(gemm_pk_kernel, grid, dim3(256), 0, s, a);
 }

@@ -9,7 +9,7 @@
 //   colsum         : bias gradients        db = sum_r dY[r, :]
 //   lstm_bwd_step  : one reverse-time step of an LSTM layer: dz_{t+1} . W^T on MFMA with the cell
 //                    backward of step t fused in the epilogue (BPTT; two layers pipelined per launch)
-//   xtab_grad      : gradient of the input-projection tables (the layer-0 x.W_x+b lookup)
+//   (the gradient of the layer-0 input-projection tables is a one-hot gemm_tn)
 //   dec_bwd_a/b    : token-logit loss, additive attention, masked softmax backward
 //   word_vecs_bwd  : gradient of the text-attention word vectors
 //   loss, grad_finish, grad_sqnorm, adam : objective and optimiser (clip_by_norm + Adam)
@@ -70,6 +70,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a, int r_per_sp
       bool sel_ok = true;
       if (isB) {
         if (a.b_sel) sel_ok = a.b_sel[src] == a.b_sel_val;
+      } else if (a.a_onehot) {          // A[r][m] = (a_onehot[r] == m): no operand in memory
+        const int hot = a.a_onehot[src];
+        reg[j].x = (rok && hot == cbeg + 0) ? 1.f : 0.f;
+        reg[j].y = (rok && hot == cbeg + 1) ? 1.f : 0.f;
+        reg[j].z = (rok && hot == cbeg + 2) ? 1.f : 0.f;
+        reg[j].w = (rok && hot == cbeg + 3) ? 1.f : 0.f;
+        continue;
       } else if (a.a_group_idx) {
         const int g = src / a.a_group_size;
         src = a.a_group_idx[g] * a.a_group_size + (src - g * a.a_group_size);
@@ -195,15 +202,16 @@ __global__ void pack_tiles_t_kernel(const float* __restrict__ W, int ld, int row
 // decoder's gradient of the encoder state) enters through dH / dC.
 //
 // CDNA4 mapping mirrors lstm_step_kernel: a workgroup owns 16 hidden units (one 16x16x4 MFMA
-// N-tile) x 32 batch rows; its 8 waves split K and stream dz (k-interleaved [unit][row][4 gates],
+// N-tile) x 16 batch rows; its 8 waves split K and stream dz (k-interleaved [unit][row][4 gates],
 // so an A fragment is 4 x 256-B contiguous) and the pre-transposed weight tile straight from L2
 // into MFMA registers; partial tiles are reduced through LDS and the cell backward runs in the
-// same kernel.  Layer 0's job contracts over [dz1_{t}; dz0_{t+1}] (K = 8L) so that the gradient
+// same kernel.  The step is fp32-MFMA bound per workgroup (2*16*16*K flops on one CU), so the row
+// block is a single 16-row M tile: 2 jobs x 32 column tiles x N/16 row blocks = 256 workgroups.  Layer 0's job contracts over [dz1_{t}; dz0_{t+1}] (K = 8L) so that the gradient
 // from the layer above and the recurrent gradient come out of ONE accumulation.
 // ---------------------------------------------------------------------------------------------
 constexpr int BW_WAVES = 8;
 constexpr int BW_THREADS = BW_WAVES * 64;
-constexpr int BW_MT = 2;                 // 16-row M tiles per workgroup
+constexpr int BW_MT = 1;                 // 16-row M tiles per workgroup
 
 struct LstmBwdJobs {
   LstmBwdJob j[2];
@@ -276,7 +284,7 @@ __global__ __launch_bounds__(BW_THREADS) void lstm_bwd_step_kernel(LstmBwdJobs j
   // ---- epilogue: thread = (row, unit) ---------------------------------------------------------
   const int erow = tid >> 4, ul = tid & 15;
   const int n = row0 + erow;
-  if (erow >= ROWS || n >= N) return;
+  if (erow >= ROWS || n >= N) return;          // 16*ROWS threads own one (row, unit) each
   const int u = 16 * tile + ul;
   float rec = 0.f;
 #pragma unroll
@@ -305,28 +313,6 @@ __global__ __launch_bounds__(BW_THREADS) void lstm_bwd_step_kernel(LstmBwdJobs j
   *reinterpret_cast<float4*>(jb.dz_k + ((size_t)u * jb.R + n) * 4) = dz;
   float* zr = jb.dz_rm + (size_t)n * 4 * L + u;
   zr[0] = dz.x; zr[L] = dz.y; zr[2 * L] = dz.z; zr[3 * L] = dz.w;
-}
-
-// dxtab[v][c] = sum_{r: idx[r]==v} dz[r][c]; grid (V, ncols/256).  No atomics: the row indices are
-// scanned from LDS in ascending order by every thread (uniform branch), so the sum is deterministic.
-__global__ __launch_bounds__(256) void xtab_grad_kernel(const float* __restrict__ dz,
-                                                        const int32_t* __restrict__ idx, int R,
-                                                        int ncols, float* __restrict__ dxtab) {
-  __shared__ int32_t lidx[256];
-  const int v = blockIdx.x;
-  const int c = blockIdx.y * 256 + threadIdx.x;
-  const int cc = c < ncols ? c : 0;
-  float s = 0.f;
-  for (int rb = 0; rb < R; rb += 256) {
-    const int r = rb + threadIdx.x;
-    lidx[threadIdx.x] = r < R ? idx[r] : -1;
-    __syncthreads();
-    const int lim = min(256, R - rb);
-    for (int i = 0; i < lim; ++i)
-      if (lidx[i] == v) s += dz[(size_t)(rb + i) * ncols + cc];
-    __syncthreads();
-  }
-  if (c < ncols) dxtab[(size_t)v * ncols + c] = s;
 }
 
 __global__ void dec_xidx_kernel(const int32_t* __restrict__ gt, int Td, int N, int go_row,
@@ -644,10 +630,11 @@ __global__ __launch_bounds__(256) void adam_kernel(const float* __restrict__ gra
 void launch_gemm_tn(const GemmTnArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0 || a.R <= 0) return;
   const int gx = (a.N + TBN - 1) / TBN, gy = (a.M + TBM - 1) / TBM;
-  // split the reduction until the launch has ~2 workgroups per CU (k-tiles of 32 rows)
+  // split the reduction until the launch has ~6 workgroups per CU (one 64x64 tile keeps a single
+  // wave per SIMD busy, so latency hiding has to come from co-resident workgroups)
   int splits = 1;
   const int nkt = (a.R + TBK - 1) / TBK;
-  while (gx * gy * splits < 512 && splits * 2 <= nkt / 4) splits *= 2;
+  while (gx * gy * splits < 1536 && splits * 2 <= nkt / 4) splits *= 2;
   int r_per = ((nkt + splits - 1) / splits) * TBK;
   splits = (a.R + r_per - 1) / r_per;
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(gx, gy, splits), dim3(256), 0, s, a, r_per);
@@ -687,12 +674,6 @@ void launch_lstm_bwd_step(const LstmBwdJob* jobs, int njobs, int N, int L, hipSt
   }
   dim3 grid(L / 16, njobs, (N + 16 * BW_MT - 1) / (16 * BW_MT));
   hipLaunchKernelGGL(lstm_bwd_step_kernel, grid, dim3(BW_THREADS), 0, s, js, N, L);
-}
-
-void launch_xtab_grad(const float* dz, const int32_t* idx, int R, int ncols, int V, float* dxtab,
-                      hipStream_t s) {
-  hipLaunchKernelGGL(xtab_grad_kernel, dim3(V, (ncols + 255) / 256), dim3(256), 0, s, dz, idx, R,
-                     ncols, dxtab);
 }
 
 void launch_dec_xidx(const int32_t* gt, int Td, int N, int go_row, int32_t* idx, hipStream_t s) {

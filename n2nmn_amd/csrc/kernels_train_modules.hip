@@ -146,25 +146,20 @@ __global__ __launch_bounds__(PB_T) void pool_bwd_kernel(ModuleWeights w, ModuleB
     else wi = 3;
     const float* Wm = w.Watt[wi];
     for (int m = tid; m < b.M; m += PB_T) atomicAdd(g.gbatt[wi] + m, dA[i * Mp + m]);   // d b_att
-    for (int d0 = wv; d0 < D; d0 += 4 * NW) {
-      float s[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int d = d0 + u * NW;
-        if (d < D) {
-          for (int m = 4 * lane; m < Mp; m += 256) {
-            const float4 w4 = *reinterpret_cast<const float4*>(Wm + (size_t)d * Mp + m);
-            const float4 a4 = *reinterpret_cast<const float4*>(dA + i * Mp + m);
-            s[u] += w4.x * a4.x + w4.y * a4.y + w4.z * a4.z + w4.w * a4.w;
-          }
-        }
+    // thread per feature channel d: streams its own (contiguous, padded) W_att row with 16-B
+    // loads, dA broadcast from LDS -- no cross-lane reductions
+    for (int d = tid; d < D; d += PB_T) {
+      const float4* wr = reinterpret_cast<const float4*>(Wm + (size_t)d * Mp);
+      const float4* ar = reinterpret_cast<const float4*>(dA + i * Mp);
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll 8
+      for (int m4 = 0; m4 < Mp / 4; m4 += 2) {
+        const float4 w0 = wr[m4], w1 = wr[m4 + 1];
+        const float4 a0 = ar[m4], a1 = ar[m4 + 1];
+        s0 += w0.x * a0.x + w0.y * a0.y + w0.z * a0.z + w0.w * a0.w;
+        s1 += w1.x * a1.x + w1.y * a1.y + w1.z * a1.z + w1.w * a1.w;
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int d = d0 + u * NW;
-        const float r = wave_sum(s[u]);
-        if (lane == 0 && d < D) dpl[i * D + d] = r;
-      }
+      dpl[i * D + d] = s0 + s1;
     }
   }
   // softmax of the input logits (as the forward pool_kernel)
@@ -652,7 +647,9 @@ __global__ __launch_bounds__(MT) void textmap_bwd_kernel(ModuleWeights w, Module
   }
   __syncthreads();
   const float* Wp = w.Wtxt[ws];
-  for (int e = wid; e < E; e += MT / 64) {
+  const int eper = (E + gridDim.y - 1) / gridDim.y;
+  const int e0 = blockIdx.y * eper, e1 = min(E, e0 + eper);
+  for (int e = e0 + wid; e < e1; e += MT / 64) {
     float s[TM_GROUP];
 #pragma unroll
     for (int gi = 0; gi < TM_GROUP; ++gi) s[gi] = 0.f;
@@ -711,7 +708,8 @@ void launch_att_bwd(const ModuleWeights& w, const ModuleBuffers& b, const Module
 void launch_textmap_bwd(const ModuleWeights& w, const ModuleBuffers& b, const ModuleGrads& g,
                         int tab_off, int count, hipStream_t s) {
   const size_t smem = sizeof(float) * ((size_t)TM_GROUP * b.Mp);
-  hipLaunchKernelGGL(textmap_bwd_kernel, dim3(count), dim3(MT), smem, s, w, b, g, tab_off);
+  // grid.y splits the embedding rows so that the ~N/8 node groups still fill the chip
+  hipLaunchKernelGGL(textmap_bwd_kernel, dim3(count, 10), dim3(MT), smem, s, w, b, g, tab_off);
 }
 
 }  // namespace n2nmn

@@ -28,5 +28,21 @@ def main(path):
                  gaps[int(len(gaps) * 0.9)] / 1e3))
 
 
+def by_grid(path, pattern):
+    """per (kernel, grid size) rows for kernels whose name contains `pattern`"""
+    cur = sqlite3.connect(path).cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    gcol = 'grid_x' if 'grid_x' in cols else ('grid_size_x' if 'grid_size_x' in cols else None)
+    q = ("select name, %s, count(*), avg(end-start), min(end-start), max(end-start) from kernels "
+         "where name like ? group by name, %s order by name, %s" % (gcol, gcol, gcol))
+    print('# per grid size, kernels matching %r (grid column %s)' % (pattern, gcol))
+    for name, g, n, avg, mn, mx in cur.execute(q, ('%' + pattern + '%',)):
+        short = name.replace('n2nmn::(anonymous namespace)::', '').split('(')[0]
+        print('%-40s grid_x %8s calls %6d avg %9.2f min %9.2f max %9.2f us' % (
+            short[:40], g, n, avg / 1e3, mn / 1e3, mx / 1e3))
+
+
 if __name__ == '__main__':
     main(sys.argv[1])
+    for pat in sys.argv[2:]:
+        by_grid(sys.argv[1], pat)
