@@ -65,7 +65,18 @@ typedef struct {
   int32_t T_decoder;          /* 20  maximum decoder length */
   int32_t N;                  /* 64  maximum batch size */
   int32_t kernel_size;        /* 5   TransformModule conv kernel */
+  int32_t variant;            /* N2NMN_VARIANT_CLEVR (models_clevr) or N2NMN_VARIANT_VQA (models_vqa) */
+  int32_t qpn_hidden;         /* VQA: hidden width of question_prior_net (500), 0 = use_qpn False */
 } n2nmn_dims;
+
+/* Model variants.  models_vqa (exp_vqa/eval_vqa2.py:27-39, models_vqa/nmn3_modules.py) has four
+ * modules over the feature grid WITH its two coordinate channels appended by the caller
+ * (add_spatial_coordinate_map, nmn3_modules.py:11-31): _Find (= FindModule), _Transform (the
+ * attention-pooled three-way product: arithmetic of models_clevr's FindSamePropertyModule, run
+ * under N2NMN_OP_FIND_SAME_PROPERTY with the variables of scope TransformModule), _And, _Describe,
+ * plus the question prior network.  Other operator codes are rejected (N2NMN_EKEY). */
+#define N2NMN_VARIANT_CLEVR 0
+#define N2NMN_VARIANT_VQA   1
 
 const char *n2nmn_last_error(void);
 const char *n2nmn_version(void);
@@ -194,6 +205,18 @@ int n2nmn_program_num_launches(const n2nmn_program *p);
 int n2nmn_execute_program(n2nmn_ctx *ctx, n2nmn_program *p, const float *image_feat,
                           const float *word_vecs, int N_full, float *scores,
                           n2nmn_stream stream);
+
+/* models_vqa: out[n,h,w,:] = [feat[n,h,w,0:D0], x(w), y(h), 0...]  with x = linspace(-1,1,W)[w],
+ * y = linspace(-1,1,H)[h]  (add_spatial_coordinate_map, models_vqa/nmn3_modules.py:11-31).
+ * feat [N,H,W,D0]; out [N,H,W,D] with D = the context's (padded) feature depth >= D0 + 2. */
+int n2nmn_add_coords(n2nmn_ctx *ctx, const float *feat, int N, int D0, float *out,
+                     n2nmn_stream stream);
+
+/* VQA only: scores[n, :] += fc2(relu(fc1(concat_layers(encoder h))))   (models_vqa/
+ * question_prior_net.py:10-28 and `self.scores = self.scores_nmn + self.scores_qpn`,
+ * models_vqa/nmn3_model.py:106-114), from the final encoder state held by the context after
+ * n2nmn_encoder_forward / n2nmn_seq2seq_forward.  scores [N, num_choices]. */
+int n2nmn_question_prior_add(n2nmn_ctx *ctx, int N, float *scores, n2nmn_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * (5) one direct entry per module operator, mirroring Modules.<X>Module(input_0[, input_1],

@@ -18,7 +18,7 @@ class Dims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'H', 'W', 'D', 'map_dim', 'embed_dim_txt', 'embed_dim_nmn', 'lstm_dim', 'num_layers',
         'num_vocab_txt', 'num_vocab_nmn', 'num_choices', 'T_encoder', 'T_decoder', 'N',
-        'kernel_size')]
+        'kernel_size', 'variant', 'qpn_hidden')]
 
 
 class Seq2SeqIO(C.Structure):
@@ -82,6 +82,8 @@ SYMBOLS = [
     ('n2nmn_program_num_launches', _I, [_P]),
     ('n2nmn_execute_program', _I, [_P, _P, _P, _P, _I, _P, _P]),
     ('n2nmn_module_forward', _I, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    ('n2nmn_add_coords', _I, [_P, _P, _I, _I, _P, _P]),
+    ('n2nmn_question_prior_add', _I, [_P, _I, _P, _P]),
     ('n2nmn_train_enable', _I, [_P]),
     ('n2nmn_grad_numel', C.c_int64, [_P]),
     ('n2nmn_grad_split', C.c_int64, [_P]),

@@ -27,13 +27,20 @@ const n2nmn_ctx* root(const n2nmn_ctx* c) { return c->parent ? c->parent : c; }
 bool is_committed(const n2nmn_ctx* c) { return root(c)->committed; }
 bool has_tables(const n2nmn_ctx* c) { return root(c)->have_tables; }
 
-static void add_var(n2nmn_ctx* c, const std::string& name, std::vector<int64_t> shape) {
+static void add_var(n2nmn_ctx* c, const std::string& name, std::vector<int64_t> shape,
+                    bool present = true) {
   Var v;
   v.name = name;
   v.shape = std::move(shape);
-  v.numel = 1;
-  for (auto s : v.shape) v.numel *= (size_t)s;
-  c->index[name] = (int)c->vars.size();
+  v.present = present;
+  v.numel = present ? 1 : 0;
+  if (present) {
+    for (auto s : v.shape) v.numel *= (size_t)s;
+    c->index[name] = (int)c->vars.size();
+    c->pub.push_back((int)c->vars.size());
+  } else {
+    v.set = true;                       // nothing to load
+  }
   c->vars.push_back(std::move(v));
 }
 
@@ -68,38 +75,48 @@ static void build_vars(n2nmn_ctx* c) {
   add_var(c, lstm(dec, 0, "biases"), {4 * L});
   add_var(c, lstm(dec, 1, "weights"), {2 * L, 4 * L});
   add_var(c, lstm(dec, 1, "biases"), {4 * L});
-  auto layer = [&](const char* scope, const char* name, std::vector<int64_t> shape) {
+  const bool vqa = d.variant == N2NMN_VARIANT_VQA;
+  auto layer = [&](const char* scope, const char* name, std::vector<int64_t> shape,
+                   bool present = true) {
     const int64_t out = shape.back();
-    add_var(c, mod + scope + "/" + name + "/weights", shape);
-    add_var(c, mod + scope + "/" + name + "/biases", {out});
+    add_var(c, mod + scope + "/" + name + "/weights", shape, present);
+    add_var(c, mod + scope + "/" + name + "/biases", {out}, present);
   };
   layer("FindModule", "conv_image", {D, M});
   layer("FindModule", "fc_text", {E, M});
   layer("FindModule", "conv_eltwise", {M, 1});
-  layer("FindSamePropertyModule", "conv_image", {D, M});
-  layer("FindSamePropertyModule", "fc_text", {E, M});
-  layer("FindSamePropertyModule", "fc_att", {D, M});
-  layer("FindSamePropertyModule", "conv_eltwise", {M, 1});
-  layer("TransformModule", "conv_maps", {ks, ks, 1, M});
-  layer("TransformModule", "text_fc", {E, M});
-  layer("TransformModule", "conv_eltwise", {M, 1});
-  layer("ExistModule", "fc_scores", {3, C});
-  layer("CountModule", "fc_scores", {HW + 2, C});
-  layer("EqualNumModule", "fc_scores", {2 * HW + 4, C});
-  layer("MoreNumModule", "fc_scores", {2 * HW + 4, C});
-  layer("LessNumModule", "fc_scores", {2 * HW + 4, C});
-  layer("SamePropertyModule", "fc_text", {E, M});
-  layer("SamePropertyModule", "fc_att_0", {D, M});
-  layer("SamePropertyModule", "fc_att_1", {D, M});
-  layer("SamePropertyModule", "fc_eltwise", {M, C});
+  // models_vqa: the three-way product module is called TransformModule
+  // (models_vqa/nmn3_modules.py:123-171); it occupies the FindSameProperty slots
+  const char* fsp = vqa ? "TransformModule" : "FindSamePropertyModule";
+  layer(fsp, "conv_image", {D, M});
+  layer(fsp, "fc_text", {E, M});
+  layer(fsp, "fc_att", {D, M});
+  layer(fsp, "conv_eltwise", {M, 1});
+  layer("TransformModule", "conv_maps", {ks, ks, 1, M}, !vqa);
+  layer("TransformModule", "text_fc", {E, M}, !vqa);
+  layer("TransformModule", "conv_eltwise", {M, 1}, !vqa);
+  layer("ExistModule", "fc_scores", {3, C}, !vqa);
+  layer("CountModule", "fc_scores", {HW + 2, C}, !vqa);
+  layer("EqualNumModule", "fc_scores", {2 * HW + 4, C}, !vqa);
+  layer("MoreNumModule", "fc_scores", {2 * HW + 4, C}, !vqa);
+  layer("LessNumModule", "fc_scores", {2 * HW + 4, C}, !vqa);
+  layer("SamePropertyModule", "fc_text", {E, M}, !vqa);
+  layer("SamePropertyModule", "fc_att_0", {D, M}, !vqa);
+  layer("SamePropertyModule", "fc_att_1", {D, M}, !vqa);
+  layer("SamePropertyModule", "fc_eltwise", {M, C}, !vqa);
   layer("DescribeModule", "fc_text", {E, M});
   layer("DescribeModule", "fc_att", {D, M});
   layer("DescribeModule", "fc_eltwise", {M, C});
+  // models_vqa/question_prior_net.py:10-28 (scope neural_module_network/question_prior_net)
+  const bool qpn = vqa && d.qpn_hidden > 0;
+  const int64_t Hq = d.qpn_hidden > 0 ? d.qpn_hidden : 1;
+  const std::string q = "neural_module_network/question_prior_net/";
+  add_var(c, q + "fc1/weights", {2 * L, Hq}, qpn);
+  add_var(c, q + "fc1/biases", {Hq}, qpn);
+  add_var(c, q + "fc2/weights", {Hq, C}, qpn);
+  add_var(c, q + "fc2/biases", {C}, qpn);
 }
 
-
-
-// lays out the weight store (mirrors, packed operands, tables); base == nullptr: size only
 static size_t carve_weights(n2nmn_ctx* c, char* base) {
   const n2nmn_dims& d = c->d;
   const size_t L = d.lstm_dim, E = d.embed_dim_txt, N = d.N, T = d.T_encoder, Td = d.T_decoder,
@@ -120,6 +137,10 @@ static size_t carve_weights(n2nmn_ctx* c, char* base) {
   c->find_img_p = k.take<float>((size_t)c->KpD * Mp);
   c->fsp_img_p = k.take<float>((size_t)c->KpD * Mp);
   c->dec_emb_cat = k.take<float>((V + 1) * (size_t)d.embed_dim_nmn);
+  if (d.variant == N2NMN_VARIANT_VQA && d.qpn_hidden > 0) {
+    c->qpn_W1_p = k.take<float>((size_t)round_up(2 * d.lstm_dim, 32) * round_up(d.qpn_hidden, 64));
+    c->qpn_W2_p = k.take<float>((size_t)round_up(d.qpn_hidden, 32) * round_up(d.num_choices, 64));
+  }
   for (int i = 0; i < 5; ++i) c->wtxt_pad[i] = k.take<float>(E * Mp);
   for (int i = 0; i < 5; ++i) c->btxt_pad[i] = k.take<float>(Mp);
   for (int i = 0; i < 4; ++i) c->watt_pad[i] = k.take<float>(D * Mp);
@@ -156,6 +177,10 @@ static size_t carve_workspace(n2nmn_ctx* c, char* base) {
   c->dec_h1_all = k.take<float>(Td * N * L);
   c->ent_t = k.take<float>(Td * N);
   c->dh1_rm = k.take<float>(N * L);
+  if (d.variant == N2NMN_VARIANT_VQA && d.qpn_hidden > 0) {
+    c->qpn_h = k.take<float>(N * 2 * L);
+    c->qpn_hid = k.take<float>(N * (size_t)d.qpn_hidden);
+  }
   c->state = k.take<int32_t>(N * 3);
   c->next_idx = k.take<int32_t>(N);
   c->tokens = k.take<int32_t>(Td * N);
@@ -453,9 +478,14 @@ int run_program(n2nmn_ctx* c, Program& p, const float* feat, const float* word_v
   N2_REQUIRE(nn <= c->max_nodes && p.num_text <= c->max_text && p.num_pool <= c->max_pool &&
                  (int)p.tab.size() <= c->max_tab,
              N2NMN_ECAPACITY, "execute_program: program larger than the context workspace");
-  for (const DevNode& nd : p.dev_nodes)
+  for (const DevNode& nd : p.dev_nodes) {
     N2_REQUIRE(nd.op == OP_INPUT || (nd.n < N_full && nd.t < d.T_decoder), N2NMN_EINVAL,
                "execute_program: batch_idx / time_idx out of range");
+    if (d.variant == N2NMN_VARIANT_VQA)
+      N2_REQUIRE(nd.op == OP_INPUT || nd.op == N2NMN_OP_FIND || nd.op == N2NMN_OP_AND ||
+                     nd.op == N2NMN_OP_FIND_SAME_PROPERTY || nd.op == N2NMN_OP_DESCRIBE,
+                 N2NMN_EKEY, "execute_program: operator does not exist in models_vqa");
+  }
   const int HW = d.H * d.W, C = d.num_choices;
   if (scores && p.num_rows > 0)
     N2_HIP(hipMemsetAsync(scores, 0, sizeof(float) * (size_t)p.num_rows * C, s));  // INVALID_EXPR
@@ -490,6 +520,7 @@ int run_program(n2nmn_ctx* c, Program& p, const float* feat, const float* word_v
   b.pfc = c->pfc; b.mfind = c->mfind; b.mfsp = c->mfsp; b.feat = feat; b.word_vecs = word_vecs;
   b.scores = scores; b.N_full = N_full; b.H = d.H; b.W = d.W; b.D = d.D; b.M = d.map_dim;
   b.pooled = c->rec ? c->rec->pooled : nullptr;
+  b.vqa = d.variant == N2NMN_VARIANT_VQA;
   b.Mp = c->Mp; b.wl_cap = d.map_dim * C <= 10240 ? d.map_dim * C : 0; b.E = d.embed_dim_txt; b.C = C; b.HWp = c->HWp; b.ksize = d.kernel_size;
   const double dE = d.embed_dim_txt, dM = d.map_dim, dD = d.D, dHW = HW, dC = C, dMp = c->Mp;
   for (const Launch& l : p.launches) {
@@ -619,8 +650,13 @@ int n2nmn_ctx_create(const n2nmn_dims* dims, int device, n2nmn_ctx** out) {
              "ctx_create: lstm_dim must be a multiple of 128");
   N2_REQUIRE(d.embed_dim_txt % 4 == 0 && d.embed_dim_nmn == d.embed_dim_txt, N2NMN_EINVAL,
              "ctx_create: embed dims must be equal multiples of 4");
-  N2_REQUIRE(d.D % (4 * POOL_PARTS) == 0 && (256 % (d.D / POOL_PARTS / 4)) == 0, N2NMN_EINVAL,
-             "ctx_create: D must be a multiple of 16 with D/16 dividing 256");
+  N2_REQUIRE(d.D % (4 * POOL_PARTS) == 0 && d.D <= 4096, N2NMN_EINVAL,
+             "ctx_create: D must be a multiple of 16, at most 4096");
+  N2_REQUIRE(d.variant == N2NMN_VARIANT_CLEVR || d.variant == N2NMN_VARIANT_VQA, N2NMN_EINVAL,
+             "ctx_create: unknown model variant");
+  N2_REQUIRE(d.qpn_hidden >= 0 && (d.qpn_hidden == 0 || d.variant == N2NMN_VARIANT_VQA),
+             N2NMN_EINVAL, "ctx_create: qpn_hidden is a models_vqa option");
+  N2_REQUIRE(d.map_dim <= 1024, N2NMN_EINVAL, "ctx_create: map_dim must be <= 1024");
   N2_REQUIRE(d.kernel_size == 3 || d.kernel_size == 5, N2NMN_EINVAL,
              "ctx_create: kernel_size must be 3 or 5");
   N2_REQUIRE(d.num_vocab_nmn >= 2 && d.num_vocab_nmn <= 16, N2NMN_EINVAL,
@@ -690,12 +726,12 @@ int n2nmn_ctx_dims(const n2nmn_ctx* ctx, n2nmn_dims* out) {
   return N2NMN_OK;
 }
 
-int n2nmn_num_variables(const n2nmn_ctx* ctx) { return ctx ? (int)ctx->vars.size() : N2NMN_EINVAL; }
+int n2nmn_num_variables(const n2nmn_ctx* ctx) { return ctx ? (int)ctx->pub.size() : N2NMN_EINVAL; }
 
 int n2nmn_variable_info(const n2nmn_ctx* ctx, int i, const char** name, int64_t shape[4],
                         int* ndim) {
-  N2_REQUIRE(ctx && i >= 0 && i < (int)ctx->vars.size(), N2NMN_EINVAL, "variable_info: bad index");
-  const Var& v = ctx->vars[i];
+  N2_REQUIRE(ctx && i >= 0 && i < (int)ctx->pub.size(), N2NMN_EINVAL, "variable_info: bad index");
+  const Var& v = ctx->vars[ctx->pub[i]];
   if (name) *name = v.name.c_str();
   if (ndim) *ndim = (int)v.shape.size();
   if (shape)
@@ -778,22 +814,33 @@ int n2nmn_commit_weights(n2nmn_ctx* c, n2nmn_stream stream) {
   g.A = c->dec_emb_cat; g.M = V + 1; g.Bp = c->dec_W0x_p; g.bias = m(V_DEC_B0); g.C = c->dec_xtab;
   launch_gemm_pk(g, s);
   // zero-padded copies of the [M] vectors read with float4 lanes
+  auto has = [&](int id) { return c->vars[id].present; };   // absent in this model variant: skip
   const int wes[3] = {V_FIND_E_W, V_FSP_E_W, V_TR_E_W};
   for (int i = 0; i < 3; ++i) {
+    if (!has(wes[i])) continue;
     N2_HIP(hipMemsetAsync(c->we_pad[i], 0, sizeof(float) * Mp, s));
     N2_HIP(hipMemcpyAsync(c->we_pad[i], m(wes[i]), sizeof(float) * M, hipMemcpyDeviceToDevice, s));
   }
   const int txs[5] = {V_FIND_TXT_W, V_FSP_TXT_W, V_TR_TXT_W, V_SP_TXT_W, V_DE_TXT_W};
   for (int i = 0; i < 5; ++i) {
+    if (!has(txs[i])) continue;
     launch_pad_rows(m(txs[i]), E, M, c->wtxt_pad[i], Mp, s);
     launch_pad_rows(m(txs[i] + 1), 1, M, c->btxt_pad[i], Mp, s);
   }
   const int ats[4] = {V_FSP_ATT_W, V_SP_ATT0_W, V_SP_ATT1_W, V_DE_ATT_W};
-  for (int i = 0; i < 4; ++i) launch_pad_rows(m(ats[i]), d.D, M, c->watt_pad[i], Mp, s);
+  for (int i = 0; i < 4; ++i)
+    if (has(ats[i])) launch_pad_rows(m(ats[i]), d.D, M, c->watt_pad[i], Mp, s);
   const int bas[4] = {V_FSP_ATT_B, V_SP_ATT0_B, V_SP_ATT1_B, V_DE_ATT_B};
   for (int i = 0; i < 4; ++i) {
+    if (!has(bas[i])) continue;
     N2_HIP(hipMemsetAsync(c->batt_pad[i], 0, sizeof(float) * Mp, s));
     N2_HIP(hipMemcpyAsync(c->batt_pad[i], m(bas[i]), sizeof(float) * M, hipMemcpyDeviceToDevice, s));
+  }
+  if (c->qpn_W1_p) {
+    launch_pack_pk(m(V_QPN_W1), d.qpn_hidden, 2 * L, d.qpn_hidden, c->qpn_W1_p, round_up(2 * L, 32),
+                   round_up(d.qpn_hidden, 64), s);
+    launch_pack_pk(m(V_QPN_W2), d.num_choices, d.qpn_hidden, d.num_choices, c->qpn_W2_p,
+                   round_up(d.qpn_hidden, 32), round_up(d.num_choices, 64), s);
   }
   c->committed = true;
   c->commit_epoch++;
@@ -862,6 +909,43 @@ int n2nmn_module_forward(n2nmn_ctx* ctx, int op, int Nb, const float* input_0,
   if (rc != N2NMN_OK) { set_last_error(p.error); return rc; }
   return run_program(ctx, p, image_feat, word_vecs, N_full, ans ? out : nullptr, input_0, input_1,
                      ans ? nullptr : out, k * Nb, ans ? 0 : Nb, S(stream));
+}
+
+int n2nmn_add_coords(n2nmn_ctx* c, const float* feat, int N, int D0, float* out,
+                     n2nmn_stream stream) {
+  N2_REQUIRE(c && feat && out, N2NMN_EINVAL, "add_coords: null argument");
+  N2_REQUIRE(N >= 1 && D0 >= 1 && D0 + 2 <= c->d.D, N2NMN_EINVAL,
+             "add_coords: the context's feature depth must be >= D0 + 2");
+  launch_add_coords(feat, N, c->d.H, c->d.W, D0, c->d.D, out, S(stream));
+  return check_launch("add_coords");
+}
+
+int n2nmn_question_prior_add(n2nmn_ctx* c, int N, float* scores, n2nmn_stream stream) {
+  N2_REQUIRE(c && scores, N2NMN_EINVAL, "question_prior_add: null argument");
+  N2_REQUIRE(c->qpn_h, N2NMN_EINVAL, "question_prior_add: the context has no question prior net "
+                                     "(variant VQA with qpn_hidden > 0)");
+  N2_REQUIRE(is_committed(c), N2NMN_ENOWEIGHT, "question_prior_add: weights not committed");
+  N2_REQUIRE(c->enc_T > 0 && N == c->enc_N, N2NMN_EINVAL,
+             "question_prior_add: no matching encoder results in the context");
+  const n2nmn_dims& d = c->d;
+  const int L = d.lstm_dim, Hq = d.qpn_hidden, C = d.num_choices;
+  hipStream_t s = S(stream);
+  const n2nmn_ctx* r = root(c);
+  // h_concat = [h of layer 0, h of layer 1]  (question_prior_net.py:14-20), row-major [N][2L]
+  launch_unpack_h2(c->fh0, c->fh1, c->qpn_h, N, L, d.N, s);
+  GemmArgs g{};
+  g.A = c->qpn_h; g.lda = 2 * L; g.M = N; g.K = 2 * L; g.group_size = 1;
+  g.Bp = r->qpn_W1_p; g.Np = round_up(Hq, 64); g.Kp = round_up(2 * L, 32);
+  g.bias = r->vars[V_QPN_B1].mirror; g.N = Hq; g.C = c->qpn_hid; g.ldc = Hq; g.n_store = Hq;
+  g.relu = 1;                                      // fc_relu (util/cnn.py:121-126)
+  launch_gemm_pk(g, s);
+  GemmArgs g2{};
+  g2.A = c->qpn_hid; g2.lda = Hq; g2.M = N; g2.K = Hq; g2.group_size = 1;
+  g2.Bp = r->qpn_W2_p; g2.Np = round_up(C, 64); g2.Kp = round_up(Hq, 32);
+  g2.bias = r->vars[V_QPN_B2].mirror; g2.N = C; g2.C = scores; g2.ldc = C; g2.n_store = C;
+  g2.accumulate = 1;                               // scores = scores_nmn + scores_qpn
+  launch_gemm_pk(g2, s);
+  return check_launch("question_prior_add");
 }
 
 int n2nmn_profile_begin(n2nmn_ctx* ctx) {

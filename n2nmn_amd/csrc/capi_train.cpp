@@ -257,6 +257,8 @@ extern "C" {
 int n2nmn_train_enable(n2nmn_ctx* c) {
   N2_REQUIRE(c, N2NMN_EINVAL, "train_enable: null context");
   N2_REQUIRE(!c->parent, N2NMN_EINVAL, "train_enable: train on the root context");
+  N2_REQUIRE(c->d.variant == N2NMN_VARIANT_CLEVR, N2NMN_EINVAL,
+             "train_enable: the training step is built for the models_clevr variant");
   if (c->train) return N2NMN_OK;
   N2_REQUIRE(c->d.num_vocab_nmn <= 15, N2NMN_EINVAL,
              "train_enable: num_vocab_nmn + <go> must fit 16 x-table rows");
@@ -315,9 +317,10 @@ int64_t n2nmn_grad_split(const n2nmn_ctx* c) { return (c && c->train) ? c->train
 
 int n2nmn_grad_layout(const n2nmn_ctx* c, int variable, int64_t* offset, int64_t* numel) {
   N2_REQUIRE(c && c->train, N2NMN_EINVAL, "grad_layout: training not enabled");
-  N2_REQUIRE(variable >= 0 && variable < (int)c->vars.size(), N2NMN_EINVAL, "grad_layout: bad index");
-  if (offset) *offset = c->train->var_off[variable];
-  if (numel) *numel = (int64_t)c->vars[variable].numel;
+  N2_REQUIRE(variable >= 0 && variable < (int)c->pub.size(), N2NMN_EINVAL, "grad_layout: bad index");
+  const int id = c->pub[variable];           // index space of n2nmn_variable_info
+  if (offset) *offset = c->train->var_off[id];
+  if (numel) *numel = (int64_t)c->vars[id].numel;
   return N2NMN_OK;
 }
 

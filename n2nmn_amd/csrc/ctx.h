@@ -37,6 +37,7 @@ struct Var {
   size_t numel = 0;
   float* mirror = nullptr;   // context-owned copy in the reference layout
   bool set = false;
+  bool present = true;       // false: the variable does not exist in this model variant (numel 0)
 };
 
 // indices into Ctx::vars (order of build_vars)
@@ -52,6 +53,7 @@ enum VarId {
   V_LESS_B,
   V_SP_TXT_W, V_SP_TXT_B, V_SP_ATT0_W, V_SP_ATT0_B, V_SP_ATT1_W, V_SP_ATT1_B, V_SP_E_W, V_SP_E_B,
   V_DE_TXT_W, V_DE_TXT_B, V_DE_ATT_W, V_DE_ATT_B, V_DE_E_W, V_DE_E_B,
+  V_QPN_W1, V_QPN_B1, V_QPN_W2, V_QPN_B2,      // models_vqa/question_prior_net.py (VQA variant only)
   V_COUNT_
 };
 
@@ -77,7 +79,8 @@ struct TrainState;
 struct n2nmn_ctx {
   n2nmn_dims d{};
   int device = 0;
-  std::vector<Var> vars;
+  std::vector<Var> vars;                   // indexed by VarId (absent ones have numel 0)
+  std::vector<int> pub;                    // VarIds of the variables of this variant, in order
   std::unordered_map<std::string, int> index;
   bool committed = false;
   bool have_tables = false;
@@ -102,6 +105,7 @@ struct n2nmn_ctx {
   float *enc_W0h_t = nullptr, *enc_W1_t = nullptr, *dec_W0h_t = nullptr, *dec_W1_t = nullptr;
   float *eht_W_p = nullptr, *att_W_t = nullptr, *find_img_p = nullptr, *fsp_img_p = nullptr;
   float* dec_emb_cat = nullptr;
+  float *qpn_W1_p = nullptr, *qpn_W2_p = nullptr;    // PK packs of question_prior_net fc1 / fc2
   float* wtxt_pad[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   float* btxt_pad[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   float* watt_pad[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -114,6 +118,7 @@ struct n2nmn_ctx {
   float *dh0[2] = {nullptr, nullptr}, *dh1[2] = {nullptr, nullptr}, *dc0 = nullptr, *dc1 = nullptr;
   float *fc0 = nullptr, *fh0 = nullptr, *fc1 = nullptr, *fh1 = nullptr;
   int32_t *perm = nullptr, *nact = nullptr;
+  float *qpn_h = nullptr, *qpn_hid = nullptr;        // [N][2L] concat of final h, [N][qpn_hidden]
   float *enc_out = nullptr, *eht = nullptr, *qbuf = nullptr, *dec_h1_all = nullptr, *ent_t = nullptr, *dh1_rm = nullptr;
   int32_t *state = nullptr, *next_idx = nullptr, *tokens = nullptr;
   float *tprobs = nullptr, *negent = nullptr, *atts = nullptr, *word_vecs = nullptr;

@@ -24,6 +24,7 @@ struct GemmArgs {
   float* C; int ldc; int n_store;
   int accumulate;                             // != 0: C += A.B (+ bias) instead of C = ...
   int ksplit;                                 // > 1: K split over blockIdx.z, atomic C += (needs accumulate)
+  int relu;                                   // != 0: C = max(0, A.B + bias)
 };
 void launch_gemm_pk(const GemmArgs& a, hipStream_t s);
 
@@ -84,6 +85,9 @@ void launch_lstm_step(const LstmJob* jobs, int njobs, int N, int L, int rows_per
 // launch; workgroup (n, ts) addresses element ts*N + n of it.
 // k-interleaved state [L/4][R][4] -> row-major [N][L]
 void launch_unpack_h(const float* src, float* dst, int N, int L, int R, hipStream_t s);
+// dst[n][0:L) = unpack(a)[n], dst[n][L:2L) = unpack(b)[n]
+void launch_unpack_h2(const float* a, const float* b, float* dst, int N, int L, int R,
+                      hipStream_t s);
 void launch_lstm_step_dbg(const LstmJob* jobs, int njobs, int N, int L, int rows_per_wg,
                           int variant, hipStream_t s);
 
@@ -158,8 +162,12 @@ struct ModuleBuffers {
   int N_full, H, W, D, M, Mp, E, C, HWp, ksize;
   int wl_cap;             // floats of LDS the answer heads may use to stage fc weights
   float* pooled;          // [max_pool][2][D] attention-pooled features kept for backward, or nullptr
+  int vqa;                // models_vqa: no conv Transform / raw-map answer heads (no LDS for them)
 };
 
+// out[n,h,w,:] = [feat[n,h,w,:D0], linspace(-1,1,W)[w], linspace(-1,1,H)[h], 0 ...]
+void launch_add_coords(const float* feat, int N, int H, int W, int D0, int D, float* out,
+                       hipStream_t s);
 void launch_textmap(const ModuleWeights& w, const ModuleBuffers& b, int tab_off, int count,
                     hipStream_t s);
 void launch_att_ops(const ModuleWeights& w, const ModuleBuffers& b, int tab_off, int count,

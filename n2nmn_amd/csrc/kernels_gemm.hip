@@ -141,7 +141,8 @@ __global__ __launch_bounds__(256) void gemm_pk_kernel(GemmArgs a) {
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
       if (row < a.M) {
-        const float val = (col < a.N) ? acc[r] + bias : 0.f;
+        float val = (col < a.N) ? acc[r] + bias : 0.f;
+        if (a.relu) val = fmaxf(val, 0.f);
         float* dst = a.C + (size_t)row * a.ldc + col;
         if (a.ksplit > 1) atomicAdd(dst, val);
         else *dst = a.accumulate ? *dst + val : val;

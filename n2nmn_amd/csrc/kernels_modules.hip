@@ -318,6 +318,12 @@ __device__ void transform_op(const ModuleWeights& w, const ModuleBuffers& b, con
 // answer heads on raw attention maps: Exist (:258-280), Count (:282-304),
 // EqualNum / MoreNum / LessNum (:306-400)
 // ---------------------------------------------------------------------------------------------
+// LDS floats the raw-map answer heads may use to stage their fc weights (host and device agree)
+__host__ __device__ inline int light_wl_cap(int HW, int C) {
+  const int full = (2 * HW + 4) * C;
+  return full < 12288 ? full : 12288;
+}
+
 __device__ void light_answer(const ModuleWeights& w, const ModuleBuffers& b, const DevNode& nd,
                              float* smem) {
   const int HW = b.H * b.W, C = b.C;
@@ -358,7 +364,7 @@ __device__ void light_answer(const ModuleWeights& w, const ModuleBuffers& b, con
   }
   __syncthreads();
   fc_lds(x, F, w.Wans[wi], w.bans[wi], C, b.scores + (size_t)nd.out_row * C, partial, wl,
-         (2 * HW + 4) * C);
+         light_wl_cap(HW, C));
 }
 
 __global__ __launch_bounds__(MT) void att_ops_kernel(ModuleWeights w, ModuleBuffers b,
@@ -563,7 +569,30 @@ __global__ __launch_bounds__(MT) void heads_kernel(ModuleWeights w, ModuleBuffer
          b.wl_cap);
 }
 
+// models_vqa/nmn3_modules.py:11-31: tf.linspace(-1., 1., n)[i] = -1 + i * (2 / (n - 1))
+__global__ void add_coords_kernel(const float* __restrict__ feat, int N, int H, int W, int D0,
+                                  int D, float* __restrict__ out) {
+  const size_t total = (size_t)N * H * W * D;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % D);
+    const size_t px = i / D;
+    float v = 0.f;
+    if (c < D0) v = feat[px * D0 + c];
+    else if (c == D0) { const int x = (int)(px % W); v = W > 1 ? -1.f + x * (2.f / (W - 1)) : -1.f; }
+    else if (c == D0 + 1) { const int y = (int)((px / W) % H); v = H > 1 ? -1.f + y * (2.f / (H - 1)) : -1.f; }
+    out[i] = v;
+  }
+}
+
 }  // namespace
+
+void launch_add_coords(const float* feat, int N, int H, int W, int D0, int D, float* out,
+                       hipStream_t s) {
+  const size_t total = (size_t)N * H * W * D;
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 8192);
+  hipLaunchKernelGGL(add_coords_kernel, dim3(blocks), dim3(256), 0, s, feat, N, H, W, D0, D, out);
+}
 
 void launch_textmap(const ModuleWeights& w, const ModuleBuffers& b, int tab_off, int count,
                     hipStream_t s) {
@@ -579,8 +608,13 @@ void launch_att_ops(const ModuleWeights& w, const ModuleBuffers& b, int tab_off,
   const int RS = (KK + 2 + 3) & ~3;
   const size_t tr = (size_t)b.M * RS + (((size_t)(b.H + 2 * pad) * (b.W + 2 * pad) + 3) & ~3) +
                     4 * 64 * 2;
-  const size_t la = (size_t)((2 * HW + 4 + 3) & ~3) + 16 + 256 + (size_t)(2 * HW + 4) * b.C;
-  const size_t smem = sizeof(float) * (tr > la ? tr : la);
+  const size_t la = (size_t)((2 * HW + 4 + 3) & ~3) + 16 + 256 + (size_t)light_wl_cap(HW, b.C);
+  // models_vqa has neither the conv Transform nor the raw-map answer heads: Find-type epilogues,
+  // And/Or and Scene use no dynamic LDS, so many workgroups fit a CU
+  const size_t smem = b.vqa ? 0 : sizeof(float) * (tr > la ? tr : la);
+  if (smem > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(att_ops_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(att_ops_kernel, dim3(count), dim3(MT), smem, s, w, b, tab_off);
 }
 

@@ -590,6 +590,17 @@ __global__ void unpack_h_kernel(const float* __restrict__ src, float* __restrict
   }
 }
 
+__global__ void unpack_h2_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                 float* __restrict__ dst, int N, int L, int R) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N * 2 * L) {
+    const int n = i / (2 * L), k2 = i - n * 2 * L;
+    const float* src = k2 < L ? a : b;
+    const int k = k2 < L ? k2 : k2 - L;
+    dst[i] = src[((size_t)(k >> 2) * R + n) * 4 + (k & 3)];
+  }
+}
+
 // debug: the same launch with a kernel variant (see lstm_mma DBG); variant 5 = empty kernel
 void launch_lstm_step_dbg(const LstmJob* jobs, int njobs, int N, int L, int rows_per_wg,
                           int variant, hipStream_t s) {
@@ -626,6 +637,12 @@ void launch_lstm_step_dbg(const LstmJob* jobs, int njobs, int N, int L, int rows
 void launch_unpack_h(const float* src, float* dst, int N, int L, int R, hipStream_t s) {
   hipLaunchKernelGGL(unpack_h_kernel, dim3((N * L + 255) / 256), dim3(256), 0, s, src, dst, N, L,
                      R);
+}
+
+void launch_unpack_h2(const float* a, const float* b, float* dst, int N, int L, int R,
+                      hipStream_t s) {
+  hipLaunchKernelGGL(unpack_h2_kernel, dim3((N * 2 * L + 255) / 256), dim3(256), 0, s, a, b, dst, N,
+                     L, R);
 }
 
 void launch_dec_attn(const DecStepArgs& a, int nsteps, hipStream_t s) {

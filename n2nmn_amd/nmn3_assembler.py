@@ -135,7 +135,10 @@ class ExprList(list):
 
 
 class Assembler:
-    def __init__(self, module_vocab_file):
+    def __init__(self, module_vocab_file, op_code=None):
+        """op_code: module name -> C-ABI operator code; default = the models_clevr vocabulary
+        (a token is its op code).  models_vqa passes its own map (n2nmn_amd/vqa.py)."""
+        op_code = OP_CODE if op_code is None else op_code
         if isinstance(module_vocab_file, (list, tuple)):
             self.module_names = list(module_vocab_file)
         else:
@@ -147,8 +150,8 @@ class Assembler:
         self.P, self.W, self.b = build_validity_mats(self.module_names)
         # op code of each token for the C-ABI (-1 = <eos>); KeyError on modules we do not know
         self._token_op = np.array(
-            [-1 if s == '<eos>' else OP_CODE[s] for s in self.module_names], np.int32)
-        self._op_name = {OP_CODE[s]: s for s in self.module_names if s != '<eos>'}
+            [-1 if s == '<eos>' else op_code[s] for s in self.module_names], np.int32)
+        self._op_name = {op_code[s]: s for s in self.module_names if s != '<eos>'}
 
     # -- token helpers ----------------------------------------------------------------------
     def module_list2tokens(self, module_list, T=None):

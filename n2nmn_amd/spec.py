@@ -62,6 +62,8 @@ class Dims:
     T_decoder: int = 20
     N: int = 64
     kernel_size: int = 5      # models_clevr/nmn3_modules.py:185 (TransformModule)
+    variant: int = 0          # 0: models_clevr, 1: models_vqa (n2nmn_amd/vqa.py)
+    qpn_hidden: int = 0       # models_vqa/question_prior_net.py hidden width (500); 0 = no QPN
 
     @property
     def HW(self) -> int:

@@ -21,9 +21,15 @@ from .spec import (Dims, variable_shapes, CLEVR_MODULE_NAMES, CLEVR_LAYOUT_TEMPL
 
 
 def make_weights(d: Dims, seed: int = 0, dtype=np.float32) -> Dict[str, np.ndarray]:
+    return make_weights_from_shapes(variable_shapes(d), seed, dtype)
+
+
+def make_weights_from_shapes(shapes: Dict[str, tuple], seed: int = 0,
+                             dtype=np.float32) -> Dict[str, np.ndarray]:
+    """Same distributions for any name -> shape table (e.g. n2nmn_amd.vqa.vqa_variable_shapes)."""
     rng = np.random.default_rng(seed)
     out: Dict[str, np.ndarray] = {}
-    for name, shape in variable_shapes(d).items():
+    for name, shape in shapes.items():
         if name.endswith('/biases'):
             w = rng.uniform(-0.1, 0.1, size=shape)
         elif name.endswith('/v'):

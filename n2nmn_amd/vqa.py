@@ -1,0 +1,217 @@
+"""models_vqa variant (BASELINE.json configs[4]): the VQA / VQAv2 model of the reference
+(`models_vqa/nmn3_model.py`, `models_vqa/nmn3_modules.py`, `models_vqa/question_prior_net.py`,
+`exp_vqa/eval_vqa2.py:27-39`) on the same gfx950 kernels as the CLEVR path.
+
+What is different from models_clevr, and how it maps onto the C-ABI:
+
+* four modules: `_Find` (= FindModule), `_Transform` (attention-pooled three-way product: the
+  arithmetic of models_clevr's FindSamePropertyModule, so it runs under that operator code with the
+  variables of scope `TransformModule`), `_And`, `_Describe`;
+* the feature grid gets two coordinate channels (`add_spatial_coordinate_map`): built on the GPU by
+  `n2nmn_add_coords` into a buffer whose depth is padded to a multiple of 16 (2050 -> 2064; the
+  padded channels are zero and so are the matching weight rows);
+* `lstm_dim = 1000` is not a multiple of the 128-wide K split of the LSTM kernels: the context is
+  created with 1024 and the variables are zero-padded when they are loaded (padded hidden units have
+  zero weights and biases, so c = h = 0 for them forever and every real output is unchanged);
+* `scores = scores_nmn + question_prior_net(encoder_states)` (`n2nmn_question_prior_add`).
+
+The reference-shaped variable names / shapes are `vqa_variable_shapes`; `VQAEngine.load_weights`
+takes exactly those.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, asdict
+from typing import Dict, Tuple
+
+import numpy as np
+
+from . import _lib
+from .engine import Engine
+from .nmn3_assembler import Assembler
+from .spec import Dims, lstm_var, PREFIX, _ENC, _DEC, _MOD
+
+# exp_vqa/data/vocabulary_layout.txt
+VQA_MODULE_NAMES: Tuple[str, ...] = ('_Find', '_Transform', '_And', '_Describe', '<eos>')
+# C-ABI operator code of each models_vqa module (include/n2nmn.h, enum n2nmn_op)
+VQA_OP_CODE: Dict[str, int] = {'_Find': 1, '_Transform': 3, '_And': 5, '_Describe': 13}
+_QPN = PREFIX + 'question_prior_net/'
+
+
+@dataclass(frozen=True)
+class VQADims:
+    """exp_vqa/eval_vqa2.py:27-39 (reference-side dimensions; D = image features without coords)."""
+    H: int = 14
+    W: int = 14
+    D: int = 2048
+    map_dim: int = 1024            # models_vqa/nmn3_modules.py:82,123,193
+    embed_dim_txt: int = 300
+    embed_dim_nmn: int = 300
+    lstm_dim: int = 1000
+    num_layers: int = 2
+    num_vocab_txt: int = 17742     # exp_vqa/data/vocabulary_vqa.txt
+    num_vocab_nmn: int = 5
+    num_choices: int = 3001        # exp_vqa/data/answers_vqa.txt
+    T_encoder: int = 26
+    T_decoder: int = 13
+    N: int = 128                   # BASELINE.json configs[4] (the reference itself uses 50 / 64)
+    qpn_hidden: int = 500          # question_prior_net(hidden_dim=500); 0 = use_qpn False
+
+    def asdict(self):
+        return asdict(self)
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def internal_dims(d: VQADims) -> Dims:
+    """Dimensions of the GPU context: lstm_dim padded to 128, feature depth (+2 coords) to 16."""
+    return Dims(H=d.H, W=d.W, D=_round_up(d.D + 2, 16), map_dim=d.map_dim,
+                embed_dim_txt=d.embed_dim_txt, embed_dim_nmn=d.embed_dim_nmn,
+                lstm_dim=_round_up(d.lstm_dim, 128), num_layers=d.num_layers,
+                num_vocab_txt=d.num_vocab_txt, num_vocab_nmn=d.num_vocab_nmn,
+                num_choices=d.num_choices, T_encoder=d.T_encoder, T_decoder=d.T_decoder, N=d.N,
+                kernel_size=5, variant=1, qpn_hidden=d.qpn_hidden)
+
+
+def vqa_variable_shapes(d: VQADims) -> Dict[str, Tuple[int, ...]]:
+    """name -> shape of every variable of the models_vqa graph, reference layout."""
+    L, E, En, M, C = d.lstm_dim, d.embed_dim_txt, d.embed_dim_nmn, d.map_dim, d.num_choices
+    Dc = d.D + 2
+    s: Dict[str, Tuple[int, ...]] = {}
+    s[_ENC + 'embedding_mat'] = (d.num_vocab_txt, E)
+    s[lstm_var('encoder', 0, 'weights')] = (E + L, 4 * L)
+    s[lstm_var('encoder', 0, 'biases')] = (4 * L,)
+    s[lstm_var('encoder', 1, 'weights')] = (2 * L, 4 * L)
+    s[lstm_var('encoder', 1, 'biases')] = (4 * L,)
+    s[_ENC + 'encoder_h_transform/weights'] = (L, L)
+    s[_ENC + 'encoder_h_transform/biases'] = (L,)
+    s[_DEC + 'embedding_mat'] = (d.num_vocab_nmn, En)
+    s[_DEC + 'go_embedding'] = (1, En)
+    s[_DEC + 'att_prediction/v'] = (L,)
+    s[_DEC + 'att_prediction/weights'] = (L, L)
+    s[_DEC + 'att_prediction/biases'] = (L,)
+    s[_DEC + 'token_prediction/weights'] = (2 * L, d.num_vocab_nmn)
+    s[_DEC + 'token_prediction/biases'] = (d.num_vocab_nmn,)
+    s[lstm_var('decoder', 0, 'weights')] = (En + L, 4 * L)
+    s[lstm_var('decoder', 0, 'biases')] = (4 * L,)
+    s[lstm_var('decoder', 1, 'weights')] = (2 * L, 4 * L)
+    s[lstm_var('decoder', 1, 'biases')] = (4 * L,)
+
+    def layer(scope, name, shape):
+        s[_MOD + scope + '/' + name + '/weights'] = shape
+        s[_MOD + scope + '/' + name + '/biases'] = (shape[-1],)
+
+    layer('FindModule', 'conv_image', (Dc, M))
+    layer('FindModule', 'fc_text', (E, M))
+    layer('FindModule', 'conv_eltwise', (M, 1))
+    layer('TransformModule', 'conv_image', (Dc, M))
+    layer('TransformModule', 'fc_text', (E, M))
+    layer('TransformModule', 'fc_att', (Dc, M))
+    layer('TransformModule', 'conv_eltwise', (M, 1))
+    layer('DescribeModule', 'fc_text', (E, M))
+    layer('DescribeModule', 'fc_att', (Dc, M))
+    layer('DescribeModule', 'fc_eltwise', (M, C))
+    if d.qpn_hidden > 0:
+        s[_QPN + 'fc1/weights'] = (2 * L, d.qpn_hidden)
+        s[_QPN + 'fc1/biases'] = (d.qpn_hidden,)
+        s[_QPN + 'fc2/weights'] = (d.qpn_hidden, C)
+        s[_QPN + 'fc2/biases'] = (C,)
+    return s
+
+
+def pad_variable(name: str, w: np.ndarray, d: VQADims, di: Dims) -> np.ndarray:
+    """Reference-shaped variable -> the (zero padded) shape the GPU context expects."""
+    L, Lp = d.lstm_dim, di.lstm_dim
+    Dc, Dp = d.D + 2, di.D
+    w = np.asarray(w, np.float32)
+
+    def pad_gate_cols(x):                         # [..., 4L] -> [..., 4Lp], gate-major columns
+        out = np.zeros(x.shape[:-1] + (4 * Lp,), np.float32)
+        for g in range(4):
+            out[..., g * Lp:g * Lp + L] = x[..., g * L:(g + 1) * L]
+        return out
+
+    def pad_rows_blocks(x, blocks):               # blocks: [(src0, src1, dst0)], total rows given
+        total = blocks[-1][3]
+        out = np.zeros((total,) + x.shape[1:], np.float32)
+        for s0, s1, d0, _ in blocks:
+            out[d0:d0 + (s1 - s0)] = x[s0:s1]
+        return out
+
+    if 'basic_lstm_cell/weights' in name:
+        x = pad_gate_cols(w)
+        if 'cell_0' in name:                      # [E + L] rows: input rows stay, hidden rows padded
+            E = w.shape[0] - L
+            return pad_rows_blocks(x, [(0, E + L, 0, E + Lp)])
+        return pad_rows_blocks(x, [(0, L, 0, 2 * Lp), (L, 2 * L, Lp, 2 * Lp)])
+    if 'basic_lstm_cell/biases' in name:
+        return pad_gate_cols(w)
+    if name.endswith('encoder_h_transform/weights') or name.endswith('att_prediction/weights'):
+        out = np.zeros((Lp, Lp), np.float32); out[:L, :L] = w
+        return out
+    if name.endswith('encoder_h_transform/biases') or name.endswith('att_prediction/biases') \
+            or name.endswith('att_prediction/v'):
+        out = np.zeros((Lp,), np.float32); out[:L] = w
+        return out
+    if name.endswith('token_prediction/weights') or name.endswith('question_prior_net/fc1/weights'):
+        return pad_rows_blocks(w, [(0, L, 0, 2 * Lp), (L, 2 * L, Lp, 2 * Lp)])
+    if name.endswith('conv_image/weights') or name.endswith('fc_att/weights'):
+        out = np.zeros((Dp, w.shape[1]), np.float32); out[:Dc] = w
+        return out
+    return w
+
+
+class VQAEngine:
+    """GPU context of the models_vqa variant + the eval-loop forward of exp_vqa/eval_vqa2.py."""
+
+    def __init__(self, dims: VQADims, device: int = 0):
+        self.dims = dims
+        self.idims = internal_dims(dims)
+        self.assembler = Assembler(list(VQA_MODULE_NAMES), op_code=VQA_OP_CODE)
+        self.engine = Engine(self.idims, self.assembler, device=device)
+        self._feat_c = None
+
+    def load_weights(self, weights: Dict[str, object]):
+        shapes = vqa_variable_shapes(self.dims)
+        missing = set(shapes) - set(weights)
+        if missing:
+            raise KeyError('missing variables: %s' % sorted(missing)[:3])
+        padded = {}
+        for name, shape in shapes.items():
+            w = weights[name]
+            w = w.detach().cpu().numpy() if hasattr(w, 'detach') else np.asarray(w)
+            if tuple(w.shape) != tuple(shape):
+                raise ValueError('shape mismatch for %s: %s vs %s' % (name, w.shape, shape))
+            padded[name] = pad_variable(name, w, self.dims, self.idims)
+        self.engine.load_weights(padded)
+
+    def features_with_coords(self, image_feat):
+        """[N,H,W,D] image features -> [N,H,W,Dp] with the coordinate map appended (on the GPU)."""
+        import torch
+        e, d, di = self.engine, self.dims, self.idims
+        feat = e._dev(image_feat, torch.float32)
+        n = feat.shape[0]
+        if self._feat_c is None or self._feat_c.shape[0] != n:
+            self._feat_c = torch.empty((n, di.H, di.W, di.D), dtype=torch.float32, device=e.device)
+        _lib.check(e._lib.n2nmn_add_coords(e._ctx, feat.data_ptr(), n, d.D, self._feat_c.data_ptr(),
+                                           e.stream()))
+        return self._feat_c
+
+    def forward(self, batch, use_gt_layout: bool = False, gt_layout=None, forced_tokens=None,
+                use_qpn: bool = True):
+        """phase 1 -> token fetch -> assemble -> phase 2 (+ question prior).  Returns (scores device
+        tensor [N, num_choices], tokens, validity) -- scores = scores_nmn + scores_qpn
+        (models_vqa/nmn3_model.py:106-114); the eval script's `scores[:, 0] = -1e10` is the caller's."""
+        e = self.engine
+        s2s = e.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], self.dims.T_decoder,
+                        use_gt_layout, gt_layout, None, forced_tokens)
+        tokens = s2s['predicted_tokens'].cpu().numpy()
+        packed, validity = self.assembler.assemble_packed(tokens)
+        feat_c = self.features_with_coords(batch['image_feat_batch'])
+        scores = e.execute(packed, feat_c, s2s['word_vecs'])
+        if use_qpn and self.dims.qpn_hidden > 0:
+            _lib.check(e._lib.n2nmn_question_prior_add(e._ctx, scores.shape[0], scores.data_ptr(),
+                                                       e.stream()))
+        return scores, tokens, validity

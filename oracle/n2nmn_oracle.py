@@ -469,3 +469,86 @@ def losses(w, scores, labels, log_seq_prob, weight_decay=5e-6):
     seq_likelihood_loss = np.mean(-log_seq_prob)
     return dict(avg_sample_loss=avg_sample_loss, seq_likelihood_loss=seq_likelihood_loss,
                 l2_reg=l2, total_loss=seq_likelihood_loss + avg_sample_loss + weight_decay * l2)
+
+
+# ========================================================================================
+# models_vqa variant (BASELINE.json configs[4]; exp_vqa/eval_vqa2.py:27-39,103-137)
+# Same AttentionSeq2Seq (models_vqa/nmn3_netgen_att.py is byte-identical to models_clevr's);
+# four modules over the feature grid with two coordinate channels appended; question prior net.
+# ========================================================================================
+VQA_MODULE_NAMES = ('_Find', '_Transform', '_And', '_Describe', '<eos>')
+_QPN = _P + 'question_prior_net/'
+
+
+def add_spatial_coordinate_map(feat):
+    """models_vqa/nmn3_modules.py:11-31: concat [x_map, y_map], x = linspace(-1,1,W) along W,
+    y = linspace(-1,1,H) along H (TF computes the linspace in float32)."""
+    N, H, W, _ = feat.shape
+    x = np.linspace(-1.0, 1.0, W, dtype=np.float32).astype(feat.dtype)
+    y = np.linspace(-1.0, 1.0, H, dtype=np.float32).astype(feat.dtype)
+    xm = np.broadcast_to(x[None, None, :, None], (N, H, W, 1))
+    ym = np.broadcast_to(y[None, :, None, None], (N, H, W, 1))
+    return np.concatenate([feat, xm, ym], axis=3)
+
+
+def vqa_find(w, feat, txt):                              # models_vqa/nmn3_modules.py:82-121
+    return m_find(w, feat, txt)
+
+
+def vqa_transform(w, in0, feat, txt):                    # :123-171 ("Same as FindSamePropertyModule")
+    s = 'TransformModule/'
+    img = _conv1x1(w, s + 'conv_image', feat)
+    t = _fc(w, s + 'fc_text', txt)[:, None, None, :]
+    a = _fc(w, s + 'fc_att', _att_pool(feat, in0))[:, None, None, :]
+    return _conv1x1(w, s + 'conv_eltwise', _l2n(img * t * a, 3))
+
+
+def vqa_describe(w, in0, feat, txt):                     # :193-240 (encoder_states is None)
+    return m_describe(w, in0, feat, txt)
+
+
+def question_prior_net(w, enc_states):
+    """models_vqa/question_prior_net.py:10-28 without dropout: fc2(relu(fc1(concat h)))."""
+    h = np.concatenate([s[1] for s in enc_states], axis=1)
+    fc1 = np.maximum(h @ w[_QPN + 'fc1/weights'] + w[_QPN + 'fc1/biases'], 0)
+    return fc1 @ w[_QPN + 'fc2/weights'] + w[_QPN + 'fc2/biases']
+
+
+def eval_expr_vqa(w, expr, feat_c, word_vecs, num_choices, dtype):
+    if expr['module'] == INVALID:
+        return np.zeros(num_choices, dtype)
+    N_full = word_vecs.shape[1]
+    flat = word_vecs.reshape(-1, word_vecs.shape[-1])
+
+    def rec(e):
+        t, n = e['time_idx'], e['batch_idx']
+        feat = feat_c[n:n + 1]
+        txt = flat[t * N_full + n][None]
+        ins = [rec(e[k]) for k in ('input_0', 'input_1') if k in e]
+        m = e['module']
+        if m == '_Find': return vqa_find(w, feat, txt)
+        if m == '_Transform': return vqa_transform(w, ins[0], feat, txt)
+        if m == '_And': return m_and(ins[0], ins[1])
+        if m == '_Describe': return vqa_describe(w, ins[0], feat, txt)
+        raise KeyError(m)
+
+    return rec(expr)[0]
+
+
+def forward_vqa(w, batch, T_dec, num_choices, dtype=np.float64, use_qpn=True, use_gt_layout=False,
+                gt_layout=None, forced_tokens=None):
+    """exp_vqa/eval_vqa2.py:103-135 + models_vqa/nmn3_model.py:15-121 (scores = scores_nmn +
+    scores_qpn; the eval script's `scores_val[:, 0] = -1e10` is host post-processing, not here)."""
+    names = list(VQA_MODULE_NAMES)
+    P, Wv, bv = build_validity_mats(names)
+    enc = encoder_forward(w, batch['input_seq_batch'], batch['seq_length_batch'], dtype)
+    dec = decoder_forward(w, enc, P, Wv, bv, T_dec, dtype, use_gt_layout, gt_layout, None,
+                          forced_tokens)
+    exprs, validity = assemble(names, dec['predicted_tokens'])
+    wc = _cast(w, dtype)
+    feat_c = add_spatial_coordinate_map(np.asarray(batch['image_feat_batch'], dtype))
+    wv = np.asarray(dec['word_vecs'], dtype)
+    scores_nmn = np.stack([eval_expr_vqa(wc, e, feat_c, wv, num_choices, dtype) for e in exprs])
+    scores = scores_nmn + question_prior_net(wc, enc['states']) if use_qpn else scores_nmn
+    return dict(enc=enc, dec=dec, expr_list=exprs, validity=validity, scores_nmn=scores_nmn,
+                scores=scores)

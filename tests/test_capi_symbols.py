@@ -35,7 +35,7 @@ def test_version_and_error_strings():
 
 
 def test_struct_sizes_match_header():
-    assert ctypes.sizeof(_lib.Dims) == 15 * 4
+    assert ctypes.sizeof(_lib.Dims) == 17 * 4
     assert ctypes.sizeof(_lib.Node) == 8 * 4
     # 2 ptr + 4 int32 + 13 ptr
     assert ctypes.sizeof(_lib.Seq2SeqIO) == 2 * 8 + 4 * 4 + 13 * 8

@@ -1,0 +1,89 @@
+"""BASELINE.json configs[4]: the models_vqa path (exp_vqa/eval_vqa2.py:103-137) on the GPU at the
+reference's dimensions (14x14x2048 ResNet features + 2 coordinate channels, map_dim 1024,
+lstm_dim 1000, 17742-word vocabulary, 3001 answers, T_enc 26, T_dec 13) against the fp64 oracle.
+Answer logits (scores_nmn + question prior) within 1e-4; decoder protocol as for CLEVR: token
+scores compared, the oracle's tokens forced for the module network."""
+import numpy as np
+import pytest
+
+from oracle import n2nmn_oracle as O
+from n2nmn_amd import synth, vqa
+from util import assert_close, t2n
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+NQ = 24          # questions per test batch (the oracle runs 2050x1024 1x1 convs per Find in fp64)
+
+
+@pytest.fixture(scope='module')
+def vqa_setup():
+    d = vqa.VQADims(N=NQ)
+    eng = vqa.VQAEngine(d)
+    w = synth.make_weights_from_shapes(vqa.vqa_variable_shapes(d), seed=0)
+    eng.load_weights(w)
+    return eng, d, w
+
+
+def _batch(d, seed):
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(1, d.T_encoder + 1, size=d.N).astype(np.int32)
+    seq = rng.integers(0, d.num_vocab_txt, size=(d.T_encoder, d.N)).astype(np.int32)
+    seq[np.arange(d.T_encoder)[:, None] >= lens[None, :]] = 0
+    feat = np.maximum(rng.standard_normal((d.N, d.H, d.W, d.D)), 0).astype(np.float32)
+    return dict(input_seq_batch=seq, seq_length_batch=lens, image_feat_batch=feat)
+
+
+# the layouts of exp_vqa/data/v2_gt_layout_*.npy (24 unique; these cover every module and arity)
+LAYOUTS = (['_Find', '_Describe'], ['_Find', '_Find', '_And', '_Describe'],
+           ['_Find', '_Transform', '_Describe'], ['_Find', '_Transform', '_Find', '_And', '_Describe'],
+           ['_Find', '_Find', '_Find', '_And', '_And', '_Describe'],
+           ['_Find', '_Transform', '_Transform', '_Describe'])
+
+
+def _gt(eng, d):
+    asm = eng.assembler
+    return np.array([asm.module_list2tokens(LAYOUTS[i % len(LAYOUTS)], d.T_decoder)
+                     for i in range(d.N)], np.int32).T
+
+
+def test_vqa_gt_layouts(vqa_setup):
+    eng, d, w = vqa_setup
+    batch = _batch(d, 0)
+    gt = _gt(eng, d)
+    ref = O.forward_vqa(w, batch, d.T_decoder, d.num_choices, np.float64, use_gt_layout=True,
+                        gt_layout=gt)
+    assert ref['validity'].all()
+    scores, tokens, validity = eng.forward(batch, use_gt_layout=True, gt_layout=gt)
+    assert np.array_equal(tokens, gt) and validity.all()
+    got = t2n(scores).copy()                      # the engine reuses its output buffer
+    assert_close('scores', got, ref['scores'], TOL)
+    assert np.array_equal(np.argmax(got, 1), np.argmax(ref['scores'], 1))
+    nmn, _, _ = eng.forward(batch, use_gt_layout=True, gt_layout=gt, use_qpn=False)
+    assert_close('scores_nmn', t2n(nmn), ref['scores_nmn'], TOL)
+
+
+def test_vqa_decoder_and_forced_greedy_layouts(vqa_setup):
+    eng, d, w = vqa_setup
+    batch = _batch(d, 5)
+    ref = O.forward_vqa(w, batch, d.T_decoder, d.num_choices, np.float64)
+    s2s = eng.engine.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], d.T_decoder,
+                             forced_tokens=ref['dec']['predicted_tokens'], debug=True)
+    L = d.lstm_dim
+    assert_close('token_scores', t2n(s2s['token_scores']), ref['dec']['token_scores'], TOL)
+    assert_close('encoder_outputs', t2n(s2s['encoder_outputs'])[:, :, :L], ref['enc']['outputs'], TOL)
+    assert np.abs(t2n(s2s['encoder_outputs'])[:, :, L:]).max() == 0.0      # padded units stay 0
+    assert_close('word_vecs', t2n(s2s['word_vecs']), ref['dec']['word_vecs'], TOL)
+    scores, tokens, validity = eng.forward(batch, forced_tokens=ref['dec']['predicted_tokens'])
+    assert validity.all()
+    assert_close('scores', t2n(scores), ref['scores'], TOL)
+
+
+def test_vqa_rejects_clevr_only_operators(vqa_setup):
+    eng, d, w = vqa_setup
+    import torch
+    e = eng.engine
+    feat = torch.zeros((1, d.H, d.W, eng.idims.D), device=e.device)
+    wv = torch.zeros((d.T_decoder, 1, d.embed_dim_txt), device=e.device)
+    att = torch.zeros((1, d.H, d.W, 1), device=e.device)
+    with pytest.raises(KeyError):
+        e.module_forward('_Count', [att], [0], [0], feat, wv)
