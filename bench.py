@@ -34,9 +34,10 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--config', type=int, default=2, choices=(2, 3, 4),
+    ap.add_argument('--config', type=int, default=2, choices=(2, 3, 4, 5),
                     help='2: fixed gt layouts (metric config); 3: greedy decoder layouts; '
-                         '4: training step (forward + backward + RCCL all-reduce + Adam)')
+                         '4: training step (forward + backward + RCCL all-reduce + Adam); '
+                         '5: models_vqa forward (14x14x2048 feats, batch 128)')
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--streams', type=int, default=4,
                     help='independent batches in flight per GPU (one host thread + HIP stream + '
@@ -196,6 +197,66 @@ def bench_train(args, dp, local_rank):
     dp.close()
 
 
+def bench_vqa(args, dp, local_rank):
+    """BASELINE.json configs[4]: models_vqa forward (exp_vqa/eval_vqa2.py:103-137) -- seq2seq with
+    the 17742-word vocabulary and lstm_dim 1000, coordinate map, the 4-module network at map_dim
+    1024 on 14x14x2048 features, question prior net -- batch 128 per GPU, ground-truth layouts from
+    the v2 validation histogram."""
+    import numpy as np
+    import torch
+    from n2nmn_amd import synth, vqa
+    rank, world = dp.rank, dp.world
+    d = vqa.VQADims(N=128 if args.batch == 64 else args.batch)
+    eng = vqa.VQAEngine(d, device=local_rank)
+    w = synth.make_weights_from_shapes(vqa.vqa_variable_shapes(d), seed=0)
+    eng.load_weights(w)
+    dev = eng.engine.device
+    mix = (['_Find', '_Find', '_And', '_Describe'],) * 46 + (['_Find', '_Describe'],) * 43 + \
+          (['_Find', '_Transform', '_Describe'],) * 9 + (['_Find', '_Transform', '_Find', '_And', '_Describe'],) * 2
+    rng = np.random.default_rng(dp.batch_seed(0))
+    batches, gts = [], []
+    for i in range(3):
+        lens = rng.integers(3, d.T_encoder + 1, size=d.N).astype(np.int32)
+        seq = rng.integers(0, d.num_vocab_txt, size=(d.T_encoder, d.N)).astype(np.int32)
+        seq[np.arange(d.T_encoder)[:, None] >= lens[None, :]] = 0
+        feat = torch.relu(torch.randn((d.N, d.H, d.W, d.D), generator=torch.Generator().manual_seed(i)))
+        batches.append(dict(input_seq_batch=torch.as_tensor(seq).to(dev),
+                            seq_length_batch=torch.as_tensor(lens).to(dev),
+                            image_feat_batch=feat.to(dev)))
+        order = rng.permutation(100)
+        gts.append(torch.as_tensor(np.array(
+            [eng.assembler.module_list2tokens(mix[order[n % 100]], d.T_decoder) for n in range(d.N)],
+            np.int32).T).to(dev))
+
+    def run_steps(first, count):
+        for i in range(first, first + count):
+            eng.forward(batches[i % 3], use_gt_layout=True, gt_layout=gts[i % 3])
+
+    run_steps(0, args.warmup)
+    elapsed = dp.timed(lambda: run_steps(args.warmup, args.steps),
+                       sync=lambda: torch.cuda.synchronize(dev))
+    out = None
+    if rank == 0:
+        out = {'metric': 'questions/sec (forward) on VQAv2 14x14x2048 feats, batch %d per GPU' % d.N,
+               'value': round(dp.throughput(d.N * args.steps, elapsed), 1), 'unit': 'questions/sec',
+               'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+               'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True,
+               'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': 'BASELINE.json configs[4]: models_vqa forward, gt layouts (v2 val '
+                                      'histogram), batch %d per GPU, T_enc=26, T_dec=13, single stream'
+                                      % d.N, 'global_batch': world * d.N,
+                          'parallelism': 'dp%d (question-sharded)' % world}}
+        if not args.no_profile:
+            ksteps = min(args.steps, 10)
+            eng.engine.profile_begin()
+            run_steps(0, ksteps)
+            rows = kernel_rows(eng.engine.profile_end(), ksteps)
+            out['kernels'] = rows
+            out['gpu_us_per_step'] = round(sum(r['us_per_step'] for r in rows), 1)
+        print(json.dumps(out), flush=True)
+    dp.close()
+
+
 def main():
     args = parse()
     import numpy as np
@@ -208,6 +269,8 @@ def main():
     rank, world = dp.rank, dp.world
     if args.config == 4:
         return bench_train(args, dp, local_rank)
+    if args.config == 5:
+        return bench_vqa(args, dp, local_rank)
 
     from n2nmn_amd import synth
     from n2nmn_amd.engine import Engine

@@ -137,6 +137,11 @@ static size_t carve_weights(n2nmn_ctx* c, char* base) {
   c->find_img_p = k.take<float>((size_t)c->KpD * Mp);
   c->fsp_img_p = k.take<float>((size_t)c->KpD * Mp);
   c->dec_emb_cat = k.take<float>((V + 1) * (size_t)d.embed_dim_nmn);
+  if (c->big_heads) {
+    const size_t n = (size_t)round_up(d.map_dim, 32) * round_up(d.num_choices, 64);
+    c->wans_de_p = k.take<float>(n);
+    if (d.variant == N2NMN_VARIANT_CLEVR) c->wans_sp_p = k.take<float>(n);
+  }
   if (d.variant == N2NMN_VARIANT_VQA && d.qpn_hidden > 0) {
     c->qpn_W1_p = k.take<float>((size_t)round_up(2 * d.lstm_dim, 32) * round_up(d.qpn_hidden, 64));
     c->qpn_W2_p = k.take<float>((size_t)round_up(d.qpn_hidden, 32) * round_up(d.num_choices, 64));
@@ -194,6 +199,10 @@ static size_t carve_workspace(n2nmn_ctx* c, char* base) {
   c->pfc = k.take<float>((size_t)c->max_pool * 2 * POOL_PARTS * Mp);
   c->mfind = k.take<float>(N * HW * Mp);
   c->mfsp = k.take<float>(N * HW * Mp);
+  if (c->big_heads) {
+    c->ev_out = k.take<float>((size_t)c->max_pool * Mp);
+    c->ev_rows = k.take<int32_t>(2 * (size_t)c->max_pool);
+  }
   c->dev_nodes = k.take<DevNode>(c->max_nodes);
   c->dev_tab = k.take<int32_t>(c->max_tab);
   return align_up(k.off, 256);
@@ -521,6 +530,7 @@ int run_program(n2nmn_ctx* c, Program& p, const float* feat, const float* word_v
   b.scores = scores; b.N_full = N_full; b.H = d.H; b.W = d.W; b.D = d.D; b.M = d.map_dim;
   b.pooled = c->rec ? c->rec->pooled : nullptr;
   b.vqa = d.variant == N2NMN_VARIANT_VQA;
+  b.ev_out = c->big_heads ? c->ev_out : nullptr; b.ev_rows = c->ev_rows; b.ev_stride = c->max_pool;
   b.Mp = c->Mp; b.wl_cap = d.map_dim * C <= 10240 ? d.map_dim * C : 0; b.E = d.embed_dim_txt; b.C = C; b.HWp = c->HWp; b.ksize = d.kernel_size;
   const double dE = d.embed_dim_txt, dM = d.map_dim, dD = d.D, dHW = HW, dC = C, dMp = c->Mp;
   for (const Launch& l : p.launches) {
@@ -585,6 +595,24 @@ int run_program(n2nmn_ctx* c, Program& p, const float* feat, const float* word_v
         ProfScope ps(c, F_HEADS, l.count * (2.0 * dM * dC + 8.0 * dM),
                      4.0 * (l.count * (2.0 * POOL_PARTS * dMp + dMp + dC) + dM * dC), s);
         launch_heads(w, b, l.offset, l.count, s);
+        if (c->big_heads) {       // fc_eltwise of the whole launch as a GEMM, rows scattered to scores
+          bool any_sp = false, any_de = false;
+          for (int i = 0; i < l.count; ++i) {
+            const int op = p.dev_nodes[p.tab[l.offset + i]].op;
+            any_sp |= op == N2NMN_OP_SAME_PROPERTY; any_de |= op == N2NMN_OP_DESCRIBE;
+          }
+          const n2nmn_ctx* r = root(c);
+          for (int which = 0; which < 2; ++which) {
+            if (!(which == 0 ? any_de : any_sp)) continue;
+            GemmArgs g{};
+            g.A = c->ev_out; g.lda = c->Mp; g.M = l.count; g.K = d.map_dim; g.group_size = 1;
+            g.Bp = which == 0 ? r->wans_de_p : r->wans_sp_p; g.Np = round_up(C, 64);
+            g.Kp = round_up(d.map_dim, 32);
+            g.bias = c->vars[which == 0 ? V_DE_E_B : V_SP_E_B].mirror; g.N = C; g.C = scores;
+            g.ldc = C; g.n_store = C; g.c_row_idx = c->ev_rows + which * c->max_pool;
+            launch_gemm_pk(g, s);
+          }
+        }
         break;
       }
       default: break;
@@ -679,6 +707,7 @@ int n2nmn_ctx_create(const n2nmn_dims* dims, int device, n2nmn_ctx** out) {
   c->max_text = c->max_nodes;
   c->max_pool = c->max_nodes;
   c->max_tab = c->max_nodes * 16 + 4096;
+  c->big_heads = (size_t)d.map_dim * d.num_choices > 65536;
   int rc = finish_create(c, nullptr);
   if (rc != N2NMN_OK) { delete c; return rc; }
   *out = c;
@@ -698,7 +727,7 @@ int n2nmn_ctx_fork(n2nmn_ctx* parent, n2nmn_ctx** out) {
   build_vars(c);
   c->Mp = parent->Mp; c->HWp = parent->HWp; c->KpE = parent->KpE; c->KpL = parent->KpL;
   c->KpD = parent->KpD; c->max_nodes = parent->max_nodes; c->max_text = parent->max_text;
-  c->max_pool = parent->max_pool; c->max_tab = parent->max_tab;
+  c->max_pool = parent->max_pool; c->max_tab = parent->max_tab; c->big_heads = parent->big_heads;
   int rc = finish_create(c, parent);
   if (rc != N2NMN_OK) { delete c; return rc; }
   *out = c;
@@ -835,6 +864,11 @@ int n2nmn_commit_weights(n2nmn_ctx* c, n2nmn_stream stream) {
     if (!has(bas[i])) continue;
     N2_HIP(hipMemsetAsync(c->batt_pad[i], 0, sizeof(float) * Mp, s));
     N2_HIP(hipMemcpyAsync(c->batt_pad[i], m(bas[i]), sizeof(float) * M, hipMemcpyDeviceToDevice, s));
+  }
+  if (c->big_heads) {
+    const int Kp = round_up(M, 32), Np = round_up(d.num_choices, 64);
+    launch_pack_pk(m(V_DE_E_W), d.num_choices, M, d.num_choices, c->wans_de_p, Kp, Np, s);
+    if (c->wans_sp_p) launch_pack_pk(m(V_SP_E_W), d.num_choices, M, d.num_choices, c->wans_sp_p, Kp, Np, s);
   }
   if (c->qpn_W1_p) {
     launch_pack_pk(m(V_QPN_W1), d.qpn_hidden, 2 * L, d.qpn_hidden, c->qpn_W1_p, round_up(2 * L, 32),

@@ -106,6 +106,8 @@ struct n2nmn_ctx {
   float *eht_W_p = nullptr, *att_W_t = nullptr, *find_img_p = nullptr, *fsp_img_p = nullptr;
   float* dec_emb_cat = nullptr;
   float *qpn_W1_p = nullptr, *qpn_W2_p = nullptr;    // PK packs of question_prior_net fc1 / fc2
+  float *wans_sp_p = nullptr, *wans_de_p = nullptr;  // PK packs of fc_eltwise (large num_choices only)
+  bool big_heads = false;                            // map_dim * num_choices beyond the fused head
   float* wtxt_pad[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   float* btxt_pad[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   float* watt_pad[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -128,6 +130,8 @@ struct n2nmn_ctx {
 
   // module workspace
   float *arena = nullptr, *tmap = nullptr, *pfc = nullptr, *mfind = nullptr, *mfsp = nullptr;
+  float* ev_out = nullptr;
+  int32_t* ev_rows = nullptr;
   DevNode* dev_nodes = nullptr;
   int32_t* dev_tab = nullptr;
   int max_tab = 0;

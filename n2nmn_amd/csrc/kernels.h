@@ -25,6 +25,8 @@ struct GemmArgs {
   int accumulate;                             // != 0: C += A.B (+ bias) instead of C = ...
   int ksplit;                                 // > 1: K split over blockIdx.z, atomic C += (needs accumulate)
   int relu;                                   // != 0: C = max(0, A.B + bias)
+  const int32_t* c_row_idx;                   // optional: result row r goes to C row c_row_idx[r]
+                                              // (negative: the row is not stored)
 };
 void launch_gemm_pk(const GemmArgs& a, hipStream_t s);
 
@@ -163,6 +165,11 @@ struct ModuleBuffers {
   int wl_cap;             // floats of LDS the answer heads may use to stage fc weights
   float* pooled;          // [max_pool][2][D] attention-pooled features kept for backward, or nullptr
   int vqa;                // models_vqa: no conv Transform / raw-map answer heads (no LDS for them)
+  // large answer vocabularies (map_dim * num_choices too big for the fused head): the head kernel
+  // only writes the normalised vectors and the fc_eltwise runs as one gemm_pk per launch
+  float* ev_out;          // [count][Mp] or nullptr (fused fc)
+  int32_t* ev_rows;       // [2][max_pool]: result row of entry i for Describe / SameProperty, or -1
+  int ev_stride;          // max_pool
 };
 
 // out[n,h,w,:] = [feat[n,h,w,:D0], linspace(-1,1,W)[w], linspace(-1,1,H)[h], 0 ...]

@@ -143,7 +143,12 @@ __global__ __launch_bounds__(256) void gemm_pk_kernel(GemmArgs a) {
       if (row < a.M) {
         float val = (col < a.N) ? acc[r] + bias : 0.f;
         if (a.relu) val = fmaxf(val, 0.f);
-        float* dst = a.C + (size_t)row * a.ldc + col;
+        int orow = row;
+        if (a.c_row_idx) {
+          orow = a.c_row_idx[row];
+          if (orow < 0) continue;
+        }
+        float* dst = a.C + (size_t)orow * a.ldc + col;
         if (a.ksplit > 1) atomicAdd(dst, val);
         else *dst = a.accumulate ? *dst + val : val;
       }

@@ -562,6 +562,14 @@ __global__ __launch_bounds__(MT) void heads_kernel(ModuleWeights w, ModuleBuffer
   }
   const float ss = block_reduce<0>(lss, scratch);
   const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+  if (b.ev_out) {          // large answer vocabulary: fc_eltwise runs as a GEMM over the launch
+    for (int c = threadIdx.x; c < Mp; c += MT) b.ev_out[(size_t)blockIdx.x * Mp + c] = ev[c] * inv;
+    if (threadIdx.x == 0) {
+      b.ev_rows[blockIdx.x] = same ? -1 : nd.out_row;
+      b.ev_rows[b.ev_stride + blockIdx.x] = same ? nd.out_row : -1;
+    }
+    return;
+  }
   for (int c = threadIdx.x; c < Mp; c += MT) ev[c] *= inv;
   __syncthreads();
   const int wi = same ? 5 : 6;
