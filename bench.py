@@ -39,7 +39,7 @@ def parse():
                          '4: training step (forward + backward + RCCL all-reduce + Adam); '
                          '5: models_vqa forward (14x14x2048 feats, batch 128)')
     ap.add_argument('--batch', type=int, default=64)
-    ap.add_argument('--streams', type=int, default=4,
+    ap.add_argument('--streams', type=int, default=6,
                     help='independent batches in flight per GPU (one host thread + HIP stream + '
                          'forked context each; weights shared)')
     ap.add_argument('--no-cpu-baseline', action='store_true')

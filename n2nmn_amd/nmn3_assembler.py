@@ -30,16 +30,18 @@ _ASM_ERRORS = {
 }
 
 
-def build_validity_mats(module_names: Sequence[str]):
+def build_validity_mats(module_names: Sequence[str], input_num=None, output_type=None):
     """P [V,3], W [3,V,4], b [V,4] of the decoding automaton: token s is allowed in state
     x = (#att, #ans, T_remain) iff all_c(x . W[:,s,c] >= b[s,c]); emitting s adds P[s] to x
     (semantics of models_clevr/nmn3_assembler.py:50-119, vectorised)."""
+    input_num = MODULE_INPUT_NUM if input_num is None else input_num
+    output_type = MODULE_OUTPUT_TYPE if output_type is None else output_type
     names = list(module_names)
     V = len(names)
     is_eos = np.array([s == '<eos>' for s in names])
-    arity = np.array([0 if e else MODULE_INPUT_NUM[s] for s, e in zip(names, is_eos)])
-    att_o = np.array([0 if e else int(MODULE_OUTPUT_TYPE[s] == 'att') for s, e in zip(names, is_eos)])
-    ans_o = np.array([0 if e else int(MODULE_OUTPUT_TYPE[s] == 'ans') for s, e in zip(names, is_eos)])
+    arity = np.array([0 if e else input_num[s] for s, e in zip(names, is_eos)])
+    att_o = np.array([0 if e else int(output_type[s] == 'att') for s, e in zip(names, is_eos)])
+    ans_o = np.array([0 if e else int(output_type[s] == 'ans') for s, e in zip(names, is_eos)])
     absorb = arity - att_o
     mana = int((absorb * (ans_o == 0)).max())      # most attentions a non-answer module absorbs
     maa = int((absorb * (ans_o != 0)).max())       # ... an answer module absorbs
@@ -135,10 +137,14 @@ class ExprList(list):
 
 
 class Assembler:
-    def __init__(self, module_vocab_file, op_code=None):
+    def __init__(self, module_vocab_file, op_code=None, input_num=None, output_type=None):
         """op_code: module name -> C-ABI operator code; default = the models_clevr vocabulary
-        (a token is its op code).  models_vqa passes its own map (n2nmn_amd/vqa.py)."""
+        (a token is its op code).  models_vqa / models_shapes pass their own maps (and, for
+        modules models_clevr does not have, their arity / output-type tables)."""
         op_code = OP_CODE if op_code is None else op_code
+        self._op_code = op_code
+        self._input_num = MODULE_INPUT_NUM if input_num is None else input_num
+        self._output_type = MODULE_OUTPUT_TYPE if output_type is None else output_type
         if isinstance(module_vocab_file, (list, tuple)):
             self.module_names = list(module_vocab_file)
         else:
@@ -147,7 +153,8 @@ class Assembler:
         self.EOS_idx = self.module_names.index('<eos>')
         self.name2idx_dict = {name: i for i, name in enumerate(self.module_names)}
         self.num_vocab_nmn = len(self.module_names)
-        self.P, self.W, self.b = build_validity_mats(self.module_names)
+        self.P, self.W, self.b = build_validity_mats(self.module_names, self._input_num,
+                                                     self._output_type)
         # op code of each token for the C-ABI (-1 = <eos>); KeyError on modules we do not know
         self._token_op = np.array(
             [-1 if s == '<eos>' else op_code[s] for s in self.module_names], np.int32)
@@ -187,7 +194,7 @@ class Assembler:
         roots = {}
         for i, nd in enumerate(nodes):      # topological order: inputs precede consumers
             name = self._op_name[int(nd['op'])]
-            e = {'module': name, 'output_type': MODULE_OUTPUT_TYPE[name],
+            e = {'module': name, 'output_type': self._output_type[name],
                  'time_idx': int(nd['time_idx']), 'batch_idx': int(nd['batch_idx'])}
             if nd['in0'] >= 0:
                 e['input_0'] = built[int(nd['in0'])]
@@ -202,7 +209,7 @@ class Assembler:
                 expr_list.append(roots[n])
             else:
                 kind, op, remains = packed.status(n)
-                names = {v: k for k, v in OP_CODE.items()}
+                names = self._op_name
                 expr_list.append({'module': INVALID_EXPR,
                                   'expr_str': self._layout_tokens2str(toks[:, n]),
                                   'error': _ASM_ERRORS[kind](names, op, remains)})
@@ -221,9 +228,9 @@ class Assembler:
             ins = [walk(e[k], -1) for k in ('input_0', 'input_1') if k in e]
             ins += [-1] * (2 - len(ins))
             name = e['module']
-            if len([k for k in ('input_0', 'input_1') if k in e]) != MODULE_INPUT_NUM[name]:
+            if len([k for k in ('input_0', 'input_1') if k in e]) != self._input_num[name]:
                 raise ValueError('wrong number of inputs for ' + name)
-            rows.append((OP_CODE[name], int(e['time_idx']), int(e['batch_idx']), ins[0], ins[1],
+            rows.append((self._op_code[name], int(e['time_idx']), int(e['batch_idx']), ins[0], ins[1],
                          out_row))
             return len(rows) - 1
 
