@@ -151,6 +151,7 @@ static size_t carve_weights(n2nmn_ctx* c, char* base) {
   for (int i = 0; i < 4; ++i) c->watt_pad[i] = k.take<float>(D * Mp);
   for (int i = 0; i < 3; ++i) c->we_pad[i] = k.take<float>(Mp);
   for (int i = 0; i < 4; ++i) c->batt_pad[i] = k.take<float>(Mp);
+  c->packs.dev = k.take<PackJob>(kMaxPackJobs);
   c->P = k.take<int32_t>(V * 3);
   c->Wv = k.take<int32_t>(3 * V * 4);
   c->bv = k.take<int32_t>(V * 4);
@@ -818,22 +819,57 @@ int n2nmn_commit_weights(n2nmn_ctx* c, n2nmn_stream stream) {
   const n2nmn_dims& d = c->d;
   const int L = d.lstm_dim, E = d.embed_dim_txt, M = d.map_dim, V = d.num_vocab_nmn, Mp = c->Mp;
   auto m = [&](int id) { return c->vars[id].mirror; };
-  // layer-0 input projections (rows [0,E) of the LSTM weights) -> PK, then the tables
-  launch_pack_pk(m(V_ENC_W0), 4 * L, E, 4 * L, c->enc_W0x_p, c->KpE, 4 * L, s);
-  launch_pack_pk(m(V_DEC_W0), 4 * L, E, 4 * L, c->dec_W0x_p, c->KpE, 4 * L, s);
-  // recurrent parts -> gate-interleaved column tiles
-  launch_pack_tiles(m(V_ENC_W0), 4 * L, E, L, L / 4, L, c->enc_W0h_t, s);
-  launch_pack_tiles(m(V_ENC_W1), 4 * L, 0, 2 * L, L / 4, L, c->enc_W1_t, s);
-  launch_pack_tiles(m(V_DEC_W0), 4 * L, E, L, L / 4, L, c->dec_W0h_t, s);
-  launch_pack_tiles(m(V_DEC_W1), 4 * L, 0, 2 * L, L / 4, L, c->dec_W1_t, s);
-  launch_pack_pk(m(V_EHT_W), L, L, L, c->eht_W_p, c->KpL, L, s);
-  launch_pack_tiles(m(V_ATT_W), L, 0, L, L / 16, 0, c->att_W_t, s);
-  launch_pack_pk(m(V_FIND_IMG_W), M, d.D, M, c->find_img_p, c->KpD, Mp, s);
-  launch_pack_pk(m(V_FSP_IMG_W), M, d.D, M, c->fsp_img_p, c->KpD, Mp, s);
-  N2_HIP(hipMemcpyAsync(c->dec_emb_cat, m(V_DEC_EMB), sizeof(float) * (size_t)V * E,
-                        hipMemcpyDeviceToDevice, s));
-  N2_HIP(hipMemcpyAsync(c->dec_emb_cat + (size_t)V * E, m(V_DEC_GO), sizeof(float) * E,
-                        hipMemcpyDeviceToDevice, s));
+  // every operand re-pack of the commit is one job of ONE launch (the job table is built and
+  // uploaded on the first commit; pointers and shapes never change afterwards)
+  if (!c->packs.uploaded) {
+    PackBatch& pb = c->packs;
+    auto has = [&](int id) { return c->vars[id].present; };
+    // layer-0 input projections (rows [0,E) of the LSTM weights) -> PK, then the tables
+    pb.pk(m(V_ENC_W0), 4 * L, E, 4 * L, c->enc_W0x_p, c->KpE, 4 * L);
+    pb.pk(m(V_DEC_W0), 4 * L, E, 4 * L, c->dec_W0x_p, c->KpE, 4 * L);
+    // recurrent parts -> gate-interleaved column tiles
+    pb.tiles(m(V_ENC_W0), 4 * L, E, L, L / 4, L, c->enc_W0h_t);
+    pb.tiles(m(V_ENC_W1), 4 * L, 0, 2 * L, L / 4, L, c->enc_W1_t);
+    pb.tiles(m(V_DEC_W0), 4 * L, E, L, L / 4, L, c->dec_W0h_t);
+    pb.tiles(m(V_DEC_W1), 4 * L, 0, 2 * L, L / 4, L, c->dec_W1_t);
+    pb.pk(m(V_EHT_W), L, L, L, c->eht_W_p, c->KpL, L);
+    pb.tiles(m(V_ATT_W), L, 0, L, L / 16, 0, c->att_W_t);
+    pb.pk(m(V_FIND_IMG_W), M, d.D, M, c->find_img_p, c->KpD, Mp);
+    pb.pk(m(V_FSP_IMG_W), M, d.D, M, c->fsp_img_p, c->KpD, Mp);
+    pb.pad(m(V_DEC_EMB), V, E, c->dec_emb_cat, E);
+    pb.pad(m(V_DEC_GO), 1, E, c->dec_emb_cat + (size_t)V * E, E);
+    // zero-padded copies of the [M] vectors / [.., M] matrices read with float4 lanes
+    const int wes[3] = {V_FIND_E_W, V_FSP_E_W, V_TR_E_W};
+    for (int i = 0; i < 3; ++i)
+      if (has(wes[i])) pb.pad(m(wes[i]), 1, M, c->we_pad[i], Mp);
+    const int txs[5] = {V_FIND_TXT_W, V_FSP_TXT_W, V_TR_TXT_W, V_SP_TXT_W, V_DE_TXT_W};
+    for (int i = 0; i < 5; ++i) {
+      if (!has(txs[i])) continue;
+      pb.pad(m(txs[i]), E, M, c->wtxt_pad[i], Mp);
+      pb.pad(m(txs[i] + 1), 1, M, c->btxt_pad[i], Mp);
+    }
+    const int ats[4] = {V_FSP_ATT_W, V_SP_ATT0_W, V_SP_ATT1_W, V_DE_ATT_W};
+    for (int i = 0; i < 4; ++i)
+      if (has(ats[i])) pb.pad(m(ats[i]), d.D, M, c->watt_pad[i], Mp);
+    const int bas[4] = {V_FSP_ATT_B, V_SP_ATT0_B, V_SP_ATT1_B, V_DE_ATT_B};
+    for (int i = 0; i < 4; ++i)
+      if (has(bas[i])) pb.pad(m(bas[i]), 1, M, c->batt_pad[i], Mp);
+    if (c->big_heads) {
+      const int Kp = round_up(M, 32), Np = round_up(d.num_choices, 64);
+      pb.pk(m(V_DE_E_W), d.num_choices, M, d.num_choices, c->wans_de_p, Kp, Np);
+      if (c->wans_sp_p) pb.pk(m(V_SP_E_W), d.num_choices, M, d.num_choices, c->wans_sp_p, Kp, Np);
+    }
+    if (c->qpn_W1_p) {
+      pb.pk(m(V_QPN_W1), d.qpn_hidden, 2 * L, d.qpn_hidden, c->qpn_W1_p, round_up(2 * L, 32),
+            round_up(d.qpn_hidden, 64));
+      pb.pk(m(V_QPN_W2), d.num_choices, d.qpn_hidden, d.num_choices, c->qpn_W2_p,
+            round_up(d.qpn_hidden, 32), round_up(d.num_choices, 64));
+    }
+    N2_REQUIRE((int)pb.jobs.size() <= kMaxPackJobs, N2NMN_ECAPACITY, "commit_weights: pack job table");
+    N2_HIP(hipMemcpy(pb.dev, pb.jobs.data(), sizeof(PackJob) * pb.jobs.size(), hipMemcpyHostToDevice));
+    pb.uploaded = true;
+  }
+  launch_pack_jobs(c->packs.dev, (int)c->packs.jobs.size(), c->packs.blocks, s);
   // xtab[v] = emb[v] . W_x + b : the whole input half of the layer-0 gate pre-activations
   GemmArgs g{};
   g.A = m(V_ENC_EMB); g.lda = E; g.M = d.num_vocab_txt; g.K = E; g.group_size = 1;
@@ -842,40 +878,6 @@ int n2nmn_commit_weights(n2nmn_ctx* c, n2nmn_stream stream) {
   launch_gemm_pk(g, s);
   g.A = c->dec_emb_cat; g.M = V + 1; g.Bp = c->dec_W0x_p; g.bias = m(V_DEC_B0); g.C = c->dec_xtab;
   launch_gemm_pk(g, s);
-  // zero-padded copies of the [M] vectors read with float4 lanes
-  auto has = [&](int id) { return c->vars[id].present; };   // absent in this model variant: skip
-  const int wes[3] = {V_FIND_E_W, V_FSP_E_W, V_TR_E_W};
-  for (int i = 0; i < 3; ++i) {
-    if (!has(wes[i])) continue;
-    N2_HIP(hipMemsetAsync(c->we_pad[i], 0, sizeof(float) * Mp, s));
-    N2_HIP(hipMemcpyAsync(c->we_pad[i], m(wes[i]), sizeof(float) * M, hipMemcpyDeviceToDevice, s));
-  }
-  const int txs[5] = {V_FIND_TXT_W, V_FSP_TXT_W, V_TR_TXT_W, V_SP_TXT_W, V_DE_TXT_W};
-  for (int i = 0; i < 5; ++i) {
-    if (!has(txs[i])) continue;
-    launch_pad_rows(m(txs[i]), E, M, c->wtxt_pad[i], Mp, s);
-    launch_pad_rows(m(txs[i] + 1), 1, M, c->btxt_pad[i], Mp, s);
-  }
-  const int ats[4] = {V_FSP_ATT_W, V_SP_ATT0_W, V_SP_ATT1_W, V_DE_ATT_W};
-  for (int i = 0; i < 4; ++i)
-    if (has(ats[i])) launch_pad_rows(m(ats[i]), d.D, M, c->watt_pad[i], Mp, s);
-  const int bas[4] = {V_FSP_ATT_B, V_SP_ATT0_B, V_SP_ATT1_B, V_DE_ATT_B};
-  for (int i = 0; i < 4; ++i) {
-    if (!has(bas[i])) continue;
-    N2_HIP(hipMemsetAsync(c->batt_pad[i], 0, sizeof(float) * Mp, s));
-    N2_HIP(hipMemcpyAsync(c->batt_pad[i], m(bas[i]), sizeof(float) * M, hipMemcpyDeviceToDevice, s));
-  }
-  if (c->big_heads) {
-    const int Kp = round_up(M, 32), Np = round_up(d.num_choices, 64);
-    launch_pack_pk(m(V_DE_E_W), d.num_choices, M, d.num_choices, c->wans_de_p, Kp, Np, s);
-    if (c->wans_sp_p) launch_pack_pk(m(V_SP_E_W), d.num_choices, M, d.num_choices, c->wans_sp_p, Kp, Np, s);
-  }
-  if (c->qpn_W1_p) {
-    launch_pack_pk(m(V_QPN_W1), d.qpn_hidden, 2 * L, d.qpn_hidden, c->qpn_W1_p, round_up(2 * L, 32),
-                   round_up(d.qpn_hidden, 64), s);
-    launch_pack_pk(m(V_QPN_W2), d.num_choices, d.qpn_hidden, d.num_choices, c->qpn_W2_p,
-                   round_up(d.qpn_hidden, 32), round_up(d.num_choices, 64), s);
-  }
   c->committed = true;
   c->commit_epoch++;
   c->enc_T = 0;

@@ -35,6 +35,7 @@ struct TrainState {
   float *enc_Wt1 = nullptr, *enc_Wt0 = nullptr, *dec_Wt1 = nullptr, *dec_Wt0 = nullptr;
   float *eht_WT_p = nullptr, *att_WT_p = nullptr, *enc_W0xT_p = nullptr, *dec_W0xT_p = nullptr;
   uint64_t pack_epoch = 0;
+  PackBatch packs;                    // the transposed packs as one launch
   // per-program tables (text slot -> word_vecs row / weight set; pooling slot -> fc_att set)
   int32_t *tslot_row = nullptr, *tslot_ws = nullptr, *pool_sel = nullptr;
   int32_t* tab_host = nullptr;        // pinned staging for the three tables
@@ -128,6 +129,7 @@ size_t carve_train(n2nmn_ctx* c, TrainState* t, char* base) {
   t->var_off_dev = k.take<int64_t>(V_COUNT_);
   t->decay_dev = k.take<int32_t>(V_COUNT_);
   t->segs_dev = k.take<ParamSeg>(t->nsegs);
+  t->packs.dev = k.take<PackJob>(16);
   return align_up(k.off, 256);
 }
 
@@ -142,19 +144,25 @@ int repack_transposed(n2nmn_ctx* c, hipStream_t s) {
   const n2nmn_dims& d = c->d;
   const int L = d.lstm_dim, E = d.embed_dim_txt;
   auto m = [&](int id) { return c->vars[id].mirror; };
-  // layer 1: rec = dz1 . W1[L:2L, :]^T ; layer 0: rec = [dz1 ; dz0] . [W1[0:L, :] ; W0[E:E+L, :]]^T
-  launch_pack_tiles_t(m(V_ENC_W1), 4 * L, L, L, t->enc_Wt1, 4 * L, 0, s);
-  launch_pack_tiles_t(m(V_ENC_W1), 4 * L, 0, L, t->enc_Wt0, 8 * L, 0, s);
-  launch_pack_tiles_t(m(V_ENC_W0), 4 * L, E, L, t->enc_Wt0, 8 * L, 4 * L, s);
-  launch_pack_tiles_t(m(V_DEC_W1), 4 * L, L, L, t->dec_Wt1, 4 * L, 0, s);
-  launch_pack_tiles_t(m(V_DEC_W1), 4 * L, 0, L, t->dec_Wt0, 8 * L, 0, s);
-  launch_pack_tiles_t(m(V_DEC_W0), 4 * L, E, L, t->dec_Wt0, 8 * L, 4 * L, s);
-  launch_pack_pk_t(m(V_EHT_W), L, L, L, t->eht_WT_p, c->KpL, L, s);
-  launch_pack_pk_t(m(V_ATT_W), L, L, L, t->att_WT_p, c->KpL, L, s);
-  const int Ep = round_up(E, 64);
-  // B[k][n] = W0[n][k], k < 4L (gate pre-activations), n < E (embedding dims)
-  launch_pack_pk_t(m(V_ENC_W0), 4 * L, 4 * L, E, t->enc_W0xT_p, t->KpL4, Ep, s);
-  launch_pack_pk_t(m(V_DEC_W0), 4 * L, 4 * L, E, t->dec_W0xT_p, t->KpL4, Ep, s);
+  if (!t->packs.uploaded) {
+    PackBatch& pb = t->packs;
+    // layer 1: rec = dz1 . W1[L:2L, :]^T ; layer 0: rec = [dz1 ; dz0] . [W1[0:L, :] ; W0[E:E+L, :]]^T
+    pb.tiles_t(m(V_ENC_W1), 4 * L, L, L, t->enc_Wt1, 4 * L, 0);
+    pb.tiles_t(m(V_ENC_W1), 4 * L, 0, L, t->enc_Wt0, 8 * L, 0);
+    pb.tiles_t(m(V_ENC_W0), 4 * L, E, L, t->enc_Wt0, 8 * L, 4 * L);
+    pb.tiles_t(m(V_DEC_W1), 4 * L, L, L, t->dec_Wt1, 4 * L, 0);
+    pb.tiles_t(m(V_DEC_W1), 4 * L, 0, L, t->dec_Wt0, 8 * L, 0);
+    pb.tiles_t(m(V_DEC_W0), 4 * L, E, L, t->dec_Wt0, 8 * L, 4 * L);
+    pb.pk_t(m(V_EHT_W), L, L, L, t->eht_WT_p, c->KpL, L);
+    pb.pk_t(m(V_ATT_W), L, L, L, t->att_WT_p, c->KpL, L);
+    const int Ep = round_up(E, 64);
+    // B[k][n] = W0[n][k], k < 4L (gate pre-activations), n < E (embedding dims)
+    pb.pk_t(m(V_ENC_W0), 4 * L, 4 * L, E, t->enc_W0xT_p, t->KpL4, Ep);
+    pb.pk_t(m(V_DEC_W0), 4 * L, 4 * L, E, t->dec_W0xT_p, t->KpL4, Ep);
+    N2_HIP(hipMemcpy(pb.dev, pb.jobs.data(), sizeof(PackJob) * pb.jobs.size(), hipMemcpyHostToDevice));
+    pb.uploaded = true;
+  }
+  launch_pack_jobs(t->packs.dev, (int)t->packs.jobs.size(), t->packs.blocks, s);
   t->pack_epoch = c->commit_epoch;
   return check_launch("train: repack_transposed");
 }

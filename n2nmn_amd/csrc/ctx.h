@@ -40,6 +40,40 @@ struct Var {
   bool present = true;       // false: the variable does not exist in this model variant (numel 0)
 };
 
+// Host-side recorder of the pack jobs of one commit; uploaded once, launched on every commit.
+struct PackBatch {
+  std::vector<PackJob> jobs;
+  PackJob* dev = nullptr;          // device copy (inside the weight store / training workspace)
+  int capacity = 0;
+  int blocks = 0;
+  bool uploaded = false;
+  void add(int kind, const float* src, float* dst, size_t total, int p0 = 0, int p1 = 0, int p2 = 0,
+           int p3 = 0, int p4 = 0) {
+    PackJob j{};
+    j.kind = kind; j.src = src; j.dst = dst; j.total = (uint32_t)total;
+    j.p[0] = p0; j.p[1] = p1; j.p[2] = p2; j.p[3] = p3; j.p[4] = p4;
+    j.block0 = (uint32_t)blocks;
+    blocks += (int)((total + PACK_ELEMS_PER_BLOCK - 1) / PACK_ELEMS_PER_BLOCK);
+    jobs.push_back(j);
+  }
+  void pk(const float* src, int ld, int K, int N, float* dst, int Kp, int Np) {
+    add(PJ_PK, src, dst, (size_t)Kp * Np, ld, K, N, Kp, Np);
+  }
+  void pk_t(const float* src, int ld, int K, int N, float* dst, int Kp, int Np) {
+    add(PJ_PK_T, src, dst, (size_t)Kp * Np, ld, K, N, Kp, Np);
+  }
+  void tiles(const float* W, int ld, int row0, int K, int ntiles, int gate_L, float* dst) {
+    add(PJ_TILES, W, dst, (size_t)ntiles * K * 16, ld, row0, K, gate_L);
+  }
+  void tiles_t(const float* W, int ld, int row0, int L, float* dst, int Ktot, int k_off) {
+    add(PJ_TILES_T, W, dst, (size_t)(L / 16) * L * 64, ld, row0, L, Ktot, k_off);
+  }
+  void pad(const float* src, int R, int M, float* dst, int Mp) {
+    add(PJ_PAD, src, dst, (size_t)R * Mp, R, M, Mp);
+  }
+};
+constexpr int kMaxPackJobs = 96;
+
 // indices into Ctx::vars (order of build_vars)
 enum VarId {
   V_ENC_EMB, V_ENC_W0, V_ENC_B0, V_ENC_W1, V_ENC_B1, V_EHT_W, V_EHT_B,
@@ -105,6 +139,7 @@ struct n2nmn_ctx {
   float *enc_W0h_t = nullptr, *enc_W1_t = nullptr, *dec_W0h_t = nullptr, *dec_W1_t = nullptr;
   float *eht_W_p = nullptr, *att_W_t = nullptr, *find_img_p = nullptr, *fsp_img_p = nullptr;
   float* dec_emb_cat = nullptr;
+  PackBatch packs;                                   // every re-pack of a commit, one launch
   float *qpn_W1_p = nullptr, *qpn_W2_p = nullptr;    // PK packs of question_prior_net fc1 / fc2
   float *wans_sp_p = nullptr, *wans_de_p = nullptr;  // PK packs of fc_eltwise (large num_choices only)
   bool big_heads = false;                            // map_dim * num_choices beyond the fused head
@@ -156,6 +191,8 @@ struct n2nmn_ctx {
 namespace n2nmn {
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+
 
 struct Carver {
   char* base;

@@ -41,6 +41,23 @@ void launch_pad_rows(const float* src, int R, int M, float* dst, int Mp, hipStre
 void launch_pack_tiles(const float* W, int ld, int row0, int K, int ntiles, int gate_L, float* dst,
                        hipStream_t s);
 
+// All operand re-packs of one weight commit in ONE launch: a job table (built once per context,
+// the pointers never change) replaces ~40 tiny pack / pad / copy launches per optimiser step.
+enum PackKind : int32_t { PJ_PK = 0, PJ_PK_T, PJ_TILES, PJ_TILES_T, PJ_PAD };
+struct PackJob {
+  int32_t kind;
+  int32_t p[7];            // PK / PK_T: ld, K, N, Kp, Np    TILES: ld, row0, K, gate_L
+                           // TILES_T: ld, row0, L, Ktot, k_off    PAD: R, M, Mp
+  const float* src;
+  float* dst;
+  uint32_t total;          // elements this job iterates over
+  uint32_t block0;         // first workgroup of this job
+  int32_t pad_[2];
+};
+static_assert(sizeof(PackJob) == 64, "PackJob is uploaded verbatim");
+constexpr int PACK_ELEMS_PER_BLOCK = 4096;
+void launch_pack_jobs(const PackJob* jobs_dev, int njobs, int total_blocks, hipStream_t s);
+
 // ---------------------------------------------------------------------------------------------
 // seq2seq
 // ---------------------------------------------------------------------------------------------

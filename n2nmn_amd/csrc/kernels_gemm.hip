@@ -197,7 +197,75 @@ __global__ void pad_rows_kernel(const float* __restrict__ src, int R, int M,
     dst[i] = c < M ? src[r * M + c] : 0.f;
   }
 }
+// one workgroup = PACK_ELEMS_PER_BLOCK consecutive elements of one job (same index maps as the
+// stand-alone packers above and pack_pk_t / pack_tiles_t in kernels_train.hip)
+__global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restrict__ jobs,
+                                                        int njobs) {
+  __shared__ int sj;
+  if (threadIdx.x == 0) {
+    int j = 0;
+    while (j + 1 < njobs && jobs[j + 1].block0 <= blockIdx.x) ++j;
+    sj = j;
+  }
+  __syncthreads();
+  const PackJob jb = jobs[sj];
+  const size_t base = (size_t)(blockIdx.x - jb.block0) * PACK_ELEMS_PER_BLOCK;
+  for (int e = threadIdx.x; e < PACK_ELEMS_PER_BLOCK; e += 256) {
+    const size_t i = base + e;
+    if (i >= jb.total) break;
+    switch (jb.kind) {
+      case PJ_PK:
+      case PJ_PK_T: {
+        const int ld = jb.p[0], K = jb.p[1], N = jb.p[2], Np = jb.p[4];
+        const int kk = (int)(i & 3);
+        const size_t r = i >> 2;
+        const int n = (int)(r % Np);
+        const int kq = (int)(r / Np) * 4 + kk;
+        float v = 0.f;
+        if (kq < K && n < N)
+          v = jb.kind == PJ_PK ? jb.src[(size_t)kq * ld + n] : jb.src[(size_t)n * ld + kq];
+        jb.dst[i] = v;
+        break;
+      }
+      case PJ_TILES: {
+        const int ld = jb.p[0], row0 = jb.p[1], K = jb.p[2], gate_L = jb.p[3];
+        const int kk = (int)(i & 3);
+        const int c = (int)((i >> 2) & 15);
+        const size_t r = i >> 6;
+        const int k4 = (int)(r % (K / 4));
+        const int j = (int)(r / (K / 4));
+        const int col = gate_L > 0 ? (c >> 2) * gate_L + 4 * j + (c & 3) : 16 * j + c;
+        jb.dst[i] = jb.src[(size_t)(row0 + 4 * k4 + kk) * ld + col];
+        break;
+      }
+      case PJ_TILES_T: {
+        const int ld = jb.p[0], row0 = jb.p[1], L = jb.p[2], Ktot = jb.p[3], k_off = jb.p[4];
+        const int gi = (int)(i & 3);
+        const int c = (int)((i >> 2) & 15);
+        const size_t r = i >> 6;
+        const int u = (int)(r % L);
+        const int j = (int)(r / L);
+        jb.dst[(((size_t)j * (Ktot / 4) + k_off / 4 + u) * 16 + c) * 4 + gi] =
+            jb.src[(size_t)(row0 + 16 * j + c) * ld + (size_t)gi * L + u];
+        break;
+      }
+      default: {   // PJ_PAD
+        const int M = jb.p[1], Mp = jb.p[2];
+        const int c = (int)(i % Mp);
+        const size_t r = i / Mp;
+        jb.dst[i] = c < M ? jb.src[r * M + c] : 0.f;
+        break;
+      }
+    }
+  }
+}
+
 }  // namespace
+
+void launch_pack_jobs(const PackJob* jobs_dev, int njobs, int total_blocks, hipStream_t s) {
+  if (njobs <= 0 || total_blocks <= 0) return;
+  hipLaunchKernelGGL(pack_jobs_kernel, dim3(total_blocks), dim3(256), 0, s, jobs_dev, njobs);
+}
 
 void launch_pad_rows(const float* src, int R, int M, float* dst, int Mp, hipStream_t s) {
   const size_t total = (size_t)R * Mp;
