@@ -48,21 +48,25 @@ def parse():
 
 
 PMC_FILE = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+PMC_FILE_TRAIN = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_train.json')
 PMC_KERNEL = {'lstm_step': 'lstm_step_kernel<4, 0>', 'dec_attn': 'dec_attn_kernel<256>',
               'gemm_pk': 'gemm_pk_kernel', 'att_ops': 'att_ops_kernel', 'pool': 'pool_kernel',
-              'textmap': 'textmap_kernel', 'heads': 'heads_kernel', 'word_vecs': 'word_vecs_kernel'}
+              'textmap': 'textmap_kernel', 'heads': 'heads_kernel', 'word_vecs': 'word_vecs_kernel',
+              'lstm_bwd_step': 'lstm_bwd_step_kernel', 'gemm_tn': 'gemm_tn_kernel',
+              'optimiser': 'adam_kernel'}
 
 
-def pmc_traffic(family):
+def pmc_traffic(family, path=None):
     """HBM bytes per launch of the kernel behind a profiler family, from the committed rocprofv3
     PMC passes (tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE runs of this same bench
     command, gfx950 x2 read correction).  PMC counters cannot be read inside the timed run."""
     try:
-        data = json.load(open(PMC_FILE))['kernels']
+        data = json.load(open(path or PMC_FILE))['kernels']
         for prefix, kname in PMC_KERNEL.items():
             if family.startswith(prefix) and kname in data:
                 return data[kname]['hbm_bytes_per_launch'], \
-                    'profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)'
+                    'profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)' % \
+                    os.path.basename(path or PMC_FILE)
     except Exception:
         pass
     return None, None
@@ -174,7 +178,9 @@ def bench_train(args, dp, local_rank):
         dom = rows[0]
         out['roofline'] = {'kernel': dom['kernel'], 'bound': dom['bound'],
                            'achieved': dom['achieved'], 'peak': dom['peak'], 'unit': dom['unit'],
-                           'frac': dom['frac'], 'traffic': None, 'avg_us': dom['avg_us'],
+                           'frac': dom['frac'], 'traffic': pmc_traffic(dom['kernel'], PMC_FILE_TRAIN)[0],
+                           'traffic_source': pmc_traffic(dom['kernel'], PMC_FILE_TRAIN)[1],
+                           'avg_us': dom['avg_us'],
                            'measured': 'hipEvent pairs around each launch, separate pass of %d '
                                        'steps' % ksteps}
         out['kernels'] = rows
