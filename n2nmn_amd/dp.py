@@ -16,7 +16,10 @@ class DataParallel:
         self.world = int(os.environ.get('WORLD_SIZE', '1'))
         self.device = device
         self._dist = None
-        if self.world > 1:
+        if self.world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ or \
+                os.environ.get('N2NMN_FORCE_PROCESS_GROUP') == '1':
+            # under torch.distributed.run a 1-rank job still builds its (RCCL) group, so the
+            # single-GPU run exercises the same collective calls as the 8-GPU run
             import torch.distributed as dist
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')

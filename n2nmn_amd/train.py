@@ -28,7 +28,7 @@ class GradBuckets:
     """Two-bucket all-reduce of a flat gradient vector (sum over ranks; the optimiser applies the
     1/world scale).  `late` = [split, numel) is ready first (decoder + modules), `early` =
     [0, split) (encoder) last.  Works on any torch.distributed backend (RCCL on GPUs, gloo in
-    the CPU tests); world size 1 is a no-op."""
+    the CPU tests); without a process group it is a no-op."""
 
     def __init__(self, flat, split: int, dist=None):
         self.flat = flat
@@ -41,11 +41,11 @@ class GradBuckets:
         return self.dist.get_world_size() if self.dist is not None else 1
 
     def reduce_late(self):
-        if self.dist is not None and self.world > 1:
+        if self.dist is not None:          # (a 1-rank group still goes through the collective)
             self._pending.append(self.dist.all_reduce(self.flat[self.split:], async_op=True))
 
     def reduce_early(self):
-        if self.dist is not None and self.world > 1:
+        if self.dist is not None:
             self._pending.append(self.dist.all_reduce(self.flat[:self.split], async_op=True))
 
     def wait(self) -> float:
