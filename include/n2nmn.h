@@ -313,6 +313,18 @@ int n2nmn_profile_get(const n2nmn_ctx *ctx, int family, const char **name, int64
 int n2nmn_debug_lstm_bench(n2nmn_ctx *ctx, int variant, int rows_per_wg, int njobs, int N,
                            int iters, double *us, n2nmn_stream stream);
 
+/* C[m][n] += sum_r A[row(r)][m] * B[r][n]  -- the weight-gradient GEMM of the training step, for
+ * unit parity.  a_row_idx (device, may be NULL): source row of r; a_onehot (device, may be NULL):
+ * A[r][m] = (a_onehot[r] == m) and A is ignored; b_sel (device, may be NULL): only rows with
+ * b_sel[r] == b_sel_val contribute.  M % 4 == 0 unless a_onehot; C must be initialised. */
+int n2nmn_debug_gemm_tn(n2nmn_ctx *ctx, const float *A, int lda, int M, const float *B, int ldb,
+                        int N, int R, float *C, int ldc, const int32_t *a_row_idx,
+                        const int32_t *a_onehot, const int32_t *b_sel, int b_sel_val,
+                        n2nmn_stream stream);
+/* dst[c] += sum_r src[r*ld + c] over rows with sel[r] == sel_val (sel may be NULL) */
+int n2nmn_debug_colsum(n2nmn_ctx *ctx, const float *src, int R, int ncols, int ld,
+                       const int32_t *sel, int sel_val, float *dst, n2nmn_stream stream);
+
 /* C[M,N] = A[M,K] . B[K,N] + bias[N]   (row-major fp32; B is packed internally) */
 int n2nmn_debug_gemm(n2nmn_ctx *ctx, const float *A, const float *B, const float *bias,
                      float *C, int M, int N, int K, n2nmn_stream stream);

@@ -685,6 +685,28 @@ int n2nmn_train_reset_optimizer(n2nmn_ctx* c, n2nmn_stream stream) {
   return N2NMN_OK;
 }
 
+int n2nmn_debug_gemm_tn(n2nmn_ctx* ctx, const float* A, int lda, int M, const float* B, int ldb,
+                        int N, int R, float* C, int ldc, const int32_t* a_row_idx,
+                        const int32_t* a_onehot, const int32_t* b_sel, int b_sel_val,
+                        n2nmn_stream stream) {
+  N2_REQUIRE(ctx && B && C && (A || a_onehot), N2NMN_EINVAL, "debug_gemm_tn: null argument");
+  N2_REQUIRE(M > 0 && N > 0 && R >= 0 && (a_onehot || (M % 4 == 0 && lda % 4 == 0)) && ldb % 4 == 0,
+             N2NMN_EINVAL, "debug_gemm_tn: M, lda, ldb must be multiples of 4");
+  GemmTnArgs g{};
+  g.A = A; g.lda = lda; g.M = M; g.a_group_idx = a_row_idx; g.a_group_size = 1; g.a_onehot = a_onehot;
+  g.B = B; g.ldb = ldb; g.N = N; g.b_sel = b_sel; g.b_sel_val = b_sel_val; g.R = R; g.C = C; g.ldc = ldc;
+  launch_gemm_tn(g, S(stream));
+  return check_launch("debug_gemm_tn");
+}
+
+int n2nmn_debug_colsum(n2nmn_ctx* ctx, const float* src, int R, int ncols, int ld,
+                       const int32_t* sel, int sel_val, float* dst, n2nmn_stream stream) {
+  N2_REQUIRE(ctx && src && dst && R >= 0 && ncols > 0 && ld >= ncols, N2NMN_EINVAL,
+             "debug_colsum: bad argument");
+  launch_colsum(src, R, ncols, ld, sel, sel_val, dst, S(stream));
+  return check_launch("debug_colsum");
+}
+
 int64_t n2nmn_train_debug_tensor(n2nmn_ctx* c, const char* name, float* out, int64_t capacity,
                                  n2nmn_stream stream) {
   N2_REQUIRE(c && c->train && name && out, N2NMN_EINVAL, "train_debug_tensor: bad argument");
