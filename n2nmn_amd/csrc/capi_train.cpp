@@ -7,6 +7,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <functional>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -51,6 +53,29 @@ struct TrainState {
   int64_t total = 0, split = 0;
   int KpL4 = 0;                       // round_up(4L, 32)
   int last_N = 0, last_T = 0, last_Td = 0;   // shape of the forward currently held
+  // Weight-gradient GEMMs are leaves of the backward graph: they run on a low-priority side
+  // stream while the latency-bound chains (BPTT, attention backward) continue on the caller's.
+  hipStream_t side = nullptr;
+  static constexpr int kForkEvents = 16;
+  hipEvent_t ev_fork[kForkEvents] = {};
+  hipEvent_t ev_join = nullptr;
+  int fork_i = 0;
+  bool overlap = true;
+  // side stream runs everything enqueued on `main` so far before its next kernel
+  hipStream_t fork(hipStream_t main) {
+    if (!overlap || !side) return main;
+    hipEvent_t e = ev_fork[fork_i];
+    fork_i = (fork_i + 1) % kForkEvents;
+    (void)hipEventRecord(e, main);
+    (void)hipStreamWaitEvent(side, e, 0);
+    return side;
+  }
+  // `main` waits for everything enqueued on the side stream so far
+  void join(hipStream_t main) {
+    if (!overlap || !side) return;
+    (void)hipEventRecord(ev_join, side);
+    (void)hipStreamWaitEvent(main, ev_join, 0);
+  }
 };
 
 void train_state_destroy(TrainState* t) {
@@ -58,6 +83,9 @@ void train_state_destroy(TrainState* t) {
   if (t->base) (void)hipFree(t->base);
   if (t->tab_host) (void)hipHostFree(t->tab_host);
   if (t->tab_ev) (void)hipEventDestroy(t->tab_ev);
+  for (hipEvent_t e : t->ev_fork) if (e) (void)hipEventDestroy(e);
+  if (t->ev_join) (void)hipEventDestroy(t->ev_join);
+  if (t->side) (void)hipStreamDestroy(t->side);
   delete t;
 }
 
@@ -213,6 +241,8 @@ struct BpttArgs {
   const float *c0s, *c1s;       // [(T+1)][N][L]
   const float* dout;            // [T][N][L] gradient arriving at the top layer's outputs
   const float *Wt0, *Wt1;
+  // called after launch k: layer 1 has finished steps >= T-1-k, layer 0 steps >= T-k
+  const std::function<void(int)>* after_launch = nullptr;
 };
 
 int run_bptt(n2nmn_ctx* c, const BpttArgs& a, hipStream_t s) {
@@ -249,8 +279,11 @@ int run_bptt(n2nmn_ctx* c, const BpttArgs& a, hipStream_t s) {
     const double fl = 2.0 * N * L * ((j1.active && j1.gemm ? 4.0 * L : 0) + (j0.active ? 8.0 * L : 0));
     const double by = 4.0 * ((j1.active && j1.gemm ? 4.0 * L * L + 4.0 * N * L : 0) +
                              (j0.active ? 8.0 * L * L + 8.0 * N * L : 0) + 20.0 * N * L);
-    ProfScope ps(c, F_LSTM_BWD, fl, by, s);
-    launch_lstm_bwd_step(jobs, 2, N, L, s);
+    {
+      ProfScope ps(c, F_LSTM_BWD, fl, by, s);
+      launch_lstm_bwd_step(jobs, 2, N, L, s);
+    }
+    if (a.after_launch) (*a.after_launch)(k);
   }
   return check_launch("train: bptt");
 }
@@ -317,6 +350,16 @@ int n2nmn_train_enable(n2nmn_ctx* c) {
   const size_t tabn = 2 * (size_t)c->max_text + 2 * (size_t)c->max_pool;
   N2_HIP(hipHostMalloc(reinterpret_cast<void**>(&t->tab_host), sizeof(int32_t) * tabn, 0));
   N2_HIP(hipEventCreateWithFlags(&t->tab_ev, hipEventDisableTiming));
+  {
+    int lo = 0, hi = 0;
+    N2_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));      // lo = lowest priority (largest number)
+    N2_HIP(hipStreamCreateWithPriority(&t->side, hipStreamNonBlocking, lo));
+    for (int i = 0; i < TrainState::kForkEvents; ++i)
+      N2_HIP(hipEventCreateWithFlags(&t->ev_fork[i], hipEventDisableTiming));
+    N2_HIP(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
+    const char* env = getenv("N2NMN_TRAIN_OVERLAP");
+    t->overlap = !(env && env[0] == '0');
+  }
   return N2NMN_OK;
 }
 
@@ -488,6 +531,7 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
       const int answ[7] = {V_EXIST_W, V_COUNT_W, V_EQ_W, V_MORE_W, V_LESS_W, V_SP_E_W, V_DE_E_W};
       for (int i = 0; i < 7; ++i) { g.gWans[i] = G(answ[i]); g.gbans[i] = G(answ[i] + 1); }
       bool att_done = false;
+      hipStream_t sd = nullptr;        // side stream, forked once every level launch is enqueued
       for (int li = (int)p.launches.size() - 1; li >= 0; --li) {
         const Launch& l = p.launches[li];
         switch (l.kind) {
@@ -510,39 +554,37 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
             break;
           }
           case LK_CONV_FIND:
-          case LK_CONV_FSP: {
-            const bool fsp = l.kind == LK_CONV_FSP;
+          case LK_CONV_FSP:
+          case LK_TEXTMAP: {
+            // every level launch is enqueued: dM / dpfc / dtmap are final.  The weight-gradient
+            // GEMMs below only read them -> side stream; the chain textmap_bwd -> word_vecs_bwd ->
+            // attention backward continues on the caller's stream.
+            if (!sd) sd = t->fork(s);
             if (!att_done) {            // fc_att weight gradients from the kept pooled features
               att_done = true;
               const int attw[4] = {V_FSP_ATT_W, V_SP_ATT0_W, V_SP_ATT1_W, V_DE_ATT_W};
               for (int i = 0; i < 4; ++i)
-                gemm_tn(c, s, t->rec.pooled, D, D, t->dpfc, Mp, M, 2 * p.num_pool, G(attw[i]), M,
+                gemm_tn(c, sd, t->rec.pooled, D, D, t->dpfc, Mp, M, 2 * p.num_pool, G(attw[i]), M,
                         nullptr, 1, t->pool_sel, i);
             }
-            gemm_tn(c, s, io->image_feat, D, D, fsp ? t->dmfsp : t->dmfind, Mp, M, l.count * HW,
-                    G(fsp ? V_FSP_IMG_W : V_FIND_IMG_W), M, c->dev_tab + l.offset, HW);
-            colsum(c, s, fsp ? t->dmfsp : t->dmfind, l.count * HW, M, Mp,
-                   G(fsp ? V_FSP_IMG_B : V_FIND_IMG_B));
-            break;
-          }
-          case LK_TEXTMAP: {
-            if (!att_done) {
-              att_done = true;
-              const int attw[4] = {V_FSP_ATT_W, V_SP_ATT0_W, V_SP_ATT1_W, V_DE_ATT_W};
-              for (int i = 0; i < 4; ++i)
-                gemm_tn(c, s, t->rec.pooled, D, D, t->dpfc, Mp, M, 2 * p.num_pool, G(attw[i]), M,
-                        nullptr, 1, t->pool_sel, i);
-            }
-            {
-              ProfScope ps(c, F_BWD_MISC, 2.0 * p.num_text * E * M,
-                           4.0 * (l.count * (double)E * Mp + p.num_text * (double)(E + Mp)), s);
-              launch_textmap_bwd(w, b, g, l.offset, l.count, s);
-            }
-            const int txw[5] = {V_FIND_TXT_W, V_FSP_TXT_W, V_TR_TXT_W, V_SP_TXT_W, V_DE_TXT_W};
-            for (int i = 0; i < 5; ++i) {
-              gemm_tn(c, s, c->word_vecs, E, E, t->dtmap, Mp, M, p.num_text, G(txw[i]), M,
-                      t->tslot_row, 1, t->tslot_ws, i);
-              colsum(c, s, t->dtmap, p.num_text, M, Mp, G(txw[i] + 1), t->tslot_ws, i);
+            if (l.kind == LK_TEXTMAP) {
+              {
+                ProfScope ps(c, F_BWD_MISC, 2.0 * p.num_text * E * M,
+                             4.0 * (l.count * (double)E * Mp + p.num_text * (double)(E + Mp)), s);
+                launch_textmap_bwd(w, b, g, l.offset, l.count, s);
+              }
+              const int txw[5] = {V_FIND_TXT_W, V_FSP_TXT_W, V_TR_TXT_W, V_SP_TXT_W, V_DE_TXT_W};
+              for (int i = 0; i < 5; ++i) {
+                gemm_tn(c, sd, c->word_vecs, E, E, t->dtmap, Mp, M, p.num_text, G(txw[i]), M,
+                        t->tslot_row, 1, t->tslot_ws, i);
+                colsum(c, sd, t->dtmap, p.num_text, M, Mp, G(txw[i] + 1), t->tslot_ws, i);
+              }
+            } else {
+              const bool fsp = l.kind == LK_CONV_FSP;
+              gemm_tn(c, sd, io->image_feat, D, D, fsp ? t->dmfsp : t->dmfind, Mp, M, l.count * HW,
+                      G(fsp ? V_FSP_IMG_W : V_FIND_IMG_W), M, c->dev_tab + l.offset, HW);
+              colsum(c, sd, fsp ? t->dmfsp : t->dmfind, l.count * HW, M, Mp,
+                     G(fsp ? V_FSP_IMG_B : V_FIND_IMG_B));
             }
             break;
           }
@@ -574,12 +616,15 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
       launch_dec_bwd_b(a, s);
     }
     const int RT = Td * N;
-    gemm_tn(c, s, c->dec_h1_all, L, L, t->dsc, 16, V, RT, G(V_TOK_W), V);
-    gemm_tn(c, s, t->rec.ctx, L, L, t->dsc, 16, V, RT, G(V_TOK_W) + (size_t)L * V, V);
-    colsum(c, s, t->dsc, RT, V, 16, G(V_TOK_B));
-    colsum(c, s, t->dvp, RT, L, L, G(V_ATT_V));
-    gemm_tn(c, s, c->dec_h1_all, L, L, t->dq, L, L, RT, G(V_ATT_W), L);
-    colsum(c, s, t->dq, RT, L, L, G(V_ATT_B));
+    {
+      hipStream_t sd = t->fork(s);     // token / attention projection gradients: leaves
+      gemm_tn(c, sd, c->dec_h1_all, L, L, t->dsc, 16, V, RT, G(V_TOK_W), V);
+      gemm_tn(c, sd, t->rec.ctx, L, L, t->dsc, 16, V, RT, G(V_TOK_W) + (size_t)L * V, V);
+      colsum(c, sd, t->dsc, RT, V, 16, G(V_TOK_B));
+      colsum(c, sd, t->dvp, RT, L, L, G(V_ATT_V));
+      gemm_tn(c, sd, c->dec_h1_all, L, L, t->dq, L, L, RT, G(V_ATT_W), L);
+      colsum(c, sd, t->dq, RT, L, L, G(V_ATT_B));
+    }
     gemm_nt(c, s, t->dq, L, RT, L, t->att_WT_p, L, c->KpL, L, t->dout, L, true);
     // BPTT through the decoder LSTM stack; its initial state is the encoder's final state
     N2_HIP(hipMemsetAsync(t->dH0, 0, sizeof(float) * 4 * (size_t)d.N * L, s));   // dH0,dH1,dC0,dC1
@@ -608,6 +653,7 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
     gemm_tn(c, s, t->rec.dh0s + (size_t)N * L, L, L, t->dz1_all, 4 * L, 4 * L, RT, G(V_DEC_W1), 4 * L);
     gemm_tn(c, s, t->rec.dh1s, L, L, t->dz1_all, 4 * L, 4 * L, RT, G(V_DEC_W1) + (size_t)L * 4 * L, 4 * L);
     colsum(c, s, t->dz1_all, RT, 4 * L, 4 * L, G(V_DEC_B1));
+    t->join(s);                        // decoder + module gradients complete from here on
     {
       ProfScope ps(c, F_OPTIMISER, 3.0 * (t->total - t->split), 4.0 * 3 * (t->total - t->split), s);
       launch_grad_finish(io->grads, (const float* const*)t->mirrors_dev, t->var_off_dev, t->decay_dev,
@@ -619,31 +665,59 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
 
   // ------------------------------- phase 1: encoder -----------------------------------------
   const int RT = T * N;
+  N2_HIP(hipMemsetAsync(t->dxtab_enc, 0, sizeof(float) * (size_t)Vt * 4 * L, s));
+  {
+    hipStream_t sd = t->fork(s);
+    gemm_tn(c, sd, c->enc_out, L, L, t->deht, L, L, RT, G(V_EHT_W), L);
+    colsum(c, sd, t->deht, RT, L, L, G(V_EHT_B));
+  }
   // d encoder_outputs = (through the context vectors, already in denc_out) + deht . W_eht^T
   gemm_nt(c, s, t->deht, L, RT, L, t->eht_WT_p, L, c->KpL, L, t->denc_out, L, true);
-  gemm_tn(c, s, c->enc_out, L, L, t->deht, L, L, RT, G(V_EHT_W), L);
-  colsum(c, s, t->deht, RT, L, L, G(V_EHT_B));
+  // The weight gradients are sums over time: as soon as the recurrence has left a block of steps
+  // behind, their share of dW (and of the one-hot x-table gradient) runs on the side stream while
+  // the BPTT chain continues.
+  const int nchunk = T >= 24 ? 3 : 1;
+  int done_from = T;                   // steps [done_from, T) already handed to the side stream
+  auto grads_of_steps = [&](int t0, int t1) {          // steps [t0, t1)
+    if (t1 <= t0) return;
+    hipStream_t sd = t->fork(s);
+    const int R = (t1 - t0) * N;
+    const size_t ro = (size_t)t0 * N;                   // first row of the block
+    const float* dz0 = t->dz0_all + ro * 4 * L;
+    const float* dz1 = t->dz1_all + ro * 4 * L;
+    {
+      GemmTnArgs g1{};
+      g1.A = nullptr; g1.lda = 0; g1.M = Vt; g1.a_onehot = io->input_seq + ro;
+      g1.B = dz0; g1.ldb = 4 * L; g1.N = 4 * L; g1.R = R; g1.C = t->dxtab_enc; g1.ldc = 4 * L;
+      ProfScope ps(c, F_GEMM_TN, 2.0 * Vt * 4.0 * L * R, 4.0 * ((double)R * 4 * L + Vt * 4.0 * L), sd);
+      launch_gemm_tn(g1, sd);
+    }
+    gemm_tn(c, sd, t->rec.eh0s + ro * L, L, L, dz0, 4 * L, 4 * L, R, G(V_ENC_W0) + (size_t)E * 4 * L, 4 * L);
+    gemm_tn(c, sd, t->rec.eh0s + (ro + N) * L, L, L, dz1, 4 * L, 4 * L, R, G(V_ENC_W1), 4 * L);
+    gemm_tn(c, sd, t->rec.eh1s + ro * L, L, L, dz1, 4 * L, 4 * L, R, G(V_ENC_W1) + (size_t)L * 4 * L, 4 * L);
+    colsum(c, sd, dz1, R, 4 * L, 4 * L, G(V_ENC_B1));
+  };
+  const std::function<void(int)> after = [&](int k) {
+    // after launch k layer 0 (the later one) has finished steps >= T - k
+    const int ready = T - k;
+    const int step = (T + nchunk - 1) / nchunk;
+    if (ready > 0 && done_from - ready >= step) {
+      grads_of_steps(ready, done_from);
+      done_from = ready;
+    }
+  };
   BpttArgs ba{};
   ba.T = T; ba.N = N; ba.want_init_grad = false; ba.seq_len = io->seq_length;
   ba.g0 = t->rec.eg0; ba.g1 = t->rec.eg1; ba.c0s = t->rec.ec0s; ba.c1s = t->rec.ec1s;
   ba.dout = t->denc_out; ba.Wt0 = t->enc_Wt0; ba.Wt1 = t->enc_Wt1;
+  ba.after_launch = t->overlap ? &after : nullptr;
   rc = run_bptt(c, ba, s);
   if (rc != N2NMN_OK) return rc;
-  N2_HIP(hipMemsetAsync(t->dxtab_enc, 0, sizeof(float) * (size_t)Vt * 4 * L, s));
-  {
-    GemmTnArgs g1{};
-    g1.A = nullptr; g1.lda = 0; g1.M = Vt; g1.a_onehot = io->input_seq;
-    g1.B = t->dz0_all; g1.ldb = 4 * L; g1.N = 4 * L; g1.R = RT; g1.C = t->dxtab_enc; g1.ldc = 4 * L;
-    ProfScope ps(c, F_GEMM_TN, 2.0 * Vt * 4.0 * L * RT, 4.0 * ((double)RT * 4 * L + Vt * 4.0 * L), s);
-    launch_gemm_tn(g1, s);
-  }
+  grads_of_steps(0, done_from);        // the remaining (earliest) steps
+  t->join(s);
   gemm_tn(c, s, mir(V_ENC_EMB), E, E, t->dxtab_enc, 4 * L, 4 * L, Vt, G(V_ENC_W0), 4 * L);
   colsum(c, s, t->dxtab_enc, Vt, 4 * L, 4 * L, G(V_ENC_B0));
   gemm_nt(c, s, t->dxtab_enc, 4 * L, Vt, 4 * L, t->enc_W0xT_p, Ep, t->KpL4, E, G(V_ENC_EMB), E, true);
-  gemm_tn(c, s, t->rec.eh0s, L, L, t->dz0_all, 4 * L, 4 * L, RT, G(V_ENC_W0) + (size_t)E * 4 * L, 4 * L);
-  gemm_tn(c, s, t->rec.eh0s + (size_t)N * L, L, L, t->dz1_all, 4 * L, 4 * L, RT, G(V_ENC_W1), 4 * L);
-  gemm_tn(c, s, t->rec.eh1s, L, L, t->dz1_all, 4 * L, 4 * L, RT, G(V_ENC_W1) + (size_t)L * 4 * L, 4 * L);
-  colsum(c, s, t->dz1_all, RT, 4 * L, 4 * L, G(V_ENC_B1));
   {
     ProfScope ps(c, F_OPTIMISER, 3.0 * t->split, 4.0 * 3 * t->split, s);
     launch_grad_finish(io->grads, (const float* const*)t->mirrors_dev, t->var_off_dev, t->decay_dev,
