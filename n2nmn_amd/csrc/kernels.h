@@ -214,9 +214,16 @@ struct GemmTnArgs {
   const float* B; int ldb; int N;              // n < N; rows readable up to round_up(N, 4)
   const int32_t* b_sel; int b_sel_val;         // optional: row r contributes iff b_sel[r] == val
   int R;
+  // optional compaction of the reduction: row r of BOTH operands (and of a_onehot) is row_idx[r],
+  // and the number of rows is read from the device (*r_dev <= R; R bounds the launch geometry)
+  const int32_t* row_idx;
+  const int32_t* r_dev;
   float* C; int ldc;
 };
 void launch_gemm_tn(const GemmTnArgs& a, hipStream_t s);
+// rows[0 .. *count) = { t*N + n : t < seq_len[n] } in any order; count must be zero on entry
+void launch_active_rows(const int32_t* seq_len, int T, int N, int32_t* rows, int32_t* count,
+                        hipStream_t s);
 // dst[c] += sum_r src[r*ld + c] (rows filtered by sel[r] == sel_val when sel != nullptr)
 void launch_colsum(const float* src, int R, int ncols, int ld, const int32_t* sel, int sel_val,
                    float* dst, hipStream_t s);

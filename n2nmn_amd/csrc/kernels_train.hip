@@ -44,8 +44,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a, int r_per_sp
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int m0 = blockIdx.y * TBM, n0 = blockIdx.x * TBN;
+  int Rtot = a.R;
+  if (a.r_dev) {                       // compacted reduction: re-balance the splits on the device
+    Rtot = min(a.R, *a.r_dev);
+    const int nkt_all = (Rtot + TBK - 1) / TBK;
+    r_per_split = ((nkt_all + gridDim.z - 1) / gridDim.z) * TBK;
+  }
   const int rbeg = blockIdx.z * r_per_split;
-  const int rend = min(a.R, rbeg + r_per_split);
+  const int rend = min(Rtot, rbeg + r_per_split);
   if (rbeg >= rend) return;
 
   const bool isB = tid >= 128;
@@ -67,6 +73,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a, int r_per_sp
       const int r = rbeg + kt * TBK + 4 * k4 + j;
       const bool rok = r < rend;
       int src = rok ? r : rbeg;
+      if (a.row_idx) src = a.row_idx[src];
       bool sel_ok = true;
       if (isB) {
         if (a.b_sel) sel_ok = a.b_sel[src] == a.b_sel_val;
@@ -129,6 +136,15 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a, int r_per_sp
       const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
       if (row < a.M) atomicAdd(a.C + (size_t)row * a.ldc + col, acc[r]);
     }
+  }
+}
+
+__global__ void active_rows_kernel(const int32_t* __restrict__ seq_len, int T, int N,
+                                   int32_t* __restrict__ rows, int32_t* __restrict__ count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < T * N) {
+    const int t = i / N, n = i - t * N;
+    if (t < seq_len[n]) rows[atomicAdd(count, 1)] = i;
   }
 }
 
@@ -638,6 +654,12 @@ void launch_gemm_tn(const GemmTnArgs& a, hipStream_t s) {
   int r_per = ((nkt + splits - 1) / splits) * TBK;
   splits = (a.R + r_per - 1) / r_per;
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(gx, gy, splits), dim3(256), 0, s, a, r_per);
+}
+
+void launch_active_rows(const int32_t* seq_len, int T, int N, int32_t* rows, int32_t* count,
+                        hipStream_t s) {
+  hipLaunchKernelGGL(active_rows_kernel, dim3((T * N + 255) / 256), dim3(256), 0, s, seq_len, T, N,
+                     rows, count);
 }
 
 void launch_colsum(const float* src, int R, int ncols, int ld, const int32_t* sel, int sel_val,
