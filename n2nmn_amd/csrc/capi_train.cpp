@@ -24,7 +24,7 @@ struct TrainState {
   float* scores = nullptr;            // [N][C] (when the caller passes no buffer)
   // backward scratch
   float *dscores = nullptr, *dsc = nullptr, *garena = nullptr, *dtmap = nullptr, *dpfc = nullptr,
-        *dmfind = nullptr, *dmfsp = nullptr, *dwv = nullptr, *datts_wv = nullptr, *de = nullptr,
+        *dmfind = nullptr, *dmfsp = nullptr, *dwv = nullptr, *datts_wv = nullptr, *dE = nullptr, *de = nullptr,
         *dctx = nullptr, *dq = nullptr, *dout = nullptr, *dvp = nullptr, *deht = nullptr,
         *denc_out = nullptr;
   float *dz0_all = nullptr, *dz1_all = nullptr;
@@ -122,6 +122,7 @@ size_t carve_train(n2nmn_ctx* c, TrainState* t, char* base) {
   t->dmfsp = k.take<float>(N * HW * Mp);
   t->dwv = k.take<float>(Td * N * E);
   t->datts_wv = k.take<float>(Td * T * N);
+  t->dE = k.take<float>(T * N * E);
   t->de = k.take<float>(Td * T * N);
   t->dctx = k.take<float>(Td * N * L);
   t->dq = k.take<float>(Td * N * L);
@@ -204,10 +205,10 @@ float* gptr(const n2nmn_ctx* c, const n2nmn_train_io* io, int var) {
 int gemm_tn(n2nmn_ctx* c, hipStream_t s, const float* A, int lda, int M, const float* B, int ldb,
             int N, int R, float* C, int ldc, const int32_t* a_idx = nullptr, int a_gs = 1,
             const int32_t* b_sel = nullptr, int b_val = 0, const int32_t* row_idx = nullptr,
-            const int32_t* r_dev = nullptr) {
+            const int32_t* r_dev = nullptr, float* colsum_dst = nullptr) {
   if (R <= 0) return N2NMN_OK;
   GemmTnArgs g{};
-  g.row_idx = row_idx; g.r_dev = r_dev;
+  g.row_idx = row_idx; g.r_dev = r_dev; g.colsum = colsum_dst;
   g.A = A; g.lda = lda; g.M = M; g.a_group_idx = a_idx; g.a_group_size = a_gs;
   g.B = B; g.ldb = ldb; g.N = N; g.b_sel = b_sel; g.b_sel_val = b_val; g.R = R; g.C = C; g.ldc = ldc;
   ProfScope ps(c, F_GEMM_TN, 2.0 * M * N * R, 4.0 * ((double)R * (M + N) + (double)M * N), s);
@@ -575,15 +576,13 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
               const int txw[5] = {V_FIND_TXT_W, V_FSP_TXT_W, V_TR_TXT_W, V_SP_TXT_W, V_DE_TXT_W};
               for (int i = 0; i < 5; ++i) {
                 gemm_tn(c, sd, c->word_vecs, E, E, t->dtmap, Mp, M, p.num_text, G(txw[i]), M,
-                        t->tslot_row, 1, t->tslot_ws, i);
-                colsum(c, sd, t->dtmap, p.num_text, M, Mp, G(txw[i] + 1), t->tslot_ws, i);
+                        t->tslot_row, 1, t->tslot_ws, i, nullptr, nullptr, G(txw[i] + 1));
               }
             } else {
               const bool fsp = l.kind == LK_CONV_FSP;
               gemm_tn(c, sd, io->image_feat, D, D, fsp ? t->dmfsp : t->dmfind, Mp, M, l.count * HW,
-                      G(fsp ? V_FSP_IMG_W : V_FIND_IMG_W), M, c->dev_tab + l.offset, HW);
-              colsum(c, sd, fsp ? t->dmfsp : t->dmfind, l.count * HW, M, Mp,
-                     G(fsp ? V_FSP_IMG_B : V_FIND_IMG_B));
+                      G(fsp ? V_FSP_IMG_W : V_FIND_IMG_W), M, c->dev_tab + l.offset, HW, nullptr, 0,
+                      nullptr, nullptr, G(fsp ? V_FSP_IMG_B : V_FIND_IMG_B));
             }
             break;
           }
@@ -592,10 +591,25 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
       }
     }
     // ------------------------------- decoder ----------------------------------------------
+    // rows (tau, n) inside the question's length: reduction index of every encoder-side weight
+    // gradient (here the embedding gradient through word_vecs; in phase 1 the LSTM's)
+    N2_HIP(hipMemsetAsync(t->act_count, 0, sizeof(int32_t) * 4, s));
+    launch_active_rows(io->seq_length, T, N, t->act_rows, t->act_count, s);
     {
-      ProfScope ps(c, F_BWD_MISC, 4.0 * Td * T * N * E, 4.0 * N * (double)(T * E + 2 * Td * E + 2 * Td * T), s);
+      ProfScope ps(c, F_BWD_MISC, 4.0 * Td * T * N * E, 4.0 * N * (double)(2 * T * E + 2 * Td * E + 2 * Td * T), s);
       launch_word_vecs_bwd(t->dwv, c->atts, io->input_seq, io->seq_length, mir(V_ENC_EMB), Td, T, N,
-                           E, t->datts_wv, G(V_ENC_EMB), s);
+                           E, t->datts_wv, t->dE, s);
+    }
+    {
+      // d embedding_mat (through word_vecs) = onehot(word)^T . dE over the active rows; it lands in
+      // the encoder bucket, which is only finished in phase 1 -> side stream, joined with the rest
+      hipStream_t sd = t->fork(s);
+      GemmTnArgs g1{};
+      g1.A = nullptr; g1.lda = 0; g1.M = Vt; g1.a_onehot = io->input_seq;
+      g1.B = t->dE; g1.ldb = E; g1.N = E; g1.R = T * N; g1.C = G(V_ENC_EMB); g1.ldc = E;
+      g1.row_idx = t->act_rows; g1.r_dev = t->act_count;
+      ProfScope ps(c, F_GEMM_TN, 2.0 * Vt * (double)E * T * N, 4.0 * ((double)T * N * E + Vt * (double)E), sd);
+      launch_gemm_tn(g1, sd);
     }
     DecBwdArgs a{};
     a.scores = t->rec.tscores; a.gt = io->gt_layout; a.q = c->qbuf; a.eht = c->eht;
@@ -617,12 +631,12 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
     const int RT = Td * N;
     {
       hipStream_t sd = t->fork(s);     // token / attention projection gradients: leaves
-      gemm_tn(c, sd, c->dec_h1_all, L, L, t->dsc, 16, V, RT, G(V_TOK_W), V);
+      gemm_tn(c, sd, c->dec_h1_all, L, L, t->dsc, 16, V, RT, G(V_TOK_W), V, nullptr, 1, nullptr, 0,
+              nullptr, nullptr, G(V_TOK_B));
       gemm_tn(c, sd, t->rec.ctx, L, L, t->dsc, 16, V, RT, G(V_TOK_W) + (size_t)L * V, V);
-      colsum(c, sd, t->dsc, RT, V, 16, G(V_TOK_B));
       colsum(c, sd, t->dvp, RT, L, L, G(V_ATT_V));
-      gemm_tn(c, sd, c->dec_h1_all, L, L, t->dq, L, L, RT, G(V_ATT_W), L);
-      colsum(c, sd, t->dq, RT, L, L, G(V_ATT_B));
+      gemm_tn(c, sd, c->dec_h1_all, L, L, t->dq, L, L, RT, G(V_ATT_W), L, nullptr, 1, nullptr, 0,
+              nullptr, nullptr, G(V_ATT_B));
     }
     gemm_nt(c, s, t->dq, L, RT, L, t->att_WT_p, L, c->KpL, L, t->dout, L, true);
     // BPTT through the decoder LSTM stack; its initial state is the encoder's final state
@@ -643,15 +657,15 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
       ProfScope ps(c, F_GEMM_TN, 2.0 * (V + 1) * 4.0 * L * RT, 4.0 * ((double)RT * 4 * L + (V + 1) * 4.0 * L), s);
       launch_gemm_tn(g1, s);
     }
-    gemm_tn(c, s, c->dec_emb_cat, E, E, t->dxtab_dec, 4 * L, 4 * L, V + 1, G(V_DEC_W0), 4 * L);
-    colsum(c, s, t->dxtab_dec, V + 1, 4 * L, 4 * L, G(V_DEC_B0));
+    gemm_tn(c, s, c->dec_emb_cat, E, E, t->dxtab_dec, 4 * L, 4 * L, V + 1, G(V_DEC_W0), 4 * L,
+            nullptr, 1, nullptr, 0, nullptr, nullptr, G(V_DEC_B0));
     gemm_nt(c, s, t->dxtab_dec, 4 * L, V, 4 * L, t->dec_W0xT_p, Ep, t->KpL4, E, G(V_DEC_EMB), E, true);
     gemm_nt(c, s, t->dxtab_dec + (size_t)V * 4 * L, 4 * L, 1, 4 * L, t->dec_W0xT_p, Ep, t->KpL4, E,
             G(V_DEC_GO), E, true);
     gemm_tn(c, s, t->rec.dh0s, L, L, t->dz0_all, 4 * L, 4 * L, RT, G(V_DEC_W0) + (size_t)E * 4 * L, 4 * L);
-    gemm_tn(c, s, t->rec.dh0s + (size_t)N * L, L, L, t->dz1_all, 4 * L, 4 * L, RT, G(V_DEC_W1), 4 * L);
+    gemm_tn(c, s, t->rec.dh0s + (size_t)N * L, L, L, t->dz1_all, 4 * L, 4 * L, RT, G(V_DEC_W1), 4 * L,
+            nullptr, 1, nullptr, 0, nullptr, nullptr, G(V_DEC_B1));
     gemm_tn(c, s, t->rec.dh1s, L, L, t->dz1_all, 4 * L, 4 * L, RT, G(V_DEC_W1) + (size_t)L * 4 * L, 4 * L);
-    colsum(c, s, t->dz1_all, RT, 4 * L, 4 * L, G(V_DEC_B1));
     t->join(s);                        // decoder + module gradients complete from here on
     {
       ProfScope ps(c, F_OPTIMISER, 3.0 * (t->total - t->split), 4.0 * 3 * (t->total - t->split), s);
@@ -667,15 +681,13 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
   N2_HIP(hipMemsetAsync(t->dxtab_enc, 0, sizeof(float) * (size_t)Vt * 4 * L, s));
   {
     hipStream_t sd = t->fork(s);
-    gemm_tn(c, sd, c->enc_out, L, L, t->deht, L, L, RT, G(V_EHT_W), L);
-    colsum(c, sd, t->deht, RT, L, L, G(V_EHT_B));
+    gemm_tn(c, sd, c->enc_out, L, L, t->deht, L, L, RT, G(V_EHT_W), L, nullptr, 1, nullptr, 0,
+            nullptr, nullptr, G(V_EHT_B));
   }
   // d encoder_outputs = (through the context vectors, already in denc_out) + deht . W_eht^T
   gemm_nt(c, s, t->deht, L, RT, L, t->eht_WT_p, L, c->KpL, L, t->denc_out, L, true);
   // rows (t, n) past the question's length have dz = 0: the weight-gradient GEMMs run over the
-  // compacted list of active rows (about 56 % of T*N with lengths uniform in [5, 45])
-  N2_HIP(hipMemsetAsync(t->act_count, 0, sizeof(int32_t) * 4, s));
-  launch_active_rows(io->seq_length, T, N, t->act_rows, t->act_count, s);
+  // compacted list of active rows built in phase 0 (about 56 % of T*N with lengths in [5, 45])
   BpttArgs ba{};
   ba.T = T; ba.N = N; ba.want_init_grad = false; ba.seq_len = io->seq_length;
   ba.g0 = t->rec.eg0; ba.g1 = t->rec.eg1; ba.c0s = t->rec.ec0s; ba.c1s = t->rec.ec1s;
@@ -697,13 +709,12 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
     gemm_tn(c, s, t->rec.eh0s, L, L, t->dz0_all, 4 * L, 4 * L, RT, G(V_ENC_W0) + (size_t)E * 4 * L,
             4 * L, nullptr, 1, nullptr, 0, rows, cnt);
     gemm_tn(c, s, t->rec.eh0s + (size_t)N * L, L, L, t->dz1_all, 4 * L, 4 * L, RT, G(V_ENC_W1), 4 * L,
-            nullptr, 1, nullptr, 0, rows, cnt);
+            nullptr, 1, nullptr, 0, rows, cnt, G(V_ENC_B1));
     gemm_tn(c, s, t->rec.eh1s, L, L, t->dz1_all, 4 * L, 4 * L, RT, G(V_ENC_W1) + (size_t)L * 4 * L,
             4 * L, nullptr, 1, nullptr, 0, rows, cnt);
-    colsum(c, s, t->dz1_all, RT, 4 * L, 4 * L, G(V_ENC_B1));
   }
-  gemm_tn(c, s, mir(V_ENC_EMB), E, E, t->dxtab_enc, 4 * L, 4 * L, Vt, G(V_ENC_W0), 4 * L);
-  colsum(c, s, t->dxtab_enc, Vt, 4 * L, 4 * L, G(V_ENC_B0));
+  gemm_tn(c, s, mir(V_ENC_EMB), E, E, t->dxtab_enc, 4 * L, 4 * L, Vt, G(V_ENC_W0), 4 * L,
+          nullptr, 1, nullptr, 0, nullptr, nullptr, G(V_ENC_B0));
   gemm_nt(c, s, t->dxtab_enc, 4 * L, Vt, 4 * L, t->enc_W0xT_p, Ep, t->KpL4, E, G(V_ENC_EMB), E, true);
   {
     ProfScope ps(c, F_OPTIMISER, 3.0 * t->split, 4.0 * 3 * t->split, s);

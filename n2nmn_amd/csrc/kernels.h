@@ -219,6 +219,8 @@ struct GemmTnArgs {
   const int32_t* row_idx;
   const int32_t* r_dev;
   float* C; int ldc;
+  float* colsum;                               // optional: colsum[n] += sum_r B[r][n] (the bias
+                                               // gradient that goes with dW = X^T . dY), same rows
 };
 void launch_gemm_tn(const GemmTnArgs& a, hipStream_t s);
 // rows[0 .. *count) = { t*N + n : t < seq_len[n] } in any order; count must be zero on entry
@@ -286,10 +288,11 @@ struct DecBwdArgs {
 void launch_dec_bwd_a(const DecBwdArgs& a, hipStream_t s);   // per (n, t)
 void launch_dec_bwd_b(const DecBwdArgs& a, hipStream_t s);   // per (tau, n)
 
-// word_vecs = sum_tau atts * emb[seq]: datts_wv and the embedding gradient (atomic)
+// word_vecs = sum_tau atts * emb[seq]: datts_wv [Td][T][N] and dE [T][N][E] = gradient of the
+// embedded question (rows tau < len only; the embedding gradient is a one-hot gemm_tn over them)
 void launch_word_vecs_bwd(const float* dwv, const float* atts, const int32_t* seq,
                           const int32_t* seq_len, const float* emb, int T_dec, int T_enc, int N,
-                          int E, float* datts_wv, float* gemb, hipStream_t s);
+                          int E, float* datts_wv, float* dE, hipStream_t s);
 
 // losses[0] = mean CE(scores, labels), losses[1] = mean(-log_seq_prob); dscores = (p - onehot)/N
 void launch_loss(const float* scores, const int32_t* labels, const float* log_seq_prob, int N,

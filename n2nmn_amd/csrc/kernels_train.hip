@@ -66,6 +66,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a, int r_per_sp
   const bool col_ok = cbeg < ((clim + 3) & ~3);
   const int ccl = col_ok ? cbeg : 0;
 
+  // bias gradient riding along: the workgroups of the first row of output tiles also sum the B
+  // columns they stream (every B tile is loaded exactly once per workgroup)
+  const bool do_cs = a.colsum != nullptr && blockIdx.y == 0;
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 reg[4];
   auto gload = [&](int kt) {
 #pragma unroll
@@ -94,6 +98,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a, int r_per_sp
       reg[j].y = (ok && cbeg + 1 < clim) ? t.y : 0.f;
       reg[j].z = (ok && cbeg + 2 < clim) ? t.z : 0.f;
       reg[j].w = (ok && cbeg + 3 < clim) ? t.w : 0.f;
+      if (do_cs && isB) { cs.x += reg[j].x; cs.y += reg[j].y; cs.z += reg[j].z; cs.w += reg[j].w; }
     }
   };
   auto lstore = [&](int buf) {
@@ -135,6 +140,17 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a, int r_per_sp
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
       if (row < a.M) atomicAdd(a.C + (size_t)row * a.ldc + col, acc[r]);
+    }
+  }
+  if (do_cs) {                      // uniform per workgroup; the k-loop ended with a barrier
+    float* red = reinterpret_cast<float*>(&Bs[0][0][0]);     // [8 row groups][64 columns]
+    if (isB) *reinterpret_cast<float4*>(red + k4 * 64 + 4 * c4) = cs;
+    __syncthreads();
+    if (tid < 64 && n0 + tid < a.N) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < TBK / 4; ++q) t += red[q * 64 + tid];
+      atomicAdd(a.colsum + n0 + tid, t);
     }
   }
 }
@@ -490,49 +506,56 @@ __global__ __launch_bounds__(128) void dec_bwd_b_kernel(DecBwdArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 // word_vecs_bwd: word_vecs[t,n,:] = sum_tau atts[t,tau,n] * emb[seq[tau,n],:]
-//   datts_wv[t,tau,n] = dwv[t,n,:] . emb[seq[tau,n],:]
-//   gemb[seq[tau,n],:] += sum_t atts[t,tau,n] * dwv[t,n,:]        (atomic; tau < len only)
-// one workgroup per question; its embedding rows and dwv rows are staged in LDS.
+//   blockIdx.y == 0:  datts_wv[t,tau,n] = dwv[t,n,:] . emb[seq[tau,n],:]          (tau < len, else 0)
+//   blockIdx.y == 1:  dE[tau,n,:] = sum_t atts[t,tau,n] * dwv[t,n,:]              (tau < len only)
+// dE is the gradient of the embedded question; the embedding-matrix gradient is then the one-hot
+// gemm_tn over the active rows (no atomics).  One workgroup per (question, half); the question's
+// embedding rows (row stride E+1: conflict-free across tau) and dwv rows are staged in LDS.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void word_vecs_bwd_kernel(
     const float* __restrict__ dwv, const float* __restrict__ atts, const int32_t* __restrict__ seq,
     const int32_t* __restrict__ seq_len, const float* __restrict__ emb, int T_dec, int T_enc,
-    int N, int E, float* __restrict__ datts_wv, float* __restrict__ gemb) {
+    int N, int E, float* __restrict__ datts_wv, float* __restrict__ dE) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* rows = smem;                          // [T_enc][E]
-  float* dw = rows + (size_t)T_enc * E;        // [T_dec][E]
-  float* at = dw + (size_t)T_dec * E;          // [T_dec][T_enc]
-  int* idx = reinterpret_cast<int*>(at + (size_t)T_dec * T_enc);
-  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int len = seq_len[n];
-  for (int tau = tid; tau < T_enc; tau += 256) idx[tau] = seq[tau * N + n];
-  for (int i = tid; i < T_dec * T_enc; i += 256) {
-    const int t = i / T_enc, tau = i - t * T_enc;
-    at[i] = atts[((size_t)t * T_enc + tau) * N + n];
-  }
+  const int ES = E + 1;
+  float* dw = smem;                            // [T_dec][E]
+  float* rows = dw + (size_t)T_dec * E;        // y == 0: [T_enc][E+1]   y == 1: at [T_dec][T_enc]
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int len = min(seq_len[n], T_enc);
   for (int i = tid; i < T_dec * E; i += 256) {
     const int t = i / E, e = i - t * E;
     dw[i] = dwv[((size_t)t * N + n) * E + e];
   }
-  __syncthreads();
-  for (int i = tid; i < T_enc * E; i += 256) {
-    const int tau = i / E, e = i - tau * E;
-    rows[i] = emb[(size_t)idx[tau] * E + e];
-  }
-  __syncthreads();
-  for (int p = w; p < T_dec * T_enc; p += 4) {           // wave per (t, tau)
-    const int t = p / T_enc, tau = p - t * T_enc;
-    float s = 0.f;
-    for (int e = lane; e < E; e += 64) s += dw[t * E + e] * rows[tau * E + e];
-    s = wave_sum(s);
-    if (lane == 0) datts_wv[((size_t)t * T_enc + tau) * N + n] = s;
-  }
-  for (int i = tid; i < T_enc * E; i += 256) {
-    const int tau = i / E, e = i - tau * E;
-    if (tau < len) {
+  if (blockIdx.y == 0) {
+    for (int i = tid; i < len * E; i += 256) {
+      const int tau = i / E, e = i - tau * E;
+      rows[tau * ES + e] = emb[(size_t)seq[tau * N + n] * E + e];
+    }
+    __syncthreads();
+    for (int p = tid; p < T_dec * T_enc; p += 256) {          // thread per (t, tau)
+      const int t = p / T_enc, tau = p - t * T_enc;
+      float s0 = 0.f, s1 = 0.f;
+      if (tau < len) {
+        const float* r = rows + tau * ES;
+        const float* d = dw + t * E;
+        int e = 0;
+        for (; e + 1 < E; e += 2) { s0 += r[e] * d[e]; s1 += r[e + 1] * d[e + 1]; }
+        if (e < E) s0 += r[e] * d[e];
+      }
+      datts_wv[((size_t)t * T_enc + tau) * N + n] = s0 + s1;
+    }
+  } else {
+    float* at = rows;
+    for (int i = tid; i < T_dec * T_enc; i += 256) {
+      const int t = i / T_enc, tau = i - t * T_enc;
+      at[i] = atts[((size_t)t * T_enc + tau) * N + n];
+    }
+    __syncthreads();
+    for (int i = tid; i < len * E; i += 256) {
+      const int tau = i / E, e = i - tau * E;
       float s = 0.f;
       for (int t = 0; t < T_dec; ++t) s += at[t * T_enc + tau] * dw[t * E + e];
-      atomicAdd(gemb + (size_t)idx[tau] * E + e, s);
+      dE[((size_t)tau * N + n) * E + e] = s;
     }
   }
 }
@@ -714,14 +737,14 @@ void launch_dec_bwd_b(const DecBwdArgs& a, hipStream_t s) {
 
 void launch_word_vecs_bwd(const float* dwv, const float* atts, const int32_t* seq,
                           const int32_t* seq_len, const float* emb, int T_dec, int T_enc, int N,
-                          int E, float* datts_wv, float* gemb, hipStream_t s) {
-  const size_t smem = sizeof(float) * ((size_t)T_enc * E + (size_t)T_dec * E +
-                                       (size_t)T_dec * T_enc + (size_t)T_enc + 4);
+                          int E, float* datts_wv, float* dE, hipStream_t s) {
+  const size_t smem = sizeof(float) * ((size_t)T_dec * E +
+                                       std::max((size_t)T_enc * (E + 1), (size_t)T_dec * T_enc) + 4);
   if (smem > 64 * 1024)      // a workgroup may use the whole 160 KiB LDS of a gfx950 CU
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(word_vecs_bwd_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(word_vecs_bwd_kernel, dim3(N), dim3(256), smem, s, dwv, atts, seq, seq_len,
-                     emb, T_dec, T_enc, N, E, datts_wv, gemb);
+  hipLaunchKernelGGL(word_vecs_bwd_kernel, dim3(N, 2), dim3(256), smem, s, dwv, atts, seq, seq_len,
+                     emb, T_dec, T_enc, N, E, datts_wv, dE);
 }
 
 void launch_loss(const float* scores, const int32_t* labels, const float* log_seq_prob, int N,
