@@ -30,6 +30,7 @@ struct TrainState {
   float *dz0_all = nullptr, *dz1_all = nullptr;
   float *dzk0[2] = {nullptr, nullptr}, *dzk1[2] = {nullptr, nullptr};
   float *dH0 = nullptr, *dH1 = nullptr, *dC0 = nullptr, *dC1 = nullptr;
+  char *zero_begin = nullptr, *zero_end = nullptr;   // dtmap..act_count: one memset per step
   float *dxtab_enc = nullptr, *dxtab_dec = nullptr;
   int32_t* dec_xidx = nullptr;
   int32_t *act_rows = nullptr, *act_count = nullptr;   // encoder rows (t, n) with t < len[n]
@@ -115,12 +116,20 @@ size_t carve_train(n2nmn_ctx* c, TrainState* t, char* base) {
   t->scores = k.take<float>(N * C);
   t->dscores = k.take<float>(N * C + 4);
   t->dsc = k.take<float>(Td * N * 16);
-  t->garena = k.take<float>((size_t)c->max_nodes * HWp);
+  // [zero block: cleared by ONE memset at the start of backward phase 0]
+  t->zero_begin = reinterpret_cast<char*>(k.take<float>(0));
+  t->garena = k.take<float>((size_t)c->max_nodes * HWp);     // Transform adds into its input's row
   t->dtmap = k.take<float>((size_t)c->max_text * Mp);
   t->dpfc = k.take<float>((size_t)c->max_pool * 2 * Mp);
+  t->dwv = k.take<float>(Td * N * E);
+  t->dH0 = k.take<float>(N * L); t->dH1 = k.take<float>(N * L);
+  t->dC0 = k.take<float>(N * L); t->dC1 = k.take<float>(N * L);
+  t->dxtab_enc = k.take<float>(Vt * 4 * L);
+  t->dxtab_dec = k.take<float>((V + 1) * 4 * L);
+  t->act_count = k.take<int32_t>(4);
+  t->zero_end = reinterpret_cast<char*>(k.take<float>(0));
   t->dmfind = k.take<float>(N * HW * Mp);
   t->dmfsp = k.take<float>(N * HW * Mp);
-  t->dwv = k.take<float>(Td * N * E);
   t->datts_wv = k.take<float>(Td * T * N);
   t->dE = k.take<float>(T * N * E);
   t->de = k.take<float>(Td * T * N);
@@ -136,13 +145,8 @@ size_t carve_train(n2nmn_ctx* c, TrainState* t, char* base) {
     t->dzk0[i] = k.take<float>(4 * L * N);
     t->dzk1[i] = k.take<float>(4 * L * N);
   }
-  t->dH0 = k.take<float>(N * L); t->dH1 = k.take<float>(N * L);
-  t->dC0 = k.take<float>(N * L); t->dC1 = k.take<float>(N * L);
-  t->dxtab_enc = k.take<float>(Vt * 4 * L);
-  t->dxtab_dec = k.take<float>((V + 1) * 4 * L);
   t->dec_xidx = k.take<int32_t>(Td * N);
   t->act_rows = k.take<int32_t>(T * N);
-  t->act_count = k.take<int32_t>(4);
   t->enc_Wt1 = k.take<float>(L * 4 * L); t->enc_Wt0 = k.take<float>(L * 8 * L);
   t->dec_Wt1 = k.take<float>(L * 4 * L); t->dec_Wt0 = k.take<float>(L * 8 * L);
   t->eht_WT_p = k.take<float>((size_t)c->KpL * L);
@@ -300,6 +304,8 @@ int n2nmn_train_enable(n2nmn_ctx* c) {
   N2_REQUIRE(!c->parent, N2NMN_EINVAL, "train_enable: train on the root context");
   N2_REQUIRE(c->d.variant == N2NMN_VARIANT_CLEVR, N2NMN_EINVAL,
              "train_enable: the training step is built for the models_clevr variant");
+  N2_REQUIRE((c->d.H * c->d.W + TRANSFORM_PARTS - 1) / TRANSFORM_PARTS <= 64, N2NMN_EINVAL,
+             "train_enable: the Transform backward handles at most 64 pixels per part (H*W <= 192)");
   if (c->train) return N2NMN_OK;
   N2_REQUIRE(c->d.num_vocab_nmn <= 15, N2NMN_EINVAL,
              "train_enable: num_vocab_nmn + <go> must fit 16 x-table rows");
@@ -470,10 +476,9 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
     N2_HIP(hipMemsetAsync(io->grads, 0, sizeof(float) * (size_t)t->total, s));
     // ------------------------------- module network ---------------------------------------
     const int nn = (int)p.dev_nodes.size();
-    N2_HIP(hipMemsetAsync(t->dwv, 0, sizeof(float) * (size_t)Td * N * E, s));
+    // garena, dtmap, dpfc, dwv, the carried dH/dC, both x-table gradients, the active-row counter
+    N2_HIP(hipMemsetAsync(t->zero_begin, 0, (size_t)(t->zero_end - t->zero_begin), s));
     if (nn > 0) {
-      N2_HIP(hipMemsetAsync(t->dtmap, 0, sizeof(float) * (size_t)std::max(p.num_text, 1) * Mp, s));
-      N2_HIP(hipMemsetAsync(t->dpfc, 0, sizeof(float) * (size_t)std::max(p.num_pool, 1) * 2 * Mp, s));
       if (p.num_find_img)
         N2_HIP(hipMemsetAsync(t->dmfind, 0, sizeof(float) * (size_t)p.num_find_img * HW * Mp, s));
       if (p.num_fsp_img)
@@ -593,7 +598,6 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
     // ------------------------------- decoder ----------------------------------------------
     // rows (tau, n) inside the question's length: reduction index of every encoder-side weight
     // gradient (here the embedding gradient through word_vecs; in phase 1 the LSTM's)
-    N2_HIP(hipMemsetAsync(t->act_count, 0, sizeof(int32_t) * 4, s));
     launch_active_rows(io->seq_length, T, N, t->act_rows, t->act_count, s);
     {
       ProfScope ps(c, F_BWD_MISC, 4.0 * Td * T * N * E, 4.0 * N * (double)(2 * T * E + 2 * Td * E + 2 * Td * T), s);
@@ -640,7 +644,6 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
     }
     gemm_nt(c, s, t->dq, L, RT, L, t->att_WT_p, L, c->KpL, L, t->dout, L, true);
     // BPTT through the decoder LSTM stack; its initial state is the encoder's final state
-    N2_HIP(hipMemsetAsync(t->dH0, 0, sizeof(float) * 4 * (size_t)d.N * L, s));   // dH0,dH1,dC0,dC1
     BpttArgs ba{};
     ba.T = Td; ba.N = N; ba.want_init_grad = true; ba.seq_len = nullptr;
     ba.g0 = t->rec.dg0; ba.g1 = t->rec.dg1; ba.c0s = t->rec.dc0s; ba.c1s = t->rec.dc1s;
@@ -649,7 +652,6 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
     if (rc != N2NMN_OK) return rc;
     launch_dec_xidx(io->gt_layout, Td, N, V, t->dec_xidx, s);
     // gradient of the input-projection table: dxtab = onehot(idx)^T . dz0  (one-hot gemm_tn)
-    N2_HIP(hipMemsetAsync(t->dxtab_dec, 0, sizeof(float) * (size_t)(V + 1) * 4 * L, s));
     {
       GemmTnArgs g1{};
       g1.A = nullptr; g1.lda = 0; g1.M = V + 1; g1.a_onehot = t->dec_xidx;
@@ -678,7 +680,6 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
 
   // ------------------------------- phase 1: encoder -----------------------------------------
   const int RT = T * N;
-  N2_HIP(hipMemsetAsync(t->dxtab_enc, 0, sizeof(float) * (size_t)Vt * 4 * L, s));
   {
     hipStream_t sd = t->fork(s);
     gemm_tn(c, sd, c->enc_out, L, L, t->deht, L, L, RT, G(V_EHT_W), L, nullptr, 1, nullptr, 0,

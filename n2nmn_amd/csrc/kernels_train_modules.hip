@@ -346,31 +346,35 @@ __device__ void find_epilogue_bwd(const ModuleWeights& w, const ModuleBuffers& b
 
 // ---------------------------------------------------------------------------------------------
 // Transform backward (forward: transform_op).  conv[p,c] = sum_tap K[tap,c] x[p+tap] + bt[c];
-// v = conv * tm[c];  att[p] = l2n_c(v) . w_e + b_e.  One workgroup per node (part 0 only).
-//   pass A (lanes = pixels, waves = channel quarters): per-pixel ss, dot -> coefficients
-//       dv[p,c] = A_p w_e[c] - B_p v[p,c];   G[p][tap] = sum_c dv tm[c] K[tap,c]  -> d input map
-//   pass B (threads = channels, loop over pixels): dK[tap,c], dbt[c], dtm[c], dw_e[c]
+// v = conv * tm[c];  att[p] = l2n_c(v) . w_e + b_e.  Like the forward, a node is split over
+// `nparts` workgroups by output pixels (<= 64 each); the parts are independent:
+//   pass A (lanes = own pixels, waves = channel quarters): per-pixel ss, dot -> coefficients
+//       dv[p,c] = A_p w_e[c] - B_p v[p,c];  d input[p + tap] += sum_c dv tm[c] K[tap,c]
+//       (atomic into garena[input], which is zeroed at the start of the backward pass)
+//   pass B (threads = channels, loop over own pixels): dK[tap,c], dbt[c], dtm[c], dw_e[c] partials,
+//       added atomically (dtmap / the flat gradient buffer are zeroed as well)
 // ---------------------------------------------------------------------------------------------
 template <int KS>
 __device__ void transform_bwd(const ModuleWeights& w, const ModuleBuffers& b, const ModuleGrads& g,
-                              const DevNode& nd, int node_id, float* smem) {
+                              const DevNode& nd, int node_id, int part, int nparts, float* smem) {
   constexpr int KK = KS * KS;
   constexpr int RS = (KK + 3 + 3) & ~3;      // taps + bt + we + tm
   constexpr int PAD = KS / 2;
   const int H = b.H, W = b.W, HW = H * W, M = b.M, Mp = b.Mp;
   const int PW = W + 2 * PAD, PH = H + 2 * PAD;
-  const int HWq = (HW + 3) & ~3;
   float* Kl = smem;                            // [M][RS]: K[tap] (raw), bt, we, tm
   float* xin = Kl + (size_t)M * RS;            // [PH][PW]
-  float* Ap = xin + ((PH * PW + 3) & ~3);      // [HWq]
-  float* Bp = Ap + HWq;                        // [HWq]
-  float* G = Bp + HWq;                         // [HW][KK]
-  float* red = G + ((HW * KK + 3) & ~3);       // [4 waves][64][2]
+  float* Ap = xin + ((PH * PW + 3) & ~3);      // [64]
+  float* Bp = Ap + 64;                         // [64]
+  float* red = Bp + 64;                        // [4 waves][64][2]
   float* scratch = red + 4 * 64 * 2;           // [16]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const float* in0 = b.arena + (size_t)nd.in0 * b.HWp;
   const float* tm = b.tmap + (size_t)nd.tslot * Mp;
   const float* gout = g.garena + (size_t)node_id * b.HWp;
+  const int ppp = (HW + nparts - 1) / nparts;
+  const int p0 = part * ppp, p1 = min(HW, p0 + ppp);
+  if (p1 - p0 > 64) return;                    // (forward guarantees <= 64 pixels per part)
   for (int i = tid; i < PH * PW; i += MT) {
     const int y = i / PW - PAD, x = i % PW - PAD;
     xin[i] = (y >= 0 && y < H && x >= 0 && x < W) ? in0[y * W + x] : 0.f;
@@ -384,78 +388,73 @@ __device__ void transform_bwd(const ModuleWeights& w, const ModuleBuffers& b, co
     Kl[c * RS + KK + 1] = w.we[2][c];
     Kl[c * RS + KK + 2] = tm[c];
   }
-  for (int i = tid; i < HW * KK; i += MT) G[i] = 0.f;
   __syncthreads();
-  float gsum = 0.f;
-  // ---- pass A: lanes = pixels ----
-  for (int pb = 0; pb < HW; pb += 64) {
-    const int p = pb + lane;
-    const bool on = p < HW;
-    const int y = on ? p / W : 0, x = on ? p - (p / W) * W : 0;
-    float win[KK];
+  // ---- pass A: lanes = own pixels ----
+  const int p = p0 + lane;
+  const bool on = p < p1;
+  const int py = on ? p / W : 0, px = on ? p - (p / W) * W : 0;
+  float win[KK];
+#pragma unroll
+  for (int dy = 0; dy < KS; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < KS; ++dx) win[dy * KS + dx] = xin[(py + dy) * PW + px + dx];
+  float ss = 0.f, dot = 0.f;
+  for (int c = wid; c < M; c += MT / 64) {
+    const float4* kr = reinterpret_cast<const float4*>(Kl + (size_t)c * RS);
+    float kk[RS];
+#pragma unroll
+    for (int q = 0; q < RS / 4; ++q) {
+      const float4 t4 = kr[q];
+      kk[4 * q] = t4.x; kk[4 * q + 1] = t4.y; kk[4 * q + 2] = t4.z; kk[4 * q + 3] = t4.w;
+    }
+    float cv = kk[KK];
+#pragma unroll
+    for (int tap = 0; tap < KK; ++tap) cv += kk[tap] * win[tap];
+    const float v = cv * kk[KK + 2];
+    ss += v * v;
+    dot += v * kk[KK + 1];
+  }
+  red[(wid * 64 + lane) * 2] = ss;
+  red[(wid * 64 + lane) * 2 + 1] = dot;
+  __syncthreads();
+  float s2 = 0.f, d2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < MT / 64; ++q) { s2 += red[(q * 64 + lane) * 2]; d2 += red[(q * 64 + lane) * 2 + 1]; }
+  const float inv = 1.0f / sqrtf(fmaxf(s2, 1e-12f));
+  const float gp = on ? gout[p] : 0.f;
+  const float A = gp * inv, Bc = gp * l2n_k(s2, inv) * d2;
+  if (wid == 0) { Ap[lane] = A; Bp[lane] = Bc; }
+  float ga[KK];
+#pragma unroll
+  for (int tap = 0; tap < KK; ++tap) ga[tap] = 0.f;
+  for (int c = wid; c < M; c += MT / 64) {
+    const float4* kr = reinterpret_cast<const float4*>(Kl + (size_t)c * RS);
+    float kk[RS];
+#pragma unroll
+    for (int q = 0; q < RS / 4; ++q) {
+      const float4 t4 = kr[q];
+      kk[4 * q] = t4.x; kk[4 * q + 1] = t4.y; kk[4 * q + 2] = t4.z; kk[4 * q + 3] = t4.w;
+    }
+    float cv = kk[KK];
+#pragma unroll
+    for (int tap = 0; tap < KK; ++tap) cv += kk[tap] * win[tap];
+    const float tmc = kk[KK + 2];
+    const float dconv = (A * kk[KK + 1] - Bc * cv * tmc) * tmc;
+#pragma unroll
+    for (int tap = 0; tap < KK; ++tap) ga[tap] += dconv * kk[tap];
+  }
+  if (on) {     // conv is a cross-correlation: input pixel = p + tap - PAD
+    float* gin = g.garena + (size_t)nd.in0 * b.HWp;
 #pragma unroll
     for (int dy = 0; dy < KS; ++dy)
 #pragma unroll
-      for (int dx = 0; dx < KS; ++dx) win[dy * KS + dx] = xin[(y + dy) * PW + x + dx];
-    float ss = 0.f, dot = 0.f;
-    for (int c = wid; c < M; c += MT / 64) {
-      const float* kr = Kl + (size_t)c * RS;
-      float cv = kr[KK];
-#pragma unroll
-      for (int tap = 0; tap < KK; ++tap) cv += kr[tap] * win[tap];
-      const float v = cv * kr[KK + 2];
-      ss += v * v;
-      dot += v * kr[KK + 1];
-    }
-    __syncthreads();
-    red[(wid * 64 + lane) * 2] = ss;
-    red[(wid * 64 + lane) * 2 + 1] = dot;
-    __syncthreads();
-    float s2 = 0.f, d2 = 0.f;
-#pragma unroll
-    for (int q = 0; q < MT / 64; ++q) { s2 += red[(q * 64 + lane) * 2]; d2 += red[(q * 64 + lane) * 2 + 1]; }
-    const float inv = 1.0f / sqrtf(fmaxf(s2, 1e-12f));
-    const float gp = on ? gout[p] : 0.f;
-    const float A = gp * inv, Bc = gp * l2n_k(s2, inv) * d2;
-    if (wid == 0 && on) { Ap[p] = A; Bp[p] = Bc; gsum += gp; }
-    // G[p][tap] partial over this wave's channels
-    float ga[KK];
-#pragma unroll
-    for (int tap = 0; tap < KK; ++tap) ga[tap] = 0.f;
-    for (int c = wid; c < M; c += MT / 64) {
-      const float* kr = Kl + (size_t)c * RS;
-      float cv = kr[KK];
-#pragma unroll
-      for (int tap = 0; tap < KK; ++tap) cv += kr[tap] * win[tap];
-      const float tmc = kr[KK + 2];
-      const float dv = A * kr[KK + 1] - Bc * cv * tmc;
-      const float dconv = dv * tmc;
-#pragma unroll
-      for (int tap = 0; tap < KK; ++tap) ga[tap] += dconv * kr[tap];
-    }
-    if (on) {
-#pragma unroll
-      for (int tap = 0; tap < KK; ++tap) atomicAdd(&G[p * KK + tap], ga[tap]);   // LDS, 4-way
-    }
+      for (int dx = 0; dx < KS; ++dx) {
+        const int y = py + dy - PAD, x = px + dx - PAD;
+        if (y >= 0 && y < H && x >= 0 && x < W) atomicAdd(gin + y * W + x, ga[dy * KS + dx]);
+      }
   }
-  __syncthreads();
-  // d input map: conv is a cross-correlation, x index = p + tap - PAD
-  {
-    float* gin = g.garena + (size_t)nd.in0 * b.HWp;
-    for (int q = tid; q < HW; q += MT) {
-      const int y = q / W, x = q - (q / W) * W;
-      float s = 0.f;
-#pragma unroll
-      for (int dy = 0; dy < KS; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < KS; ++dx) {
-          const int py = y - dy + PAD, px = x - dx + PAD;
-          if (py >= 0 && py < H && px >= 0 && px < W) s += G[(py * W + px) * KK + dy * KS + dx];
-        }
-      gin[q] = s;
-    }
-  }
-  // ---- pass B: threads = channels ----
+  __syncthreads();                              // Ap / Bp visible
+  // ---- pass B: threads = channels, own pixels ----
   for (int c = tid; c < M; c += MT) {
     const float* kr = Kl + (size_t)c * RS;
     float kreg[KK];
@@ -466,8 +465,8 @@ __device__ void transform_bwd(const ModuleWeights& w, const ModuleBuffers& b, co
 #pragma unroll
     for (int tap = 0; tap < KK; ++tap) dK[tap] = 0.f;
     float dbt = 0.f, dtm = 0.f, dwe = 0.f;
-    for (int p = 0; p < HW; ++p) {
-      const int y = p / W, x = p - (p / W) * W;
+    for (int q = p0; q < p1; ++q) {
+      const int y = q / W, x = q - (q / W) * W;
       float cv = btc;
       float xw[KK];
 #pragma unroll
@@ -477,10 +476,10 @@ __device__ void transform_bwd(const ModuleWeights& w, const ModuleBuffers& b, co
           xw[dy * KS + dx] = xin[(y + dy) * PW + x + dx];       // broadcast read
           cv += kreg[dy * KS + dx] * xw[dy * KS + dx];
         }
-      const float A = Ap[p], Bc = Bp[p];
+      const float Aq = Ap[q - p0], Bq = Bp[q - p0];
       const float v = cv * tmc;
-      const float dv = A * wec - Bc * v;
-      dwe += A * v;                       // g_p * inv_p * v
+      const float dv = Aq * wec - Bq * v;
+      dwe += Aq * v;                      // g_p * inv_p * v
       dtm += dv * cv;
       const float dconv = dv * tmc;
       dbt += dconv;
@@ -491,9 +490,9 @@ __device__ void transform_bwd(const ModuleWeights& w, const ModuleBuffers& b, co
     for (int tap = 0; tap < KK; ++tap) atomicAdd(g.gKt + (size_t)tap * M + c, dK[tap]);
     atomicAdd(g.gbt + c, dbt);
     atomicAdd(g.gwe[2] + c, dwe);
-    g.dtmap[(size_t)nd.tslot * Mp + c] = dtm;
+    atomicAdd(g.dtmap + (size_t)nd.tslot * Mp + c, dtm);
   }
-  const float gs = block_reduce<0>(gsum, scratch);
+  const float gs = block_reduce<0>(wid == 0 ? gp : 0.f, scratch);
   if (tid == 0) atomicAdd(g.gbe[2], gs);
 }
 
@@ -603,10 +602,8 @@ __global__ __launch_bounds__(MT) void att_bwd_kernel(ModuleWeights w, ModuleBuff
       find_epilogue_bwd(w, b, g, nd, node_id, part, nparts, smem);
       break;
     case N2NMN_OP_TRANSFORM:
-      if (part == 0) {
-        if (b.ksize == 5) transform_bwd<5>(w, b, g, nd, node_id, smem);
-        else transform_bwd<3>(w, b, g, nd, node_id, smem);
-      }
+      if (b.ksize == 5) transform_bwd<5>(w, b, g, nd, node_id, part, nparts, smem);
+      else transform_bwd<3>(w, b, g, nd, node_id, part, nparts, smem);
       break;
     case N2NMN_OP_AND:
     case N2NMN_OP_OR: {
@@ -695,7 +692,8 @@ void launch_att_bwd(const ModuleWeights& w, const ModuleBuffers& b, const Module
   const int RS = (KK + 3 + 3) & ~3;
   const int HWq = (HW + 3) & ~3;
   const size_t tr = (size_t)b.M * RS + (((size_t)(b.H + 2 * pad) * (b.W + 2 * pad) + 3) & ~3) +
-                    2 * (size_t)HWq + (((size_t)HW * KK + 3) & ~3) + 4 * 64 * 2 + 16;
+                    2 * 64 + 4 * 64 * 2 + 16;
+  (void)HWq;
   const size_t fe = 8 * (size_t)b.Mp + 16;
   const size_t la = 2 * (size_t)((2 * HW + 4 + 3) & ~3) + ((b.C + 31) & ~31) + 16;
   const size_t smem = sizeof(float) * std::max(tr, std::max(fe, la));
