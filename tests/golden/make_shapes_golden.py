@@ -42,11 +42,9 @@ def main():
         labels=sp['labels'][sel].tolist(), images_u8_b64=b64(sp['images_u8'][sel]),
         images_shape=list(sp['images_u8'][sel].shape), image_mean_b64=b64(sp['image_mean'].astype(np.float32)),
         image_mean_shape=list(sp['image_mean'].shape),
-        unique_layouts=sorted({' '.join(l) for l in (sp['layout_vocab'][t] for t in [])} | set()),
         scores_gt=r_gt['scores'].tolist(), validity_gt=r_gt['validity'].tolist(),
         tokens_free=r_free['dec']['predicted_tokens'].tolist(), validity_free=r_free['validity'].tolist(),
         scores_free=r_free['scores'].tolist(), feat_sum=float(r_gt['feat'].sum()))
-    del out['unique_layouts']
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'shapes_golden.json')
     with open(path, 'w') as f:
         json.dump(out, f)
