@@ -568,9 +568,16 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
             if (!att_done) {            // fc_att weight gradients from the kept pooled features
               att_done = true;
               const int attw[4] = {V_FSP_ATT_W, V_SP_ATT0_W, V_SP_ATT1_W, V_DE_ATT_W};
-              for (int i = 0; i < 4; ++i)
-                gemm_tn(c, sd, t->rec.pooled, D, D, t->dpfc, Mp, M, 2 * p.num_pool, G(attw[i]), M,
-                        nullptr, 1, t->pool_sel, i);
+              if (p.num_pool > 0) {     // the four fc_att weight sets in one launch
+                GemmTnArgs ga{};
+                ga.A = t->rec.pooled; ga.lda = D; ga.M = D; ga.a_group_size = 1;
+                ga.B = t->dpfc; ga.ldb = Mp; ga.N = M; ga.b_sel = t->pool_sel; ga.R = 2 * p.num_pool;
+                ga.ldc = M; ga.nsel = 4;
+                for (int i = 0; i < 4; ++i) { ga.C_sel[i] = G(attw[i]); ga.colsum_sel[i] = nullptr; }
+                ProfScope ps(c, F_GEMM_TN, 2.0 * D * M * 2.0 * p.num_pool,
+                             4.0 * (2.0 * p.num_pool * (D + Mp) + 4.0 * D * M), sd);
+                launch_gemm_tn(ga, sd);
+              }
             }
             if (l.kind == LK_TEXTMAP) {
               {
@@ -579,9 +586,15 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
                 launch_textmap_bwd(w, b, g, l.offset, l.count, s);
               }
               const int txw[5] = {V_FIND_TXT_W, V_FSP_TXT_W, V_TR_TXT_W, V_SP_TXT_W, V_DE_TXT_W};
-              for (int i = 0; i < 5; ++i) {
-                gemm_tn(c, sd, c->word_vecs, E, E, t->dtmap, Mp, M, p.num_text, G(txw[i]), M,
-                        t->tslot_row, 1, t->tslot_ws, i, nullptr, nullptr, G(txw[i] + 1));
+              if (p.num_text > 0) {     // the five fc_text weight sets (+ biases) in one launch
+                GemmTnArgs ga{};
+                ga.A = c->word_vecs; ga.lda = E; ga.M = E; ga.a_group_idx = t->tslot_row;
+                ga.a_group_size = 1; ga.B = t->dtmap; ga.ldb = Mp; ga.N = M; ga.b_sel = t->tslot_ws;
+                ga.R = p.num_text; ga.ldc = M; ga.nsel = 5;
+                for (int i = 0; i < 5; ++i) { ga.C_sel[i] = G(txw[i]); ga.colsum_sel[i] = G(txw[i] + 1); }
+                ProfScope ps(c, F_GEMM_TN, 2.0 * E * M * (double)p.num_text,
+                             4.0 * (p.num_text * (double)(E + Mp) + 5.0 * E * M), sd);
+                launch_gemm_tn(ga, sd);
               }
             } else {
               const bool fsp = l.kind == LK_CONV_FSP;

@@ -221,6 +221,11 @@ struct GemmTnArgs {
   float* C; int ldc;
   float* colsum;                               // optional: colsum[n] += sum_r B[r][n] (the bias
                                                // gradient that goes with dW = X^T . dY), same rows
+  // several row selections in ONE launch (same operands, e.g. the five fc_text weight sets):
+  // selection value v in [0, nsel) writes C_sel[v] / colsum_sel[v]; C / colsum / b_sel_val unused
+  int nsel;
+  float* C_sel[6];
+  float* colsum_sel[6];
 };
 void launch_gemm_tn(const GemmTnArgs& a, hipStream_t s);
 // rows[0 .. *count) = { t*N + n : t < seq_len[n] } in any order; count must be zero on entry

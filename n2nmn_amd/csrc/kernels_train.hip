@@ -45,12 +45,20 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a, int r_per_sp
   const int wm = wid >> 1, wn = wid & 1;
   const int m0 = blockIdx.y * TBM, n0 = blockIdx.x * TBN;
   int Rtot = a.R;
+  // blockIdx.z = split * nsel + selection
+  const int nsel = a.nsel > 0 ? a.nsel : 1;
+  const int zsel = blockIdx.z % nsel, zsplit = blockIdx.z / nsel, nsplit = gridDim.z / nsel;
+  if (a.nsel > 0) {
+    a.b_sel_val = zsel;
+    a.C = a.C_sel[zsel];
+    a.colsum = a.colsum_sel[zsel];
+  }
   if (a.r_dev) {                       // compacted reduction: re-balance the splits on the device
     Rtot = min(a.R, *a.r_dev);
     const int nkt_all = (Rtot + TBK - 1) / TBK;
-    r_per_split = ((nkt_all + gridDim.z - 1) / gridDim.z) * TBK;
+    r_per_split = ((nkt_all + nsplit - 1) / nsplit) * TBK;
   }
-  const int rbeg = blockIdx.z * r_per_split;
+  const int rbeg = zsplit * r_per_split;
   const int rend = min(Rtot, rbeg + r_per_split);
   if (rbeg >= rend) return;
 
@@ -669,14 +677,17 @@ __global__ __launch_bounds__(256) void adam_kernel(const float* __restrict__ gra
 void launch_gemm_tn(const GemmTnArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0 || a.R <= 0) return;
   const int gx = (a.N + TBN - 1) / TBN, gy = (a.M + TBM - 1) / TBM;
-  // split the reduction until the launch has ~6 workgroups per CU (one 64x64 tile keeps a single
-  // wave per SIMD busy, so latency hiding has to come from co-resident workgroups)
+  // split the reduction until the launch has ~4 workgroups per CU (one 64x64 tile keeps a single
+  // wave per SIMD busy, so latency hiding comes from co-resident workgroups), but keep >= 4 k-tiles
+  // per split: every split costs M*N atomic adds.  A/B on one box: 3.09-3.14 ms per training step
+  // with this rule, 3.23 with "1536 workgroups, >= 2 k-tiles", 3.13 with "768, >= 8".
   int splits = 1;
   const int nkt = (a.R + TBK - 1) / TBK;
-  while (gx * gy * splits < 1536 && splits * 2 <= nkt / 4) splits *= 2;
+  const int nsel = a.nsel > 0 ? a.nsel : 1;
+  while (gx * gy * nsel * splits < 1024 && nkt / (splits * 2) >= 4) splits *= 2;
   int r_per = ((nkt + splits - 1) / splits) * TBK;
   splits = (a.R + r_per - 1) / r_per;
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(gx, gy, splits), dim3(256), 0, s, a, r_per);
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(gx, gy, splits * nsel), dim3(256), 0, s, a, r_per);
 }
 
 void launch_active_rows(const int32_t* seq_len, int T, int N, int32_t* rows, int32_t* count,
