@@ -423,8 +423,15 @@ int n2nmn_train_forward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* p
     rc = repack_transposed(c, s);
     if (rc != N2NMN_OK) return rc;
   }
-  // slot 0 of the kept encoder sequences (the zero initial state) was cleared by train_enable and
-  // is never written again
+  // slot 0 of the kept encoder sequences is the zero initial state.  Slot strides follow the actual
+  // batch size, so a previous call with another N has written through what is slot 0 now: clear it
+  // whenever the shape changes (otherwise it is never written)
+  if (t->last_N != N) {
+    N2_HIP(hipMemsetAsync(t->rec.ec0s, 0, sizeof(float) * nl, s));
+    N2_HIP(hipMemsetAsync(t->rec.ec1s, 0, sizeof(float) * nl, s));
+    N2_HIP(hipMemsetAsync(t->rec.eh0s, 0, sizeof(float) * nl, s));
+    N2_HIP(hipMemsetAsync(t->rec.eh1s, 0, sizeof(float) * nl, s));
+  }
   n2nmn_seq2seq_io sio{};
   sio.input_seq = io->input_seq; sio.seq_length = io->seq_length; sio.T_enc = io->T_enc; sio.N = N;
   sio.T_dec = io->T_dec; sio.use_gt_layout = 1; sio.gt_layout = io->gt_layout;

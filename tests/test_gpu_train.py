@@ -165,3 +165,65 @@ def test_adam_steps_match_oracle_formula(trainer_setup):
         for k in cur:
             assert_close('adam[%d] %s' % (step, k), got[k], cur[k], 2e-6)
     assert loss < first_loss          # the objective goes down on a repeated batch
+
+
+def test_gradient_is_invariant_to_question_order(trainer_setup):
+    """size-independent property at the full config-4 size (no oracle involved): the losses are
+    batch means, so permuting the questions of a batch must leave every gradient unchanged up to
+    fp32 summation order (this also moves every question to a different row block / length rank)."""
+    tr, eng, d, asm, w = trainer_setup
+    eng.load_weights(w)
+    batch = synth.make_inputs(d, seed=11, min_len=1)
+    # templates without And / Or / Filter: with the synthetic weights their two candidates nearly
+    # coincide, so fp32 summation order alone can flip the selected branch (see _check)
+    from n2nmn_amd.spec import CLEVR_LAYOUT_TEMPLATES
+    keep = [tpl for tpl in CLEVR_LAYOUT_TEMPLATES if not {'_And', '_Or', '_Filter'} & set(tpl)]
+    gt = np.array([synth.module_list2tokens(keep[i % len(keep)], d.T_decoder) for i in range(d.N)],
+                  np.int32).T
+    tr.forward_backward(batch, gt, reduce=False)
+    g0 = t2n(tr.grads).copy()
+    l0 = t2n(tr.losses).copy()
+    perm = np.random.default_rng(0).permutation(d.N)
+    pb = {k: (v[:, perm] if k == 'input_seq_batch' else v[perm]) for k, v in batch.items()}
+    tr.forward_backward(pb, gt[:, perm], reduce=False)
+    g1 = t2n(tr.grads)
+    assert np.abs(t2n(tr.losses) - l0).max() <= 1e-5 * np.abs(l0).max()
+    for name, (off, n, shape) in tr.layout.items():
+        a, b = g0[off:off + n], g1[off:off + n]
+        assert np.abs(a - b).max() <= 2e-4 * np.abs(a).max() + 1e-7, name
+
+
+def test_single_question_and_full_length_batches(trainer_setup):
+    """N = 1 (one 16-row MFMA tile mostly empty) and a batch where no row is ever masked; going
+    from a small batch to a larger one also checks that nothing kept from the previous call (the
+    activation sequences are laid out with the call's own batch stride) leaks into the next."""
+    tr, eng, d, asm, w = trainer_setup
+    one = Dims(T_decoder=10, N=1)
+    b1 = synth.make_inputs(one, seed=3, min_len=7)
+    _check(tr, d, w, b1, synth.template_layout_batch(one, offset=4))   # _Find _FindSameProperty _Count
+    full = Dims(T_decoder=10, N=20)
+    b2 = synth.make_inputs(full, seed=5, min_len=full.T_encoder)        # every length == T_enc
+    assert (b2['seq_length_batch'] == full.T_encoder).all()
+    _check(tr, d, w, b2, synth.template_layout_batch(full, offset=2))
+
+
+def test_training_api_errors(trainer_setup):
+    import ctypes as C
+    from n2nmn_amd import _lib
+    from n2nmn_amd.engine import Engine
+    tr, eng, d, asm, w = trainer_setup
+    # a fork cannot train; a context without train_enable rejects the training entries
+    with pytest.raises(ValueError):
+        from n2nmn_amd.train import Trainer
+        Trainer(eng.fork())
+    e2 = Engine(Dims(T_decoder=10, N=4), asm)
+    e2.load_weights(w)
+    io = _lib.TrainIO()
+    rc = e2._lib.n2nmn_train_forward(e2._ctx, C.byref(io), None, None)
+    assert rc < 0 and b'train_forward' in e2._lib.n2nmn_last_error()
+    assert e2._lib.n2nmn_grad_numel(e2._ctx) < 0
+    # program assembled from another batch size
+    batch = synth.make_inputs(d, seed=1)
+    gt_small = synth.template_layout_batch(Dims(T_decoder=10, N=8))
+    with pytest.raises(ValueError):
+        tr.forward_backward(batch, gt_small, reduce=False)
