@@ -304,6 +304,12 @@ def main():
     engines = [eng] + [eng.fork() for _ in range(S - 1)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [None]
 
+    def set_mode(mode):
+        for e in engines:
+            e.set_mode(mode)
+
+    set_mode('throughput' if S > 1 else 'latency')
+
     def step(i, e=eng):
         b = batches[i % n_batches]
         return e.forward(b, use_gt_layout=use_gt, gt_layout=gts[i % n_batches] if use_gt else None)
@@ -358,12 +364,14 @@ def main():
                                     'decoder', d.N),
                        'global_batch': world * d.N, 'parallelism': 'dp%d (question-sharded, no '
                        'data-path collective)' % world, 'streams_per_gpu': S,
+                       'lstm_tile_mode': 'throughput (32x32)' if S > 1 else 'latency (64x16)',
                        'host_sync': 'predicted_tokens D2H between phase 1 and phase 2'},
         }
 
     # ---- the same workload with ONE batch in flight (latency-oriented number)
     if rank == 0 and S > 1:
         S_saved, S = S, 1
+        set_mode('latency')
         n1 = min(args.steps, 100)
         run_steps(0, 10)
         torch.cuda.synchronize(dev)

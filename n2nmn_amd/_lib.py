@@ -60,6 +60,7 @@ SYMBOLS = [
     ('n2nmn_ctx_fork', _I, [_P, C.POINTER(_P)]),
     ('n2nmn_ctx_destroy', _I, [_P]),
     ('n2nmn_ctx_dims', _I, [_P, C.POINTER(Dims)]),
+    ('n2nmn_ctx_set_mode', _I, [_P, _I]),
     ('n2nmn_set_weight', _I, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), _I]),
     ('n2nmn_commit_weights', _I, [_P, _P]),
     ('n2nmn_set_validity_tables', _I, [_P, _P, _P, _P]),

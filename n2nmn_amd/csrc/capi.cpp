@@ -304,7 +304,7 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s) {
       const double by = 4.0 * ((j0.active ? (double)L * 4 * L + 3.0 * N * L : 0) +
                                (j1.active ? 2.0 * L * 4 * L + 5.0 * N * L : 0));
       ProfScope ps(c, F_LSTM_ENC, fl, by, s);
-      launch_lstm_step(jobs, 2, N, L, 64, s);
+      launch_lstm_step(jobs, 2, N, L, 64, s, c->mode == N2NMN_MODE_THROUGHPUT);
     }
   }
   // encoder_h_transformed = fc(encoder_outputs)          (nmn3_netgen_att.py:102-106)
@@ -397,7 +397,7 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s) {
       }
       ProfScope ps(c, F_LSTM_DEC0, (j0.active ? fl0 : 0) + (j1.active ? fl1 : 0),
                    (j0.active ? by0 : 0) + (j1.active ? by1 : 0), s);
-      launch_lstm_step(jobs, 2, N, L, 64, s);
+      launch_lstm_step(jobs, 2, N, L, 64, s, c->mode == N2NMN_MODE_THROUGHPUT);
     }
     LstmJob jq{};                      // q = out . W_a + b_a for all steps  (nmn3_netgen_att.py:185)
     rowmajor_a(c, jq);
@@ -747,6 +747,14 @@ int n2nmn_ctx_destroy(n2nmn_ctx* ctx) {
   if (ctx->train) train_state_destroy(ctx->train);
   n2nmn_program_destroy(ctx->scratch_prog);
   delete ctx;
+  return N2NMN_OK;
+}
+
+int n2nmn_ctx_set_mode(n2nmn_ctx* ctx, int mode) {
+  N2_REQUIRE(ctx, N2NMN_EINVAL, "ctx_set_mode: null context");
+  N2_REQUIRE(mode == N2NMN_MODE_LATENCY || mode == N2NMN_MODE_THROUGHPUT, N2NMN_EINVAL,
+             "ctx_set_mode: unknown mode");
+  ctx->mode = mode;
   return N2NMN_OK;
 }
 

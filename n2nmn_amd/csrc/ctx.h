@@ -118,6 +118,7 @@ struct n2nmn_ctx {
   std::unordered_map<std::string, int> index;
   bool committed = false;
   bool have_tables = false;
+  int mode = 0;                            // N2NMN_MODE_*: tile shape of the recurrent step kernels
 
   char* base = nullptr;        // weight store (owned by the root context only)
   size_t bytes = 0;

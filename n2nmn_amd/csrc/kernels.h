@@ -97,8 +97,9 @@ struct LstmJob {
   float* save_h;          // [N][L] hidden state after this step (row-major)
 };
 // rows_per_wg: 64 (4 M-tiles per workgroup) or 32 (2 M-tiles; doubles the workgroups of a launch)
+// wide != 0: 32-row x 32-column workgroup tiles for LSTM cell jobs (throughput mode)
 void launch_lstm_step(const LstmJob* jobs, int njobs, int N, int L, int rows_per_wg,
-                      hipStream_t s);
+                      hipStream_t s, int wide = 0);
 
 // Arguments of dec_attn_kernel.  Every per-step pointer is the slice of the FIRST step of the
 // launch; workgroup (n, ts) addresses element ts*N + n of it.

@@ -256,6 +256,155 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_kernel(LstmJobs jobs, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// lstm_step_wide_kernel: the same step with a 32-row x 32-gate-column (8 hidden units) workgroup
+// tile instead of 64 x 16.  Same number of workgroups and MFMAs per workgroup, but the operand
+// bytes a workgroup streams scale with rows + columns (64 vs 80 per k), i.e. 20 % less L2 traffic;
+// a wave issues 4 operand loads per 16 MFMAs instead of 5.  LSTM cell jobs only (mode 0).
+// ---------------------------------------------------------------------------------------------
+template <int NCH, int NA>
+__device__ __forceinline__ void lstm_mma_wide(const LstmJob& jb, int N, int L, int pair, int row0,
+                                              f32x4 (*acc)[2]) {
+  const int lane = threadIdx.x & 63;
+  const int w = ((threadIdx.x >> 6) + pair) & (LSTM_WAVES - 1);
+  const int rot = (pair >> 3) & (NCH - 1);
+  const int ci = lane & 15, kg = lane >> 4;
+  const int K = jb.K;
+  const int kbeg = w * (NCH * 16);
+  const float* Asrc = (kbeg < L) ? jb.A0 : jb.A1;
+  const int kloc = (kbeg < L) ? kbeg : kbeg - L;
+  const size_t tstride = (size_t)(K / 4) * 16;          // float4 per column tile
+  const float4* Wp4 = reinterpret_cast<const float4*>(jb.Wp) + (size_t)(2 * pair) * tstride +
+                      (size_t)((kbeg >> 2) + kg) * 16 + ci;
+  float4 bq[NCH][2];
+  float4 aq[NCH][NA];
+  const float* ar[NA];
+#pragma unroll
+  for (int m = 0; m < NA; ++m) {
+    int r = row0 + 16 * m + ci;
+    r = r < N ? r : N - 1;
+    ar[m] = Asrc + (size_t)r * jb.a_rs + (size_t)((kloc >> 2) + kg) * jb.a_ks;
+  }
+#pragma unroll
+  for (int kc = 0; kc < NCH; ++kc) {
+    const int kq = (kc + rot) & (NCH - 1);
+    bq[kc][0] = Wp4[(size_t)kq * 64];
+    bq[kc][1] = Wp4[tstride + (size_t)kq * 64];
+#pragma unroll
+    for (int m = 0; m < NA; ++m)
+      aq[kc][m] = *reinterpret_cast<const float4*>(ar[m] + (size_t)(4 * kq) * jb.a_ks);
+  }
+#pragma unroll
+  for (int kc = 0; kc < NCH; ++kc) {
+#pragma unroll
+    for (int m = 0; m < NA; ++m) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[kc][m].x, bq[kc][j].x, acc[m][j], 0, 0, 0);
+        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[kc][m].y, bq[kc][j].y, acc[m][j], 0, 0, 0);
+        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[kc][m].z, bq[kc][j].z, acc[m][j], 0, 0, 0);
+        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[kc][m].w, bq[kc][j].w, acc[m][j], 0, 0, 0);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(LSTM_THREADS) void lstm_step_wide_kernel(LstmJobs jobs, int N, int L) {
+  const LstmJob& jb = jobs.j[blockIdx.y];
+  if (!jb.active) return;
+  const int pair = blockIdx.x;                  // column tiles 2*pair, 2*pair + 1
+  if (2 * pair >= jb.ntiles) return;
+  constexpr int MT = 2, ROWS = 32;
+  __shared__ float part[LSTM_WAVES][ROWS][33];
+  const int row0 = blockIdx.z * ROWS;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int ci = lane & 15, kg = lane >> 4;
+  const int nact = jb.n_active ? *jb.n_active : N;
+
+  // ---- epilogue operands (thread = (row, unit) for tid < 8*ROWS) --------------------------------
+  const int erow = tid >> 3, ul8 = tid & 7;
+  const int tloc = ul8 >> 2, ul = ul8 & 3;
+  const int tile = 2 * pair + tloc;
+  const int gr = row0 + erow;
+  const bool eact = tid < 8 * ROWS && gr < N;
+  const int orow = (eact && jb.perm) ? jb.perm[gr] : gr;
+  float add[4] = {0.f, 0.f, 0.f, 0.f};
+  float c_old = 0.f, h_prev = 0.f;
+  bool masked = false;
+  if (eact) {
+    const int u = 4 * tile + ul;
+    if (jb.xtab) {
+      const int xi = jb.xidx ? jb.xidx[orow] : jb.xidx_const;
+      const float* xr = jb.xtab + (size_t)xi * 4 * L + u;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) add[g] = xr[g * L];
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) add[g] = jb.bias[g * L + u];
+    }
+    const size_t idx = (size_t)gr * L + u;
+    c_old = jb.c_in[idx];
+    if (jb.seq_len && jb.t >= jb.seq_len[orow]) {
+      masked = true;
+      h_prev = jb.h_old[jb.hp_R > 0 ? ((size_t)tile * jb.hp_R + gr) * 4 + ul : idx];
+    }
+  }
+
+  f32x4 acc[MT][2];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nch = jb.K / (LSTM_WAVES * 16);
+  int na = (nact - row0 + 15) >> 4;
+  na = na < 0 ? 0 : (na > MT ? MT : na);
+  if (nch == 4) {
+    if (na == 2) lstm_mma_wide<4, 2>(jb, N, L, pair, row0, acc);
+    else if (na == 1) lstm_mma_wide<4, 1>(jb, N, L, pair, row0, acc);
+  } else {
+    if (na == 2) lstm_mma_wide<8, 2>(jb, N, L, pair, row0, acc);
+    else if (na == 1) lstm_mma_wide<8, 1>(jb, N, L, pair, row0, acc);
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[w][16 * m + 4 * kg + r][16 * j + ci] = acc[m][j][r];
+  __syncthreads();
+
+  if (eact) {
+    float z[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float s = add[g];
+#pragma unroll
+      for (int ww = 0; ww < LSTM_WAVES; ++ww) s += part[ww][erow][16 * tloc + g * 4 + ul];
+      z[g] = s;
+    }
+    const size_t idx = (size_t)gr * L + 4 * tile + ul;
+    const float gi = fast_sigmoid(z[0]), gj = fast_tanh(z[1]), gf = fast_sigmoid(z[2] + 1.0f),
+                go = fast_sigmoid(z[3]);
+    float c_new = c_old * gf + gi * gj;
+    float h_new = fast_tanh(c_new) * go;
+    float o = h_new;
+    if (masked) { c_new = c_old; h_new = h_prev; o = 0.f; }
+    jb.c_out[idx] = c_new;
+    jb.h_new[jb.hp_R > 0 ? ((size_t)tile * jb.hp_R + gr) * 4 + ul : idx] = h_new;
+    const size_t oidx = (size_t)orow * L + 4 * tile + ul;
+    if (jb.save_gates) {
+      jb.save_gates[oidx] = make_float4(gi, gj, gf, go);
+      jb.save_c[oidx] = c_new;
+      jb.save_h[oidx] = h_new;
+    }
+    if (jb.out_seq) jb.out_seq[oidx] = o;
+    if (jb.fin_c && jb.seq_len && jb.t == jb.seq_len[orow] - 1) {
+      jb.fin_c[oidx] = c_new;
+      jb.fin_h[((size_t)tile * jb.hp_R + orow) * 4 + ul] = h_new;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // dec_attn_kernel: everything of a decoder step after the LSTM cell, one workgroup per
 // (question n, step t = blockIdx.y) (nmn3_netgen_att.py:184-268):
 //   additive attention over the encoder steps, masked renormalised softmax, context vector,
@@ -562,14 +711,25 @@ __global__ __launch_bounds__(256) void word_vecs_kernel(const float* __restrict_
 }  // namespace
 
 void launch_lstm_step(const LstmJob* jobs, int njobs, int N, int L, int rows_per_wg,
-                      hipStream_t s) {
+                      hipStream_t s, int wide) {
   LstmJobs js;
   for (int i = 0; i < 2; ++i) {
     if (i < njobs) js.j[i] = jobs[i];
     else { js.j[i] = LstmJob{}; js.j[i].active = 0; }
   }
   int nt = 0;
-  for (int i = 0; i < njobs; ++i) nt = jobs[i].ntiles > nt ? jobs[i].ntiles : nt;
+  bool cells = true;
+  for (int i = 0; i < njobs; ++i) {
+    nt = jobs[i].ntiles > nt ? jobs[i].ntiles : nt;
+    const int nch = jobs[i].K / (LSTM_WAVES * 16);
+    cells = cells && jobs[i].mode == 0 && jobs[i].ntiles % 2 == 0 && (nch == 4 || nch == 8) &&
+            jobs[i].K % (LSTM_WAVES * 16) == 0;
+  }
+  if (wide && cells) {
+    dim3 grid(nt / 2, njobs, (N + 31) / 32);
+    hipLaunchKernelGGL(lstm_step_wide_kernel, grid, dim3(LSTM_THREADS), 0, s, js, N, L);
+    return;
+  }
   if (rows_per_wg == 32) {
     dim3 grid(nt, njobs, (N + 31) / 32);
     hipLaunchKernelGGL((lstm_step_kernel<2, 0>), grid, dim3(LSTM_THREADS), 0, s, js, N, L);

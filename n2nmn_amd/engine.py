@@ -54,6 +54,11 @@ class Engine:
             except Exception:
                 pass
 
+    def set_mode(self, mode: str):
+        """'latency' (default) or 'throughput': workgroup tile shape of the recurrent step kernels
+        (n2nmn_ctx_set_mode) -- use 'throughput' when several batches are in flight on forks."""
+        _lib.check(self._lib.n2nmn_ctx_set_mode(self._ctx, {'latency': 0, 'throughput': 1}[mode]))
+
     def fork(self) -> 'Engine':
         """A sibling engine sharing this engine's weights with its own workspace, for running
         another batch concurrently on another stream / host thread."""

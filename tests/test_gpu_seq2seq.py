@@ -140,3 +140,32 @@ def test_capacity_and_argument_errors(clevr_engine):
     batch = synth.make_inputs(d, seed=1, n=4)
     with pytest.raises(ValueError):
         eng.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], use_gt_layout=True)
+
+
+@pytest.mark.parametrize('n,seed', [(64, 10), (37, 11), (3, 12)])
+def test_throughput_mode_tiles(clevr_engine, n, seed):
+    """N2NMN_MODE_THROUGHPUT switches the recurrent step kernels to 32-row x 32-column workgroup
+    tiles (lstm_step_wide_kernel): encoder, final states and the teacher-forced decoder must match the
+    oracle exactly as in the default mode (ragged lengths, partial row blocks, N < 16)."""
+    eng, d, asm, w = clevr_engine
+    batch = synth.make_inputs(d, seed=seed, n=n, min_len=1)
+    gt = synth.template_layout_batch(d, n=n, offset=seed)
+    eng.set_mode('throughput')
+    try:
+        out = eng.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], use_gt_layout=True,
+                          gt_layout=gt, debug=True)
+        enc = _oracle_enc(w, batch)
+        assert_close('encoder_outputs', t2n(out['encoder_outputs']), enc['outputs'], TOL)
+        st = t2n(out['encoder_states'])
+        for l in range(2):
+            assert_close('c%d' % l, st[l, 0], enc['states'][l][0], TOL)
+            assert_close('h%d' % l, st[l, 1], enc['states'][l][1], TOL)
+        P, Wv, bv = O.build_validity_mats(list(asm.module_names))
+        dec = O.decoder_forward(w, enc, P, Wv, bv, d.T_decoder, np.float64, use_gt_layout=True,
+                                gt_layout=gt)
+        _check_decoder(out, dec, d)
+    finally:
+        eng.set_mode('latency')
+    from n2nmn_amd import _lib
+    with pytest.raises(ValueError):
+        _lib.check(eng._lib.n2nmn_ctx_set_mode(eng._ctx, 7))
