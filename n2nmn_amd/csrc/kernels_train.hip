@@ -38,7 +38,7 @@ __device__ __forceinline__ float fast_tanh(float x) {
 constexpr int TBM = 64, TBN = 64, TBK = 32;
 constexpr int TLDS = TBM + 1;   // float4 units
 
-__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a, int r_per_split) {
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTnArgs a, int r_per_split) {
   __shared__ float4 As[2][TBK / 4][TLDS];
   __shared__ float4 Bs[2][TBK / 4][TLDS];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -48,11 +48,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a, int r_per_sp
   // blockIdx.z = split * nsel + selection
   const int nsel = a.nsel > 0 ? a.nsel : 1;
   const int zsel = blockIdx.z % nsel, zsplit = blockIdx.z / nsel, nsplit = gridDim.z / nsel;
-  if (a.nsel > 0) {
-    a.b_sel_val = zsel;
-    a.C = a.C_sel[zsel];
-    a.colsum = a.colsum_sel[zsel];
-  }
+  // (the argument block is never written: a modified by-value struct is copied to scratch memory)
+  const int b_sel_val = a.nsel > 0 ? zsel : a.b_sel_val;
+  float* const Cout = a.nsel > 0 ? a.C_sel[zsel] : a.C;
+  float* const colsum_out = a.nsel > 0 ? a.colsum_sel[zsel] : a.colsum;
   if (a.r_dev) {                       // compacted reduction: re-balance the splits on the device
     Rtot = min(a.R, *a.r_dev);
     const int nkt_all = (Rtot + TBK - 1) / TBK;
@@ -76,7 +75,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a, int r_per_sp
 
   // bias gradient riding along: the workgroups of the first row of output tiles also sum the B
   // columns they stream (every B tile is loaded exactly once per workgroup)
-  const bool do_cs = a.colsum != nullptr && blockIdx.y == 0;
+  const bool do_cs = colsum_out != nullptr && blockIdx.y == 0;
   float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 reg[4];
   auto gload = [&](int kt) {
@@ -88,7 +87,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a, int r_per_sp
       if (a.row_idx) src = a.row_idx[src];
       bool sel_ok = true;
       if (isB) {
-        if (a.b_sel) sel_ok = a.b_sel[src] == a.b_sel_val;
+        if (a.b_sel) sel_ok = a.b_sel[src] == b_sel_val;
       } else if (a.a_onehot) {          // A[r][m] = (a_onehot[r] == m): no operand in memory
         const int hot = a.a_onehot[src];
         reg[j].x = (rok && hot == cbeg + 0) ? 1.f : 0.f;
@@ -147,7 +146,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a, int r_per_sp
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-      if (row < a.M) atomicAdd(a.C + (size_t)row * a.ldc + col, acc[r]);
+      if (row < a.M) atomicAdd(Cout + (size_t)row * a.ldc + col, acc[r]);
     }
   }
   if (do_cs) {                      // uniform per workgroup; the k-loop ended with a barrier
@@ -158,7 +157,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a, int r_per_sp
       float t = 0.f;
 #pragma unroll
       for (int q = 0; q < TBK / 4; ++q) t += red[q * 64 + tid];
-      atomicAdd(a.colsum + n0 + tid, t);
+      atomicAdd(colsum_out + n0 + tid, t);
     }
   }
 }
