@@ -220,6 +220,26 @@ int gemm_tn(n2nmn_ctx* c, hipStream_t s, const float* A, int lda, int M, const f
   return N2NMN_OK;
 }
 
+// nprob weight-gradient GEMMs of one shape (M, N, R, strides, row list) in one launch
+struct TnProblem { const float* A; const float* B; float* C; float* colsum; };
+void gemm_tn_batch(n2nmn_ctx* c, hipStream_t s, int nprob, const TnProblem* pr, int lda, int M,
+                   int ldb, int N, int R, int ldc, const int32_t* row_idx = nullptr,
+                   const int32_t* r_dev = nullptr) {
+  if (R <= 0 || nprob <= 0) return;
+  GemmTnArgs g{};
+  g.row_idx = row_idx; g.r_dev = r_dev;
+  g.lda = lda; g.M = M; g.a_group_size = 1; g.ldb = ldb; g.N = N; g.R = R; g.ldc = ldc;
+  g.nprob = nprob;
+  for (int i = 0; i < nprob; ++i) {
+    g.A_p[i] = pr[i].A; g.B_p[i] = pr[i].B; g.C_p[i] = pr[i].C; g.colsum_p[i] = pr[i].colsum;
+    g.bsel_p[i] = 0;
+  }
+  g.A = pr[0].A; g.B = pr[0].B;
+  ProfScope ps(c, F_GEMM_TN, 2.0 * M * N * R * nprob,
+               4.0 * nprob * ((double)R * (M + N) + (double)M * N), s);
+  launch_gemm_tn(g, s);
+}
+
 // C (+)= A[M,K] . Bp   (NT GEMMs of the backward pass go through the forward gemm_pk kernel)
 void gemm_nt(n2nmn_ctx* c, hipStream_t s, const float* A, int lda, int M, int K, const float* Bp,
              int Np, int Kp, int N, float* C, int ldc, bool accumulate) {
@@ -579,8 +599,11 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
                 GemmTnArgs ga{};
                 ga.A = t->rec.pooled; ga.lda = D; ga.M = D; ga.a_group_size = 1;
                 ga.B = t->dpfc; ga.ldb = Mp; ga.N = M; ga.b_sel = t->pool_sel; ga.R = 2 * p.num_pool;
-                ga.ldc = M; ga.nsel = 4;
-                for (int i = 0; i < 4; ++i) { ga.C_sel[i] = G(attw[i]); ga.colsum_sel[i] = nullptr; }
+                ga.ldc = M; ga.nprob = 4;
+                for (int i = 0; i < 4; ++i) {
+                  ga.A_p[i] = ga.A; ga.B_p[i] = ga.B; ga.bsel_p[i] = i;
+                  ga.C_p[i] = G(attw[i]); ga.colsum_p[i] = nullptr;
+                }
                 ProfScope ps(c, F_GEMM_TN, 2.0 * D * M * 2.0 * p.num_pool,
                              4.0 * (2.0 * p.num_pool * (D + Mp) + 4.0 * D * M), sd);
                 launch_gemm_tn(ga, sd);
@@ -597,8 +620,11 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
                 GemmTnArgs ga{};
                 ga.A = c->word_vecs; ga.lda = E; ga.M = E; ga.a_group_idx = t->tslot_row;
                 ga.a_group_size = 1; ga.B = t->dtmap; ga.ldb = Mp; ga.N = M; ga.b_sel = t->tslot_ws;
-                ga.R = p.num_text; ga.ldc = M; ga.nsel = 5;
-                for (int i = 0; i < 5; ++i) { ga.C_sel[i] = G(txw[i]); ga.colsum_sel[i] = G(txw[i] + 1); }
+                ga.R = p.num_text; ga.ldc = M; ga.nprob = 5;
+                for (int i = 0; i < 5; ++i) {
+                  ga.A_p[i] = ga.A; ga.B_p[i] = ga.B; ga.bsel_p[i] = i;
+                  ga.C_p[i] = G(txw[i]); ga.colsum_p[i] = G(txw[i] + 1);
+                }
                 ProfScope ps(c, F_GEMM_TN, 2.0 * E * M * (double)p.num_text,
                              4.0 * (p.num_text * (double)(E + Mp) + 5.0 * E * M), sd);
                 launch_gemm_tn(ga, sd);
@@ -655,9 +681,9 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
     const int RT = Td * N;
     {
       hipStream_t sd = t->fork(s);     // token / attention projection gradients: leaves
-      gemm_tn(c, sd, c->dec_h1_all, L, L, t->dsc, 16, V, RT, G(V_TOK_W), V, nullptr, 1, nullptr, 0,
-              nullptr, nullptr, G(V_TOK_B));
-      gemm_tn(c, sd, t->rec.ctx, L, L, t->dsc, 16, V, RT, G(V_TOK_W) + (size_t)L * V, V);
+      const TnProblem tok[2] = {{c->dec_h1_all, t->dsc, G(V_TOK_W), G(V_TOK_B)},
+                                {t->rec.ctx, t->dsc, G(V_TOK_W) + (size_t)L * V, nullptr}};
+      gemm_tn_batch(c, sd, 2, tok, L, L, 16, V, RT, V);
       colsum(c, sd, t->dvp, RT, L, L, G(V_ATT_V));
       gemm_tn(c, sd, c->dec_h1_all, L, L, t->dq, L, L, RT, G(V_ATT_W), L, nullptr, 1, nullptr, 0,
               nullptr, nullptr, G(V_ATT_B));
@@ -684,10 +710,15 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
     gemm_nt(c, s, t->dxtab_dec, 4 * L, V, 4 * L, t->dec_W0xT_p, Ep, t->KpL4, E, G(V_DEC_EMB), E, true);
     gemm_nt(c, s, t->dxtab_dec + (size_t)V * 4 * L, 4 * L, 1, 4 * L, t->dec_W0xT_p, Ep, t->KpL4, E,
             G(V_DEC_GO), E, true);
-    gemm_tn(c, s, t->rec.dh0s, L, L, t->dz0_all, 4 * L, 4 * L, RT, G(V_DEC_W0) + (size_t)E * 4 * L, 4 * L);
-    gemm_tn(c, s, t->rec.dh0s + (size_t)N * L, L, L, t->dz1_all, 4 * L, 4 * L, RT, G(V_DEC_W1), 4 * L,
-            nullptr, 1, nullptr, 0, nullptr, nullptr, G(V_DEC_B1));
-    gemm_tn(c, s, t->rec.dh1s, L, L, t->dz1_all, 4 * L, 4 * L, RT, G(V_DEC_W1) + (size_t)L * 4 * L, 4 * L);
+    {
+      // the three recurrent weight gradients of the stack, one launch: W0 (h part) = h0(t-1)^T dz0,
+      // W1 = [h0(t) ; h1(t-1)]^T dz1 (+ b1)
+      const TnProblem dw[3] = {
+          {t->rec.dh0s, t->dz0_all, G(V_DEC_W0) + (size_t)E * 4 * L, nullptr},
+          {t->rec.dh0s + (size_t)N * L, t->dz1_all, G(V_DEC_W1), G(V_DEC_B1)},
+          {t->rec.dh1s, t->dz1_all, G(V_DEC_W1) + (size_t)L * 4 * L, nullptr}};
+      gemm_tn_batch(c, s, 3, dw, L, L, 4 * L, 4 * L, RT, 4 * L);
+    }
     t->join(s);                        // decoder + module gradients complete from here on
     {
       ProfScope ps(c, F_OPTIMISER, 3.0 * (t->total - t->split), 4.0 * 3 * (t->total - t->split), s);
@@ -727,12 +758,11 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
       ProfScope ps(c, F_GEMM_TN, 2.0 * Vt * 4.0 * L * RT, 4.0 * ((double)RT * 4 * L + Vt * 4.0 * L), s);
       launch_gemm_tn(g1, s);
     }
-    gemm_tn(c, s, t->rec.eh0s, L, L, t->dz0_all, 4 * L, 4 * L, RT, G(V_ENC_W0) + (size_t)E * 4 * L,
-            4 * L, nullptr, 1, nullptr, 0, rows, cnt);
-    gemm_tn(c, s, t->rec.eh0s + (size_t)N * L, L, L, t->dz1_all, 4 * L, 4 * L, RT, G(V_ENC_W1), 4 * L,
-            nullptr, 1, nullptr, 0, rows, cnt, G(V_ENC_B1));
-    gemm_tn(c, s, t->rec.eh1s, L, L, t->dz1_all, 4 * L, 4 * L, RT, G(V_ENC_W1) + (size_t)L * 4 * L,
-            4 * L, nullptr, 1, nullptr, 0, rows, cnt);
+    const TnProblem dw[3] = {
+        {t->rec.eh0s, t->dz0_all, G(V_ENC_W0) + (size_t)E * 4 * L, nullptr},
+        {t->rec.eh0s + (size_t)N * L, t->dz1_all, G(V_ENC_W1), G(V_ENC_B1)},
+        {t->rec.eh1s, t->dz1_all, G(V_ENC_W1) + (size_t)L * 4 * L, nullptr}};
+    gemm_tn_batch(c, s, 3, dw, L, L, 4 * L, 4 * L, RT, 4 * L, rows, cnt);
   }
   gemm_tn(c, s, mir(V_ENC_EMB), E, E, t->dxtab_enc, 4 * L, 4 * L, Vt, G(V_ENC_W0), 4 * L,
           nullptr, 1, nullptr, 0, nullptr, nullptr, G(V_ENC_B0));

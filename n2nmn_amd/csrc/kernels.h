@@ -222,11 +222,18 @@ struct GemmTnArgs {
   float* C; int ldc;
   float* colsum;                               // optional: colsum[n] += sum_r B[r][n] (the bias
                                                // gradient that goes with dW = X^T . dY), same rows
-  // several row selections in ONE launch (same operands, e.g. the five fc_text weight sets):
-  // selection value v in [0, nsel) writes C_sel[v] / colsum_sel[v]; C / colsum / b_sel_val unused
-  int nsel;
-  float* C_sel[6];
-  float* colsum_sel[6];
+  // several problems of the same shape in ONE launch (the launch fills the chip with fewer splits
+  // of the reduction, hence fewer atomic adds, and pays its fixed latencies once): problem p in
+  // [0, nprob) uses A_p / B_p / C_p / colsum_p / bsel_p[p] instead of A / B / C / colsum /
+  // b_sel_val; everything else is shared.  The same operands with bsel_p[p] = p is "several row
+  // selections" (e.g. the five fc_text weight sets); distinct operands is a batch of GEMMs (e.g.
+  // the three recurrent weight gradients of an LSTM stack).  nprob = 0: one problem.
+  int nprob;
+  const float* A_p[6];
+  const float* B_p[6];
+  float* C_p[6];
+  float* colsum_p[6];
+  int bsel_p[6];
 };
 void launch_gemm_tn(const GemmTnArgs& a, hipStream_t s);
 // rows[0 .. *count) = { t*N + n : t < seq_len[n] } in any order; count must be zero on entry

@@ -14,6 +14,7 @@
 //   word_vecs_bwd  : gradient of the text-attention word vectors
 //   loss, grad_finish, grad_sqnorm, adam : objective and optimiser (clip_by_norm + Adam)
 #include <algorithm>
+#include <type_traits>
 
 #include "device_utils.h"
 #include "kernels.h"
@@ -29,134 +30,248 @@ __device__ __forceinline__ float fast_tanh(float x) {
 
 // ---------------------------------------------------------------------------------------------
 // gemm_tn: C[m][n] += sum_r A[row(r)][m] * B[r][n]
-// 64x64 output tile, 4 waves (2x2) of one 32x32x2 fp32 MFMA accumulator each; the reduction runs
-// over rows r in k-tiles of 32.  Both operands arrive with r as the slow axis, so each loading
-// thread fetches a 4(r) x 4(m) block with four 16-B loads (coalesced along m), transposes it in
-// registers and writes the k-interleaved LDS layout [r/4][m][4] that lets one ds_read_b128 feed
-// four MFMAs (same compute loop as gemm_pk).  Threads 0..127 load A, 128..255 load B.
+// Workgroup tile (64 WT) x (64 WT), 4 waves (2x2), each wave WT x WT accumulators of one 32x32x2
+// fp32 MFMA; the reduction runs over rows r in k-tiles of BK (64x64x32 or 128x128x16).  Both
+// operands arrive with r as the slow axis and stay that way in LDS ([r][m], unpadded): a loading
+// thread copies four 16-B pieces per tile global -> registers -> ds_write_b128 with no arithmetic
+// in between (lanes along m: coalesced loads, contiguous conflict-free writes), and the MFMA
+// operands A[k][m0 + lane % 32] are ds_read_b32 of 32 consecutive words.  Waves 0,1 stream A,
+// waves 2,3 stream B (wave-uniform roles: every mode test below is a scalar branch).
+//
+// The first measured version of this kernel issued 14 VALU instructions per MFMA (per-element
+// masks, a register transpose for a k-interleaved LDS layout, 64-bit addresses) and ran at the
+// VALU's pace, 37 % of the MFMA peak; tools/gemm_tn_microbench.py, profiles/r01_gemm_tn.txt.
 // ---------------------------------------------------------------------------------------------
-constexpr int TBM = 64, TBN = 64, TBK = 32;
-constexpr int TLDS = TBM + 1;   // float4 units
-
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTnArgs a, int r_per_split) {
-  __shared__ float4 As[2][TBK / 4][TLDS];
-  __shared__ float4 Bs[2][TBK / 4][TLDS];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+template <int WT, int BK>
+__global__ __launch_bounds__(256, WT == 1 ? 4 : 2) void gemm_tn_kernel(const GemmTnArgs a,
+                                                                       int r_per_split) {
+  constexpr int TB = 64 * WT;              // tile edge (both M and N)
+  constexpr int C4N = TB / 4;              // float4 pieces per tile row
+  constexpr int RP = 128 / C4N;            // tile rows covered by one pass of 128 loading threads
+  static_assert(BK == 4 * RP, "four pieces per loading thread and tile");
+  __shared__ float4 As[2][BK][C4N];
+  __shared__ float4 Bs[2][BK][C4N];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;
-  const int m0 = blockIdx.y * TBM, n0 = blockIdx.x * TBN;
+  const int m0 = blockIdx.y * TB, n0 = blockIdx.x * TB;
   int Rtot = a.R;
-  // blockIdx.z = split * nsel + selection
-  const int nsel = a.nsel > 0 ? a.nsel : 1;
-  const int zsel = blockIdx.z % nsel, zsplit = blockIdx.z / nsel, nsplit = gridDim.z / nsel;
+  // blockIdx.z = split * nprob + problem
+  const int nprob = a.nprob > 0 ? a.nprob : 1;
+  const int zp = blockIdx.z % nprob, zsplit = blockIdx.z / nprob, nsplit = gridDim.z / nprob;
   // (the argument block is never written: a modified by-value struct is copied to scratch memory)
-  const int b_sel_val = a.nsel > 0 ? zsel : a.b_sel_val;
-  float* const Cout = a.nsel > 0 ? a.C_sel[zsel] : a.C;
-  float* const colsum_out = a.nsel > 0 ? a.colsum_sel[zsel] : a.colsum;
+  const bool multi = a.nprob > 0;
+  const float* const Ain = multi ? a.A_p[zp] : a.A;
+  const float* const Bin = multi ? a.B_p[zp] : a.B;
+  const int b_sel_val = multi ? a.bsel_p[zp] : a.b_sel_val;
+  float* const Cout = multi ? a.C_p[zp] : a.C;
+  float* const colsum_out = multi ? a.colsum_p[zp] : a.colsum;
   if (a.r_dev) {                       // compacted reduction: re-balance the splits on the device
     Rtot = min(a.R, *a.r_dev);
-    const int nkt_all = (Rtot + TBK - 1) / TBK;
-    r_per_split = ((nkt_all + nsplit - 1) / nsplit) * TBK;
+    const int nkt_all = (Rtot + BK - 1) / BK;
+    r_per_split = ((nkt_all + nsplit - 1) / nsplit) * BK;
   }
   const int rbeg = zsplit * r_per_split;
   const int rend = min(Rtot, rbeg + r_per_split);
   if (rbeg >= rend) return;
+  const int nkt = (rend - rbeg + BK - 1) / BK;
 
-  const bool isB = tid >= 128;
+  const bool isB = wid >= 2;
   const int lt = tid & 127;
-  const int k4 = lt >> 4;            // 0..7: which group of 4 r-rows inside the k-tile
-  const int c4 = lt & 15;            // which float4 column (4 consecutive m or n)
-  const float* base = isB ? a.B : a.A;
-  const int ld = isB ? a.ldb : a.lda;
+  const int trow = lt / C4N;         // tile rows trow + j * RP, j = 0..3
+  const int c4 = lt % C4N;           // which 16-B piece of the row (4 consecutive m or n)
+  const unsigned ld = isB ? a.ldb : a.lda;
   const int cbeg = (isB ? n0 : m0) + 4 * c4;
-  const int clim = isB ? a.N : a.M;                 // columns >= clim read as zero
-  // a float4 load is issued when its first column is inside the (4-padded) row
-  const bool col_ok = cbeg < ((clim + 3) & ~3);
-  const int ccl = col_ok ? cbeg : 0;
+  const int clim = isB ? a.N : a.M;
+  // Columns >= clim of a tile only reach rows / columns of C that are never written, so operand
+  // columns need no mask: a piece starting outside the (4-padded) row just re-reads column 0.
+  const unsigned ccl = cbeg < ((clim + 3) & ~3) ? cbeg : 0;
+
+  // Row metadata is a chain of up to two dependent loads (row_idx -> a_group_idx / a_onehot /
+  // b_sel) in front of the operand load.  The three stages run as a software pipeline, one k-tile
+  // apart, so an iteration issues its loads back to back and waits for none before its MFMAs:
+  //   S1(t): l1[j]   = row_idx[r]                      (tile t)
+  //   S2(t): l2[j]   = table2[src1 or src1 / group]    (tile t; src1 from l1)
+  //   S3(t): data[j] = base[src * ld + col]            (tile t; src / mask from l2)
+  const bool use1 = a.row_idx != nullptr;
+  const bool onehot = !isB && a.a_onehot != nullptr;
+  const bool group = !isB && !onehot && a.a_group_idx != nullptr;
+  const bool bsel = isB && a.b_sel != nullptr;
+  const bool use2 = onehot || group || bsel;
+  const int32_t* const p2 = onehot ? a.a_onehot : group ? a.a_group_idx : a.b_sel;
+  const int gs = group ? a.a_group_size : 1;
+  const float inv_gs = 1.0f / (float)gs;
+  const float* const base = isB || onehot ? Bin : Ain;     // (one-hot: any readable address)
 
   // bias gradient riding along: the workgroups of the first row of output tiles also sum the B
   // columns they stream (every B tile is loaded exactly once per workgroup)
-  const bool do_cs = colsum_out != nullptr && blockIdx.y == 0;
+  const bool do_cs = isB && colsum_out != nullptr && blockIdx.y == 0;
   float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 reg[4];
-  auto gload = [&](int kt) {
+  int l1[4], l2[4], src1[4], rem[4];
+  // two operand tiles in flight per thread (slot = tile & 1)
+  int aux[2][4];                     // one-hot: the hot column; b_sel: the row's selection value
+  float4 reg[2][4];
+  auto row_of = [&](int kt, int j) {         // tile row -> reduction row, clamped into the split
+    const int r = rbeg + kt * BK + trow + j * RP;
+    return r < rend ? r : rbeg;
+  };
+  auto stage1 = [&](int kt) {
+    if (!use1) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) l1[j] = a.row_idx[row_of(kt, j)];
+  };
+  auto stage2 = [&](int kt) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int r = rbeg + kt * TBK + 4 * k4 + j;
-      const bool rok = r < rend;
-      int src = rok ? r : rbeg;
-      if (a.row_idx) src = a.row_idx[src];
-      bool sel_ok = true;
-      if (isB) {
-        if (a.b_sel) sel_ok = a.b_sel[src] == b_sel_val;
-      } else if (a.a_onehot) {          // A[r][m] = (a_onehot[r] == m): no operand in memory
-        const int hot = a.a_onehot[src];
-        reg[j].x = (rok && hot == cbeg + 0) ? 1.f : 0.f;
-        reg[j].y = (rok && hot == cbeg + 1) ? 1.f : 0.f;
-        reg[j].z = (rok && hot == cbeg + 2) ? 1.f : 0.f;
-        reg[j].w = (rok && hot == cbeg + 3) ? 1.f : 0.f;
-        continue;
-      } else if (a.a_group_idx) {
-        const int g = src / a.a_group_size;
-        src = a.a_group_idx[g] * a.a_group_size + (src - g * a.a_group_size);
+      const int s1 = use1 ? l1[j] : row_of(kt, j);
+      src1[j] = s1;
+      if (use2) {
+        int g = s1;
+        if (gs > 1) {                    // exact floor(s1 / gs) for s1 < 2^22
+          g = __float2int_rz(((float)s1 + 0.5f) * inv_gs);
+          if (g * gs > s1) --g;
+          if ((g + 1) * gs <= s1) ++g;
+          rem[j] = s1 - g * gs;
+        }
+        l2[j] = p2[g];
       }
-      const float4 t = *reinterpret_cast<const float4*>(base + (size_t)src * ld + ccl);
-      const bool ok = rok && col_ok && sel_ok;
-      reg[j].x = (ok && cbeg + 0 < clim) ? t.x : 0.f;
-      reg[j].y = (ok && cbeg + 1 < clim) ? t.y : 0.f;
-      reg[j].z = (ok && cbeg + 2 < clim) ? t.z : 0.f;
-      reg[j].w = (ok && cbeg + 3 < clim) ? t.w : 0.f;
-      if (do_cs && isB) { cs.x += reg[j].x; cs.y += reg[j].y; cs.z += reg[j].z; cs.w += reg[j].w; }
     }
   };
-  auto lstore = [&](int buf) {
-    float4(*dst)[TLDS] = isB ? Bs[buf] : As[buf];
-    dst[k4][4 * c4 + 0] = make_float4(reg[0].x, reg[1].x, reg[2].x, reg[3].x);
-    dst[k4][4 * c4 + 1] = make_float4(reg[0].y, reg[1].y, reg[2].y, reg[3].y);
-    dst[k4][4 * c4 + 2] = make_float4(reg[0].z, reg[1].z, reg[2].z, reg[3].z);
-    dst[k4][4 * c4 + 3] = make_float4(reg[0].w, reg[1].w, reg[2].w, reg[3].w);
+  auto stage3 = [&](auto slot_c, int kt) {
+    constexpr int SL = decltype(slot_c)::value;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      unsigned src = src1[j];
+      if (group) src = gs > 1 ? l2[j] * gs + rem[j] : l2[j];
+      if (use2) aux[SL][j] = l2[j];
+      const unsigned off = onehot ? 0u : src * ld + ccl;      // operands span < 2^30 floats
+      reg[SL][j] = *reinterpret_cast<const float4*>(base + (size_t)off);
+    }
+  };
+  auto lstore = [&](auto slot_c, int kt) {   // tile kt: register slot kt & 1 -> LDS buffer kt & 1
+    constexpr int SL = decltype(slot_c)::value;
+    float4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = reg[SL][j];
+    if (onehot) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int h = aux[SL][j] - cbeg;
+        v[j] = make_float4(h == 0 ? 1.f : 0.f, h == 1 ? 1.f : 0.f, h == 2 ? 1.f : 0.f,
+                           h == 3 ? 1.f : 0.f);
+      }
+    }
+    // rows outside the split (last tile) or of another selection contribute zero: B is enough
+    if (isB && (bsel || rbeg + (kt + 1) * BK > rend)) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bool ok = rbeg + kt * BK + trow + j * RP < rend;
+        if (bsel) ok = ok && aux[SL][j] == b_sel_val;
+        if (!ok) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    if (do_cs) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { cs.x += v[j].x; cs.y += v[j].y; cs.z += v[j].z; cs.w += v[j].w; }
+    }
+    float4(*dst)[C4N] = isB ? Bs[SL] : As[SL];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dst[trow + j * RP][c4] = v[j];
   };
 
-  f32x16 acc;
+  f32x16 acc[WT][WT];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int j = 0; j < WT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const int li = lane & 31, kh = lane >> 5;
-  const int nkt = (rend - rbeg + TBK - 1) / TBK;
 
-  gload(0);
-  lstore(0);
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  stage1(0);
+  stage2(0);
+  stage1(1);
+  stage3(S0{}, 0);
+  stage2(1);
+  stage1(2);
+  stage3(S1{}, 1);
+  stage2(2);
+  stage1(3);
+  lstore(S0{}, 0);
   __syncthreads();
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nkt) gload(kt + 1);          // in flight during the MFMAs of tile kt
+  // iteration kt (parity P): issue tile kt+2's operand loads and the metadata of tiles kt+3 / kt+4
+  // (tiles past the end re-read row rbeg, masked), MFMAs of tile kt from LDS buffer P, then tile
+  // kt+1 (landed during the previous iteration's MFMAs) moves from its registers to buffer 1-P
+  auto body = [&](auto par_c, int kt) {
+    constexpr int P = decltype(par_c)::value;
+    stage3(par_c, kt + 2);
+    stage2(kt + 3);
+    stage1(kt + 4);
+    const float* Af = reinterpret_cast<const float*>(&As[P][0][0]) + kh * TB + wm * (32 * WT) + li;
+    const float* Bf = reinterpret_cast<const float*>(&Bs[P][0][0]) + kh * TB + wn * (32 * WT) + li;
+    // operand reads run one group of GS k-pair steps (>= 4 MFMAs) ahead of the MFMAs that use
+    // them; left to itself the compiler reloads the same registers after every group and waits
+    constexpr int GS = WT == 1 ? 4 : 1, NG = BK / 2 / GS;
+    float av[2][GS][WT], bv[2][GS][WT];
+    auto lds_group = [&](int set, int g) {
 #pragma unroll
-    for (int kq = 0; kq < TBK / 8; ++kq) {
-      const float4 av = As[cur][2 * kq + kh][wm * 32 + li];
-      const float4 bv = Bs[cur][2 * kq + kh][wn * 32 + li];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+      for (int q = 0; q < GS; ++q)
+#pragma unroll
+        for (int i = 0; i < WT; ++i) {
+          av[set][q][i] = Af[(g * GS + q) * 2 * TB + i * 32];
+          bv[set][q][i] = Bf[(g * GS + q) * 2 * TB + i * 32];
+        }
+    };
+    lds_group(0, 0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (g + 1 < NG) lds_group((g + 1) & 1, g + 1);
+      __builtin_amdgcn_sched_barrier(0);       // keep the reads of group g+1 ahead of these MFMAs
+#pragma unroll
+      for (int q = 0; q < GS; ++q)
+#pragma unroll
+        for (int i = 0; i < WT; ++i)
+#pragma unroll
+          for (int j = 0; j < WT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][q][i], bv[g & 1][q][j],
+                                                             acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (kt + 1 < nkt) lstore(cur ^ 1);        // the other buffer was last read in iteration kt-1
+    if (kt + 1 < nkt) lstore(std::integral_constant<int, 1 - P>{}, kt + 1);
     __syncthreads();
+  };
+  for (int kt = 0; kt < nkt; kt += 2) {
+    body(S0{}, kt);
+    if (kt + 1 < nkt) body(S1{}, kt + 1);
   }
   // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const int col = n0 + wn * 32 + li;
-  if (col < a.N) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-      if (row < a.M) atomicAdd(Cout + (size_t)row * a.ldc + col, acc[r]);
+  for (int j = 0; j < WT; ++j) {
+    const int col = n0 + (wn * WT + j) * 32 + li;
+    if (col >= a.N) continue;
+#pragma unroll
+    for (int i = 0; i < WT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (wm * WT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (row < a.M) {
+          float* dst = Cout + (size_t)row * a.ldc + col;
+          if (nsplit == 1) *dst += acc[i][j][r];       // this workgroup owns the tile
+          else atomicAdd(dst, acc[i][j][r]);
+        }
+      }
     }
   }
-  if (do_cs) {                      // uniform per workgroup; the k-loop ended with a barrier
-    float* red = reinterpret_cast<float*>(&Bs[0][0][0]);     // [8 row groups][64 columns]
-    if (isB) *reinterpret_cast<float4*>(red + k4 * 64 + 4 * c4) = cs;
+  if (colsum_out != nullptr && blockIdx.y == 0) {   // uniform per workgroup; the k-loop ended
+    float* red = reinterpret_cast<float*>(&Bs[0][0][0]);     // with a barrier.  [RP rows][TB cols]
+    if (isB) *reinterpret_cast<float4*>(red + trow * TB + 4 * c4) = cs;
     __syncthreads();
-    if (tid < 64 && n0 + tid < a.N) {
+    if (tid < TB && n0 + tid < a.N) {
       float t = 0.f;
 #pragma unroll
-      for (int q = 0; q < TBK / 4; ++q) t += red[q * 64 + tid];
+      for (int q = 0; q < RP; ++q) t += red[q * TB + tid];
       atomicAdd(colsum_out + n0 + tid, t);
     }
   }
@@ -675,18 +790,20 @@ __global__ __launch_bounds__(256) void adam_kernel(const float* __restrict__ gra
 // ---------------------------------------------------------------------------------------------
 void launch_gemm_tn(const GemmTnArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0 || a.R <= 0) return;
-  const int gx = (a.N + TBN - 1) / TBN, gy = (a.M + TBM - 1) / TBM;
-  // split the reduction until the launch has ~4 workgroups per CU (one 64x64 tile keeps a single
-  // wave per SIMD busy, so latency hiding comes from co-resident workgroups), but keep >= 4 k-tiles
-  // per split: every split costs M*N atomic adds.  A/B on one box: 3.09-3.14 ms per training step
-  // with this rule, 3.23 with "1536 workgroups, >= 2 k-tiles", 3.13 with "768, >= 8".
+  const int nprob = a.nprob > 0 ? a.nprob : 1;
+  constexpr int TB = 64, BK = 32;
+  const int gx = (a.N + TB - 1) / TB, gy = (a.M + TB - 1) / TB;
+  // Four workgroups fit a CU (1024 on the chip).  Split the reduction while the launch stays
+  // within that and a split keeps >= 4 k-tiles: every split costs M*N atomic adds, and a single
+  // split writes its tile with plain read-modify-writes.  (Whole training step, same box: 2.917 ms
+  // with this rule, 2.954 with "split until >= 1024 workgroups", 2.969 with a 2048 target.)
   int splits = 1;
-  const int nkt = (a.R + TBK - 1) / TBK;
-  const int nsel = a.nsel > 0 ? a.nsel : 1;
-  while (gx * gy * nsel * splits < 1024 && nkt / (splits * 2) >= 4) splits *= 2;
-  int r_per = ((nkt + splits - 1) / splits) * TBK;
+  const int nkt = (a.R + BK - 1) / BK;
+  while (gx * gy * nprob * splits * 2 <= 1024 && nkt / (splits * 2) >= 4) splits *= 2;
+  int r_per = ((nkt + splits - 1) / splits) * BK;
   splits = (a.R + r_per - 1) / r_per;
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(gx, gy, splits * nsel), dim3(256), 0, s, a, r_per);
+  hipLaunchKernelGGL((gemm_tn_kernel<1, 32>), dim3(gx, gy, splits * nprob), dim3(256), 0, s, a,
+                     r_per);
 }
 
 void launch_active_rows(const int32_t* seq_len, int T, int N, int32_t* rows, int32_t* count,
