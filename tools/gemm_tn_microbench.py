@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """gemm_tn (weight-gradient GEMM, C += A^T . B) on the shapes of one CLEVR training step, through
-n2nmn_debug_gemm_tn.  Prints us per launch and TFLOP/s; used for same-box A/B of kernel variants
-(N2NMN_GEMM_TN_VARIANT is read by the library when it is built with -DN2NMN_GEMM_TN_AB)."""
+n2nmn_debug_gemm_tn.  Prints us per launch and TFLOP/s; used for same-box A/B of kernel revisions
+(profiles/r01_gemm_tn.txt)."""
 import os
 import sys
 
