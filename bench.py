@@ -6,9 +6,12 @@
 
 One "step" = one pass of the hot path over one batch of 64 questions (BASELINE.json configs[1]:
 CLEVR forward, fixed ground-truth layouts, 10x15x512 synthetic pool5 features): phase 1 (LSTM
-encoder + teacher-forced attentional decoder) -> predicted_tokens fetched to the host (the sync the
-reference's API mandates, exp_clevr/eval_clevr.py:111-125) -> C++ assemble/pack -> phase 2 (module
-network) -> answer logits in HBM.  Inputs are resident in HBM before the timed region.
+encoder + teacher-forced attentional decoder), C++ assemble/pack of the layout, phase 2 (module
+network) -> answer logits in HBM.  With ground-truth layouts the predicted tokens ARE the host's
+gt_layout (models_clevr/nmn3_netgen_att.py:236-238), so the program is assembled from the host copy
+while phase 1 runs and the step never synchronises; --fetch-tokens (and config 3, where the decoder
+chooses the layout) fetches predicted_tokens to the host between the phases as
+exp_clevr/eval_clevr.py:111-125 does.  Inputs are resident in HBM before the timed region.
 Multi-GPU: the path shards by question with no data-path collective (weak scaling: every rank runs
 its own batch-64 stream); timing = barrier + synchronize on both sides, max over ranks.
 
@@ -42,6 +45,9 @@ def parse():
     ap.add_argument('--streams', type=int, default=6,
                     help='independent batches in flight per GPU (one host thread + HIP stream + '
                          'forked context each; weights shared)')
+    ap.add_argument('--fetch-tokens', action='store_true',
+                    help='config 2: fetch predicted_tokens from the device before assembling (as '
+                         'eval_clevr.py does) instead of assembling from the host copy of gt_layout')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     return ap.parse_args()
@@ -297,7 +303,10 @@ def main():
     for i in range(n_batches):
         b = synth.make_inputs(d, seed=dp.batch_seed(i))
         batches.append({k: torch.as_tensor(v).to(dev) for k, v in b.items()})
-        gts.append(torch.as_tensor(synth.template_layout_batch(d, offset=i)).to(dev))
+        gt_host = synth.template_layout_batch(d, offset=i)
+        # gt layouts arrive as host arrays (the reference's data reader, data_reader.py:74-82): the
+        # engine assembles the program from them while phase 1 runs -- no token fetch, no sync
+        gts.append(torch.as_tensor(gt_host).to(dev) if args.fetch_tokens else gt_host)
     use_gt = args.config == 2
 
     S = max(1, args.streams)
@@ -365,7 +374,10 @@ def main():
                        'global_batch': world * d.N, 'parallelism': 'dp%d (question-sharded, no '
                        'data-path collective)' % world, 'streams_per_gpu': S,
                        'lstm_tile_mode': 'throughput (32x32)' if S > 1 else 'latency (64x16)',
-                       'host_sync': 'predicted_tokens D2H between phase 1 and phase 2'},
+                       'host_sync': 'predicted_tokens D2H between phase 1 and phase 2'
+                       if (not use_gt or args.fetch_tokens) else
+                       'none: with gt layouts the program is assembled from the host copy of '
+                       'gt_layout (= the predicted tokens, nmn3_netgen_att.py:236-238)'},
         }
 
     # ---- the same workload with ONE batch in flight (latency-oriented number)

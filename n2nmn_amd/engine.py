@@ -34,6 +34,8 @@ class Engine:
         cd = _lib.Dims(**{k: int(v) for k, v in dims.asdict().items()})
         self._ctx = C.c_void_p()
         self._bufs: Dict[tuple, object] = {}
+        self._ring = [None] * 4       # pinned staging slots for per-step host inputs (upload_i32)
+        self._ring_i = 0
         self._parent = _parent
         if _parent is not None:
             _lib.check(self._lib.n2nmn_ctx_fork(_parent._ctx, C.byref(self._ctx)))
@@ -109,6 +111,27 @@ class Engine:
         if t.device != self.device or t.dtype != dtype or not t.is_contiguous():
             t = t.to(device=self.device, dtype=dtype).contiguous()
         return t
+
+    def upload_i32(self, host):
+        """Host int32 array -> device through a pinned slot, WITHOUT synchronising the stream (a
+        plain .to(device) from pageable memory waits for everything queued before it).  A slot is
+        rewritten only after the copy that last read it has completed; the returned tensor stays
+        valid until the call after next-but-two on this engine."""
+        torch = _torch()
+        host = np.ascontiguousarray(host, np.int32)
+        i = self._ring_i % len(self._ring)
+        self._ring_i += 1
+        slot = self._ring[i]
+        if slot is None or tuple(slot[0].shape) != host.shape:
+            pin = torch.empty(host.shape, dtype=torch.int32).pin_memory()
+            dev = torch.empty(host.shape, dtype=torch.int32, device=self.device)
+            slot = self._ring[i] = (pin, dev, torch.cuda.Event())
+        pin, dev, ev = slot
+        ev.synchronize()
+        pin.numpy()[...] = host
+        dev.copy_(pin, non_blocking=True)
+        ev.record(torch.cuda.current_stream(self.device))
+        return dev
 
     def seq2seq(self, input_seq, seq_len, T_dec: Optional[int] = None, use_gt_layout: bool = False,
                 gt_layout=None, sample_uniforms=None, forced_tokens=None, debug: bool = False,
@@ -234,7 +257,19 @@ class Engine:
                 gt_layout=None, sample_uniforms=None):
         """The whole hot path of exp_clevr/eval_clevr.py:103-135 for one batch:
         phase 1 -> token fetch (the one host sync) -> C++ assemble/pack -> phase 2.
-        Returns (scores device tensor, tokens numpy [T_dec,N], validity numpy [N])."""
+        Returns (scores device tensor, tokens numpy [T_dec,N], validity numpy [N]).
+
+        With use_gt_layout and a HOST gt_layout (numpy, as the reference's data reader delivers
+        it, util/clevr_train/data_reader.py:74-82) the predicted tokens are the ground-truth layout
+        by construction (models_clevr/nmn3_netgen_att.py:236-238), so the program is assembled
+        from the host copy up front and the step has no host synchronisation at all."""
+        if use_gt_layout and isinstance(gt_layout, np.ndarray):
+            tokens = np.ascontiguousarray(gt_layout, np.int32)
+            packed, validity = self.assembler.assemble_packed(tokens)
+            s2s = self.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], T_dec,
+                               True, self.upload_i32(tokens), sample_uniforms)
+            scores = self.execute(packed, batch['image_feat_batch'], s2s['word_vecs'])
+            return scores, tokens, validity
         s2s = self.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], T_dec,
                            use_gt_layout, gt_layout, sample_uniforms)
         tokens = s2s['predicted_tokens'].cpu().numpy()

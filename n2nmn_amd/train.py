@@ -90,29 +90,8 @@ class Trainer:
             _lib.check(self._lib.n2nmn_grad_layout(self._ctx, i, C.byref(off), C.byref(n)))
             self.layout[name] = (int(off.value), int(n.value), shape)
         self._keep = None
-        self._ring = [None] * 4       # pinned staging slots for the per-step host inputs
-        self._ring_i = 0
 
     # ------------------------------------------------------------------------------------
-    def _upload(self, host: np.ndarray):
-        """Host array -> device through a pinned slot, without synchronising the stream (a plain
-        .to(device) from pageable memory waits for everything queued before it, i.e. for the whole
-        previous step).  A slot is rewritten only after the copy that last read it completed."""
-        torch = _torch()
-        i = self._ring_i % len(self._ring)
-        self._ring_i += 1
-        slot = self._ring[i]
-        if slot is None or slot[0].shape != host.shape or slot[0].dtype != torch.int32:
-            pin = torch.empty(host.shape, dtype=torch.int32).pin_memory()
-            dev = torch.empty(host.shape, dtype=torch.int32, device=self.engine.device)
-            slot = self._ring[i] = (pin, dev, torch.cuda.Event())
-        pin, dev, ev = slot
-        ev.synchronize()
-        pin.numpy()[...] = host
-        dev.copy_(pin, non_blocking=True)
-        ev.record()
-        return dev
-
     def _io(self, batch, gt_layout):
         torch = _torch()
         e = self.engine
@@ -123,7 +102,7 @@ class Trainer:
         labels = e._dev(batch['answer_label_batch'], torch.int32)
         gt_host = np.ascontiguousarray(np.asarray(
             gt_layout.cpu().numpy() if hasattr(gt_layout, 'cpu') else gt_layout), np.int32)
-        gt = self._upload(gt_host) if e.device.type == 'cuda' else e._dev(gt_host, torch.int32)
+        gt = e.upload_i32(gt_host)       # pinned slot: no stream synchronisation per step
         T, N = seq.shape
         Td = gt.shape[0]
         # teacher forcing: the layout is known before the forward, so the program is assembled
