@@ -27,6 +27,24 @@ def test_config2_gt_layouts(clevr_engine):
     assert np.array_equal(np.argmax(t2n(scores), 1), np.argmax(ref['scores'], 1))
 
 
+def test_gt_layout_host_and_device_paths_agree(clevr_engine):
+    """gt_layout as a host array: program assembled up front, no token fetch (sync-free step);
+    as a device tensor: predicted_tokens fetched between the phases (the eval_clevr.py flow).
+    Same tokens, bit-identical logits -- also over several steps in a row (pinned upload ring)."""
+    import torch
+    eng, d, asm, w = clevr_engine
+    for step in range(6):
+        batch = synth.make_inputs(d, seed=40 + step)
+        gt = synth.template_layout_batch(d, offset=step)
+        s_host, t_host, v_host = eng.forward(batch, use_gt_layout=True, gt_layout=gt)
+        s_host = t2n(s_host).copy()
+        s_dev, t_dev, v_dev = eng.forward(batch, use_gt_layout=True,
+                                          gt_layout=torch.as_tensor(gt).to(eng.device))
+        assert np.array_equal(t_host, gt) and np.array_equal(t_dev, gt)
+        assert np.array_equal(v_host, v_dev)
+        assert np.array_equal(s_host, t2n(s_dev))
+
+
 def test_config3_greedy_layouts(clevr_engine):
     eng, d, asm, w = clevr_engine
     batch = synth.make_inputs(d, seed=21)
