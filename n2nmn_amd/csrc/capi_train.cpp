@@ -23,7 +23,7 @@ struct TrainState {
   // forward results kept inside the context
   float* scores = nullptr;            // [N][C] (when the caller passes no buffer)
   // backward scratch
-  float *dscores = nullptr, *dsc = nullptr, *garena = nullptr, *dtmap = nullptr, *dpfc = nullptr,
+  float *dscores = nullptr, *dsc = nullptr, *garena = nullptr, *dtmap = nullptr, *dpfc = nullptr, *gda = nullptr,
         *dmfind = nullptr, *dmfsp = nullptr, *dwv = nullptr, *datts_wv = nullptr, *dE = nullptr, *de = nullptr,
         *dctx = nullptr, *dq = nullptr, *dout = nullptr, *dvp = nullptr, *deht = nullptr,
         *denc_out = nullptr;
@@ -121,6 +121,7 @@ size_t carve_train(n2nmn_ctx* c, TrainState* t, char* base) {
   t->garena = k.take<float>((size_t)c->max_nodes * HWp);     // Transform adds into its input's row
   t->dtmap = k.take<float>((size_t)c->max_text * Mp);
   t->dpfc = k.take<float>((size_t)c->max_pool * 2 * Mp);
+  t->gda = k.take<float>((size_t)c->max_pool * 2 * ((HW + 3) & ~3));
   t->dwv = k.take<float>(Td * N * E);
   t->dH0 = k.take<float>(N * L); t->dH1 = k.take<float>(N * L);
   t->dC0 = k.take<float>(N * L); t->dC1 = k.take<float>(N * L);
@@ -552,7 +553,7 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
       b.M = M; b.Mp = Mp; b.wl_cap = 0; b.E = E; b.C = C; b.HWp = c->HWp; b.ksize = d.kernel_size;
       b.pooled = t->rec.pooled;
       ModuleGrads g{};
-      g.garena = t->garena; g.dtmap = t->dtmap; g.dpfc = t->dpfc; g.dmfind = t->dmfind;
+      g.garena = t->garena; g.dtmap = t->dtmap; g.dpfc = t->dpfc; g.gda = t->gda; g.dmfind = t->dmfind;
       g.dmfsp = t->dmfsp; g.dscores = t->dscores; g.dwv = t->dwv;
       g.gwe[0] = G(V_FIND_E_W); g.gbe[0] = G(V_FIND_E_B);
       g.gwe[1] = G(V_FSP_E_W); g.gbe[1] = G(V_FSP_E_B);

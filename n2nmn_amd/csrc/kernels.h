@@ -317,6 +317,7 @@ struct ModuleGrads {
   float* garena;          // [max_nodes][HWp]   d loss / d attention map of a node
   float* dtmap;           // [max_text][Mp]     (zeroed; Find-type parts add atomically)
   float* dpfc;            // [max_pool][2][Mp]  d fc_att output (zeroed)
+  float* gda;             // [max_pool][2][HWq] d softmax weights of the pools (zeroed; parts add)
   float* dmfind;          // [N][HW][Mp]        d conv_image map, FindModule weights (zeroed)
   float* dmfsp;
   const float* dscores;   // [rows][C]

@@ -116,10 +116,16 @@ __global__ __launch_bounds__(MT) void heads_bwd_kernel(ModuleWeights w, ModuleBu
 // pool_bwd: a = softmax_HW(logits); pooled = sum_hw a[hw] feat[n,hw,:]; A = pooled . W_att + b
 // given dA (dpfc):  dpooled = W_att . dA;  da[hw] = feat[n,hw,:] . dpooled  (the HBM-bound read
 // of the [H*W, D] map, shared by both inputs of SameProperty);  dlogit = a * (da - sum a da).
-// One workgroup (512 threads) per pooling node.  dW_att comes from gemm_tn over the saved pooled
-// features.
+//
+// pool_bwd_kernel: one workgroup per (pooling node, channel part): the part's rows of W_att are read
+// one row per wave (coalesced 1-KB rows, wave reduction) -- a thread streaming its own row, as the
+// first version did, touches 64 cache lines per load instruction and made the kernel 40-58 us --
+// then the part's slice of every feature row is dotted with dpooled and the partial da[hw] is added
+// into gda (zeroed with the rest of the per-step block).  pool_bwd_fin_kernel: softmax backward of
+// the summed da.  dW_att comes from gemm_tn over the saved pooled features.
 // ---------------------------------------------------------------------------------------------
 constexpr int PB_T = 512;
+constexpr int PB_PARTS = 4;
 __global__ __launch_bounds__(PB_T) void pool_bwd_kernel(ModuleWeights w, ModuleBuffers b,
                                                         ModuleGrads g, int tab_off, int stride) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -127,94 +133,135 @@ __global__ __launch_bounds__(PB_T) void pool_bwd_kernel(ModuleWeights w, ModuleB
   const DevNode nd = b.nodes[node_id];
   const int HW = b.H * b.W, D = b.D, Mp = b.Mp;
   const int HWq = (HW + 3) & ~3;
+  const int part = blockIdx.y;
+  const int dper = ((D / PB_PARTS) + 3) & ~3;        // channels of this part (multiple of 4)
+  const int d0 = part * dper, d1 = min(D, d0 + dper);
   float* dA = smem;                 // [2][Mp]
-  float* dpl = dA + 2 * Mp;         // [2][D]
-  float* as = dpl + 2 * D;          // [2][HWq] softmax
-  float* gda = as + 2 * HWq;        // [2][HWq]
-  float* scratch = gda + 2 * HWq;   // [16]
+  float* dpl = dA + 2 * Mp;         // [2][dper]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   constexpr int NW = PB_T / 64;
   const int nin = nd.op == N2NMN_OP_SAME_PROPERTY ? 2 : 1;
   for (int i = tid; i < nin * Mp; i += PB_T)
     dA[i] = g.dpfc[((size_t)nd.pslot * 2 + i / Mp) * Mp + (i % Mp)];
   __syncthreads();
-  // dpooled_i[d] = sum_m W_att[d][m] dA_i[m]        (wave per d, float4 lanes over m)
+  // dpooled_i[d] = sum_m W_att[d][m] dA_i[m]: wave per row d, lanes over m (16-B pieces)
   for (int i = 0; i < nin; ++i) {
     int wi;
     if (nd.op == N2NMN_OP_FIND_SAME_PROPERTY) wi = 0;
     else if (nd.op == N2NMN_OP_SAME_PROPERTY) wi = 1 + i;
     else wi = 3;
     const float* Wm = w.Watt[wi];
-    for (int m = tid; m < b.M; m += PB_T) atomicAdd(g.gbatt[wi] + m, dA[i * Mp + m]);   // d b_att
-    // thread per feature channel d: streams its own (contiguous, padded) W_att row with 16-B
-    // loads, dA broadcast from LDS -- no cross-lane reductions
-    for (int d = tid; d < D; d += PB_T) {
-      const float4* wr = reinterpret_cast<const float4*>(Wm + (size_t)d * Mp);
-      const float4* ar = reinterpret_cast<const float4*>(dA + i * Mp);
-      float s0 = 0.f, s1 = 0.f;
-#pragma unroll 8
-      for (int m4 = 0; m4 < Mp / 4; m4 += 2) {
-        const float4 w0 = wr[m4], w1 = wr[m4 + 1];
-        const float4 a0 = ar[m4], a1 = ar[m4 + 1];
-        s0 += w0.x * a0.x + w0.y * a0.y + w0.z * a0.z + w0.w * a0.w;
-        s1 += w1.x * a1.x + w1.y * a1.y + w1.z * a1.z + w1.w * a1.w;
+    if (part == 0)
+      for (int m = tid; m < b.M; m += PB_T) atomicAdd(g.gbatt[wi] + m, dA[i * Mp + m]);   // d b_att
+    constexpr int U1 = 8;                       // rows of a wave in flight
+    for (int dbase = d0 + wv; dbase < d1; dbase += U1 * NW) {
+      float sacc[U1];
+      const float* wrow[U1];
+#pragma unroll
+      for (int u = 0; u < U1; ++u) {
+        sacc[u] = 0.f;
+        wrow[u] = Wm + (size_t)min(dbase + u * NW, d1 - 1) * Mp;   // clamped: loads unconditional
       }
-      dpl[i * D + d] = s0 + s1;
+      for (int m = 4 * lane; m < Mp; m += 256) {       // all U1 row loads issued back to back
+        const float4 a4 = *reinterpret_cast<const float4*>(dA + i * Mp + m);
+        float4 w4[U1];
+#pragma unroll
+        for (int u = 0; u < U1; ++u) w4[u] = *reinterpret_cast<const float4*>(wrow[u] + m);
+#pragma unroll
+        for (int u = 0; u < U1; ++u)
+          sacc[u] += w4[u].x * a4.x + w4[u].y * a4.y + w4[u].z * a4.z + w4[u].w * a4.w;
+      }
+#pragma unroll
+      for (int u = 0; u < U1; ++u) {
+        const int d = dbase + u * NW;
+        const float t = wave_sum(sacc[u]);
+        if (lane == 0 && d < d1) dpl[i * dper + (d - d0)] = t;
+      }
     }
-  }
-  // softmax of the input logits (as the forward pool_kernel)
-  for (int i = 0; i < nin; ++i) {
-    const float* src = b.arena + (size_t)(i == 0 ? nd.in0 : nd.in1) * b.HWp;
-    float* dst = as + i * HWq;
-    float lm = -INFINITY;
-    for (int r = tid; r < HW; r += PB_T) lm = fmaxf(lm, src[r]);
-    const float mx = block_reduce<1>(lm, scratch);
-    float ls = 0.f;
-    for (int r = tid; r < HW; r += PB_T) {
-      const float ex = expf(src[r] - mx);
-      dst[r] = ex;
-      ls += ex;
-    }
-    const float sum = block_reduce<0>(ls, scratch);
-    for (int r = tid; r < HW; r += PB_T) dst[r] = dst[r] / sum;
   }
   __syncthreads();
-  // da_i[hw] = feat[n, hw, :] . dpooled_i           (wave per row, 4 rows in flight)
+  // partial da_i[hw] = feat[n, hw, d0:d1] . dpooled_i[d0:d1]: half a wave per row, 4 rows of a
+  // half-wave in flight
   {
-    const float* fb = b.feat + (size_t)nd.n * HW * D;
-    for (int r0 = wv; r0 < HW; r0 += 4 * NW) {
-      float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* fb = b.feat + (size_t)nd.n * HW * D + d0;
+    const int hl = lane & 31, hsel = lane >> 5;
+    const int dn = d1 - d0;
+    float* gd = g.gda + (size_t)nd.pslot * 2 * HWq;
+    constexpr int U3 = 10;                      // rows of a half-wave in flight (16 half-waves x 10 >= 150)
+    for (int r0 = 2 * wv + hsel; r0 < HW; r0 += U3 * 2 * NW) {
+      float s0[U3], s1[U3];
+      const float* frow[U3];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int r = r0 + u * NW;
-        if (r < HW) {
-          for (int d = 4 * lane; d < D; d += 256) {
-            const float4 f4 = *reinterpret_cast<const float4*>(fb + (size_t)r * D + d);
-            const float4 p0 = *reinterpret_cast<const float4*>(dpl + d);
-            s0[u] += f4.x * p0.x + f4.y * p0.y + f4.z * p0.z + f4.w * p0.w;
-            if (nin == 2) {
-              const float4 p1 = *reinterpret_cast<const float4*>(dpl + D + d);
-              s1[u] += f4.x * p1.x + f4.y * p1.y + f4.z * p1.z + f4.w * p1.w;
-            }
-          }
+      for (int u = 0; u < U3; ++u) {
+        s0[u] = 0.f; s1[u] = 0.f;
+        frow[u] = fb + (size_t)min(r0 + u * 2 * NW, HW - 1) * D;
+      }
+      for (int d = 4 * hl; d < dn; d += 128) {         // all U3 row loads issued back to back
+        float4 f4[U3];
+#pragma unroll
+        for (int u = 0; u < U3; ++u) f4[u] = *reinterpret_cast<const float4*>(frow[u] + d);
+        const float4 p0 = *reinterpret_cast<const float4*>(dpl + d);
+#pragma unroll
+        for (int u = 0; u < U3; ++u)
+          s0[u] += f4[u].x * p0.x + f4[u].y * p0.y + f4[u].z * p0.z + f4[u].w * p0.w;
+        if (nin == 2) {
+          const float4 p1 = *reinterpret_cast<const float4*>(dpl + dper + d);
+#pragma unroll
+          for (int u = 0; u < U3; ++u)
+            s1[u] += f4[u].x * p1.x + f4[u].y * p1.y + f4[u].z * p1.z + f4[u].w * p1.w;
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int r = r0 + u * NW;
-        const float t0 = wave_sum(s0[u]);
-        const float t1 = nin == 2 ? wave_sum(s1[u]) : 0.f;
-        if (lane == 0 && r < HW) { gda[r] = t0; gda[HWq + r] = t1; }
+      for (int u = 0; u < U3; ++u) {
+        const int r = r0 + u * 2 * NW;
+        float t0 = s0[u], t1 = s1[u];
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) {      // reduce inside each half-wave
+          t0 += __shfl_xor(t0, off);
+          if (nin == 2) t1 += __shfl_xor(t1, off);
+        }
+        if (hl == 0 && r < HW) {
+          atomicAdd(gd + r, t0);
+          if (nin == 2) atomicAdd(gd + HWq + r, t1);
+        }
       }
     }
   }
-  __syncthreads();
+}
+
+// d logits of the pooling node's inputs from the summed da (one workgroup per node)
+__global__ __launch_bounds__(256) void pool_bwd_fin_kernel(ModuleBuffers b, ModuleGrads g,
+                                                           int tab_off, int stride) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int node_id = b.tab[tab_off + blockIdx.x * stride];
+  const DevNode nd = b.nodes[node_id];
+  const int HW = b.H * b.W, tid = threadIdx.x;
+  const int HWq = (HW + 3) & ~3;
+  float* scratch = smem;            // [16]
+  float* as_ = smem + 16;           // [2][HWq]
+  const int nin = nd.op == N2NMN_OP_SAME_PROPERTY ? 2 : 1;
   for (int i = 0; i < nin; ++i) {
+    const float* src = b.arena + (size_t)(i == 0 ? nd.in0 : nd.in1) * b.HWp;
+    const float* gd = g.gda + ((size_t)nd.pslot * 2 + i) * HWq;
+    float lm = -INFINITY;
+    for (int r = tid; r < HW; r += 256) lm = fmaxf(lm, src[r]);
+    const float mx = block_reduce<1>(lm, scratch);
     float ls = 0.f;
-    for (int r = tid; r < HW; r += PB_T) ls += as[i * HWq + r] * gda[i * HWq + r];
-    const float sad = block_reduce<0>(ls, scratch);
+    for (int r = tid; r < HW; r += 256) {
+      const float ex = expf(src[r] - mx);      // softmax as in the forward pool_kernel
+      as_[i * HWq + r] = ex;
+      ls += ex;
+    }
+    const float sum = block_reduce<0>(ls, scratch);
+    float la = 0.f;
+    for (int r = tid; r < HW; r += 256) {
+      const float a = as_[i * HWq + r] / sum;
+      as_[i * HWq + r] = a;
+      la += a * gd[r];
+    }
+    const float sad = block_reduce<0>(la, scratch);
     float* go = g.garena + (size_t)(i == 0 ? nd.in0 : nd.in1) * b.HWp;
-    for (int r = tid; r < HW; r += PB_T) go[r] = as[i * HWq + r] * (gda[i * HWq + r] - sad);
+    for (int r = tid; r < HW; r += 256) go[r] = as_[i * HWq + r] * (gd[r] - sad);
   }
 }
 
@@ -242,6 +289,7 @@ __device__ void find_epilogue_bwd(const ModuleWeights& w, const ModuleBuffers& b
   const float* gout = g.garena + (size_t)node_id * b.HWp;
   float* red = smem;                      // [4 waves][2][Mp]
   float* scratch = red + 8 * Mp;          // [16]
+  float* xp = scratch + 16 + wid * 256;   // [4 waves][256]: lane <-> channel transpose for dM
 
   float4 t4[MAXCI], e4[MAXCI];
   float4 dtt[MAXCI], dwe[MAXCI];
@@ -266,51 +314,80 @@ __device__ void find_epilogue_bwd(const ModuleWeights& w, const ModuleBuffers& b
     }
   }
   float dbe = 0.f;
-  for (int r = r0 + wid; r < r1; r += MT / 64) {
-    float4 m4[MAXCI];
-    float ss = 0.f, dot = 0.f;
+  // a wave takes rows r0 + wid, + 4, ...; the map rows (and gradients) of UR of them are fetched
+  // before any is processed -- one row per trip left every trip waiting on its own round trip
+  constexpr int UR = 5;
+  constexpr int RSTEP = MT / 64;
+  for (int rb = r0 + wid; rb < r1; rb += UR * RSTEP) {
+    float4 mrow[UR][MAXCI];
+    float grv[UR], xin[UR];
 #pragma unroll
-    for (int i = 0; i < MAXCI; ++i) {
-      const int c = 4 * lane + 256 * i;
-      if (c < Mp) {
-        m4[i] = *reinterpret_cast<const float4*>(Mbuf + (size_t)r * Mp + c);
-        const float p0 = m4[i].x * t4[i].x, p1 = m4[i].y * t4[i].y, p2 = m4[i].z * t4[i].z,
-                    p3 = m4[i].w * t4[i].w;
-        ss += p0 * p0 + p1 * p1 + p2 * p2 + p3 * p3;
-        dot += p0 * e4[i].x + p1 * e4[i].y + p2 * e4[i].z + p3 * e4[i].w;
+    for (int u = 0; u < UR; ++u) {
+      const int r = min(rb + u * RSTEP, r1 - 1);       // clamped: loads stay unconditional
+#pragma unroll
+      for (int i = 0; i < MAXCI; ++i) {
+        const int c = 4 * lane + 256 * i;
+        if (c < Mp) mrow[u][i] = *reinterpret_cast<const float4*>(Mbuf + (size_t)r * Mp + c);
       }
+      grv[u] = gout[r];
+      xin[u] = in0 ? in0[r] : 0.f;
     }
-    ss = wave_sum(ss);
-    dot = wave_sum(dot);
-    const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
-    float gr = gout[r];
-    if (in0) {                                     // Filter: tf.minimum(input_0, att), tie -> input_0
-      const float att = dot * inv + be;
-      const float x = in0[r];
-      const bool to_x = x <= att;
-      if (lane == 0) gin0[r] = to_x ? gr : 0.f;
-      gr = to_x ? 0.f : gr;
-    }
-    dbe += gr;
-    // dP[c] = gr * (inv * w_e[c] - k3 * dot * P[c]),   P = M * tt
-    const float ka = gr * inv, kb = gr * l2n_k(ss, inv) * dot;
 #pragma unroll
-    for (int i = 0; i < MAXCI; ++i) {
-      const int c = 4 * lane + 256 * i;
-      if (c < Mp) {
-        const float p0 = m4[i].x * t4[i].x, p1 = m4[i].y * t4[i].y, p2 = m4[i].z * t4[i].z,
-                    p3 = m4[i].w * t4[i].w;
-        const float d0 = ka * e4[i].x - kb * p0, d1 = ka * e4[i].y - kb * p1,
-                    d2 = ka * e4[i].z - kb * p2, d3 = ka * e4[i].w - kb * p3;
-        dwe[i].x += ka * p0; dwe[i].y += ka * p1; dwe[i].z += ka * p2; dwe[i].w += ka * p3;
-        dtt[i].x += d0 * m4[i].x; dtt[i].y += d1 * m4[i].y; dtt[i].z += d2 * m4[i].z;
-        dtt[i].w += d3 * m4[i].w;
-        if (gr != 0.f) {                            // wave-uniform
-          float* dm = dMbuf + (size_t)r * Mp + c;
-          if (c + 0 < M) atomicAdd(dm + 0, d0 * t4[i].x);
-          if (c + 1 < M) atomicAdd(dm + 1, d1 * t4[i].y);
-          if (c + 2 < M) atomicAdd(dm + 2, d2 * t4[i].z);
-          if (c + 3 < M) atomicAdd(dm + 3, d3 * t4[i].w);
+    for (int u = 0; u < UR; ++u) {
+      const int r = rb + u * RSTEP;
+      if (r >= r1) break;                               // wave-uniform
+      float4* m4 = mrow[u];
+      float ss = 0.f, dot = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXCI; ++i) {
+        const int c = 4 * lane + 256 * i;
+        if (c < Mp) {
+          const float p0 = m4[i].x * t4[i].x, p1 = m4[i].y * t4[i].y, p2 = m4[i].z * t4[i].z,
+                      p3 = m4[i].w * t4[i].w;
+          ss += p0 * p0 + p1 * p1 + p2 * p2 + p3 * p3;
+          dot += p0 * e4[i].x + p1 * e4[i].y + p2 * e4[i].z + p3 * e4[i].w;
+        }
+      }
+      ss = wave_sum(ss);
+      dot = wave_sum(dot);
+      const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+      float gr = grv[u];
+      if (in0) {                                     // Filter: tf.minimum(input_0, att), tie -> input_0
+        const float att = dot * inv + be;
+        const float x = xin[u];
+        const bool to_x = x <= att;
+        if (lane == 0) gin0[r] = to_x ? gr : 0.f;
+        gr = to_x ? 0.f : gr;
+      }
+      dbe += gr;
+      // dP[c] = gr * (inv * w_e[c] - k3 * dot * P[c]),   P = M * tt
+      const float ka = gr * inv, kb = gr * l2n_k(ss, inv) * dot;
+#pragma unroll
+      for (int i = 0; i < MAXCI; ++i) {
+        const int c = 4 * lane + 256 * i;
+        if (c < Mp) {
+          const float p0 = m4[i].x * t4[i].x, p1 = m4[i].y * t4[i].y, p2 = m4[i].z * t4[i].z,
+                      p3 = m4[i].w * t4[i].w;
+          const float d0 = ka * e4[i].x - kb * p0, d1 = ka * e4[i].y - kb * p1,
+                      d2 = ka * e4[i].z - kb * p2, d3 = ka * e4[i].w - kb * p3;
+          dwe[i].x += ka * p0; dwe[i].y += ka * p1; dwe[i].z += ka * p2; dwe[i].w += ka * p3;
+          dtt[i].x += d0 * m4[i].x; dtt[i].y += d1 * m4[i].y; dtt[i].z += d2 * m4[i].z;
+          dtt[i].w += d3 * m4[i].w;
+          if (gr != 0.f) {                            // wave-uniform
+            // several nodes may share a conv_image slab -> atomic adds; a lane holds 4 consecutive
+            // channels, so adding them directly is four 16-B-strided atomics (8 cache lines each,
+            // 30 of the kernel's 51 us): transposed through LDS each atomic covers 64 consecutive
+            // channels (2 lines)
+            *reinterpret_cast<float4*>(xp + 4 * lane) =
+                make_float4(d0 * t4[i].x, d1 * t4[i].y, d2 * t4[i].z, d3 * t4[i].w);
+            float* dm = dMbuf + (size_t)r * Mp + 256 * i;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int cc = lane + 64 * k;
+              const float v = xp[cc];
+              if (256 * i + cc < M) atomicAdd(dm + cc, v);
+            }
+          }
         }
       }
     }
@@ -679,9 +756,13 @@ void launch_heads_bwd(const ModuleWeights& w, const ModuleBuffers& b, const Modu
 
 void launch_pool_bwd(const ModuleWeights& w, const ModuleBuffers& b, const ModuleGrads& g,
                      int tab_off, int count, int stride, hipStream_t s) {
+  const int dper = ((b.D / PB_PARTS) + 3) & ~3;
+  const size_t smem = sizeof(float) * (2 * (size_t)b.Mp + 2 * (size_t)dper);
+  hipLaunchKernelGGL(pool_bwd_kernel, dim3(count, PB_PARTS), dim3(PB_T), smem, s, w, b, g, tab_off,
+                     stride);
   const int HWq = (b.H * b.W + 3) & ~3;
-  const size_t smem = sizeof(float) * (2 * (size_t)b.Mp + 2 * (size_t)b.D + 4 * (size_t)HWq + 16);
-  hipLaunchKernelGGL(pool_bwd_kernel, dim3(count), dim3(PB_T), smem, s, w, b, g, tab_off, stride);
+  hipLaunchKernelGGL(pool_bwd_fin_kernel, dim3(count), dim3(256),
+                     sizeof(float) * (16 + 2 * (size_t)HWq), s, b, g, tab_off, stride);
 }
 
 void launch_att_bwd(const ModuleWeights& w, const ModuleBuffers& b, const ModuleGrads& g,
@@ -694,7 +775,7 @@ void launch_att_bwd(const ModuleWeights& w, const ModuleBuffers& b, const Module
   const size_t tr = (size_t)b.M * RS + (((size_t)(b.H + 2 * pad) * (b.W + 2 * pad) + 3) & ~3) +
                     2 * 64 + 4 * 64 * 2 + 16;
   (void)HWq;
-  const size_t fe = 8 * (size_t)b.Mp + 16;
+  const size_t fe = 8 * (size_t)b.Mp + 16 + 4 * 256;
   const size_t la = 2 * (size_t)((2 * HW + 4 + 3) & ~3) + ((b.C + 31) & ~31) + 16;
   const size_t smem = sizeof(float) * std::max(tr, std::max(fe, la));
   if (smem > 64 * 1024)
