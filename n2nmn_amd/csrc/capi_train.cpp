@@ -155,9 +155,9 @@ size_t carve_train(n2nmn_ctx* c, TrainState* t, char* base) {
   const size_t Ep = round_up((int)E, 64);
   t->enc_W0xT_p = k.take<float>((size_t)t->KpL4 * Ep);
   t->dec_W0xT_p = k.take<float>((size_t)t->KpL4 * Ep);
-  t->tslot_row = k.take<int32_t>(c->max_text);
-  t->tslot_ws = k.take<int32_t>(c->max_text);
-  t->pool_sel = k.take<int32_t>((size_t)c->max_pool * 2);
+  t->tslot_row = k.take<int32_t>(2 * (size_t)c->max_text + 2 * (size_t)c->max_pool);   // one block,
+  t->tslot_ws = t->tslot_row + c->max_text;                  // laid out like the pinned tab_host
+  t->pool_sel = t->tslot_ws + c->max_text;
   t->m = k.take<float>((size_t)t->total);
   t->v = k.take<float>((size_t)t->total);
   t->norm2 = k.take<float>(V_COUNT_);
@@ -501,16 +501,23 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
   auto mir = [&](int var) { return (const float*)c->vars[var].mirror; };
 
   if (phase == 0) {
-    N2_HIP(hipMemsetAsync(io->grads, 0, sizeof(float) * (size_t)t->total, s));
     // ------------------------------- module network ---------------------------------------
     const int nn = (int)p.dev_nodes.size();
-    // garena, dtmap, dpfc, dwv, the carried dH/dC, both x-table gradients, the active-row counter
-    N2_HIP(hipMemsetAsync(t->zero_begin, 0, (size_t)(t->zero_end - t->zero_begin), s));
+    {
+      // one launch clears the flat gradient, the per-step block (garena, dtmap, dpfc, gda, dwv, the
+      // carried dH/dC, both x-table gradients, the active-row counter) and the used part of the
+      // two d conv_image slabs
+      ZeroRanges z{};
+      auto add = [&](void* ptr, size_t bytes) { if (bytes) { z.ptr[z.n] = ptr; z.bytes[z.n] = bytes; ++z.n; } };
+      add(io->grads, sizeof(float) * (size_t)t->total);
+      add(t->zero_begin, (size_t)(t->zero_end - t->zero_begin));
+      if (nn > 0) {
+        add(t->dmfind, sizeof(float) * (size_t)p.num_find_img * HW * Mp);
+        add(t->dmfsp, sizeof(float) * (size_t)p.num_fsp_img * HW * Mp);
+      }
+      launch_zero_ranges(z, s);
+    }
     if (nn > 0) {
-      if (p.num_find_img)
-        N2_HIP(hipMemsetAsync(t->dmfind, 0, sizeof(float) * (size_t)p.num_find_img * HW * Mp, s));
-      if (p.num_fsp_img)
-        N2_HIP(hipMemsetAsync(t->dmfsp, 0, sizeof(float) * (size_t)p.num_fsp_img * HW * Mp, s));
       // tables: text slot -> (word_vecs row, weight set); pooling slot/input -> fc_att weight set
       {
         N2_HIP(hipEventSynchronize(t->tab_ev));
@@ -537,12 +544,10 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
             else sel[2 * nd.pslot] = 3;
           }
         }
-        if (p.num_text) {
-          N2_HIP(hipMemcpyAsync(t->tslot_row, row, sizeof(int32_t) * p.num_text, hipMemcpyHostToDevice, s));
-          N2_HIP(hipMemcpyAsync(t->tslot_ws, ws, sizeof(int32_t) * p.num_text, hipMemcpyHostToDevice, s));
-        }
-        if (p.num_pool)
-          N2_HIP(hipMemcpyAsync(t->pool_sel, sel, sizeof(int32_t) * 2 * p.num_pool, hipMemcpyHostToDevice, s));
+        // the three tables are one block on both sides: one upload
+        N2_HIP(hipMemcpyAsync(t->tslot_row, row,
+                              sizeof(int32_t) * (2 * (size_t)c->max_text + 2 * (size_t)p.num_pool),
+                              hipMemcpyHostToDevice, s));
         N2_HIP(hipEventRecord(t->tab_ev, s));
       }
       ModuleWeights w = module_weights(c);

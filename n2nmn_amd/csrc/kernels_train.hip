@@ -277,6 +277,23 @@ __global__ __launch_bounds__(256, WT == 1 ? 4 : 2) void gemm_tn_kernel(const Gem
   }
 }
 
+__global__ __launch_bounds__(256) void zero_ranges_kernel(ZeroRanges z) {
+  const size_t gtid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const size_t gsz = gridDim.x * (size_t)blockDim.x;
+  for (int i = 0; i < z.n; ++i) {
+    char* p = static_cast<char*>(z.ptr[i]);
+    const size_t nb = z.bytes[i];
+    // head up to a 16-B boundary, 16-B body, 4-B tail
+    const size_t head = min(nb, (size_t)((16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15));
+    const size_t body = (nb - head) / 16;
+    const size_t tail0 = head + body * 16;
+    if (gtid < head / 4) reinterpret_cast<float*>(p)[gtid] = 0.f;
+    float4* b4 = reinterpret_cast<float4*>(p + head);
+    for (size_t j = gtid; j < body; j += gsz) b4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gtid < (nb - tail0) / 4) reinterpret_cast<float*>(p + tail0)[gtid] = 0.f;
+  }
+}
+
 __global__ void active_rows_kernel(const int32_t* __restrict__ seq_len, int T, int N,
                                    int32_t* __restrict__ rows, int32_t* __restrict__ count) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -520,19 +537,46 @@ __global__ __launch_bounds__(256) void dec_bwd_a_kernel(DecBwdArgs a) {
     else { dctx[k - L] = s; a.dctx[tn * L + (k - L)] = s; }
   }
   __syncthreads();
-  // datt[tau] = dctx . eout[tau, n, :] + datts_wv     (wave per tau)
-  for (int tau = w; tau < T; tau += 4) {
-    float s = 0.f;
-    if (tau < len) {
-      const float* er = a.eout + ((size_t)tau * N + n) * L;
-      for (int k = 4 * lane; k < L; k += 256) {
-        const float4 e4 = *reinterpret_cast<const float4*>(er + k);
-        const float4 d4 = *reinterpret_cast<const float4*>(dctx + k);
-        s += e4.x * d4.x + e4.y * d4.y + e4.z * d4.z + e4.w * d4.w;
+  // datt[tau] = dctx . eout[tau, n, :] + datts_wv     (wave per tau; the rows of UT taus are
+  // fetched before any is reduced -- one row per trip made every trip a full memory round trip)
+  constexpr int UT = 4;
+  {
+    float4 d4[DB_MAXKI];
+#pragma unroll
+    for (int i = 0; i < DB_MAXKI; ++i) {
+      const int k = 4 * lane + 256 * i;
+      if (k < L) d4[i] = *reinterpret_cast<const float4*>(dctx + k);
+    }
+    for (int tau0 = w; tau0 < T; tau0 += 4 * UT) {
+      float4 e4[UT][DB_MAXKI];
+      float wvv[UT];
+#pragma unroll
+      for (int u = 0; u < UT; ++u) {
+        const int tau = tau0 + 4 * u;
+        const int tr = tau < len ? tau : 0;              // clamped: loads stay unconditional
+        const float* er = a.eout + ((size_t)tr * N + n) * L;
+#pragma unroll
+        for (int i = 0; i < DB_MAXKI; ++i) {
+          const int k = 4 * lane + 256 * i;
+          if (k < L) e4[u][i] = *reinterpret_cast<const float4*>(er + k);
+        }
+        wvv[u] = a.datts_wv[((size_t)t * T + (tau < T ? tau : 0)) * N + n];
+      }
+#pragma unroll
+      for (int u = 0; u < UT; ++u) {
+        const int tau = tau0 + 4 * u;
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < DB_MAXKI; ++i) {
+          const int k = 4 * lane + 256 * i;
+          if (k < L)
+            sacc += e4[u][i].x * d4[i].x + e4[u][i].y * d4[i].y + e4[u][i].z * d4[i].z +
+                    e4[u][i].w * d4[i].w;
+        }
+        sacc = wave_sum(sacc);
+        if (lane == 0 && tau < T) des[tau] = (tau < len ? sacc : 0.f) + wvv[u];
       }
     }
-    s = wave_sum(s);
-    if (lane == 0) des[tau] = s + a.datts_wv[((size_t)t * T + tau) * N + n];
   }
   __syncthreads();
   {
@@ -560,19 +604,36 @@ __global__ __launch_bounds__(256) void dec_bwd_a_kernel(DecBwdArgs a) {
         q4[i] = *reinterpret_cast<const float4*>(qrow + k);
       }
     }
-    for (int tau = w; tau < len && tau < T; tau += 4) {
-      const float d = des[tau];
-      const float* er = a.eht + ((size_t)tau * N + n) * L;
+    const int tend = min(len, T);
+    for (int tau0 = w; tau0 < tend; tau0 += 4 * UT) {
+      float4 e4[UT][DB_MAXKI];
+      float dd[UT];
 #pragma unroll
-      for (int i = 0; i < DB_MAXKI; ++i) {
-        const int k = 4 * lane + 256 * i;
-        if (k < L) {
-          const float4 e4 = *reinterpret_cast<const float4*>(er + k);
-          const float t0 = fast_tanh(q4[i].x + e4.x), t1 = fast_tanh(q4[i].y + e4.y),
-                      t2 = fast_tanh(q4[i].z + e4.z), t3 = fast_tanh(q4[i].w + e4.w);
-          dv4[i].x += d * t0; dv4[i].y += d * t1; dv4[i].z += d * t2; dv4[i].w += d * t3;
-          dq4[i].x += d * v4[i].x * (1.f - t0 * t0); dq4[i].y += d * v4[i].y * (1.f - t1 * t1);
-          dq4[i].z += d * v4[i].z * (1.f - t2 * t2); dq4[i].w += d * v4[i].w * (1.f - t3 * t3);
+      for (int u = 0; u < UT; ++u) {                   // rows of UT taus in flight
+        const int tau = tau0 + 4 * u;
+        const int tr = tau < tend ? tau : tau0;
+        dd[u] = tau < tend ? des[tau] : 0.f;           // a zero weight switches the trip off
+        const float* er = a.eht + ((size_t)tr * N + n) * L;
+#pragma unroll
+        for (int i = 0; i < DB_MAXKI; ++i) {
+          const int k = 4 * lane + 256 * i;
+          if (k < L) e4[u][i] = *reinterpret_cast<const float4*>(er + k);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UT; ++u) {
+        const float d = dd[u];
+#pragma unroll
+        for (int i = 0; i < DB_MAXKI; ++i) {
+          const int k = 4 * lane + 256 * i;
+          if (k < L) {
+            const float4 e = e4[u][i];
+            const float t0 = fast_tanh(q4[i].x + e.x), t1 = fast_tanh(q4[i].y + e.y),
+                        t2 = fast_tanh(q4[i].z + e.z), t3 = fast_tanh(q4[i].w + e.w);
+            dv4[i].x += d * t0; dv4[i].y += d * t1; dv4[i].z += d * t2; dv4[i].w += d * t3;
+            dq4[i].x += d * v4[i].x * (1.f - t0 * t0); dq4[i].y += d * v4[i].y * (1.f - t1 * t1);
+            dq4[i].z += d * v4[i].z * (1.f - t2 * t2); dq4[i].w += d * v4[i].w * (1.f - t3 * t3);
+          }
         }
       }
     }
@@ -804,6 +865,11 @@ void launch_gemm_tn(const GemmTnArgs& a, hipStream_t s) {
   splits = (a.R + r_per - 1) / r_per;
   hipLaunchKernelGGL((gemm_tn_kernel<1, 32>), dim3(gx, gy, splits * nprob), dim3(256), 0, s, a,
                      r_per);
+}
+
+void launch_zero_ranges(const ZeroRanges& z, hipStream_t s) {
+  if (z.n <= 0) return;
+  hipLaunchKernelGGL(zero_ranges_kernel, dim3(2048), dim3(256), 0, s, z);
 }
 
 void launch_active_rows(const int32_t* seq_len, int T, int N, int32_t* rows, int32_t* count,
