@@ -84,9 +84,18 @@ __global__ __launch_bounds__(MT) void heads_bwd_kernel(ModuleWeights w, ModuleBu
       const float en = evs[c] * inv;
       const float* wr = w.Wans[wi] + (size_t)c * C;
       float* gw = g.gWans[wi] + (size_t)c * C;
-      for (int k = 0; k < C; ++k) {
-        den += wr[k] * ds[k];
-        atomicAdd(gw + k, en * ds[k]);
+      // loads first, atomics afterwards, in chunks: interleaved, every W_e load waits behind the
+      // preceding atomic (they may alias as far as the compiler knows) -- C round trips in a chain
+      for (int k0 = 0; k0 < C; k0 += 8) {
+        float wv8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wv8[j] = wr[min(k0 + j, C - 1)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (k0 + j < C) den += wv8[j] * ds[k0 + j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (k0 + j < C) atomicAdd(gw + k0 + j, en * ds[k0 + j]);
       }
       ldot += evs[c] * den;
     }
@@ -715,32 +724,58 @@ __global__ __launch_bounds__(MT) void textmap_bwd_kernel(ModuleWeights w, Module
   const int E = b.E, Mp = b.Mp;
   float* dt = smem;                         // [TM_GROUP][Mp]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  for (int i = tid; i < TM_GROUP * Mp; i += MT) {
-    const int gi = i / Mp, c = i - gi * Mp;
-    dt[i] = gi < cnt ? g.dtmap[(size_t)b.nodes[tab[2 + gi]].tslot * Mp + c] : 0.f;
+  // a wave copies whole d tmap rows: the node -> slot lookup (two dependent loads) once per row,
+  // not once per element
+  for (int gi = wid; gi < TM_GROUP; gi += MT / 64) {
+    const int slot = gi < cnt ? b.nodes[tab[2 + gi]].tslot : -1;
+    for (int c = 4 * lane; c < Mp; c += 256)
+      *reinterpret_cast<float4*>(dt + gi * Mp + c) =
+          slot >= 0 ? *reinterpret_cast<const float4*>(g.dtmap + (size_t)slot * Mp + c)
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   __syncthreads();
   const float* Wp = w.Wtxt[ws];
   const int eper = (E + gridDim.y - 1) / gridDim.y;
   const int e0 = blockIdx.y * eper, e1 = min(E, e0 + eper);
-  for (int e = e0 + wid; e < e1; e += MT / 64) {
-    float s[TM_GROUP];
+  // a wave takes rows e0 + wid, + 4, ...: the W_txt rows of UE of them are fetched together
+  constexpr int UE = 8;
+  constexpr int MAXM4 = 4;                   // Mp <= 1024
+  for (int eb = e0 + wid; eb < e1; eb += UE * (MT / 64)) {
+    float4 w4[UE][MAXM4];
 #pragma unroll
-    for (int gi = 0; gi < TM_GROUP; ++gi) s[gi] = 0.f;
-    for (int m = 4 * lane; m < Mp; m += 256) {
-      const float4 w4 = *reinterpret_cast<const float4*>(Wp + (size_t)e * Mp + m);
+    for (int u = 0; u < UE; ++u) {
+      const int e = min(eb + u * (MT / 64), e1 - 1);   // clamped: loads stay unconditional
 #pragma unroll
-      for (int gi = 0; gi < TM_GROUP; ++gi) {
-        const float4 d4 = *reinterpret_cast<const float4*>(dt + gi * Mp + m);
-        s[gi] += w4.x * d4.x + w4.y * d4.y + w4.z * d4.z + w4.w * d4.w;
+      for (int i = 0; i < MAXM4; ++i) {
+        const int m = 4 * lane + 256 * i;
+        if (m < Mp) w4[u][i] = *reinterpret_cast<const float4*>(Wp + (size_t)e * Mp + m);
       }
     }
 #pragma unroll
-    for (int gi = 0; gi < TM_GROUP; ++gi) {
-      const float r = wave_sum(s[gi]);
-      if (lane == 0 && gi < cnt) {
-        const DevNode& nd = b.nodes[tab[2 + gi]];
-        g.dwv[((size_t)nd.t * b.N_full + nd.n) * E + e] = r;
+    for (int u = 0; u < UE; ++u) {
+      const int e = eb + u * (MT / 64);
+      if (e >= e1) break;                              // wave-uniform
+      float s[TM_GROUP];
+#pragma unroll
+      for (int gi = 0; gi < TM_GROUP; ++gi) s[gi] = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXM4; ++i) {
+        const int m = 4 * lane + 256 * i;
+        if (m < Mp) {
+#pragma unroll
+          for (int gi = 0; gi < TM_GROUP; ++gi) {
+            const float4 d4 = *reinterpret_cast<const float4*>(dt + gi * Mp + m);
+            s[gi] += w4[u][i].x * d4.x + w4[u][i].y * d4.y + w4[u][i].z * d4.z + w4[u][i].w * d4.w;
+          }
+        }
+      }
+#pragma unroll
+      for (int gi = 0; gi < TM_GROUP; ++gi) {
+        const float r = wave_sum(s[gi]);
+        if (lane == 0 && gi < cnt) {
+          const DevNode& nd = b.nodes[tab[2 + gi]];
+          g.dwv[((size_t)nd.t * b.N_full + nd.n) * E + e] = r;
+        }
       }
     }
   }
