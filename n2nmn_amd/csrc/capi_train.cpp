@@ -92,7 +92,7 @@ void train_state_destroy(TrainState* t) {
 
 namespace {
 
-constexpr int SEG_ELEMS = 4096;
+constexpr int SEG_ELEMS = 16384;
 
 size_t carve_train(n2nmn_ctx* c, TrainState* t, char* base) {
   const n2nmn_dims& d = c->d;
