@@ -209,54 +209,68 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
   }
   __syncthreads();
   const PackJob jb = jobs[sj];
-  const size_t base = (size_t)(blockIdx.x - jb.block0) * PACK_ELEMS_PER_BLOCK;
-  for (int e = threadIdx.x; e < PACK_ELEMS_PER_BLOCK; e += 256) {
-    const size_t i = base + e;
-    if (i >= jb.total) break;
+  const uint32_t base = (uint32_t)(blockIdx.x - jb.block0) * PACK_ELEMS_PER_BLOCK;
+  // 32-bit index arithmetic (every job has < 2^31 elements; the 64-bit divisions of the first
+  // version were most of the kernel), and the 16 elements of a thread are gathered in two groups
+  // of 8 independent loads before anything is stored
+  constexpr int PER = PACK_ELEMS_PER_BLOCK / 256, U = 8;
+  static_assert(PER % U == 0, "whole groups");
+  // element i -> (source offset or -1 for a zero, destination offset)
+  auto map = [&](uint32_t i, int64_t& so, uint32_t& dofs) {
+    dofs = i;
     switch (jb.kind) {
       case PJ_PK:
       case PJ_PK_T: {
-        const int ld = jb.p[0], K = jb.p[1], N = jb.p[2], Np = jb.p[4];
-        const int kk = (int)(i & 3);
-        const size_t r = i >> 2;
-        const int n = (int)(r % Np);
-        const int kq = (int)(r / Np) * 4 + kk;
-        float v = 0.f;
-        if (kq < K && n < N)
-          v = jb.kind == PJ_PK ? jb.src[(size_t)kq * ld + n] : jb.src[(size_t)n * ld + kq];
-        jb.dst[i] = v;
+        const uint32_t ld = jb.p[0], K = jb.p[1], N = jb.p[2], Np = jb.p[4];
+        const uint32_t kk = i & 3, r = i >> 2;
+        const uint32_t q = r / Np, n = r - q * Np;
+        const uint32_t kq = q * 4 + kk;
+        so = (kq < K && n < N) ? (jb.kind == PJ_PK ? (int64_t)kq * ld + n : (int64_t)n * ld + kq)
+                               : -1;
         break;
       }
       case PJ_TILES: {
-        const int ld = jb.p[0], row0 = jb.p[1], K = jb.p[2], gate_L = jb.p[3];
-        const int kk = (int)(i & 3);
-        const int c = (int)((i >> 2) & 15);
-        const size_t r = i >> 6;
-        const int k4 = (int)(r % (K / 4));
-        const int j = (int)(r / (K / 4));
-        const int col = gate_L > 0 ? (c >> 2) * gate_L + 4 * j + (c & 3) : 16 * j + c;
-        jb.dst[i] = jb.src[(size_t)(row0 + 4 * k4 + kk) * ld + col];
+        const uint32_t ld = jb.p[0], row0 = jb.p[1], K = jb.p[2], gate_L = jb.p[3];
+        const uint32_t kk = i & 3, c = (i >> 2) & 15, r = i >> 6;
+        const uint32_t K4 = K >> 2;
+        const uint32_t j = r / K4, k4 = r - j * K4;
+        const uint32_t col = gate_L > 0 ? (c >> 2) * gate_L + 4 * j + (c & 3) : 16 * j + c;
+        so = (int64_t)(row0 + 4 * k4 + kk) * ld + col;
         break;
       }
       case PJ_TILES_T: {
-        const int ld = jb.p[0], row0 = jb.p[1], L = jb.p[2], Ktot = jb.p[3], k_off = jb.p[4];
-        const int gi = (int)(i & 3);
-        const int c = (int)((i >> 2) & 15);
-        const size_t r = i >> 6;
-        const int u = (int)(r % L);
-        const int j = (int)(r / L);
-        jb.dst[(((size_t)j * (Ktot / 4) + k_off / 4 + u) * 16 + c) * 4 + gi] =
-            jb.src[(size_t)(row0 + 16 * j + c) * ld + (size_t)gi * L + u];
+        const uint32_t ld = jb.p[0], row0 = jb.p[1], L = jb.p[2], Ktot = jb.p[3], k_off = jb.p[4];
+        const uint32_t gi = i & 3, c = (i >> 2) & 15, r = i >> 6;
+        const uint32_t j = r / L, u = r - j * L;
+        dofs = ((j * (Ktot >> 2) + (k_off >> 2) + u) * 16 + c) * 4 + gi;
+        so = (int64_t)(row0 + 16 * j + c) * ld + (int64_t)gi * L + u;
         break;
       }
       default: {   // PJ_PAD
-        const int M = jb.p[1], Mp = jb.p[2];
-        const int c = (int)(i % Mp);
-        const size_t r = i / Mp;
-        jb.dst[i] = c < M ? jb.src[r * M + c] : 0.f;
+        const uint32_t M = jb.p[1], Mp = jb.p[2];
+        const uint32_t r = i / Mp, c = i - r * Mp;
+        so = c < M ? (int64_t)r * M + c : -1;
         break;
       }
     }
+  };
+  for (int g0 = 0; g0 < PER; g0 += U) {
+    float v[U];
+    uint32_t dofs[U];
+    bool on[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t i = base + threadIdx.x + 256 * (g0 + u);
+      on[u] = i < jb.total;
+      int64_t so = -1;
+      dofs[u] = 0;
+      if (on[u]) map(i, so, dofs[u]);
+      v[u] = jb.src[so >= 0 ? so : 0];          // unconditional load from a valid address
+      if (so < 0) v[u] = 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (on[u]) jb.dst[dofs[u]] = v[u];
   }
 }
 
