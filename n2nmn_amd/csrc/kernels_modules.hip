@@ -114,14 +114,17 @@ __global__ __launch_bounds__(MT) void textmap_kernel(ModuleWeights w, ModuleBuff
   float* wv = smem;                       // [TM_GROUP][E]
   float* part = wv + TM_GROUP * E;        // [4 waves][TM_GROUP][256]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  for (int i = tid; i < TM_GROUP * E; i += MT) {
-    const int g = i / E, e = i - g * E;
-    float v = 0.f;
+  // a wave copies whole word vectors: the node lookup (two dependent loads) once per row instead
+  // of once per element in front of every load
+  __shared__ int tslots[TM_GROUP];
+  for (int g = wid; g < TM_GROUP; g += MT / 64) {
+    const float* src = nullptr;
     if (g < cnt) {
       const DevNode& nd = b.nodes[tab[2 + g]];
-      v = b.word_vecs[((size_t)nd.t * b.N_full + nd.n) * E + e];   // nmn3_modules.py:53-57
+      src = b.word_vecs + ((size_t)nd.t * b.N_full + nd.n) * E;    // nmn3_modules.py:53-57
+      if (lane == 0) tslots[g] = nd.tslot;
     }
-    wv[i] = v;
+    for (int e = lane; e < E; e += 64) wv[g * E + e] = src ? src[e] : 0.f;
   }
   __syncthreads();
   // K-split over the 4 waves, float4 columns over the lanes: every lane streams its slice of
@@ -135,13 +138,22 @@ __global__ __launch_bounds__(MT) void textmap_kernel(ModuleWeights w, ModuleBuff
 #pragma unroll
     for (int g = 0; g < TM_GROUP; ++g) acc[g] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float4* wp = Wp4 + (cb >> 2) + lane;
-#pragma unroll 5
-    for (int e = e0; e < e1; ++e) {
-      const float4 w4 = wp[(size_t)e * (Mp >> 2)];
+    constexpr int UE = 15;                  // weight rows of a lane in flight
+    for (int eb = e0; eb < e1; eb += UE) {
+      float4 w4[UE];
 #pragma unroll
-      for (int g = 0; g < TM_GROUP; ++g) {
-        const float x = wv[g * E + e];
-        acc[g].x += x * w4.x; acc[g].y += x * w4.y; acc[g].z += x * w4.z; acc[g].w += x * w4.w;
+      for (int u = 0; u < UE; ++u) w4[u] = wp[(size_t)min(eb + u, e1 - 1) * (Mp >> 2)];
+#pragma unroll
+      for (int u = 0; u < UE; ++u) {
+        const int e = eb + u;
+        if (e < e1) {
+#pragma unroll
+          for (int g = 0; g < TM_GROUP; ++g) {
+            const float x = wv[g * E + e];
+            acc[g].x += x * w4[u].x; acc[g].y += x * w4[u].y; acc[g].z += x * w4[u].z;
+            acc[g].w += x * w4[u].w;
+          }
+        }
       }
     }
     __syncthreads();
@@ -155,7 +167,7 @@ __global__ __launch_bounds__(MT) void textmap_kernel(ModuleWeights w, ModuleBuff
         float r = bm[cb + c];
 #pragma unroll
         for (int q = 0; q < 4; ++q) r += part[(size_t)(q * TM_GROUP + g) * 256 + c];
-        b.tmap[(size_t)b.nodes[tab[2 + g]].tslot * Mp + cb + c] = r;
+        b.tmap[(size_t)tslots[g] * Mp + cb + c] = r;
       }
     }
   }
