@@ -267,10 +267,29 @@ typedef struct {
   float weight_decay;              /* 5e-6 (train_clevr_gt_layout.py:39)                     */
   /* outputs */
   float *scores;                   /* [N, num_choices] answer logits                         */
-  float *losses;                   /* [4]: avg_sample_loss, seq_likelihood_loss, l2_reg, total_loss
-                                      (l2_reg / total_loss are complete after backward phase 1) */
+  float *losses;                   /* [8]: avg_sample_loss, seq_likelihood_loss (cloning) or
+                                      policy_gradient_loss (policy gradient), l2_reg, total_loss,
+                                      entropy_reg, 3 reserved  (l2_reg / total_loss are complete
+                                      after backward phase 1)                                */
   float *grads;                    /* flat [n2nmn_grad_numel]: d total_loss / d variable     */
+  /* objective (zero-initialised = behavioural cloning, the fields below are then ignored).
+   * N2NMN_OBJ_POLICY_GRADIENT = exp_clevr/train_clevr_rl_gt_layout.py:107-129:
+   *   final_loss = expr_validity ? CE : invalid_expr_loss;  avg_sample_loss = mean(final_loss)
+   *   policy_gradient_loss = mean(stop_gradient(final_loss - baseline) * log_seq_prob)
+   *   total_loss = policy_gradient_loss + avg_sample_loss + lambda_entropy * entropy_reg
+   *                + weight_decay * l2_reg;   baseline += (1 - baseline_decay)(avg - baseline)
+   * gt_layout then holds the tokens the decoder SAMPLED for this batch (n2nmn_seq2seq_forward
+   * with sample_uniforms); token validity comes from the automaton as it did when they were drawn
+   * (nmn3_netgen_att.py:200-260), `p` is the program assembled from them.                   */
+  int32_t objective;
+  const int32_t *expr_validity;    /* [N] device: 1 = the layout assembled (n2nmn_assemble)  */
+  float invalid_expr_loss;         /* 0.5           (train_clevr_rl_gt_layout.py:40)         */
+  float lambda_entropy;            /* 0.005         (:41)                                    */
+  float baseline_decay;            /* 0.99          (:42)                                    */
+  float *baseline;                 /* device float[1]: read for this step's loss, then updated */
 } n2nmn_train_io;
+#define N2NMN_OBJ_CLONING 0
+#define N2NMN_OBJ_POLICY_GRADIENT 1
 
 /* Allocates the training workspace of a ROOT context (saved activations, backward scratch, Adam
  * moments: ~0.5 GB at CLEVR dimensions).  Idempotent. */

@@ -39,7 +39,10 @@ class TrainIO(C.Structure):
         ('T_enc', C.c_int32), ('N', C.c_int32), ('T_dec', C.c_int32),
         ('gt_layout', C.c_void_p), ('image_feat', C.c_void_p), ('answer_labels', C.c_void_p),
         ('weight_decay', C.c_float),
-        ('scores', C.c_void_p), ('losses', C.c_void_p), ('grads', C.c_void_p)]
+        ('scores', C.c_void_p), ('losses', C.c_void_p), ('grads', C.c_void_p),
+        ('objective', C.c_int32), ('expr_validity', C.c_void_p),
+        ('invalid_expr_loss', C.c_float), ('lambda_entropy', C.c_float),
+        ('baseline_decay', C.c_float), ('baseline', C.c_void_p)]
 
 
 class Node(C.Structure):

@@ -410,9 +410,11 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s) {
     a.q = c->qbuf; a.out = c->dec_h1_all; a.gt = io->gt_layout; a.uni = nullptr; a.forced = nullptr;
     a.tokens = tokens; a.tprobs = tprobs; a.ent_t = c->ent_t; a.atts = atts;
     a.scores = io->token_scores; a.next_idx = nullptr;
+    a.Td = Td;
     if (c->rec) {
       a.ctx_out = c->rec->ctx;
       if (!a.scores) a.scores = c->rec->tscores;
+      a.valid_bits = c->rec->valid_bits;
     }
     {
       ProfScope ps(c, F_DEC_STEP, Td * att_fl, Td * att_by, s);

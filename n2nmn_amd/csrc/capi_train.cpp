@@ -23,6 +23,7 @@ struct TrainState {
   // forward results kept inside the context
   float* scores = nullptr;            // [N][C] (when the caller passes no buffer)
   // backward scratch
+  float *rl_coef = nullptr;           // policy gradient: d total_loss / d log_seq_prob per question
   float *dscores = nullptr, *dsc = nullptr, *garena = nullptr, *dtmap = nullptr, *dpfc = nullptr, *gda = nullptr,
         *dmfind = nullptr, *dmfsp = nullptr, *dwv = nullptr, *datts_wv = nullptr, *dE = nullptr, *de = nullptr,
         *dctx = nullptr, *dq = nullptr, *dout = nullptr, *dvp = nullptr, *deht = nullptr,
@@ -115,6 +116,8 @@ size_t carve_train(n2nmn_ctx* c, TrainState* t, char* base) {
   r.pooled = k.take<float>((size_t)c->max_pool * 2 * D);
   t->scores = k.take<float>(N * C);
   t->dscores = k.take<float>(N * C + 4);
+  t->rl_coef = k.take<float>(N);
+  r.valid_bits = k.take<int32_t>(Td * N);
   t->dsc = k.take<float>(Td * N * 16);
   // [zero block: cleared by ONE memset at the start of backward phase 0]
   t->zero_begin = reinterpret_cast<char*>(k.take<float>(0));
@@ -427,6 +430,16 @@ static int check_train_io(const n2nmn_ctx* c, const n2nmn_train_io* io, const n2
              N2NMN_ECAPACITY, std::string(what) + ": N / T_enc / T_dec exceed the context capacity");
   N2_REQUIRE(p->prog.num_rows == io->N, N2NMN_EINVAL,
              std::string(what) + ": program was not assembled from this batch");
+  N2_REQUIRE(io->objective == N2NMN_OBJ_CLONING || io->objective == N2NMN_OBJ_POLICY_GRADIENT,
+             N2NMN_EINVAL, std::string(what) + ": unknown objective");
+  if (io->objective == N2NMN_OBJ_POLICY_GRADIENT) {
+    N2_REQUIRE(io->expr_validity && io->baseline, N2NMN_EINVAL,
+               std::string(what) + ": policy gradient needs expr_validity and baseline");
+    N2_REQUIRE(io->baseline_decay >= 0.f && io->baseline_decay <= 1.f, N2NMN_EINVAL,
+               std::string(what) + ": baseline_decay outside [0, 1]");
+    N2_REQUIRE(c->d.num_vocab_nmn <= 32, N2NMN_ECAPACITY,
+               std::string(what) + ": policy gradient keeps token validity in 32-bit masks");
+  }
   return N2NMN_OK;
 }
 
@@ -455,7 +468,9 @@ int n2nmn_train_forward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* p
   }
   n2nmn_seq2seq_io sio{};
   sio.input_seq = io->input_seq; sio.seq_length = io->seq_length; sio.T_enc = io->T_enc; sio.N = N;
-  sio.T_dec = io->T_dec; sio.use_gt_layout = 1; sio.gt_layout = io->gt_layout;
+  // policy gradient: the given tokens are the decoder's own samples -> automaton validity (mode 2)
+  const bool rl = io->objective == N2NMN_OBJ_POLICY_GRADIENT;
+  sio.T_dec = io->T_dec; sio.use_gt_layout = rl ? 2 : 1; sio.gt_layout = io->gt_layout;
   t->last_N = N; t->last_T = io->T_enc; t->last_Td = io->T_dec;
   c->rec = &t->rec;
   rc = encoder_impl(c, &sio, s);
@@ -476,10 +491,20 @@ int n2nmn_train_forward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* p
   if (scores != t->scores)
     N2_HIP(hipMemcpyAsync(t->scores, scores, sizeof(float) * (size_t)N * d.num_choices,
                           hipMemcpyDeviceToDevice, s));
-  N2_HIP(hipMemsetAsync(io->losses, 0, sizeof(float) * 4, s));
+  N2_HIP(hipMemsetAsync(io->losses, 0, sizeof(float) * 8, s));
   {
     ProfScope ps(c, F_BWD_MISC, 6.0 * N * d.num_choices, 4.0 * 2 * N * d.num_choices, s);
-    launch_loss(t->scores, io->answer_labels, t->rec.lsp, N, d.num_choices, t->dscores, io->losses, s);
+    if (rl) {
+      LossRlArgs la{};
+      la.scores = t->scores; la.labels = io->answer_labels; la.log_seq_prob = t->rec.lsp;
+      la.neg_entropy = c->negent; la.expr_validity = io->expr_validity; la.N = N;
+      la.C = d.num_choices; la.invalid_expr_loss = io->invalid_expr_loss;
+      la.baseline_decay = io->baseline_decay; la.baseline = io->baseline; la.dscores = t->dscores;
+      la.losses = io->losses; la.coef = t->rl_coef;
+      launch_loss_rl(la, s);
+    } else {
+      launch_loss(t->scores, io->answer_labels, t->rec.lsp, N, d.num_choices, t->dscores, io->losses, s);
+    }
   }
   return check_launch("train_forward");
 }
@@ -672,6 +697,10 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
     a.eout = c->enc_out; a.atts = c->atts; a.datts_wv = t->datts_wv; a.seq_len = io->seq_length;
     a.v = mir(V_ATT_V); a.Wy = mir(V_TOK_W); a.T = T; a.N = N; a.L = L; a.V = V; a.Td = Td;
     a.inv_n = 1.0f / (float)N;
+    if (io->objective == N2NMN_OBJ_POLICY_GRADIENT) {
+      a.coef = t->rl_coef; a.valid_bits = t->rec.valid_bits;
+      a.ent_coef = io->lambda_entropy / (float)N;
+    }
     a.dsc = t->dsc; a.dout = t->dout; a.dctx = t->dctx; a.de = t->de; a.dq = t->dq; a.dvp = t->dvp;
     a.deht = t->deht; a.deout = t->denc_out;
     {
@@ -778,7 +807,8 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
     launch_grad_finish(io->grads, (const float* const*)t->mirrors_dev, t->var_off_dev, t->decay_dev,
                        t->segs_dev, t->nsegs_early, 1.0f, io->weight_decay, io->losses + 2, s);
   }
-  launch_loss_total(io->losses, io->weight_decay, s);
+  launch_loss_total(io->losses, io->weight_decay,
+                    io->objective == N2NMN_OBJ_POLICY_GRADIENT ? io->lambda_entropy : 0.f, s);
   return check_launch("train_backward(1)");
 }
 

@@ -105,6 +105,7 @@ struct TrainRec {
   float *ctx = nullptr;        // [Td][N][L]
   float *tscores = nullptr;    // [Td][N][V]
   float *lsp = nullptr;        // [N] log_seq_prob
+  int32_t *valid_bits = nullptr;   // [Td][N] token validity of the forward (policy gradient)
   float *pooled = nullptr;     // [max_pool][2][D]
 };
 struct TrainState;

@@ -127,8 +127,11 @@ struct DecStepArgs {
   const int32_t* gt;       // [steps][N] teacher-forcing tokens or nullptr
   const float* uni;        // [steps][N] uniforms or nullptr
   const int32_t* forced;   // [steps][N] or nullptr
-  int use_gt;
+  int use_gt;              // 0 free-running (state), 1 ground truth (all tokens valid), 2 given
+                           // tokens with the automaton's validity (state = prefix sum of P)
   int T, N, L, V;
+  int Td;                  // use_gt == 2: total decoder steps (initial automaton state)
+  int32_t* valid_bits;     // optional [steps][N]: bit v = token v valid at that step
   // state / outputs
   int32_t* state;          // [N][3]   (sequential decoding only)
   int32_t* tokens;         // [steps][N]
@@ -289,6 +292,9 @@ struct DecBwdArgs {
   const float* Wy;         // [2L][V]
   int T, N, L, V, Td;
   float inv_n;             // 1/N of the batch mean
+  // d loss / d log p(chosen token) per question (nullptr: -1/N, behavioural cloning), validity
+  // bits of the forward (nullptr: all valid), weight of d neg_entropy (lambda_entropy / N)
+  const float* coef; const int32_t* valid_bits; float ent_coef;
   float* dsc;              // [Td][N][16] d token logits (zero padded)
   float* dout;             // [Td][N][L] direct part of d(top-layer h)
   float* dctx;             // [Td][N][L]
@@ -308,10 +314,17 @@ void launch_word_vecs_bwd(const float* dwv, const float* atts, const int32_t* se
                           int E, float* datts_wv, float* dE, hipStream_t s);
 
 // losses[0] = mean CE(scores, labels), losses[1] = mean(-log_seq_prob); dscores = (p - onehot)/N
+// policy-gradient objective (train_clevr_rl_gt_layout.py:107-129); coef[n] = (final_loss - baseline)/N
+struct LossRlArgs {
+  const float* scores; const int32_t* labels; const float* log_seq_prob; const float* neg_entropy;
+  const int32_t* expr_validity; int N, C; float invalid_expr_loss, baseline_decay;
+  float* baseline; float* dscores; float* losses; float* coef;
+};
+void launch_loss_rl(const LossRlArgs& a, hipStream_t s);
 void launch_loss(const float* scores, const int32_t* labels, const float* log_seq_prob, int N,
                  int C, float* dscores, float* losses, hipStream_t s);
 
-void launch_loss_total(float* losses, float wd, hipStream_t s);
+void launch_loss_total(float* losses, float wd, float lambda_entropy, hipStream_t s);
 // zero up to 6 byte ranges (4-byte aligned starts and sizes) in ONE launch: a memset node costs ~5 us
 // on the stream whatever its size, and the backward pass starts with four of them
 struct ZeroRanges { void* ptr[6]; size_t bytes[6]; int n; };

@@ -570,8 +570,16 @@ __global__ __launch_bounds__(NT) void dec_attn_kernel(DecStepArgs a) {
     }
     int x0 = 0, x1 = 0, x2 = 0;
     bool valid = on;
-    if (!a.use_gt) {
-      x0 = a.state[n * 3 + 0]; x1 = a.state[n * 3 + 1]; x2 = a.state[n * 3 + 2];
+    if (a.use_gt != 1) {
+      if (a.use_gt == 2) {                   // tokens known: X = [0, 0, T_dec] + sum of P[earlier tokens]
+        x2 = a.Td;
+        for (int tau = 0; tau < ts; ++tau) {
+          const int tk = a.gt[(size_t)tau * N + n];
+          x0 += a.P[tk * 3 + 0]; x1 += a.P[tk * 3 + 1]; x2 += a.P[tk * 3 + 2];
+        }
+      } else {
+        x0 = a.state[n * 3 + 0]; x1 = a.state[n * 3 + 1]; x2 = a.state[n * 3 + 2];
+      }
       if (on) {
         for (int c = 0; c < 4; ++c) {        // all_c( X . W[:, s, c] - b[s, c] >= 0 )   (:8-11)
           const int val = x0 * a.Wv[(0 * V + lane) * 4 + c] + x1 * a.Wv[(1 * V + lane) * 4 + c] +
@@ -605,6 +613,10 @@ __global__ __launch_bounds__(NT) void dec_attn_kernel(DecStepArgs a) {
       tok = ok ? samp : tok;
     }
     if (a.use_gt && a.gt) tok = a.gt[tn];    // (:239-241)
+    if (a.valid_bits) {
+      const unsigned long long vb = __ballot(on && valid);
+      if (lane == 0) a.valid_bits[tn] = (int32_t)vb;
+    }
     if (a.forced) tok = a.forced[tn];
     // robust softmax restricted to valid tokens                                        (:245-260)
     const float mx = wave_max(sc);

@@ -515,14 +515,27 @@ __global__ __launch_bounds__(256) void dec_bwd_a_kernel(DecBwdArgs a) {
   const size_t tn = (size_t)t * N + n;
   const int len = a.seq_len[n];
 
-  if (w == 0) {                       // softmax of the token logits
+  if (w == 0) {                       // d token logits
+    // p = softmax restricted to the valid tokens (nmn3_netgen_att.py:245-247);
+    //   d log p[chosen] / d sc_v = [v == chosen] - p_v            (valid v; invalid ones: 0)
+    //   d neg_entropy   / d sc_v = p_v (g_v - sum_u p_u g_u),  g = log p + 1, or log 1e-5 where the
+    //                              clamp of :259 is active
+    // cloning: coef = -1/N, every token valid, no entropy term -> (softmax - onehot) / N
     const bool on = lane < V;
-    const float sc = on ? a.scores[tn * V + lane] : -INFINITY;
+    const bool valid = on && (a.valid_bits ? ((a.valid_bits[tn] >> lane) & 1) != 0 : true);
+    const float sc = valid ? a.scores[tn * V + lane] : -INFINITY;
     const float mx = wave_max(sc);
-    const float ex = on ? expf(sc - mx) : 0.f;
+    const float ex = valid ? expf(sc - mx) : 0.f;
     const float den = wave_sum(ex);
+    const float pv = ex / den;
+    const float coef = a.coef ? a.coef[n] : -a.inv_n;
+    float d = valid ? coef * ((lane == a.gt[tn] ? 1.f : 0.f) - pv) : 0.f;
+    if (a.ent_coef != 0.f) {
+      const float gv = valid ? (pv >= 1e-5f ? logf(pv) + 1.f : logf(1e-5f)) : 0.f;
+      const float pg = wave_sum(pv * gv);
+      d += valid ? a.ent_coef * pv * (gv - pg) : 0.f;
+    }
     if (lane < 16) {
-      const float d = on ? (ex / den - (lane == a.gt[tn] ? 1.f : 0.f)) * a.inv_n : 0.f;
       dscs[lane] = d;
       a.dsc[tn * 16 + lane] = d;
     }
@@ -773,9 +786,51 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ sco
   }
 }
 
-// total_loss = seq_likelihood_loss + avg_sample_loss + weight_decay * l2_reg   (:113-114)
-__global__ void loss_total_kernel(float* __restrict__ losses, float wd) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) losses[3] = losses[0] + losses[1] + wd * losses[2];
+// policy-gradient objective (exp_clevr/train_clevr_rl_gt_layout.py:107-129):
+//   final[n] = validity[n] ? CE(scores[n], label[n]) : invalid_expr_loss
+//   losses[0] = mean(final); losses[1] = mean((final - baseline) * log_seq_prob);
+//   losses[4] = mean(neg_entropy);  coef[n] = (final[n] - baseline) / N  (d total / d log_seq_prob)
+//   dscores[n] = validity[n] ? (softmax - onehot) / N : 0;  then baseline += (1-decay)(mean - baseline)
+__global__ __launch_bounds__(256) void loss_rl_kernel(LossRlArgs a) {
+  __shared__ float scratch[16];
+  const int N = a.N, C = a.C;
+  const float base = *a.baseline;
+  float fl = 0.f, pg = 0.f, en = 0.f;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const float* z = a.scores + (size_t)n * C;
+    const bool ok = a.expr_validity[n] != 0;
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, z[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(z[c] - mx);
+    const int lab = a.labels[n];
+    const float fin = ok ? logf(s) + mx - z[lab] : a.invalid_expr_loss;
+    for (int c = 0; c < C; ++c)
+      a.dscores[(size_t)n * C + c] =
+          ok ? (expf(z[c] - mx) / s - (c == lab ? 1.f : 0.f)) / (float)N : 0.f;
+    a.coef[n] = (fin - base) / (float)N;
+    fl += fin;
+    pg += (fin - base) * a.log_seq_prob[n];
+    en += a.neg_entropy[n];
+  }
+  const float tfl = block_reduce<0>(fl, scratch);
+  const float tpg = block_reduce<0>(pg, scratch);
+  const float ten = block_reduce<0>(en, scratch);
+  if (threadIdx.x == 0) {
+    const float avg = tfl / (float)N;
+    a.losses[0] = avg;
+    a.losses[1] = tpg / (float)N;
+    a.losses[4] = ten / (float)N;
+    *a.baseline = base + (1.f - a.baseline_decay) * (avg - base);
+  }
+}
+
+// total_loss = seq_likelihood_loss | policy_gradient_loss + avg_sample_loss
+//              + lambda_entropy * entropy_reg + weight_decay * l2_reg
+// (train_clevr_gt_layout.py:113-114, train_clevr_rl_gt_layout.py:126-129)
+__global__ void loss_total_kernel(float* __restrict__ losses, float wd, float lambda_entropy) {
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    losses[3] = losses[0] + losses[1] + lambda_entropy * losses[4] + wd * losses[2];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -982,8 +1037,12 @@ void launch_loss(const float* scores, const int32_t* labels, const float* log_se
                      dscores, losses);
 }
 
-void launch_loss_total(float* losses, float wd, hipStream_t s) {
-  hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(64), 0, s, losses, wd);
+void launch_loss_rl(const LossRlArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(loss_rl_kernel, dim3(1), dim3(256), 0, s, a);
+}
+
+void launch_loss_total(float* losses, float wd, float lambda_entropy, hipStream_t s) {
+  hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(64), 0, s, losses, wd, lambda_entropy);
 }
 
 void launch_grad_finish(float* grads, const float* const* mirrors, const int64_t* var_off,

@@ -362,7 +362,10 @@ __device__ void find_epilogue_bwd(const ModuleWeights& w, const ModuleBuffers& b
       const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
       float gr = grv[u];
       if (in0) {                                     // Filter: tf.minimum(input_0, att), tie -> input_0
-        const float att = dot * inv + be;
+        // att recomputed with the forward's exact arithmetic (find_epilogue: d2 / sqrt(...) + be):
+        // nested Filters with identical text parameters (length-1 questions) produce EXACT ties,
+        // and a 1-ulp difference in the recomputation would flip the branch
+        const float att = dot / sqrtf(fmaxf(ss, 1e-12f)) + be;
         const float x = xin[u];
         const bool to_x = x <= att;
         if (lane == 0) gin0[r] = to_x ? gr : 0.f;

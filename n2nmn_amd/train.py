@@ -78,7 +78,13 @@ class Trainer:
         self.hyper = dict(lr=float(lr), beta1=float(beta1), beta2=float(beta2), eps=float(eps),
                           max_grad_l2_norm=float(max_grad_l2_norm))
         self.grads = torch.zeros(self.numel, dtype=torch.float32, device=engine.device)
-        self.losses = torch.zeros(4, dtype=torch.float32, device=engine.device)
+        # avg_sample_loss, seq_likelihood | policy_gradient loss, l2_reg, total_loss, entropy_reg, -
+        self.losses = torch.zeros(8, dtype=torch.float32, device=engine.device)
+        # policy gradient (train_clevr_rl_gt_layout.py:38-42,120): baseline starts at
+        # invalid_expr_loss and is an EMA of avg_sample_loss, kept on the device
+        self.rl = dict(invalid_expr_loss=0.5, lambda_entropy=0.005, baseline_decay=0.99)
+        self.baseline = torch.full((1,), self.rl['invalid_expr_loss'], dtype=torch.float32,
+                                   device=engine.device)
         self.scores = None
         self.buckets = GradBuckets(self.grads, self.split, dist)
         self.iteration = 0
@@ -92,7 +98,7 @@ class Trainer:
         self._keep = None
 
     # ------------------------------------------------------------------------------------
-    def _io(self, batch, gt_layout):
+    def _io(self, batch, gt_layout, objective: int = 0):
         torch = _torch()
         e = self.engine
         d = e.dims
@@ -117,13 +123,24 @@ class Trainer:
         io.answer_labels = labels.data_ptr(); io.weight_decay = self.weight_decay
         io.scores = self.scores.data_ptr(); io.losses = self.losses.data_ptr()
         io.grads = self.grads.data_ptr()
-        self._keep = (seq, lens, feat, labels, gt, packed)
+        val = None
+        if objective == 1:
+            val = e.upload_i32(np.asarray(validity, np.int32))
+            io.objective = 1
+            io.expr_validity = val.data_ptr()
+            io.invalid_expr_loss = self.rl['invalid_expr_loss']
+            io.lambda_entropy = self.rl['lambda_entropy']
+            io.baseline_decay = self.rl['baseline_decay']
+            io.baseline = self.baseline.data_ptr()
+        self._keep = (seq, lens, feat, labels, gt, packed, val)
         return io, packed, validity
 
-    def forward_backward(self, batch, gt_layout, reduce: bool = True) -> float:
+    def forward_backward(self, batch, gt_layout, reduce: bool = True, objective: int = 0) -> float:
         """Forward + both backward phases (+ the bucketed all-reduce).  Afterwards self.grads is
-        d total_loss / d variables summed over ranks; returns the 1/world scale."""
-        io, packed, _ = self._io(batch, gt_layout)
+        d total_loss / d variables summed over ranks; returns the 1/world scale.
+        objective 0: behavioural cloning on ground-truth layouts; 1: policy gradient, gt_layout
+        then being the layout the decoder sampled for this batch (see step_rl)."""
+        io, packed, _ = self._io(batch, gt_layout, objective)
         s = self.engine.stream()
         _lib.check(self._lib.n2nmn_train_forward(self._ctx, C.byref(io), packed.handle, s))
         _lib.check(self._lib.n2nmn_train_backward(self._ctx, C.byref(io), packed.handle, 0, s))
@@ -147,6 +164,24 @@ class Trainer:
         scale = self.forward_backward(batch, gt_layout)
         self.apply(scale)
         return self.losses
+
+    def step_rl(self, batch, sample_uniforms, lr: Optional[float] = 1e-4):
+        """One iteration of exp_clevr/train_clevr_rl_gt_layout.py:183-214: the decoder samples a
+        layout per question (sample_uniforms [T_dec, N] in [0,1) replace tf.multinomial's RNG),
+        the tokens are fetched and assembled on the host (the reference's partial_run does the
+        same), then forward + backward of the policy-gradient loss and an Adam step with the
+        fine-tuning learning rate.  Returns (losses, tokens, expr_validity)."""
+        e = self.engine
+        s2s = e.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'],
+                        sample_uniforms=sample_uniforms)
+        tokens = s2s['predicted_tokens'].cpu().numpy()
+        scale = self.forward_backward(batch, tokens, objective=1)
+        if lr is not None:
+            saved, self.hyper['lr'] = self.hyper['lr'], float(lr)
+            self.apply(scale)
+            self.hyper['lr'] = saved
+        validity = self._keep[6].cpu().numpy().astype(bool) if self._keep[6] is not None else None
+        return self.losses, tokens, validity
 
     # ------------------------------------------------------------------------------------
     def gradients(self) -> Dict[str, object]:

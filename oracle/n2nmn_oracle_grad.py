@@ -346,6 +346,110 @@ def loss_and_grads(w, module_names, batch, T_dec, num_choices, gt_layout, weight
     return losses, grads, extras
 
 
+# ---- policy-gradient objective: exp_clevr/train_clevr_rl_gt_layout.py:107-129 ----------------
+def decoder_forward_tokens(w, enc, T_dec, tokens, token_validity):
+    """Decoder run on GIVEN tokens with the automaton's validity masks (constants: they depend on
+    the tokens only): what the sampling decoder computed when it drew `tokens`
+    (nmn3_netgen_att.py:175-312 with decoder_sampling=True), as a differentiable function of the
+    weights.  token_validity [T_dec, N, V] bool."""
+    (c0, h0), (c1, h1) = enc['states']
+    N = h0.shape[0]
+    tok = torch.as_tensor(np.asarray(tokens)).long()
+    vm = torch.as_tensor(np.asarray(token_validity, np.float64))
+    demb = w[_DEC + 'embedding_mat']
+    x = w[_DEC + 'go_embedding'].expand(N, -1)
+    v = w[_DEC + 'att_prediction/v']
+    Wa, ba = w[_DEC + 'att_prediction/weights'], w[_DEC + 'att_prediction/biases']
+    Wy, by = w[_DEC + 'token_prediction/weights'], w[_DEC + 'token_prediction/biases']
+    W0, b0 = _lstm_w(w, 'decoder', 0)
+    W1, b1 = _lstm_w(w, 'decoder', 1)
+    eht, eout, nf = enc['h_transformed'], enc['outputs'], enc['not_finished']
+    atts, scores = [], []
+    for t in range(T_dec):
+        c0, h0 = _lstm_cell(x, c0, h0, W0, b0)
+        c1, h1 = _lstm_cell(h0, c1, h1, W1, b1)
+        q = h1 @ Wa + ba
+        e = torch.sum(torch.tanh(q[None] + eht) * v, dim=2, keepdim=True)
+        att = torch.softmax(e, dim=0) * nf
+        att = att / torch.sum(att, dim=0, keepdim=True)
+        ctx = torch.sum(att * eout, dim=0)
+        sc = torch.cat([h1, ctx], dim=1) @ Wy + by
+        x = demb[tok[t]]
+        atts.append(att); scores.append(sc)
+    atts = torch.stack(atts)
+    scores = torch.stack(scores)                                 # [T_dec, N, V]
+    p = torch.softmax(scores, dim=2) * vm                        # :245
+    p = p / torch.sum(p, dim=2, keepdim=True)                    # :247
+    tprobs = torch.gather(p, 2, tok[:, :, None])[:, :, 0]        # :251-256
+    neg_entropy = torch.sum(p * torch.log(torch.clamp(p + (1.0 - vm), min=1e-5)), dim=(0, 2))  # :258-260
+    word_vecs = torch.sum(atts * enc['embedded'][None], dim=1)
+    return dict(token_probs=tprobs, neg_entropy=neg_entropy, atts=atts, word_vecs=word_vecs,
+                token_scores=scores)
+
+
+def train_forward_rl(wt, module_names, batch, T_dec, num_choices, tokens, token_validity, baseline,
+                     invalid_expr_loss=0.5, lambda_entropy=0.005, weight_decay=5e-6):
+    """Loss of train_clevr_rl_gt_layout.py:107-129 for one batch whose layouts `tokens` were sampled
+    by the decoder.  baseline: python float (tf.Variable, not trainable)."""
+    enc = encoder_forward(wt, batch['input_seq_batch'], batch['seq_length_batch'])
+    dec = decoder_forward_tokens(wt, enc, T_dec, tokens, token_validity)
+    exprs, validity = O.assemble(module_names, np.asarray(tokens))
+    feat = _t(batch['image_feat_batch'])
+    _MARGIN['min_gap'] = {}
+    rows = []
+    for n, e in enumerate(exprs):
+        _MARGIN['example'] = n
+        if validity[n]:
+            rows.append(eval_expr(wt, e, feat, dec['word_vecs'], num_choices))
+        else:                                   # INVALID_EXPR: zero logits (nmn3_model.py:146,155)
+            rows.append(torch.zeros(num_choices, dtype=torch.float64))
+    _MARGIN['example'] = None
+    scores = torch.stack(rows)
+    labels = torch.as_tensor(np.asarray(batch['answer_label_batch'])).long()
+    log_seq_prob = torch.sum(torch.log(dec['token_probs']), dim=0)
+    ce = torch.logsumexp(scores, dim=1) - scores[torch.arange(len(labels)), labels]
+    valid_t = torch.as_tensor(np.asarray(validity, bool))
+    final = torch.where(valid_t, ce, torch.full_like(ce, invalid_expr_loss))      # :112-114
+    avg_sample_loss = final.mean()                                                # :119
+    policy = torch.mean((final - baseline).detach() * log_seq_prob)               # :123-124
+    entropy_reg = dec['neg_entropy'].mean()                                       # nmn3_model.py:162
+    l2 = sum(0.5 * torch.sum(v * v) for k, v in wt.items() if k.endswith('weights'))
+    total = policy + avg_sample_loss + lambda_entropy * entropy_reg + weight_decay * l2   # :126-129
+    return dict(enc=enc, dec=dec, expr_list=exprs, validity=validity, scores=scores,
+                log_seq_prob=log_seq_prob, avg_sample_loss=avg_sample_loss,
+                policy_gradient_loss=policy, entropy_reg=entropy_reg, l2_reg=l2, total_loss=total)
+
+
+def loss_and_grads_rl(w, module_names, batch, T_dec, num_choices, tokens, token_validity, baseline,
+                      invalid_expr_loss=0.5, lambda_entropy=0.005, weight_decay=5e-6,
+                      baseline_decay=0.99):
+    """numpy in / numpy out; like loss_and_grads.  losses additionally hold 'new_baseline'
+    (baseline + (1 - decay) * (avg_sample_loss - baseline), :120-122)."""
+    wt = {k: _t(v).clone().requires_grad_(True) for k, v in w.items()}
+    r = train_forward_rl(wt, module_names, batch, T_dec, num_choices, tokens, token_validity,
+                         baseline, invalid_expr_loss, lambda_entropy, weight_decay)
+    inter = dict(word_vecs=r['dec']['word_vecs'], token_scores=r['dec']['token_scores'],
+                 scores=r['scores'])
+    for v in inter.values():
+        if v.requires_grad:
+            v.retain_grad()
+    r['total_loss'].backward()
+    grads = {k: (v.grad.numpy().copy() if v.grad is not None else np.zeros(tuple(v.shape)))
+             for k, v in wt.items()}
+    losses = {k: float(r[k].detach()) for k in ('avg_sample_loss', 'policy_gradient_loss',
+                                                'entropy_reg', 'l2_reg', 'total_loss')}
+    losses['new_baseline'] = baseline + (1.0 - baseline_decay) * (losses['avg_sample_loss'] - baseline)
+    extras = {'d_' + k: (v.grad.numpy().copy() if v.grad is not None else None)
+              for k, v in inter.items()}
+    extras['scores'] = r['scores'].detach().numpy().copy()
+    extras['validity'] = np.asarray(r['validity'], bool)
+    extras['selection_gap'] = np.array([_MARGIN['min_gap'].get(n, np.inf)
+                                        for n in range(len(r['expr_list']))])
+    extras['log_seq_prob'] = r['log_seq_prob'].detach().numpy().copy()
+    extras['neg_entropy'] = r['dec']['neg_entropy'].detach().numpy().copy()
+    return losses, grads, extras
+
+
 # ---- optimiser: exp_clevr/train_clevr_gt_layout.py:112-120 -------------------------------
 def clip_by_norm(g, c):
     """tf.clip_by_norm(g, c) = g * c / max(||g||_2, c)  (Appendix A.4)."""

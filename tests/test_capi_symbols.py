@@ -40,4 +40,5 @@ def test_struct_sizes_match_header():
     # 2 ptr + 4 int32 + 13 ptr
     assert ctypes.sizeof(_lib.Seq2SeqIO) == 2 * 8 + 4 * 4 + 13 * 8
     # 2 ptr + 3 int32 (+4 pad) + 3 ptr + float (+4 pad) + 3 ptr
-    assert ctypes.sizeof(_lib.TrainIO) == 2 * 8 + 16 + 3 * 8 + 8 + 3 * 8
+    # ... + objective (4 + 4 pad) + expr_validity + 3 floats (+ 4 pad) + baseline
+    assert ctypes.sizeof(_lib.TrainIO) == 2 * 8 + 16 + 3 * 8 + 8 + 3 * 8 + 8 + 8 + 16 + 8

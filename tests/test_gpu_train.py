@@ -125,6 +125,23 @@ def test_gradients_ragged_small_batch(trainer_setup):
     _check(tr, d, w, batch, gt)
 
 
+def test_exact_ties_in_nested_filters(trainer_setup):
+    """Length-1 questions give every decoder step the same word vector, so nested Filters compare
+    bit-identical attention maps: tf.minimum's tie rule (first argument) decides where the gradient
+    goes, and the backward pass has to recompute the forward's value bit for bit to see the tie."""
+    tr, eng, d, asm, w = trainer_setup
+    small = Dims(T_decoder=10, N=16, T_encoder=9)
+    batch = synth.make_inputs(small, seed=9, min_len=1)
+    batch['seq_length_batch'][:] = 1
+    batch['input_seq_batch'][1:] = 0
+    tpl = [['_Scene', '_Filter', '_Filter', '_Filter', '_Exist'],
+           ['_Find', '_Filter', '_Filter', '_Count'],
+           ['_Scene', '_Filter', '_Filter', '_Find', '_SameProperty']]
+    gt = np.array([synth.module_list2tokens(tpl[i % 3], small.T_decoder) for i in range(small.N)],
+                  np.int32).T
+    _check(tr, d, w, batch, gt)
+
+
 def test_flat_layout_and_buckets(trainer_setup):
     tr, eng, d, asm, w = trainer_setup
     from n2nmn_amd.spec import num_parameters

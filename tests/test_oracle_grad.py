@@ -87,3 +87,58 @@ def test_adam_step_first_update_is_lr_sign():
     # first Adam step moves every coordinate with a non-zero gradient by ~lr
     assert np.allclose(w2['a/weights'], [1.0 - 1e-3, -2.0 + 1e-3, 3.0], atol=1e-8)
     assert np.allclose(m2['b/biases'], [1.0]) and np.allclose(v2['b/biases'], [0.1])
+
+
+# ---- policy-gradient objective (exp_clevr/train_clevr_rl_gt_layout.py:107-129) -------------------
+def _rl_numpy_total(d, w, batch, tokens, baseline, inv_loss, lam):
+    """total loss from the NUMPY oracle run on forced tokens (its own validity masks, token
+    probabilities, entropy and module network); the policy term's coefficient is a constant
+    (stop_gradient), so it is taken from the unperturbed weights by the caller."""
+    r = O.forward(w, CLEVR_MODULE_NAMES, batch, d.T_decoder, d.num_choices, np.float64,
+                  forced_tokens=tokens)
+    sc = r['scores']
+    lab = np.asarray(batch['answer_label_batch'])
+    ce = np.log(np.sum(np.exp(sc - sc.max(1, keepdims=True)), 1)) + sc.max(1) - sc[np.arange(len(lab)), lab]
+    final = np.where(r['validity'], ce, inv_loss)
+    lsp = np.sum(np.log(r['dec']['token_probs']), axis=0)
+    l2 = sum(0.5 * np.sum(v * v) for k, v in w.items() if k.endswith('weights'))
+    return dict(final=final, lsp=lsp, avg=final.mean(), ent=r['dec']['neg_entropy'].mean(), l2=l2,
+                dec=r['dec'], scores=sc)
+
+
+def test_policy_gradient_oracle_matches_numpy_oracle_and_finite_differences():
+    d = SMALL
+    w = synth.make_weights(d, seed=4, dtype=np.float64)
+    batch = synth.make_inputs(d, seed=4, n=d.N, min_len=1)
+    uni = np.random.default_rng(2).random((d.T_decoder, d.N))
+    fw = O.forward(w, CLEVR_MODULE_NAMES, batch, d.T_decoder, d.num_choices, np.float64,
+                   sample_uniforms=uni)
+    tokens, tv = fw['dec']['predicted_tokens'], fw['dec']['token_validity']
+    assert fw['validity'].all() and len({tuple(c) for c in tokens.T}) > 3
+    base, inv_loss, lam = 0.8, 0.5, 0.05
+    losses, grads, ex = G.loss_and_grads_rl(w, CLEVR_MODULE_NAMES, batch, d.T_decoder,
+                                            d.num_choices, tokens, tv, base, inv_loss, lam, WD)
+    r0 = _rl_numpy_total(d, w, batch, tokens, base, inv_loss, lam)
+    assert np.abs(ex['scores'] - r0['scores']).max() < 1e-12
+    assert np.abs(ex['log_seq_prob'] - r0['lsp']).max() < 1e-12
+    assert abs(losses['entropy_reg'] - r0['ent']) < 1e-12
+    assert abs(losses['avg_sample_loss'] - r0['avg']) < 1e-12
+    assert abs(losses['policy_gradient_loss'] - np.mean((r0['final'] - base) * r0['lsp'])) < 1e-12
+    assert abs(losses['new_baseline'] - (base + 0.01 * (r0['avg'] - base))) < 1e-12
+    coef = r0['final'] - base                      # stop_gradient(final_loss - baseline)
+
+    def total(wx):
+        r = _rl_numpy_total(d, wx, batch, tokens, base, inv_loss, lam)
+        return np.mean(coef * r['lsp']) + r['avg'] + lam * r['ent'] + WD * r['l2']
+
+    rng = np.random.default_rng(0)
+    h = 1e-6
+    for name in sorted(w):
+        dirn = rng.standard_normal(w[name].shape)
+        dirn /= np.sqrt(np.sum(dirn ** 2))
+        wp = dict(w); wm = dict(w)
+        wp[name] = w[name] + h * dirn
+        wm[name] = w[name] - h * dirn
+        fd = (total(wp) - total(wm)) / (2 * h)
+        an = float(np.sum(grads[name] * dirn))
+        assert abs(fd - an) <= 2e-5 * max(1.0, abs(an)) + 1e-7, (name, fd, an)
