@@ -27,6 +27,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, shared
+# with the framework's own streams).  The batches in flight only overlap when each stream has a
+# queue of its own, and four step kernels (8 waves per workgroup, 2 per SIMD) exactly fill the 8
+# wave slots of a SIMD: 4 streams on >= 6 queues measured 142-143 k questions/s, 4 streams on the
+# default 4 queues 108 k, 6 streams on 4 queues 128 k, 5 or more truly concurrent streams 85-89 k
+# (the fifth kernel's workgroups wait for wave slots).  Must be set before the runtime starts.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3    # MI355X_MICROARCH.md: fp32-input MFMA dense peak
 MFMA_FAMILIES = ('lstm_step', 'gemm_pk', 'lstm_bwd_step', 'gemm_tn')
@@ -42,7 +50,7 @@ def parse():
                          '4: training step (forward + backward + RCCL all-reduce + Adam); '
                          '5: models_vqa forward (14x14x2048 feats, batch 128)')
     ap.add_argument('--batch', type=int, default=64)
-    ap.add_argument('--streams', type=int, default=6,
+    ap.add_argument('--streams', type=int, default=4,
                     help='independent batches in flight per GPU (one host thread + HIP stream + '
                          'forked context each; weights shared)')
     ap.add_argument('--fetch-tokens', action='store_true',
@@ -373,6 +381,7 @@ def main():
                                     'decoder', d.N),
                        'global_batch': world * d.N, 'parallelism': 'dp%d (question-sharded, no '
                        'data-path collective)' % world, 'streams_per_gpu': S,
+                       'hw_queues': os.environ.get('GPU_MAX_HW_QUEUES'),
                        'lstm_tile_mode': 'throughput (32x32)' if S > 1 else 'latency (64x16)',
                        'host_sync': 'predicted_tokens D2H between phase 1 and phase 2'
                        if (not use_gt or args.fetch_tokens) else
