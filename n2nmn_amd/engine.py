@@ -82,10 +82,15 @@ class Engine:
             out[name.value.decode()] = tuple(int(shape[k]) for k in range(nd.value))
         return out
 
-    def load_weights(self, weights: Dict[str, object]):
-        """weights: reference variable name -> numpy array or torch tensor (any device)."""
+    def load_weights(self, weights: Dict[str, object], strict: bool = True):
+        """weights: reference variable name -> numpy array or torch tensor (any device).
+        strict=False skips names that are not variables of the model (e.g. the optimiser slots and
+        the `baseline` of a TF checkpoint read with n2nmn_amd.tf_checkpoint.read_checkpoint)."""
         torch = _torch()
+        known = None if strict else set(self.variable_names())
         for name, w in weights.items():
+            if known is not None and name not in known:
+                continue
             t = torch.as_tensor(w).to(device=self.device, dtype=torch.float32).contiguous()
             shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
             _lib.check(self._lib.n2nmn_set_weight(self._ctx, name.encode(), t.data_ptr(), shape,
