@@ -77,8 +77,9 @@ def pmc_traffic(family, path=None):
     try:
         data = json.load(open(path or PMC_FILE))['kernels']
         for prefix, kname in PMC_KERNEL.items():
-            if family.startswith(prefix) and kname in data:
-                return data[kname]['hbm_bytes_per_launch'], \
+            hit = [k for k in data if k.startswith(kname)]       # (template arguments vary)
+            if family.startswith(prefix) and hit:
+                return data[hit[0]]['hbm_bytes_per_launch'], \
                     'profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)' % \
                     os.path.basename(path or PMC_FILE)
     except Exception:
