@@ -482,15 +482,20 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s) {
 
 int run_program(n2nmn_ctx* c, Program& p, const float* feat, const float* word_vecs,
                        int N_full, float* scores, const float* ext0, const float* ext1,
-                       float* att_out, int att_out_first, int att_out_count, hipStream_t s) {
+                       float* att_out, int att_out_first, int att_out_count, hipStream_t s,
+                       int stages) {
+  // stages (bit mask, RP_ALL by default): RP_PREP = checks, INVALID_EXPR zero rows, program upload;
+  // RP_CONV = the hoisted conv_image GEMMs, which need only the image features (the training
+  // forward runs them on its side stream beside the encoder); RP_REST = everything else
   const n2nmn_dims& d = c->d;
+  const bool do_prep = stages & RP_PREP, do_conv = stages & RP_CONV, do_rest = stages & RP_REST;
   N2_REQUIRE(is_committed(c), N2NMN_ENOWEIGHT, "execute_program: weights not committed");
   N2_REQUIRE(N_full >= 1 && N_full <= d.N, N2NMN_ECAPACITY, "execute_program: N_full > capacity");
   const int nn = (int)p.dev_nodes.size();
   N2_REQUIRE(nn <= c->max_nodes && p.num_text <= c->max_text && p.num_pool <= c->max_pool &&
                  (int)p.tab.size() <= c->max_tab,
              N2NMN_ECAPACITY, "execute_program: program larger than the context workspace");
-  for (const DevNode& nd : p.dev_nodes) {
+  if (do_prep) for (const DevNode& nd : p.dev_nodes) {
     N2_REQUIRE(nd.op == OP_INPUT || (nd.n < N_full && nd.t < d.T_decoder), N2NMN_EINVAL,
                "execute_program: batch_idx / time_idx out of range");
     if (d.variant == N2NMN_VARIANT_VQA)
@@ -499,10 +504,10 @@ int run_program(n2nmn_ctx* c, Program& p, const float* feat, const float* word_v
                  N2NMN_EKEY, "execute_program: operator does not exist in models_vqa");
   }
   const int HW = d.H * d.W, C = d.num_choices;
-  if (scores && p.num_rows > 0)
+  if (do_prep && scores && p.num_rows > 0)
     N2_HIP(hipMemsetAsync(scores, 0, sizeof(float) * (size_t)p.num_rows * C, s));  // INVALID_EXPR
   if (nn == 0) return N2NMN_OK;
-  {
+  if (do_prep) {
     // nodes + tables travel through a pinned staging slot so the upload is truly asynchronous;
     // a slot is reused only after the copy that last read it has completed
     const size_t nb = sizeof(DevNode) * nn, tb = sizeof(int32_t) * p.tab.size();
@@ -518,7 +523,7 @@ int run_program(n2nmn_ctx* c, Program& p, const float* feat, const float* word_v
     N2_HIP(hipEventRecord(c->stage_ev[slot], s));
   }
   // externally supplied attention maps (module_forward): node i <- ext[time_idx][batch_idx]
-  for (int i = 0; i < nn; ++i) {
+  for (int i = 0; do_rest && i < nn; ++i) {
     const DevNode& nd = p.dev_nodes[i];
     if (nd.op != OP_INPUT) continue;
     const float* src = (nd.t == 0 ? ext0 : ext1);
@@ -537,6 +542,8 @@ int run_program(n2nmn_ctx* c, Program& p, const float* feat, const float* word_v
   b.Mp = c->Mp; b.wl_cap = d.map_dim * C <= 10240 ? d.map_dim * C : 0; b.E = d.embed_dim_txt; b.C = C; b.HWp = c->HWp; b.ksize = d.kernel_size;
   const double dE = d.embed_dim_txt, dM = d.map_dim, dD = d.D, dHW = HW, dC = C, dMp = c->Mp;
   for (const Launch& l : p.launches) {
+    const bool is_conv = l.kind == LK_CONV_FIND || l.kind == LK_CONV_FSP;
+    if (is_conv ? !do_conv : !do_rest) continue;
     switch (l.kind) {
       case LK_TEXTMAP: {
         // groups of <= TM_GROUP nodes; one [E,M] weight stream per group
@@ -621,7 +628,7 @@ int run_program(n2nmn_ctx* c, Program& p, const float* feat, const float* word_v
       default: break;
     }
   }
-  if (att_out && att_out_count > 0) {
+  if (do_rest && att_out && att_out_count > 0) {
     N2_HIP(hipMemcpy2DAsync(att_out, sizeof(float) * HW,
                             c->arena + (size_t)att_out_first * c->HWp, sizeof(float) * c->HWp,
                             sizeof(float) * HW, att_out_count, hipMemcpyDeviceToDevice, s));

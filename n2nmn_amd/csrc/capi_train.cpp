@@ -473,7 +473,15 @@ int n2nmn_train_forward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* p
   sio.T_dec = io->T_dec; sio.use_gt_layout = rl ? 2 : 1; sio.gt_layout = io->gt_layout;
   t->last_N = N; t->last_T = io->T_enc; t->last_Td = io->T_dec;
   c->rec = &t->rec;
-  rc = encoder_impl(c, &sio, s);
+  float* scores = io->scores ? io->scores : t->scores;
+  // the hoisted conv_image GEMMs of the module network need only the image features: they run on
+  // the side stream beside the (strictly sequential) encoder
+  rc = run_program(c, p->prog, io->image_feat, c->word_vecs, N, scores, nullptr, nullptr, nullptr,
+                   0, 0, s, RP_PREP);
+  if (rc == N2NMN_OK)
+    rc = run_program(c, p->prog, io->image_feat, c->word_vecs, N, scores, nullptr, nullptr,
+                     nullptr, 0, 0, t->fork(s), RP_CONV);
+  if (rc == N2NMN_OK) rc = encoder_impl(c, &sio, s);
   if (rc == N2NMN_OK) {
     // the decoder starts from the encoder's final state (nmn3_netgen_att.py:177)
     (void)hipMemcpyAsync(t->rec.dc0s, c->fc0, sizeof(float) * nl, hipMemcpyDeviceToDevice, s);
@@ -482,10 +490,10 @@ int n2nmn_train_forward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* p
     launch_unpack_h(c->fh1, t->rec.dh1s, N, L, d.N, s);
     rc = decoder_impl(c, &sio, s);
   }
-  float* scores = io->scores ? io->scores : t->scores;
+  t->join(s);
   if (rc == N2NMN_OK)
     rc = run_program(c, p->prog, io->image_feat, c->word_vecs, N, scores, nullptr, nullptr, nullptr,
-                     0, 0, s);
+                     0, 0, s, RP_REST);
   c->rec = nullptr;
   if (rc != N2NMN_OK) return rc;
   if (scores != t->scores)

@@ -247,8 +247,9 @@ void rowmajor_a(const n2nmn_ctx* c, LstmJob& j);
 int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s);
 int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s);
 void train_state_destroy(TrainState* t);
+enum { RP_PREP = 1, RP_CONV = 2, RP_REST = 4, RP_ALL = 7 };
 int run_program(n2nmn_ctx* c, Program& p, const float* feat, const float* word_vecs, int N_full,
                 float* scores, const float* ext0, const float* ext1, float* att_out,
-                int att_out_first, int att_out_count, hipStream_t s);
+                int att_out_first, int att_out_count, hipStream_t s, int stages = RP_ALL);
 
 }  // namespace n2nmn
