@@ -419,7 +419,10 @@ def main():
                            'frac': dom['frac'], 'traffic': traffic, 'traffic_source': traffic_src,
                            'avg_us': dom['avg_us'],
                            'measured': 'hipEvent pairs around each launch on the launch stream, '
-                                       'separate pass of %d steps right after the timed region'
+                                       'separate pass of %d steps right after the timed region; an '
+                                       'event pair includes ~1.5 us of marker / dispatch latency: '
+                                       'rocprofv3 --kernel-trace reports 8.6-9.1 us for this kernel '
+                                       '(profiles/r01_h_kernel_stats.txt, r01_lstm_microbench.txt)'
                                        % ksteps}
         out['kernels'] = rows
         out['gpu_us_per_step'] = round(sum(r['us_per_step'] for r in rows), 1)
