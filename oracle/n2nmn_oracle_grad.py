@@ -388,12 +388,15 @@ def decoder_forward_tokens(w, enc, T_dec, tokens, token_validity):
 
 
 def train_forward_rl(wt, module_names, batch, T_dec, num_choices, tokens, token_validity, baseline,
-                     invalid_expr_loss=0.5, lambda_entropy=0.005, weight_decay=5e-6):
+                     invalid_expr_loss=0.5, lambda_entropy=0.005, weight_decay=5e-6,
+                     validity_override=None):
     """Loss of train_clevr_rl_gt_layout.py:107-129 for one batch whose layouts `tokens` were sampled
     by the decoder.  baseline: python float (tf.Variable, not trainable)."""
     enc = encoder_forward(wt, batch['input_seq_batch'], batch['seq_length_batch'])
     dec = decoder_forward_tokens(wt, enc, T_dec, tokens, token_validity)
     exprs, validity = O.assemble(module_names, np.asarray(tokens))
+    if validity_override is not None:           # expr_validity_batch is a placeholder (:86): the
+        validity = np.asarray(validity_override, bool)   # loss sees whatever the caller feeds
     feat = _t(batch['image_feat_batch'])
     _MARGIN['min_gap'] = {}
     rows = []
@@ -422,12 +425,13 @@ def train_forward_rl(wt, module_names, batch, T_dec, num_choices, tokens, token_
 
 def loss_and_grads_rl(w, module_names, batch, T_dec, num_choices, tokens, token_validity, baseline,
                       invalid_expr_loss=0.5, lambda_entropy=0.005, weight_decay=5e-6,
-                      baseline_decay=0.99):
+                      baseline_decay=0.99, validity_override=None):
     """numpy in / numpy out; like loss_and_grads.  losses additionally hold 'new_baseline'
     (baseline + (1 - decay) * (avg_sample_loss - baseline), :120-122)."""
     wt = {k: _t(v).clone().requires_grad_(True) for k, v in w.items()}
     r = train_forward_rl(wt, module_names, batch, T_dec, num_choices, tokens, token_validity,
-                         baseline, invalid_expr_loss, lambda_entropy, weight_decay)
+                         baseline, invalid_expr_loss, lambda_entropy, weight_decay,
+                         validity_override)
     inter = dict(word_vecs=r['dec']['word_vecs'], token_scores=r['dec']['token_scores'],
                  scores=r['scores'])
     for v in inter.values():

@@ -1,0 +1,1 @@
+"""tensorflow.python package of the eager stub (see ../__init__.py)."""
