@@ -214,6 +214,51 @@ int n2nmn_execute_program(n2nmn_ctx *ctx, n2nmn_program *p, const float *image_f
                           const float *word_vecs, int N_full, float *scores,
                           n2nmn_stream stream);
 
+/* ------------------------------------------------------------------------------------------
+ * (4b) phase 2 WITHOUT the host hop: layouts are decoded and executed on the device.
+ *     Replaces, for inference, the host block between the two partial runs of
+ *     exp_clevr/eval_clevr.py:111-132 -- the predicted_tokens fetch, Assembler.assemble
+ *     (models_clevr/nmn3_assembler.py:153-222), compiler.build_feed_dict and Loom's per-depth
+ *     batching (models_clevr/nmn3_model.py:55-159) -- by ONE kernel in which a workgroup decodes
+ *     its question's RPN tokens (same five validity checks; invalid -> zero logits, validity 0)
+ *     and runs the whole tree.  The Python Assembler / n2nmn_assemble stay
+ *     as the compatibility path (expression dicts, error strings, explicit programs, training).
+ * ---------------------------------------------------------------------------------------- */
+/* op code of every layout token (HOST int32 [V], -1 for <eos>): what Assembler passes to
+ * n2nmn_assemble per call, kept on the device for the walker.  Root context only. */
+int n2nmn_set_token_ops(n2nmn_ctx *ctx, const int32_t *token_op_host, int V);
+/* 1 if the context's dimensions fit the walker's tiling (models_clevr dimensions do;
+ * models_vqa runs through n2nmn_execute_program). */
+int n2nmn_walk_supported(const n2nmn_ctx *ctx);
+
+#define N2NMN_CONV_FIND 1   /* FindModule conv_image (shared by _Find and _Filter, nmn3_modules.py:129) */
+#define N2NMN_CONV_FSP  2   /* FindSamePropertyModule conv_image */
+/* The hoisted, text-independent 1x1 convolution image_feat . W_img + b (nmn3_modules.py:98-99,
+ * 158-159 via util/empty_safe_conv.py:8-32) of all N images into the context's workspace; needs only
+ * the features, so it can run beside phase 1.  tokens (device [T_dec, N]) or NULL: when given, the
+ * FindSameProperty map is computed only for images whose layout contains that token. */
+int n2nmn_conv_image(n2nmn_ctx *ctx, const float *image_feat, int N, int which,
+                     const int32_t *tokens, int T_dec, n2nmn_stream stream);
+
+typedef struct {
+  n2nmn_ctx *ctx;               /* context (root or fork) whose workspace holds THIS batch's conv_image
+                                   maps (n2nmn_conv_image was called on it); NULL = the calling one */
+  const int32_t *tokens;        /* [T_dec, N] layout tokens (predicted_tokens or gt_layout), device */
+  const float *image_feat;      /* [N, H, W, D]                                               */
+  const float *word_vecs;       /* [T_dec, N, E]                                              */
+  float *scores;                /* [N, num_choices] out                                       */
+  int32_t *validity;            /* [N] out: 1 / 0 like expr_validity_array, or NULL          */
+} n2nmn_walk_batch;
+/* One launch for the questions of K in-flight batches ("super-bucket", 1 <= K <= 16; every batch
+ * has N questions and T_dec steps).  The caller orders `stream` after each batch's phase 1 and
+ * n2nmn_conv_image (events). */
+int n2nmn_walk_layouts(n2nmn_ctx *ctx, const n2nmn_walk_batch *batches, int K, int T_dec, int N,
+                       n2nmn_stream stream);
+/* single batch: n2nmn_conv_image(FIND | FSP gated by tokens) + n2nmn_walk_layouts(K = 1) */
+int n2nmn_execute_tokens(n2nmn_ctx *ctx, const int32_t *tokens, int T_dec, int N,
+                         const float *image_feat, const float *word_vecs, float *scores,
+                         int32_t *validity, n2nmn_stream stream);
+
 /* models_vqa: out[n,h,w,:] = [feat[n,h,w,0:D0], x(w), y(h), 0...]  with x = linspace(-1,1,W)[w],
  * y = linspace(-1,1,H)[h]  (add_spatial_coordinate_map, models_vqa/nmn3_modules.py:11-31).
  * feat [N,H,W,D0]; out [N,H,W,D] with D = the context's (padded) feature depth >= D0 + 2. */

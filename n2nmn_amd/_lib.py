@@ -50,6 +50,12 @@ class Node(C.Structure):
         'op', 'time_idx', 'batch_idx', 'in0', 'in1', 'level', 'out_row', 'reserved')]
 
 
+class WalkBatch(C.Structure):
+    """n2nmn_walk_batch (include/n2nmn.h section 4b)"""
+    _fields_ = [('ctx', C.c_void_p), ('tokens', C.c_void_p), ('image_feat', C.c_void_p),
+                ('word_vecs', C.c_void_p), ('scores', C.c_void_p), ('validity', C.c_void_p)]
+
+
 ERRORS = {-1: 'N2NMN_EINVAL', -2: 'N2NMN_EHIP', -3: 'N2NMN_ENOWEIGHT', -4: 'N2NMN_ECAPACITY',
           -5: 'N2NMN_EKEY'}
 
@@ -86,6 +92,11 @@ SYMBOLS = [
     ('n2nmn_program_num_launches', _I, [_P]),
     ('n2nmn_execute_program', _I, [_P, _P, _P, _P, _I, _P, _P]),
     ('n2nmn_module_forward', _I, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    ('n2nmn_set_token_ops', _I, [_P, _P, _I]),
+    ('n2nmn_walk_supported', _I, [_P]),
+    ('n2nmn_conv_image', _I, [_P, _P, _I, _I, _P, _I, _P]),
+    ('n2nmn_walk_layouts', _I, [_P, C.POINTER(WalkBatch), _I, _I, _I, _P]),
+    ('n2nmn_execute_tokens', _I, [_P, _P, _I, _I, _P, _P, _P, _P, _P]),
     ('n2nmn_add_coords', _I, [_P, _P, _I, _I, _P, _P]),
     ('n2nmn_question_prior_add', _I, [_P, _I, _P, _P]),
     ('n2nmn_train_enable', _I, [_P]),
@@ -129,6 +140,15 @@ def lib():
                 raise RuntimeError(
                     'n2nmn_amd: the HIP extension %s is missing and could not be built (%s). '
                     'There is no CPU fallback.' % (_build.LIB, e))
+            # an older binary exists but csrc/ is newer and does not compile: running it would test
+            # kernels and ctypes structs that no longer match the sources
+            if os.environ.get('N2NMN_ALLOW_STALE_LIB') != '1':
+                raise RuntimeError(
+                    'n2nmn_amd: %s is older than csrc/ and the rebuild failed (%s); fix the build '
+                    'or set N2NMN_ALLOW_STALE_LIB=1 to load the stale library anyway'
+                    % (_build.LIB, e))
+            import warnings
+            warnings.warn('n2nmn_amd: loading a STALE %s (rebuild failed: %s)' % (_build.LIB, e))
     L = C.CDLL(_build.LIB)
     for name, res, args in SYMBOLS:
         fn = getattr(L, name)       # AttributeError if the .so does not export the symbol

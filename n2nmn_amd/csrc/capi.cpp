@@ -155,6 +155,7 @@ static size_t carve_weights(n2nmn_ctx* c, char* base) {
   c->P = k.take<int32_t>(V * 3);
   c->Wv = k.take<int32_t>(3 * V * 4);
   c->bv = k.take<int32_t>(V * 4);
+  c->token_op = k.take<int32_t>(V);
   (void)N; (void)T; (void)Td; (void)HW; (void)HWp;
   return align_up(k.off, 256);
 }
@@ -206,6 +207,7 @@ static size_t carve_workspace(n2nmn_ctx* c, char* base) {
   }
   c->dev_nodes = k.take<DevNode>(c->max_nodes);
   c->dev_tab = k.take<int32_t>(c->max_tab);
+  c->walk_stats = k.take<unsigned long long>(WALK_STATS);
   return align_up(k.off, 256);
 }
 
@@ -214,7 +216,7 @@ const char* kFamilyNames[F_COUNT] = {
   "lstm_step(linear q)", "dec_attn", "gemm_pk(encoder_h_transform)", "word_vecs", "textmap", "gemm_pk(conv_image)",
   "att_ops", "pool", "heads",
   "lstm_bwd_step", "gemm_tn(weight grads)", "backward misc (modules/attention/gemm_nt)",
-  "optimiser"};
+  "optimiser", "walk(layout walker)"};
 
 
 hipStream_t S(n2nmn_stream s) { return reinterpret_cast<hipStream_t>(s); }
@@ -964,6 +966,111 @@ int n2nmn_module_forward(n2nmn_ctx* ctx, int op, int Nb, const float* input_0,
                      ans ? nullptr : out, k * Nb, ans ? 0 : Nb, S(stream));
 }
 
+
+int n2nmn_set_token_ops(n2nmn_ctx* ctx, const int32_t* token_op_host, int V) {
+  N2_REQUIRE(ctx && token_op_host, N2NMN_EINVAL, "set_token_ops: null argument");
+  N2_REQUIRE(!ctx->parent, N2NMN_EINVAL, "set_token_ops: set them on the root context");
+  N2_REQUIRE(V == ctx->d.num_vocab_nmn, N2NMN_EINVAL, "set_token_ops: V != num_vocab_nmn");
+  for (int i = 0; i < V; ++i)
+    N2_REQUIRE(token_op_host[i] < 0 || (op_arity(token_op_host[i]) >= 0 && token_op_host[i] != OP_INPUT),
+               N2NMN_EKEY, "set_token_ops: unknown op code");
+  N2_HIP(hipMemcpy(ctx->token_op, token_op_host, sizeof(int32_t) * V, hipMemcpyHostToDevice));
+  ctx->have_token_ops = true;
+  return N2NMN_OK;
+}
+
+int n2nmn_walk_supported(const n2nmn_ctx* c) {
+  if (!c) return 0;
+  const n2nmn_dims& d = c->d;
+  if (d.variant != N2NMN_VARIANT_CLEVR || c->big_heads) return 0;
+  return walk_supported(d.H, d.W, d.D, d.map_dim, c->Mp, c->HWp, d.embed_dim_txt, d.num_choices,
+                        d.T_decoder, d.kernel_size);
+}
+
+int n2nmn_conv_image(n2nmn_ctx* c, const float* image_feat, int N, int which,
+                     const int32_t* tokens, int T_dec, n2nmn_stream stream) {
+  N2_REQUIRE(c && image_feat, N2NMN_EINVAL, "conv_image: null argument");
+  N2_REQUIRE(is_committed(c), N2NMN_ENOWEIGHT, "conv_image: weights not committed");
+  const n2nmn_dims& d = c->d;
+  N2_REQUIRE(N >= 1 && N <= d.N, N2NMN_ECAPACITY, "conv_image: N > capacity");
+  N2_REQUIRE(!tokens || (root(c)->have_token_ops && T_dec >= 1), N2NMN_EINVAL,
+             "conv_image: gating by tokens needs n2nmn_set_token_ops and T_dec");
+  const int HW = d.H * d.W;
+  const n2nmn_ctx* r = root(c);
+  hipStream_t s = S(stream);
+  const double dHW = HW, dD = d.D, dM = d.map_dim, dMp = c->Mp;
+  for (int fsp = 0; fsp < 2; ++fsp) {
+    if (!(which & (fsp ? N2NMN_CONV_FSP : N2NMN_CONV_FIND))) continue;
+    GemmArgs g{};
+    g.A = image_feat; g.lda = d.D; g.M = N * HW; g.K = d.D; g.group_size = HW;
+    g.Bp = fsp ? c->fsp_img_p : c->find_img_p; g.Np = c->Mp; g.Kp = c->KpD;
+    g.bias = c->vars[fsp ? V_FSP_IMG_B : V_FIND_IMG_B].mirror; g.N = d.map_dim;
+    g.C = fsp ? c->mfsp : c->mfind; g.ldc = c->Mp; g.n_store = c->Mp;
+    if (fsp && tokens) {
+      g.gate_tokens = tokens; g.gate_token_op = r->token_op; g.gate_T = T_dec; g.gate_N = N;
+      g.gate_V = d.num_vocab_nmn; g.gate_op = N2NMN_OP_FIND_SAME_PROPERTY; g.gate_rows = HW;
+    }
+    // algorithmic work of the gated launch is not known on the host: the profile line counts the
+    // ungated FindModule GEMM in full and the gated one as the reference mix's 1 image in 10
+    const double frac = (fsp && tokens) ? 0.1 : 1.0;
+    ProfScope ps(c, F_CONV_IMAGE, frac * 2.0 * N * dHW * dD * dM,
+                 frac * 4.0 * (N * dHW * (dD + dMp)) + 4.0 * dD * dM, s);
+    launch_gemm_pk(g, s);
+  }
+  return check_launch("conv_image");
+}
+
+int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int T_dec, int N,
+                       n2nmn_stream stream) {
+  N2_REQUIRE(c && batches, N2NMN_EINVAL, "walk_layouts: null argument");
+  N2_REQUIRE(is_committed(c), N2NMN_ENOWEIGHT, "walk_layouts: weights not committed");
+  N2_REQUIRE(root(c)->have_token_ops, N2NMN_EINVAL, "walk_layouts: call n2nmn_set_token_ops first");
+  N2_REQUIRE(n2nmn_walk_supported(c), N2NMN_EINVAL,
+             "walk_layouts: dimensions outside the walker's tiling (use n2nmn_execute_program)");
+  const n2nmn_dims& d = c->d;
+  N2_REQUIRE(K >= 1 && K <= WALK_MAX_BATCHES, N2NMN_ECAPACITY, "walk_layouts: 1 <= K <= 16");
+  N2_REQUIRE(N >= 1 && N <= d.N, N2NMN_ECAPACITY, "walk_layouts: N > capacity");
+  N2_REQUIRE(T_dec >= 1 && T_dec <= d.T_decoder && T_dec <= WALK_MAX_T, N2NMN_ECAPACITY,
+             "walk_layouts: T_dec > capacity");
+  WalkArgs a{};
+  for (int k = 0; k < K; ++k) {
+    const n2nmn_walk_batch& b = batches[k];
+    N2_REQUIRE(b.tokens && b.image_feat && b.word_vecs && b.scores, N2NMN_EINVAL,
+               "walk_layouts: null buffer in a batch");
+    const n2nmn_ctx* owner = b.ctx ? b.ctx : c;
+    N2_REQUIRE(root(owner) == root(c), N2NMN_EINVAL,
+               "walk_layouts: a batch's context does not share this context's weights");
+    a.b[k].tokens = b.tokens; a.b[k].feat = b.image_feat; a.b[k].word_vecs = b.word_vecs;
+    a.b[k].scores = b.scores; a.b[k].validity = b.validity;
+    a.b[k].mfind = owner->mfind; a.b[k].mfsp = owner->mfsp;
+  }
+  a.K = K; a.N = N; a.T = T_dec; a.V = d.num_vocab_nmn; a.token_op = root(c)->token_op;
+  a.H = d.H; a.W = d.W; a.D = d.D; a.M = d.map_dim; a.Mp = c->Mp; a.HWp = c->HWp;
+  a.E = d.embed_dim_txt; a.C = d.num_choices; a.ksize = d.kernel_size;
+  a.stats = c->prof_on ? c->walk_stats : nullptr;
+  ModuleWeights w = module_weights(c);
+  hipStream_t s = S(stream);
+  {
+    ProfScope ps(c, F_WALK, 0.0, 0.0, s);     // work filled in from the device counters
+    launch_walk(w, a, s);
+  }
+  return check_launch("walk_layouts");
+}
+
+int n2nmn_execute_tokens(n2nmn_ctx* c, const int32_t* tokens, int T_dec, int N,
+                         const float* image_feat, const float* word_vecs, float* scores,
+                         int32_t* validity, n2nmn_stream stream) {
+  N2_REQUIRE(c && tokens && image_feat && word_vecs && scores, N2NMN_EINVAL,
+             "execute_tokens: null argument");
+  int rc = n2nmn_conv_image(c, image_feat, N, N2NMN_CONV_FIND | N2NMN_CONV_FSP, tokens, T_dec,
+                            stream);
+  if (rc != N2NMN_OK) return rc;
+  n2nmn_walk_batch b{};
+  b.ctx = c; b.tokens = tokens; b.image_feat = image_feat; b.word_vecs = word_vecs;
+  b.scores = scores; b.validity = validity;
+  return n2nmn_walk_layouts(c, &b, 1, T_dec, N, stream);
+}
+
 int n2nmn_add_coords(n2nmn_ctx* c, const float* feat, int N, int D0, float* out,
                      n2nmn_stream stream) {
   N2_REQUIRE(c && feat && out, N2NMN_EINVAL, "add_coords: null argument");
@@ -1004,10 +1111,11 @@ int n2nmn_question_prior_add(n2nmn_ctx* c, int N, float* scores, n2nmn_stream st
 int n2nmn_profile_begin(n2nmn_ctx* ctx) {
   N2_REQUIRE(ctx, N2NMN_EINVAL, "profile_begin: null context");
   ctx->prof_recs.clear();
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < 24; ++i) {
     ctx->prof_ms[i] = ctx->prof_flops[i] = ctx->prof_bytes[i] = 0;
     ctx->prof_launches[i] = 0;
   }
+  N2_HIP(hipMemset(ctx->walk_stats, 0, sizeof(unsigned long long) * WALK_STATS));
   ctx->prof_on = true;
   return N2NMN_OK;
 }
@@ -1022,6 +1130,22 @@ int n2nmn_profile_end(n2nmn_ctx* ctx, n2nmn_stream stream) {
     const auto& r = ctx->prof_recs[i];
     ctx->prof_ms[r.fam] += ms; ctx->prof_flops[r.fam] += r.flops;
     ctx->prof_bytes[r.fam] += r.bytes; ctx->prof_launches[r.fam] += 1;
+  }
+  if (ctx->prof_launches[F_WALK] > 0) {
+    // the walker decodes its layouts on the device, so the host learns what it executed from the
+    // node counters the profiled launches accumulated (algorithmic work)
+    unsigned long long st[WALK_STATS];
+    N2_HIP(hipMemcpy(st, ctx->walk_stats, sizeof(st), hipMemcpyDeviceToHost));
+    const n2nmn_dims& d = ctx->d;
+    const double HW = (double)d.H * d.W, D = d.D, M = d.map_dim, Mp = ctx->Mp, E = d.embed_dim_txt,
+                 C = d.num_choices, KK = (double)d.kernel_size * d.kernel_size;
+    const double n_find = (double)st[0], n_pool_in = (double)st[1], n_pool = (double)st[2],
+                 n_text = (double)st[3], n_tr = (double)st[4], n_q = (double)st[5];
+    ctx->prof_bytes[F_WALK] += 4.0 * (n_find * (HW * Mp + HW) + n_pool * HW * D + n_pool_in * HW +
+                                      n_text * E + n_q * C) +
+                               ctx->prof_launches[F_WALK] * 4.0 * (5 * E * M + 4 * D * M);
+    ctx->prof_flops[F_WALK] += n_find * 5.0 * HW * M + n_pool_in * (2.0 * HW * D + 2.0 * D * M) +
+                               n_text * 2.0 * E * M + n_tr * HW * M * (2.0 * KK + 5.0);
   }
   return (int)ctx->prof_recs.size();
 }

@@ -151,6 +151,8 @@ struct n2nmn_ctx {
   float* we_pad[3] = {nullptr, nullptr, nullptr};
   float* batt_pad[4] = {nullptr, nullptr, nullptr, nullptr};
   int32_t *P = nullptr, *Wv = nullptr, *bv = nullptr;
+  int32_t* token_op = nullptr;             // [V] op code per layout token (-1: <eos>), device
+  bool have_token_ops = false;
 
   // seq2seq workspace
   float *eh0[2] = {nullptr, nullptr}, *eh1[2] = {nullptr, nullptr}, *ec0 = nullptr, *ec1 = nullptr;
@@ -185,8 +187,9 @@ struct n2nmn_ctx {
   std::vector<hipEvent_t> prof_events;      // pairs
   struct ProfRec { int fam; double flops, bytes; };
   std::vector<ProfRec> prof_recs;
-  double prof_ms[16] = {0}, prof_flops[16] = {0}, prof_bytes[16] = {0};
-  long prof_launches[16] = {0};
+  double prof_ms[24] = {0}, prof_flops[24] = {0}, prof_bytes[24] = {0};
+  long prof_launches[24] = {0};
+  unsigned long long* walk_stats = nullptr;   // device [WALK_STATS]: node counts of profiled walks
 };
 
 
@@ -212,7 +215,7 @@ struct Carver {
 enum Family {
   F_LSTM_ENC = 0, F_LSTM_DEC0, F_LSTM_DEC1, F_LINEAR_Q, F_DEC_STEP, F_GEMM_EHT, F_WORD_VECS,
   F_TEXTMAP, F_CONV_IMAGE, F_ATT_OPS, F_POOL, F_HEADS,
-  F_LSTM_BWD, F_GEMM_TN, F_BWD_MISC, F_OPTIMISER, F_COUNT
+  F_LSTM_BWD, F_GEMM_TN, F_BWD_MISC, F_OPTIMISER, F_WALK, F_COUNT
 };
 extern const char* kFamilyNames[F_COUNT];
 

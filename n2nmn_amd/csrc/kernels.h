@@ -27,6 +27,11 @@ struct GemmArgs {
   int relu;                                   // != 0: C = max(0, A.B + bias)
   const int32_t* c_row_idx;                   // optional: result row r goes to C row c_row_idx[r]
                                               // (negative: the row is not stored)
+  // optional gate (hoisted conv_image of an operator only some layouts use): a row tile is computed
+  // only if a layout of one of its row groups (group = gate_rows consecutive rows = one image)
+  // contains a token whose op code is gate_op.  gate_tokens [gate_T][gate_N] device.
+  const int32_t* gate_tokens; const int32_t* gate_token_op;
+  int gate_T, gate_N, gate_V, gate_op, gate_rows;
 };
 void launch_gemm_pk(const GemmArgs& a, hipStream_t s);
 
@@ -192,6 +197,36 @@ struct ModuleBuffers {
   int32_t* ev_rows;       // [2][max_pool]: result row of entry i for Describe / SameProperty, or -1
   int ev_stride;          // max_pool
 };
+
+// ---- layout walker (kernels_walk.hip): one workgroup runs one question's whole module network
+// straight from its RPN tokens.  A launch covers the questions of up to WALK_MAX_BATCHES in-flight
+// batches ("super-bucket"): workgroup q handles question q % N of batch q / N.
+constexpr int WALK_THREADS = 512;
+constexpr int WALK_POOL_ROWS = 38;   // feature rows a thread keeps in flight (H*W / (512 / (D/4)))
+constexpr int WALK_MAX_T = 32;
+constexpr int WALK_MAX_BATCHES = 16;
+struct WalkBatch {
+  const int32_t* tokens;   // [T][N] layout tokens (decoder output or ground truth), device
+  const float* feat;       // [N][HW][D]
+  const float* word_vecs;  // [T][N][E]
+  float* scores;           // [N][C]
+  int32_t* validity;       // [N] 1 / 0 (expr_validity_array) or nullptr
+  const float* mfind;      // [N][HW][Mp] conv_image maps, FindModule weights
+  const float* mfsp;       // [N][HW][Mp] conv_image maps, FindSamePropertyModule weights (only the
+                           // images whose layout has a _FindSameProperty token are filled in)
+};
+struct WalkArgs {
+  WalkBatch b[WALK_MAX_BATCHES];
+  int K, N, T, V;
+  const int32_t* token_op; // [V] device: op code of each layout token, -1 for <eos>
+  int H, W, D, M, Mp, HWp, E, C, ksize;
+  // profiling only: [0] Find-type nodes, [1] pooled inputs, [2] pooling nodes, [3] text maps,
+  // [4] Transform nodes, [5] valid questions (atomic adds by thread 0 of each workgroup)
+  unsigned long long* stats;
+};
+constexpr int WALK_STATS = 8;
+int walk_supported(int H, int W, int D, int M, int Mp, int HWp, int E, int C, int T, int ksize);
+void launch_walk(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
 
 // out[n,h,w,:] = [feat[n,h,w,:D0], linspace(-1,1,W)[w], linspace(-1,1,H)[h], 0 ...]
 void launch_add_coords(const float* feat, int N, int H, int W, int D0, int D, float* out,

@@ -38,6 +38,20 @@ __global__ __launch_bounds__(256) void gemm_pk_kernel(GemmArgs a) {
   const int lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  if (a.gate_tokens) {        // uniform early exit: none of this tile's images needs the map
+    __shared__ int need;
+    if (tid == 0) need = 0;
+    __syncthreads();
+    const int g0 = m0 / a.gate_rows, g1 = min(m0 + BM - 1, a.M - 1) / a.gate_rows;
+    const int per = a.gate_T;
+    if (tid < (g1 - g0 + 1) * per) {
+      const int g = g0 + tid / per, t = tid % per;
+      const int tok = a.gate_tokens[(size_t)t * a.gate_N + g];
+      if (tok >= 0 && tok < a.gate_V && a.gate_token_op[tok] == a.gate_op) need = 1;
+    }
+    __syncthreads();
+    if (!need) return;
+  }
 
   // ---- global load assignment: 2 float4 of A and 2 of B per thread -----------------------
   // A: float4 index i = tid + 256 j -> row = i >> 3, k4 = i & 7 (8 lanes cover 128 contiguous B)

@@ -1,0 +1,578 @@
+// Layout walker: the whole module network of ONE question in ONE workgroup, straight from the
+// decoder's Reverse-Polish tokens -- on-device replacement of
+//   Assembler.assemble               models_clevr/nmn3_assembler.py:153-222  (stack decode + validity)
+//   td.Compiler.build_feed_dict/Loom models_clevr/nmn3_model.py:55-159       (per-depth batching)
+//   Modules.<X>Module                models_clevr/nmn3_modules.py:60-495
+// for the inference path.
+//
+// Why a walker instead of per-(level, stage) launches: questions are independent and a CLEVR layout
+// has <= T_dec nodes whose attention maps are 150 floats each, so a question's whole tree fits one
+// workgroup's LDS.  The level scheduler (schedule.cpp) pays a kernel boundary per level stage and its
+// launches carry ~15 jobs each; here the grid is (questions of ALL in-flight batches) workgroups of
+// 512 threads, every operator runs as soon as its inputs exist, nothing but the answer logits is
+// written back, and no host synchronisation or program upload sits between the two phases.
+//
+// Per workgroup (question n of batch k):
+//   1. thread 0 decodes the RPN column tokens[:, n] with the reference's five validity checks;
+//      an invalid layout writes zero logits (nmn3_model.py:146,155) and validity = 0.
+//   2. nodes run in token order (= a valid topological order); node t keeps its attention map in
+//      LDS slot t.  Text maps (fc_text) are computed on the fly from word_vecs[t, n].
+//   3. Find / Filter / FindSameProperty read the hoisted conv_image map of image n (one MFMA GEMM
+//      per batch, run beside phase 1), the pooling operators stream feat[n] (the HBM-bound read:
+//      every thread has all of its 16-B loads in flight before the softmax), answer operators write
+//      scores[n, :].
+//
+// HBM traffic per question: conv_image map 150 KB per Find-type node + 307 KB per pooling node
+// (+ weights from L2); algorithmic bytes are counted by n2nmn_walk_layouts for the roofline.
+#include <algorithm>
+
+#include "device_utils.h"
+#include "kernels.h"
+
+namespace n2nmn {
+
+namespace {
+
+constexpr int WT = WALK_THREADS;       // 512: 8 waves with up to 256 VGPRs each (one workgroup per CU)
+constexpr int WW = WT / 64;            // 8 waves
+constexpr int MAXT = WALK_MAX_T;       // decoder steps a layout may have
+constexpr int MAXCI = 4;               // float4 column groups per lane: Mp <= 256 * CI, CI <= 4
+
+struct WalkLds {
+  int op[MAXT], in0[MAXT], in1[MAXT];
+  int tok_op[MAXT];        // op code of token t (-1: <eos>, -2: token out of range)
+  int stack[MAXT];
+  int n_nodes, valid;
+};
+
+// block reductions through `scr` (>= 16 floats); every thread gets the result
+template <int OP>
+__device__ __forceinline__ float wg_reduce(float v, float* scr) {
+  return block_reduce<OP>(v, scr);
+}
+
+// out[c] (c < Mp, LDS) = bias[c] + sum_k x[k] * Wp[k][c]   with Wp zero-padded [K][Mp] in HBM/L2,
+// x in LDS.  K-split over the waves, float4 columns over the lanes; every lane has all of its
+// weight rows in flight before the first FMA (<= KU rows per pass).  `red` needs WW*Mp floats.
+// scale (LDS, may be nullptr): out[c] *= scale[c] after the bias.
+template <int KU>
+__device__ __forceinline__ void fc_pad(int tid, const float* x, int K, const float* __restrict__ Wp,
+                                       const float* __restrict__ bias, int Mp, float* out,
+                                       float* red, const float* scale) {
+  const int lane = tid & 63, wid = tid >> 6;
+  const int kper = (K + WW - 1) / WW;
+  const int k0 = wid * kper, k1 = min(K, k0 + kper);
+  for (int cb = 0; cb < Mp; cb += 256) {
+    const bool col_ok = cb + 4 * lane < Mp;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // uniform base (SGPR pair) + 32-bit per-lane offset: one address VGPR per load in flight
+    const unsigned col = (unsigned)min(cb + 4 * lane, Mp - 4);
+    for (int kb = k0; kb < k1; kb += KU) {
+      float4 w4[KU];
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        const unsigned k = (unsigned)min(kb + u, k1 - 1);
+        w4[u] = *reinterpret_cast<const float4*>(Wp + (k * (unsigned)Mp + col));
+      }
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        if (kb + u < k1) {
+          const float xv = x[kb + u];
+          acc.x += xv * w4[u].x; acc.y += xv * w4[u].y; acc.z += xv * w4[u].z; acc.w += xv * w4[u].w;
+        }
+      }
+    }
+    if (col_ok) *reinterpret_cast<float4*>(red + (size_t)wid * 256 + 4 * lane) = acc;
+    __syncthreads();
+    if (tid < 256 && cb + tid < Mp) {
+      float r = bias[cb + tid];
+#pragma unroll
+      for (int q = 0; q < WW; ++q) r += red[q * 256 + tid];
+      if (scale) r *= scale[cb + tid];
+      out[cb + tid] = r;
+    }
+    __syncthreads();
+  }
+}
+
+// scores[c] = b[c] + sum_f x[f] * Wm[f*C + c], x in LDS (F values), C <= WT.  Thread (slice, c)
+// takes f = slice, slice + nsl, ...: consecutive threads read consecutive floats of Wm.
+__device__ __forceinline__ void fc_out(int tid, const float* x, int F,
+                                       const float* __restrict__ Wm, const float* __restrict__ b,
+                                       int C, float* __restrict__ out, float* red) {
+  const int nsl = WT / C;
+  const int c = tid % C, sl = tid / C;
+  float s0 = 0.f, s1 = 0.f;
+  if (sl < nsl) {
+    int f = sl;
+    for (; f + nsl < F; f += 2 * nsl) {
+      s0 += x[f] * Wm[(size_t)f * C + c];
+      s1 += x[f + nsl] * Wm[(size_t)(f + nsl) * C + c];
+    }
+    if (f < F) s0 += x[f] * Wm[(size_t)f * C + c];
+    red[sl * C + c] = s0 + s1;
+  }
+  __syncthreads();
+  if (tid < C) {
+    float r = b[tid];
+    for (int q = 0; q < nsl; ++q) r += red[q * C + tid];
+    out[tid] = r;
+  }
+  __syncthreads();
+}
+
+}  // namespace
+
+// LDS carve (floats) shared by host and device
+__host__ __device__ inline size_t walk_lds_floats(int T, int HWp, int Mp, int E, int D, int M,
+                                                  int ksize, int H, int W, int C) {
+  const int HW = H * W;
+  const size_t arena = (size_t)T * HWp;
+  const size_t vecs = 4 * (size_t)Mp + ((E + 3) & ~3) + 2 * (size_t)D + 2 * (size_t)HWp + 32;
+  // scratch: max of  fc reductions [WW][256] | pool stage [rows in flight][2][D] |
+  //                  Transform taps [M][RS] + padded map + red [WW][64][2] | answer features + red
+  const int KK = ksize * ksize, RS = (KK + 2 + 3) & ~3, pad = ksize / 2;
+  const int ncol = D / 4, nrow = WT / ncol;
+  size_t s0 = (size_t)WW * 256;
+  size_t s1 = (size_t)nrow * 2 * D;
+  size_t s2 = (size_t)M * RS + (((size_t)(H + 2 * pad) * (W + 2 * pad) + 3) & ~3) + (size_t)WW * 64 * 2;
+  size_t s3 = (size_t)((2 * HW + 4 + 3) & ~3) + (size_t)WT;
+  size_t s = s0 > s1 ? s0 : s1;
+  s = s > s2 ? s : s2;
+  s = s > s3 ? s : s3;
+  return arena + vecs + s + 64;
+}
+
+namespace {
+
+template <int KS>
+__device__ __forceinline__ void walk_transform(int tid, const ModuleWeights& w, const WalkArgs& a,
+                                               const float* in0, const float* tm, float* outp,
+                                               float* scr) {
+  constexpr int KK = KS * KS;
+  constexpr int RS = (KK + 2 + 3) & ~3;
+  constexpr int PAD = KS / 2;
+  const int H = a.H, W = a.W, HW = H * W, M = a.M;
+  const int PW = W + 2 * PAD, PH = H + 2 * PAD;
+  float* Kl = scr;                              // [M][RS]
+  float* xin = Kl + (size_t)M * RS;             // [PH][PW]
+  float* red = xin + ((PH * PW + 3) & ~3);      // [WW][64][2]
+  const int lane = tid & 63, wid = tid >> 6;
+  for (int i = tid; i < PH * PW; i += WT) {
+    const int y = i / PW - PAD, x = i % PW - PAD;
+    xin[i] = (y >= 0 && y < H && x >= 0 && x < W) ? in0[y * W + x] : 0.f;
+  }
+  for (int i = tid; i < KK * M; i += WT) {      // coalesced over c
+    const int tap = i / M, c = i - tap * M;
+    Kl[c * RS + tap] = w.Kt[i] * tm[c];
+  }
+  for (int c = tid; c < M; c += WT) {
+    Kl[c * RS + KK] = w.bt[c] * tm[c];
+    Kl[c * RS + KK + 1] = w.we[2][c];
+  }
+  __syncthreads();
+  // waves = pixel groups (64 pixels) x channel groups
+  const int PG = (HW + 63) / 64;
+  const int CG = WW / PG > 0 ? WW / PG : 1;
+  const float be = w.be[2][0];
+  for (int pg0 = 0; pg0 < PG; pg0 += WW / CG) {
+    const int pg = pg0 + wid / CG, cg = wid % CG;
+    const bool wave_on = wid < (WW / CG) * CG && pg < PG;
+    const int p = pg * 64 + lane;
+    const bool on = wave_on && p < HW;
+    float ss = 0.f, dot = 0.f;
+    if (wave_on) {
+      const int y = on ? p / W : 0, x = on ? p - (p / W) * W : 0;
+      float win[KK];
+#pragma unroll
+      for (int dy = 0; dy < KS; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < KS; ++dx) win[dy * KS + dx] = xin[(y + dy) * PW + x + dx];
+      for (int c = cg; c < M; c += CG) {
+        const float4* kr = reinterpret_cast<const float4*>(Kl + (size_t)c * RS);
+        float k[RS];
+#pragma unroll
+        for (int q = 0; q < RS / 4; ++q) {
+          const float4 t = kr[q];
+          k[4 * q] = t.x; k[4 * q + 1] = t.y; k[4 * q + 2] = t.z; k[4 * q + 3] = t.w;
+        }
+        float v = k[KK];
+#pragma unroll
+        for (int tap = 0; tap < KK; ++tap) v += k[tap] * win[tap];
+        ss += v * v;
+        dot += v * k[KK + 1];
+      }
+    }
+    red[(wid * 64 + lane) * 2] = ss;
+    red[(wid * 64 + lane) * 2 + 1] = dot;
+    __syncthreads();
+    if (wave_on && cg == 0 && on) {
+      float s2 = 0.f, d2 = 0.f;
+      for (int q = 0; q < CG; ++q) {
+        s2 += red[((wid + q) * 64 + lane) * 2];
+        d2 += red[((wid + q) * 64 + lane) * 2 + 1];
+      }
+      outp[p] = d2 / sqrtf(fmaxf(s2, 1e-12f)) + be;
+    }
+    __syncthreads();
+  }
+}
+
+template <int CI>
+__global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ WalkLds L;
+  const int q = blockIdx.x;
+  const int kb = q / a.N, n = q - kb * a.N;
+  const WalkBatch& B = a.b[kb];
+  const int tid0 = threadIdx.x;
+  const int H = a.H, W = a.W, HW = H * W, D = a.D, M = a.M, Mp = a.Mp, E = a.E, C = a.C;
+  const int HWp = a.HWp, T = a.T;
+
+  float* arena = smem;                                 // [T][HWp]
+  float* tml = arena + (size_t)T * HWp;                // [Mp] text map (x amap for FSP)
+  float* am0 = tml + Mp;                               // [Mp] fc_att of input 0
+  float* am1 = am0 + Mp;                               // [Mp] fc_att of input 1
+  float* ev = am1 + Mp;                                // [Mp]
+  float* wv = ev + Mp;                                 // [E] word vector
+  float* pooled = wv + ((E + 3) & ~3);                 // [2][D]
+  float* sa0 = pooled + 2 * (size_t)D;                 // [HWp] softmax weights
+  float* sa1 = sa0 + HWp;
+  float* rs = sa1 + HWp;                               // [32] reduction scratch
+  float* scr = rs + 32;                                // operator scratch (see walk_lds_floats)
+
+  // ---- 1. decode the RPN column (nmn3_assembler.py:153-222) ---------------------------------
+  // the T token loads (and their op-code lookups) go out in parallel; thread 0 then runs the stack
+  // machine on LDS values only
+  if (tid0 < T) {
+    const int tok = B.tokens[(size_t)tid0 * a.N + n];
+    L.tok_op[tid0] = (tok < 0 || tok >= a.V) ? -2 : a.token_op[tok];
+  }
+  __syncthreads();
+  if (tid0 == 0) {
+    int sp = 0, nn = 0, ok = 1;
+    bool has_eos = false;
+    for (int t = 0; t < T; ++t) {
+      if (L.tok_op[t] == -2) ok = 0;                             // garbage token: not a layout
+      if (L.tok_op[t] < 0) has_eos = true;
+    }
+    if (!has_eos) ok = 0;                                        // 'cannot find <eos>'
+    for (int t = 0; ok && t < T; ++t) {
+      const int op = L.tok_op[t];
+      if (op < 0) break;                                         // <eos>
+      int k;
+      bool ans;
+      switch (op) {
+        case N2NMN_OP_SCENE: case N2NMN_OP_FIND: k = 0; ans = false; break;
+        case N2NMN_OP_FILTER: case N2NMN_OP_FIND_SAME_PROPERTY: case N2NMN_OP_TRANSFORM:
+          k = 1; ans = false; break;
+        case N2NMN_OP_AND: case N2NMN_OP_OR: k = 2; ans = false; break;
+        case N2NMN_OP_EXIST: case N2NMN_OP_COUNT: case N2NMN_OP_DESCRIBE: k = 1; ans = true; break;
+        case N2NMN_OP_EQUAL_NUM: case N2NMN_OP_MORE_NUM: case N2NMN_OP_LESS_NUM:
+        case N2NMN_OP_SAME_PROPERTY: k = 2; ans = true; break;
+        default: k = -1; ans = false; break;
+      }
+      if (k < 0 || sp < k) { ok = 0; break; }                    // 'not enough input for ...'
+      int i0 = -1, i1 = -1;
+      for (int j = k - 1; j >= 0; --j) {                         // input_{k-1} = stack top
+        const int top = L.stack[--sp];
+        if (L.op[top] & 0x100) { ok = 0; break; }                // 'input incompatible for ...'
+        (j == 0 ? i0 : i1) = top;
+      }
+      if (!ok) break;
+      L.op[t] = op | (ans ? 0x100 : 0); L.in0[t] = i0; L.in1[t] = i1;
+      L.stack[sp++] = t;
+      nn = t + 1;
+    }
+    if (ok && (sp != 1 || !(L.op[L.stack[0]] & 0x100))) ok = 0;  // stack size / result type
+    L.n_nodes = nn; L.valid = ok;
+  }
+  __syncthreads();
+  float* srow = B.scores + (size_t)n * C;
+  if (tid0 == 0 && B.validity) B.validity[n] = L.valid;
+  if (!L.valid) {                                                // INVALID_EXPR: zero logits
+    for (int c = tid0; c < C; c += WT) srow[c] = 0.f;
+    return;
+  }
+  const int nn = L.n_nodes;
+  if (a.stats && tid0 == 0) {
+    unsigned long long cf = 0, cpi = 0, cp = 0, ct = 0, ctr = 0;
+    for (int t = 0; t < nn; ++t) {
+      const int o = L.op[t] & 0xff;
+      const bool f = o == N2NMN_OP_FIND || o == N2NMN_OP_FILTER || o == N2NMN_OP_FIND_SAME_PROPERTY;
+      const bool p = o == N2NMN_OP_FIND_SAME_PROPERTY || o == N2NMN_OP_SAME_PROPERTY || o == N2NMN_OP_DESCRIBE;
+      cf += f; cp += p; cpi += p ? (o == N2NMN_OP_SAME_PROPERTY ? 2 : 1) : 0;
+      ct += (f || p || o == N2NMN_OP_TRANSFORM); ctr += o == N2NMN_OP_TRANSFORM;
+    }
+    atomicAdd(a.stats + 0, cf); atomicAdd(a.stats + 1, cpi); atomicAdd(a.stats + 2, cp);
+    atomicAdd(a.stats + 3, ct); atomicAdd(a.stats + 4, ctr); atomicAdd(a.stats + 5, 1ull);
+  }
+  const float* feat = B.feat + (size_t)n * HW * D;
+  const int ncol = D / 4, nrow = WT / ncol;
+  constexpr int PR = WALK_POOL_ROWS;
+
+  // ---- 2. nodes in token order -------------------------------------------------------------
+  for (int t = 0; t < nn; ++t) {
+    // every per-thread index below derives from this opaque copy, so the compiler cannot hoist the
+    // (dozens of) per-load address computations of one operator out of the node loop, where they
+    // would stay live across all the other operators and spill
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wid = tid >> 6;
+    const int lc = tid % ncol, lr = tid / ncol;
+    const int op = L.op[t] & 0xff;
+    const float* in0 = L.in0[t] >= 0 ? arena + (size_t)L.in0[t] * HWp : nullptr;
+    const float* in1 = L.in1[t] >= 0 ? arena + (size_t)L.in1[t] * HWp : nullptr;
+    float* outp = arena + (size_t)t * HWp;
+
+    const bool pools = op == N2NMN_OP_FIND_SAME_PROPERTY || op == N2NMN_OP_SAME_PROPERTY ||
+                       op == N2NMN_OP_DESCRIBE;
+
+    // text parameter -> text map (fc_text / text_fc): nmn3_modules.py:53-57,101,161,209,424,479
+    int ws = -1;
+    switch (op) {
+      case N2NMN_OP_FIND: case N2NMN_OP_FILTER: ws = 0; break;
+      case N2NMN_OP_FIND_SAME_PROPERTY: ws = 1; break;
+      case N2NMN_OP_TRANSFORM: ws = 2; break;
+      case N2NMN_OP_SAME_PROPERTY: ws = 3; break;
+      case N2NMN_OP_DESCRIBE: ws = 4; break;
+      default: break;
+    }
+    if (ws >= 0) {
+      const float* src = B.word_vecs + ((size_t)t * a.N + n) * E;
+      for (int e = tid; e < E; e += WT) wv[e] = src[e];
+      __syncthreads();
+      fc_pad<38>(tid, wv, E, w.Wtxt[ws], w.btxt[ws], Mp, tml, scr, nullptr);
+    }
+
+    if (pools) {
+      // the feature rows of this thread do not depend on the softmax: all of its 16-B loads go out
+      // first (the whole [HW, D] map of the question is in flight at once) and land while the
+      // softmax is computed
+      float4 fr[PR];
+      const int myrows = lr < nrow ? (HW - lr + nrow - 1) / nrow : 0;
+      {
+        const unsigned rowstep = (unsigned)(nrow * D);
+        unsigned off = (unsigned)(lr * D + 4 * lc);
+        const unsigned last = (unsigned)(((myrows > 0 ? lr + (myrows - 1) * nrow : 0)) * D + 4 * lc);
+#pragma unroll
+        for (int qq = 0; qq < PR; ++qq) {
+          fr[qq] = *reinterpret_cast<const float4*>(feat + min(off, last));
+          off += rowstep;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // softmax over the H*W logits of each input (:170-172,432-437,482-484)
+      const int nin = op == N2NMN_OP_SAME_PROPERTY ? 2 : 1;
+      for (int i = 0; i < nin; ++i) {
+        const float* src = i == 0 ? in0 : in1;
+        float* dst = i == 0 ? sa0 : sa1;
+        float lm = -INFINITY;
+        for (int r = tid; r < HW; r += WT) lm = fmaxf(lm, src[r]);
+        const float mx = wg_reduce<1>(lm, rs);
+        float ls = 0.f;
+        for (int r = tid; r < HW; r += WT) {
+          const float ex = expf(src[r] - mx);
+          dst[r] = ex;
+          ls += ex;
+        }
+        const float sum = wg_reduce<0>(ls, rs);
+        for (int r = tid; r < HW; r += WT) dst[r] = dst[r] / sum;
+      }
+      __syncthreads();
+      float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
+      float* stage = scr;                                // [nrow][2][D]
+      if (lr < nrow) {
+#pragma unroll
+        for (int qq = 0; qq < PR; ++qq) {
+          if (qq < myrows) {
+            const int r = lr + qq * nrow;
+            const float w0 = sa0[r], w1 = nin == 2 ? sa1[r] : 0.f;
+            acc0.x += w0 * fr[qq].x; acc0.y += w0 * fr[qq].y; acc0.z += w0 * fr[qq].z; acc0.w += w0 * fr[qq].w;
+            acc1.x += w1 * fr[qq].x; acc1.y += w1 * fr[qq].y; acc1.z += w1 * fr[qq].z; acc1.w += w1 * fr[qq].w;
+          }
+        }
+        *reinterpret_cast<float4*>(stage + (size_t)(lr * 2 + 0) * D + 4 * lc) = acc0;
+        *reinterpret_cast<float4*>(stage + (size_t)(lr * 2 + 1) * D + 4 * lc) = acc1;
+      }
+      __syncthreads();
+      for (int i = tid; i < nin * D; i += WT) {
+        const int which = i / D, c = i - which * D;
+        float s = 0.f;
+        for (int qq = 0; qq < nrow; ++qq) s += stage[(size_t)(qq * 2 + which) * D + c];
+        pooled[i] = s;
+      }
+      __syncthreads();
+      // fc_att (:173-176,438-446,487-490)
+      const int wi0 = op == N2NMN_OP_FIND_SAME_PROPERTY ? 0 : (op == N2NMN_OP_SAME_PROPERTY ? 1 : 3);
+      fc_pad<32>(tid, pooled, D, w.Watt[wi0], w.batt[wi0], Mp, am0, scr, nullptr);
+      if (nin == 2) fc_pad<32>(tid, pooled + D, D, w.Watt[2], w.batt[2], Mp, am1, scr, nullptr);
+    }
+
+    switch (op) {
+      case N2NMN_OP_SCENE:                                       // :60-72
+        for (int r = tid; r < HW; r += WT) outp[r] = 3.0f;
+        break;
+      case N2NMN_OP_AND:                                         // :218-236
+        for (int r = tid; r < HW; r += WT) outp[r] = fminf(in0[r], in1[r]);
+        break;
+      case N2NMN_OP_OR:                                          // :238-256
+        for (int r = tid; r < HW; r += WT) outp[r] = fmaxf(in0[r], in1[r]);
+        break;
+      case N2NMN_OP_FIND:
+      case N2NMN_OP_FILTER:
+      case N2NMN_OP_FIND_SAME_PROPERTY: {
+        // att[r] = l2norm_c(M[r,c] * tmap[c] (* amap[c])) . w_e + b_e  [min with input_0: Filter]
+        // (:104-108, :129-130, :178-180); one wave per row, all rows of a wave in flight
+        const bool fsp = op == N2NMN_OP_FIND_SAME_PROPERTY;
+        const int wsel = fsp ? 1 : 0;
+        const float* Mbuf = (fsp ? B.mfsp : B.mfind) + (size_t)n * HW * Mp;
+        const float be = w.be[wsel][0];
+        float4 t4[CI], e4[CI];
+#pragma unroll
+        for (int i = 0; i < CI; ++i) {
+          const int c = 4 * lane + 256 * i;
+          if (c < Mp) {
+            t4[i] = *reinterpret_cast<const float4*>(tml + c);
+            e4[i] = *reinterpret_cast<const float4*>(w.we[wsel] + c);
+            if (fsp) {
+              const float4 a4 = *reinterpret_cast<const float4*>(am0 + c);
+              t4[i].x *= a4.x; t4[i].y *= a4.y; t4[i].z *= a4.z; t4[i].w *= a4.w;
+            }
+          } else {
+            t4[i] = make_float4(0.f, 0.f, 0.f, 0.f); e4[i] = t4[i];
+          }
+        }
+        constexpr int UNR = CI == 1 ? 19 : (CI == 2 ? 10 : 5);
+        for (int rb = wid; rb < HW; rb += UNR * WW) {
+          float4 m4[UNR][CI];
+#pragma unroll
+          for (int u = 0; u < UNR; ++u) {
+            const unsigned r = (unsigned)min(rb + u * WW, HW - 1);
+#pragma unroll
+            for (int i = 0; i < CI; ++i) {
+              const unsigned c = (unsigned)min(4 * lane + 256 * i, Mp - 4);
+              m4[u][i] = *reinterpret_cast<const float4*>(Mbuf + (r * (unsigned)Mp + c));
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < UNR; ++u) {
+            const int r = rb + u * WW;
+            float ss = 0.f, dot = 0.f;
+#pragma unroll
+            for (int i = 0; i < CI; ++i) {
+              const float p0 = m4[u][i].x * t4[i].x, p1 = m4[u][i].y * t4[i].y,
+                          p2 = m4[u][i].z * t4[i].z, p3 = m4[u][i].w * t4[i].w;
+              ss += p0 * p0 + p1 * p1 + p2 * p2 + p3 * p3;
+              dot += p0 * e4[i].x + p1 * e4[i].y + p2 * e4[i].z + p3 * e4[i].w;
+            }
+            const float s2 = wave_sum(ss);
+            const float d2 = wave_sum(dot);
+            if (lane == 0 && r < HW) {
+              float att = d2 / sqrtf(fmaxf(s2, 1e-12f)) + be;     // tf.nn.l2_normalize eps (A.4)
+              if (op == N2NMN_OP_FILTER) att = fminf(in0[r], att);  // Filter = And(input_0, Find)
+              outp[r] = att;
+            }
+          }
+        }
+        break;
+      }
+      case N2NMN_OP_TRANSFORM:                                   // :185-216
+        if (a.ksize == 5) walk_transform<5>(tid, w, a, in0, tml, outp, scr);
+        else walk_transform<3>(tid, w, a, in0, tml, outp, scr);
+        break;
+      case N2NMN_OP_DESCRIBE:                                    // :479-493
+      case N2NMN_OP_SAME_PROPERTY: {                             // :424-450
+        const bool same = op == N2NMN_OP_SAME_PROPERTY;
+        float lss = 0.f;
+        for (int c = tid; c < Mp; c += WT) {
+          float v = 0.f;
+          if (c < M) {
+            v = am0[c] * tml[c];
+            if (same) v *= am1[c];
+          }
+          ev[c] = v;
+          lss += v * v;
+        }
+        const float ss = wg_reduce<0>(lss, rs);
+        const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+        for (int c = tid; c < Mp; c += WT) ev[c] *= inv;
+        __syncthreads();
+        const int wi = same ? 5 : 6;
+        fc_out(tid, ev, M, w.Wans[wi], w.bans[wi], C, srow, scr);
+        break;
+      }
+      default: {
+        // Exist (:258-280), Count (:282-304), EqualNum / MoreNum / LessNum (:306-400)
+        float* x = scr;                                  // up to 2*HW + 4 features
+        float* red = x + ((2 * HW + 4 + 3) & ~3);
+        const int nin = (op == N2NMN_OP_EXIST || op == N2NMN_OP_COUNT) ? 1 : 2;
+        float mn[2], mx[2], sm[2];
+        for (int i = 0; i < nin; ++i) {
+          const float* src = i == 0 ? in0 : in1;
+          float lmn = INFINITY, lmx = -INFINITY, lsm = 0.f;
+          for (int r = tid; r < HW; r += WT) {
+            const float v = src[r];
+            x[i * (HW + 2) + r] = v;                     // row-major y*W + x flatten (:297)
+            lmn = fminf(lmn, v); lmx = fmaxf(lmx, v); lsm += v;
+          }
+          mn[i] = wg_reduce<2>(lmn, rs);
+          mx[i] = wg_reduce<1>(lmx, rs);
+          sm[i] = wg_reduce<0>(lsm, rs);
+        }
+        __syncthreads();
+        int F, wi;
+        if (op == N2NMN_OP_EXIST) {
+          if (tid == 0) { x[0] = mn[0]; x[1] = sm[0] / (float)HW; x[2] = mx[0]; }
+          F = 3; wi = 0;
+        } else if (op == N2NMN_OP_COUNT) {
+          if (tid == 0) { x[HW] = mn[0]; x[HW + 1] = mx[0]; }
+          F = HW + 2; wi = 1;
+        } else {
+          if (tid == 0) {
+            x[HW] = mn[0]; x[HW + 1] = mx[0];
+            x[2 * HW + 2] = mn[1]; x[2 * HW + 3] = mx[1];
+          }
+          F = 2 * HW + 4;
+          wi = op == N2NMN_OP_EQUAL_NUM ? 2 : (op == N2NMN_OP_MORE_NUM ? 3 : 4);
+        }
+        __syncthreads();
+        fc_out(tid, x, F, w.Wans[wi], w.bans[wi], C, srow, red);
+        break;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+int walk_supported(int H, int W, int D, int M, int Mp, int HWp, int E, int C, int T, int ksize) {
+  const int HW = H * W;
+  if (D % 4 != 0 || D / 4 > WT || WT % (D / 4) != 0) return 0;
+  const int nrow = WT / (D / 4);
+  if ((HW + nrow - 1) / nrow > WALK_POOL_ROWS) return 0;
+  if (Mp > 256 * MAXCI || Mp % 4 != 0 || C > WT || T > MAXT) return 0;
+  if (ksize != 3 && ksize != 5) return 0;
+  const int PG = (HW + 63) / 64;
+  if (PG > WW) return 0;
+  const size_t bytes = sizeof(float) * walk_lds_floats(T, HWp, Mp, E, D, M, ksize, H, W, C);
+  return bytes <= 150 * 1024;
+}
+
+void launch_walk(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) {
+  const size_t smem = sizeof(float) * walk_lds_floats(a.T, a.HWp, a.Mp, a.E, a.D, a.M, a.ksize,
+                                                      a.H, a.W, a.C);
+  auto go = [&](auto kern) {
+    if (smem > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(kern, dim3(a.K * a.N), dim3(WT), smem, s, w, a);
+  };
+  const int ci = (a.Mp + 255) / 256;
+  if (ci == 1) go(walk_kernel<1>);
+  else if (ci == 2) go(walk_kernel<2>);
+  else go(walk_kernel<4>);
+}
+
+}  // namespace n2nmn

@@ -46,6 +46,8 @@ class Engine:
         b = np.ascontiguousarray(assembler.b, np.int32)
         _lib.check(self._lib.n2nmn_set_validity_tables(self._ctx, P.ctypes.data, W.ctypes.data,
                                                        b.ctypes.data))
+        tok_op = np.ascontiguousarray(assembler._token_op, np.int32)
+        _lib.check(self._lib.n2nmn_set_token_ops(self._ctx, tok_op.ctypes.data, tok_op.shape[0]))
         self._bufs: Dict[tuple, object] = {}
 
     def __del__(self):
@@ -201,6 +203,55 @@ class Engine:
                                                    self.stream()))
         return scores
 
+    # ---- phase 2 without the host hop (include/n2nmn.h section 4b) ---------------------------
+    def walk_supported(self) -> bool:
+        return bool(self._lib.n2nmn_walk_supported(self._ctx))
+
+    def conv_image(self, image_feat, tokens=None, T_dec: Optional[int] = None,
+                   find: bool = True, fsp: bool = True):
+        """Hoisted conv_image GEMMs of all images into this engine's workspace (needs only the
+        features: callers run it on a side stream beside phase 1).  tokens (device [T_dec, N]): the
+        FindSameProperty map is computed only for images whose layout uses that operator."""
+        torch = _torch()
+        feat = self._dev(image_feat, torch.float32)
+        tok = self._dev(tokens, torch.int32)
+        Td = 0 if tok is None else (tok.shape[0] if T_dec is None else int(T_dec))
+        _lib.check(self._lib.n2nmn_conv_image(
+            self._ctx, feat.data_ptr(), feat.shape[0], (1 if find else 0) | (2 if fsp else 0),
+            tok.data_ptr() if tok is not None else None, Td, self.stream()))
+        return feat
+
+    def walk(self, jobs, N: int, T_dec: int):
+        """One walker launch over K in-flight batches.  jobs: list of (engine, tokens, image_feat,
+        word_vecs, scores, validity) device tensors; `engine` is the (fork of this) engine whose
+        conv_image() was called for that batch."""
+        arr = (_lib.WalkBatch * len(jobs))()
+        for i, (eng, tok, feat, wv, sc, val) in enumerate(jobs):
+            arr[i].ctx = eng._ctx
+            arr[i].tokens = tok.data_ptr(); arr[i].image_feat = feat.data_ptr()
+            arr[i].word_vecs = wv.data_ptr(); arr[i].scores = sc.data_ptr()
+            arr[i].validity = val.data_ptr() if val is not None else None
+        _lib.check(self._lib.n2nmn_walk_layouts(self._ctx, arr, len(jobs), int(T_dec), int(N),
+                                                self.stream()))
+
+    def execute_tokens(self, tokens, image_feat, word_vecs, reuse_buffers: bool = True,
+                       conv_done: bool = False):
+        """Phase 2 straight from DEVICE tokens [T_dec, N]: no token fetch, no host assembly, no
+        program upload.  Returns (scores [N, C], validity [N] int32) device tensors."""
+        torch = _torch()
+        tok = self._dev(tokens, torch.int32)
+        feat = self._dev(image_feat, torch.float32)
+        wv = self._dev(word_vecs, torch.float32)
+        Td, N = tok.shape
+        mk = (lambda k, s, dt: self._buf(k, s, dt)) if reuse_buffers else \
+            (lambda k, s, dt: torch.empty(s, dtype=dt, device=self.device))
+        scores = mk('wscores', (N, self.dims.num_choices), torch.float32)
+        validity = mk('wvalid', (N,), torch.int32)
+        if not conv_done:
+            self.conv_image(feat, tok, Td)
+        self.walk([(self, tok, feat, wv, scores, validity)], N, Td)
+        return scores, validity
+
     def module_forward(self, name: str, inputs, time_idx, batch_idx, image_feat, word_vecs):
         """One module operator on explicit inputs (Modules.<X>Module)."""
         torch = _torch()
@@ -259,15 +310,31 @@ class Engine:
 
     # ------------------------------------------------------------------------------------
     def forward(self, batch, T_dec: Optional[int] = None, use_gt_layout: bool = False,
-                gt_layout=None, sample_uniforms=None):
+                gt_layout=None, sample_uniforms=None, host_assemble: bool = False,
+                fetch: bool = True):
         """The whole hot path of exp_clevr/eval_clevr.py:103-135 for one batch:
         phase 1 -> token fetch (the one host sync) -> C++ assemble/pack -> phase 2.
         Returns (scores device tensor, tokens numpy [T_dec,N], validity numpy [N]).
+
+        Default (dimensions the walker supports): phase 1 -> n2nmn_execute_tokens; the layouts are
+        decoded on the device, nothing synchronises between the phases, and with fetch=False the
+        tokens / validity are returned as device tensors (no synchronisation at all).
+        host_assemble=True keeps the reference's flow (token fetch, C++ Assembler, level scheduler).
 
         With use_gt_layout and a HOST gt_layout (numpy, as the reference's data reader delivers
         it, util/clevr_train/data_reader.py:74-82) the predicted tokens are the ground-truth layout
         by construction (models_clevr/nmn3_netgen_att.py:236-238), so the program is assembled
         from the host copy up front and the step has no host synchronisation at all."""
+        if self.walk_supported() and not host_assemble:
+            # device path: the walker decodes the layouts itself (no sync between the phases)
+            gt_dev = self.upload_i32(gt_layout) if isinstance(gt_layout, np.ndarray) else gt_layout
+            s2s = self.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], T_dec,
+                               use_gt_layout, gt_dev, sample_uniforms)
+            scores, validity = self.execute_tokens(s2s['predicted_tokens'],
+                                                   batch['image_feat_batch'], s2s['word_vecs'])
+            if not fetch:
+                return scores, s2s['predicted_tokens'], validity
+            return scores, s2s['predicted_tokens'].cpu().numpy(), validity.cpu().numpy().astype(bool)
         if use_gt_layout and isinstance(gt_layout, np.ndarray):
             tokens = np.ascontiguousarray(gt_layout, np.int32)
             packed, validity = self.assembler.assemble_packed(tokens)

@@ -1,0 +1,155 @@
+"""The layout walker (n2nmn_execute_tokens / n2nmn_walk_layouts: on-device Assembler.assemble + Fold
+batching + every Modules.* operator in one kernel) against
+  * the reference's own assembler goldens: the DEVICE's validity bit of every one of the ~1070 CLEVR
+    reference-generated token sequences (bit-exact, models_clevr/nmn3_assembler.py:153-222),
+  * the fp64 oracle and the reference-code fixture (1e-4),
+  * the level-scheduler path (n2nmn_assemble + n2nmn_execute_program), which stays the compatibility
+    and training path.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import n2nmn_oracle as O
+from n2nmn_amd import synth
+from n2nmn_amd.spec import CLEVR_MODULE_NAMES
+from util import assert_close, t2n
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+import float_cases as FC  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+NAMES = list(CLEVR_MODULE_NAMES)
+
+
+def test_walker_is_the_default_path(clevr_engine):
+    eng, d, asm, w = clevr_engine
+    assert eng.walk_supported()
+
+
+def test_device_validity_equals_reference_assembler_on_every_golden_case(clevr_engine, golden):
+    """The five validity checks run on the GPU: every reference-generated sequence (KATs, templates,
+    random soup, short prefixes, automaton walks) gets the reference's validity bit, and invalid
+    layouts give exactly zero logits."""
+    import torch
+    eng, d, asm, w = clevr_engine
+    batch = synth.make_inputs(d, seed=3)
+    checked = invalid = 0
+    for case in golden['clevr']['cases']:
+        toks = np.array(case['tokens'], np.int32)          # [T, n]
+        T, n = toks.shape
+        if T > d.T_decoder:
+            continue
+        for c0 in range(0, n, d.N):
+            tk = toks[:, c0:c0 + d.N]
+            nb = tk.shape[1]
+            wv = torch.zeros((T, nb, d.embed_dim_txt), device=eng.device)
+            scores, validity = eng.execute_tokens(tk, batch['image_feat_batch'][:nb], wv)
+            want = np.array(case['validity'][c0:c0 + nb], bool)
+            got = t2n(validity).astype(bool)
+            assert np.array_equal(got, want), case['tag']
+            sc = t2n(scores)
+            assert np.all(sc[~want] == 0.0), case['tag']
+            assert np.isfinite(sc).all()
+            checked += nb
+            invalid += int((~want).sum())
+    assert checked > 1000 and invalid > 500
+
+
+@pytest.mark.parametrize('seed', [1, 2, 3])
+def test_walker_matches_oracle_and_level_path_on_random_trees(clevr_engine, seed):
+    eng, d, asm, w = clevr_engine
+    batch = synth.make_inputs(d, seed=50 + seed, min_len=1)
+    toks = synth.random_valid_layouts(d, asm.P, asm.W, asm.b, seed=10 + seed,
+                                      max_len=[4, 9, None][seed - 1])
+    ref = O.forward(w, NAMES, batch, d.T_decoder, d.num_choices, np.float64, forced_tokens=toks)
+    s2s = eng.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], forced_tokens=toks)
+    scores, validity = eng.execute_tokens(s2s['predicted_tokens'], batch['image_feat_batch'],
+                                          s2s['word_vecs'])
+    assert t2n(validity).all()
+    got = t2n(scores).copy()
+    assert_close('walker vs oracle', got, ref['scores'], TOL)
+    packed, v2 = asm.assemble_packed(toks)
+    lvl = t2n(eng.execute(packed, batch['image_feat_batch'], s2s['word_vecs']))
+    assert_close('walker vs level scheduler', got, lvl, 2e-5)
+
+
+def test_walker_mixed_valid_and_invalid_rows(clevr_engine):
+    eng, d, asm, w = clevr_engine
+    batch = synth.make_inputs(d, seed=61)
+    toks = synth.template_layout_batch(d)
+    eos = asm.EOS_idx
+    toks[:, 3] = eos                                     # empty layout: stack size 0
+    toks[:, 7] = asm.name2idx_dict['_Find']              # no <eos>
+    toks[:3, 11] = [asm.name2idx_dict['_Find'], asm.name2idx_dict['_And'], asm.name2idx_dict['_Count']]
+    toks[3:, 11] = eos                                   # not enough input for _And
+    toks[:3, 12] = [asm.name2idx_dict['_Find'], asm.name2idx_dict['_Count'], asm.name2idx_dict['_Exist']]
+    toks[3:, 12] = eos                                   # input incompatible (ans fed to Exist)
+    toks[:2, 13] = [asm.name2idx_dict['_Find'], asm.name2idx_dict['_Transform']]
+    toks[2:, 13] = eos                                   # result type must be ans
+    ref = O.forward(w, NAMES, batch, d.T_decoder, d.num_choices, np.float64, forced_tokens=toks)
+    s2s = eng.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], forced_tokens=toks)
+    scores, validity = eng.execute_tokens(s2s['predicted_tokens'], batch['image_feat_batch'],
+                                          s2s['word_vecs'])
+    assert np.array_equal(t2n(validity).astype(bool), ref['validity'])
+    assert not ref['validity'][[3, 7, 11, 12, 13]].any()
+    assert_close('scores', t2n(scores), ref['scores'], TOL)
+
+
+def test_walker_small_ragged_batch(clevr_engine):
+    eng, d, asm, w = clevr_engine
+    from n2nmn_amd.spec import Dims
+    small = Dims(N=5, T_encoder=9, T_decoder=12)
+    batch = synth.make_inputs(small, seed=5, min_len=1)
+    toks = synth.template_layout_batch(small, offset=3)
+    ref = O.forward(w, NAMES, batch, small.T_decoder, d.num_choices, np.float64, forced_tokens=toks)
+    scores, tokens, validity = eng.forward(batch, T_dec=small.T_decoder, use_gt_layout=True,
+                                           gt_layout=toks)
+    ref_gt = O.forward(w, NAMES, batch, small.T_decoder, d.num_choices, np.float64,
+                       use_gt_layout=True, gt_layout=toks)
+    assert validity.all() and np.array_equal(tokens, toks)
+    assert_close('scores', t2n(scores), ref_gt['scores'], TOL)
+    del ref
+
+
+def test_super_bucket_of_forked_batches_equals_single_batches(clevr_engine):
+    """K = 3 in-flight batches (forked contexts: own workspace, shared weights) in ONE walker
+    launch give bit-identical logits to three single-batch launches."""
+    import torch
+    eng, d, asm, w = clevr_engine
+    engines = [eng, eng.fork(), eng.fork()]
+    jobs, singles = [], []
+    for k, e in enumerate(engines):
+        batch = synth.make_inputs(d, seed=70 + k)
+        toks = synth.random_valid_layouts(d, asm.P, asm.W, asm.b, seed=20 + k, max_len=6)
+        s2s = e.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], forced_tokens=toks,
+                        reuse_buffers=False)
+        feat = e._dev(batch['image_feat_batch'], torch.float32)
+        sc1, _ = e.execute_tokens(s2s['predicted_tokens'], feat, s2s['word_vecs'],
+                                  reuse_buffers=False)
+        singles.append(t2n(sc1).copy())
+        scores = torch.full((d.N, d.num_choices), float('nan'), device=eng.device)
+        valid = torch.zeros((d.N,), dtype=torch.int32, device=eng.device)
+        jobs.append((e, s2s['predicted_tokens'], feat, s2s['word_vecs'], scores, valid))
+    torch.cuda.synchronize()
+    eng.walk(jobs, d.N, d.T_decoder)
+    for k in range(3):
+        assert np.array_equal(t2n(jobs[k][4]), singles[k])
+        assert t2n(jobs[k][5]).all()
+
+
+def test_walker_on_the_reference_code_fixture(clevr_engine):
+    """the greedy case of tests/golden/float_golden.npz (numbers produced by the reference's own
+    code): decoder tokens -> walker, nothing fetched in between."""
+    eng, d0, asm, w = clevr_engine
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden',
+                             'float_golden.npz'))
+    d, batch = FC.clevr_inputs('greedy')
+    scores, tokens, validity = eng.forward(batch, T_dec=d.T_decoder, fetch=False)
+    assert np.array_equal(t2n(tokens), z['greedy/predicted_tokens'])
+    assert np.array_equal(t2n(validity).astype(bool), z['greedy/validity'])
+    assert_close('scores', t2n(scores), z['greedy/scores'], TOL)
