@@ -398,6 +398,13 @@ int n2nmn_debug_colsum(n2nmn_ctx *ctx, const float *src, int R, int ncols, int l
                        const int32_t *sel, int sel_val, float *dst, n2nmn_stream stream);
 
 /* C[M,N] = A[M,K] . B[K,N] + bias[N]   (row-major fp32; B is packed internally) */
+/* Mean HIP-event-pair time (us) around an EMPTY kernel on `stream`: the fixed cost every entry of the
+ * n2nmn_profile_* table carries on top of its kernel's duration. */
+int n2nmn_debug_event_overhead(n2nmn_ctx *ctx, int iters, double *us_pair, n2nmn_stream stream);
+/* Debugging: when timeline_dev != NULL every following walker launch of this context stamps the
+ * shader clock of thread 0 at the phase boundaries of each node into
+ * timeline_dev[question][32][4] (int64: start, after text map, after pooling + fc_att, end). */
+int n2nmn_debug_walk_timeline(n2nmn_ctx *ctx, long long *timeline_dev);
 int n2nmn_debug_gemm(n2nmn_ctx *ctx, const float *A, const float *B, const float *bias,
                      float *C, int M, int N, int K, n2nmn_stream stream);
 

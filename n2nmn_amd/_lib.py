@@ -119,6 +119,8 @@ SYMBOLS = [
     ('n2nmn_debug_lstm_bench', _I, [_P, _I, _I, _I, _I, _I, C.POINTER(C.c_double), _P]),
     ('n2nmn_debug_gemm_tn', _I, [_P, _P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P]),
     ('n2nmn_debug_colsum', _I, [_P, _P, _I, _I, _I, _P, _I, _P, _P]),
+    ('n2nmn_debug_event_overhead', _I, [_P, _I, C.POINTER(C.c_double), _P]),
+    ('n2nmn_debug_walk_timeline', _I, [_P, _P]),
     ('n2nmn_debug_gemm', _I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
 ]
 

@@ -208,6 +208,7 @@ static size_t carve_workspace(n2nmn_ctx* c, char* base) {
   c->dev_nodes = k.take<DevNode>(c->max_nodes);
   c->dev_tab = k.take<int32_t>(c->max_tab);
   c->walk_stats = k.take<unsigned long long>(WALK_STATS);
+  c->wtmap = k.take<float>(Td * N * Mp);
   return align_up(k.off, 256);
 }
 
@@ -1042,19 +1043,56 @@ int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int
                "walk_layouts: a batch's context does not share this context's weights");
     a.b[k].tokens = b.tokens; a.b[k].feat = b.image_feat; a.b[k].word_vecs = b.word_vecs;
     a.b[k].scores = b.scores; a.b[k].validity = b.validity;
-    a.b[k].mfind = owner->mfind; a.b[k].mfsp = owner->mfsp;
+    a.b[k].mfind = owner->mfind; a.b[k].mfsp = owner->mfsp; a.b[k].tmap = owner->wtmap;
   }
   a.K = K; a.N = N; a.T = T_dec; a.V = d.num_vocab_nmn; a.token_op = root(c)->token_op;
   a.H = d.H; a.W = d.W; a.D = d.D; a.M = d.map_dim; a.Mp = c->Mp; a.HWp = c->HWp;
   a.E = d.embed_dim_txt; a.C = d.num_choices; a.ksize = d.kernel_size;
   a.stats = c->prof_on ? c->walk_stats : nullptr;
+  a.timeline = c->walk_timeline;
   ModuleWeights w = module_weights(c);
   hipStream_t s = S(stream);
+  {
+    // text maps of all K batches: <= ceil(N/8) * 5 * T_dec * K workgroups, most exit after the scan
+    const double dE = d.embed_dim_txt, dM = d.map_dim;
+    ProfScope ps(c, F_TEXTMAP, 0.0, 4.0 * 5 * dE * dM, s);
+    launch_walk_textmap(w, a, s);
+  }
   {
     ProfScope ps(c, F_WALK, 0.0, 0.0, s);     // work filled in from the device counters
     launch_walk(w, a, s);
   }
   return check_launch("walk_layouts");
+}
+
+__global__ void n2nmn_empty_kernel() {}
+
+int n2nmn_debug_event_overhead(n2nmn_ctx* c, int iters, double* us_pair, n2nmn_stream stream) {
+  N2_REQUIRE(c && us_pair && iters >= 1 && iters <= 4096, N2NMN_EINVAL, "debug_event_overhead: bad argument");
+  hipStream_t s = S(stream);
+  std::vector<hipEvent_t> ev(2 * (size_t)iters);
+  for (auto& e : ev) N2_HIP(hipEventCreate(&e));
+  for (int i = 0; i < iters; ++i) {
+    N2_HIP(hipEventRecord(ev[2 * i], s));
+    hipLaunchKernelGGL(n2nmn_empty_kernel, dim3(1), dim3(64), 0, s);
+    N2_HIP(hipEventRecord(ev[2 * i + 1], s));
+  }
+  N2_HIP(hipStreamSynchronize(s));
+  double tot = 0;
+  for (int i = 0; i < iters; ++i) {
+    float ms = 0.f;
+    N2_HIP(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+    tot += ms;
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  *us_pair = 1e3 * tot / iters;
+  return N2NMN_OK;
+}
+
+int n2nmn_debug_walk_timeline(n2nmn_ctx* c, long long* timeline_dev) {
+  N2_REQUIRE(c, N2NMN_EINVAL, "debug_walk_timeline: null context");
+  c->walk_timeline = timeline_dev;
+  return N2NMN_OK;
 }
 
 int n2nmn_execute_tokens(n2nmn_ctx* c, const int32_t* tokens, int T_dec, int N,

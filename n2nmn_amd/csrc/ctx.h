@@ -168,6 +168,7 @@ struct n2nmn_ctx {
   const int32_t* enc_len = nullptr;
 
   // module workspace
+  float* wtmap = nullptr;                  // [T_dec][N][Mp] text maps of the walker path
   float *arena = nullptr, *tmap = nullptr, *pfc = nullptr, *mfind = nullptr, *mfsp = nullptr;
   float* ev_out = nullptr;
   int32_t* ev_rows = nullptr;
@@ -189,6 +190,7 @@ struct n2nmn_ctx {
   std::vector<ProfRec> prof_recs;
   double prof_ms[24] = {0}, prof_flops[24] = {0}, prof_bytes[24] = {0};
   long prof_launches[24] = {0};
+  long long* walk_timeline = nullptr;         // n2nmn_debug_walk_timeline (caller-owned)
   unsigned long long* walk_stats = nullptr;   // device [WALK_STATS]: node counts of profiled walks
 };
 

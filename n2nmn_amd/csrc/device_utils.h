@@ -7,20 +7,44 @@ namespace n2nmn {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Wave (64-lane) reductions on the DPP path: quad swaps, half-row / row mirrors, then the two
+// row broadcasts; the total lands in lane 63 and is broadcast with v_readlane.  Six VALU
+// instructions instead of six dependent ds_bpermute round trips through the LDS hardware
+// (__shfl_xor), which made a per-row reduction cost more than streaming the row.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float old, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL,
+                                                    ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float readlane63(float v) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
+  v += dpp_f<0xB1, 0xF>(0.f, v);     // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E, 0xF>(0.f, v);     // quad_perm [2,3,0,1]
+  v += dpp_f<0x141, 0xF>(0.f, v);    // row_half_mirror
+  v += dpp_f<0x140, 0xF>(0.f, v);    // row_mirror: every lane holds its 16-lane row's sum
+  v += dpp_f<0x142, 0xA>(0.f, v);    // row_bcast15 -> rows 1, 3
+  v += dpp_f<0x143, 0xC>(0.f, v);    // row_bcast31 -> rows 2, 3
+  return readlane63(v);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
-  return v;
+  v = fmaxf(v, dpp_f<0xB1, 0xF>(v, v));
+  v = fmaxf(v, dpp_f<0x4E, 0xF>(v, v));
+  v = fmaxf(v, dpp_f<0x141, 0xF>(v, v));
+  v = fmaxf(v, dpp_f<0x140, 0xF>(v, v));
+  v = fmaxf(v, dpp_f<0x142, 0xA>(v, v));
+  v = fmaxf(v, dpp_f<0x143, 0xC>(v, v));
+  return readlane63(v);
 }
 __device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m, 64));
-  return v;
+  v = fminf(v, dpp_f<0xB1, 0xF>(v, v));
+  v = fminf(v, dpp_f<0x4E, 0xF>(v, v));
+  v = fminf(v, dpp_f<0x141, 0xF>(v, v));
+  v = fminf(v, dpp_f<0x140, 0xF>(v, v));
+  v = fminf(v, dpp_f<0x142, 0xA>(v, v));
+  v = fminf(v, dpp_f<0x143, 0xC>(v, v));
+  return readlane63(v);
 }
 
 // Block-wide reductions through a caller-provided LDS scratch of >= 16 floats.

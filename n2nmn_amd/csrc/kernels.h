@@ -205,6 +205,7 @@ constexpr int WALK_THREADS = 512;
 constexpr int WALK_POOL_ROWS = 38;   // feature rows a thread keeps in flight (H*W / (512 / (D/4)))
 constexpr int WALK_MAX_T = 32;
 constexpr int WALK_MAX_BATCHES = 16;
+constexpr int WALK_MAX_PIXEL_GROUPS = 3;   // H*W <= 192 (64-pixel groups a Transform wave holds)
 struct WalkBatch {
   const int32_t* tokens;   // [T][N] layout tokens (decoder output or ground truth), device
   const float* feat;       // [N][HW][D]
@@ -214,6 +215,7 @@ struct WalkBatch {
   const float* mfind;      // [N][HW][Mp] conv_image maps, FindModule weights
   const float* mfsp;       // [N][HW][Mp] conv_image maps, FindSamePropertyModule weights (only the
                            // images whose layout has a _FindSameProperty token are filled in)
+  float* tmap;             // [T][N][Mp] text maps (walk_textmap_kernel fills the rows that are read)
 };
 struct WalkArgs {
   WalkBatch b[WALK_MAX_BATCHES];
@@ -223,9 +225,13 @@ struct WalkArgs {
   // profiling only: [0] Find-type nodes, [1] pooled inputs, [2] pooling nodes, [3] text maps,
   // [4] Transform nodes, [5] valid questions (atomic adds by thread 0 of each workgroup)
   unsigned long long* stats;
+  // debugging only: [question][WALK_MAX_T][4] shader-clock stamps of thread 0 per node
+  // (start, after text map, after pooling + fc_att, end)
+  long long* timeline;
 };
 constexpr int WALK_STATS = 8;
 int walk_supported(int H, int W, int D, int M, int Mp, int HWp, int E, int C, int T, int ksize);
+void launch_walk_textmap(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
 void launch_walk(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
 
 // out[n,h,w,:] = [feat[n,h,w,:D0], linspace(-1,1,W)[w], linspace(-1,1,H)[h], 0 ...]

@@ -135,7 +135,8 @@ __host__ __device__ inline size_t walk_lds_floats(int T, int HWp, int Mp, int E,
   const int ncol = D / 4, nrow = WT / ncol;
   size_t s0 = (size_t)WW * 256;
   size_t s1 = (size_t)nrow * 2 * D;
-  size_t s2 = (size_t)M * RS + (((size_t)(H + 2 * pad) * (W + 2 * pad) + 3) & ~3) + (size_t)WW * 64 * 2;
+  size_t s2 = (size_t)M * RS + (((size_t)(H + 2 * pad) * (W + 2 * pad) + 3) & ~3) +
+              (size_t)WW * WALK_MAX_PIXEL_GROUPS * 64 * 2;
   size_t s3 = (size_t)((2 * HW + 4 + 3) & ~3) + (size_t)WT;
   size_t s = s0 > s1 ? s0 : s1;
   s = s > s2 ? s : s2;
@@ -145,6 +146,12 @@ __host__ __device__ inline size_t walk_lds_floats(int T, int HWp, int Mp, int E,
 
 namespace {
 
+// Transform (nmn3_modules.py:185-216): KSxKS SAME convolution of the 1-channel attention map to M
+// channels, times the text map, l2-normalise over channels, dot with w_e.
+// Wave w owns channels w, w + 8, ...; lanes are pixels, and a wave keeps the KSxKS windows of ALL
+// its (up to PGMAX) 64-pixel groups in registers, so one broadcast read of a channel's taps from
+// LDS feeds PGMAX independent FMA chains (the first version split waves over pixel groups instead:
+// 3x the LDS tap traffic, one dependent chain per wave, two idle waves -- 45 us per node).
 template <int KS>
 __device__ __forceinline__ void walk_transform(int tid, const ModuleWeights& w, const WalkArgs& a,
                                                const float* in0, const float* tm, float* outp,
@@ -152,67 +159,208 @@ __device__ __forceinline__ void walk_transform(int tid, const ModuleWeights& w, 
   constexpr int KK = KS * KS;
   constexpr int RS = (KK + 2 + 3) & ~3;
   constexpr int PAD = KS / 2;
+  constexpr int PGMAX = WALK_MAX_PIXEL_GROUPS;
   const int H = a.H, W = a.W, HW = H * W, M = a.M;
   const int PW = W + 2 * PAD, PH = H + 2 * PAD;
-  float* Kl = scr;                              // [M][RS]
-  float* xin = Kl + (size_t)M * RS;             // [PH][PW]
-  float* red = xin + ((PH * PW + 3) & ~3);      // [WW][64][2]
+  float* Kl = scr;                              // [M][RS]: taps * tm[c], bias * tm[c], w_e[c]
+  float* xin = Kl + (size_t)M * RS;             // [PH][PW] zero-padded input map
+  float* red = xin + ((PH * PW + 3) & ~3);      // [WW][PGMAX][64][2]
   const int lane = tid & 63, wid = tid >> 6;
   for (int i = tid; i < PH * PW; i += WT) {
     const int y = i / PW - PAD, x = i % PW - PAD;
     xin[i] = (y >= 0 && y < H && x >= 0 && x < W) ? in0[y * W + x] : 0.f;
   }
-  for (int i = tid; i < KK * M; i += WT) {      // coalesced over c
-    const int tap = i / M, c = i - tap * M;
-    Kl[c * RS + tap] = w.Kt[i] * tm[c];
-  }
-  for (int c = tid; c < M; c += WT) {
-    Kl[c * RS + KK] = w.bt[c] * tm[c];
+  for (int c = tid; c < M; c += WT) {           // coalesced over c for every tap
+    const float t = tm[c];
+#pragma unroll
+    for (int tap = 0; tap < KK; ++tap) Kl[c * RS + tap] = w.Kt[tap * M + c] * t;
+    Kl[c * RS + KK] = w.bt[c] * t;
     Kl[c * RS + KK + 1] = w.we[2][c];
   }
   __syncthreads();
-  // waves = pixel groups (64 pixels) x channel groups
   const int PG = (HW + 63) / 64;
-  const int CG = WW / PG > 0 ? WW / PG : 1;
-  const float be = w.be[2][0];
-  for (int pg0 = 0; pg0 < PG; pg0 += WW / CG) {
-    const int pg = pg0 + wid / CG, cg = wid % CG;
-    const bool wave_on = wid < (WW / CG) * CG && pg < PG;
-    const int p = pg * 64 + lane;
-    const bool on = wave_on && p < HW;
-    float ss = 0.f, dot = 0.f;
-    if (wave_on) {
-      const int y = on ? p / W : 0, x = on ? p - (p / W) * W : 0;
-      float win[KK];
+  float win[PGMAX][KK];
 #pragma unroll
-      for (int dy = 0; dy < KS; ++dy)
+  for (int g = 0; g < PGMAX; ++g) {
+    const int p = min(g * 64 + lane, HW - 1);
+    const int y = p / W, x = p - y * W;
 #pragma unroll
-        for (int dx = 0; dx < KS; ++dx) win[dy * KS + dx] = xin[(y + dy) * PW + x + dx];
-      for (int c = cg; c < M; c += CG) {
-        const float4* kr = reinterpret_cast<const float4*>(Kl + (size_t)c * RS);
-        float k[RS];
+    for (int dy = 0; dy < KS; ++dy)
 #pragma unroll
-        for (int q = 0; q < RS / 4; ++q) {
-          const float4 t = kr[q];
-          k[4 * q] = t.x; k[4 * q + 1] = t.y; k[4 * q + 2] = t.z; k[4 * q + 3] = t.w;
-        }
-        float v = k[KK];
+      for (int dx = 0; dx < KS; ++dx) win[g][dy * KS + dx] = xin[(y + dy) * PW + x + dx];
+  }
+  float ss[PGMAX], dot[PGMAX];
 #pragma unroll
-        for (int tap = 0; tap < KK; ++tap) v += k[tap] * win[tap];
-        ss += v * v;
-        dot += v * k[KK + 1];
+  for (int g = 0; g < PGMAX; ++g) { ss[g] = 0.f; dot[g] = 0.f; }
+  // PGMAX pixel groups x 2 channels = 6 independent FMA chains per iteration, each split in two
+  // halves: a dependent v_fmac chain issues one FMA per ~8 cycles, so a single 27-deep chain per
+  // wave ran the VALU at a quarter of its rate.  Groups beyond PG recompute the last pixel (cheap,
+  // branch-free) and are ignored below.
+  const int cw = __builtin_amdgcn_readfirstlane(wid);    // wave-uniform: scalar loop control
+  for (int c = cw; c < M; c += 2 * WW) {
+    const int c2 = min(c + WW, M - 1);
+    const bool two = c + WW < M;
+    const float4* kr0 = reinterpret_cast<const float4*>(Kl + (size_t)c * RS);
+    const float4* kr1 = reinterpret_cast<const float4*>(Kl + (size_t)c2 * RS);
+    float k0[RS], k1[RS];
+#pragma unroll
+    for (int q = 0; q < RS / 4; ++q) {
+      const float4 t0 = kr0[q], t1 = kr1[q];
+      k0[4 * q] = t0.x; k0[4 * q + 1] = t0.y; k0[4 * q + 2] = t0.z; k0[4 * q + 3] = t0.w;
+      k1[4 * q] = t1.x; k1[4 * q + 1] = t1.y; k1[4 * q + 2] = t1.z; k1[4 * q + 3] = t1.w;
+    }
+    float va[PGMAX], vb[PGMAX], ua[PGMAX], ub[PGMAX];
+#pragma unroll
+    for (int g = 0; g < PGMAX; ++g) { va[g] = k0[KK]; vb[g] = 0.f; ua[g] = k1[KK]; ub[g] = 0.f; }
+#pragma unroll
+    for (int tap = 0; tap + 1 < KK; tap += 2) {
+#pragma unroll
+      for (int g = 0; g < PGMAX; ++g) {
+        va[g] += k0[tap] * win[g][tap];
+        vb[g] += k0[tap + 1] * win[g][tap + 1];
+        ua[g] += k1[tap] * win[g][tap];
+        ub[g] += k1[tap + 1] * win[g][tap + 1];
       }
     }
-    red[(wid * 64 + lane) * 2] = ss;
-    red[(wid * 64 + lane) * 2 + 1] = dot;
-    __syncthreads();
-    if (wave_on && cg == 0 && on) {
-      float s2 = 0.f, d2 = 0.f;
-      for (int q = 0; q < CG; ++q) {
-        s2 += red[((wid + q) * 64 + lane) * 2];
-        d2 += red[((wid + q) * 64 + lane) * 2 + 1];
+    if (KK & 1) {
+#pragma unroll
+      for (int g = 0; g < PGMAX; ++g) {
+        va[g] += k0[KK - 1] * win[g][KK - 1];
+        ua[g] += k1[KK - 1] * win[g][KK - 1];
       }
-      outp[p] = d2 / sqrtf(fmaxf(s2, 1e-12f)) + be;
+    }
+    const float m1 = two ? 1.f : 0.f;
+#pragma unroll
+    for (int g = 0; g < PGMAX; ++g) {
+      const float v = va[g] + vb[g], u = (ua[g] + ub[g]) * m1;
+      ss[g] += v * v + u * u;
+      dot[g] += v * k0[KK + 1] + u * k1[KK + 1];
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < PGMAX; ++g) {
+    red[((wid * PGMAX + g) * 64 + lane) * 2] = ss[g];
+    red[((wid * PGMAX + g) * 64 + lane) * 2 + 1] = dot[g];
+  }
+  __syncthreads();
+  const float be = w.be[2][0];
+  for (int p = tid; p < HW; p += WT) {
+    const int g = p >> 6, l = p & 63;
+    float s2 = 0.f, d2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < WW; ++q) {
+      s2 += red[((q * PGMAX + g) * 64 + l) * 2];
+      d2 += red[((q * PGMAX + g) * 64 + l) * 2 + 1];
+    }
+    outp[p] = d2 / sqrtf(fmaxf(s2, 1e-12f)) + be;
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Text maps of every (step, question) that has a text parameter, hoisted out of the walker:
+//   tmap[t, n, :] = word_vecs[t, n, :] . W_txt[ws] + b_txt[ws]     (nmn3_modules.py:53-57,101,161,
+//   209,424,479), ws chosen by the token at (t, n).
+// One workgroup = up to 8 nodes of ONE weight set at ONE step, so the [E, M] weight stream (300 KB)
+// is read once per 8 nodes and the streams of a batch spread over the chip instead of sitting on
+// each question's critical path (5.6 us per text node inside the walker).  Table-free: workgroup
+// (g, ws, t) scans the step's tokens, ranks the questions whose operator uses weight set ws, and
+// takes ranks [8g, 8g + 8); workgroups without work exit.
+// ---------------------------------------------------------------------------------------------
+constexpr int TMG = 8;
+__device__ __forceinline__ int text_ws_of(int op) {
+  switch (op) {
+    case N2NMN_OP_FIND: case N2NMN_OP_FILTER: return 0;
+    case N2NMN_OP_FIND_SAME_PROPERTY: return 1;
+    case N2NMN_OP_TRANSFORM: return 2;
+    case N2NMN_OP_SAME_PROPERTY: return 3;
+    case N2NMN_OP_DESCRIBE: return 4;
+    default: return -1;
+  }
+}
+
+__global__ __launch_bounds__(WT) void walk_textmap_kernel(ModuleWeights w, WalkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ int wcount[WW];
+  __shared__ int sel[TMG];
+  const int g = blockIdx.x, ws = blockIdx.y;
+  const int t = blockIdx.z % a.T, kb = blockIdx.z / a.T;
+  const WalkBatch& B = a.b[kb];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int N = a.N, E = a.E, Mp = a.Mp;
+  // ---- rank the questions of this step whose operator reads weight set ws
+  int base = 0, total = 0;
+  for (int n0 = 0; n0 < N; n0 += WT) {
+    const int n = n0 + tid;
+    bool hit = false;
+    if (n < N) {
+      const int tok = B.tokens[(size_t)t * N + n];
+      hit = tok >= 0 && tok < a.V && text_ws_of(a.token_op[tok]) == ws;
+    }
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) wcount[wid] = __builtin_popcountll(m);
+    __syncthreads();
+    int before = base;
+    for (int q = 0; q < wid; ++q) before += wcount[q];
+    int all = 0;
+    for (int q = 0; q < WW; ++q) all += wcount[q];
+    const int rank = before + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+    if (hit && rank >= TMG * g && rank < TMG * g + TMG) sel[rank - TMG * g] = n;
+    base += all;
+    __syncthreads();
+  }
+  total = base;
+  const int cnt = min(TMG, total - TMG * g);
+  if (cnt <= 0) return;
+  float* wvl = smem;                         // [TMG][E]
+  float* part = wvl + TMG * ((E + 3) & ~3);  // [WW][TMG][256]
+  const int Ep = (E + 3) & ~3;
+  for (int gi = wid; gi < TMG; gi += WW) {
+    const float* src = gi < cnt ? B.word_vecs + ((size_t)t * N + sel[gi]) * E : nullptr;
+    for (int e = lane; e < E; e += 64) wvl[gi * Ep + e] = src ? src[e] : 0.f;
+  }
+  __syncthreads();
+  const float* Wp = w.Wtxt[ws];
+  const float* bm = w.btxt[ws];
+  const int kper = (E + WW - 1) / WW;
+  const int k0 = wid * kper, k1 = min(E, k0 + kper);
+  constexpr int KU = 19;
+  for (int cb = 0; cb < Mp; cb += 256) {
+    float4 acc[TMG];
+#pragma unroll
+    for (int gi = 0; gi < TMG; ++gi) acc[gi] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned col = (unsigned)min(cb + 4 * lane, Mp - 4);
+    for (int kq = k0; kq < k1; kq += KU) {
+      float4 w4[KU];
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        const unsigned k = (unsigned)min(kq + u, k1 - 1);
+        w4[u] = *reinterpret_cast<const float4*>(Wp + (k * (unsigned)Mp + col));
+      }
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        if (kq + u < k1) {
+#pragma unroll
+          for (int gi = 0; gi < TMG; ++gi) {
+            const float x = wvl[gi * Ep + kq + u];
+            acc[gi].x += x * w4[u].x; acc[gi].y += x * w4[u].y; acc[gi].z += x * w4[u].z;
+            acc[gi].w += x * w4[u].w;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int gi = 0; gi < TMG; ++gi)
+      *reinterpret_cast<float4*>(part + ((size_t)(wid * TMG + gi) * 256) + 4 * lane) = acc[gi];
+    __syncthreads();
+    for (int i = tid; i < TMG * 256; i += WT) {
+      const int gi = i >> 8, c = i & 255;
+      if (gi < cnt && cb + c < Mp) {
+        float r = bm[cb + c];
+#pragma unroll
+        for (int q = 0; q < WW; ++q) r += part[(size_t)(q * TMG + gi) * 256 + c];
+        B.tmap[((size_t)t * N + sel[gi]) * Mp + cb + c] = r;
+      }
     }
     __syncthreads();
   }
@@ -321,6 +469,8 @@ __global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
     const int lane = tid & 63, wid = tid >> 6;
     const int lc = tid % ncol, lr = tid / ncol;
     const int op = L.op[t] & 0xff;
+    long long* tl = a.timeline ? a.timeline + ((size_t)q * MAXT + t) * 4 : nullptr;
+    if (tl && tid0 == 0) tl[0] = clock64();
     const float* in0 = L.in0[t] >= 0 ? arena + (size_t)L.in0[t] * HWp : nullptr;
     const float* in1 = L.in1[t] >= 0 ? arena + (size_t)L.in1[t] * HWp : nullptr;
     float* outp = arena + (size_t)t * HWp;
@@ -328,23 +478,15 @@ __global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
     const bool pools = op == N2NMN_OP_FIND_SAME_PROPERTY || op == N2NMN_OP_SAME_PROPERTY ||
                        op == N2NMN_OP_DESCRIBE;
 
-    // text parameter -> text map (fc_text / text_fc): nmn3_modules.py:53-57,101,161,209,424,479
-    int ws = -1;
-    switch (op) {
-      case N2NMN_OP_FIND: case N2NMN_OP_FILTER: ws = 0; break;
-      case N2NMN_OP_FIND_SAME_PROPERTY: ws = 1; break;
-      case N2NMN_OP_TRANSFORM: ws = 2; break;
-      case N2NMN_OP_SAME_PROPERTY: ws = 3; break;
-      case N2NMN_OP_DESCRIBE: ws = 4; break;
-      default: break;
+    // text map of this node, computed by walk_textmap_kernel: one 4*Mp-byte row
+    const bool has_text = op == N2NMN_OP_FIND || op == N2NMN_OP_FILTER || pools ||
+                          op == N2NMN_OP_TRANSFORM;
+    if (has_text) {
+      const float* src = B.tmap + ((size_t)t * a.N + n) * Mp;
+      for (int c = 4 * tid; c < Mp; c += 4 * WT)
+        *reinterpret_cast<float4*>(tml + c) = *reinterpret_cast<const float4*>(src + c);
     }
-    if (ws >= 0) {
-      const float* src = B.word_vecs + ((size_t)t * a.N + n) * E;
-      for (int e = tid; e < E; e += WT) wv[e] = src[e];
-      __syncthreads();
-      fc_pad<38>(tid, wv, E, w.Wtxt[ws], w.btxt[ws], Mp, tml, scr, nullptr);
-    }
-
+    if (tl && tid0 == 0) tl[1] = clock64();
     if (pools) {
       // the feature rows of this thread do not depend on the softmax: all of its 16-B loads go out
       // first (the whole [HW, D] map of the question is in flight at once) and land while the
@@ -409,6 +551,8 @@ __global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
       if (nin == 2) fc_pad<32>(tid, pooled + D, D, w.Watt[2], w.batt[2], Mp, am1, scr, nullptr);
     }
 
+    __syncthreads();
+    if (tl && tid0 == 0) tl[2] = clock64();
     switch (op) {
       case N2NMN_OP_SCENE:                                       // :60-72
         for (int r = tid; r < HW; r += WT) outp[r] = 3.0f;
@@ -542,6 +686,7 @@ __global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
       }
     }
     __syncthreads();
+    if (tl && tid0 == 0) tl[3] = clock64();
   }
 }
 
@@ -555,9 +700,19 @@ int walk_supported(int H, int W, int D, int M, int Mp, int HWp, int E, int C, in
   if (Mp > 256 * MAXCI || Mp % 4 != 0 || C > WT || T > MAXT) return 0;
   if (ksize != 3 && ksize != 5) return 0;
   const int PG = (HW + 63) / 64;
-  if (PG > WW) return 0;
+  if (PG > WALK_MAX_PIXEL_GROUPS) return 0;
   const size_t bytes = sizeof(float) * walk_lds_floats(T, HWp, Mp, E, D, M, ksize, H, W, C);
   return bytes <= 150 * 1024;
+}
+
+void launch_walk_textmap(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) {
+  const int Ep = (a.E + 3) & ~3;
+  const size_t smem = sizeof(float) * ((size_t)TMG * Ep + (size_t)WW * TMG * 256);
+  if (smem > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(walk_textmap_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(walk_textmap_kernel, dim3((a.N + TMG - 1) / TMG, 5, a.T * a.K), dim3(WT), smem,
+                     s, w, a);
 }
 
 void launch_walk(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) {

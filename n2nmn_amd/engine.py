@@ -6,6 +6,7 @@ HIP stream and D2H copies.  All arithmetic runs in libn2nmn_hip.so; there is no 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -36,6 +37,12 @@ class Engine:
         self._bufs: Dict[tuple, object] = {}
         self._ring = [None] * 4       # pinned staging slots for per-step host inputs (upload_i32)
         self._ring_i = 0
+        self._side = None             # side stream + event for the hoisted conv_image GEMMs
+        self._side_ev = None
+        # N2NMN_OVERLAP_CONV=1: hoisted conv_image GEMMs on a side stream beside phase 1.  Off by
+        # default: measured on MI355X the chip-filling recurrent steps slow down by more than the
+        # GEMMs take (0.882 ms per batch overlapped vs 0.812 ms in line, profiles/r02_notes.md)
+        self.overlap_conv = os.environ.get('N2NMN_OVERLAP_CONV', '0') == '1'
         self._parent = _parent
         if _parent is not None:
             _lib.check(self._lib.n2nmn_ctx_fork(_parent._ctx, C.byref(self._ctx)))
@@ -283,6 +290,12 @@ class Engine:
     def profile_begin(self):
         _lib.check(self._lib.n2nmn_profile_begin(self._ctx))
 
+    def event_overhead_us(self, iters: int = 200) -> float:
+        """fixed cost of one profiler entry (event pair around an empty kernel), microseconds"""
+        us = C.c_double()
+        _lib.check(self._lib.n2nmn_debug_event_overhead(self._ctx, iters, C.byref(us), self.stream()))
+        return us.value
+
     def profile_end(self):
         """-> list of dicts {name, launches, total_ms, flops, bytes} per kernel family."""
         _lib.check(self._lib.n2nmn_profile_end(self._ctx, self.stream()))
@@ -326,12 +339,33 @@ class Engine:
         by construction (models_clevr/nmn3_netgen_att.py:236-238), so the program is assembled
         from the host copy up front and the step has no host synchronisation at all."""
         if self.walk_supported() and not host_assemble:
-            # device path: the walker decodes the layouts itself (no sync between the phases)
-            gt_dev = self.upload_i32(gt_layout) if isinstance(gt_layout, np.ndarray) else gt_layout
+            # device path: the walker decodes the layouts itself (no sync between the phases).  The
+            # hoisted conv_image GEMMs need only the features, so they run on a side stream beside
+            # the (latency-bound) recurrent chain of phase 1
+            torch = _torch()
+            gt_dev = self.upload_i32(gt_layout) if isinstance(gt_layout, np.ndarray) else \
+                self._dev(gt_layout, torch.int32)
+            feat = self._dev(batch['image_feat_batch'], torch.float32)
+            cur = torch.cuda.current_stream(self.device)
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+                self._side_ev = torch.cuda.Event()
+            known = use_gt_layout and gt_dev is not None     # layouts known before phase 1
+            if self.overlap_conv:
+                self._side.wait_stream(cur)
+                with torch.cuda.stream(self._side):
+                    self.conv_image(feat, gt_dev if known else None, T_dec, find=True, fsp=known)
+                    self._side_ev.record(self._side)
             s2s = self.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], T_dec,
                                use_gt_layout, gt_dev, sample_uniforms)
-            scores, validity = self.execute_tokens(s2s['predicted_tokens'],
-                                                   batch['image_feat_batch'], s2s['word_vecs'])
+            if not self.overlap_conv:
+                self.conv_image(feat, s2s['predicted_tokens'], find=True, fsp=True)
+            elif not known:
+                self.conv_image(feat, s2s['predicted_tokens'], find=False, fsp=True)
+            if self.overlap_conv:
+                cur.wait_event(self._side_ev)
+            scores, validity = self.execute_tokens(s2s['predicted_tokens'], feat, s2s['word_vecs'],
+                                                   conv_done=True)
             if not fetch:
                 return scores, s2s['predicted_tokens'], validity
             return scores, s2s['predicted_tokens'].cpu().numpy(), validity.cpu().numpy().astype(bool)
