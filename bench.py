@@ -12,8 +12,11 @@ which decodes the layouts on the device and runs every question's module tree ->
 HBM.  Nothing synchronises inside a step (no token fetch, no host assembly, no program upload).
 
 Throughput number (`value`): `--inflight K` batches of 64 are super-bucketed (n2nmn_amd/superbucket.py,
-SURVEY.md 8(f) rank 2): their questions share every launch of both phases, on ONE stream.  K steps
-are one pass; `--steps` counts batches of 64, so exactly `--steps` batches are timed.
+SURVEY.md 8(f) rank 2): their questions share every launch of both phases; `--streams S` such passes
+are in flight (pre-spawned host threads, one HIP stream and forked context each, shared weights).
+`--steps` counts batches of 64: exactly `--steps` batches are timed, split evenly over the streams.
+Measured (profiles/r02_stream_sweep.txt): 1 x 4 batches 131 k q/s, 2 x 4 181 k, 3 x 4 190 k, 4 x 4
+191 k, the same with the default hardware-queue count and with GPU_MAX_HW_QUEUES=8.
 Latency number (`single_batch`): one batch of 64 in flight, same code path.
 `config3`: the same with layouts chosen by the greedy decoder (BASELINE.json configs[2]).
 
@@ -55,6 +58,9 @@ def parse():
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--inflight', type=int, default=4,
                     help='batches of --batch questions super-bucketed into one pass (1..16)')
+    ap.add_argument('--streams', type=int, default=3,
+                    help='independent super-buckets in flight per GPU (one pre-spawned host thread + '
+                         'HIP stream + forked context each; weights shared)')
     ap.add_argument('--host-assemble', action='store_true',
                     help='reference flow: token fetch + C++ Assembler + level scheduler instead of '
                          'the on-device layout walker')
@@ -398,6 +404,7 @@ def main():
     from n2nmn_amd.superbucket import SuperBucket
 
     K = max(1, min(16, args.inflight))
+    S = max(1, args.streams)
     d = Dims(N=args.batch)
     names = list(CLEVR_MODULE_NAMES)
     asm = Assembler(names)
@@ -407,41 +414,83 @@ def main():
     sb.load_weights(w)
     dev = eng.device
     use_gt = args.config == 2
-    # every rank streams its own questions (weak scaling).  Two buckets are alternated so a pass does
-    # not find its feature maps in the caches the previous pass left; each holds K distinct batches
-    buckets = [sb, SuperBucket(d, asm, K, device=local_rank, engine=eng)]
-    host_gt = []
-    for j, b in enumerate(buckets):
-        for k in range(K):
-            i = j * K + k
-            b.fill(k, synth.make_inputs(d, seed=dp.batch_seed(i)),
-                   synth.template_layout_batch(d, offset=i))
-            if j == 0:
-                host_gt.append(synth.template_layout_batch(d, offset=i))
+    # every rank streams its own questions (weak scaling).  A worker = one host thread + HIP stream +
+    # forked context (shared weights) + two buckets of K distinct batches, alternated so a pass does
+    # not find its feature maps in the caches the previous pass left
+    import threading
+    engines = [eng] + [eng.fork() for _ in range(S - 1)]
+    workers = []
+    for si, e in enumerate(engines):
+        e.set_mode('throughput' if S > 1 else 'latency')
+        bk = [sb if si == 0 else SuperBucket(d, asm, K, device=local_rank, engine=e),
+              SuperBucket(d, asm, K, device=local_rank, engine=e)]
+        for j, b in enumerate(bk):
+            for k in range(K):
+                i = (si * 2 + j) * K + k
+                b.fill(k, synth.make_inputs(d, seed=dp.batch_seed(i)),
+                       synth.template_layout_batch(d, offset=i))
+        workers.append(dict(engine=e, buckets=bk, stream=torch.cuda.Stream(device=dev) if S > 1 else None,
+                            todo=0))
+    buckets = workers[0]['buckets']
     torch.cuda.synchronize(dev)
 
-    def run_batches(count, gt=use_gt, first=0):
-        """`count` batches of d.N questions: full passes of K slots, then one partial pass"""
-        done, j = 0, first
+    def run_on(wk, count, gt):
+        """`count` batches of d.N questions on one worker: full passes of K slots, then a partial one"""
+        done, j = 0, 0
         while done < count:
             n = min(K, count - done)
-            b = buckets[j % 2]
+            b = wk['buckets'][j % 2]
             if n == K:
                 b.run(use_gt_layout=gt)
             else:                              # remainder: the first n slots only
                 v = dict(input_seq_batch=b.input_seq[:, :n * d.N].contiguous(),
                          seq_length_batch=b.seq_length[:n * d.N],
                          image_feat_batch=b.image_feat[:n * d.N])
-                eng.forward(v, use_gt_layout=gt,
-                            gt_layout=b.gt_layout[:, :n * d.N].contiguous() if gt else None,
-                            fetch=False, host_assemble=args.host_assemble)
+                wk['engine'].forward(v, use_gt_layout=gt,
+                                     gt_layout=b.gt_layout[:, :n * d.N].contiguous() if gt else None,
+                                     fetch=False, host_assemble=args.host_assemble)
             done += n
             j += 1
 
-    sync = lambda: torch.cuda.synchronize(dev)    # noqa: E731
-    run_batches(max(args.warmup, K))
-    elapsed, repeats, blocks = timed_blocks(dp, lambda: run_batches(args.steps), sync)
+    # worker threads exist before anything is timed; a timed block only releases them and waits
+    start_b, done_b = threading.Barrier(S + 1), threading.Barrier(S + 1)
+    state = {'stop': False, 'gt': use_gt, 'err': None}
 
+    def worker_main(wk):
+        torch.cuda.set_device(dev)
+        while True:
+            start_b.wait()
+            if state['stop']:
+                return
+            try:
+                with torch.cuda.stream(wk['stream']):
+                    run_on(wk, wk['todo'], state['gt'])
+                    wk['stream'].synchronize()
+            except Exception as ex:           # surface worker failures instead of hanging
+                state['err'] = ex
+            done_b.wait()
+
+    threads = []
+    if S > 1:
+        threads = [threading.Thread(target=worker_main, args=(wk,), daemon=True) for wk in workers]
+        for t in threads:
+            t.start()
+
+    def run_batches(count, gt=use_gt):
+        """exactly `count` batches, split as evenly as possible over the S workers"""
+        if S == 1:
+            return run_on(workers[0], count, gt)
+        for i, wk in enumerate(workers):
+            wk['todo'] = count // S + (1 if i < count % S else 0)
+        state['gt'] = gt
+        start_b.wait()
+        done_b.wait()
+        if state['err'] is not None:
+            raise state['err']
+
+    sync = lambda: torch.cuda.synchronize(dev)    # noqa: E731
+    run_batches(max(args.warmup, S * K))
+    elapsed, repeats, blocks = timed_blocks(dp, lambda: run_batches(args.steps), sync)
     out = None
     if rank == 0:
         qps = dp.throughput(d.N * args.steps, elapsed)
@@ -456,13 +505,14 @@ def main():
             'blocks_s': [round(x, 5) for x in blocks],
             'config': {'workload': 'BASELINE.json configs[%d]: CLEVR forward, %s, batches of %d '
                                    'questions, 10x15x512 synthetic pool5, T_enc=45, T_dec=20; one step '
-                                   '= one batch; %d batches in flight are super-bucketed into one pass '
-                                   '(their questions share every launch), one stream' %
+                                   '= one batch; %d batches are super-bucketed into one pass (their '
+                                   'questions share every launch); %d such passes in flight on %d '
+                                   'streams' %
                                    (args.config - 1,
                                     'fixed ground-truth layouts (10-template mix, teacher-forced '
                                     'decoder)' if use_gt else 'layouts chosen by the greedy seq2seq '
-                                    'decoder', d.N, K),
-                       'global_batch': world * d.N, 'inflight_batches': K,
+                                    'decoder', d.N, K, S, S),
+                       'global_batch': world * d.N, 'inflight_batches': K * S, 'streams_per_gpu': S,
                        'questions_per_pass_per_gpu': K * d.N,
                        'parallelism': 'dp%d (question-sharded, no data-path collective)' % world,
                        'host_sync': 'none: layouts are decoded on the device by the walker'
@@ -493,23 +543,28 @@ def main():
         def one_greedy():
             eng.forward(one, fetch=False, host_assemble=args.host_assemble)
 
+        eng.set_mode('latency')
         t_one = wall(one_gt if use_gt else one_greedy, n1)
         out['single_batch'] = {'value': round(d.N / t_one, 1), 'unit': 'questions/sec',
                                'ms_per_step': round(1e3 * t_one, 4), 'steps': n1,
                                'note': 'one batch of %d questions in flight' % d.N}
+        if not use_gt:
+            eng.set_mode('throughput' if S > 1 else 'latency')
         # ---- BASELINE.json configs[2]: the decoder chooses the layouts (greedy), walker decodes them
         if use_gt:
             t3 = wall(one_greedy, n1)
-            passes = max(3, min(25, args.steps // K))
-            t3k = wall(lambda: sb.run(use_gt_layout=False), passes)
+            eng.set_mode('throughput' if S > 1 else 'latency')
+            reps = max(3, min(15, args.steps // (S * K)))
+            t3k = wall(lambda: run_batches(S * K, gt=False), reps)
             toks3 = sb.tokens.cpu().numpy()
             f3, p3, _ = layout_work(toks3, names)
             out['config3'] = {
                 'workload': 'BASELINE.json configs[2]: greedy attentional decoder (4 launches per '
                             'decoder step) chooses the layouts, no token fetch',
                 'single_batch': {'value': round(d.N / t3, 1), 'ms_per_step': round(1e3 * t3, 4)},
-                'super_bucket': {'value': round(K * d.N / t3k, 1), 'ms_per_step': round(1e3 * t3k / K, 4),
-                                 'inflight_batches': K},
+                'super_bucket': {'value': round(S * K * d.N / t3k, 1),
+                                 'ms_per_step': round(1e3 * t3k / (S * K), 4),
+                                 'inflight_batches': S * K, 'streams_per_gpu': S},
                 'unit': 'questions/sec',
                 'layouts': {'valid_fraction': float(sb.validity.float().mean().item()),
                             'find_type_nodes_per_question': round(f3 / toks3.shape[1], 2),
@@ -572,6 +627,9 @@ def main():
             return sc.cpu().numpy()
         out['cpu_baseline'] = cpu_baseline(d, w, names, use_gt, gpu_scores)
 
+    if S > 1:
+        state['stop'] = True
+        start_b.wait()
     if rank == 0:
         print(json.dumps(out), flush=True)
     dp.close()
