@@ -149,7 +149,11 @@ typedef struct {
   float *encoder_h_transformed;    /* [T_enc, N, lstm_dim]                                  */
   float *encoder_states;           /* [2 layers][c,h][N, lstm_dim]                          */
   float *log_seq_prob;             /* [N] sum_t log token_probs (models_clevr/nmn3_model.py:46) */
+  int32_t flags;                   /* N2NMN_S2S_* */
 } n2nmn_seq2seq_io;
+/* skip word_vecs / neg_entropy / log_seq_prob (one launch): for inference through
+ * n2nmn_walk_layouts with attention maps, which derives the text maps from atts directly */
+#define N2NMN_S2S_NO_WORD_VECS 1
 
 int n2nmn_encoder_forward(n2nmn_ctx *ctx, const n2nmn_seq2seq_io *io, n2nmn_stream stream);
 /* decoder uses the encoder results held in the context by the preceding encoder call */
@@ -245,15 +249,24 @@ typedef struct {
                                    maps (n2nmn_conv_image was called on it); NULL = the calling one */
   const int32_t *tokens;        /* [T_dec, N] layout tokens (predicted_tokens or gt_layout), device */
   const float *image_feat;      /* [N, H, W, D]                                               */
-  const float *word_vecs;       /* [T_dec, N, E]                                              */
+  const float *word_vecs;       /* [T_dec, N, E], or NULL when atts is given                  */
   float *scores;                /* [N, num_choices] out                                       */
   int32_t *validity;            /* [N] out: 1 / 0 like expr_validity_array, or NULL          */
+  /* Optional (all batches or none): the decoder's attention maps instead of word_vecs.  A text
+   * parameter is word_vecs[t, n] = sum_tau atts[t, tau, n] * embedding_mat[input_seq[tau, n]]
+   * (nmn3_netgen_att.py:312) and every use of it is fc_text(word_vec) (nmn3_modules.py:101,161,209,
+   * 424,479), so the walker evaluates  b + sum_tau atts * (embedding_mat . W_txt)[input_seq]  from
+   * a [num_vocab_txt, map_dim] table per weight set built at commit time: no word_vecs launch and
+   * no text-map launch.  Needs num_vocab_txt <= 4096. */
+  const float *atts;            /* [T_dec, T_enc, N]                                          */
+  const int32_t *input_seq;     /* [T_enc, N]                                                 */
+  const int32_t *seq_length;    /* [N]                                                        */
 } n2nmn_walk_batch;
 /* One launch for the questions of K in-flight batches ("super-bucket", 1 <= K <= 16; every batch
  * has N questions and T_dec steps).  The caller orders `stream` after each batch's phase 1 and
  * n2nmn_conv_image (events). */
-int n2nmn_walk_layouts(n2nmn_ctx *ctx, const n2nmn_walk_batch *batches, int K, int T_dec, int N,
-                       n2nmn_stream stream);
+int n2nmn_walk_layouts(n2nmn_ctx *ctx, const n2nmn_walk_batch *batches, int K, int T_dec,
+                       int T_enc /* only with atts */, int N, n2nmn_stream stream);
 /* single batch: n2nmn_conv_image(FIND | FSP gated by tokens) + n2nmn_walk_layouts(K = 1) */
 int n2nmn_execute_tokens(n2nmn_ctx *ctx, const int32_t *tokens, int T_dec, int N,
                          const float *image_feat, const float *word_vecs, float *scores,

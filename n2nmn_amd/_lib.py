@@ -30,7 +30,7 @@ class Seq2SeqIO(C.Structure):
         ('predicted_tokens', C.c_void_p), ('token_probs', C.c_void_p), ('neg_entropy', C.c_void_p),
         ('atts', C.c_void_p), ('word_vecs', C.c_void_p), ('token_scores', C.c_void_p),
         ('encoder_outputs', C.c_void_p), ('encoder_h_transformed', C.c_void_p),
-        ('encoder_states', C.c_void_p), ('log_seq_prob', C.c_void_p)]
+        ('encoder_states', C.c_void_p), ('log_seq_prob', C.c_void_p), ('flags', C.c_int32)]
 
 
 class TrainIO(C.Structure):
@@ -53,7 +53,8 @@ class Node(C.Structure):
 class WalkBatch(C.Structure):
     """n2nmn_walk_batch (include/n2nmn.h section 4b)"""
     _fields_ = [('ctx', C.c_void_p), ('tokens', C.c_void_p), ('image_feat', C.c_void_p),
-                ('word_vecs', C.c_void_p), ('scores', C.c_void_p), ('validity', C.c_void_p)]
+                ('word_vecs', C.c_void_p), ('scores', C.c_void_p), ('validity', C.c_void_p),
+                ('atts', C.c_void_p), ('input_seq', C.c_void_p), ('seq_length', C.c_void_p)]
 
 
 ERRORS = {-1: 'N2NMN_EINVAL', -2: 'N2NMN_EHIP', -3: 'N2NMN_ENOWEIGHT', -4: 'N2NMN_ECAPACITY',
@@ -95,7 +96,7 @@ SYMBOLS = [
     ('n2nmn_set_token_ops', _I, [_P, _P, _I]),
     ('n2nmn_walk_supported', _I, [_P]),
     ('n2nmn_conv_image', _I, [_P, _P, _I, _I, _P, _I, _P]),
-    ('n2nmn_walk_layouts', _I, [_P, C.POINTER(WalkBatch), _I, _I, _I, _P]),
+    ('n2nmn_walk_layouts', _I, [_P, C.POINTER(WalkBatch), _I, _I, _I, _I, _P]),
     ('n2nmn_execute_tokens', _I, [_P, _P, _I, _I, _P, _P, _P, _P, _P]),
     ('n2nmn_add_coords', _I, [_P, _P, _I, _I, _P, _P]),
     ('n2nmn_question_prior_add', _I, [_P, _I, _P, _P]),

@@ -148,6 +148,11 @@ static size_t carve_weights(n2nmn_ctx* c, char* base) {
   }
   for (int i = 0; i < 5; ++i) c->wtxt_pad[i] = k.take<float>(E * Mp);
   for (int i = 0; i < 5; ++i) c->btxt_pad[i] = k.take<float>(Mp);
+  if (d.variant == N2NMN_VARIANT_CLEVR && d.num_vocab_txt <= 4096)
+    for (int i = 0; i < 5; ++i) {
+      c->wtxt_pk[i] = k.take<float>((size_t)c->KpE * Mp);
+      c->ew[i] = k.take<float>((size_t)d.num_vocab_txt * Mp);
+    }
   for (int i = 0; i < 4; ++i) c->watt_pad[i] = k.take<float>(D * Mp);
   for (int i = 0; i < 3; ++i) c->we_pad[i] = k.take<float>(Mp);
   for (int i = 0; i < 4; ++i) c->batt_pad[i] = k.take<float>(Mp);
@@ -473,7 +478,7 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s) {
       }
     }
   }
-  {
+  if (!(io->flags & N2NMN_S2S_NO_WORD_VECS)) {
     const double E = d.embed_dim_txt;
     ProfScope ps(c, F_WORD_VECS, 2.0 * Td * T * N * E, 4.0 * N * (T * E + Td * T + Td * E), s);
     launch_word_vecs(atts, c->enc_seq, c->vars[V_ENC_EMB].mirror, Td, T, N, d.embed_dim_txt, wv,
@@ -867,6 +872,7 @@ int n2nmn_commit_weights(n2nmn_ctx* c, n2nmn_stream stream) {
       if (!has(txs[i])) continue;
       pb.pad(m(txs[i]), E, M, c->wtxt_pad[i], Mp);
       pb.pad(m(txs[i] + 1), 1, M, c->btxt_pad[i], Mp);
+      if (c->wtxt_pk[i]) pb.pk(m(txs[i]), M, E, M, c->wtxt_pk[i], c->KpE, Mp);
     }
     const int ats[4] = {V_FSP_ATT_W, V_SP_ATT0_W, V_SP_ATT1_W, V_DE_ATT_W};
     for (int i = 0; i < 4; ++i)
@@ -898,6 +904,14 @@ int n2nmn_commit_weights(n2nmn_ctx* c, n2nmn_stream stream) {
   launch_gemm_pk(g, s);
   g.A = c->dec_emb_cat; g.M = V + 1; g.Bp = c->dec_W0x_p; g.bias = m(V_DEC_B0); g.C = c->dec_xtab;
   launch_gemm_pk(g, s);
+  for (int i = 0; i < 5; ++i) {        // ew[ws] = embedding_mat . W_txt[ws]  (walker text maps)
+    if (!c->ew[i]) continue;
+    GemmArgs t{};
+    t.A = m(V_ENC_EMB); t.lda = E; t.M = d.num_vocab_txt; t.K = E; t.group_size = 1;
+    t.Bp = c->wtxt_pk[i]; t.Np = c->Mp; t.Kp = c->KpE; t.bias = nullptr; t.N = d.map_dim;
+    t.C = c->ew[i]; t.ldc = c->Mp; t.n_store = c->Mp;
+    launch_gemm_pk(t, s);
+  }
   c->committed = true;
   c->commit_epoch++;
   c->enc_T = 0;
@@ -985,7 +999,7 @@ int n2nmn_walk_supported(const n2nmn_ctx* c) {
   const n2nmn_dims& d = c->d;
   if (d.variant != N2NMN_VARIANT_CLEVR || c->big_heads) return 0;
   return walk_supported(d.H, d.W, d.D, d.map_dim, c->Mp, c->HWp, d.embed_dim_txt, d.num_choices,
-                        d.T_decoder, d.kernel_size);
+                        d.T_decoder, d.kernel_size, d.T_encoder);
 }
 
 int n2nmn_conv_image(n2nmn_ctx* c, const float* image_feat, int N, int which,
@@ -1021,8 +1035,8 @@ int n2nmn_conv_image(n2nmn_ctx* c, const float* image_feat, int N, int which,
   return check_launch("conv_image");
 }
 
-int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int T_dec, int N,
-                       n2nmn_stream stream) {
+int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int T_dec, int T_enc,
+                       int N, n2nmn_stream stream) {
   N2_REQUIRE(c && batches, N2NMN_EINVAL, "walk_layouts: null argument");
   N2_REQUIRE(is_committed(c), N2NMN_ENOWEIGHT, "walk_layouts: weights not committed");
   N2_REQUIRE(root(c)->have_token_ops, N2NMN_EINVAL, "walk_layouts: call n2nmn_set_token_ops first");
@@ -1034,13 +1048,23 @@ int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int
   N2_REQUIRE(T_dec >= 1 && T_dec <= d.T_decoder && T_dec <= WALK_MAX_T, N2NMN_ECAPACITY,
              "walk_layouts: T_dec > capacity");
   WalkArgs a{};
+  const bool use_table = batches[0].atts != nullptr;
+  N2_REQUIRE(!use_table || root(c)->ew[0], N2NMN_EINVAL,
+             "walk_layouts: attention-table text maps need num_vocab_txt <= 4096");
+  N2_REQUIRE(!use_table || (T_enc >= 1 && T_enc <= d.T_encoder), N2NMN_ECAPACITY,
+             "walk_layouts: T_enc out of range");
   for (int k = 0; k < K; ++k) {
     const n2nmn_walk_batch& b = batches[k];
-    N2_REQUIRE(b.tokens && b.image_feat && b.word_vecs && b.scores, N2NMN_EINVAL,
+    N2_REQUIRE(b.tokens && b.image_feat && (b.word_vecs || b.atts) && b.scores, N2NMN_EINVAL,
                "walk_layouts: null buffer in a batch");
     const n2nmn_ctx* owner = b.ctx ? b.ctx : c;
     N2_REQUIRE(root(owner) == root(c), N2NMN_EINVAL,
                "walk_layouts: a batch's context does not share this context's weights");
+    N2_REQUIRE(!b.atts == !use_table, N2NMN_EINVAL,
+               "walk_layouts: either every batch gives atts / input_seq / seq_length or none does");
+    N2_REQUIRE(!use_table || (b.input_seq && b.seq_length), N2NMN_EINVAL,
+               "walk_layouts: atts needs input_seq and seq_length");
+    a.b[k].atts = b.atts; a.b[k].seq = b.input_seq; a.b[k].seq_len = b.seq_length;
     a.b[k].tokens = b.tokens; a.b[k].feat = b.image_feat; a.b[k].word_vecs = b.word_vecs;
     a.b[k].scores = b.scores; a.b[k].validity = b.validity;
     a.b[k].mfind = owner->mfind; a.b[k].mfsp = owner->mfsp; a.b[k].tmap = owner->wtmap;
@@ -1050,9 +1074,12 @@ int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int
   a.E = d.embed_dim_txt; a.C = d.num_choices; a.ksize = d.kernel_size;
   a.stats = c->prof_on ? c->walk_stats : nullptr;
   a.timeline = c->walk_timeline;
+  a.T_enc = use_table ? T_enc : 0;
+  for (int i = 0; i < 5; ++i) a.ew[i] = root(c)->ew[i];
+  a.V_txt = d.num_vocab_txt;
   ModuleWeights w = module_weights(c);
   hipStream_t s = S(stream);
-  {
+  if (!use_table) {
     // text maps of all K batches: <= ceil(N/8) * 5 * T_dec * K workgroups, most exit after the scan
     const double dE = d.embed_dim_txt, dM = d.map_dim;
     ProfScope ps(c, F_TEXTMAP, 0.0, 4.0 * 5 * dE * dM, s);
@@ -1106,7 +1133,7 @@ int n2nmn_execute_tokens(n2nmn_ctx* c, const int32_t* tokens, int T_dec, int N,
   n2nmn_walk_batch b{};
   b.ctx = c; b.tokens = tokens; b.image_feat = image_feat; b.word_vecs = word_vecs;
   b.scores = scores; b.validity = validity;
-  return n2nmn_walk_layouts(c, &b, 1, T_dec, N, stream);
+  return n2nmn_walk_layouts(c, &b, 1, T_dec, 0, N, stream);
 }
 
 int n2nmn_add_coords(n2nmn_ctx* c, const float* feat, int N, int D0, float* out,

@@ -72,7 +72,7 @@ struct PackBatch {
     add(PJ_PAD, src, dst, (size_t)R * Mp, R, M, Mp);
   }
 };
-constexpr int kMaxPackJobs = 96;
+constexpr int kMaxPackJobs = 112;
 
 // indices into Ctx::vars (order of build_vars)
 enum VarId {
@@ -146,6 +146,10 @@ struct n2nmn_ctx {
   float *wans_sp_p = nullptr, *wans_de_p = nullptr;  // PK packs of fc_eltwise (large num_choices only)
   bool big_heads = false;                            // map_dim * num_choices beyond the fused head
   float* wtxt_pad[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  // walker text maps as a table: ew[ws][v] = encoder embedding_mat[v] . W_txt[ws]  ([V_txt][Mp]),
+  // so  fc_text(sum_tau att * emb[seq]) = b + sum_tau att * ew[seq]  (small vocabularies only)
+  float* wtxt_pk[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  float* ew[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   float* btxt_pad[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   float* watt_pad[4] = {nullptr, nullptr, nullptr, nullptr};
   float* we_pad[3] = {nullptr, nullptr, nullptr};

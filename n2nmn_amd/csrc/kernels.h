@@ -216,12 +216,18 @@ struct WalkBatch {
   const float* mfsp;       // [N][HW][Mp] conv_image maps, FindSamePropertyModule weights (only the
                            // images whose layout has a _FindSameProperty token are filled in)
   float* tmap;             // [T][N][Mp] text maps (walk_textmap_kernel fills the rows that are read)
+  // attention-table text maps (T_enc > 0): word_vecs / tmap unused
+  const float* atts;       // [T][T_enc][N]
+  const int32_t* seq;      // [T_enc][N]
+  const int32_t* seq_len;  // [N]
 };
 struct WalkArgs {
   WalkBatch b[WALK_MAX_BATCHES];
   int K, N, T, V;
   const int32_t* token_op; // [V] device: op code of each layout token, -1 for <eos>
   int H, W, D, M, Mp, HWp, E, C, ksize;
+  int T_enc, V_txt;        // T_enc > 0: text maps from ew[ws][seq] weighted by atts
+  const float* ew[5];      // [V_txt][Mp] embedding_mat . W_txt[ws]
   // profiling only: [0] Find-type nodes, [1] pooled inputs, [2] pooling nodes, [3] text maps,
   // [4] Transform nodes, [5] valid questions (atomic adds by thread 0 of each workgroup)
   unsigned long long* stats;
@@ -230,7 +236,8 @@ struct WalkArgs {
   long long* timeline;
 };
 constexpr int WALK_STATS = 8;
-int walk_supported(int H, int W, int D, int M, int Mp, int HWp, int E, int C, int T, int ksize);
+int walk_supported(int H, int W, int D, int M, int Mp, int HWp, int E, int C, int T, int ksize,
+                   int T_enc);
 void launch_walk_textmap(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
 void launch_walk(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
 

@@ -427,6 +427,88 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_wide_kernel(LstmJobs j
 constexpr int MAXV = 16;
 constexpr int MAXKI = 4;      // lstm_dim <= 1024
 
+// validity automaton, token choice, probabilities and entropy of ONE (question, step): wave 0,
+// lanes 0..V-1 own one token each; sc = that token's logit (-INFINITY for lanes >= V)  (:200-268)
+__device__ __forceinline__ void dec_token_tail(const DecStepArgs& a, int n, int ts, size_t tn,
+                                               float sc, int lane) {
+  const int V = a.V, N = a.N;
+  const bool on = lane < V;
+  if (on && a.scores) a.scores[tn * V + lane] = sc;
+  int x0 = 0, x1 = 0, x2 = 0;
+  bool valid = on;
+  if (a.use_gt != 1) {
+    if (a.use_gt == 2) {                   // tokens known: X = [0, 0, T_dec] + sum of P[earlier tokens]
+      x2 = a.Td;
+      for (int tau = 0; tau < ts; ++tau) {
+        const int tk = a.gt[(size_t)tau * N + n];
+        x0 += a.P[tk * 3 + 0]; x1 += a.P[tk * 3 + 1]; x2 += a.P[tk * 3 + 2];
+      }
+    } else {
+      x0 = a.state[n * 3 + 0]; x1 = a.state[n * 3 + 1]; x2 = a.state[n * 3 + 2];
+    }
+    if (on) {
+      for (int c = 0; c < 4; ++c) {        // all_c( X . W[:, s, c] - b[s, c] >= 0 )   (:8-11)
+        const int val = x0 * a.Wv[(0 * V + lane) * 4 + c] + x1 * a.Wv[(1 * V + lane) * 4 + c] +
+                        x2 * a.Wv[(2 * V + lane) * 4 + c] - a.bv[lane * 4 + c];
+        valid = valid && (val >= 0);
+      }
+    }
+  }                                        // use_gt: logical_or(valid, True)          (:204-207)
+  // greedy: first index of the maximum over valid tokens (invalid ones sit at min-1)  (:234-238)
+  const float key = (on && valid) ? sc : -INFINITY;
+  const float kmax = wave_max(key);
+  const unsigned long long hit = __ballot(on && valid && key == kmax);
+  int tok = hit ? (int)__builtin_ctzll(hit) : 0;
+  if (a.uni) {                             // sampling with a caller-supplied uniform   (:212-232)
+    const float sv = on ? sc - (valid ? 0.f : 50.f) : -INFINITY;
+    const float mx = wave_max(sv);
+    const float ex = on ? expf(sv - mx) : 0.f;
+    const float den = wave_sum(ex);
+    const float ps = ex / den;
+    float cdf = 0.f, tot = 0.f;            // inclusive scan over V <= 16 lanes, in order
+    for (int s = 0; s < V; ++s) {
+      const float v = __shfl(ps, s, 64);
+      tot += v;
+      if (s == lane) cdf = tot;
+    }
+    const float thr = a.uni[tn] * tot;
+    const unsigned long long le = __ballot(on && cdf <= thr);
+    int samp = __builtin_popcountll(le);
+    samp = samp < V - 1 ? samp : V - 1;
+    const bool ok = (__ballot(on && valid) >> samp) & 1ull;
+    tok = ok ? samp : tok;
+  }
+  if (a.use_gt && a.gt) tok = a.gt[tn];    // (:239-241)
+  if (a.valid_bits) {
+    const unsigned long long vb = __ballot(on && valid);
+    if (lane == 0) a.valid_bits[tn] = (int32_t)vb;
+  }
+  if (a.forced) tok = a.forced[tn];
+  // robust softmax restricted to valid tokens                                        (:245-260)
+  const float mx = wave_max(sc);
+  const float ex = on ? expf(sc - mx) : 0.f;
+  const float den = wave_sum(ex);
+  float p = (on && valid) ? ex / den : 0.f;
+  const float psum = wave_sum(p);
+  p = p / psum;
+  const float tp = __shfl(p, tok, 64);
+  float ent = on ? p * logf(fmaxf(1e-5f, p + (valid ? 0.f : 1.f))) : 0.f;
+  ent = wave_sum(ent);
+  if (lane == 0) {
+    a.tokens[tn] = tok;
+    a.tprobs[tn] = tp;
+    a.ent_t[tn] = ent;
+    if (!a.use_gt) {
+      a.next_idx[n] = tok;
+      a.state[n * 3 + 0] = x0 + a.P[tok * 3 + 0];        // X += P[token]            (:13-15)
+      a.state[n * 3 + 1] = x1 + a.P[tok * 3 + 1];
+      a.state[n * 3 + 2] = x2 + a.P[tok * 3 + 2];
+    } else if (a.next_idx) {
+      a.next_idx[n] = tok;
+    }
+  }
+}
+
 template <int NT>
 __global__ __launch_bounds__(NT) void dec_attn_kernel(DecStepArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -441,7 +523,7 @@ __global__ __launch_bounds__(NT) void dec_attn_kernel(DecStepArgs a) {
   float* red = es + ((T + 3) & ~3);           // [NW][MAXV]
   const int n = blockIdx.x, ts = blockIdx.y;  // ts: step offset inside this launch
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int len = a.seq_len[n];
+  const int len = min(max(a.seq_len[n], 0), T);   // device-side lengths are not visible to the host checks
   const size_t tn = (size_t)ts * N + n;
   const float* qrow = a.q + tn * L;
   const float* orow = a.out + tn * L;
@@ -561,85 +643,178 @@ __global__ __launch_bounds__(NT) void dec_attn_kernel(DecStepArgs a) {
 
   // ---- validity, choice, probabilities: lanes 0..V-1 of wave 0                      (:200-268)
   if (w == 0) {
-    const bool on = lane < V;
     float sc = -INFINITY;
-    if (on) {
+    if (lane < V) {
       sc = a.by[lane];
       for (int ww = 0; ww < NW; ++ww) sc += red[ww * MAXV + lane];
-      if (a.scores) a.scores[tn * V + lane] = sc;
     }
-    int x0 = 0, x1 = 0, x2 = 0;
-    bool valid = on;
-    if (a.use_gt != 1) {
-      if (a.use_gt == 2) {                   // tokens known: X = [0, 0, T_dec] + sum of P[earlier tokens]
-        x2 = a.Td;
-        for (int tau = 0; tau < ts; ++tau) {
-          const int tk = a.gt[(size_t)tau * N + n];
-          x0 += a.P[tk * 3 + 0]; x1 += a.P[tk * 3 + 1]; x2 += a.P[tk * 3 + 2];
+    dec_token_tail(a, n, ts, tn, sc, lane);
+  }
+}
+
+// All decoder steps are known up front (teacher forcing / given tokens): one workgroup handles TS
+// steps of one question, so each encoder row (eht and encoder_outputs, 2 KB each) is loaded ONCE for
+// TS query vectors instead of once per step -- the single-step grid re-read 184 KB per (question,
+// step) from L2 (236 MB per launch at N = 64) and ran at the L2's pace.
+template <int KI, int TS>
+__global__ __launch_bounds__(256) void dec_attn_multi_kernel(DecStepArgs a, int nsteps) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NT = 256, NW = 4;
+  const int L = a.L, T = a.T, N = a.N, V = a.V;
+  const int Tp = (T + 3) & ~3;
+  const int ncol = L / 4;
+  const int nsplit = NT / ncol > 0 ? NT / ncol : 1;
+  float* outs = smem;                               // [TS][L]
+  float* ctx = outs + (size_t)TS * L;               // [TS][L]
+  float* ctxp = ctx + (size_t)TS * L;               // [nsplit][TS][L]
+  float* es = ctxp + (size_t)nsplit * TS * L;       // [TS][Tp]
+  float* red = es + (size_t)TS * Tp;                // [NW][TS][MAXV]
+  const int n = blockIdx.x, ts0 = blockIdx.y * TS;
+  const int nts = min(TS, nsteps - ts0);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int len = min(max(a.seq_len[n], 0), T);
+
+  for (int i = tid; i < TS * L; i += NT) {
+    const int j = i / L, k = i - j * L;
+    outs[i] = j < nts ? a.out[((size_t)(ts0 + j) * N + n) * L + k] : 0.f;
+  }
+  // ---- e[j][tau] = sum_k v_k tanh(q_j,k + eht[tau, n, k])                           (:184-187)
+  {
+    float4 v4[KI], q4[TS][KI];
+#pragma unroll
+    for (int i = 0; i < KI; ++i) {
+      const int k = min(4 * lane + 256 * i, L - 4);
+      const bool ok = 4 * lane + 256 * i < L;
+      v4[i] = ok ? *reinterpret_cast<const float4*>(a.v + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int j = 0; j < TS; ++j) {
+        const int jj = min(j, nts - 1);
+        q4[j][i] = *reinterpret_cast<const float4*>(a.q + ((size_t)(ts0 + jj) * N + n) * L + k);
+      }
+    }
+    constexpr int UNR = 2;
+    for (int j0 = 0; j0 * NW + w < T; j0 += UNR) {
+      float4 e4[UNR][KI];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int tau = min(w + NW * (j0 + u), T - 1);
+        const float* er = a.eht + ((size_t)tau * N + n) * L;
+#pragma unroll
+        for (int i = 0; i < KI; ++i)
+          e4[u][i] = *reinterpret_cast<const float4*>(er + min(4 * lane + 256 * i, L - 4));
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int tau = w + NW * (j0 + u);
+#pragma unroll
+        for (int j = 0; j < TS; ++j) {
+          float sacc = 0.f;
+#pragma unroll
+          for (int i = 0; i < KI; ++i) {
+            sacc += v4[i].x * fast_tanh(q4[j][i].x + e4[u][i].x) +
+                    v4[i].y * fast_tanh(q4[j][i].y + e4[u][i].y) +
+                    v4[i].z * fast_tanh(q4[j][i].z + e4[u][i].z) +
+                    v4[i].w * fast_tanh(q4[j][i].w + e4[u][i].w);
+          }
+          const float r = wave_sum(sacc);
+          if (lane == 0 && tau < T) es[j * Tp + tau] = r;
         }
-      } else {
-        x0 = a.state[n * 3 + 0]; x1 = a.state[n * 3 + 1]; x2 = a.state[n * 3 + 2];
       }
-      if (on) {
-        for (int c = 0; c < 4; ++c) {        // all_c( X . W[:, s, c] - b[s, c] >= 0 )   (:8-11)
-          const int val = x0 * a.Wv[(0 * V + lane) * 4 + c] + x1 * a.Wv[(1 * V + lane) * 4 + c] +
-                          x2 * a.Wv[(2 * V + lane) * 4 + c] - a.bv[lane * 4 + c];
-          valid = valid && (val >= 0);
+    }
+  }
+  __syncthreads();
+  // ---- softmax over ALL T rows, mask finished rows, renormalise                    (:190-191)
+  for (int j = w; j < nts; j += NW) {
+    float* ej = es + j * Tp;
+    float m = -INFINITY;
+    for (int tau = lane; tau < T; tau += 64) m = fmaxf(m, ej[tau]);
+    m = wave_max(m);
+    float sm = 0.f;
+    for (int tau = lane; tau < T; tau += 64) sm += expf(ej[tau] - m);
+    sm = wave_sum(sm);
+    float s2 = 0.f;
+    for (int tau = lane; tau < T; tau += 64) {
+      float p = expf(ej[tau] - m) / sm;
+      p = tau < len ? p : 0.f;
+      ej[tau] = p;
+      s2 += p;
+    }
+    s2 = wave_sum(s2);
+    float* arow = a.atts + (size_t)(ts0 + j) * T * N;
+    for (int tau = lane; tau < T; tau += 64) {
+      const float att = ej[tau] / s2;
+      ej[tau] = att;
+      arow[(size_t)tau * N + n] = att;
+    }
+  }
+  __syncthreads();
+  // ---- ctx[j] = sum_tau att[j][tau] * eout[tau, n, :]                                (:193)
+  {
+    for (int c = tid; c < ncol * nsplit; c += NT) {
+      const int col = c % ncol, sp = c / ncol;
+      float4 acc[TS];
+#pragma unroll
+      for (int j = 0; j < TS; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float* ob = a.eout + (size_t)n * L + 4 * col;
+#pragma unroll 4
+      for (int tau = sp; tau < len; tau += nsplit) {
+        const float4 o4 = *reinterpret_cast<const float4*>(ob + (size_t)tau * N * L);
+#pragma unroll
+        for (int j = 0; j < TS; ++j) {
+          const float at = es[j * Tp + tau];
+          acc[j].x += at * o4.x; acc[j].y += at * o4.y; acc[j].z += at * o4.z; acc[j].w += at * o4.w;
         }
       }
-    }                                        // use_gt: logical_or(valid, True)          (:204-207)
-    // greedy: first index of the maximum over valid tokens (invalid ones sit at min-1)  (:234-238)
-    const float key = (on && valid) ? sc : -INFINITY;
-    const float kmax = wave_max(key);
-    const unsigned long long hit = __ballot(on && valid && key == kmax);
-    int tok = hit ? (int)__builtin_ctzll(hit) : 0;
-    if (a.uni) {                             // sampling with a caller-supplied uniform   (:212-232)
-      const float sv = on ? sc - (valid ? 0.f : 50.f) : -INFINITY;
-      const float mx = wave_max(sv);
-      const float ex = on ? expf(sv - mx) : 0.f;
-      const float den = wave_sum(ex);
-      const float ps = ex / den;
-      float cdf = 0.f, tot = 0.f;            // inclusive scan over V <= 16 lanes, in order
-      for (int s = 0; s < V; ++s) {
-        const float v = __shfl(ps, s, 64);
-        tot += v;
-        if (s == lane) cdf = tot;
-      }
-      const float thr = a.uni[tn] * tot;
-      const unsigned long long le = __ballot(on && cdf <= thr);
-      int samp = __builtin_popcountll(le);
-      samp = samp < V - 1 ? samp : V - 1;
-      const bool ok = (__ballot(on && valid) >> samp) & 1ull;
-      tok = ok ? samp : tok;
+#pragma unroll
+      for (int j = 0; j < TS; ++j)
+        *reinterpret_cast<float4*>(ctxp + ((size_t)sp * TS + j) * L + 4 * col) = acc[j];
     }
-    if (a.use_gt && a.gt) tok = a.gt[tn];    // (:239-241)
-    if (a.valid_bits) {
-      const unsigned long long vb = __ballot(on && valid);
-      if (lane == 0) a.valid_bits[tn] = (int32_t)vb;
+    __syncthreads();
+    for (int i = tid; i < TS * L; i += NT) {
+      const int j = i / L, k = i - j * L;
+      float sacc = 0.f;
+      for (int sp = 0; sp < nsplit; ++sp) sacc += ctxp[((size_t)sp * TS + j) * L + k];
+      ctx[i] = sacc;
+      if (a.ctx_out && j < nts) a.ctx_out[((size_t)(ts0 + j) * N + n) * L + k] = sacc;
     }
-    if (a.forced) tok = a.forced[tn];
-    // robust softmax restricted to valid tokens                                        (:245-260)
-    const float mx = wave_max(sc);
-    const float ex = on ? expf(sc - mx) : 0.f;
-    const float den = wave_sum(ex);
-    float p = (on && valid) ? ex / den : 0.f;
-    const float psum = wave_sum(p);
-    p = p / psum;
-    const float tp = __shfl(p, tok, 64);
-    float ent = on ? p * logf(fmaxf(1e-5f, p + (valid ? 0.f : 1.f))) : 0.f;
-    ent = wave_sum(ent);
-    if (lane == 0) {
-      a.tokens[tn] = tok;
-      a.tprobs[tn] = tp;
-      a.ent_t[tn] = ent;
-      if (!a.use_gt) {
-        a.next_idx[n] = tok;
-        a.state[n * 3 + 0] = x0 + a.P[tok * 3 + 0];        // X += P[token]            (:13-15)
-        a.state[n * 3 + 1] = x1 + a.P[tok * 3 + 1];
-        a.state[n * 3 + 2] = x2 + a.P[tok * 3 + 2];
-      } else if (a.next_idx) {
-        a.next_idx[n] = tok;
+    __syncthreads();
+  }
+  // ---- token logits = [out, ctx] . W_y + b_y                                        (:196-198)
+  {
+    float ps[TS][MAXV];
+#pragma unroll
+    for (int j = 0; j < TS; ++j)
+#pragma unroll
+      for (int sI = 0; sI < MAXV; ++sI) ps[j][sI] = 0.f;
+    for (int k = tid; k < 2 * L; k += NT) {
+      const float* wr = a.Wy + (size_t)k * V;
+      float wv[MAXV];
+#pragma unroll
+      for (int sI = 0; sI < MAXV; ++sI) wv[sI] = sI < V ? wr[sI] : 0.f;
+#pragma unroll
+      for (int j = 0; j < TS; ++j) {
+        const float x = k < L ? outs[j * L + k] : ctx[j * L + k - L];
+#pragma unroll
+        for (int sI = 0; sI < MAXV; ++sI) ps[j][sI] += x * wv[sI];
       }
+    }
+#pragma unroll
+    for (int j = 0; j < TS; ++j)
+#pragma unroll
+      for (int sI = 0; sI < MAXV; ++sI) {
+        const float r = wave_sum(ps[j][sI]);
+        if (lane == 0) red[(w * TS + j) * MAXV + sI] = r;
+      }
+  }
+  __syncthreads();
+  if (w == 0) {
+    for (int j = 0; j < nts; ++j) {
+      float sc = -INFINITY;
+      if (lane < V) {
+        sc = a.by[lane];
+        for (int ww = 0; ww < NW; ++ww) sc += red[(ww * TS + j) * MAXV + lane];
+      }
+      dec_token_tail(a, n, ts0 + j, (size_t)(ts0 + j) * N + n, sc, lane);
     }
   }
 }
@@ -824,7 +999,33 @@ void launch_unpack_h2(const float* a, const float* b, float* dst, int N, int L, 
                      L, R);
 }
 
+template <int KI, int TS>
+static void launch_dec_multi(const DecStepArgs& a, int nsteps, hipStream_t s) {
+  const int ncol = a.L / 4;
+  const int nsplit = 256 / ncol > 0 ? 256 / ncol : 1;
+  const size_t smem = sizeof(float) * ((size_t)(2 + nsplit) * TS * a.L + (size_t)TS * ((a.T + 3) & ~3) +
+                                       (size_t)4 * TS * MAXV + 16);
+  if (smem > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_multi_kernel<KI, TS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL((dec_attn_multi_kernel<KI, TS>), dim3(a.N, (nsteps + TS - 1) / TS), dim3(256),
+                     smem, s, a, nsteps);
+}
+
 void launch_dec_attn(const DecStepArgs& a, int nsteps, hipStream_t s) {
+  if (nsteps > 1 && a.L % 256 == 0 && a.L <= 1024) {
+    // steps per workgroup: as many as keep >= ~2 workgroups per CU in the launch
+    const int groups4 = (nsteps + 3) / 4;
+    const bool four = (long)a.N * groups4 >= 512 || nsteps <= 2;
+    if (a.L <= 512) {
+      if (four) launch_dec_multi<2, 4>(a, nsteps, s);
+      else launch_dec_multi<2, 2>(a, nsteps, s);
+    } else {
+      if (four) launch_dec_multi<4, 4>(a, nsteps, s);
+      else launch_dec_multi<4, 2>(a, nsteps, s);
+    }
+    return;
+  }
   const int nt = nsteps > 1 ? 256 : 1024;
   const int ncol = a.L / 4;
   int nsplit = nt / ncol;

@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256) void dec_bwd_a_kernel(DecBwdArgs a) {
   const int n = blockIdx.x, t = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const size_t tn = (size_t)t * N + n;
-  const int len = a.seq_len[n];
+  const int len = min(max(a.seq_len[n], 0), a.T);
 
   if (w == 0) {                       // d token logits
     // p = softmax restricted to the valid tokens (nmn3_netgen_att.py:245-247);
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(256) void dec_bwd_a_kernel(DecBwdArgs a) {
 __global__ __launch_bounds__(128) void dec_bwd_b_kernel(DecBwdArgs a) {
   const int L = a.L, T = a.T, N = a.N;
   const int tau = blockIdx.x, n = blockIdx.y;
-  const int len = a.seq_len[n];
+  const int len = min(max(a.seq_len[n], 0), T);
   const size_t row = ((size_t)tau * N + n) * L;
   for (int k = 4 * threadIdx.x; k < L; k += 512) {
     float4 dh = make_float4(0.f, 0.f, 0.f, 0.f), dob = dh;

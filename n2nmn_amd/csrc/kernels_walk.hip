@@ -125,10 +125,11 @@ __device__ __forceinline__ void fc_out(int tid, const float* x, int F,
 
 // LDS carve (floats) shared by host and device
 __host__ __device__ inline size_t walk_lds_floats(int T, int HWp, int Mp, int E, int D, int M,
-                                                  int ksize, int H, int W, int C) {
+                                                  int ksize, int H, int W, int C, int T_enc = 0) {
   const int HW = H * W;
   const size_t arena = (size_t)T * HWp;
-  const size_t vecs = 4 * (size_t)Mp + ((E + 3) & ~3) + 2 * (size_t)D + 2 * (size_t)HWp + 32;
+  const size_t vecs = 4 * (size_t)Mp + ((E + 3) & ~3) + 2 * (size_t)D + 2 * (size_t)HWp + 32 +
+                      (size_t)((T_enc + 3) & ~3) + (T_enc > 0 ? (size_t)T * (Mp + ((T_enc + 3) & ~3)) : 0);
   // scratch: max of  fc reductions [WW][256] | pool stage [rows in flight][2][D] |
   //                  Transform taps [M][RS] + padded map + red [WW][64][2] | answer features + red
   const int KK = ksize * ksize, RS = (KK + 2 + 3) & ~3, pad = ksize / 2;
@@ -378,8 +379,8 @@ __global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
   const int HWp = a.HWp, T = a.T;
 
   float* arena = smem;                                 // [T][HWp]
-  float* tml = arena + (size_t)T * HWp;                // [Mp] text map (x amap for FSP)
-  float* am0 = tml + Mp;                               // [Mp] fc_att of input 0
+  float* tml_buf = arena + (size_t)T * HWp;            // [Mp] text map fetched from HBM (word_vecs path)
+  float* am0 = tml_buf + Mp;                           // [Mp] fc_att of input 0
   float* am1 = am0 + Mp;                               // [Mp] fc_att of input 1
   float* ev = am1 + Mp;                                // [Mp]
   float* wv = ev + Mp;                                 // [E] word vector
@@ -387,7 +388,11 @@ __global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
   float* sa0 = pooled + 2 * (size_t)D;                 // [HWp] softmax weights
   float* sa1 = sa0 + HWp;
   float* rs = sa1 + HWp;                               // [32] reduction scratch
-  float* scr = rs + 32;                                // operator scratch (see walk_lds_floats)
+  const int Tep = (a.T_enc + 3) & ~3;
+  int* seql = reinterpret_cast<int*>(rs + 32);         // [T_enc] the question's words
+  float* tmaps = reinterpret_cast<float*>(seql + Tep); // [T][Mp] text maps of this question's nodes
+  float* attall = tmaps + (a.T_enc > 0 ? (size_t)T * Mp : 0);       // [T][T_enc] decoder attention
+  float* scr = attall + (a.T_enc > 0 ? (size_t)T * Tep : 0);        // operator scratch
 
   // ---- 1. decode the RPN column (nmn3_assembler.py:153-222) ---------------------------------
   // the T token loads (and their op-code lookups) go out in parallel; thread 0 then runs the stack
@@ -456,6 +461,61 @@ __global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
     atomicAdd(a.stats + 3, ct); atomicAdd(a.stats + 4, ctr); atomicAdd(a.stats + 5, 1ull);
   }
   const float* feat = B.feat + (size_t)n * HW * D;
+  int qlen = 0;
+  if (a.T_enc > 0) {                                   // the question's words, once
+    qlen = min(max(B.seq_len[n], 0), a.T_enc);
+    for (int tau = tid0; tau < a.T_enc; tau += WT) {
+      const int v = B.seq[(size_t)tau * a.N + n];
+      seql[tau] = min(max(v, 0), a.V_txt - 1);
+    }
+    // ---- text maps of ALL nodes of the question, before the chain starts: they depend only on the
+    // decoder's attention.  word_vec = sum_tau att[tau] * emb[word[tau]]  =>  fc_text(word_vec) =
+    // b + sum_tau att[tau] * (emb . W_txt)[word[tau]]: a weighted sum of <= len rows of a small
+    // L2-resident table.  One WAVE per node (no cross-wave reduction), every node in flight at once.
+    for (int i = tid0; i < nn * a.T_enc; i += WT) {
+      const int t = i / a.T_enc, tau = i - t * a.T_enc;
+      attall[t * Tep + tau] = tau < qlen ? B.atts[((size_t)t * a.T_enc + tau) * a.N + n] : 0.f;
+    }
+    __syncthreads();
+    {
+      const int lane0 = tid0 & 63, wid0 = tid0 >> 6;
+      for (int t = wid0; t < nn; t += WW) {
+        const int o = L.op[t] & 0xff;
+        int ws;
+        switch (o) {
+          case N2NMN_OP_FIND: case N2NMN_OP_FILTER: ws = 0; break;
+          case N2NMN_OP_FIND_SAME_PROPERTY: ws = 1; break;
+          case N2NMN_OP_TRANSFORM: ws = 2; break;
+          case N2NMN_OP_SAME_PROPERTY: ws = 3; break;
+          case N2NMN_OP_DESCRIBE: ws = 4; break;
+          default: ws = -1; break;
+        }
+        if (ws < 0) continue;                            // wave-uniform
+        const float* ewp = a.ew[ws];
+        const float* at = attall + t * Tep;
+        for (int cb = 0; cb < Mp; cb += 256) {
+          const unsigned col = (unsigned)min(cb + 4 * lane0, Mp - 4);
+          float4 acc = *reinterpret_cast<const float4*>(w.btxt[ws] + col);
+          constexpr int RU = 16;
+          for (int tb = 0; tb < qlen; tb += RU) {
+            float4 r4[RU];
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+              const int tau = min(tb + u, a.T_enc - 1);
+              r4[u] = *reinterpret_cast<const float4*>(ewp + ((unsigned)seql[tau] * (unsigned)Mp + col));
+            }
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+              const float av = tb + u < qlen ? at[tb + u] : 0.f;
+              acc.x += av * r4[u].x; acc.y += av * r4[u].y; acc.z += av * r4[u].z; acc.w += av * r4[u].w;
+            }
+          }
+          if (cb + 4 * lane0 < Mp) *reinterpret_cast<float4*>(tmaps + (size_t)t * Mp + col) = acc;
+        }
+      }
+    }
+    __syncthreads();
+  }
   const int ncol = D / 4, nrow = WT / ncol;
   constexpr int PR = WALK_POOL_ROWS;
 
@@ -469,6 +529,7 @@ __global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
     const int lane = tid & 63, wid = tid >> 6;
     const int lc = tid % ncol, lr = tid / ncol;
     const int op = L.op[t] & 0xff;
+    float* tml = tml_buf;
     long long* tl = a.timeline ? a.timeline + ((size_t)q * MAXT + t) * 4 : nullptr;
     if (tl && tid0 == 0) tl[0] = clock64();
     const float* in0 = L.in0[t] >= 0 ? arena + (size_t)L.in0[t] * HWp : nullptr;
@@ -478,10 +539,13 @@ __global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
     const bool pools = op == N2NMN_OP_FIND_SAME_PROPERTY || op == N2NMN_OP_SAME_PROPERTY ||
                        op == N2NMN_OP_DESCRIBE;
 
-    // text map of this node, computed by walk_textmap_kernel: one 4*Mp-byte row
+    // text map of this node (fc_text / text_fc of its text parameter, nmn3_modules.py:53-57,101,
+    // 161,209,424,479)
     const bool has_text = op == N2NMN_OP_FIND || op == N2NMN_OP_FILTER || pools ||
                           op == N2NMN_OP_TRANSFORM;
-    if (has_text) {
+    if (has_text && a.T_enc > 0) {
+      tml = tmaps + (size_t)t * Mp;                      // computed in the pre-pass above
+    } else if (has_text) {                              // hoisted: walk_textmap_kernel's row
       const float* src = B.tmap + ((size_t)t * a.N + n) * Mp;
       for (int c = 4 * tid; c < Mp; c += 4 * WT)
         *reinterpret_cast<float4*>(tml + c) = *reinterpret_cast<const float4*>(src + c);
@@ -692,7 +756,8 @@ __global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
 
 }  // namespace
 
-int walk_supported(int H, int W, int D, int M, int Mp, int HWp, int E, int C, int T, int ksize) {
+int walk_supported(int H, int W, int D, int M, int Mp, int HWp, int E, int C, int T, int ksize,
+                   int T_enc) {
   const int HW = H * W;
   if (D % 4 != 0 || D / 4 > WT || WT % (D / 4) != 0) return 0;
   const int nrow = WT / (D / 4);
@@ -701,7 +766,7 @@ int walk_supported(int H, int W, int D, int M, int Mp, int HWp, int E, int C, in
   if (ksize != 3 && ksize != 5) return 0;
   const int PG = (HW + 63) / 64;
   if (PG > WALK_MAX_PIXEL_GROUPS) return 0;
-  const size_t bytes = sizeof(float) * walk_lds_floats(T, HWp, Mp, E, D, M, ksize, H, W, C);
+  const size_t bytes = sizeof(float) * walk_lds_floats(T, HWp, Mp, E, D, M, ksize, H, W, C, T_enc);
   return bytes <= 150 * 1024;
 }
 
@@ -717,7 +782,7 @@ void launch_walk_textmap(const ModuleWeights& w, const WalkArgs& a, hipStream_t 
 
 void launch_walk(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) {
   const size_t smem = sizeof(float) * walk_lds_floats(a.T, a.HWp, a.Mp, a.E, a.D, a.M, a.ksize,
-                                                      a.H, a.W, a.C);
+                                                      a.H, a.W, a.C, a.T_enc);
   auto go = [&](auto kern) {
     if (smem > 64 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

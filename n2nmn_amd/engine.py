@@ -149,7 +149,7 @@ class Engine:
 
     def seq2seq(self, input_seq, seq_len, T_dec: Optional[int] = None, use_gt_layout: bool = False,
                 gt_layout=None, sample_uniforms=None, forced_tokens=None, debug: bool = False,
-                reuse_buffers: bool = True, phase: str = 'both'):
+                reuse_buffers: bool = True, phase: str = 'both', word_vecs: bool = True):
         """Phase 1.  input_seq [T,N] int32, seq_len [N] int32 (device tensors or anything
         convertible).  Returns a dict of device tensors named like the reference attributes
         (models_clevr/nmn3_netgen_att.py:305-322).  With reuse_buffers the outputs are views of
@@ -187,10 +187,15 @@ class Engine:
         io.forced_tokens = forced.data_ptr() if forced is not None else None
         for k, t in out.items():
             setattr(io, k, t.data_ptr())
+        if not word_vecs:        # N2NMN_S2S_NO_WORD_VECS: word_vecs / neg_entropy / log_seq_prob not computed
+            io.flags = 1
+            for k in ('word_vecs', 'neg_entropy', 'log_seq_prob'):
+                out.pop(k)
         fn = {'both': self._lib.n2nmn_seq2seq_forward, 'encoder': self._lib.n2nmn_encoder_forward,
               'decoder': self._lib.n2nmn_decoder_forward}[phase]
         _lib.check(fn(self._ctx, C.byref(io), self.stream()))
         out['_keepalive'] = (seq, lens, gt, uni, forced)
+        out['_input_seq'], out['_seq_length'] = seq, lens
         return out
 
     def execute(self, packed: PackedLayouts, image_feat, word_vecs, reuse_buffers: bool = True):
@@ -233,16 +238,24 @@ class Engine:
         word_vecs, scores, validity) device tensors; `engine` is the (fork of this) engine whose
         conv_image() was called for that batch."""
         arr = (_lib.WalkBatch * len(jobs))()
-        for i, (eng, tok, feat, wv, sc, val) in enumerate(jobs):
+        T_enc = 0
+        for i, job in enumerate(jobs):
+            eng, tok, feat, wv, sc, val = job[:6]
             arr[i].ctx = eng._ctx
             arr[i].tokens = tok.data_ptr(); arr[i].image_feat = feat.data_ptr()
-            arr[i].word_vecs = wv.data_ptr(); arr[i].scores = sc.data_ptr()
+            arr[i].word_vecs = wv.data_ptr() if wv is not None else None
+            arr[i].scores = sc.data_ptr()
             arr[i].validity = val.data_ptr() if val is not None else None
-        _lib.check(self._lib.n2nmn_walk_layouts(self._ctx, arr, len(jobs), int(T_dec), int(N),
+            if len(job) > 6 and job[6] is not None:      # (atts [T_dec,T_enc,N], input_seq, seq_length)
+                atts, seq, lens = job[6]
+                arr[i].atts = atts.data_ptr(); arr[i].input_seq = seq.data_ptr()
+                arr[i].seq_length = lens.data_ptr()
+                T_enc = int(atts.shape[1])
+        _lib.check(self._lib.n2nmn_walk_layouts(self._ctx, arr, len(jobs), int(T_dec), T_enc, int(N),
                                                 self.stream()))
 
     def execute_tokens(self, tokens, image_feat, word_vecs, reuse_buffers: bool = True,
-                       conv_done: bool = False):
+                       conv_done: bool = False, atts=None):
         """Phase 2 straight from DEVICE tokens [T_dec, N]: no token fetch, no host assembly, no
         program upload.  Returns (scores [N, C], validity [N] int32) device tensors."""
         torch = _torch()
@@ -256,7 +269,9 @@ class Engine:
         validity = mk('wvalid', (N,), torch.int32)
         if not conv_done:
             self.conv_image(feat, tok, Td)
-        self.walk([(self, tok, feat, wv, scores, validity)], N, Td)
+        # atts = (atts [T_dec, T_enc, N], input_seq [T_enc, N], seq_length [N]): text maps from the
+        # decoder's attention and the commit-time (embedding . W_txt) tables; word_vecs not needed
+        self.walk([(self, tok, feat, wv, scores, validity, atts)], N, Td)
         return scores, validity
 
     def module_forward(self, name: str, inputs, time_idx, batch_idx, image_feat, word_vecs):
@@ -356,16 +371,18 @@ class Engine:
                 with torch.cuda.stream(self._side):
                     self.conv_image(feat, gt_dev if known else None, T_dec, find=True, fsp=known)
                     self._side_ev.record(self._side)
+            table = self.dims.num_vocab_txt <= 4096
             s2s = self.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], T_dec,
-                               use_gt_layout, gt_dev, sample_uniforms)
+                               use_gt_layout, gt_dev, sample_uniforms, word_vecs=not table)
             if not self.overlap_conv:
                 self.conv_image(feat, s2s['predicted_tokens'], find=True, fsp=True)
             elif not known:
                 self.conv_image(feat, s2s['predicted_tokens'], find=False, fsp=True)
             if self.overlap_conv:
                 cur.wait_event(self._side_ev)
-            scores, validity = self.execute_tokens(s2s['predicted_tokens'], feat, s2s['word_vecs'],
-                                                   conv_done=True)
+            scores, validity = self.execute_tokens(
+                s2s['predicted_tokens'], feat, s2s.get('word_vecs'), conv_done=True,
+                atts=(s2s['atts'], s2s['_input_seq'], s2s['_seq_length']) if table else None)
             if not fetch:
                 return scores, s2s['predicted_tokens'], validity
             return scores, s2s['predicted_tokens'].cpu().numpy(), validity.cpu().numpy().astype(bool)

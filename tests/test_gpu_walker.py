@@ -153,3 +153,22 @@ def test_walker_on_the_reference_code_fixture(clevr_engine):
     assert np.array_equal(t2n(tokens), z['greedy/predicted_tokens'])
     assert np.array_equal(t2n(validity).astype(bool), z['greedy/validity'])
     assert_close('scores', t2n(scores), z['greedy/scores'], TOL)
+
+
+def test_attention_table_text_maps_equal_word_vec_text_maps(clevr_engine):
+    """fc_text(sum_tau att * emb[word]) == b + sum_tau att * (emb . W_txt)[word]: the walker fed with
+    the decoder's attention maps (no word_vecs / text-map launches) against the walker fed with
+    word_vecs, and against the oracle."""
+    eng, d, asm, w = clevr_engine
+    batch = synth.make_inputs(d, seed=77, min_len=1)
+    toks = synth.random_valid_layouts(d, asm.P, asm.W, asm.b, seed=31, max_len=8)
+    ref = O.forward(w, NAMES, batch, d.T_decoder, d.num_choices, np.float64, forced_tokens=toks)
+    s2s = eng.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], forced_tokens=toks,
+                      reuse_buffers=False)
+    a, _ = eng.execute_tokens(s2s['predicted_tokens'], batch['image_feat_batch'], s2s['word_vecs'],
+                              reuse_buffers=False)
+    b, _ = eng.execute_tokens(s2s['predicted_tokens'], batch['image_feat_batch'], None,
+                              reuse_buffers=False,
+                              atts=(s2s['atts'], s2s['_input_seq'], s2s['_seq_length']))
+    assert_close('table vs word_vecs', t2n(b), t2n(a), 2e-5)
+    assert_close('table vs oracle', t2n(b), ref['scores'], TOL)
