@@ -148,6 +148,7 @@ static size_t carve_weights(n2nmn_ctx* c, char* base) {
   }
   for (int i = 0; i < 5; ++i) c->wtxt_pad[i] = k.take<float>(E * Mp);
   for (int i = 0; i < 5; ++i) c->btxt_pad[i] = k.take<float>(Mp);
+  c->tr_At = k.take<float>((size_t)((d.kernel_size * d.kernel_size + 1 + 3) & ~3) * round_up(d.map_dim, 16));
   if (d.variant == N2NMN_VARIANT_CLEVR && d.num_vocab_txt <= 4096)
     for (int i = 0; i < 5; ++i) {
       c->wtxt_pk[i] = k.take<float>((size_t)c->KpE * Mp);
@@ -244,7 +245,7 @@ ModuleWeights module_weights(const n2nmn_ctx* c) {
   for (int i = 0; i < 5; ++i) { w.Wtxt[i] = c->wtxt_pad[i]; w.btxt[i] = c->btxt_pad[i]; }
   for (int i = 0; i < 3; ++i) w.we[i] = c->we_pad[i];
   w.be[0] = m(V_FIND_E_B); w.be[1] = m(V_FSP_E_B); w.be[2] = m(V_TR_E_B);
-  w.Kt = m(V_TR_MAPS_W); w.bt = m(V_TR_MAPS_B);
+  w.Kt = m(V_TR_MAPS_W); w.bt = m(V_TR_MAPS_B); w.trA = root(c)->tr_At;
   const int attw[4] = {V_FSP_ATT_W, V_SP_ATT0_W, V_SP_ATT1_W, V_DE_ATT_W};
   (void)attw;
   for (int i = 0; i < 4; ++i) { w.Watt[i] = c->watt_pad[i]; w.batt[i] = c->batt_pad[i]; }
@@ -867,6 +868,11 @@ int n2nmn_commit_weights(n2nmn_ctx* c, n2nmn_stream stream) {
     const int wes[3] = {V_FIND_E_W, V_FSP_E_W, V_TR_E_W};
     for (int i = 0; i < 3; ++i)
       if (has(wes[i])) pb.pad(m(wes[i]), 1, M, c->we_pad[i], Mp);
+    if (has(V_TR_MAPS_W)) {          // k-major [KK + 1 (+pad)][Mq] operand of the walker's MFMA Transform
+      const int KK = d.kernel_size * d.kernel_size, Mq = round_up(M, 16);
+      pb.pad(m(V_TR_MAPS_W), KK, M, c->tr_At, Mq);
+      pb.pad(m(V_TR_MAPS_B), 1, M, c->tr_At + (size_t)KK * Mq, Mq);
+    }
     const int txs[5] = {V_FIND_TXT_W, V_FSP_TXT_W, V_TR_TXT_W, V_SP_TXT_W, V_DE_TXT_W};
     for (int i = 0; i < 5; ++i) {
       if (!has(txs[i])) continue;
@@ -894,6 +900,11 @@ int n2nmn_commit_weights(n2nmn_ctx* c, n2nmn_stream stream) {
     N2_REQUIRE((int)pb.jobs.size() <= kMaxPackJobs, N2NMN_ECAPACITY, "commit_weights: pack job table");
     N2_HIP(hipMemcpy(pb.dev, pb.jobs.data(), sizeof(PackJob) * pb.jobs.size(), hipMemcpyHostToDevice));
     pb.uploaded = true;
+  }
+  {
+    const int KK = d.kernel_size * d.kernel_size, KD = (KK + 1 + 3) & ~3, Mq = round_up(d.map_dim, 16);
+    if (KD > KK + 1)
+      N2_HIP(hipMemsetAsync(c->tr_At + (size_t)(KK + 1) * Mq, 0, sizeof(float) * (size_t)(KD - KK - 1) * Mq, s));
   }
   launch_pack_jobs(c->packs.dev, (int)c->packs.jobs.size(), c->packs.blocks, s);
   // xtab[v] = emb[v] . W_x + b : the whole input half of the layer-0 gate pre-activations

@@ -148,6 +148,7 @@ struct n2nmn_ctx {
   float* wtxt_pad[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   // walker text maps as a table: ew[ws][v] = encoder embedding_mat[v] . W_txt[ws]  ([V_txt][Mp]),
   // so  fc_text(sum_tau att * emb[seq]) = b + sum_tau att * ew[seq]  (small vocabularies only)
+  float* tr_At = nullptr;                  // k-major Transform taps + bias (ModuleWeights::trA)
   float* wtxt_pk[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   float* ew[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   float* btxt_pad[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -170,6 +170,9 @@ struct ModuleWeights {     // device pointers into the context's packed weight s
   const float* we[3]; const float* be[3];
   // Transform conv_maps [k*k][M], bias [M]
   const float* Kt; const float* bt;
+  // the same, k-major and zero padded for the walker's MFMA Transform: [(k*k + 1 + 3) & ~3][Mq],
+  // rows 0..k*k-1 = taps, row k*k = bias, Mq = round_up(M, 16)
+  const float* trA;
   // fc_att of FSP, SameProperty(0,1), Describe: zero-padded [D][Mp] + bias [Mp]
   const float* Watt[4]; const float* batt[4];
   // answer FCs: Exist [3][C], Count [HW+2][C], Equal/More/Less [2HW+4][C], SameProp/Describe [M][C]
@@ -228,7 +231,8 @@ struct WalkArgs {
   int H, W, D, M, Mp, HWp, E, C, ksize;
   int T_enc, V_txt;        // T_enc > 0: text maps from ew[ws][seq] weighted by atts
   const float* ew[5];      // [V_txt][Mp] embedding_mat . W_txt[ws]
-  // profiling only: [0] Find-type nodes, [1] pooled inputs, [2] pooling nodes, [3] text maps,
+  // profiling only: [0] conv_image map reads (one per <= 4 Find / Filter nodes of a question, one per
+  // FindSameProperty node), [1] pooled inputs, [2] pooling nodes, [3] text maps,
   // [4] Transform nodes, [5] valid questions (atomic adds by thread 0 of each workgroup)
   unsigned long long* stats;
   // debugging only: [question][WALK_MAX_T][4] shader-clock stamps of thread 0 per node

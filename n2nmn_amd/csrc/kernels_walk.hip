@@ -42,7 +42,8 @@ struct WalkLds {
   int op[MAXT], in0[MAXT], in1[MAXT];
   int tok_op[MAXT];        // op code of token t (-1: <eos>, -2: token out of range)
   int stack[MAXT];
-  int n_nodes, valid;
+  int flist[MAXT];         // nodes that read the FindModule conv_image map (Find, Filter)
+  int n_nodes, valid, n_find;
 };
 
 // block reductions through `scr` (>= 16 floats); every thread gets the result
@@ -136,8 +137,9 @@ __host__ __device__ inline size_t walk_lds_floats(int T, int HWp, int Mp, int E,
   const int ncol = D / 4, nrow = WT / ncol;
   size_t s0 = (size_t)WW * 256;
   size_t s1 = (size_t)nrow * 2 * D;
-  size_t s2 = (size_t)M * RS + (((size_t)(H + 2 * pad) * (W + 2 * pad) + 3) & ~3) +
-              (size_t)WW * WALK_MAX_PIXEL_GROUPS * 64 * 2;
+  const int KD = (KK + 1 + 3) & ~3, Mq = (M + 15) / 16 * 16, Pq = (HW + 15) / 16 * 16;
+  size_t s2 = (((size_t)(H + 2 * pad) * (W + 2 * pad) + 4) & ~3) + (size_t)WW * Pq * 2;
+  (void)RS; (void)KD; (void)Mq;
   size_t s3 = (size_t)((2 * HW + 4 + 3) & ~3) + (size_t)WT;
   size_t s = s0 > s1 ? s0 : s1;
   s = s > s2 ? s : s2;
@@ -148,110 +150,129 @@ __host__ __device__ inline size_t walk_lds_floats(int T, int HWp, int Mp, int E,
 namespace {
 
 // Transform (nmn3_modules.py:185-216): KSxKS SAME convolution of the 1-channel attention map to M
-// channels, times the text map, l2-normalise over channels, dot with w_e.
-// Wave w owns channels w, w + 8, ...; lanes are pixels, and a wave keeps the KSxKS windows of ALL
-// its (up to PGMAX) 64-pixel groups in registers, so one broadcast read of a channel's taps from
-// LDS feeds PGMAX independent FMA chains (the first version split waves over pixel groups instead:
-// 3x the LDS tap traffic, one dependent chain per wave, two idle waves -- 45 us per node).
+// channels, times the text map, l2-normalise over channels, dot with w_e -- as ONE small GEMM on the
+// matrix cores.  With u[c, p] = sum_k A[c, k] * X[k, p], A[c, :] = [taps(c), bias(c), 0..] (weights
+// only: packed k-major at commit time, ModuleWeights::trA) and X[:, p] = [KSxKS window of pixel p, 1,
+// 0..], the text map enters only the epilogue:
+//     att[p] = (sum_c tm[c] w_e[c] u[c,p]) / sqrt(max(sum_c (tm[c] u[c,p])^2, eps)) + b_e.
+// Wave w owns channel tiles w, w + 8, ...: its A fragments come straight from L2 (64-B segments), the
+// B fragments straight from the zero-padded map in LDS (no im2col buffer: per-lane window offsets),
+// all pixel tiles accumulate in independent MFMA chains (a single dependent chain per wave ran the
+// matrix pipe at ~1/6 of its rate), and u is folded into per-pixel partial sums in the MFMA's own
+// output layout (a lane holds 4 channels of one pixel), so it never leaves registers.
+// History: VALU, taps broadcast from LDS: 45 us per node; 6 interleaved FMA chains: 13 us;
+// MFMA with per-node operand build + one chain: 15 us.
 template <int KS>
 __device__ __forceinline__ void walk_transform(int tid, const ModuleWeights& w, const WalkArgs& a,
                                                const float* in0, const float* tm, float* outp,
-                                               float* scr) {
+                                               float* scr, long long* tl) {
   constexpr int KK = KS * KS;
-  constexpr int RS = (KK + 2 + 3) & ~3;
+  constexpr int KD = (KK + 1 + 3) & ~3;          // taps + bias row, padded to the MFMA's k = 4
+  constexpr int NS = KD / 4;                     // k-steps
   constexpr int PAD = KS / 2;
-  constexpr int PGMAX = WALK_MAX_PIXEL_GROUPS;
+  constexpr int PTMAX = (WALK_MAX_PIXEL_GROUPS * 64 + 15) / 16;
   const int H = a.H, W = a.W, HW = H * W, M = a.M;
   const int PW = W + 2 * PAD, PH = H + 2 * PAD;
-  float* Kl = scr;                              // [M][RS]: taps * tm[c], bias * tm[c], w_e[c]
-  float* xin = Kl + (size_t)M * RS;             // [PH][PW] zero-padded input map
-  float* red = xin + ((PH * PW + 3) & ~3);      // [WW][PGMAX][64][2]
+  const int Mt = (M + 15) >> 4, Pt = (HW + 15) >> 4;     // 16-wide channel / pixel tiles
+  const int Mq = Mt * 16, Pq = Pt * 16;
+  float* xin = scr;                              // [PH][PW] zero-padded input map (+ 1 spare = 0)
+  float* red = xin + ((PH * PW + 4) & ~3);       // [WW][Pq][2]
   const int lane = tid & 63, wid = tid >> 6;
-  for (int i = tid; i < PH * PW; i += WT) {
+  const int ci = lane & 15, kg = lane >> 4;
+  const int cw = __builtin_amdgcn_readfirstlane(wid);
+  // A fragments of this wave's first channel tile: issued before anything else
+  float af[NS];
+  {
+    const int ct0 = min(cw, Mt - 1);
+#pragma unroll
+    for (int sI = 0; sI < NS; ++sI) af[sI] = w.trA[(4 * sI + kg) * Mq + 16 * ct0 + ci];
+  }
+  for (int i = tid; i <= PH * PW; i += WT) {
     const int y = i / PW - PAD, x = i % PW - PAD;
-    xin[i] = (y >= 0 && y < H && x >= 0 && x < W) ? in0[y * W + x] : 0.f;
+    xin[i] = (i < PH * PW && y >= 0 && y < H && x >= 0 && x < W) ? in0[y * W + x] : 0.f;
   }
-  for (int c = tid; c < M; c += WT) {           // coalesced over c for every tap
-    const float t = tm[c];
+  // per-lane window offsets: k = 4*sI + kg -> (dy, dx); the bias row is a constant 1, rows beyond 0
+  int koff[NS];
+  float kmask[NS], kone[NS];
 #pragma unroll
-    for (int tap = 0; tap < KK; ++tap) Kl[c * RS + tap] = w.Kt[tap * M + c] * t;
-    Kl[c * RS + KK] = w.bt[c] * t;
-    Kl[c * RS + KK + 1] = w.we[2][c];
+  for (int sI = 0; sI < NS; ++sI) {
+    const int k = 4 * sI + kg;
+    const int dy = k / KS, dx = k - dy * KS;
+    koff[sI] = k < KK ? dy * PW + dx : 0;
+    kmask[sI] = k < KK ? 1.f : 0.f;
+    kone[sI] = k == KK ? 1.f : 0.f;
   }
-  __syncthreads();
-  const int PG = (HW + 63) / 64;
-  float win[PGMAX][KK];
+  int poff[PTMAX];
 #pragma unroll
-  for (int g = 0; g < PGMAX; ++g) {
-    const int p = min(g * 64 + lane, HW - 1);
-    const int y = p / W, x = p - y * W;
-#pragma unroll
-    for (int dy = 0; dy < KS; ++dy)
-#pragma unroll
-      for (int dx = 0; dx < KS; ++dx) win[g][dy * KS + dx] = xin[(y + dy) * PW + x + dx];
-  }
-  float ss[PGMAX], dot[PGMAX];
-#pragma unroll
-  for (int g = 0; g < PGMAX; ++g) { ss[g] = 0.f; dot[g] = 0.f; }
-  // PGMAX pixel groups x 2 channels = 6 independent FMA chains per iteration, each split in two
-  // halves: a dependent v_fmac chain issues one FMA per ~8 cycles, so a single 27-deep chain per
-  // wave ran the VALU at a quarter of its rate.  Groups beyond PG recompute the last pixel (cheap,
-  // branch-free) and are ignored below.
-  const int cw = __builtin_amdgcn_readfirstlane(wid);    // wave-uniform: scalar loop control
-  for (int c = cw; c < M; c += 2 * WW) {
-    const int c2 = min(c + WW, M - 1);
-    const bool two = c + WW < M;
-    const float4* kr0 = reinterpret_cast<const float4*>(Kl + (size_t)c * RS);
-    const float4* kr1 = reinterpret_cast<const float4*>(Kl + (size_t)c2 * RS);
-    float k0[RS], k1[RS];
-#pragma unroll
-    for (int q = 0; q < RS / 4; ++q) {
-      const float4 t0 = kr0[q], t1 = kr1[q];
-      k0[4 * q] = t0.x; k0[4 * q + 1] = t0.y; k0[4 * q + 2] = t0.z; k0[4 * q + 3] = t0.w;
-      k1[4 * q] = t1.x; k1[4 * q + 1] = t1.y; k1[4 * q + 2] = t1.z; k1[4 * q + 3] = t1.w;
-    }
-    float va[PGMAX], vb[PGMAX], ua[PGMAX], ub[PGMAX];
-#pragma unroll
-    for (int g = 0; g < PGMAX; ++g) { va[g] = k0[KK]; vb[g] = 0.f; ua[g] = k1[KK]; ub[g] = 0.f; }
-#pragma unroll
-    for (int tap = 0; tap + 1 < KK; tap += 2) {
-#pragma unroll
-      for (int g = 0; g < PGMAX; ++g) {
-        va[g] += k0[tap] * win[g][tap];
-        vb[g] += k0[tap + 1] * win[g][tap + 1];
-        ua[g] += k1[tap] * win[g][tap];
-        ub[g] += k1[tap + 1] * win[g][tap + 1];
-      }
-    }
-    if (KK & 1) {
-#pragma unroll
-      for (int g = 0; g < PGMAX; ++g) {
-        va[g] += k0[KK - 1] * win[g][KK - 1];
-        ua[g] += k1[KK - 1] * win[g][KK - 1];
-      }
-    }
-    const float m1 = two ? 1.f : 0.f;
-#pragma unroll
-    for (int g = 0; g < PGMAX; ++g) {
-      const float v = va[g] + vb[g], u = (ua[g] + ub[g]) * m1;
-      ss[g] += v * v + u * u;
-      dot[g] += v * k0[KK + 1] + u * k1[KK + 1];
-    }
-  }
-#pragma unroll
-  for (int g = 0; g < PGMAX; ++g) {
-    red[((wid * PGMAX + g) * 64 + lane) * 2] = ss[g];
-    red[((wid * PGMAX + g) * 64 + lane) * 2 + 1] = dot[g];
+  for (int pt = 0; pt < PTMAX; ++pt) {
+    const int p = min(16 * pt + ci, HW - 1);
+    const int y = p / W;
+    poff[pt] = y * PW + (p - y * W);
   }
   __syncthreads();
+  if (tl && threadIdx.x == 0) tl[1] = clock64();       // debug timeline: operands ready
+  float ssp[PTMAX], dtp[PTMAX];
+#pragma unroll
+  for (int pt = 0; pt < PTMAX; ++pt) { ssp[pt] = 0.f; dtp[pt] = 0.f; }
+  // B fragments are the same for every channel tile: read them from LDS once
+  float xf[NS][PTMAX];
+#pragma unroll
+  for (int sI = 0; sI < NS; ++sI)
+#pragma unroll
+    for (int pt = 0; pt < PTMAX; ++pt) xf[sI][pt] = xin[poff[pt] + koff[sI]] * kmask[sI] + kone[sI];
+  for (int ct = cw; ct < Mt; ct += WW) {
+    // text map and w_e of this lane's 4 channel rows: both are zero padded to Mp >= Mq, so one
+    // 16-byte read each and no bounds branch (four branchy scalar loads here serialised four global
+    // round trips per channel tile: 18 k of the node's 22 k clocks)
+    const float4 tmv = *reinterpret_cast<const float4*>(tm + 16 * ct + 4 * kg);
+    const float4 wev = *reinterpret_cast<const float4*>(w.we[2] + 16 * ct + 4 * kg);
+    const float tm4[4] = {tmv.x, tmv.y, tmv.z, tmv.w};
+    const float tw4[4] = {tmv.x * wev.x, tmv.y * wev.y, tmv.z * wev.z, tmv.w * wev.w};
+    f32x4 acc[PTMAX];
+#pragma unroll
+    for (int pt = 0; pt < PTMAX; ++pt) acc[pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sI = 0; sI < NS; ++sI) {
+#pragma unroll
+      for (int pt = 0; pt < PTMAX; ++pt) {
+        acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[sI], xf[sI][pt], acc[pt], 0, 0, 0);
+      }
+    }
+    // next channel tile's A fragments (if any) while the MFMAs drain
+    if (ct + WW < Mt) {
+#pragma unroll
+      for (int sI = 0; sI < NS; ++sI) af[sI] = w.trA[(4 * sI + kg) * Mq + 16 * (ct + WW) + ci];
+    }
+#pragma unroll
+    for (int pt = 0; pt < PTMAX; ++pt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = tm4[r] * acc[pt][r];
+        ssp[pt] += v * v;
+        dtp[pt] += tw4[r] * acc[pt][r];
+      }
+    }
+  }
+  // a pixel's channels sit in the four 16-lane rows of the wave: fold them, then across waves
+#pragma unroll
+  for (int pt = 0; pt < PTMAX; ++pt) {
+    float s2 = ssp[pt], d2 = dtp[pt];
+    s2 += __shfl_xor(s2, 16, 64); d2 += __shfl_xor(d2, 16, 64);
+    s2 += __shfl_xor(s2, 32, 64); d2 += __shfl_xor(d2, 32, 64);
+    if (kg == 0 && pt < Pt) {
+      red[((size_t)wid * Pq + 16 * pt + ci) * 2] = s2;
+      red[((size_t)wid * Pq + 16 * pt + ci) * 2 + 1] = d2;
+    }
+  }
+  __syncthreads();
+  if (tl && threadIdx.x == 0) tl[2] = clock64();       // debug timeline: MFMA phase done
   const float be = w.be[2][0];
   for (int p = tid; p < HW; p += WT) {
-    const int g = p >> 6, l = p & 63;
     float s2 = 0.f, d2 = 0.f;
 #pragma unroll
     for (int q = 0; q < WW; ++q) {
-      s2 += red[((q * PGMAX + g) * 64 + l) * 2];
-      d2 += red[((q * PGMAX + g) * 64 + l) * 2 + 1];
+      s2 += red[((size_t)q * Pq + p) * 2];
+      d2 += red[((size_t)q * Pq + p) * 2 + 1];
     }
     outp[p] = d2 / sqrtf(fmaxf(s2, 1e-12f)) + be;
   }
@@ -367,6 +388,60 @@ __global__ __launch_bounds__(WT) void walk_textmap_kernel(ModuleWeights w, WalkA
   }
 }
 
+// Find / Filter epilogue for NF nodes of ONE question in one pass over the image's conv_image map:
+//   att_f[r] = l2norm_c(M[r,c] * tmap_f[c]) . w_e + b_e     (nmn3_modules.py:104-108; Filter's
+// find_result :129).  The nodes share the FindModule weights and the map (153.6 KB) and differ only
+// in the text map, so a layout with three Find-type nodes streams the map once instead of three
+// times.  One wave per row, all rows of a wave in flight.
+template <int CI, int NF>
+__device__ __forceinline__ void walk_find_pass(int tid, const ModuleWeights& w, const float* Mbuf,
+                                               const float* const* ts, float* const* os, int HW,
+                                               int Mp) {
+  const int lane = tid & 63, wid = tid >> 6;
+  const float be = w.be[0][0];
+  float4 t4[NF][CI], e4[CI];
+#pragma unroll
+  for (int i = 0; i < CI; ++i) {
+    const int c = 4 * lane + 256 * i;
+    const bool ok = c < Mp;
+    e4[i] = ok ? *reinterpret_cast<const float4*>(w.we[0] + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+      t4[j][i] = ok ? *reinterpret_cast<const float4*>(ts[j] + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  constexpr int UNR = CI == 1 ? 19 : (CI == 2 ? 10 : 5);
+  for (int rb = wid; rb < HW; rb += UNR * WW) {
+    float4 m4[UNR][CI];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const unsigned r = (unsigned)min(rb + u * WW, HW - 1);
+#pragma unroll
+      for (int i = 0; i < CI; ++i) {
+        const unsigned c = (unsigned)min(4 * lane + 256 * i, Mp - 4);
+        m4[u][i] = *reinterpret_cast<const float4*>(Mbuf + (r * (unsigned)Mp + c));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int r = rb + u * WW;
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        float ss = 0.f, dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < CI; ++i) {
+          const float p0 = m4[u][i].x * t4[j][i].x, p1 = m4[u][i].y * t4[j][i].y,
+                      p2 = m4[u][i].z * t4[j][i].z, p3 = m4[u][i].w * t4[j][i].w;
+          ss += p0 * p0 + p1 * p1 + p2 * p2 + p3 * p3;
+          dot += p0 * e4[i].x + p1 * e4[i].y + p2 * e4[i].z + p3 * e4[i].w;
+        }
+        const float s2 = wave_sum(ss);
+        const float d2 = wave_sum(dot);
+        if (lane == 0 && r < HW) os[j][r] = d2 / sqrtf(fmaxf(s2, 1e-12f)) + be;
+      }
+    }
+  }
+}
+
 template <int CI>
 __global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -438,7 +513,12 @@ __global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
       nn = t + 1;
     }
     if (ok && (sp != 1 || !(L.op[L.stack[0]] & 0x100))) ok = 0;  // stack size / result type
-    L.n_nodes = nn; L.valid = ok;
+    int nf = 0;
+    for (int t = 0; ok && t < nn; ++t) {
+      const int o = L.op[t] & 0xff;
+      if (o == N2NMN_OP_FIND || o == N2NMN_OP_FILTER) L.flist[nf++] = t;
+    }
+    L.n_nodes = nn; L.valid = ok; L.n_find = nf;
   }
   __syncthreads();
   float* srow = B.scores + (size_t)n * C;
@@ -454,9 +534,10 @@ __global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
       const int o = L.op[t] & 0xff;
       const bool f = o == N2NMN_OP_FIND || o == N2NMN_OP_FILTER || o == N2NMN_OP_FIND_SAME_PROPERTY;
       const bool p = o == N2NMN_OP_FIND_SAME_PROPERTY || o == N2NMN_OP_SAME_PROPERTY || o == N2NMN_OP_DESCRIBE;
-      cf += f; cp += p; cpi += p ? (o == N2NMN_OP_SAME_PROPERTY ? 2 : 1) : 0;
+      cf += o == N2NMN_OP_FIND_SAME_PROPERTY; cp += p;      // cf: conv_image map READS (see below) cpi += p ? (o == N2NMN_OP_SAME_PROPERTY ? 2 : 1) : 0;
       ct += (f || p || o == N2NMN_OP_TRANSFORM); ctr += o == N2NMN_OP_TRANSFORM;
     }
+    cf += (unsigned long long)((L.n_find + 3) / 4);      // Find / Filter nodes share one pass per 4
     atomicAdd(a.stats + 0, cf); atomicAdd(a.stats + 1, cpi); atomicAdd(a.stats + 2, cp);
     atomicAdd(a.stats + 3, ct); atomicAdd(a.stats + 4, ctr); atomicAdd(a.stats + 5, 1ull);
   }
@@ -519,6 +600,29 @@ __global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
   const int ncol = D / 4, nrow = WT / ncol;
   constexpr int PR = WALK_POOL_ROWS;
 
+  // ---- Find / Filter epilogues of the whole question in ONE pass over the image's conv_image map
+  // (walk_find_pass), off the dependent chain
+  {
+    const float* Mbuf = B.mfind + (size_t)n * HW * Mp;
+    for (int f0 = 0; f0 < L.n_find; f0 += 4) {
+      const int nf = min(4, L.n_find - f0);
+      const float* ts[4];
+      float* os[4];
+      for (int j = 0; j < 4; ++j) {
+        const int t = L.flist[f0 + min(j, nf - 1)];
+        ts[j] = a.T_enc > 0 ? tmaps + (size_t)t * Mp : B.tmap + ((size_t)t * a.N + n) * Mp;
+        os[j] = arena + (size_t)t * HWp;
+      }
+      switch (nf) {
+        case 1: walk_find_pass<CI, 1>(tid0, w, Mbuf, ts, os, HW, Mp); break;
+        case 2: walk_find_pass<CI, 2>(tid0, w, Mbuf, ts, os, HW, Mp); break;
+        case 3: walk_find_pass<CI, 3>(tid0, w, Mbuf, ts, os, HW, Mp); break;
+        default: walk_find_pass<CI, 4>(tid0, w, Mbuf, ts, os, HW, Mp); break;
+      }
+    }
+    __syncthreads();
+  }
+
   // ---- 2. nodes in token order -------------------------------------------------------------
   for (int t = 0; t < nn; ++t) {
     // every per-thread index below derives from this opaque copy, so the compiler cannot hoist the
@@ -550,7 +654,7 @@ __global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
       for (int c = 4 * tid; c < Mp; c += 4 * WT)
         *reinterpret_cast<float4*>(tml + c) = *reinterpret_cast<const float4*>(src + c);
     }
-    if (tl && tid0 == 0) tl[1] = clock64();
+    if (tl && tid0 == 0 && op != N2NMN_OP_TRANSFORM) tl[1] = clock64();
     if (pools) {
       // the feature rows of this thread do not depend on the softmax: all of its 16-B loads go out
       // first (the whole [HW, D] map of the question is in flight at once) and land while the
@@ -616,7 +720,7 @@ __global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
     }
 
     __syncthreads();
-    if (tl && tid0 == 0) tl[2] = clock64();
+    if (tl && tid0 == 0 && op != N2NMN_OP_TRANSFORM) tl[2] = clock64();
     switch (op) {
       case N2NMN_OP_SCENE:                                       // :60-72
         for (int r = tid; r < HW; r += WT) outp[r] = 3.0f;
@@ -627,12 +731,15 @@ __global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
       case N2NMN_OP_OR:                                          // :238-256
         for (int r = tid; r < HW; r += WT) outp[r] = fmaxf(in0[r], in1[r]);
         break;
-      case N2NMN_OP_FIND:
-      case N2NMN_OP_FILTER:
+      case N2NMN_OP_FIND:                                        // done in the pre-pass
+        break;
+      case N2NMN_OP_FILTER:                                      // And(input_0, find_result) :129-130
+        for (int r = tid; r < HW; r += WT) outp[r] = fminf(in0[r], outp[r]);
+        break;
       case N2NMN_OP_FIND_SAME_PROPERTY: {
         // att[r] = l2norm_c(M[r,c] * tmap[c] (* amap[c])) . w_e + b_e  [min with input_0: Filter]
         // (:104-108, :129-130, :178-180); one wave per row, all rows of a wave in flight
-        const bool fsp = op == N2NMN_OP_FIND_SAME_PROPERTY;
+        constexpr bool fsp = true;
         const int wsel = fsp ? 1 : 0;
         const float* Mbuf = (fsp ? B.mfsp : B.mfind) + (size_t)n * HW * Mp;
         const float be = w.be[wsel][0];
@@ -678,7 +785,6 @@ __global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
             const float d2 = wave_sum(dot);
             if (lane == 0 && r < HW) {
               float att = d2 / sqrtf(fmaxf(s2, 1e-12f)) + be;     // tf.nn.l2_normalize eps (A.4)
-              if (op == N2NMN_OP_FILTER) att = fminf(in0[r], att);  // Filter = And(input_0, Find)
               outp[r] = att;
             }
           }
@@ -686,8 +792,8 @@ __global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
         break;
       }
       case N2NMN_OP_TRANSFORM:                                   // :185-216
-        if (a.ksize == 5) walk_transform<5>(tid, w, a, in0, tml, outp, scr);
-        else walk_transform<3>(tid, w, a, in0, tml, outp, scr);
+        if (a.ksize == 5) walk_transform<5>(tid, w, a, in0, tml, outp, scr, tl);
+        else walk_transform<3>(tid, w, a, in0, tml, outp, scr, tl);
         break;
       case N2NMN_OP_DESCRIBE:                                    // :479-493
       case N2NMN_OP_SAME_PROPERTY: {                             // :424-450
