@@ -34,6 +34,8 @@ struct GemmArgs {
   int gate_T, gate_N, gate_V, gate_op, gate_rows;
 };
 void launch_gemm_pk(const GemmArgs& a, hipStream_t s);
+// two problems (no split-K) in one launch
+void launch_gemm_pk2(const GemmArgs& a0, const GemmArgs& a1, hipStream_t s);
 
 // generic packer: dst PK layout <- src[k*ld + n] (k < K, n < N), zero padded
 void launch_pack_pk(const float* src, int ld, int K, int N, float* dst, int Kp, int Np,
@@ -152,8 +154,9 @@ void launch_dec_attn(const DecStepArgs& a, int nsteps, hipStream_t s);
 
 void launch_dec_init(int32_t* state, int N, int T_dec, hipStream_t s);
 // perm = rows sorted by decreasing length (stable); n_active[t] = #{n : seq_len[n] > t}, t < T
+// also zeroes `zero_floats` floats at `zero` (multiple of 4; the recurrent state block) in the same launch
 void launch_enc_prepare(const int32_t* seq_len, int N, int T, int32_t* perm, int32_t* n_active,
-                        hipStream_t s);
+                        float* zero, size_t zero_floats, hipStream_t s);
 
 // word_vecs[t][n][:] = sum_tau atts[t][tau][n] * emb[seq[tau][n]][:];  log_seq_prob
 void launch_word_vecs(const float* atts, const int32_t* seq, const float* emb, int T_dec,

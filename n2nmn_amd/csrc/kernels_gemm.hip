@@ -30,7 +30,7 @@ namespace {
 constexpr int BM = 64, BN = 64, BK = 32;
 constexpr int LDS_STRIDE = BM + 1;   // in float4 units
 
-__global__ __launch_bounds__(256) void gemm_pk_kernel(GemmArgs a) {
+__device__ __forceinline__ void gemm_pk_body(const GemmArgs& a, const int bz) {
   __shared__ float4 As[2][BK / 4][LDS_STRIDE];
   __shared__ float4 Bs[2][BK / 4][LDS_STRIDE];
 
@@ -73,12 +73,12 @@ __global__ __launch_bounds__(256) void gemm_pk_kernel(GemmArgs a) {
   const float4* b_ptr0 = reinterpret_cast<const float4*>(a.Bp) + (size_t)b_k40 * a.Np + n0 + b_n0;
   const float4* b_ptr1 = reinterpret_cast<const float4*>(a.Bp) + (size_t)b_k41 * a.Np + n0 + b_n1;
 
-  // split-K (ksplit > 1, accumulate only): blockIdx.z owns a contiguous range of k-tiles and adds
+  // split-K (ksplit > 1, accumulate only): bz owns a contiguous range of k-tiles and adds
   // its partial tile atomically -- for the skinny NT products of the backward pass ([V,4L].[4L,E])
   int ktb = 0, nkt = a.Kp / BK;
   if (a.ksplit > 1) {
     const int per = (nkt + a.ksplit - 1) / a.ksplit;
-    ktb = blockIdx.z * per;
+    ktb = bz * per;
     nkt = min(per, nkt - ktb);
     if (nkt <= 0) return;
   }
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void gemm_pk_kernel(GemmArgs a) {
   // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int col = n0 + wn * 32 + li;
   if (col < a.n_store) {
-    const float bias = (a.bias && col < a.N && blockIdx.z == 0) ? a.bias[col] : 0.f;
+    const float bias = (a.bias && col < a.N && bz == 0) ? a.bias[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
@@ -168,6 +168,17 @@ __global__ __launch_bounds__(256) void gemm_pk_kernel(GemmArgs a) {
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void gemm_pk_kernel(GemmArgs a) { gemm_pk_body(a, blockIdx.z); }
+
+// two independent problems of the same tile shape in one launch (blockIdx.z selects): the hoisted
+// conv_image GEMMs of FindModule and (token-gated) FindSamePropertyModule share one grid, so the
+// gated problem's few live tiles fill the first problem's tail instead of paying a launch of their own
+__global__ __launch_bounds__(256) void gemm_pk2_kernel(GemmArgs a0, GemmArgs a1) {
+  const GemmArgs a = blockIdx.z == 0 ? a0 : a1;
+  if ((int)blockIdx.y * BM >= a.M || (int)blockIdx.x * BN >= a.Np) return;
+  gemm_pk_body(a, 0);
 }
 
 __global__ void pack_pk_kernel(const float* __restrict__ src, int ld, int K, int N,
@@ -299,6 +310,12 @@ void launch_pad_rows(const float* src, int R, int M, float* dst, int Mp, hipStre
   const size_t total = (size_t)R * Mp;
   const int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
   hipLaunchKernelGGL(pad_rows_kernel, dim3(blocks), dim3(256), 0, s, src, R, M, dst, Mp);
+}
+
+void launch_gemm_pk2(const GemmArgs& a0, const GemmArgs& a1, hipStream_t s) {
+  const int gx = std::max((a0.n_store + BN - 1) / BN, (a1.n_store + BN - 1) / BN);
+  const int gy = std::max((a0.M + BM - 1) / BM, (a1.M + BM - 1) / BM);
+  hipLaunchKernelGGL(gemm_pk2_kernel, dim3(gx, gy, 2), dim3(256), 0, s, a0, a1);
 }
 
 void launch_gemm_pk(const GemmArgs& a, hipStream_t s) {

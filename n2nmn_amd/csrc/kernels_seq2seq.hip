@@ -692,7 +692,7 @@ __global__ __launch_bounds__(256) void dec_attn_multi_kernel(DecStepArgs a, int 
         q4[j][i] = *reinterpret_cast<const float4*>(a.q + ((size_t)(ts0 + jj) * N + n) * L + k);
       }
     }
-    constexpr int UNR = 2;
+    constexpr int UNR = TS <= 2 ? 6 : 3;     // encoder rows of a wave in flight
     for (int j0 = 0; j0 * NW + w < T; j0 += UNR) {
       float4 e4[UNR][KI];
 #pragma unroll
@@ -819,22 +819,34 @@ __global__ __launch_bounds__(256) void dec_attn_multi_kernel(DecStepArgs a, int 
   }
 }
 
-// perm[rank] = n with rows ranked by decreasing length (ties by index); n_active[t] = #{len > t}
-__global__ void enc_prepare_kernel(const int32_t* __restrict__ seq_len, int N, int T,
-                                   int32_t* __restrict__ perm, int32_t* __restrict__ n_active) {
+// perm[rank] = n with rows ranked by decreasing length (ties by index); n_active[t] = #{len > t}.
+// The same launch clears the recurrent state block (a separate memset node costs ~5 us on the
+// stream): workgroup 0 ranks, every workgroup zeroes its slice.
+constexpr int PREP_MAXN = 1024;
+__global__ __launch_bounds__(256) void enc_prepare_kernel(const int32_t* __restrict__ seq_len,
+                                                          int N, int T, int32_t* __restrict__ perm,
+                                                          int32_t* __restrict__ n_active,
+                                                          float4* __restrict__ zero, size_t zero4) {
   const int tid = threadIdx.x;
-  for (int i = tid; i < N; i += blockDim.x) {
-    const int li = seq_len[i];
+  for (size_t i = (size_t)blockIdx.x * 256 + tid; i < zero4; i += (size_t)gridDim.x * 256)
+    zero[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (blockIdx.x != 0) return;
+  __shared__ int lens[PREP_MAXN];
+  for (int i = tid; i < N && i < PREP_MAXN; i += 256) lens[i] = seq_len[i];
+  __syncthreads();
+  const bool in_lds = N <= PREP_MAXN;
+  for (int i = tid; i < N; i += 256) {
+    const int li = in_lds ? lens[i] : seq_len[i];
     int rank = 0;
     for (int j = 0; j < N; ++j) {
-      const int lj = seq_len[j];
+      const int lj = in_lds ? lens[j] : seq_len[j];
       rank += (lj > li) || (lj == li && j < i);
     }
     perm[rank] = i;
   }
-  for (int t = tid; t < T; t += blockDim.x) {
+  for (int t = tid; t < T; t += 256) {
     int c = 0;
-    for (int j = 0; j < N; ++j) c += seq_len[j] > t;
+    for (int j = 0; j < N; ++j) c += (in_lds ? lens[j] : seq_len[j]) > t;
     n_active[t] = c;
   }
 }
@@ -1039,8 +1051,11 @@ void launch_dec_attn(const DecStepArgs& a, int nsteps, hipStream_t s) {
 }
 
 void launch_enc_prepare(const int32_t* seq_len, int N, int T, int32_t* perm, int32_t* n_active,
-                        hipStream_t s) {
-  hipLaunchKernelGGL(enc_prepare_kernel, dim3(1), dim3(256), 0, s, seq_len, N, T, perm, n_active);
+                        float* zero, size_t zero_floats, hipStream_t s) {
+  const size_t z4 = zero_floats / 4;             // the state block is a multiple of 4 floats
+  const int blocks = zero ? (int)std::min<size_t>(256, (z4 + 1023) / 1024 + 1) : 1;
+  hipLaunchKernelGGL(enc_prepare_kernel, dim3(blocks), dim3(256), 0, s, seq_len, N, T, perm, n_active,
+                     reinterpret_cast<float4*>(zero), zero ? z4 : 0);
 }
 
 void launch_dec_init(int32_t* state, int N, int T_dec, hipStream_t s) {
