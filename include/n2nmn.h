@@ -267,6 +267,12 @@ typedef struct {
  * n2nmn_conv_image (events). */
 int n2nmn_walk_layouts(n2nmn_ctx *ctx, const n2nmn_walk_batch *batches, int K, int T_dec,
                        int T_enc /* only with atts */, int N, n2nmn_stream stream);
+/* Where the answer operators that pool image features (_Describe, _SameProperty: always the root of a
+ * layout) run.  0: inside the walker (lowest single-batch latency).  1: the walker only computes
+ * their soft-max weights, and two chip-wide launches follow: the attention-weighted feature sums
+ * of all such questions (8 workgroups per question: the HBM-bound kernel of the attention-module
+ * path), then fc_att + answer head.  -1 (default): 1 when a launch carries >= 128 questions. */
+int n2nmn_walk_set_defer_pool(n2nmn_ctx *ctx, int mode);
 /* single batch: n2nmn_conv_image(FIND | FSP gated by tokens) + n2nmn_walk_layouts(K = 1) */
 int n2nmn_execute_tokens(n2nmn_ctx *ctx, const int32_t *tokens, int T_dec, int N,
                          const float *image_feat, const float *word_vecs, float *scores,
@@ -414,6 +420,11 @@ int n2nmn_debug_colsum(n2nmn_ctx *ctx, const float *src, int R, int ncols, int l
 /* Mean HIP-event-pair time (us) around an EMPTY kernel on `stream`: the fixed cost every entry of the
  * n2nmn_profile_* table carries on top of its kernel's duration. */
 int n2nmn_debug_event_overhead(n2nmn_ctx *ctx, int iters, double *us_pair, n2nmn_stream stream);
+/* Re-launch one kernel of the LAST n2nmn_walk_layouts call `iters` times back to back inside one HIP
+ * event pair (which: 0 walker, 1 deferred pooling kernel, 2 heads kernel) and return the average
+ * microseconds per launch: the live duration the roofline of short kernels is computed from (an
+ * event pair around a single ~5 us launch reads ~4 us too much).  Inputs must still be alive. */
+int n2nmn_debug_walk_replay(n2nmn_ctx *ctx, int which, int iters, double *us_avg, n2nmn_stream stream);
 /* Debugging: when timeline_dev != NULL every following walker launch of this context stamps the
  * shader clock of thread 0 at the phase boundaries of each node into
  * timeline_dev[question][32][4] (int64: start, after text map, after pooling + fc_att, end). */

@@ -95,6 +95,7 @@ SYMBOLS = [
     ('n2nmn_module_forward', _I, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     ('n2nmn_set_token_ops', _I, [_P, _P, _I]),
     ('n2nmn_walk_supported', _I, [_P]),
+    ('n2nmn_walk_set_defer_pool', _I, [_P, _I]),
     ('n2nmn_conv_image', _I, [_P, _P, _I, _I, _P, _I, _P]),
     ('n2nmn_walk_layouts', _I, [_P, C.POINTER(WalkBatch), _I, _I, _I, _I, _P]),
     ('n2nmn_execute_tokens', _I, [_P, _P, _I, _I, _P, _P, _P, _P, _P]),
@@ -121,6 +122,7 @@ SYMBOLS = [
     ('n2nmn_debug_gemm_tn', _I, [_P, _P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P]),
     ('n2nmn_debug_colsum', _I, [_P, _P, _I, _I, _I, _P, _I, _P, _P]),
     ('n2nmn_debug_event_overhead', _I, [_P, _I, C.POINTER(C.c_double), _P]),
+    ('n2nmn_debug_walk_replay', _I, [_P, _I, _I, C.POINTER(C.c_double), _P]),
     ('n2nmn_debug_walk_timeline', _I, [_P, _P]),
     ('n2nmn_debug_gemm', _I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
 ]

@@ -215,6 +215,11 @@ static size_t carve_workspace(n2nmn_ctx* c, char* base) {
   c->dev_tab = k.take<int32_t>(c->max_tab);
   c->walk_stats = k.take<unsigned long long>(WALK_STATS);
   c->wtmap = k.take<float>(Td * N * Mp);
+  c->wpjob = k.take<int32_t>(N);
+  c->wpw = k.take<float>(N * 2 * HWp);
+  c->wptm = k.take<float>(N * Mp);
+  c->wpooled = k.take<float>(N * 2 * (size_t)d.D);
+  c->wpfc = k.take<float>(N * 2 * WALK_POOL_PARTS * Mp);
   return align_up(k.off, 256);
 }
 
@@ -1004,6 +1009,12 @@ int n2nmn_set_token_ops(n2nmn_ctx* ctx, const int32_t* token_op_host, int V) {
   return N2NMN_OK;
 }
 
+int n2nmn_walk_set_defer_pool(n2nmn_ctx* c, int mode) {
+  N2_REQUIRE(c && mode >= -1 && mode <= 1, N2NMN_EINVAL, "walk_set_defer_pool: mode is -1, 0 or 1");
+  c->walk_defer_pool = mode;
+  return N2NMN_OK;
+}
+
 int n2nmn_walk_supported(const n2nmn_ctx* c) {
   if (!c) return 0;
   const n2nmn_dims& d = c->d;
@@ -1089,6 +1100,8 @@ int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int
     a.b[k].tokens = b.tokens; a.b[k].feat = b.image_feat; a.b[k].word_vecs = b.word_vecs;
     a.b[k].scores = b.scores; a.b[k].validity = b.validity;
     a.b[k].mfind = owner->mfind; a.b[k].mfsp = owner->mfsp; a.b[k].tmap = owner->wtmap;
+    a.b[k].pjob = owner->wpjob; a.b[k].pw = owner->wpw; a.b[k].ptm = owner->wptm;
+    a.b[k].pooled = owner->wpooled; a.b[k].pfc = owner->wpfc;
   }
   a.K = K; a.N = N; a.T = T_dec; a.V = d.num_vocab_nmn; a.token_op = root(c)->token_op;
   a.H = d.H; a.W = d.W; a.D = d.D; a.M = d.map_dim; a.Mp = c->Mp; a.HWp = c->HWp;
@@ -1106,9 +1119,25 @@ int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int
     ProfScope ps(c, F_TEXTMAP, 0.0, 4.0 * 5 * dE * dM, s);
     launch_walk_textmap(w, a, s);
   }
+  // throughput mode (>= 128 questions in the launch, or forced by the mode switch): the pooling
+  // answer operators leave the walker and run as chip-wide launches of their own
+  const int dp_env = c->walk_defer_pool;
+  a.defer_pool = (dp_env < 0 ? K * N >= 128 : dp_env > 0) && walk_pool_supported(d.H, d.W, d.D);
   {
     ProfScope ps(c, F_WALK, 0.0, 0.0, s);     // work filled in from the device counters
     launch_walk(w, a, s);
+  }
+  c->last_walk = a;
+  c->have_last_walk = true;
+  if (a.defer_pool) {
+    {
+      ProfScope ps(c, F_POOL, 0.0, 0.0, s);   // jobs are counted on the device (walk stats [6], [7])
+      launch_walk_pool(w, a, s);
+    }
+    {
+      ProfScope ps(c, F_HEADS, 0.0, 0.0, s);
+      launch_walk_heads(w, a, s);
+    }
   }
   return check_launch("walk_layouts");
 }
@@ -1135,6 +1164,34 @@ int n2nmn_debug_event_overhead(n2nmn_ctx* c, int iters, double* us_pair, n2nmn_s
   for (auto& e : ev) (void)hipEventDestroy(e);
   *us_pair = 1e3 * tot / iters;
   return N2NMN_OK;
+}
+
+int n2nmn_debug_walk_replay(n2nmn_ctx* c, int which, int iters, double* us_avg, n2nmn_stream stream) {
+  N2_REQUIRE(c && us_avg && iters >= 1 && iters <= 10000, N2NMN_EINVAL, "debug_walk_replay: bad argument");
+  N2_REQUIRE(c->have_last_walk, N2NMN_EINVAL, "debug_walk_replay: no walker launch to replay");
+  N2_REQUIRE(which == 0 || c->last_walk.defer_pool, N2NMN_EINVAL,
+             "debug_walk_replay: the last launch did not defer its pooling jobs");
+  hipStream_t s = S(stream);
+  ModuleWeights w = module_weights(c);
+  WalkArgs a = c->last_walk;
+  a.stats = nullptr; a.timeline = nullptr;
+  hipEvent_t e0, e1;
+  N2_HIP(hipEventCreate(&e0)); N2_HIP(hipEventCreate(&e1));
+  auto one = [&]() {
+    if (which == 0) launch_walk(w, a, s);
+    else if (which == 1) launch_walk_pool(w, a, s);
+    else launch_walk_heads(w, a, s);
+  };
+  for (int i = 0; i < 3; ++i) one();
+  N2_HIP(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i) one();
+  N2_HIP(hipEventRecord(e1, s));
+  N2_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  N2_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  *us_avg = 1e3 * ms / iters;
+  return check_launch("debug_walk_replay");
 }
 
 int n2nmn_debug_walk_timeline(n2nmn_ctx* c, long long* timeline_dev) {
@@ -1232,6 +1289,18 @@ int n2nmn_profile_end(n2nmn_ctx* ctx, n2nmn_stream stream) {
                                ctx->prof_launches[F_WALK] * 4.0 * (5 * E * M + 4 * D * M);
     ctx->prof_flops[F_WALK] += n_find * 5.0 * HW * M + n_pool_in * (2.0 * HW * D + 2.0 * D * M) +
                                n_text * 2.0 * E * M + n_tr * HW * M * (2.0 * KK + 5.0);
+    // pooling jobs the walker handed to walk_pool_kernel: their feature read belongs to that kernel
+    const double n_def = (double)st[6], n_def_in = (double)st[7];
+    if (n_def > 0) {
+      const double fb = 4.0 * (n_def * HW * D + n_def_in * (HW + D));
+      ctx->prof_bytes[F_WALK] -= 4.0 * (n_def * HW * D + n_def_in * HW);
+      ctx->prof_bytes[F_POOL] += fb;
+      ctx->prof_flops[F_POOL] += n_def_in * 2.0 * HW * D;
+      ctx->prof_flops[F_WALK] -= n_def_in * (2.0 * HW * D + 2.0 * D * M);
+      ctx->prof_flops[F_HEADS] += n_def_in * 2.0 * D * M + n_def * 2.0 * M * C;
+      ctx->prof_bytes[F_HEADS] += 4.0 * (n_def_in * (D + D * M) + n_def * (M * C + C));
+    }
+    ctx->walk_jobs_deferred = n_def;
   }
   return (int)ctx->prof_recs.size();
 }

@@ -174,6 +174,8 @@ struct n2nmn_ctx {
 
   // module workspace
   float* wtmap = nullptr;                  // [T_dec][N][Mp] text maps of the walker path
+  // deferred pooling of the walker path: job code, soft-max weights, text map, pooled features
+  int32_t* wpjob = nullptr; float *wpw = nullptr, *wptm = nullptr, *wpooled = nullptr, *wpfc = nullptr;
   float *arena = nullptr, *tmap = nullptr, *pfc = nullptr, *mfind = nullptr, *mfsp = nullptr;
   float* ev_out = nullptr;
   int32_t* ev_rows = nullptr;
@@ -195,6 +197,10 @@ struct n2nmn_ctx {
   std::vector<ProfRec> prof_recs;
   double prof_ms[24] = {0}, prof_flops[24] = {0}, prof_bytes[24] = {0};
   long prof_launches[24] = {0};
+  WalkArgs last_walk{};                       // arguments of the last walker launch (debug replay)
+  bool have_last_walk = false;
+  int walk_defer_pool = -1;                   // -1 auto (>= 128 questions per launch), 0 never, 1 always
+  double walk_jobs_deferred = 0;              // pooling jobs of the last profiled passes
   long long* walk_timeline = nullptr;         // n2nmn_debug_walk_timeline (caller-owned)
   unsigned long long* walk_stats = nullptr;   // device [WALK_STATS]: node counts of profiled walks
 };

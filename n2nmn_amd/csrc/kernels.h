@@ -211,6 +211,8 @@ constexpr int WALK_THREADS = 512;
 constexpr int WALK_POOL_ROWS = 38;   // feature rows a thread keeps in flight (H*W / (512 / (D/4)))
 constexpr int WALK_MAX_T = 32;
 constexpr int WALK_MAX_BATCHES = 16;
+constexpr int WALK_POOL_PARTS = 8;    // channel parts of a deferred pooling job (walk_pool_kernel)
+constexpr int WALK_POOLK_ROWS = 10;   // feature rows a walk_pool_kernel thread keeps in flight
 constexpr int WALK_MAX_PIXEL_GROUPS = 3;   // H*W <= 192 (64-pixel groups a Transform wave holds)
 struct WalkBatch {
   const int32_t* tokens;   // [T][N] layout tokens (decoder output or ground truth), device
@@ -222,6 +224,10 @@ struct WalkBatch {
   const float* mfsp;       // [N][HW][Mp] conv_image maps, FindSamePropertyModule weights (only the
                            // images whose layout has a _FindSameProperty token are filled in)
   float* tmap;             // [T][N][Mp] text maps (walk_textmap_kernel fills the rows that are read)
+  // deferred pooling (WalkArgs::defer_pool): per question job code (0 none / op), soft-max weights
+  // [N][2][HWp], text map [N][Mp], pooled features [N][2][D]
+  int32_t* pjob; float* pw; float* ptm; float* pooled;
+  float* pfc;              // [N][2][WALK_POOL_PARTS][Mp] partial fc_att rows of the deferred jobs
   // attention-table text maps (T_enc > 0): word_vecs / tmap unused
   const float* atts;       // [T][T_enc][N]
   const int32_t* seq;      // [T_enc][N]
@@ -232,6 +238,7 @@ struct WalkArgs {
   int K, N, T, V;
   const int32_t* token_op; // [V] device: op code of each layout token, -1 for <eos>
   int H, W, D, M, Mp, HWp, E, C, ksize;
+  int defer_pool;          // root Describe / SameProperty -> walk_pool_kernel + walk_heads_kernel
   int T_enc, V_txt;        // T_enc > 0: text maps from ew[ws][seq] weighted by atts
   const float* ew[5];      // [V_txt][Mp] embedding_mat . W_txt[ws]
   // profiling only: [0] conv_image map reads (one per <= 4 Find / Filter nodes of a question, one per
@@ -247,6 +254,9 @@ int walk_supported(int H, int W, int D, int M, int Mp, int HWp, int E, int C, in
                    int T_enc);
 void launch_walk_textmap(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
 void launch_walk(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
+void launch_walk_pool(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
+void launch_walk_heads(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
+int walk_pool_supported(int H, int W, int D);
 
 // out[n,h,w,:] = [feat[n,h,w,:D0], linspace(-1,1,W)[w], linspace(-1,1,H)[h], 0 ...]
 void launch_add_coords(const float* feat, int N, int H, int W, int D0, int D, float* out,

@@ -523,6 +523,7 @@ __global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
   __syncthreads();
   float* srow = B.scores + (size_t)n * C;
   if (tid0 == 0 && B.validity) B.validity[n] = L.valid;
+  if (tid0 == 0 && a.defer_pool) B.pjob[n] = 0;
   if (!L.valid) {                                                // INVALID_EXPR: zero logits
     for (int c = tid0; c < C; c += WT) srow[c] = 0.f;
     return;
@@ -540,6 +541,12 @@ __global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
     cf += (unsigned long long)((L.n_find + 3) / 4);      // Find / Filter nodes share one pass per 4
     atomicAdd(a.stats + 0, cf); atomicAdd(a.stats + 1, cpi); atomicAdd(a.stats + 2, cp);
     atomicAdd(a.stats + 3, ct); atomicAdd(a.stats + 4, ctr); atomicAdd(a.stats + 5, 1ull);
+    if (a.defer_pool && nn > 0) {
+      const int ro = L.op[nn - 1] & 0xff;
+      if (ro == N2NMN_OP_DESCRIBE || ro == N2NMN_OP_SAME_PROPERTY) {
+        atomicAdd(a.stats + 6, 1ull); atomicAdd(a.stats + 7, ro == N2NMN_OP_SAME_PROPERTY ? 2ull : 1ull);
+      }
+    }
   }
   const float* feat = B.feat + (size_t)n * HW * D;
   int qlen = 0;
@@ -655,6 +662,28 @@ __global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
         *reinterpret_cast<float4*>(tml + c) = *reinterpret_cast<const float4*>(src + c);
     }
     if (tl && tid0 == 0 && op != N2NMN_OP_TRANSFORM) tl[1] = clock64();
+    // throughput mode: the answer operators that pool (Describe / SameProperty, always the root) only
+    // compute their soft-max weights here; the feature stream, fc_att and the answer head of ALL
+    // such questions of the launch run chip-wide in walk_pool_kernel / walk_heads_kernel
+    const bool defer = a.defer_pool && pools && op != N2NMN_OP_FIND_SAME_PROPERTY;
+    if (defer) {
+      const int nin = op == N2NMN_OP_SAME_PROPERTY ? 2 : 1;
+      float* pw = B.pw + (size_t)n * 2 * HWp;
+      for (int i = 0; i < nin; ++i) {                  // :432-437,482-484
+        const float* src = i == 0 ? in0 : in1;
+        float lm = -INFINITY;
+        for (int r = tid; r < HW; r += WT) lm = fmaxf(lm, src[r]);
+        const float mx = wg_reduce<1>(lm, rs);
+        float ls = 0.f;
+        for (int r = tid; r < HW; r += WT) ls += expf(src[r] - mx);
+        const float sum = wg_reduce<0>(ls, rs);
+        for (int r = tid; r < HW; r += WT) pw[i * HWp + r] = expf(src[r] - mx) / sum;
+      }
+      float* ptm = B.ptm + (size_t)n * Mp;
+      for (int c = tid; c < Mp; c += WT) ptm[c] = tml[c];
+      if (tid == 0) B.pjob[n] = op;
+      break;                                           // the root is the last node
+    }
     if (pools) {
       // the feature rows of this thread do not depend on the softmax: all of its 16-B loads go out
       // first (the whole [HW, D] map of the question is in flight at once) and land while the
@@ -861,6 +890,146 @@ __global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
 }
 
 }  // namespace
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// Deferred attention pooling (throughput mode): f_i = sum_hw a_i[hw] * feat[n, hw, :] for the
+// questions whose root is Describe / SameProperty (nmn3_modules.py:438-441,485-486) -- THE HBM-bound
+// kernel of the attention-module path: the [H*W, D] feature map (307 KB at CLEVR dims) is read once
+// per question (both inputs of SameProperty from the same read) and nothing else moves.
+// One workgroup per (channel part, question): POOLP parts of D / POOLP channels, so a launch with J
+// jobs puts POOLP * J workgroups on the chip (a batch of 64 questions alone would be ~25 jobs; the
+// super-bucket brings it to hundreds).  All feature loads of a thread are issued before the soft-max
+// weights are read.  Questions without such a root exit after one 4-byte read.
+// ---------------------------------------------------------------------------------------------
+constexpr int POOLP = WALK_POOL_PARTS;
+__global__ __launch_bounds__(256) void walk_pool_kernel(WalkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int part = blockIdx.x, q = blockIdx.y;
+  const int kb = q / a.N, n = q - kb * a.N;
+  const WalkBatch& B = a.b[kb];
+  const int op = B.pjob[n];
+  if (op == 0) return;
+  const int HW = a.H * a.W, D = a.D, HWp = a.HWp;
+  const int Dp = D / POOLP, ncol = Dp / 4, nrow = 256 / ncol;
+  const int tid = threadIdx.x, lc = tid % ncol, lr = tid / ncol;
+  const int nin = op == N2NMN_OP_SAME_PROPERTY ? 2 : 1;
+  constexpr int PR = WALK_POOLK_ROWS;
+  const float* fp = B.feat + (size_t)n * HW * D + part * Dp + 4 * lc;
+  const int myrows = lr < nrow ? (HW - lr + nrow - 1) / nrow : 0;
+  float4 fr[PR];
+  {
+    const unsigned rowstep = (unsigned)(nrow * D);
+    unsigned off = (unsigned)(lr * D);
+    const unsigned last = (unsigned)((myrows > 0 ? lr + (myrows - 1) * nrow : 0) * D);
+#pragma unroll
+    for (int qq = 0; qq < PR; ++qq) {
+      fr[qq] = *reinterpret_cast<const float4*>(fp + min(off, last));
+      off += rowstep;
+    }
+  }
+  float* a0 = smem;                      // [HWp]
+  float* a1 = a0 + HWp;                  // [HWp]
+  float* stage = a1 + HWp;               // [nrow][2][Dp]
+  const float* pw = B.pw + (size_t)n * 2 * HWp;
+  for (int r = tid; r < HW; r += 256) {
+    a0[r] = pw[r];
+    a1[r] = nin == 2 ? pw[HWp + r] : 0.f;
+  }
+  __syncthreads();
+  float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
+  if (lr < nrow) {
+#pragma unroll
+    for (int qq = 0; qq < PR; ++qq) {
+      if (qq < myrows) {
+        const int r = lr + qq * nrow;
+        const float w0 = a0[r], w1 = a1[r];
+        acc0.x += w0 * fr[qq].x; acc0.y += w0 * fr[qq].y; acc0.z += w0 * fr[qq].z; acc0.w += w0 * fr[qq].w;
+        acc1.x += w1 * fr[qq].x; acc1.y += w1 * fr[qq].y; acc1.z += w1 * fr[qq].z; acc1.w += w1 * fr[qq].w;
+      }
+    }
+    *reinterpret_cast<float4*>(stage + (size_t)(lr * 2 + 0) * Dp + 4 * lc) = acc0;
+    *reinterpret_cast<float4*>(stage + (size_t)(lr * 2 + 1) * Dp + 4 * lc) = acc1;
+  }
+  __syncthreads();
+  float* out = B.pooled + (size_t)n * 2 * D + part * Dp;
+  for (int i = tid; i < nin * Dp; i += 256) {
+    const int which = i / Dp, c = i - which * Dp;
+    float sacc = 0.f;
+    for (int qq = 0; qq < nrow; ++qq) sacc += stage[(size_t)(qq * 2 + which) * Dp + c];
+    out[(size_t)which * D + c] = sacc;
+  }
+}
+
+// fc_att, l2-normalised product with the text map, fc_eltwise of the deferred questions
+// (nmn3_modules.py:442-450, 487-493): one workgroup per question, same arithmetic as the walker's
+// in-line path.  (Folding a partial fc_att into walk_pool_kernel was measured: pool 10.0 -> 15.7 us,
+// heads 26.1 -> 10.3 us per 256-question launch; kept apart so the pooling kernel is a pure stream.)
+__global__ __launch_bounds__(WT) void walk_heads_kernel(ModuleWeights w, WalkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int q = blockIdx.x;
+  const int kb = q / a.N, n = q - kb * a.N;
+  const WalkBatch& B = a.b[kb];
+  const int op = B.pjob[n];
+  if (op == 0) return;
+  const int D = a.D, M = a.M, Mp = a.Mp, C = a.C;
+  const int tid = threadIdx.x;
+  float* pooled = smem;                  // [2][D]
+  float* am0 = pooled + 2 * (size_t)D;   // [Mp]
+  float* am1 = am0 + Mp;
+  float* tm = am1 + Mp;
+  float* ev = tm + Mp;
+  float* rs = ev + Mp;                   // [32]
+  float* scr = rs + 32;                  // [WW][256] | [WT]
+  const bool same = op == N2NMN_OP_SAME_PROPERTY;
+  const int nin = same ? 2 : 1;
+  const float* pg = B.pooled + (size_t)n * 2 * D;
+  for (int i = tid; i < nin * D; i += WT) pooled[i] = pg[i];
+  for (int c = tid; c < Mp; c += WT) tm[c] = B.ptm[(size_t)n * Mp + c];
+  __syncthreads();
+  fc_pad<32>(tid, pooled, D, w.Watt[same ? 1 : 3], w.batt[same ? 1 : 3], Mp, am0, scr, nullptr);
+  if (same) fc_pad<32>(tid, pooled + D, D, w.Watt[2], w.batt[2], Mp, am1, scr, nullptr);
+  float lss = 0.f;
+  for (int c = tid; c < Mp; c += WT) {
+    float v = 0.f;
+    if (c < M) {
+      v = am0[c] * tm[c];
+      if (same) v *= am1[c];
+    }
+    ev[c] = v;
+    lss += v * v;
+  }
+  const float ss = wg_reduce<0>(lss, rs);
+  const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+  for (int c = tid; c < Mp; c += WT) ev[c] *= inv;
+  __syncthreads();
+  const int wi = same ? 5 : 6;
+  fc_out(tid, ev, M, w.Wans[wi], w.bans[wi], C, B.scores + (size_t)n * C, scr);
+}
+
+}  // namespace
+
+void launch_walk_pool(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) {
+  const int Dp = a.D / POOLP, nrow = 256 / (Dp / 4);
+  const size_t smem = sizeof(float) * (2 * (size_t)a.HWp + (size_t)nrow * 2 * Dp);
+  hipLaunchKernelGGL(walk_pool_kernel, dim3(POOLP, a.K * a.N), dim3(256), smem, s, a);
+  (void)w;
+}
+
+void launch_walk_heads(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) {
+  const size_t scr = std::max<size_t>((size_t)WW * 256, WT);
+  const size_t smem = sizeof(float) * (2 * (size_t)a.D + 4 * (size_t)a.Mp + 32 + scr);
+  hipLaunchKernelGGL(walk_heads_kernel, dim3(a.K * a.N), dim3(WT), smem, s, w, a);
+}
+
+int walk_pool_supported(int H, int W, int D) {
+  if (D % (4 * POOLP) != 0) return 0;
+  const int ncol = D / POOLP / 4;
+  if (ncol > 256 || 256 % ncol != 0) return 0;
+  const int nrow = 256 / ncol;
+  return (H * W + nrow - 1) / nrow <= WALK_POOLK_ROWS;
+}
 
 int walk_supported(int H, int W, int D, int M, int Mp, int HWp, int E, int C, int T, int ksize,
                    int T_enc) {

@@ -216,6 +216,11 @@ class Engine:
         return scores
 
     # ---- phase 2 without the host hop (include/n2nmn.h section 4b) ---------------------------
+    def set_defer_pool(self, mode: int):
+        """-1 auto (>= 128 questions per launch), 0 pooling answers inside the walker, 1 as separate
+        chip-wide launches (n2nmn_walk_set_defer_pool)."""
+        _lib.check(self._lib.n2nmn_walk_set_defer_pool(self._ctx, int(mode)))
+
     def walk_supported(self) -> bool:
         return bool(self._lib.n2nmn_walk_supported(self._ctx))
 
@@ -309,6 +314,13 @@ class Engine:
         """fixed cost of one profiler entry (event pair around an empty kernel), microseconds"""
         us = C.c_double()
         _lib.check(self._lib.n2nmn_debug_event_overhead(self._ctx, iters, C.byref(us), self.stream()))
+        return us.value
+
+    def walk_replay_us(self, which: int, iters: int = 50) -> float:
+        """average us per launch of the last walker launch's kernel (0 walker, 1 pool, 2 heads),
+        `iters` back-to-back launches inside one event pair (n2nmn_debug_walk_replay)"""
+        us = C.c_double()
+        _lib.check(self._lib.n2nmn_debug_walk_replay(self._ctx, which, iters, C.byref(us), self.stream()))
         return us.value
 
     def profile_end(self):

@@ -118,7 +118,7 @@ def test_walker_small_ragged_batch(clevr_engine):
 
 def test_super_bucket_of_forked_batches_equals_single_batches(clevr_engine):
     """K = 3 in-flight batches (forked contexts: own workspace, shared weights) in ONE walker
-    launch give bit-identical logits to three single-batch launches."""
+    launch give the logits of three single-batch launches."""
     import torch
     eng, d, asm, w = clevr_engine
     engines = [eng, eng.fork(), eng.fork()]
@@ -136,10 +136,17 @@ def test_super_bucket_of_forked_batches_equals_single_batches(clevr_engine):
         valid = torch.zeros((d.N,), dtype=torch.int32, device=eng.device)
         jobs.append((e, s2s['predicted_tokens'], feat, s2s['word_vecs'], scores, valid))
     torch.cuda.synchronize()
-    eng.walk(jobs, d.N, d.T_decoder)
+    eng.walk(jobs, d.N, d.T_decoder)           # 192 questions: pooling answers run deferred
+    for k in range(3):
+        assert_close('batch %d' % k, t2n(jobs[k][4]), singles[k], 2e-5)
+        assert t2n(jobs[k][5]).all()
+    try:
+        eng.set_defer_pool(0)                  # same path as the single launches: bit-identical
+        eng.walk(jobs, d.N, d.T_decoder)
+    finally:
+        eng.set_defer_pool(-1)
     for k in range(3):
         assert np.array_equal(t2n(jobs[k][4]), singles[k])
-        assert t2n(jobs[k][5]).all()
 
 
 def test_walker_on_the_reference_code_fixture(clevr_engine):
@@ -172,3 +179,31 @@ def test_attention_table_text_maps_equal_word_vec_text_maps(clevr_engine):
                               atts=(s2s['atts'], s2s['_input_seq'], s2s['_seq_length']))
     assert_close('table vs word_vecs', t2n(b), t2n(a), 2e-5)
     assert_close('table vs oracle', t2n(b), ref['scores'], TOL)
+
+
+@pytest.mark.parametrize('seed', [1, 2])
+def test_deferred_pooling_equals_inline_pooling(clevr_engine, seed):
+    """throughput mode: root Describe / SameProperty leave the walker for walk_pool_kernel +
+    walk_heads_kernel; same logits as the in-walker path and the oracle."""
+    eng, d, asm, w = clevr_engine
+    batch = synth.make_inputs(d, seed=80 + seed, min_len=1)
+    toks = synth.random_valid_layouts(d, asm.P, asm.W, asm.b, seed=40 + seed, max_len=5) \
+        if seed == 1 else synth.template_layout_batch(d, offset=2)
+    ref = O.forward(w, NAMES, batch, d.T_decoder, d.num_choices, np.float64, forced_tokens=toks)
+    s2s = eng.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], forced_tokens=toks,
+                      reuse_buffers=False)
+    names = asm.module_names
+    roots = [names[toks[(toks[:, n] != asm.EOS_idx).sum() - 1, n]] for n in range(d.N)]
+    assert sum(r in ('_Describe', '_SameProperty') for r in roots) >= 8
+    out = {}
+    try:
+        for mode in (0, 1):
+            eng.set_defer_pool(mode)
+            sc, val = eng.execute_tokens(s2s['predicted_tokens'], batch['image_feat_batch'],
+                                         s2s['word_vecs'], reuse_buffers=False)
+            out[mode] = t2n(sc).copy()
+            assert t2n(val).all()
+    finally:
+        eng.set_defer_pool(-1)
+    assert_close('deferred vs inline', out[1], out[0], 2e-5)
+    assert_close('deferred vs oracle', out[1], ref['scores'], TOL)
