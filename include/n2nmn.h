@@ -386,6 +386,34 @@ int64_t n2nmn_train_debug_tensor(n2nmn_ctx *ctx, const char *name, float *out, i
                                  n2nmn_stream stream);
 
 /* ------------------------------------------------------------------------------------------
+ * (6b) gradient all-reduce over RCCL / xGMI for the data-parallel training step (SURVEY.md 8(b) item
+ *     6, 8(e)).  The reference is single-GPU (no collective exists in it); this is the exchange step
+ *     of exp_clevr/train_clevr_gt_layout.py:112-120 run on several GPUs: every rank computes the
+ *     gradient of its own batch (n2nmn_train_forward / n2nmn_train_backward), the flat gradient
+ *     vector is summed over ranks in two buckets, and n2nmn_adam_step applies scale = 1 / world.
+ *     One process per GPU.  librccl is bound at run time.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct n2nmn_comm n2nmn_comm;
+#define N2NMN_COMM_ID_BYTES 128
+/* rank 0: create the 128-byte id (ncclGetUniqueId) and hand it to the other ranks by any channel */
+int n2nmn_comm_unique_id(void *id_out_128);
+/* every rank: join the communicator (ncclCommInitRank) on `device`; creates the library-owned side
+ * stream the collectives run on */
+int n2nmn_comm_create(const void *unique_id_128, int rank, int world, int device, n2nmn_comm **out);
+int n2nmn_comm_world(const n2nmn_comm *comm);
+/* In-place sum over ranks of one bucket of the flat gradient vector `grads` (n2nmn_grad_numel
+ * floats): bucket 0 = [split, numel) (decoder + module variables, final after backward phase 0),
+ * bucket 1 = [0, split) (encoder variables, final after phase 1), split = n2nmn_grad_split.
+ * Asynchronous: forked from `stream` with an event (the bucket's gradients must have been written
+ * by work already enqueued on `stream`), runs on the communicator's side stream -- so bucket 0
+ * overlaps backward phase 1. */
+int n2nmn_allreduce_grads(n2nmn_ctx *ctx, n2nmn_comm *comm, int bucket, float *grads,
+                          n2nmn_stream stream);
+/* make `stream` wait for the buckets issued so far (call before n2nmn_adam_step) */
+int n2nmn_allreduce_wait(n2nmn_comm *comm, n2nmn_stream stream);
+int n2nmn_comm_destroy(n2nmn_comm *comm);
+
+/* ------------------------------------------------------------------------------------------
  * (7) introspection used by the roofline report: algorithmic bytes / flops of one launch of a
  *     kernel family (SURVEY.md section 8d figures), and a plain GEMM entry for unit parity.
  * ---------------------------------------------------------------------------------------- */

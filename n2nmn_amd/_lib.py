@@ -112,6 +112,12 @@ SYMBOLS = [
     ('n2nmn_train_reset_optimizer', _I, [_P, _P]),
     ('n2nmn_get_weight', _I, [_P, C.c_char_p, _P, _P]),
     ('n2nmn_train_debug_tensor', C.c_int64, [_P, C.c_char_p, _P, C.c_int64, _P]),
+    ('n2nmn_comm_unique_id', _I, [_P]),
+    ('n2nmn_comm_create', _I, [_P, _I, _I, _I, C.POINTER(_P)]),
+    ('n2nmn_comm_world', _I, [_P]),
+    ('n2nmn_allreduce_grads', _I, [_P, _P, _I, _P, _P]),
+    ('n2nmn_allreduce_wait', _I, [_P, _P]),
+    ('n2nmn_comm_destroy', _I, [_P]),
     ('n2nmn_profile_begin', _I, [_P]),
     ('n2nmn_profile_end', _I, [_P, _P]),
     ('n2nmn_profile_num_families', _I, []),

@@ -57,6 +57,59 @@ class GradBuckets:
         return 1.0 / self.world
 
 
+class RcclBuckets:
+    """The same two buckets through the C-ABI's own RCCL communicator (n2nmn_comm_create /
+    n2nmn_allreduce_grads / n2nmn_allreduce_wait, include/n2nmn.h section 6b): the collectives run
+    on a library-owned side stream forked from and joined to the caller's stream with events.
+    torch.distributed is used for ONE thing only: handing rank 0's 128-byte ncclUniqueId to the other
+    ranks.  dist=None: a 1-rank communicator (the code path of the 8-GPU run on one GPU)."""
+
+    def __init__(self, engine: Engine, flat, dist=None):
+        torch = _torch()
+        self.engine, self.flat, self.dist = engine, flat, dist
+        self._lib = engine._lib
+        self.rank = dist.get_rank() if dist is not None else 0
+        self._world = dist.get_world_size() if dist is not None else 1
+        uid = (C.c_char * 128)()
+        if self.rank == 0:
+            _lib.check(self._lib.n2nmn_comm_unique_id(uid))
+        if dist is not None and self._world > 1:
+            box = [bytes(uid.raw) if self.rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, device=engine.device)
+            C.memmove(uid, box[0], 128)
+        self._comm = C.c_void_p()
+        _lib.check(self._lib.n2nmn_comm_create(uid, self.rank, self._world, engine.device.index,
+                                               C.byref(self._comm)))
+        torch.cuda.synchronize(engine.device)
+
+    @property
+    def world(self) -> int:
+        return self._world
+
+    def reduce_late(self):
+        _lib.check(self._lib.n2nmn_allreduce_grads(self.engine._ctx, self._comm, 0,
+                                                   self.flat.data_ptr(), self.engine.stream()))
+
+    def reduce_early(self):
+        _lib.check(self._lib.n2nmn_allreduce_grads(self.engine._ctx, self._comm, 1,
+                                                   self.flat.data_ptr(), self.engine.stream()))
+
+    def wait(self) -> float:
+        _lib.check(self._lib.n2nmn_allreduce_wait(self._comm, self.engine.stream()))
+        return 1.0 / self._world
+
+    def close(self):
+        comm, self._comm = self._comm, None
+        if comm:
+            self._lib.n2nmn_comm_destroy(comm)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Trainer:
     """One model replica on one GPU.  `step(batch, gt_layout)` = one iteration of
     train_clevr_gt_layout.py: returns the losses of that iteration (device tensor of 4 floats:
@@ -64,7 +117,10 @@ class Trainer:
 
     def __init__(self, engine: Engine, weight_decay: float = 5e-6, lr: float = 1e-3,
                  beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
-                 max_grad_l2_norm: float = 10.0, dist=None):
+                 max_grad_l2_norm: float = 10.0, dist=None, rccl: Optional[bool] = None):
+        """dist: an initialised torch.distributed module (or None).  rccl: all-reduce through the
+        C-ABI's own RCCL communicator (default: whenever `dist` runs on the nccl backend; True
+        without `dist` builds a 1-rank communicator); False / gloo: torch.distributed collectives."""
         torch = _torch()
         if engine._parent is not None:
             raise ValueError('train on the root engine, not on a fork')
@@ -86,7 +142,10 @@ class Trainer:
         self.baseline = torch.full((1,), self.rl['invalid_expr_loss'], dtype=torch.float32,
                                    device=engine.device)
         self.scores = None
-        self.buckets = GradBuckets(self.grads, self.split, dist)
+        if rccl is None:
+            rccl = dist is not None and dist.get_backend() == 'nccl'
+        self.buckets = RcclBuckets(engine, self.grads, dist) if rccl else \
+            GradBuckets(self.grads, self.split, dist)
         self.iteration = 0
         _lib.check(self._lib.n2nmn_train_reset_optimizer(self._ctx, engine.stream()))
         self.layout: Dict[str, tuple] = {}

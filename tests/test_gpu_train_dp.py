@@ -93,3 +93,38 @@ def test_two_ranks_one_gpu_gloo(tmp_path):
     # variable relative to its scale, at both steps (the second one on the updated weights; the two
     # trajectories only differ by fp32 summation order, amplified by Adam's lr-sized first step)
     assert res[0]['err'] < 5e-3, res
+
+
+def test_c_abi_rccl_communicator_world_1():
+    import numpy as np
+    from n2nmn_amd import synth
+    from n2nmn_amd.spec import Dims, CLEVR_MODULE_NAMES
+    """n2nmn_comm_* / n2nmn_allreduce_grads (include/n2nmn.h 6b) on a 1-rank RCCL communicator: the
+    code path of the multi-GPU step (library-owned side stream, event fork / join, two buckets) gives
+    the gradients and the update of the single-GPU step."""
+    from n2nmn_amd.nmn3_assembler import Assembler
+    from n2nmn_amd.engine import Engine
+    from n2nmn_amd.train import Trainer, RcclBuckets
+    d = Dims(T_decoder=10)
+    eng = Engine(d, Assembler(list(CLEVR_MODULE_NAMES)))
+    w = synth.make_weights(d, seed=0)
+    batch = synth.make_inputs(d, seed=11)
+    gt = synth.template_layout_batch(d, offset=2)
+    out = {}
+    for use in (False, True):
+        eng.load_weights(w)
+        tr = Trainer(eng, rccl=use)
+        assert isinstance(tr.buckets, RcclBuckets) == use
+        scale = tr.forward_backward(batch, gt)           # reduce=True: both buckets issued
+        assert scale == 1.0
+        g = tr.grads.detach().cpu().numpy().copy()
+        tr.apply(scale)
+        w1 = {k: v.cpu().numpy() for k, v in tr.get_weights().items()}
+        out[use] = (g, w1, tr.losses.cpu().numpy().copy())
+        if use:
+            assert tr.buckets.world == 1
+            tr.buckets.close()
+    assert np.array_equal(out[True][0], out[False][0])
+    assert np.array_equal(out[True][2], out[False][2])
+    for k in out[True][1]:
+        assert np.array_equal(out[True][1][k], out[False][1][k]), k
