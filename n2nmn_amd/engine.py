@@ -107,6 +107,15 @@ class Engine:
         torch.cuda.synchronize(self.device)
         _lib.check(self._lib.n2nmn_commit_weights(self._ctx, self.stream()))
 
+    def load_tf_checkpoint(self, prefix: str, verify: bool = True):
+        """Load a TF V2 checkpoint (`<prefix>.index` + `.data-*`, README.md:75-79 of the reference)
+        reading ONLY this model's variables (not the optimiser slots).  Returns the names found."""
+        from .tf_checkpoint import read_checkpoint
+        w = read_checkpoint(prefix, names=list(self.variable_names()), verify=verify,
+                            skip_missing=True)
+        self.load_weights(w)
+        return sorted(w)
+
     # ------------------------------------------------------------------------------------
     def _buf(self, key, shape, dtype):
         torch = _torch()

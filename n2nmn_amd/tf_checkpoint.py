@@ -230,13 +230,19 @@ def read_index(path: str, verify: bool = True) -> Tuple[dict, Dict[str, dict]]:
     return header, entries
 
 
-def read_checkpoint(prefix: str, names=None, verify: bool = True) -> Dict[str, np.ndarray]:
+def read_checkpoint(prefix: str, names=None, verify: bool = True,
+                    skip_missing: bool = False) -> Dict[str, np.ndarray]:
     """All (or the named) tensors of the checkpoint `<prefix>.index` / `<prefix>.data-*`, by the
-    variable names the graph used.  verify: check the table-block and per-tensor CRC32Cs."""
+    variable names the graph used.  verify: check the table-block and per-tensor CRC32Cs (the CRC is
+    a pure-Python byte loop: pass `names` -- e.g. `Engine.variable_names()` -- so the Adam slots of a
+    training snapshot, two thirds of its bytes, are neither read nor checksummed).
+    skip_missing: names absent from the checkpoint are left out instead of raising KeyError."""
     header, entries = read_index(prefix + '.index', verify)
     shards: Dict[int, bytes] = {}
     out: Dict[str, np.ndarray] = {}
     for name in (sorted(entries) if names is None else names):
+        if skip_missing and name not in entries:
+            continue
         if name not in entries:
             raise KeyError('tf_checkpoint: no tensor named %r in %s' % (name, prefix))
         e = entries[name]

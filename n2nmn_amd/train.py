@@ -224,19 +224,21 @@ class Trainer:
         self.apply(scale)
         return self.losses
 
-    def step_rl(self, batch, sample_uniforms, lr: Optional[float] = 1e-4):
+    def step_rl(self, batch, sample_uniforms, lr: Optional[float] = 1e-4, update: bool = True):
         """One iteration of exp_clevr/train_clevr_rl_gt_layout.py:183-214: the decoder samples a
         layout per question (sample_uniforms [T_dec, N] in [0,1) replace tf.multinomial's RNG),
         the tokens are fetched and assembled on the host (the reference's partial_run does the
         same), then forward + backward of the policy-gradient loss and an Adam step with the
-        fine-tuning learning rate.  Returns (losses, tokens, expr_validity)."""
+        fine-tuning learning rate (lr=None: the trainer's own).  update=False computes the losses and
+        gradients only (no Adam step).  Returns (losses, tokens, expr_validity)."""
         e = self.engine
         s2s = e.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'],
                         sample_uniforms=sample_uniforms)
         tokens = s2s['predicted_tokens'].cpu().numpy()
         scale = self.forward_backward(batch, tokens, objective=1)
-        if lr is not None:
-            saved, self.hyper['lr'] = self.hyper['lr'], float(lr)
+        if update:               # lr=None: the trainer's own learning rate
+            saved = self.hyper['lr']
+            self.hyper['lr'] = saved if lr is None else float(lr)
             self.apply(scale)
             self.hyper['lr'] = saved
         validity = self._keep[6].cpu().numpy().astype(bool) if self._keep[6] is not None else None

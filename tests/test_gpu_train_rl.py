@@ -55,7 +55,7 @@ def test_policy_gradient_step_matches_oracle(rl_setup, seed, baseline):
     batch = synth.make_inputs(d, seed=60 + seed, min_len=1)
     uni = np.random.default_rng(seed).random((d.T_decoder, d.N)).astype(np.float32)
     tr.baseline.fill_(baseline)
-    losses, tokens, validity = tr.step_rl(batch, uni, lr=None)        # no optimiser step
+    losses, tokens, validity = tr.step_rl(batch, uni, update=False)   # no optimiser step
     losses = t2n(losses)
     assert validity.all()            # the automaton only lets valid layouts through
     assert len({tuple(c) for c in tokens.T}) > 5          # the batch really has sampled layouts
