@@ -16,7 +16,8 @@ SURVEY.md 8(f) rank 2): their questions share every launch of both phases; `--st
 are in flight (pre-spawned host threads, one HIP stream and forked context each, shared weights).
 `--steps` counts batches of 64: exactly `--steps` batches are timed, split evenly over the streams.
 Measured (profiles/r02_stream_sweep.txt): 1 x 4 batches 131 k q/s, 2 x 4 181 k, 3 x 4 190 k, 4 x 4
-191 k, the same with the default hardware-queue count and with GPU_MAX_HW_QUEUES=8.
+191 k, 2 x 8 190 k, the same with the default hardware-queue count and with GPU_MAX_HW_QUEUES=8.
+Default: 2 streams x 8 batches.
 Latency number (`single_batch`): one batch of 64 in flight, same code path.
 `config3`: the same with layouts chosen by the greedy decoder (BASELINE.json configs[2]).
 
@@ -56,14 +57,17 @@ def parse():
                          '4: training step (forward + backward + RCCL all-reduce + Adam); '
                          '5: models_vqa forward (14x14x2048 feats, batch 128)')
     ap.add_argument('--batch', type=int, default=64)
-    ap.add_argument('--inflight', type=int, default=4,
+    ap.add_argument('--inflight', type=int, default=8,
                     help='batches of --batch questions super-bucketed into one pass (1..16)')
-    ap.add_argument('--streams', type=int, default=3,
+    ap.add_argument('--streams', type=int, default=2,
                     help='independent super-buckets in flight per GPU (one pre-spawned host thread + '
                          'HIP stream + forked context each; weights shared)')
     ap.add_argument('--host-assemble', action='store_true',
                     help='reference flow: token fetch + C++ Assembler + level scheduler instead of '
                          'the on-device layout walker')
+    ap.add_argument('--plain', action='store_true',
+                    help='only the timed throughput region (no single_batch / config3 / per-kernel pass / '
+                         'cpu baseline): the command the rocprofv3 traces in profiles/ are taken from')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     return ap.parse_args()
@@ -382,6 +386,8 @@ def layout_work(tokens, names):
 
 def main():
     args = parse()
+    if args.plain:
+        args.no_profile = args.no_cpu_baseline = True
     ensure_world(args, sys.argv[1:])
     import numpy as np
     import torch
@@ -405,11 +411,12 @@ def main():
     from n2nmn_amd.superbucket import SuperBucket
 
     K = max(1, min(16, args.inflight))
+    KCAP = 16 if K > 1 else 1           # slots a bucket holds: passes are 1..KCAP batches wide
     S = max(1, args.streams)
     d = Dims(N=args.batch)
     names = list(CLEVR_MODULE_NAMES)
     asm = Assembler(names)
-    sb = SuperBucket(d, asm, K, device=local_rank)
+    sb = SuperBucket(d, asm, KCAP, device=local_rank)
     eng = sb.engine
     w = synth.make_weights(d, seed=0)
     sb.load_weights(w)
@@ -423,11 +430,11 @@ def main():
     workers = []
     for si, e in enumerate(engines):
         e.set_mode('throughput' if S > 1 else 'latency')
-        bk = [sb if si == 0 else SuperBucket(d, asm, K, device=local_rank, engine=e),
-              SuperBucket(d, asm, K, device=local_rank, engine=e)]
+        bk = [sb if si == 0 else SuperBucket(d, asm, KCAP, device=local_rank, engine=e),
+              SuperBucket(d, asm, KCAP, device=local_rank, engine=e)]
         for j, b in enumerate(bk):
-            for k in range(K):
-                i = (si * 2 + j) * K + k
+            for k in range(KCAP):
+                i = (si * 2 + j) * KCAP + k
                 b.fill(k, synth.make_inputs(d, seed=dp.batch_seed(i)),
                        synth.template_layout_batch(d, offset=i))
         workers.append(dict(engine=e, buckets=bk, stream=torch.cuda.Stream(device=dev) if S > 1 else None,
@@ -435,21 +442,28 @@ def main():
     buckets = workers[0]['buckets']
     torch.cuda.synchronize(dev)
 
+    def run_pass(e, b, n, gt):
+        """one pass over the first n slots of bucket b; returns (scores, tokens, validity)"""
+        if n == KCAP:
+            return b.run(use_gt_layout=gt)
+        v = dict(input_seq_batch=b.input_seq[:, :n * d.N].contiguous(),
+                 seq_length_batch=b.seq_length[:n * d.N], image_feat_batch=b.image_feat[:n * d.N])
+        return e.forward(v, use_gt_layout=gt,
+                         gt_layout=b.gt_layout[:, :n * d.N].contiguous() if gt else None,
+                         fetch=False, host_assemble=args.host_assemble)
+
     def run_on(wk, count, gt):
-        """`count` batches of d.N questions on one worker: full passes of K slots, then a partial one"""
+        """`count` batches of d.N questions on one worker, as passes of (nearly) equal size: about K
+        slots each, never more than the buckets hold (KCAP)"""
+        if count <= 0:
+            return
+        n_pass = max(1, int(round(count / K)))
+        while -(-count // n_pass) > KCAP:
+            n_pass += 1
         done, j = 0, 0
-        while done < count:
-            n = min(K, count - done)
-            b = wk['buckets'][j % 2]
-            if n == K:
-                b.run(use_gt_layout=gt)
-            else:                              # remainder: the first n slots only
-                v = dict(input_seq_batch=b.input_seq[:, :n * d.N].contiguous(),
-                         seq_length_batch=b.seq_length[:n * d.N],
-                         image_feat_batch=b.image_feat[:n * d.N])
-                wk['engine'].forward(v, use_gt_layout=gt,
-                                     gt_layout=b.gt_layout[:, :n * d.N].contiguous() if gt else None,
-                                     fetch=False, host_assemble=args.host_assemble)
+        for pi in range(n_pass):
+            n = (count - done + (n_pass - pi) - 1) // (n_pass - pi)
+            run_pass(wk['engine'], wk['buckets'][j % 2], n, gt)
             done += n
             j += 1
 
@@ -530,7 +544,7 @@ def main():
         sync()
         return (time.perf_counter() - t0) / n
 
-    if rank == 0:
+    if rank == 0 and not args.plain:
         # ---- one batch of d.N questions in flight (latency-oriented number), same code path
         one = dict(input_seq_batch=sb.input_seq[:, :d.N].contiguous(), seq_length_batch=sb.seq_length[:d.N],
                    image_feat_batch=sb.image_feat[:d.N])
@@ -557,7 +571,8 @@ def main():
             eng.set_mode('throughput' if S > 1 else 'latency')
             reps = max(3, min(15, args.steps // (S * K)))
             t3k = wall(lambda: run_batches(S * K, gt=False), reps)
-            toks3 = sb.tokens.cpu().numpy()
+            _, tk3, val3 = run_pass(eng, sb, K, False)
+            toks3 = tk3.cpu().numpy()
             f3, p3, _ = layout_work(toks3, names)
             out['config3'] = {
                 'workload': 'BASELINE.json configs[2]: greedy attentional decoder (4 launches per '
@@ -567,7 +582,7 @@ def main():
                                  'ms_per_step': round(1e3 * t3k / (S * K), 4),
                                  'inflight_batches': S * K, 'streams_per_gpu': S},
                 'unit': 'questions/sec',
-                'layouts': {'valid_fraction': float(sb.validity.float().mean().item()),
+                'layouts': {'valid_fraction': float(val3.float().mean().item()),
                             'find_type_nodes_per_question': round(f3 / toks3.shape[1], 2),
                             'pooling_nodes_per_question': round(p3 / toks3.shape[1], 2)}}
 
@@ -579,7 +594,7 @@ def main():
         eng.profile_begin()
         t0 = time.perf_counter()
         for j in range(kpass):
-            buckets[j % 2].run(use_gt_layout=use_gt)
+            run_pass(eng, buckets[j % 2], K, use_gt)
         fams = eng.profile_end()                 # synchronises the stream
         prof_wall = time.perf_counter() - t0
         rows = kernel_rows(fams, kpass * K, ovh)
@@ -607,9 +622,9 @@ def main():
         # duration the fractions below use; rocprofv3's kernel trace agrees (profiles/).
         if use_gt and eng.walk_supported():
             b0 = buckets[0]
-            b0.run(use_gt_layout=True)
+            run_pass(eng, b0, K, True)
             sync()
-            toks = b0.gt_layout.cpu().numpy()
+            toks = b0.gt_layout[:, :K * d.N].cpu().numpy()
             idx = {n: i for i, n in enumerate(names)}
             last = toks[(toks != idx['<eos>']).sum(0) - 1, np.arange(toks.shape[1])]
             n_desc = int((last == idx['_Describe']).sum())
@@ -630,7 +645,15 @@ def main():
                         'unit': 'GB/s', 'frac': round(walk_bytes / us_walk / 1e3 / HBM_PEAK_GBS, 4),
                         'traffic': pmc_traffic('walk')[0], 'traffic_source': pmc_traffic('walk')[1]})
             if deferred:
-                us_pool = eng.walk_replay_us(1, 100)
+                # in the pass itself the feature maps come from HBM (PMC: FETCH bytes == algorithmic
+                # bytes); back-to-back replays find them in the Infinity Cache.  Both are reported:
+                # `avg_us` / `frac` = the launch inside the profiled passes (its event pair minus what
+                # a pair adds to this very kernel, calibrated by replaying it both ways), `warm_*` =
+                # the back-to-back replay
+                us_warm = eng.walk_replay_us(1, 100)
+                pair_cost = max(eng.walk_replay_us(0x11, 100) - us_warm, 0.0)
+                prow = [r for r in rows if r['kernel'] == 'pool'][0]
+                us_pool = max(prow['avg_us'] - pair_cost, us_warm)
                 jobs = n_desc + n_same
                 pool_bytes = 4.0 * (jobs * HW * D + (n_desc + 2 * n_same) * (HW + D))
                 att.insert(0, {
@@ -640,6 +663,9 @@ def main():
                     'algorithmic_bytes_per_launch': round(pool_bytes),
                     'achieved': round(pool_bytes / us_pool / 1e3, 1), 'peak': HBM_PEAK_GBS,
                     'unit': 'GB/s', 'frac': round(pool_bytes / us_pool / 1e3 / HBM_PEAK_GBS, 4),
+                    'event_pair_us': prow['avg_us'], 'event_pair_cost_us': round(pair_cost, 3),
+                    'warm_replay_us': round(us_warm, 3),
+                    'warm_replay_frac': round(pool_bytes / us_warm / 1e3 / HBM_PEAK_GBS, 4),
                     'traffic': pmc_traffic('pool')[0], 'traffic_source': pmc_traffic('pool')[1]})
                 att.append({'kernel': 'walk_heads_kernel (fc_att + answer head of the pooled questions; '
                                       'weights from L2)', 'bound': 'l2',

@@ -1175,22 +1175,32 @@ int n2nmn_debug_walk_replay(n2nmn_ctx* c, int which, int iters, double* us_avg, 
   ModuleWeights w = module_weights(c);
   WalkArgs a = c->last_walk;
   a.stats = nullptr; a.timeline = nullptr;
-  hipEvent_t e0, e1;
-  N2_HIP(hipEventCreate(&e0)); N2_HIP(hipEventCreate(&e1));
+  const bool pairs = (which & 0x10) != 0;       // one event pair PER launch (calibrates the pair cost)
+  which &= 0xf;
   auto one = [&]() {
     if (which == 0) launch_walk(w, a, s);
     else if (which == 1) launch_walk_pool(w, a, s);
     else launch_walk_heads(w, a, s);
   };
   for (int i = 0; i < 3; ++i) one();
-  N2_HIP(hipEventRecord(e0, s));
-  for (int i = 0; i < iters; ++i) one();
-  N2_HIP(hipEventRecord(e1, s));
-  N2_HIP(hipEventSynchronize(e1));
-  float ms = 0.f;
-  N2_HIP(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  *us_avg = 1e3 * ms / iters;
+  std::vector<hipEvent_t> ev(pairs ? 2 * (size_t)iters : 2);
+  for (auto& e : ev) N2_HIP(hipEventCreate(&e));
+  if (!pairs) N2_HIP(hipEventRecord(ev[0], s));
+  for (int i = 0; i < iters; ++i) {
+    if (pairs) N2_HIP(hipEventRecord(ev[2 * i], s));
+    one();
+    if (pairs) N2_HIP(hipEventRecord(ev[2 * i + 1], s));
+  }
+  if (!pairs) N2_HIP(hipEventRecord(ev[1], s));
+  N2_HIP(hipStreamSynchronize(s));
+  double tot = 0;
+  for (size_t i = 0; i + 1 < ev.size(); i += 2) {
+    float ms = 0.f;
+    N2_HIP(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+    tot += ms;
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  *us_avg = 1e3 * tot / iters;
   return check_launch("debug_walk_replay");
 }
 
