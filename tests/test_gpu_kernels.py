@@ -14,7 +14,7 @@ TOL = 1e-4
                                    (257, 130, 100), (2880, 512, 512), (19250, 250, 512),
                                    (20011, 512, 300), (19200, 200, 64)])
 def test_gemm_matches_fp64(clevr_engine, M, N, K):
-    """(the M >= 19200 cases run the A-stationary 64 x 256 tile, the others the 64 x 64 tile)"""
+    """(tall cases included: conv_image at super-bucket sizes has M = 38400 and more)"""
     eng = clevr_engine[0]
     rng = np.random.default_rng(M * 7 + N)
     A = rng.standard_normal((M, K)).astype(np.float32)
