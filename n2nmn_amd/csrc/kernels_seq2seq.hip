@@ -821,7 +821,7 @@ __global__ __launch_bounds__(256) void dec_attn_multi_kernel(DecStepArgs a, int 
 
 // perm[rank] = n with rows ranked by decreasing length (ties by index); n_active[t] = #{len > t}.
 // The same launch clears the recurrent state block (a separate memset node costs ~5 us on the
-// stream): workgroup 0 ranks, every workgroup zeroes its slice.
+// stream).
 constexpr int PREP_MAXN = 1024;
 __global__ __launch_bounds__(256) void enc_prepare_kernel(const int32_t* __restrict__ seq_len,
                                                           int N, int T, int32_t* __restrict__ perm,
@@ -830,12 +830,14 @@ __global__ __launch_bounds__(256) void enc_prepare_kernel(const int32_t* __restr
   const int tid = threadIdx.x;
   for (size_t i = (size_t)blockIdx.x * 256 + tid; i < zero4; i += (size_t)gridDim.x * 256)
     zero[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (blockIdx.x != 0) return;
+  // ranks and active-row counts are spread over the workgroups too (one workgroup needed 81 us for
+  // the O(N^2) ranking of a 512-question super-bucket)
   __shared__ int lens[PREP_MAXN];
+  __shared__ float scratch[16];
   for (int i = tid; i < N && i < PREP_MAXN; i += 256) lens[i] = seq_len[i];
   __syncthreads();
   const bool in_lds = N <= PREP_MAXN;
-  for (int i = tid; i < N; i += 256) {
+  for (int i = blockIdx.x * 256 + tid; i < N; i += gridDim.x * 256) {
     const int li = in_lds ? lens[i] : seq_len[i];
     int rank = 0;
     for (int j = 0; j < N; ++j) {
@@ -844,10 +846,11 @@ __global__ __launch_bounds__(256) void enc_prepare_kernel(const int32_t* __restr
     }
     perm[rank] = i;
   }
-  for (int t = tid; t < T; t += 256) {
-    int c = 0;
-    for (int j = 0; j < N; ++j) c += (in_lds ? lens[j] : seq_len[j]) > t;
-    n_active[t] = c;
+  for (int t = blockIdx.x; t < T; t += gridDim.x) {
+    float c = 0.f;
+    for (int j = tid; j < N; j += 256) c += (in_lds ? lens[j] : seq_len[j]) > t ? 1.f : 0.f;
+    const float tot = block_reduce<0>(c, scratch);
+    if (tid == 0) n_active[t] = (int)(tot + 0.5f);
   }
 }
 
@@ -1053,7 +1056,8 @@ void launch_dec_attn(const DecStepArgs& a, int nsteps, hipStream_t s) {
 void launch_enc_prepare(const int32_t* seq_len, int N, int T, int32_t* perm, int32_t* n_active,
                         float* zero, size_t zero_floats, hipStream_t s) {
   const size_t z4 = zero_floats / 4;             // the state block is a multiple of 4 floats
-  const int blocks = zero ? (int)std::min<size_t>(256, (z4 + 1023) / 1024 + 1) : 1;
+  int blocks = zero ? (int)std::min<size_t>(256, (z4 + 1023) / 1024 + 1) : 1;
+  blocks = std::max(blocks, std::min(64, (N + 255) / 256 + T / 4));
   hipLaunchKernelGGL(enc_prepare_kernel, dim3(blocks), dim3(256), 0, s, seq_len, N, T, perm, n_active,
                      reinterpret_cast<float4*>(zero), zero ? z4 : 0);
 }
