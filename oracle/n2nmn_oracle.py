@@ -12,11 +12,15 @@ PARITY PINNING STATUS
   * integer / host logic (validity matrices P/W/b, RPN assembler): PINNED -- checked against
     golden vectors produced by importing the reference's own numpy code
     (tests/golden/make_assembler_golden.py -> tests/golden/assembler_golden.json).
-  * floating-point path (LSTM encoder/decoder, module operators): "PARITY UNPINNED" at the
-    TensorFlow boundary.  TF 1.0.0 and TF-Fold 0.0.1 are third-party, un-vendored
-    (README.md:20-23), not installable here, and the reference tree holds no golden logits,
-    snapshots or recorded activations.  The restatement is anchored on the reference call sites
-    and cross-checked against an independent torch-CPU restatement (tests/test_oracle_crosscheck.py).
+  * floating-point path (LSTM encoder/decoder, module operators, losses): PINNED since round 2 to
+    the reference's OWN model code.  TF 1.0.0 / TF-Fold 0.0.1 cannot be installed, so
+    tests/golden/make_float_golden.py imports the unmodified models_clevr/*.py, models_vqa/*.py and
+    util/cnn.py under oracle/tf1_stub/ (eager float64 stand-ins for the ~60 TF ops and the Fold
+    blocks they call), runs them on the seeded inputs of tests/golden/float_cases.py and commits the
+    outputs as tests/golden/float_golden.npz; tests/test_oracle_vs_reference_code.py holds this
+    module to that fixture at 1e-10.  What is still restated rather than executed is TensorFlow
+    LIBRARY code (BasicLSTMCell, dynamic_rnn, raw_rnn, Adam, the arithmetic of each primitive op):
+    DESIGN.md section 6 lists it.
 """
 from __future__ import annotations
 

@@ -17,9 +17,11 @@ TF 1.0.0 defaults (train_clevr_gt_layout.py:112-120).
 
 The forward VALUES of this module are checked against the numpy oracle in
 tests/test_oracle_grad.py (same weights/inputs, fp64 round-off); the gradients are checked there
-against central finite differences of the numpy oracle's loss.  PARITY STATUS is the numpy
-oracle's: "parity unpinned" at the TensorFlow boundary (TF 1.0.0 / Fold 0.0.1 un-vendored, no
-golden gradients in the reference tree).
+against central finite differences of the numpy oracle's loss.  PARITY STATUS: PINNED since round 2
+-- every variable's gradient of both objectives, the per-tensor clip, one Adam step and the EMA
+baseline are held (1e-9 relative) to what the reference's own model files and the loss blocks of
+exp_clevr/train_clevr_gt_layout.py / train_clevr_rl_gt_layout.py compute under the eager TF1/Fold
+stand-in (tests/golden/make_float_golden.py -> float_golden.npz, tests/test_oracle_vs_reference_code.py).
 
 TF gradient conventions restated here (TF 1.0.0 math_grad.py):
   * tf.minimum / tf.maximum (And / Or / Filter): ties send the gradient to the FIRST argument

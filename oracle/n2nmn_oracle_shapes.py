@@ -11,8 +11,9 @@ Restates `models_shapes/*` on top of the shared pieces of oracle/n2nmn_oracle.py
     (models_shapes/nmn3_modules.py:27-144)
   * data plumbing of exp_shapes/eval_shapes.py:60-114 (vocabularies, np.random.seed(3) shuffle,
     tokenisation, mean subtraction): `load_split`.
-PARITY STATUS: "parity unpinned" (TF 1.0.0 / Fold un-vendored, no snapshot); the data plumbing is
-pinned to the reference's own dataset files through tests/golden/shapes_golden.json.
+PARITY STATUS: the float path of THIS variant is "parity unpinned" (models_shapes is not among the
+files run under the TF1 stand-in; models_clevr and models_vqa are); the data plumbing is pinned to
+the reference's own dataset files through tests/golden/shapes_golden.json.
 """
 from __future__ import annotations
 

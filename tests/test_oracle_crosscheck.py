@@ -1,4 +1,5 @@
-"""Second opinion on the float path of the oracle (which is 'parity unpinned' at the TF boundary):
+"""Second opinion on the float path of the oracle (round 1's only anchor; since round 2 the oracle is
+also pinned to the reference's own code, tests/test_oracle_vs_reference_code.py):
 an INDEPENDENT restatement on torch-CPU library ops -- torch.nn.LSTMCell (different gate order and
 bias handling than TF's BasicLSTMCell, mapped explicitly), F.conv2d, F.normalize, torch.softmax --
 must agree with the numpy oracle to fp64 round-off."""
