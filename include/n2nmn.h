@@ -150,6 +150,12 @@ typedef struct {
   float *encoder_states;           /* [2 layers][c,h][N, lstm_dim]                          */
   float *log_seq_prob;             /* [N] sum_t log token_probs (models_clevr/nmn3_model.py:46) */
   int32_t flags;                   /* N2NMN_S2S_* */
+  /* optional input: [N, H, W, D] image features of the same batch.  When given, the hoisted
+   * conv_image GEMMs (n2nmn_conv_image with FIND | FSP, the second gated by gt_layout under teacher
+   * forcing, by the chosen tokens otherwise) are issued by this call -- under teacher forcing in ONE
+   * launch with encoder_h_transform and q -- and n2nmn_walk_layouts can follow directly.  Only
+   * n2nmn_decoder_forward / n2nmn_seq2seq_forward read it. */
+  const float *image_feat;
 } n2nmn_seq2seq_io;
 /* skip word_vecs / neg_entropy / log_seq_prob (one launch): for inference through
  * n2nmn_walk_layouts with attention maps, which derives the text maps from atts directly */

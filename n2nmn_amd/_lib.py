@@ -30,7 +30,8 @@ class Seq2SeqIO(C.Structure):
         ('predicted_tokens', C.c_void_p), ('token_probs', C.c_void_p), ('neg_entropy', C.c_void_p),
         ('atts', C.c_void_p), ('word_vecs', C.c_void_p), ('token_scores', C.c_void_p),
         ('encoder_outputs', C.c_void_p), ('encoder_h_transformed', C.c_void_p),
-        ('encoder_states', C.c_void_p), ('log_seq_prob', C.c_void_p), ('flags', C.c_int32)]
+        ('encoder_states', C.c_void_p), ('log_seq_prob', C.c_void_p), ('flags', C.c_int32),
+        ('image_feat', C.c_void_p)]
 
 
 class TrainIO(C.Structure):

@@ -134,6 +134,7 @@ static size_t carve_weights(n2nmn_ctx* c, char* base) {
   c->dec_W1_t = k.take<float>(2 * L * 4 * L);
   c->eht_W_p = k.take<float>((size_t)c->KpL * L);
   c->att_W_t = k.take<float>(L * L);
+  c->att_W_p = k.take<float>((size_t)c->KpL * L);
   c->find_img_p = k.take<float>((size_t)c->KpD * Mp);
   c->fsp_img_p = k.take<float>((size_t)c->KpD * Mp);
   c->dec_emb_cat = k.take<float>((V + 1) * (size_t)d.embed_dim_nmn);
@@ -228,7 +229,7 @@ const char* kFamilyNames[F_COUNT] = {
   "lstm_step(linear q)", "dec_attn", "gemm_pk(encoder_h_transform)", "word_vecs", "textmap", "gemm_pk(conv_image)",
   "att_ops", "pool", "heads",
   "lstm_bwd_step", "gemm_tn(weight grads)", "backward misc (modules/attention/gemm_nt)",
-  "optimiser", "walk(layout walker)"};
+  "optimiser", "walk(layout walker)", "gemm_pkn(encoder_h_transform + q + conv_image)"};
 
 
 hipStream_t S(n2nmn_stream s) { return reinterpret_cast<hipStream_t>(s); }
@@ -267,7 +268,30 @@ void rowmajor_a(const n2nmn_ctx* c, LstmJob& j) {
   j.a_rs = c->d.lstm_dim; j.a_ks = 4; j.hp_R = 0;
 }
 
-int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s) {
+// The two hoisted conv_image problems (FindModule / FindSamePropertyModule weight sets) over the N
+// images of a batch; tokens != nullptr gates the second per row tile by the layouts.
+static void conv_image_problems(n2nmn_ctx* c, const float* image_feat, int N, const int32_t* tokens,
+                                int T_dec, GemmArgs ga[2]) {
+  const n2nmn_dims& d = c->d;
+  const int HW = d.H * d.W;
+  const n2nmn_ctx* r = root(c);
+  for (int fsp = 0; fsp < 2; ++fsp) {
+    GemmArgs& g = ga[fsp];
+    g = GemmArgs{};
+    g.A = image_feat; g.lda = d.D; g.M = N * HW; g.K = d.D; g.group_size = HW;
+    g.Bp = fsp ? c->fsp_img_p : c->find_img_p; g.Np = c->Mp; g.Kp = c->KpD;
+    g.bias = c->vars[fsp ? V_FSP_IMG_B : V_FIND_IMG_B].mirror; g.N = d.map_dim;
+    g.C = fsp ? c->mfsp : c->mfind; g.ldc = c->Mp; g.n_store = c->Mp;
+    if (fsp && tokens) {
+      g.gate_tokens = tokens; g.gate_token_op = r->token_op; g.gate_T = T_dec; g.gate_N = N;
+      g.gate_V = d.num_vocab_nmn; g.gate_op = N2NMN_OP_FIND_SAME_PROPERTY; g.gate_rows = HW;
+    }
+  }
+}
+
+// defer_eht != nullptr: the encoder_h_transform GEMM is described there instead of launched -- the
+// decoder puts it into its own GEMM launch (launch_gemm_pkn), nothing in between reads `eht`
+int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmArgs* defer_eht) {
   const n2nmn_dims& d = c->d;
   N2_REQUIRE(is_committed(c), N2NMN_ENOWEIGHT, "encoder_forward: weights not committed");
   N2_REQUIRE(io && io->input_seq && io->seq_length, N2NMN_EINVAL, "encoder_forward: null input");
@@ -325,7 +349,9 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s) {
   g.A = c->enc_out; g.lda = L; g.M = T * N; g.K = L; g.group_idx = nullptr; g.group_size = 1;
   g.Bp = c->eht_W_p; g.Np = L; g.Kp = c->KpL; g.bias = c->vars[V_EHT_B].mirror; g.N = L;
   g.C = c->eht; g.ldc = L; g.n_store = L;
-  {
+  if (defer_eht) {
+    *defer_eht = g;
+  } else {
     ProfScope ps(c, F_GEMM_EHT, 2.0 * T * N * L * L, 4.0 * (2.0 * T * N * L + (double)L * L), s);
     launch_gemm_pk(g, s);
   }
@@ -345,7 +371,10 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s) {
   return check_launch("encoder_forward");
 }
 
-int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s) {
+// pre / npre: GEMM problems that must be complete before the attention runs (the deferred
+// encoder_h_transform); they and -- with io->image_feat -- the hoisted conv_image problems share the
+// decoder's own GEMM launch.
+int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const GemmArgs* pre, int npre) {
   const n2nmn_dims& d = c->d;
   N2_REQUIRE(is_committed(c), N2NMN_ENOWEIGHT, "decoder_forward: weights not committed");
   N2_REQUIRE(has_tables(c), N2NMN_ENOWEIGHT,
@@ -412,13 +441,34 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s) {
                    (j0.active ? by0 : 0) + (j1.active ? by1 : 0), s);
       launch_lstm_step(jobs, 2, N, L, 64, s, c->mode == N2NMN_MODE_THROUGHPUT);
     }
-    LstmJob jq{};                      // q = out . W_a + b_a for all steps  (nmn3_netgen_att.py:185)
-    rowmajor_a(c, jq);
-    jq.active = 1; jq.mode = 1; jq.A0 = c->dec_h1_all; jq.K = L; jq.Wp = c->att_W_t;
-    jq.ntiles = L / 16; jq.bias = c->vars[V_ATT_B].mirror; jq.h_new = c->qbuf; jq.ldo = L;
+    // q = out . W_a + b_a for all steps (nmn3_netgen_att.py:185), in ONE launch with whatever else
+    // is due before the attention / the layout walk: encoder_h_transform, conv_image
     {
-      ProfScope ps(c, F_LINEAR_Q, 2.0 * Td * N * L * L, 4.0 * ((double)L * L + 2.0 * Td * N * L), s);
-      launch_lstm_step(&jq, 1, Td * N, L, 64, s);
+      GemmArgs list[4];
+      int nl = 0;
+      double fl = 0, by = 0;
+      for (int i = 0; i < npre && nl < 2; ++i) {
+        list[nl++] = pre[i];
+        fl += 2.0 * pre[i].M * pre[i].K * pre[i].N;
+        by += 4.0 * ((double)pre[i].M * (pre[i].K + pre[i].N) + (double)pre[i].K * pre[i].N);
+      }
+      GemmArgs& gq = list[nl++];
+      gq = GemmArgs{};
+      gq.A = c->dec_h1_all; gq.lda = L; gq.M = Td * N; gq.K = L; gq.group_size = 1;
+      gq.Bp = c->att_W_p; gq.Np = L; gq.Kp = c->KpL; gq.bias = c->vars[V_ATT_B].mirror; gq.N = L;
+      gq.C = c->qbuf; gq.ldc = L; gq.n_store = L;
+      fl += 2.0 * Td * N * L * L; by += 4.0 * ((double)L * L + 2.0 * Td * N * L);
+      const bool conv = io->image_feat && nl <= 2;
+      if (conv) {
+        const bool gate = root(c)->have_token_ops;
+        conv_image_problems(c, io->image_feat, N, gate ? io->gt_layout : nullptr, Td, list + nl);
+        nl += 2;
+        const double HW = d.H * d.W, frac = gate ? 1.1 : 2.0;     // gated share: see n2nmn_conv_image
+        fl += frac * 2.0 * N * HW * d.D * d.map_dim;
+        by += frac * 4.0 * N * HW * (d.D + c->Mp) + 4.0 * d.D * d.map_dim;
+      }
+      ProfScope ps(c, nl > 1 ? F_GEMM_MULTI : F_LINEAR_Q, fl, by, s);
+      launch_gemm_pkn(list, nl, s);
     }
     a.q = c->qbuf; a.out = c->dec_h1_all; a.gt = io->gt_layout; a.uni = nullptr; a.forced = nullptr;
     a.tokens = tokens; a.tprobs = tprobs; a.ent_t = c->ent_t; a.atts = atts;
@@ -434,6 +484,25 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s) {
       launch_dec_attn(a, Td, s);
     }
   } else {
+    GemmArgs cv[2];
+    if (io->image_feat) conv_image_problems(c, io->image_feat, N, nullptr, Td, cv);
+    if (npre > 0 || io->image_feat) {
+      GemmArgs list[4];
+      int nl = 0;
+      double fl = 0, by = 0;
+      for (int i = 0; i < npre && nl < 3; ++i) {
+        list[nl++] = pre[i];
+        fl += 2.0 * pre[i].M * pre[i].K * pre[i].N;
+        by += 4.0 * ((double)pre[i].M * (pre[i].K + pre[i].N) + (double)pre[i].K * pre[i].N);
+      }
+      if (io->image_feat) {
+        list[nl++] = cv[0];
+        fl += 2.0 * cv[0].M * cv[0].K * cv[0].N;
+        by += 4.0 * ((double)cv[0].M * (cv[0].K + c->Mp) + (double)cv[0].K * cv[0].N);
+      }
+      ProfScope ps(c, nl > 1 ? F_GEMM_MULTI : (io->image_feat ? F_CONV_IMAGE : F_GEMM_EHT), fl, by, s);
+      launch_gemm_pkn(list, nl, s);
+    }
     launch_dec_init(c->state, N, Td, s);
     for (int t = 0; t < Td; ++t) {
       LstmJob j0{};
@@ -481,6 +550,13 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s) {
         ProfScope ps(c, F_DEC_STEP, att_fl, att_by, s);
         launch_dec_attn(a, 1, s);
       }
+    }
+    if (io->image_feat) {              // FindSameProperty maps of the layouts the decoder chose
+      conv_image_problems(c, io->image_feat, N, root(c)->have_token_ops ? tokens : nullptr, Td, cv);
+      const double frac = root(c)->have_token_ops ? 0.1 : 1.0;
+      ProfScope ps(c, F_CONV_IMAGE, frac * 2.0 * cv[1].M * cv[1].K * cv[1].N,
+                   frac * 4.0 * cv[1].M * (cv[1].K + c->Mp), s);
+      launch_gemm_pkn(cv + 1, 1, s);
     }
   }
   if (!(io->flags & N2NMN_S2S_NO_WORD_VECS)) {
@@ -864,6 +940,7 @@ int n2nmn_commit_weights(n2nmn_ctx* c, n2nmn_stream stream) {
     pb.tiles(m(V_DEC_W1), 4 * L, 0, 2 * L, L / 4, L, c->dec_W1_t);
     pb.pk(m(V_EHT_W), L, L, L, c->eht_W_p, c->KpL, L);
     pb.tiles(m(V_ATT_W), L, 0, L, L / 16, 0, c->att_W_t);
+    pb.pk(m(V_ATT_W), L, L, L, c->att_W_p, c->KpL, L);
     pb.pk(m(V_FIND_IMG_W), M, d.D, M, c->find_img_p, c->KpD, Mp);
     pb.pk(m(V_FSP_IMG_W), M, d.D, M, c->fsp_img_p, c->KpD, Mp);
     pb.pad(m(V_DEC_EMB), V, E, c->dec_emb_cat, E);
@@ -935,19 +1012,23 @@ int n2nmn_commit_weights(n2nmn_ctx* c, n2nmn_stream stream) {
 
 int n2nmn_encoder_forward(n2nmn_ctx* ctx, const n2nmn_seq2seq_io* io, n2nmn_stream stream) {
   N2_REQUIRE(ctx, N2NMN_EINVAL, "encoder_forward: null context");
-  return encoder_impl(ctx, io, S(stream));
+  return encoder_impl(ctx, io, S(stream), nullptr);
 }
 
 int n2nmn_decoder_forward(n2nmn_ctx* ctx, const n2nmn_seq2seq_io* io, n2nmn_stream stream) {
   N2_REQUIRE(ctx, N2NMN_EINVAL, "decoder_forward: null context");
-  return decoder_impl(ctx, io, S(stream));
+  return decoder_impl(ctx, io, S(stream), nullptr, 0);
 }
 
 int n2nmn_seq2seq_forward(n2nmn_ctx* ctx, const n2nmn_seq2seq_io* io, n2nmn_stream stream) {
   N2_REQUIRE(ctx, N2NMN_EINVAL, "seq2seq_forward: null context");
-  const int rc = encoder_impl(ctx, io, S(stream));
+  // the encoder_h_transform GEMM rides in the decoder's GEMM launch unless the caller wants a copy
+  // of it (the copy is made by the encoder half)
+  GemmArgs eht{};
+  const bool defer = io && !io->encoder_h_transformed;
+  const int rc = encoder_impl(ctx, io, S(stream), defer ? &eht : nullptr);
   if (rc != N2NMN_OK) return rc;
-  return decoder_impl(ctx, io, S(stream));
+  return decoder_impl(ctx, io, S(stream), defer ? &eht : nullptr, defer ? 1 : 0);
 }
 
 int n2nmn_execute_program(n2nmn_ctx* ctx, n2nmn_program* p, const float* image_feat,
@@ -1032,22 +1113,10 @@ int n2nmn_conv_image(n2nmn_ctx* c, const float* image_feat, int N, int which,
   N2_REQUIRE(!tokens || (root(c)->have_token_ops && T_dec >= 1), N2NMN_EINVAL,
              "conv_image: gating by tokens needs n2nmn_set_token_ops and T_dec");
   const int HW = d.H * d.W;
-  const n2nmn_ctx* r = root(c);
   hipStream_t s = S(stream);
   const double dHW = HW, dD = d.D, dM = d.map_dim, dMp = c->Mp;
   GemmArgs ga[2];
-  for (int fsp = 0; fsp < 2; ++fsp) {
-    GemmArgs& g = ga[fsp];
-    g = GemmArgs{};
-    g.A = image_feat; g.lda = d.D; g.M = N * HW; g.K = d.D; g.group_size = HW;
-    g.Bp = fsp ? c->fsp_img_p : c->find_img_p; g.Np = c->Mp; g.Kp = c->KpD;
-    g.bias = c->vars[fsp ? V_FSP_IMG_B : V_FIND_IMG_B].mirror; g.N = d.map_dim;
-    g.C = fsp ? c->mfsp : c->mfind; g.ldc = c->Mp; g.n_store = c->Mp;
-    if (fsp && tokens) {
-      g.gate_tokens = tokens; g.gate_token_op = r->token_op; g.gate_T = T_dec; g.gate_N = N;
-      g.gate_V = d.num_vocab_nmn; g.gate_op = N2NMN_OP_FIND_SAME_PROPERTY; g.gate_rows = HW;
-    }
-  }
+  conv_image_problems(c, image_feat, N, tokens, T_dec, ga);
   // algorithmic work of the gated problem is not known on the host: the profile line counts the
   // ungated FindModule GEMM in full and the gated one as the reference mix's 1 image in 10
   const double one_fl = 2.0 * N * dHW * dD * dM, one_by = 4.0 * (N * dHW * (dD + dMp)) + 4.0 * dD * dM;
@@ -1055,7 +1124,7 @@ int n2nmn_conv_image(n2nmn_ctx* c, const float* image_feat, int N, int which,
   if (both) {
     const double frac = tokens ? 1.1 : 2.0;
     ProfScope ps(c, F_CONV_IMAGE, frac * one_fl, frac * one_by, s);
-    launch_gemm_pk2(ga[0], ga[1], s);
+    launch_gemm_pkn(ga, 2, s);
   } else {
     for (int fsp = 0; fsp < 2; ++fsp) {
       if (!(which & (fsp ? N2NMN_CONV_FSP : N2NMN_CONV_FIND))) continue;

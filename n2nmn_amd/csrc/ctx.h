@@ -139,7 +139,7 @@ struct n2nmn_ctx {
   // packed weights / derived tables
   float *enc_W0x_p = nullptr, *dec_W0x_p = nullptr, *enc_xtab = nullptr, *dec_xtab = nullptr;
   float *enc_W0h_t = nullptr, *enc_W1_t = nullptr, *dec_W0h_t = nullptr, *dec_W1_t = nullptr;
-  float *eht_W_p = nullptr, *att_W_t = nullptr, *find_img_p = nullptr, *fsp_img_p = nullptr;
+  float *eht_W_p = nullptr, *att_W_t = nullptr, *att_W_p = nullptr, *find_img_p = nullptr, *fsp_img_p = nullptr;
   float* dec_emb_cat = nullptr;
   PackBatch packs;                                   // every re-pack of a commit, one launch
   float *qpn_W1_p = nullptr, *qpn_W2_p = nullptr;    // PK packs of question_prior_net fc1 / fc2
@@ -228,7 +228,7 @@ struct Carver {
 enum Family {
   F_LSTM_ENC = 0, F_LSTM_DEC0, F_LSTM_DEC1, F_LINEAR_Q, F_DEC_STEP, F_GEMM_EHT, F_WORD_VECS,
   F_TEXTMAP, F_CONV_IMAGE, F_ATT_OPS, F_POOL, F_HEADS,
-  F_LSTM_BWD, F_GEMM_TN, F_BWD_MISC, F_OPTIMISER, F_WALK, F_COUNT
+  F_LSTM_BWD, F_GEMM_TN, F_BWD_MISC, F_OPTIMISER, F_WALK, F_GEMM_MULTI, F_COUNT
 };
 extern const char* kFamilyNames[F_COUNT];
 
@@ -260,8 +260,9 @@ int check_launch(const char* what);
 ModuleWeights module_weights(const n2nmn_ctx* c);
 void packed_state(const n2nmn_ctx* c, LstmJob& j);
 void rowmajor_a(const n2nmn_ctx* c, LstmJob& j);
-int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s);
-int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s);
+int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmArgs* defer_eht = nullptr);
+int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const GemmArgs* pre = nullptr,
+                 int npre = 0);
 void train_state_destroy(TrainState* t);
 enum { RP_PREP = 1, RP_CONV = 2, RP_REST = 4, RP_ALL = 7 };
 int run_program(n2nmn_ctx* c, Program& p, const float* feat, const float* word_vecs, int N_full,

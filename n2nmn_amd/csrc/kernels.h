@@ -36,6 +36,9 @@ struct GemmArgs {
 void launch_gemm_pk(const GemmArgs& a, hipStream_t s);
 // two problems (no split-K) in one launch
 void launch_gemm_pk2(const GemmArgs& a0, const GemmArgs& a1, hipStream_t s);
+// up to four problems (no split-K) as one flat, XCD-ordered tile list
+struct GemmBatch { GemmArgs a[4]; int start[5]; };
+void launch_gemm_pkn(const GemmArgs* a, int n, hipStream_t s);
 
 // generic packer: dst PK layout <- src[k*ld + n] (k < K, n < N), zero padded
 void launch_pack_pk(const float* src, int ld, int K, int N, float* dst, int Kp, int Np,

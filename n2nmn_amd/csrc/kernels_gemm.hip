@@ -30,14 +30,14 @@ namespace {
 constexpr int BM = 64, BN = 64, BK = 32;
 constexpr int LDS_STRIDE = BM + 1;   // in float4 units
 
-__device__ __forceinline__ void gemm_pk_body(const GemmArgs& a, const int bz) {
+__device__ __forceinline__ void gemm_pk_body(const GemmArgs& a, const int bz, const int bx, const int by) {
   __shared__ float4 As[2][BK / 4][LDS_STRIDE];
   __shared__ float4 Bs[2][BK / 4][LDS_STRIDE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int m0 = by * BM, n0 = bx * BN;
   if (a.gate_tokens) {        // uniform early exit: none of this tile's images needs the map
     __shared__ int need;
     if (tid == 0) need = 0;
@@ -170,7 +170,9 @@ __device__ __forceinline__ void gemm_pk_body(const GemmArgs& a, const int bz) {
   }
 }
 
-__global__ __launch_bounds__(256) void gemm_pk_kernel(GemmArgs a) { gemm_pk_body(a, blockIdx.z); }
+__global__ __launch_bounds__(256) void gemm_pk_kernel(GemmArgs a) {
+  gemm_pk_body(a, blockIdx.z, blockIdx.x, blockIdx.y);
+}
 
 // two independent problems of the same tile shape in one launch (blockIdx.z selects): the hoisted
 // conv_image GEMMs of FindModule and (token-gated) FindSamePropertyModule share one grid, so the
@@ -178,7 +180,28 @@ __global__ __launch_bounds__(256) void gemm_pk_kernel(GemmArgs a) { gemm_pk_body
 __global__ __launch_bounds__(256) void gemm_pk2_kernel(GemmArgs a0, GemmArgs a1) {
   const GemmArgs a = blockIdx.z == 0 ? a0 : a1;
   if ((int)blockIdx.y * BM >= a.M || (int)blockIdx.x * BN >= a.Np) return;
-  gemm_pk_body(a, 0);
+  gemm_pk_body(a, 0, blockIdx.x, blockIdx.y);
+}
+
+// Up to four independent problems of this tile shape in ONE launch over a flat tile list (no
+// split-K).  Small GEMMs of the forward pass (encoder_h_transform 360 tiles, q 160, conv_image
+// 600 + the gated FindSameProperty tiles) each fill the 256 CUs for one and a fraction rounds; as one
+// list the fractions add up instead of each paying a partly empty last round and a launch.
+// XCD-aware order: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2),
+// so id -> (xcd = id % 8, slot = id / 8) is mapped to list position ((slot / 8) * 8 + xcd) * 8 +
+// slot % 8: runs of 8 consecutive positions -- the column tiles of one or two row tiles, which
+// share their A rows -- execute on ONE XCD and fetch those rows into one L2 instead of up to
+// eight, while the runs themselves rotate over the XCDs so that every XCD sees the same mix of
+// problems (a contiguous eighth of the list per XCD left the XCDs holding the gated problem idle).
+__global__ __launch_bounds__(256) void gemm_pkn_kernel(GemmBatch b) {
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int t = (((slot >> 3) << 3) + xcd) * 8 + (slot & 7);
+  if (t >= b.start[4]) return;
+  const int p = (t >= b.start[1]) + (t >= b.start[2]) + (t >= b.start[3]);
+  const GemmArgs a = p == 0 ? b.a[0] : p == 1 ? b.a[1] : p == 2 ? b.a[2] : b.a[3];
+  const int local = t - (p == 0 ? 0 : p == 1 ? b.start[1] : p == 2 ? b.start[2] : b.start[3]);
+  const int gx = (a.n_store + BN - 1) / BN;
+  gemm_pk_body(a, 0, local % gx, local / gx);
 }
 
 __global__ void pack_pk_kernel(const float* __restrict__ src, int ld, int K, int N,
@@ -316,6 +339,21 @@ void launch_gemm_pk2(const GemmArgs& a0, const GemmArgs& a1, hipStream_t s) {
   const int gx = std::max((a0.n_store + BN - 1) / BN, (a1.n_store + BN - 1) / BN);
   const int gy = std::max((a0.M + BM - 1) / BM, (a1.M + BM - 1) / BM);
   hipLaunchKernelGGL(gemm_pk2_kernel, dim3(gx, gy, 2), dim3(256), 0, s, a0, a1);
+}
+
+void launch_gemm_pkn(const GemmArgs* a, int n, hipStream_t s) {
+  GemmBatch b{};
+  int tiles = 0, np = 0;
+  for (int i = 0; i < n && np < 4; ++i) {
+    if (a[i].M <= 0) continue;
+    b.a[np] = a[i];
+    b.start[np] = tiles;
+    tiles += ((a[i].n_store + BN - 1) / BN) * ((a[i].M + BM - 1) / BM);
+    ++np;
+  }
+  if (!np) return;
+  for (int i = np; i <= 4; ++i) b.start[i] = tiles;
+  hipLaunchKernelGGL(gemm_pkn_kernel, dim3((tiles + 63) / 64 * 64), dim3(256), 0, s, b);
 }
 
 void launch_gemm_pk(const GemmArgs& a, hipStream_t s) {

@@ -158,11 +158,14 @@ class Engine:
 
     def seq2seq(self, input_seq, seq_len, T_dec: Optional[int] = None, use_gt_layout: bool = False,
                 gt_layout=None, sample_uniforms=None, forced_tokens=None, debug: bool = False,
-                reuse_buffers: bool = True, phase: str = 'both', word_vecs: bool = True):
+                reuse_buffers: bool = True, phase: str = 'both', word_vecs: bool = True,
+                image_feat=None):
         """Phase 1.  input_seq [T,N] int32, seq_len [N] int32 (device tensors or anything
         convertible).  Returns a dict of device tensors named like the reference attributes
         (models_clevr/nmn3_netgen_att.py:305-322).  With reuse_buffers the outputs are views of
-        engine-owned buffers that the next call overwrites."""
+        engine-owned buffers that the next call overwrites.  image_feat (optional): the hoisted
+        conv_image GEMMs of the batch are issued by this call too (n2nmn_seq2seq_io.image_feat) and
+        walk() / execute_tokens(conv_done=True) can follow directly."""
         torch = _torch()
         d = self.dims
         seq = self._dev(input_seq, torch.int32)
@@ -196,6 +199,11 @@ class Engine:
         io.forced_tokens = forced.data_ptr() if forced is not None else None
         for k, t in out.items():
             setattr(io, k, t.data_ptr())
+        feat = self._dev(image_feat, torch.float32)
+        if feat is not None:
+            if phase == 'encoder':
+                raise ValueError('image_feat is read by the decoder half')
+            io.image_feat = feat.data_ptr()
         if not word_vecs:        # N2NMN_S2S_NO_WORD_VECS: word_vecs / neg_entropy / log_seq_prob not computed
             io.flags = 1
             for k in ('word_vecs', 'neg_entropy', 'log_seq_prob'):
@@ -203,7 +211,7 @@ class Engine:
         fn = {'both': self._lib.n2nmn_seq2seq_forward, 'encoder': self._lib.n2nmn_encoder_forward,
               'decoder': self._lib.n2nmn_decoder_forward}[phase]
         _lib.check(fn(self._ctx, C.byref(io), self.stream()))
-        out['_keepalive'] = (seq, lens, gt, uni, forced)
+        out['_keepalive'] = (seq, lens, gt, uni, forced, feat)
         out['_input_seq'], out['_seq_length'] = seq, lens
         return out
 
@@ -376,8 +384,9 @@ class Engine:
         from the host copy up front and the step has no host synchronisation at all."""
         if self.walk_supported() and not host_assemble:
             # device path: the walker decodes the layouts itself (no sync between the phases).  The
-            # hoisted conv_image GEMMs need only the features, so they run on a side stream beside
-            # the (latency-bound) recurrent chain of phase 1
+            # hoisted conv_image GEMMs ride in phase 1's own GEMM launch (with encoder_h_transform
+            # and q); N2NMN_OVERLAP_CONV=1 puts them on a side stream beside the recurrent chain
+            # instead (measured slower: they take CUs from the chip-filling step kernels)
             torch = _torch()
             gt_dev = self.upload_i32(gt_layout) if isinstance(gt_layout, np.ndarray) else \
                 self._dev(gt_layout, torch.int32)
@@ -394,10 +403,9 @@ class Engine:
                     self._side_ev.record(self._side)
             table = self.dims.num_vocab_txt <= 4096
             s2s = self.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], T_dec,
-                               use_gt_layout, gt_dev, sample_uniforms, word_vecs=not table)
-            if not self.overlap_conv:
-                self.conv_image(feat, s2s['predicted_tokens'], find=True, fsp=True)
-            elif not known:
+                               use_gt_layout, gt_dev, sample_uniforms, word_vecs=not table,
+                               image_feat=None if self.overlap_conv else feat)
+            if self.overlap_conv and not known:
                 self.conv_image(feat, s2s['predicted_tokens'], find=False, fsp=True)
             if self.overlap_conv:
                 cur.wait_event(self._side_ev)

@@ -124,7 +124,16 @@ def test_c_abi_rccl_communicator_world_1():
         if use:
             assert tr.buckets.world == 1
             tr.buckets.close()
-    assert np.array_equal(out[True][0], out[False][0])
-    assert np.array_equal(out[True][2], out[False][2])
+    # the backward pass accumulates several gradients with float atomics, so two runs of the SAME
+    # step agree to round-off (~1e-7 relative to the largest gradient), not bit for bit
+    def close(a, b, what):
+        tol = 2e-6 * max(float(np.abs(b).max()), 1e-6)
+        assert float(np.abs(a - b).max()) <= tol, what
+    close(out[True][0], out[False][0], 'gradients')
+    close(out[True][2], out[False][2], 'losses')
     for k in out[True][1]:
-        assert np.array_equal(out[True][1][k], out[False][1][k]), k
+        # the first Adam step moves a weight by lr * g / (|g| + eps): round-off in a near-zero g
+        # is amplified up to the step size (lr = 1e-3), so the bulk must agree and no element may
+        # be further apart than two steps
+        diff = np.abs(out[True][1][k] - out[False][1][k])
+        assert float(diff.max()) <= 2.001e-3 and float(diff.mean()) <= 2e-6, k
