@@ -131,8 +131,11 @@ def _lstm_w(w, which, layer):
     return w[base + 'weights'], w[base + 'biases']
 
 
-def encoder_forward(w, input_seq, seq_len):
-    """models_clevr/nmn3_netgen_att.py:73-113 (dynamic_rnn with sequence_length, Appendix A.2)."""
+def encoder_forward(w, input_seq, seq_len, drop0=None):
+    """models_clevr/nmn3_netgen_att.py:73-113 (dynamic_rnn with sequence_length, Appendix A.2).
+    drop0 [T, N, L] of {0, 1} (encoder_dropout=True, models_vqa/nmn3_netgen_att.py:17-44): the
+    DropoutWrapper(output_keep_prob=0.5) around every layer but the last scales the OUTPUT that
+    feeds the next layer by mask / 0.5; the recurrent state h is not touched."""
     T, N = input_seq.shape
     seq = torch.as_tensor(np.asarray(input_seq)).long()
     lens = torch.as_tensor(np.asarray(seq_len)).long()
@@ -146,7 +149,8 @@ def encoder_forward(w, input_seq, seq_len):
     for t in range(T):
         act = (t < lens)[:, None]
         nc0, nh0 = _lstm_cell(E[t], c0, h0, W0, b0)
-        nc1, nh1 = _lstm_cell(nh0, c1, h1, W1, b1)
+        x1 = nh0 if drop0 is None else nh0 * (_t(drop0[t]) * 2.0)
+        nc1, nh1 = _lstm_cell(x1, c1, h1, W1, b1)
         outs.append(torch.where(act, nh1, torch.zeros_like(nh1)))
         c0 = torch.where(act, nc0, c0); h0 = torch.where(act, nh0, h0)
         c1 = torch.where(act, nc1, c1); h1 = torch.where(act, nh1, h1)
@@ -158,9 +162,10 @@ def encoder_forward(w, input_seq, seq_len):
                 states=((c0, h0), (c1, h1)))
 
 
-def decoder_forward_gt(w, enc, T_dec, gt_layout):
+def decoder_forward_gt(w, enc, T_dec, gt_layout, drop0=None):
     """Teacher-forced decoder (nmn3_netgen_att.py:175-312 with use_gt_layout=True): all tokens
-    valid, predicted_token = gt, token_prob = softmax(token_scores)[gt]."""
+    valid, predicted_token = gt, token_prob = softmax(token_scores)[gt].  drop0 [T_dec, N, L]:
+    decoder_dropout=True, as in encoder_forward."""
     (c0, h0), (c1, h1) = enc['states']
     N = h0.shape[0]
     gt = torch.as_tensor(np.asarray(gt_layout)).long()
@@ -175,7 +180,7 @@ def decoder_forward_gt(w, enc, T_dec, gt_layout):
     atts, scores = [], []
     for t in range(T_dec):
         c0, h0 = _lstm_cell(x, c0, h0, W0, b0)
-        c1, h1 = _lstm_cell(h0, c1, h1, W1, b1)
+        c1, h1 = _lstm_cell(h0 if drop0 is None else h0 * (_t(drop0[t]) * 2.0), c1, h1, W1, b1)
         out = h1
         q = out @ Wa + ba
         e = torch.sum(torch.tanh(q[None] + eht) * v, dim=2, keepdim=True)
@@ -349,6 +354,116 @@ def loss_and_grads(w, module_names, batch, T_dec, num_choices, gt_layout, weight
 
 
 # ---- policy-gradient objective: exp_clevr/train_clevr_rl_gt_layout.py:107-129 ----------------
+# ---- models_vqa training (exp_vqa/train_vqa_gt_layout.py:83-116) ------------------------------
+_QPN = O._QPN
+
+
+def add_spatial_coordinate_map(feat):
+    """models_vqa/nmn3_modules.py:11-31 (linspace computed in float32 like TF)."""
+    N, H, W, _ = feat.shape
+    x = _t(np.linspace(-1.0, 1.0, W, dtype=np.float32))
+    y = _t(np.linspace(-1.0, 1.0, H, dtype=np.float32))
+    xm = x[None, None, :, None].expand(N, H, W, 1)
+    ym = y[None, :, None, None].expand(N, H, W, 1)
+    return torch.cat([feat, xm, ym], dim=3)
+
+
+def eval_expr_vqa(w, expr, feat_c, word_vecs, num_choices):
+    """models_vqa/nmn3_modules.py:82-240: _Find, _Transform (the three-way product), _And, _Describe."""
+    if expr['module'] == O.INVALID:
+        return torch.zeros(num_choices, dtype=F64)
+    N_full = word_vecs.shape[1]
+    flat = word_vecs.reshape(-1, word_vecs.shape[-1])
+
+    def find(scope, feat, txt, extra=None):
+        img = _conv1x1(w, scope + 'conv_image', feat)
+        t = _fc(w, scope + 'fc_text', txt)[:, None, None, :]
+        el = img * t if extra is None else img * t * extra
+        return _conv1x1(w, scope + 'conv_eltwise', _l2n(el, 3))
+
+    def rec(e):
+        t, n = e['time_idx'], e['batch_idx']
+        feat = feat_c[n:n + 1]
+        txt = flat[t * N_full + n][None]
+        ins = [rec(e[k]) for k in ('input_0', 'input_1') if k in e]
+        m = e['module']
+        if m == '_Find':
+            return find('FindModule/', feat, txt)
+        if m == '_Transform':
+            s = 'TransformModule/'
+            a = _fc(w, s + 'fc_att', _att_pool(feat, ins[0]))[:, None, None, :]
+            return find(s, feat, txt, a)
+        if m == '_And':
+            return tf_minimum(ins[0], ins[1])
+        if m == '_Describe':
+            s = 'DescribeModule/'
+            tt = _fc(w, s + 'fc_text', txt)
+            a = _fc(w, s + 'fc_att', _att_pool(feat, ins[0]))
+            return _fc(w, s + 'fc_eltwise', _l2n(tt * a, 1))
+        raise KeyError(m)
+
+    return rec(expr)[0]
+
+
+def question_prior_net(w, enc_states, drop_h=None, drop_fc1=None):
+    """models_vqa/question_prior_net.py:10-28; drop_* are {0, 1} keep masks (qpn_dropout=True,
+    keep_prob 0.5 -> kept activations are doubled)."""
+    h = torch.cat([st[1] for st in enc_states], dim=1)
+    if drop_h is not None:
+        h = h * (_t(drop_h) * 2.0)
+    fc1 = torch.relu(h @ w[_QPN + 'fc1/weights'] + w[_QPN + 'fc1/biases'])
+    if drop_fc1 is not None:
+        fc1 = fc1 * (_t(drop_fc1) * 2.0)
+    return fc1 @ w[_QPN + 'fc2/weights'] + w[_QPN + 'fc2/biases']
+
+
+def train_forward_vqa(wt, batch, T_dec, num_choices, gt_layout, masks=None, weight_decay=0.0):
+    """exp_vqa/train_vqa_gt_layout.py:83-116: total = mean(-log_seq_prob) + mean(CE(scores_nmn +
+    scores_qpn)) + weight_decay * l2 (weight_decay = 0 there; NO gradient clipping, :119-123).
+    masks: dict enc0 [T_enc, N, L], dec0 [T_dec, N, L], qpn_h [N, 2L], qpn_fc1 [N, hidden] of {0, 1}
+    keep masks (TF draws them from its RNG; here they are inputs), or None for no dropout."""
+    mk = masks or {}
+    names = list(O.VQA_MODULE_NAMES)
+    enc = encoder_forward(wt, batch['input_seq_batch'], batch['seq_length_batch'], mk.get('enc0'))
+    dec = decoder_forward_gt(wt, enc, T_dec, gt_layout, mk.get('dec0'))
+    exprs, validity = O.assemble(names, np.asarray(gt_layout))
+    feat_c = add_spatial_coordinate_map(_t(batch['image_feat_batch']))
+    _MARGIN['min_gap'] = {}
+    rows = []
+    for n, e in enumerate(exprs):
+        _MARGIN['example'] = n
+        rows.append(eval_expr_vqa(wt, e, feat_c, dec['word_vecs'], num_choices))
+    _MARGIN['example'] = None
+    scores_nmn = torch.stack(rows)
+    scores = scores_nmn + question_prior_net(wt, enc['states'], mk.get('qpn_h'), mk.get('qpn_fc1'))
+    labels = torch.as_tensor(np.asarray(batch['answer_label_batch'])).long()
+    log_seq_prob = torch.sum(torch.log(dec['token_probs']), dim=0)
+    ce = torch.logsumexp(scores, dim=1) - scores[torch.arange(len(labels)), labels]
+    avg_sample_loss = ce.mean()
+    seq_likelihood_loss = torch.mean(-log_seq_prob)
+    l2 = sum(0.5 * torch.sum(v * v) for k, v in wt.items() if k.endswith('weights'))
+    total = seq_likelihood_loss + avg_sample_loss + weight_decay * l2
+    return dict(enc=enc, dec=dec, expr_list=exprs, validity=validity, scores=scores,
+                scores_nmn=scores_nmn, log_seq_prob=log_seq_prob, avg_sample_loss=avg_sample_loss,
+                seq_likelihood_loss=seq_likelihood_loss, l2_reg=l2, total_loss=total)
+
+
+def loss_and_grads_vqa(w, batch, T_dec, num_choices, gt_layout, masks=None, weight_decay=0.0):
+    """numpy in / numpy out: (losses, grads name -> ndarray fp64, extras)."""
+    wt = {k: _t(v).clone().requires_grad_(True) for k, v in w.items()}
+    r = train_forward_vqa(wt, batch, T_dec, num_choices, gt_layout, masks, weight_decay)
+    r['total_loss'].backward()
+    grads = {k: (v.grad.numpy().copy() if v.grad is not None else np.zeros(tuple(v.shape)))
+             for k, v in wt.items()}
+    losses = {k: float(r[k].detach()) for k in ('avg_sample_loss', 'seq_likelihood_loss', 'l2_reg',
+                                                 'total_loss')}
+    extras = dict(scores=r['scores'].detach().numpy().copy(),
+                  log_seq_prob=r['log_seq_prob'].detach().numpy().copy(),
+                  selection_gap=np.array([_MARGIN['min_gap'].get(n, np.inf)
+                                          for n in range(len(r['expr_list']))]))
+    return losses, grads, extras
+
+
 def decoder_forward_tokens(w, enc, T_dec, tokens, token_validity):
     """Decoder run on GIVEN tokens with the automaton's validity masks (constants: they depend on
     the tokens only): what the sampling decoder computed when it drew `tokens`
@@ -469,7 +584,9 @@ def adam_step(w, grads, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8,
     lr_t = lr * np.sqrt(1.0 - beta2 ** step) / (1.0 - beta1 ** step)
     w2, m2, v2 = {}, {}, {}
     for k in w:
-        g = clip_by_norm(np.asarray(grads[k], np.float64), max_grad_l2_norm)
+        g = np.asarray(grads[k], np.float64)
+        if max_grad_l2_norm is not None:           # exp_vqa/train_vqa_gt_layout.py:119-123: no clipping
+            g = clip_by_norm(g, max_grad_l2_norm)
         m2[k] = beta1 * m[k] + (1.0 - beta1) * g
         v2[k] = beta2 * v[k] + (1.0 - beta2) * g * g
         w2[k] = np.asarray(w[k], np.float64) - lr_t * m2[k] / (np.sqrt(v2[k]) + eps)

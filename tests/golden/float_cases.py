@@ -119,6 +119,22 @@ def vqa_setup():
     return d, batch, gt
 
 
+def vqa_labels(d):
+    """answer_label_batch of the VQA training case."""
+    return (np.random.default_rng(VQA_CASE['seed'] + 1).integers(0, d.num_choices, size=d.N)
+            .astype(np.int32))
+
+
+def vqa_dropout_masks(d):
+    """{0, 1} keep masks of the VQA training case (keep_prob 0.5): TF draws them from its RNG, here
+    they are inputs.  enc0 / dec0: DropoutWrapper on the output of LSTM layer 0 (per step);
+    qpn_h / qpn_fc1: the two tf.nn.dropout calls of question_prior_net."""
+    rng = np.random.default_rng(VQA_CASE['seed'] + 2)
+    bern = lambda *shape: (rng.random(shape) < 0.5).astype(np.float32)
+    return dict(enc0=bern(d.T_encoder, d.N, d.lstm_dim), dec0=bern(d.T_decoder, d.N, d.lstm_dim),
+                qpn_h=bern(d.N, d.num_layers * d.lstm_dim), qpn_fc1=bern(d.N, d.qpn_hidden))
+
+
 def vqa_weights(d, dtype=np.float32):
     from n2nmn_amd.vqa import vqa_variable_shapes
     return synth.make_weights_from_shapes(vqa_variable_shapes(d), seed=WEIGHT_SEED, dtype=dtype)

@@ -75,11 +75,11 @@ def fresh_graph(weights, none_dim, requires_grad=False):
     tf.config.multinomial_uniforms = None
 
 
-def exec_loss_block(script, env):
+def exec_loss_block(script, env, first='compiler = nmn3_model_trn.compiler'):
     """exec the reference's loss / optimiser lines (from `compiler = nmn3_model_trn.compiler` to
     `solver_op = solver.apply_gradients(gradients)`) with the script's own training constants."""
     lines = open(os.path.join(REF, script)).read().split('\n')
-    start = next(i for i, l in enumerate(lines) if l.startswith('compiler = nmn3_model_trn.compiler'))
+    start = next(i for i, l in enumerate(lines) if l.startswith(first))
     end = next(i for i, l in enumerate(lines) if l.startswith('solver_op = solver.apply_gradients'))
     for l in lines[:start]:                              # module-level literal constants
         m = re.match(r'^(\w+)\s*=\s*([^#]+?)\s*(#.*)?$', l)
@@ -261,9 +261,64 @@ def case_vqa(out, meta):
                          variables=sorted(v.op.name for v in tf.trainable_variables()))
 
 
+def case_vqa_train(out, meta):
+    """models_vqa with encoder / decoder / question-prior dropout and the loss block of
+    exp_vqa/train_vqa_gt_layout.py:113-131 (no clipping, weight_decay 0, Adam defaults)."""
+    from models_vqa.nmn3_assembler import Assembler
+    from models_vqa.nmn3_model import NMN3Model
+    d, batch, gt = FC.vqa_setup()
+    masks = FC.vqa_dropout_masks(d)
+    labels = FC.vqa_labels(d)
+    fresh_graph(FC.vqa_weights(d), d.N, requires_grad=True)
+    # the masks are handed out in the order the graph asks for them: T_enc encoder steps, T_dec
+    # decoder steps (DropoutWrapper on layer 0), then the two dropouts of question_prior_net
+    order = [masks['enc0'][t] for t in range(d.T_encoder)] + \
+            [masks['dec0'][t] for t in range(d.T_decoder)] + [masks['qpn_h'], masks['qpn_fc1']]
+    it = iter(order)
+
+    def next_mask(shape, keep_prob):
+        m = next(it)
+        assert tuple(shape) == m.shape and keep_prob == 0.5, (shape, m.shape, keep_prob)
+        return m
+    tf.config.dropout_masks = next_mask
+    asm = Assembler(os.path.join(REF, 'exp_vqa/data/vocabulary_layout.txt'))
+    model = NMN3Model(T64(batch['image_feat_batch']), torch.as_tensor(batch['input_seq_batch']),
+                      torch.as_tensor(batch['seq_length_batch']), T_decoder=d.T_decoder,
+                      num_vocab_txt=d.num_vocab_txt, embed_dim_txt=d.embed_dim_txt,
+                      num_vocab_nmn=d.num_vocab_nmn, embed_dim_nmn=d.embed_dim_nmn,
+                      lstm_dim=d.lstm_dim, num_layers=d.num_layers, assembler=asm,
+                      encoder_dropout=True, decoder_dropout=True, decoder_sampling=False,
+                      num_choices=d.num_choices, use_qpn=True, qpn_dropout=True,
+                      use_gt_layout=torch.tensor(True), gt_layout_batch=torch.as_tensor(gt))
+    assert next(it, None) is None, 'not every dropout mask was consumed'
+    tf.config.dropout_masks = None
+    exprs, validity = asm.assemble(n(model.predicted_tokens))
+    assert np.all(validity) and np.array_equal(n(model.predicted_tokens), gt)
+    scores = tf.Session().run(model.scores, feed_dict=model.compiler.build_feed_dict(exprs))
+    key = 'vqa_train'
+    seq2seq_outputs(out, key, model)
+    out[key + '/scores'] = n(scores)
+    proxy = types.SimpleNamespace(compiler=model.compiler, scores=scores,
+                                  log_seq_prob=model.log_seq_prob, l2_reg=model.l2_reg,
+                                  entropy_reg=model.entropy_reg)
+    env = exec_loss_block('exp_vqa/train_vqa_gt_layout.py', dict(
+        tf=tf, nmn3_model_trn=proxy, answer_label_batch=torch.as_tensor(labels)),
+        first='softmax_loss_per_sample = ')
+    solver = env['solver']
+    m = dict(total_loss=float(env['total_loss'].detach()),
+             avg_sample_loss=float(env['avg_sample_loss'].detach()),
+             seq_likelihood_loss=float(env['seq_likelihood_loss'].detach()),
+             weight_decay=env['weight_decay'], fold_batches=model.compiler.batch_sizes,
+             variables=sorted(v.op.name for v in tf.trainable_variables()))
+    m['grad'] = probes(out, key + '/grad', {v.op.name: g for g, v in solver.last_raw_gradients})
+    env['solver_op'].run()                               # one Adam step (TF 1.0.0 defaults)
+    m['adam_w1'] = probes(out, key + '/adam_w1', {v.op.name: v for v in tf.trainable_variables()})
+    meta[key] = m
+
+
 def generate():
     out, meta = {}, {}
-    for fn in (case_greedy, case_gt, case_sampled, case_modules, case_vqa):
+    for fn in (case_greedy, case_gt, case_sampled, case_modules, case_vqa, case_vqa_train):
         fn(out, meta)
         print('%-14s done (%d arrays so far)' % (fn.__name__, len(out)), flush=True)
     out['meta_json'] = np.frombuffer(json.dumps(meta, sort_keys=True).encode(), np.uint8)

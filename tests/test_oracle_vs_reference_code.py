@@ -194,6 +194,31 @@ def test_vqa_model(fx, mode):
             {'FindModule', 'TransformModule', 'AndModule', 'DescribeModule'}
 
 
+def test_vqa_training_step_with_dropout(fx):
+    """models_vqa with encoder / decoder / question-prior dropout + the loss block of
+    exp_vqa/train_vqa_gt_layout.py: losses, logits, EVERY variable's gradient, one Adam step
+    (no clipping, weight_decay 0)."""
+    z, meta = fx
+    m = meta['vqa_train']
+    d, batch, gt = FC.vqa_setup()
+    batch = dict(batch, answer_label_batch=FC.vqa_labels(d))
+    masks = FC.vqa_dropout_masks(d)
+    w = {k: v.astype(np.float64) for k, v in FC.vqa_weights(d).items()}
+    assert m['variables'] == sorted(w)
+    losses, grads, ex = G.loss_and_grads_vqa(w, batch, d.T_decoder, d.num_choices, gt, masks,
+                                             m['weight_decay'])
+    close('scores', ex['scores'], z['vqa_train/scores'], 1e-9)
+    close('log_seq_prob', ex['log_seq_prob'], z['vqa_train/log_seq_prob'])
+    for k in ('total_loss', 'avg_sample_loss', 'seq_likelihood_loss'):
+        assert abs(losses[k] - m[k]) <= 1e-10 * max(1.0, abs(m[k])), k
+    check_probes(z, 'vqa_train/grad', m['grad'], grads)
+    zeros = {k: np.zeros_like(v) for k, v in w.items()}
+    w1, _, _ = G.adam_step(w, grads, zeros, zeros, 1, max_grad_l2_norm=None)
+    check_probes(z, 'vqa_train/adam_w1', m['adam_w1'], w1)
+    # dropout really changed the result: the no-dropout logits differ
+    assert np.abs(ex['scores'] - z['vqa_gt/scores']).max() > 1e-3
+
+
 @pytest.mark.skipif(not os.path.isdir('/root/reference/models_clevr'),
                     reason='reference checkout not present (GPU box)')
 def test_fixture_is_what_the_reference_code_computes_today():
