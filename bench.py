@@ -52,10 +52,11 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--config', type=int, default=2, choices=(2, 3, 4, 5),
+    ap.add_argument('--config', type=int, default=2, choices=(2, 3, 4, 5, 6),
                     help='2: fixed gt layouts (metric config); 3: greedy decoder layouts; '
                          '4: training step (forward + backward + RCCL all-reduce + Adam); '
-                         '5: models_vqa forward (14x14x2048 feats, batch 128)')
+                         '5: models_vqa forward (14x14x2048 feats, batch 128); '
+                         '6: models_vqa training step (batch 64, dropout, Adam)')
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--inflight', type=int, default=8,
                     help='batches of --batch questions super-bucketed into one pass (1..16)')
@@ -330,6 +331,66 @@ def bench_vqa(args, dp, local_rank):
     dp.close()
 
 
+def bench_vqa_train(args, dp, local_rank):
+    """models_vqa training step (exp_vqa/train_vqa_gt_layout.py:27-39,148-190): batch 64 per GPU,
+    encoder / decoder / question-prior dropout, forward + backward + Adam (no clipping), ground-truth
+    layouts from the v2 histogram, 17742-word vocabulary, 3001 answers."""
+    import numpy as np
+    import torch
+    from n2nmn_amd import synth, vqa
+    rank, world = dp.rank, dp.world
+    d = vqa.VQADims(N=args.batch)
+    eng = vqa.VQAEngine(d, device=local_rank)
+    eng.load_weights(synth.make_weights_from_shapes(vqa.vqa_variable_shapes(d), seed=0))
+    dev = eng.engine.device
+    tr = vqa.VQATrainer(eng, dist=dp._dist)
+    mix = (['_Find', '_Find', '_And', '_Describe'],) * 46 + (['_Find', '_Describe'],) * 43 + \
+          (['_Find', '_Transform', '_Describe'],) * 9 + (['_Find', '_Transform', '_Find', '_And', '_Describe'],) * 2
+    rng = np.random.default_rng(dp.batch_seed(0))
+    batches, gts = [], []
+    for i in range(3):
+        lens = rng.integers(3, d.T_encoder + 1, size=d.N).astype(np.int32)
+        seq = rng.integers(0, d.num_vocab_txt, size=(d.T_encoder, d.N)).astype(np.int32)
+        seq[np.arange(d.T_encoder)[:, None] >= lens[None, :]] = 0
+        feat = torch.relu(torch.randn((d.N, d.H, d.W, d.D), generator=torch.Generator().manual_seed(i)))
+        batches.append(dict(input_seq_batch=torch.as_tensor(seq).to(dev),
+                            seq_length_batch=torch.as_tensor(lens).to(dev),
+                            image_feat_batch=feat.to(dev),
+                            answer_label_batch=torch.as_tensor(
+                                rng.integers(0, d.num_choices, size=d.N).astype(np.int32)).to(dev)))
+        order = rng.permutation(100)
+        gts.append(np.array([eng.assembler.module_list2tokens(mix[order[n % 100]], d.T_decoder)
+                             for n in range(d.N)], np.int32).T.copy())
+
+    def run_steps(first, count):
+        for i in range(first, first + count):
+            tr.step(batches[i % 3], gts[i % 3])
+
+    run_steps(0, args.warmup)
+    elapsed = dp.timed(lambda: run_steps(args.warmup, args.steps),
+                       sync=lambda: torch.cuda.synchronize(dev))
+    if rank == 0:
+        out = {'metric': 'questions/sec (training step) on VQAv2 14x14x2048 feats, batch %d per GPU' % d.N,
+               'value': round(dp.throughput(d.N * args.steps, elapsed), 1), 'unit': 'questions/sec',
+               'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+               'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True,
+               'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': 'models_vqa training step (exp_vqa/train_vqa_gt_layout.py): forward '
+                                      '+ backward + Adam, dropout on, gt layouts (v2 histogram), batch %d '
+                                      'per GPU, T_enc=26, T_dec=13' % d.N,
+                          'global_batch': world * d.N, 'parallelism': 'dp%d' % world},
+               'losses': [round(float(x), 4) for x in tr.losses[:4].cpu()]}
+        if not args.no_profile:
+            ksteps = min(args.steps, 5)
+            eng.engine.profile_begin()
+            run_steps(0, ksteps)
+            rows = kernel_rows(eng.engine.profile_end(), ksteps)
+            out['kernels'] = rows
+            out['gpu_us_per_step'] = round(sum(r['us_per_step'] for r in rows), 1)
+        print(json.dumps(out), flush=True)
+    dp.close()
+
+
 def spawn_command(args, argv):
     """The torch.distributed.run command that runs this script on args.gpus ranks of one node."""
     import socket
@@ -402,6 +463,8 @@ def main():
     rank, world = dp.rank, dp.world
     if args.config == 4:
         return bench_train(args, dp, local_rank)
+    if args.config == 6:
+        return bench_vqa_train(args, dp, local_rank)
     if args.config == 5:
         return bench_vqa(args, dp, local_rank)
 

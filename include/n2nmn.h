@@ -357,6 +357,16 @@ typedef struct {
   float lambda_entropy;            /* 0.005         (:41)                                    */
   float baseline_decay;            /* 0.99          (:42)                                    */
   float *baseline;                 /* device float[1]: read for this step's loss, then updated */
+  /* dropout of the models_vqa training graph (encoder_dropout / decoder_dropout / qpn_dropout,
+   * exp_vqa/train_vqa_gt_layout.py:33-39; models_vqa/nmn3_netgen_att.py:17-44: DropoutWrapper on the
+   * OUTPUT of every LSTM layer but the last; models_vqa/question_prior_net.py:22-26).  TF draws the
+   * masks from its own RNG stream; here they are inputs: float MULTIPLIERS, 0 for a dropped element
+   * and 1 / keep_prob (= 2) for a kept one (n2nmn_dropout_multipliers fills such a buffer from a
+   * counter-based generator).  NULL = that dropout is off.  Row order: the batch's own. */
+  const float *drop_enc0;          /* [T_enc, N, lstm_dim]: encoder LSTM layer 0 -> layer 1   */
+  const float *drop_dec0;          /* [T_dec, N, lstm_dim]: decoder LSTM layer 0 -> layer 1   */
+  const float *drop_qpn_h;         /* [N, 2 * lstm_dim]: question_prior_net input h_concat    */
+  const float *drop_qpn_fc1;       /* [N, qpn_hidden]: after fc1 + ReLU                       */
 } n2nmn_train_io;
 #define N2NMN_OBJ_CLONING 0
 #define N2NMN_OBJ_POLICY_GRADIENT 1
@@ -375,8 +385,15 @@ int n2nmn_train_forward(n2nmn_ctx *ctx, const n2nmn_train_io *io, n2nmn_program 
  * n2nmn_train_forward with the same io / program, in this order, on the same stream. */
 int n2nmn_train_backward(n2nmn_ctx *ctx, const n2nmn_train_io *io, n2nmn_program *p, int phase,
                          n2nmn_stream stream);
+/* out[i] = u_i < keep_prob ? 1 / keep_prob : 0 for i in [0, n), u_i the element offset + i of the
+ * counter-based stream `seed` (tf.nn.dropout / DropoutWrapper draw from TF's RNG,
+ * models_vqa/question_prior_net.py:22-26, models_vqa/nmn3_netgen_att.py:27): the multiplier buffers
+ * n2nmn_train_io.drop_* expect.  Stateless: any slice can be regenerated from (seed, offset). */
+int n2nmn_dropout_multipliers(float *out, int64_t n, float keep_prob, uint64_t seed, uint64_t offset,
+                              n2nmn_stream stream);
 /* g = grads * grad_scale (1/world_size after a sum all-reduce); per-tensor tf.clip_by_norm(g,
- * max_grad_l2_norm); Adam update (TF 1.0.0: lr_t = lr*sqrt(1-b2^step)/(1-b1^step)) of the
+ * max_grad_l2_norm) -- max_grad_l2_norm <= 0: no clipping, as exp_vqa/train_vqa_gt_layout.py:119-123
+ * trains --; Adam update (TF 1.0.0: lr_t = lr*sqrt(1-b2^step)/(1-b1^step)) of the
  * registered variables in place; re-packs the weights (n2nmn_commit_weights).  step = 1 first. */
 int n2nmn_adam_step(n2nmn_ctx *ctx, const float *grads, float grad_scale, float lr, float beta1,
                     float beta2, float eps, float max_grad_l2_norm, int64_t step,

@@ -43,7 +43,9 @@ class TrainIO(C.Structure):
         ('scores', C.c_void_p), ('losses', C.c_void_p), ('grads', C.c_void_p),
         ('objective', C.c_int32), ('expr_validity', C.c_void_p),
         ('invalid_expr_loss', C.c_float), ('lambda_entropy', C.c_float),
-        ('baseline_decay', C.c_float), ('baseline', C.c_void_p)]
+        ('baseline_decay', C.c_float), ('baseline', C.c_void_p),
+        ('drop_enc0', C.c_void_p), ('drop_dec0', C.c_void_p), ('drop_qpn_h', C.c_void_p),
+        ('drop_qpn_fc1', C.c_void_p)]
 
 
 class Node(C.Structure):
@@ -110,6 +112,7 @@ SYMBOLS = [
     ('n2nmn_train_backward', _I, [_P, C.POINTER(TrainIO), _P, _I, _P]),
     ('n2nmn_adam_step', _I, [_P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                              C.c_float, C.c_int64, _P]),
+    ('n2nmn_dropout_multipliers', _I, [_P, C.c_int64, C.c_float, C.c_uint64, C.c_uint64, _P]),
     ('n2nmn_train_reset_optimizer', _I, [_P, _P]),
     ('n2nmn_get_weight', _I, [_P, C.c_char_p, _P, _P]),
     ('n2nmn_train_debug_tensor', C.c_int64, [_P, C.c_char_p, _P, C.c_int64, _P]),

@@ -319,6 +319,14 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmAr
     j1.active = st >= 0;
     packed_state(c, j1);
     j1.A0 = c->eh0[st & 1]; j1.A1 = c->eh1[(st + 1) & 1]; j1.K = 2 * L; j1.Wp = c->enc_W1_t;
+    if (c->rec && c->rec->drop_enc0) {   // DropoutWrapper on layer 0's output (training, models_vqa)
+      const size_t nl = (size_t)N * L;
+      if (j0.active) {
+        j0.drop = c->rec->drop_enc0 + (size_t)k * nl; j0.h_drop = c->rec->ehd[k & 1];
+        j0.save_hd = c->rec->eh0d + (size_t)k * nl;
+      }
+      j1.A0 = c->rec->ehd[st & 1];
+    }
     j1.xtab = nullptr; j1.xidx = nullptr; j1.bias = c->vars[V_ENC_B1].mirror;
     j1.c_in = c->ec1; j1.c_out = c->ec1; j1.ntiles = L / 4;
     j1.h_old = c->eh1[(st + 1) & 1]; j1.h_new = c->eh1[st & 1];
@@ -423,6 +431,14 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
       packed_state(c, j1);
       j1.A0 = c->dh0[st & 1]; j1.A1 = st == 0 ? c->fh1 : c->dh1[(st + 1) & 1];
       j1.K = 2 * L; j1.Wp = c->dec_W1_t; j1.ntiles = L / 4; j1.bias = c->vars[V_DEC_B1].mirror;
+      if (c->rec && c->rec->drop_dec0) {
+        const size_t nl = (size_t)N * L;
+        if (j0.active) {
+          j0.drop = c->rec->drop_dec0 + (size_t)k * nl; j0.h_drop = c->rec->dhd[k & 1];
+          j0.save_hd = c->rec->dh0d + (size_t)k * nl;
+        }
+        j1.A0 = c->rec->dhd[st & 1];
+      }
       j1.c_in = st == 0 ? c->fc1 : c->dc1; j1.c_out = c->dc1;
       j1.h_old = j1.A1; j1.h_new = c->dh1[st & 1];
       j1.out_seq = st >= 0 ? c->dec_h1_all + (size_t)st * N * L : nullptr;
@@ -567,6 +583,33 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
                      io->log_seq_prob ? io->log_seq_prob : (c->rec ? c->rec->lsp : nullptr), s);
   }
   return check_launch("decoder_forward");
+}
+
+// scores += fc2(drop(relu(fc1(drop(h_concat)))))   (models_vqa/question_prior_net.py:10-28).
+// drop_h / drop_fc1: dropout multipliers (training) or nullptr.  What the backward pass needs stays
+// in the workspace: qpn_h (the dropped input) and qpn_hid (the dropped ReLU output).
+int qpn_forward(n2nmn_ctx* c, int N, float* scores, const float* drop_h, const float* drop_fc1,
+                hipStream_t s) {
+  const n2nmn_dims& d = c->d;
+  const int L = d.lstm_dim, Hq = d.qpn_hidden, C = d.num_choices;
+  const n2nmn_ctx* r = root(c);
+  // h_concat = [h of layer 0, h of layer 1]  (question_prior_net.py:14-20), row-major [N][2L]
+  launch_unpack_h2(c->fh0, c->fh1, c->qpn_h, N, L, d.N, s);
+  if (drop_h) launch_ew_mul(c->qpn_h, drop_h, (size_t)N * 2 * L, s);
+  GemmArgs g{};
+  g.A = c->qpn_h; g.lda = 2 * L; g.M = N; g.K = 2 * L; g.group_size = 1;
+  g.Bp = r->qpn_W1_p; g.Np = round_up(Hq, 64); g.Kp = round_up(2 * L, 32);
+  g.bias = r->vars[V_QPN_B1].mirror; g.N = Hq; g.C = c->qpn_hid; g.ldc = Hq; g.n_store = Hq;
+  g.relu = 1;                                      // fc_relu (util/cnn.py:121-126)
+  launch_gemm_pk(g, s);
+  if (drop_fc1) launch_ew_mul(c->qpn_hid, drop_fc1, (size_t)N * Hq, s);
+  GemmArgs g2{};
+  g2.A = c->qpn_hid; g2.lda = Hq; g2.M = N; g2.K = Hq; g2.group_size = 1;
+  g2.Bp = r->qpn_W2_p; g2.Np = round_up(C, 64); g2.Kp = round_up(Hq, 32);
+  g2.bias = r->vars[V_QPN_B2].mirror; g2.N = C; g2.C = scores; g2.ldc = C; g2.n_store = C;
+  g2.accumulate = 1;                               // scores = scores_nmn + scores_qpn
+  launch_gemm_pk(g2, s);
+  return check_launch("question_prior_net");
 }
 
 int run_program(n2nmn_ctx* c, Program& p, const float* feat, const float* word_vecs,
@@ -1309,25 +1352,7 @@ int n2nmn_question_prior_add(n2nmn_ctx* c, int N, float* scores, n2nmn_stream st
   N2_REQUIRE(is_committed(c), N2NMN_ENOWEIGHT, "question_prior_add: weights not committed");
   N2_REQUIRE(c->enc_T > 0 && N == c->enc_N, N2NMN_EINVAL,
              "question_prior_add: no matching encoder results in the context");
-  const n2nmn_dims& d = c->d;
-  const int L = d.lstm_dim, Hq = d.qpn_hidden, C = d.num_choices;
-  hipStream_t s = S(stream);
-  const n2nmn_ctx* r = root(c);
-  // h_concat = [h of layer 0, h of layer 1]  (question_prior_net.py:14-20), row-major [N][2L]
-  launch_unpack_h2(c->fh0, c->fh1, c->qpn_h, N, L, d.N, s);
-  GemmArgs g{};
-  g.A = c->qpn_h; g.lda = 2 * L; g.M = N; g.K = 2 * L; g.group_size = 1;
-  g.Bp = r->qpn_W1_p; g.Np = round_up(Hq, 64); g.Kp = round_up(2 * L, 32);
-  g.bias = r->vars[V_QPN_B1].mirror; g.N = Hq; g.C = c->qpn_hid; g.ldc = Hq; g.n_store = Hq;
-  g.relu = 1;                                      // fc_relu (util/cnn.py:121-126)
-  launch_gemm_pk(g, s);
-  GemmArgs g2{};
-  g2.A = c->qpn_hid; g2.lda = Hq; g2.M = N; g2.K = Hq; g2.group_size = 1;
-  g2.Bp = r->qpn_W2_p; g2.Np = round_up(C, 64); g2.Kp = round_up(Hq, 32);
-  g2.bias = r->vars[V_QPN_B2].mirror; g2.N = C; g2.C = scores; g2.ldc = C; g2.n_store = C;
-  g2.accumulate = 1;                               // scores = scores_nmn + scores_qpn
-  launch_gemm_pk(g2, s);
-  return check_launch("question_prior_add");
+  return qpn_forward(c, N, scores, nullptr, nullptr, S(stream));
 }
 
 int n2nmn_profile_begin(n2nmn_ctx* ctx) {

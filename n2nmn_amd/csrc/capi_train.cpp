@@ -29,6 +29,13 @@ struct TrainState {
         *dctx = nullptr, *dq = nullptr, *dout = nullptr, *dvp = nullptr, *deht = nullptr,
         *denc_out = nullptr;
   float *dz0_all = nullptr, *dz1_all = nullptr;
+  // models_vqa: large answer head and question prior net as batch GEMMs
+  int Cp = 0;                         // num_choices rounded up to 4 (row stride of ds_pad)
+  float *ds_pad = nullptr;            // [N][Cp] zero-padded dscores
+  float *hb_den = nullptr, *hb_en = nullptr;   // [N][Mp]
+  int32_t* hb_sel = nullptr;          // [N] 1 where the row has a Describe head
+  float *qpn_dad = nullptr, *qpn_dh = nullptr; // [N][Hq], [N][2L]
+  float *wde_T_p = nullptr, *qpn_W2T_p = nullptr, *qpn_W1T_p = nullptr;   // transposed packs
   float *dzk0[2] = {nullptr, nullptr}, *dzk1[2] = {nullptr, nullptr};
   float *dH0 = nullptr, *dH1 = nullptr, *dC0 = nullptr, *dC1 = nullptr;
   char *zero_begin = nullptr, *zero_end = nullptr;   // dtmap..act_count: one memset per step
@@ -111,6 +118,11 @@ size_t carve_train(n2nmn_ctx* c, TrainState* t, char* base) {
   r.dc0s = k.take<float>((Td + 1) * N * L); r.dc1s = k.take<float>((Td + 1) * N * L);
   r.dh0s = k.take<float>((Td + 1) * N * L); r.dh1s = k.take<float>((Td + 1) * N * L);
   r.ctx = k.take<float>(Td * N * L);
+  if (d.variant == N2NMN_VARIANT_VQA) {      // dropout on LSTM layer 0's output (models_vqa training)
+    for (int i = 0; i < 2; ++i) { r.ehd[i] = k.take<float>(N * L); r.dhd[i] = k.take<float>(N * L); }
+    r.eh0d = k.take<float>(T * N * L);
+    r.dh0d = k.take<float>(Td * N * L);
+  }
   r.tscores = k.take<float>(Td * N * V);
   r.lsp = k.take<float>(N);
   r.pooled = k.take<float>((size_t)c->max_pool * 2 * D);
@@ -131,7 +143,25 @@ size_t carve_train(n2nmn_ctx* c, TrainState* t, char* base) {
   t->dxtab_enc = k.take<float>(Vt * 4 * L);
   t->dxtab_dec = k.take<float>((V + 1) * 4 * L);
   t->act_count = k.take<int32_t>(4);
+  if (c->big_heads) {
+    t->hb_en = k.take<float>(N * Mp);
+    t->hb_sel = k.take<int32_t>(N);
+  }
   t->zero_end = reinterpret_cast<char*>(k.take<float>(0));
+  t->Cp = (int)((C + 3) & ~(size_t)3);
+  if (c->big_heads) {
+    t->ds_pad = k.take<float>(N * (size_t)t->Cp);
+    t->hb_den = k.take<float>(N * Mp);
+    t->wde_T_p = k.take<float>((size_t)round_up((int)C, 32) * round_up(d.map_dim, 64));
+  }
+  if (c->qpn_h) {
+    const size_t Hq = d.qpn_hidden;
+    if (!t->ds_pad) t->ds_pad = k.take<float>(N * (size_t)t->Cp);
+    t->qpn_dad = k.take<float>(N * Hq);
+    t->qpn_dh = k.take<float>(N * 2 * L);
+    t->qpn_W2T_p = k.take<float>((size_t)round_up((int)C, 32) * round_up((int)Hq, 64));
+    t->qpn_W1T_p = k.take<float>((size_t)round_up((int)Hq, 32) * round_up((int)(2 * L), 64));
+  }
   t->dmfind = k.take<float>(N * HW * Mp);
   t->dmfsp = k.take<float>(N * HW * Mp);
   t->datts_wv = k.take<float>(Td * T * N);
@@ -194,6 +224,13 @@ int repack_transposed(n2nmn_ctx* c, hipStream_t s) {
     pb.tiles_t(m(V_DEC_W0), 4 * L, E, L, t->dec_Wt0, 8 * L, 4 * L);
     pb.pk_t(m(V_EHT_W), L, L, L, t->eht_WT_p, c->KpL, L);
     pb.pk_t(m(V_ATT_W), L, L, L, t->att_WT_p, c->KpL, L);
+    const int Cc = d.num_choices, Hq = d.qpn_hidden;
+    if (t->wde_T_p)        // den = dscores . W_e^T: B'[k = class][n = map channel]
+      pb.pk_t(m(V_DE_E_W), Cc, Cc, d.map_dim, t->wde_T_p, round_up(Cc, 32), round_up(d.map_dim, 64));
+    if (t->qpn_W2T_p) {
+      pb.pk_t(m(V_QPN_W2), Cc, Cc, Hq, t->qpn_W2T_p, round_up(Cc, 32), round_up(Hq, 64));
+      pb.pk_t(m(V_QPN_W1), Hq, Hq, 2 * L, t->qpn_W1T_p, round_up(Hq, 32), round_up(2 * L, 64));
+    }
     const int Ep = round_up(E, 64);
     // B[k][n] = W0[n][k], k < 4L (gate pre-activations), n < E (embedding dims)
     pb.pk_t(m(V_ENC_W0), 4 * L, 4 * L, E, t->enc_W0xT_p, t->KpL4, Ep);
@@ -274,6 +311,7 @@ struct BpttArgs {
   const float *c0s, *c1s;       // [(T+1)][N][L]
   const float* dout;            // [T][N][L] gradient arriving at the top layer's outputs
   const float *Wt0, *Wt1;
+  const float* drop0;           // [T][N][L] dropout multipliers of layer 0's output, or nullptr
 };
 
 int run_bptt(n2nmn_ctx* c, const BpttArgs& a, hipStream_t s) {
@@ -306,6 +344,7 @@ int run_bptt(n2nmn_ctx* c, const BpttArgs& a, hipStream_t s) {
       j0.gates = a.g0 + (size_t)t0 * nl; j0.c_new = a.c0s + (size_t)(t0 + 1) * nl;
       j0.c_prev = a.c0s + (size_t)t0 * nl; j0.dout = nullptr;
       j0.dz_rm = t->dz0_all + (size_t)t0 * N * 4 * L;
+      if (a.drop0) j0.drop = a.drop0 + (size_t)t0 * nl;
     }
     const double fl = 2.0 * N * L * ((j1.active && j1.gemm ? 4.0 * L : 0) + (j0.active ? 8.0 * L : 0));
     const double by = 4.0 * ((j1.active && j1.gemm ? 4.0 * L * L + 4.0 * N * L : 0) +
@@ -326,10 +365,12 @@ extern "C" {
 int n2nmn_train_enable(n2nmn_ctx* c) {
   N2_REQUIRE(c, N2NMN_EINVAL, "train_enable: null context");
   N2_REQUIRE(!c->parent, N2NMN_EINVAL, "train_enable: train on the root context");
-  N2_REQUIRE(c->d.variant == N2NMN_VARIANT_CLEVR, N2NMN_EINVAL,
-             "train_enable: the training step is built for the models_clevr variant");
-  N2_REQUIRE((c->d.H * c->d.W + TRANSFORM_PARTS - 1) / TRANSFORM_PARTS <= 64, N2NMN_EINVAL,
+  const bool vqa_variant = c->d.variant == N2NMN_VARIANT_VQA;
+  N2_REQUIRE(vqa_variant || (c->d.H * c->d.W + TRANSFORM_PARTS - 1) / TRANSFORM_PARTS <= 64, N2NMN_EINVAL,
              "train_enable: the Transform backward handles at most 64 pixels per part (H*W <= 192)");
+  N2_REQUIRE(!c->big_heads || (vqa_variant && c->d.map_dim % 4 == 0), N2NMN_EINVAL,
+             "train_enable: map_dim * num_choices beyond the fused answer head is built for models_vqa "
+             "(map_dim a multiple of 4)");
   if (c->train) return N2NMN_OK;
   N2_REQUIRE(c->d.num_vocab_nmn <= 15, N2NMN_EINVAL,
              "train_enable: num_vocab_nmn + <go> must fit 16 x-table rows");
@@ -472,6 +513,10 @@ int n2nmn_train_forward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* p
   const bool rl = io->objective == N2NMN_OBJ_POLICY_GRADIENT;
   sio.T_dec = io->T_dec; sio.use_gt_layout = rl ? 2 : 1; sio.gt_layout = io->gt_layout;
   t->last_N = N; t->last_T = io->T_enc; t->last_Td = io->T_dec;
+  const bool vqa = d.variant == N2NMN_VARIANT_VQA;
+  N2_REQUIRE(vqa || !(io->drop_enc0 || io->drop_dec0 || io->drop_qpn_h || io->drop_qpn_fc1),
+             N2NMN_EINVAL, "train_forward: dropout belongs to the models_vqa variant");
+  t->rec.drop_enc0 = io->drop_enc0; t->rec.drop_dec0 = io->drop_dec0;
   c->rec = &t->rec;
   float* scores = io->scores ? io->scores : t->scores;
   // the hoisted conv_image GEMMs of the module network need only the image features: they run on
@@ -496,6 +541,10 @@ int n2nmn_train_forward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* p
                      0, 0, s, RP_REST);
   c->rec = nullptr;
   if (rc != N2NMN_OK) return rc;
+  if (c->qpn_h) {                    // scores = scores_nmn + scores_qpn (models_vqa/nmn3_model.py:106-112)
+    rc = qpn_forward(c, N, scores, io->drop_qpn_h, io->drop_qpn_fc1, s);
+    if (rc != N2NMN_OK) return rc;
+  }
   if (scores != t->scores)
     N2_HIP(hipMemcpyAsync(t->scores, scores, sizeof(float) * (size_t)N * d.num_choices,
                           hipMemcpyDeviceToDevice, s));
@@ -511,7 +560,8 @@ int n2nmn_train_forward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* p
       la.losses = io->losses; la.coef = t->rl_coef;
       launch_loss_rl(la, s);
     } else {
-      launch_loss(t->scores, io->answer_labels, t->rec.lsp, N, d.num_choices, t->dscores, io->losses, s);
+      launch_loss(t->scores, io->answer_labels, t->rec.lsp, N, d.num_choices, t->dscores, io->losses, s,
+                  t->ds_pad, t->Cp);
     }
   }
   return check_launch("train_forward");
@@ -601,6 +651,11 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
       for (int i = 0; i < 4; ++i) g.gbatt[i] = G(attb[i]);
       const int answ[7] = {V_EXIST_W, V_COUNT_W, V_EQ_W, V_MORE_W, V_LESS_W, V_SP_E_W, V_DE_E_W};
       for (int i = 0; i < 7; ++i) { g.gWans[i] = G(answ[i]); g.gbans[i] = G(answ[i] + 1); }
+      if (c->big_heads) {              // den[n] = dscores[n] . W_e^T for the whole batch
+        gemm_nt(c, s, t->ds_pad, t->Cp, N, t->Cp, t->wde_T_p, round_up(M, 64), round_up(C, 32), M,
+                t->hb_den, Mp, false);
+        g.hb_den = t->hb_den; g.hb_en = t->hb_en; g.hb_sel = t->hb_sel;
+      }
       bool att_done = false;
       hipStream_t sd = nullptr;        // side stream, forked once every level launch is enqueued
       for (int li = (int)p.launches.size() - 1; li >= 0; --li) {
@@ -638,10 +693,14 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
                 GemmTnArgs ga{};
                 ga.A = t->rec.pooled; ga.lda = D; ga.M = D; ga.a_group_size = 1;
                 ga.B = t->dpfc; ga.ldb = Mp; ga.N = M; ga.b_sel = t->pool_sel; ga.R = 2 * p.num_pool;
-                ga.ldc = M; ga.nprob = 4;
+                ga.ldc = M; ga.nprob = 0;
+                // weight sets the variant does not have (models_vqa: SameProperty) are left out:
+                // their gradient slots have no storage of their own
                 for (int i = 0; i < 4; ++i) {
-                  ga.A_p[i] = ga.A; ga.B_p[i] = ga.B; ga.bsel_p[i] = i;
-                  ga.C_p[i] = G(attw[i]); ga.colsum_p[i] = nullptr;
+                  if (c->vars[attw[i]].numel == 0) continue;
+                  const int q = ga.nprob++;
+                  ga.A_p[q] = ga.A; ga.B_p[q] = ga.B; ga.bsel_p[q] = i;
+                  ga.C_p[q] = G(attw[i]); ga.colsum_p[q] = nullptr;
                 }
                 ProfScope ps(c, F_GEMM_TN, 2.0 * D * M * 2.0 * p.num_pool,
                              4.0 * (2.0 * p.num_pool * (D + Mp) + 4.0 * D * M), sd);
@@ -659,10 +718,12 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
                 GemmTnArgs ga{};
                 ga.A = c->word_vecs; ga.lda = E; ga.M = E; ga.a_group_idx = t->tslot_row;
                 ga.a_group_size = 1; ga.B = t->dtmap; ga.ldb = Mp; ga.N = M; ga.b_sel = t->tslot_ws;
-                ga.R = p.num_text; ga.ldc = M; ga.nprob = 5;
+                ga.R = p.num_text; ga.ldc = M; ga.nprob = 0;
                 for (int i = 0; i < 5; ++i) {
-                  ga.A_p[i] = ga.A; ga.B_p[i] = ga.B; ga.bsel_p[i] = i;
-                  ga.C_p[i] = G(txw[i]); ga.colsum_p[i] = G(txw[i] + 1);
+                  if (c->vars[txw[i]].numel == 0) continue;
+                  const int q = ga.nprob++;
+                  ga.A_p[q] = ga.A; ga.B_p[q] = ga.B; ga.bsel_p[q] = i;
+                  ga.C_p[q] = G(txw[i]); ga.colsum_p[q] = G(txw[i] + 1);
                 }
                 ProfScope ps(c, F_GEMM_TN, 2.0 * E * M * (double)p.num_text,
                              4.0 * (p.num_text * (double)(E + Mp) + 5.0 * E * M), sd);
@@ -679,6 +740,27 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
           default: break;
         }
       }
+      if (c->big_heads) {              // dW_e = en^T . dscores (+ db_e) over the rows that have a head
+        hipStream_t sh = t->fork(s);
+        gemm_tn(c, sh, t->hb_en, Mp, M, t->ds_pad, t->Cp, C, N, G(V_DE_E_W), C, nullptr, 1,
+                t->hb_sel, 1, nullptr, nullptr, G(V_DE_E_B));
+      }
+    }
+    if (c->qpn_h) {
+      // question prior net backward (models_vqa/question_prior_net.py:10-28): scores_qpn shares
+      // dscores with the module network's answer
+      const int Hq = d.qpn_hidden;
+      hipStream_t sq = t->fork(s);
+      gemm_tn(c, sq, c->qpn_hid, Hq, Hq, t->ds_pad, t->Cp, C, N, G(V_QPN_W2), C, nullptr, 1, nullptr, 0,
+              nullptr, nullptr, G(V_QPN_B2));
+      gemm_nt(c, s, t->ds_pad, t->Cp, N, t->Cp, t->qpn_W2T_p, round_up(Hq, 64), round_up(C, 32), Hq,
+              t->qpn_dad, Hq, false);
+      launch_qpn_dpre(t->qpn_dad, c->qpn_hid, io->drop_qpn_fc1, (size_t)N * Hq, s);
+      sq = t->fork(s);
+      gemm_tn(c, sq, c->qpn_h, 2 * L, 2 * L, t->qpn_dad, Hq, Hq, N, G(V_QPN_W1), Hq, nullptr, 1, nullptr,
+              0, nullptr, nullptr, G(V_QPN_B1));
+      gemm_nt(c, s, t->qpn_dad, Hq, N, Hq, t->qpn_W1T_p, round_up(2 * L, 64), round_up(Hq, 32), 2 * L,
+              t->qpn_dh, 2 * L, false);
     }
     // ------------------------------- decoder ----------------------------------------------
     // rows (tau, n) inside the question's length: reduction index of every encoder-side weight
@@ -736,9 +818,11 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
     BpttArgs ba{};
     ba.T = Td; ba.N = N; ba.want_init_grad = true; ba.seq_len = nullptr;
     ba.g0 = t->rec.dg0; ba.g1 = t->rec.dg1; ba.c0s = t->rec.dc0s; ba.c1s = t->rec.dc1s;
-    ba.dout = t->dout; ba.Wt0 = t->dec_Wt0; ba.Wt1 = t->dec_Wt1;
+    ba.dout = t->dout; ba.Wt0 = t->dec_Wt0; ba.Wt1 = t->dec_Wt1; ba.drop0 = io->drop_dec0;
     rc = run_bptt(c, ba, s);
     if (rc != N2NMN_OK) return rc;
+    if (c->qpn_h)                    // dH now holds the decoder's gradient of the encoder's final h
+      launch_qpn_dh_add(t->qpn_dh, io->drop_qpn_h, t->dH0, t->dH1, N, L, s);
     launch_dec_xidx(io->gt_layout, Td, N, V, t->dec_xidx, s);
     // gradient of the input-projection table: dxtab = onehot(idx)^T . dz0  (one-hot gemm_tn)
     {
@@ -758,7 +842,8 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
       // W1 = [h0(t) ; h1(t-1)]^T dz1 (+ b1)
       const TnProblem dw[3] = {
           {t->rec.dh0s, t->dz0_all, G(V_DEC_W0) + (size_t)E * 4 * L, nullptr},
-          {t->rec.dh0s + (size_t)N * L, t->dz1_all, G(V_DEC_W1), G(V_DEC_B1)},
+          // layer 1 saw layer 0's output through the dropout multipliers
+          {io->drop_dec0 ? t->rec.dh0d : t->rec.dh0s + (size_t)N * L, t->dz1_all, G(V_DEC_W1), G(V_DEC_B1)},
           {t->rec.dh1s, t->dz1_all, G(V_DEC_W1) + (size_t)L * 4 * L, nullptr}};
       gemm_tn_batch(c, s, 3, dw, L, L, 4 * L, 4 * L, RT, 4 * L);
     }
@@ -786,7 +871,7 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
   BpttArgs ba{};
   ba.T = T; ba.N = N; ba.want_init_grad = false; ba.seq_len = io->seq_length;
   ba.g0 = t->rec.eg0; ba.g1 = t->rec.eg1; ba.c0s = t->rec.ec0s; ba.c1s = t->rec.ec1s;
-  ba.dout = t->denc_out; ba.Wt0 = t->enc_Wt0; ba.Wt1 = t->enc_Wt1;
+  ba.dout = t->denc_out; ba.Wt0 = t->enc_Wt0; ba.Wt1 = t->enc_Wt1; ba.drop0 = io->drop_enc0;
   rc = run_bptt(c, ba, s);
   if (rc != N2NMN_OK) return rc;
   t->join(s);                          // W_eht gradient (side stream) done
@@ -803,7 +888,7 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
     }
     const TnProblem dw[3] = {
         {t->rec.eh0s, t->dz0_all, G(V_ENC_W0) + (size_t)E * 4 * L, nullptr},
-        {t->rec.eh0s + (size_t)N * L, t->dz1_all, G(V_ENC_W1), G(V_ENC_B1)},
+        {io->drop_enc0 ? t->rec.eh0d : t->rec.eh0s + (size_t)N * L, t->dz1_all, G(V_ENC_W1), G(V_ENC_B1)},
         {t->rec.eh1s, t->dz1_all, G(V_ENC_W1) + (size_t)L * 4 * L, nullptr}};
     gemm_tn_batch(c, s, 3, dw, L, L, 4 * L, 4 * L, RT, 4 * L, rows, cnt);
   }
@@ -818,6 +903,16 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
   launch_loss_total(io->losses, io->weight_decay,
                     io->objective == N2NMN_OBJ_POLICY_GRADIENT ? io->lambda_entropy : 0.f, s);
   return check_launch("train_backward(1)");
+}
+
+int n2nmn_dropout_multipliers(float* out, int64_t n, float keep_prob, uint64_t seed, uint64_t offset,
+                              n2nmn_stream stream) {
+  N2_REQUIRE(out && n >= 0, N2NMN_EINVAL, "dropout_multipliers: bad argument");
+  N2_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f, N2NMN_EINVAL,
+             "dropout_multipliers: keep_prob must be in (0, 1]");
+  if (n == 0) return N2NMN_OK;
+  launch_dropout_mult(out, (size_t)n, keep_prob, seed, offset, S(stream));
+  return check_launch("dropout_multipliers");
 }
 
 int n2nmn_adam_step(n2nmn_ctx* c, const float* grads, float grad_scale, float lr, float beta1,
@@ -838,7 +933,9 @@ int n2nmn_adam_step(n2nmn_ctx* c, const float* grads, float grad_scale, float lr
   {
     ProfScope ps(c, F_OPTIMISER, 12.0 * t->total, 4.0 * 7 * t->total, s);
     launch_adam(grads, t->mirrors_dev, t->var_off_dev, t->segs_dev, t->nsegs, t->norm2, grad_scale,
-                max_grad_l2_norm, (float)lr_t, beta1, beta2, eps, t->m, t->v, s);
+                // <= 0: no clipping (exp_vqa/train_vqa_gt_layout.py:119-123): clip / max(|g|, clip) = 1
+                max_grad_l2_norm > 0.f ? max_grad_l2_norm : 3.0e38f, (float)lr_t, beta1, beta2, eps,
+                t->m, t->v, s);
   }
   int rc = check_launch("adam_step");
   if (rc != N2NMN_OK) return rc;

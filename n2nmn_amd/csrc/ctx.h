@@ -107,6 +107,11 @@ struct TrainRec {
   float *lsp = nullptr;        // [N] log_seq_prob
   int32_t *valid_bits = nullptr;   // [Td][N] token validity of the forward (policy gradient)
   float *pooled = nullptr;     // [max_pool][2][D]
+  // dropout on the output of LSTM layer 0 (models_vqa training): multipliers of this step (inputs)
+  // and what the forward keeps: the dropped h0 the layer above consumed
+  const float *drop_enc0 = nullptr, *drop_dec0 = nullptr;   // [T][N][L], [Td][N][L]
+  float *ehd[2] = {nullptr, nullptr}, *dhd[2] = {nullptr, nullptr};   // packed state layout
+  float *eh0d = nullptr, *dh0d = nullptr;                   // [T][N][L], [Td][N][L] row-major
 };
 struct TrainState;
 }  // namespace n2nmn
@@ -260,6 +265,8 @@ int check_launch(const char* what);
 ModuleWeights module_weights(const n2nmn_ctx* c);
 void packed_state(const n2nmn_ctx* c, LstmJob& j);
 void rowmajor_a(const n2nmn_ctx* c, LstmJob& j);
+int qpn_forward(n2nmn_ctx* c, int N, float* scores, const float* drop_h, const float* drop_fc1,
+                hipStream_t s);
 int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmArgs* defer_eht = nullptr);
 int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const GemmArgs* pre = nullptr,
                  int npre = 0);

@@ -105,6 +105,11 @@ struct LstmJob {
   float4* save_gates;     // [N][L] (i, j, f, o) after their nonlinearities, this step
   float* save_c;          // [N][L] cell state after this step
   float* save_h;          // [N][L] hidden state after this step (row-major)
+  // DropoutWrapper on this layer's OUTPUT (models_vqa/nmn3_netgen_att.py:17-44): the layer above
+  // reads h * drop, the recurrent state stays h.  drop: multipliers [N][L], ORIGINAL row order.
+  const float* drop;      // nullptr: no dropout
+  float* h_drop;          // h * drop in the layout of h_new (the next layer's A0)
+  float* save_hd;         // [N][L] row-major copy of it (training: operand of the W1 gradient)
 };
 // rows_per_wg: 64 (4 M-tiles per workgroup) or 32 (2 M-tiles; doubles the workgroups of a launch)
 // wide != 0: 32-row x 32-column workgroup tiles for LSTM cell jobs (throughput mode)
@@ -341,6 +346,8 @@ struct LstmBwdJob {
   float* dC;              // [N][L] carried gradient of the cell state (in/out)
   float* dz_k;            // out: k-interleaved [L][R][4]
   float* dz_rm;           // out: row-major [N][4L], reference column order g*L+u
+  const float* drop;      // [N][L] dropout multipliers of THIS layer's output at step t (or nullptr):
+                          // the gradient arriving through A0 (the layer above) is scaled by them
 };
 void launch_lstm_bwd_step(const LstmBwdJob* jobs, int njobs, int N, int L, hipStream_t s);
 
@@ -390,7 +397,14 @@ struct LossRlArgs {
 };
 void launch_loss_rl(const LossRlArgs& a, hipStream_t s);
 void launch_loss(const float* scores, const int32_t* labels, const float* log_seq_prob, int N,
-                 int C, float* dscores, float* losses, hipStream_t s);
+                 int C, float* dscores, float* losses, hipStream_t s, float* ds_pad = nullptr,
+                 int Cp = 0);      // ds_pad [N][Cp]: zero-padded copy of dscores (GEMM operand)
+void launch_ew_mul(float* x, const float* m, size_t n, hipStream_t s);
+void launch_dropout_mult(float* out, size_t n, float keep_prob, unsigned long long seed,
+                         unsigned long long offset, hipStream_t s);
+void launch_qpn_dpre(float* dad, const float* ad, const float* m1, size_t n, hipStream_t s);
+void launch_qpn_dh_add(const float* dh, const float* mh, float* dH0, float* dH1, int N, int L,
+                       hipStream_t s);
 
 void launch_loss_total(float* losses, float wd, float lambda_entropy, hipStream_t s);
 // zero up to 6 byte ranges (4-byte aligned starts and sizes) in ONE launch: a memset node costs ~5 us
@@ -412,6 +426,11 @@ struct ModuleGrads {
   float* gKt; float* gbt;              // Transform conv_maps
   float* gbatt[4];                     // fc_att biases: FSP, SameProperty(0,1), Describe
   float* gWans[7]; float* gbans[7];    // answer FCs (order of ModuleWeights::Wans)
+  // large answer vocabulary (map_dim * num_choices beyond the fused head, models_vqa): fc_eltwise's
+  // backward runs as GEMMs over the whole batch.  hb_den [rows][Mp] = dscores . W_e^T is computed
+  // before the level loop; heads_bwd reads its row, writes the normalised product it recomputed
+  // into hb_en [rows][Mp] and marks the row in hb_sel; dW_e = hb_en^T . dscores follows the loop.
+  const float* hb_den; float* hb_en; int32_t* hb_sel;
 };
 void launch_heads_bwd(const ModuleWeights& w, const ModuleBuffers& b, const ModuleGrads& g,
                       int tab_off, int count, hipStream_t s);

@@ -248,6 +248,11 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_kernel(LstmJobs jobs, 
       jb.save_h[oidx] = h_new;
     }
     if (jb.out_seq) jb.out_seq[oidx] = o;
+    if (jb.h_drop) {              // dropped copy of the OUTPUT for the layer above
+      const float hd = h_new * jb.drop[oidx];
+      jb.h_drop[jb.hp_R > 0 ? ((size_t)tile * jb.hp_R + gr) * 4 + ul : idx] = hd;
+      if (jb.save_hd) jb.save_hd[oidx] = hd;
+    }
     if (jb.fin_c && jb.seq_len && jb.t == jb.seq_len[orow] - 1) {   // the row's last valid step
       jb.fin_c[oidx] = c_new;
       jb.fin_h[((size_t)tile * jb.hp_R + orow) * 4 + ul] = h_new;
@@ -404,6 +409,11 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_wide_kernel(LstmJobs j
       jb.save_h[oidx] = h_new;
     }
     if (jb.out_seq) jb.out_seq[oidx] = o;
+    if (jb.h_drop) {              // dropped copy of the OUTPUT for the layer above
+      const float hd = h_new * jb.drop[oidx];
+      jb.h_drop[jb.hp_R > 0 ? ((size_t)tile * jb.hp_R + gr) * 4 + ul : idx] = hd;
+      if (jb.save_hd) jb.save_hd[oidx] = hd;
+    }
     if (jb.fin_c && jb.seq_len && jb.t == jb.seq_len[orow] - 1) {
       jb.fin_c[oidx] = c_new;
       jb.fin_h[((size_t)tile * jb.hp_R + orow) * 4 + ul] = h_new;

@@ -457,10 +457,21 @@ __global__ __launch_bounds__(BW_THREADS) void lstm_bwd_step_kernel(LstmBwdJobs j
   const int n = row0 + erow;
   if (erow >= ROWS || n >= N) return;          // 16*ROWS threads own one (row, unit) each
   const int u = 16 * tile + ul;
-  float rec = 0.f;
-#pragma unroll
-  for (int ww = 0; ww < BW_WAVES; ++ww) rec += part[ww][erow][ul];
   const size_t idx = (size_t)n * L + u;
+  float rec = 0.f;
+  if (jb.drop && jb.A1) {
+    // waves [0, BW_WAVES/2) contracted A0 (the gradient from the layer above, which saw this
+    // layer's output through the dropout multipliers), the rest A1 (this layer's own recurrence)
+    float up = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < BW_WAVES / 2; ++ww) up += part[ww][erow][ul];
+#pragma unroll
+    for (int ww = BW_WAVES / 2; ww < BW_WAVES; ++ww) rec += part[ww][erow][ul];
+    rec += up * jb.drop[idx];
+  } else {
+#pragma unroll
+    for (int ww = 0; ww < BW_WAVES; ++ww) rec += part[ww][erow][ul];
+  }
   const int len = jb.seq_len ? jb.seq_len[n] : jb.T;
   const bool m_next = jb.t + 1 >= len;            // step t+1 carried the state through
   const float dh_state = rec + (m_next ? jb.dH[idx] : 0.f);
@@ -763,26 +774,76 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ sco
                                                    const int32_t* __restrict__ labels,
                                                    const float* __restrict__ log_seq_prob, int N,
                                                    int C, float* __restrict__ dscores,
-                                                   float* __restrict__ losses) {
-  __shared__ float scratch[16];
+                                                   float* __restrict__ losses,
+                                                   float* __restrict__ ds_pad, int Cp) {
+  // one wave per question (4 per workgroup, one workgroup): lanes stride the classes
+  __shared__ float part[4][2];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float ce = 0.f, nl = 0.f;
-  for (int n = threadIdx.x; n < N; n += 256) {
+  for (int n = w; n < N; n += 4) {
     const float* z = scores + (size_t)n * C;
     float mx = -INFINITY;
-    for (int c = 0; c < C; ++c) mx = fmaxf(mx, z[c]);
+    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, z[c]);
+    mx = wave_max(mx);
     float s = 0.f;
-    for (int c = 0; c < C; ++c) s += expf(z[c] - mx);
+    for (int c = lane; c < C; c += 64) s += expf(z[c] - mx);
+    s = wave_sum(s);
     const int lab = labels[n];
-    ce += logf(s) + mx - z[lab];
-    for (int c = 0; c < C; ++c)
-      dscores[(size_t)n * C + c] = (expf(z[c] - mx) / s - (c == lab ? 1.f : 0.f)) / (float)N;
-    nl -= log_seq_prob[n];
+    for (int c = lane; c < C; c += 64) {
+      const float d = (expf(z[c] - mx) / s - (c == lab ? 1.f : 0.f)) / (float)N;
+      dscores[(size_t)n * C + c] = d;
+      if (ds_pad) ds_pad[(size_t)n * Cp + c] = d;
+    }
+    if (ds_pad) for (int c = C + lane; c < Cp; c += 64) ds_pad[(size_t)n * Cp + c] = 0.f;
+    if (lane == 0) { ce += logf(s) + mx - z[lab]; nl -= log_seq_prob[n]; }
   }
-  const float tce = block_reduce<0>(ce, scratch);
-  const float tnl = block_reduce<0>(nl, scratch);
+  if (lane == 0) { part[w][0] = ce; part[w][1] = nl; }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    losses[0] = tce / (float)N;
-    losses[1] = tnl / (float)N;
+    losses[0] = (part[0][0] + part[1][0] + part[2][0] + part[3][0]) / (float)N;
+    losses[1] = (part[0][1] + part[1][1] + part[2][1] + part[3][1]) / (float)N;
+  }
+}
+
+// Dropout multipliers from a counter-based generator: element i of the stream (seed, offset + i)
+// is splitmix64 of its counter, so any slice can be regenerated independently (no state).
+__global__ void dropout_mult_kernel(float* __restrict__ out, size_t n, float keep_prob,
+                                    unsigned long long seed, unsigned long long offset) {
+  const float scale = 1.0f / keep_prob;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    unsigned long long z = seed + (offset + i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const float u = (float)(z >> 40) * (1.0f / 16777216.0f);      // 24 bits -> [0, 1)
+    out[i] = u < keep_prob ? scale : 0.f;
+  }
+}
+
+// small elementwise helpers of the question-prior-net step (models_vqa/question_prior_net.py:22-27)
+__global__ void ew_mul_kernel(float* __restrict__ x, const float* __restrict__ m, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    x[i] *= m[i];
+}
+// d fc1 pre-activation = d(dropped relu output) * dropout multiplier * [relu output > 0]
+__global__ void qpn_dpre_kernel(float* __restrict__ dad, const float* __restrict__ ad,
+                                const float* __restrict__ m1, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    dad[i] = ad[i] > 0.f ? dad[i] * (m1 ? m1[i] : 1.f) : 0.f;
+}
+// dH0[n][u] += dh[n][u] * mh, dH1[n][u] += dh[n][L + u] * mh: the question prior reads the final
+// hidden states of both encoder layers
+__global__ void qpn_dh_add_kernel(const float* __restrict__ dh, const float* __restrict__ mh,
+                                  float* __restrict__ dH0, float* __restrict__ dH1, int N, int L) {
+  const size_t n2 = (size_t)N * 2 * L;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n2;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / (2 * L)), j = (int)(i - (size_t)n * 2 * L);
+    const float v = dh[i] * (mh ? mh[i] : 1.f);
+    if (j < L) dH0[(size_t)n * L + j] += v; else dH1[(size_t)n * L + j - L] += v;
   }
 }
 
@@ -1032,9 +1093,27 @@ void launch_word_vecs_bwd(const float* dwv, const float* atts, const int32_t* se
 }
 
 void launch_loss(const float* scores, const int32_t* labels, const float* log_seq_prob, int N,
-                 int C, float* dscores, float* losses, hipStream_t s) {
+                 int C, float* dscores, float* losses, hipStream_t s, float* ds_pad, int Cp) {
   hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(256), 0, s, scores, labels, log_seq_prob, N, C,
-                     dscores, losses);
+                     dscores, losses, ds_pad, Cp);
+}
+
+static int ew_blocks(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 1024); }
+void launch_dropout_mult(float* out, size_t n, float keep_prob, unsigned long long seed,
+                         unsigned long long offset, hipStream_t s) {
+  hipLaunchKernelGGL(dropout_mult_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, out, n, keep_prob, seed,
+                     offset);
+}
+void launch_ew_mul(float* x, const float* m, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(ew_mul_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, m, n);
+}
+void launch_qpn_dpre(float* dad, const float* ad, const float* m1, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(qpn_dpre_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, dad, ad, m1, n);
+}
+void launch_qpn_dh_add(const float* dh, const float* mh, float* dH0, float* dH1, int N, int L,
+                       hipStream_t s) {
+  hipLaunchKernelGGL(qpn_dh_add_kernel, dim3(ew_blocks((size_t)N * 2 * L)), dim3(256), 0, s, dh, mh,
+                     dH0, dH1, N, L);
 }
 
 void launch_loss_rl(const LossRlArgs& a, hipStream_t s) {

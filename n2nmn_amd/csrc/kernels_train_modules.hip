@@ -68,11 +68,13 @@ __global__ __launch_bounds__(MT) void heads_bwd_kernel(ModuleWeights w, ModuleBu
     a0s[c] = a0; a1s[c] = a1; tms[c] = t; evs[c] = v;
     lss += v * v;
   }
-  for (int c = tid; c < C; c += MT) {
-    const float d = g.dscores[(size_t)nd.out_row * C + c];
-    ds[c] = d;
-    atomicAdd(g.gbans[wi] + c, d);
-  }
+  const bool big = g.hb_den != nullptr;
+  if (!big)
+    for (int c = tid; c < C; c += MT) {
+      const float d = g.dscores[(size_t)nd.out_row * C + c];
+      ds[c] = d;
+      atomicAdd(g.gbans[wi] + c, d);
+    }
   const float ss = block_reduce<0>(lss, scratch);      // (also orders the LDS writes above)
   const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
   // den[m] = W_e[m,:] . ds ;  dW_e[m,c] += en[m] ds[c]
@@ -80,7 +82,13 @@ __global__ __launch_bounds__(MT) void heads_bwd_kernel(ModuleWeights w, ModuleBu
   float den_l[4];                 // Mp <= 1024 with 256 threads
   for (int c = tid, q = 0; c < Mp; c += MT, ++q) {
     float den = 0.f;
-    if (c < M) {
+    if (big) {                    // den comes from the batch GEMM; keep en for the weight gradient
+      if (c < M) {
+        den = g.hb_den[(size_t)nd.out_row * Mp + c];
+        ldot += evs[c] * den;
+      }
+      g.hb_en[(size_t)nd.out_row * Mp + c] = c < M ? evs[c] * inv : 0.f;
+    } else if (c < M) {
       const float en = evs[c] * inv;
       const float* wr = w.Wans[wi] + (size_t)c * C;
       float* gw = g.gWans[wi] + (size_t)c * C;
@@ -101,6 +109,7 @@ __global__ __launch_bounds__(MT) void heads_bwd_kernel(ModuleWeights w, ModuleBu
     }
     den_l[q] = den;
   }
+  if (big && tid == 0) g.hb_sel[nd.out_row] = 1;
   const float xdy = block_reduce<0>(ldot, scratch);    // ev . den
   const float k3 = l2n_k(ss, inv);
   float* dt = g.dtmap + (size_t)nd.tslot * Mp;

@@ -28,6 +28,7 @@ import numpy as np
 
 from . import _lib
 from .engine import Engine
+from .train import Trainer
 from .nmn3_assembler import Assembler
 from .spec import Dims, lstm_var, PREFIX, _ENC, _DEC, _MOD
 
@@ -215,3 +216,109 @@ class VQAEngine:
             _lib.check(e._lib.n2nmn_question_prior_add(e._ctx, scores.shape[0], scores.data_ptr(),
                                                        e.stream()))
         return scores, tokens, validity
+
+
+def unpad_variable(name: str, g: np.ndarray, d: VQADims, di: Dims) -> np.ndarray:
+    """Inverse of pad_variable for a gradient / weight in the GPU context's padded shape."""
+    L, Lp = d.lstm_dim, di.lstm_dim
+    Dc = d.D + 2
+    g = np.asarray(g)
+
+    def gate_cols(x):
+        return np.concatenate([x[..., k * Lp:k * Lp + L] for k in range(4)], axis=-1)
+
+    if 'basic_lstm_cell/weights' in name:
+        x = gate_cols(g)
+        if 'cell_0' in name:
+            E = g.shape[0] - Lp
+            return x[:E + L]
+        return np.concatenate([x[:L], x[Lp:Lp + L]], axis=0)
+    if 'basic_lstm_cell/biases' in name:
+        return gate_cols(g)
+    if name.endswith('encoder_h_transform/weights') or name.endswith('att_prediction/weights'):
+        return g[:L, :L]
+    if name.endswith('encoder_h_transform/biases') or name.endswith('att_prediction/biases') \
+            or name.endswith('att_prediction/v'):
+        return g[:L]
+    if name.endswith('token_prediction/weights') or name.endswith('question_prior_net/fc1/weights'):
+        return np.concatenate([g[:L], g[Lp:Lp + L]], axis=0)
+    if name.endswith('conv_image/weights') or name.endswith('fc_att/weights'):
+        return g[:Dc]
+    return g
+
+
+class VQATrainer(Trainer):
+    """One iteration of exp_vqa/train_vqa_gt_layout.py:148-190 on the GPU: models_vqa forward with
+    encoder / decoder / question-prior dropout, total = mean(-log_seq_prob) + mean(CE), every
+    gradient, Adam without clipping (:119-123) and without weight decay (:42)."""
+
+    def __init__(self, vqa: VQAEngine, lr: float = 1e-3, weight_decay: float = 0.0, dist=None,
+                 rccl=None, encoder_dropout: bool = True, decoder_dropout: bool = True,
+                 qpn_dropout: bool = True, keep_prob: float = 0.5):
+        super().__init__(vqa.engine, weight_decay=weight_decay, lr=lr, max_grad_l2_norm=0.0,
+                         dist=dist, rccl=rccl)
+        self.vqa = vqa
+        self.dropout = dict(enc0=encoder_dropout, dec0=decoder_dropout, qpn_h=qpn_dropout,
+                            qpn_fc1=qpn_dropout and vqa.dims.qpn_hidden > 0)
+        self.keep_prob = float(keep_prob)
+        self.masks = None            # dict of keep masks for the next step (tests); None: drawn
+        self.seed = 0                # stream of n2nmn_dropout_multipliers; the offset advances
+        self._drawn = 0
+        self._mult = None
+
+    def _multipliers(self, T, N, Td):
+        """Reference-shaped {0, 1} keep masks -> multipliers (0 or 1 / keep_prob) in the context's
+        padded layout (padded hidden units are zero anyway; their multiplier is 0)."""
+        import torch
+        d, di, dev = self.vqa.dims, self.vqa.idims, self.engine.device
+        L, Lp = d.lstm_dim, di.lstm_dim
+        shapes = dict(enc0=(T, N, L), dec0=(Td, N, L), qpn_h=(N, d.num_layers * L),
+                      qpn_fc1=(N, d.qpn_hidden))
+        out = {}
+        for key, on in self.dropout.items():
+            if not on:
+                continue
+            if self.masks is not None:
+                keep = torch.as_tensor(np.asarray(self.masks[key], np.float32), device=dev)
+                if tuple(keep.shape) != shapes[key]:
+                    raise ValueError('dropout mask %s: shape %s, expected %s' %
+                                     (key, tuple(keep.shape), shapes[key]))
+                m = keep / self.keep_prob
+            else:
+                m = torch.empty(shapes[key], dtype=torch.float32, device=dev)
+                _lib.check(self._lib.n2nmn_dropout_multipliers(
+                    m.data_ptr(), m.numel(), self.keep_prob, self.seed, self._drawn,
+                    self.engine.stream()))
+                self._drawn += m.numel()
+            if key in ('enc0', 'dec0'):
+                p = torch.zeros(shapes[key][:2] + (Lp,), device=dev)
+                p[..., :L] = m
+            elif key == 'qpn_h':
+                p = torch.zeros((N, 2 * Lp), device=dev)
+                p[:, :L] = m[:, :L]
+                p[:, Lp:Lp + L] = m[:, L:]
+            else:
+                p = m
+            out[key] = p.contiguous()
+        return out
+
+    def _io(self, batch, gt_layout, objective: int = 0):
+        b = dict(batch)
+        b['image_feat_batch'] = self.vqa.features_with_coords(batch['image_feat_batch'])
+        io, packed, validity = super()._io(b, gt_layout, objective)
+        self._mult = self._multipliers(io.T_enc, io.N, io.T_dec)
+        for key, field in (('enc0', 'drop_enc0'), ('dec0', 'drop_dec0'), ('qpn_h', 'drop_qpn_h'),
+                           ('qpn_fc1', 'drop_qpn_fc1')):
+            if key in self._mult:
+                setattr(io, field, self._mult[key].data_ptr())
+        return io, packed, validity
+
+    def gradients_reference_shaped(self):
+        """name -> numpy gradient in the reference's (unpadded) variable shape."""
+        d, di = self.vqa.dims, self.vqa.idims
+        return {k: unpad_variable(k, v.detach().cpu().numpy(), d, di)
+                for k, v in self.gradients().items()}
+
+    def weights_reference_shaped(self):
+        d, di = self.vqa.dims, self.vqa.idims
+        return {k: unpad_variable(k, v.cpu().numpy(), d, di) for k, v in self.get_weights().items()}

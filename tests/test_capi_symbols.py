@@ -44,4 +44,4 @@ def test_struct_sizes_match_header():
     assert ctypes.sizeof(_lib.WalkBatch) == 9 * 8
     # 2 ptr + 3 int32 (+4 pad) + 3 ptr + float (+4 pad) + 3 ptr
     # ... + objective (4 + 4 pad) + expr_validity + 3 floats (+ 4 pad) + baseline
-    assert ctypes.sizeof(_lib.TrainIO) == 2 * 8 + 16 + 3 * 8 + 8 + 3 * 8 + 8 + 8 + 16 + 8
+    assert ctypes.sizeof(_lib.TrainIO) == 2 * 8 + 16 + 3 * 8 + 8 + 3 * 8 + 8 + 8 + 16 + 8 + 4 * 8

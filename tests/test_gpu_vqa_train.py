@@ -1,0 +1,113 @@
+"""models_vqa training step (exp_vqa/train_vqa_gt_layout.py) on the HIP path against numbers computed
+by the REFERENCE'S OWN CODE: tests/golden/float_golden.npz `vqa_train/*` = the unmodified
+models_vqa/*.py with encoder / decoder / question-prior dropout under the TF1 stand-in, the loss
+block of the training script, autograd gradients of every variable and one Adam step (float64).
+The dropout masks are inputs on both sides (tests/golden/float_cases.py::vqa_dropout_masks).
+
+Bar: logits / log_seq_prob 1e-4 absolute, losses 1e-4 relative, gradient probes 2e-4 * max|g|,
+weights after the Adam step 2e-3 of a step (lr) except where the gradient is round-off small."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from util import assert_close, t2n
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+import float_cases as FC  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'float_golden.npz')
+GRAD_RTOL = 2e-4
+
+
+@pytest.fixture(scope='module')
+def fx():
+    z = np.load(GOLDEN)
+    return z, json.loads(bytes(z['meta_json']).decode())
+
+
+@pytest.fixture(scope='module')
+def setup():
+    from n2nmn_amd.vqa import VQAEngine, VQATrainer
+    d, batch, gt = FC.vqa_setup()
+    batch = dict(batch, answer_label_batch=FC.vqa_labels(d))
+    eng = VQAEngine(d)
+    w = FC.vqa_weights(d)
+    eng.load_weights(w)
+    return d, batch, gt, eng, VQATrainer(eng), w
+
+
+def _probe_check(z, key, meta, got, rtol):
+    bad = []
+    for name, m in meta.items():
+        g = np.asarray(got[name], np.float64).reshape(-1)
+        d = np.max(np.abs(g[FC.probe_indices(name, g.size)] - z[key + '/' + name]))
+        tol = rtol * m['absmax'] + 1e-7
+        nd = abs(np.sqrt(np.sum(g * g)) - m['norm'])
+        if not (d <= tol and nd <= 5 * rtol * m['norm'] + 1e-7 and np.isfinite(g).all()):
+            bad.append('%s: probe diff %.3e (tol %.3e), norm %.6e vs %.6e' % (
+                name, d, tol, np.sqrt(np.sum(g * g)), m['norm']))
+    assert not bad, '\n'.join(bad)
+
+
+def test_vqa_training_step_with_dropout_matches_reference_code(setup, fx):
+    d, batch, gt, eng, tr, w = setup
+    z, meta = fx
+    m = meta['vqa_train']
+    eng.load_weights(w)
+    tr.masks = FC.vqa_dropout_masks(d)
+    tr.forward_backward(batch, gt, reduce=False)
+    assert_close('scores', t2n(tr.scores), z['vqa_train/scores'], 1e-4)
+    ls = t2n(tr.losses)
+    for i, k in enumerate(('avg_sample_loss', 'seq_likelihood_loss')):
+        assert abs(ls[i] - m[k]) <= 1e-4 * max(1.0, abs(m[k])), (k, ls[i], m[k])
+    assert abs(ls[3] - m['total_loss']) <= 1e-4 * abs(m['total_loss'])
+    grads = tr.gradients_reference_shaped()
+    assert sorted(grads) == m['variables']
+    _probe_check(z, 'vqa_train/grad', m['grad'], grads, GRAD_RTOL)
+    # padded hidden units / feature channels receive exactly zero gradient
+    flat = t2n(tr.grads)
+    assert np.isfinite(flat).all()
+    tr.iteration = 0
+    tr.apply(1.0)
+    w1 = tr.weights_reference_shaped()
+    lr = tr.hyper['lr']
+    for name, mm in m['adam_w1'].items():
+        got = np.asarray(w1[name], np.float64).reshape(-1)[FC.probe_indices(name, w1[name].size)]
+        want = z['vqa_train/adam_w1/' + name]
+        # the first Adam step moves every weight by lr * g / (|g| + eps): compare at that scale,
+        # except where |g| is so small that fp32 round-off decides the sign
+        g = np.asarray(grads[name], np.float64).reshape(-1)[FC.probe_indices(name, w1[name].size)]
+        ok = np.abs(g) > 1e-3 * m['grad'][name]['absmax']
+        assert np.all(np.abs(got - want)[ok] <= 2e-2 * lr + 1e-6), name
+        assert np.all(np.abs(got - want) <= 2.001 * lr + 1e-6), name
+
+
+def test_vqa_training_without_dropout_equals_plain_forward(setup, fx):
+    """dropout switched off: the training forward's logits are the eval forward's (fixture vqa_gt)."""
+    from n2nmn_amd.vqa import VQATrainer
+    d, batch, gt, eng, tr, w = setup
+    z, meta = fx
+    eng.load_weights(w)
+    saved = dict(tr.dropout)
+    tr.dropout = {k: False for k in saved}
+    try:
+        tr.forward_backward(batch, gt, reduce=False)
+    finally:
+        tr.dropout = saved
+    assert_close('scores', t2n(tr.scores), z['vqa_gt/scores'], 1e-4)
+    assert np.isfinite(t2n(tr.grads)).all()
+
+
+def test_drawn_masks_keep_about_half(setup):
+    d, batch, gt, eng, tr, w = setup
+    eng.load_weights(w)
+    tr.masks = None
+    tr.forward_backward(batch, gt, reduce=False)
+    m = tr._mult['enc0'][..., :d.lstm_dim]
+    frac = float((m > 0).float().mean())
+    assert 0.45 < frac < 0.55 and float(m.max()) == 2.0
+    assert np.isfinite(t2n(tr.losses)[:2]).all()
