@@ -126,7 +126,7 @@ static size_t carve_weights(n2nmn_ctx* c, char* base) {
   for (auto& v : c->vars) v.mirror = k.take<float>(v.numel);
   c->enc_W0x_p = k.take<float>((size_t)c->KpE * 4 * L);
   c->dec_W0x_p = k.take<float>((size_t)c->KpE * 4 * L);
-  c->enc_xtab = k.take<float>(Vt * 4 * L);
+  c->enc_xtab = c->big_vocab ? nullptr : k.take<float>(Vt * 4 * L);
   c->dec_xtab = k.take<float>((V + 1) * 4 * L);
   c->enc_W0h_t = k.take<float>(L * 4 * L);
   c->enc_W1_t = k.take<float>(2 * L * 4 * L);
@@ -180,6 +180,10 @@ static size_t carve_workspace(n2nmn_ctx* c, char* base) {
   c->ec0 = st + 4 * N * L; c->ec1 = st + 5 * N * L;
   // final encoder state in ORIGINAL row order (written at each row's last valid step)
   c->fc0 = st + 6 * N * L; c->fh0 = st + 7 * N * L; c->fc1 = st + 8 * N * L; c->fh1 = st + 9 * N * L;
+  if (c->big_vocab) {
+    c->xproj = k.take<float>(T * N * 4 * L);
+    c->iota = k.take<int32_t>(T * N);
+  }
   c->perm = k.take<int32_t>(N);
   c->nact = k.take<int32_t>(T + 1);
   float* ds = k.take<float>(6 * N * L);
@@ -300,6 +304,18 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmAr
              "encoder_forward: T_enc / N exceed the context capacity");
   launch_enc_prepare(io->seq_length, N, T, c->perm, c->nact, c->eh0[0], 10 * (size_t)d.N * L, s);
   const float* W0x_bias_table = c->enc_xtab;
+  if (c->big_vocab) {
+    // x . W_x + b of the batch's own words: one GEMM whose A rows are gathered by word index
+    GemmArgs g{};
+    g.A = c->vars[V_ENC_EMB].mirror; g.lda = d.embed_dim_txt; g.M = T * N; g.K = d.embed_dim_txt;
+    g.group_idx = io->input_seq; g.group_size = 1;
+    g.Bp = c->enc_W0x_p; g.Np = 4 * L; g.Kp = c->KpE; g.bias = c->vars[V_ENC_B0].mirror; g.N = 4 * L;
+    g.C = c->xproj; g.ldc = 4 * L; g.n_store = 4 * L;
+    ProfScope ps(c, F_GEMM_EHT, 2.0 * T * N * d.embed_dim_txt * 4.0 * L,
+                 4.0 * ((double)T * N * (d.embed_dim_txt + 4.0 * L) + 4.0 * L * d.embed_dim_txt), s);
+    launch_gemm_pk(g, s);
+    W0x_bias_table = c->xproj;
+  }
   // software-pipelined over time: launch k runs layer-0 step k and layer-1 step k-1
   for (int k = 0; k <= T; ++k) {
     LstmJob jobs[2];
@@ -308,7 +324,8 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmAr
     j0.active = k < T;
     packed_state(c, j0);
     j0.A0 = c->eh0[(k + 1) & 1]; j0.A1 = nullptr; j0.K = L; j0.Wp = c->enc_W0h_t;
-    j0.xtab = W0x_bias_table; j0.xidx = io->input_seq + (size_t)k * N; j0.xidx_const = 0;
+    j0.xtab = W0x_bias_table; j0.xidx_const = 0;
+    j0.xidx = (c->big_vocab ? c->iota : io->input_seq) + (size_t)k * N;
     j0.bias = nullptr; j0.c_in = c->ec0; j0.c_out = c->ec0; j0.ntiles = L / 4;
     j0.h_old = c->eh0[(k + 1) & 1]; j0.h_new = c->eh0[k & 1];
     j0.out_seq = nullptr; j0.seq_len = io->seq_length; j0.t = k;
@@ -794,6 +811,11 @@ static int finish_create(n2nmn_ctx* c, n2nmn_ctx* parent) {
     return N2NMN_EHIP;
   }
   carve_workspace(c, c->ws_base);
+  if (c->iota) {
+    std::vector<int32_t> io((size_t)c->d.T_encoder * c->d.N);
+    for (size_t i = 0; i < io.size(); ++i) io[i] = (int32_t)i;
+    N2_HIP(hipMemcpy(c->iota, io.data(), sizeof(int32_t) * io.size(), hipMemcpyHostToDevice));
+  }
   c->stage_bytes = align_up(sizeof(DevNode) * (size_t)c->max_nodes, 256) +
                    sizeof(int32_t) * (size_t)c->max_tab;
   for (int i = 0; i < n2nmn_ctx::kStage; ++i) {
@@ -850,6 +872,7 @@ int n2nmn_ctx_create(const n2nmn_dims* dims, int device, n2nmn_ctx** out) {
   c->max_pool = c->max_nodes;
   c->max_tab = c->max_nodes * 16 + 4096;
   c->big_heads = (size_t)d.map_dim * d.num_choices > 65536;
+  c->big_vocab = d.num_vocab_txt > 4096;
   int rc = finish_create(c, nullptr);
   if (rc != N2NMN_OK) { delete c; return rc; }
   *out = c;
@@ -870,6 +893,7 @@ int n2nmn_ctx_fork(n2nmn_ctx* parent, n2nmn_ctx** out) {
   c->Mp = parent->Mp; c->HWp = parent->HWp; c->KpE = parent->KpE; c->KpL = parent->KpL;
   c->KpD = parent->KpD; c->max_nodes = parent->max_nodes; c->max_text = parent->max_text;
   c->max_pool = parent->max_pool; c->max_tab = parent->max_tab; c->big_heads = parent->big_heads;
+  c->big_vocab = parent->big_vocab;
   int rc = finish_create(c, parent);
   if (rc != N2NMN_OK) { delete c; return rc; }
   *out = c;
@@ -1036,7 +1060,7 @@ int n2nmn_commit_weights(n2nmn_ctx* c, n2nmn_stream stream) {
   g.A = m(V_ENC_EMB); g.lda = E; g.M = d.num_vocab_txt; g.K = E; g.group_size = 1;
   g.Bp = c->enc_W0x_p; g.Np = 4 * L; g.Kp = c->KpE; g.bias = m(V_ENC_B0); g.N = 4 * L;
   g.C = c->enc_xtab; g.ldc = 4 * L; g.n_store = 4 * L;
-  launch_gemm_pk(g, s);
+  if (!c->big_vocab) launch_gemm_pk(g, s);
   g.A = c->dec_emb_cat; g.M = V + 1; g.Bp = c->dec_W0x_p; g.bias = m(V_DEC_B0); g.C = c->dec_xtab;
   launch_gemm_pk(g, s);
   for (int i = 0; i < 5; ++i) {        // ew[ws] = embedding_mat . W_txt[ws]  (walker text maps)
@@ -1446,7 +1470,8 @@ int n2nmn_debug_lstm_bench(n2nmn_ctx* c, int variant, int rows_per_wg, int njobs
       j0 = LstmJob{};
       if (layout) packed_state(c, j0); else rowmajor_a(c, j0);
       j0.active = 1; j0.A0 = c->eh0[(k + 1) & 1]; j0.K = L; j0.Wp = c->enc_W0h_t;
-      j0.ntiles = L / 4; j0.xtab = c->enc_xtab; j0.xidx = nullptr; j0.xidx_const = 1;
+      j0.ntiles = L / 4; j0.xtab = c->big_vocab ? c->xproj : c->enc_xtab; j0.xidx = nullptr;
+      j0.xidx_const = 1;
       j0.c_in = c->ec0; j0.c_out = c->ec0; j0.h_old = j0.A0; j0.h_new = c->eh0[k & 1];
       LstmJob& j1 = jobs[njobs == 2 ? 1 : 0];
       j1 = LstmJob{};

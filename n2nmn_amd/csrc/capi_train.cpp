@@ -140,7 +140,7 @@ size_t carve_train(n2nmn_ctx* c, TrainState* t, char* base) {
   t->dwv = k.take<float>(Td * N * E);
   t->dH0 = k.take<float>(N * L); t->dH1 = k.take<float>(N * L);
   t->dC0 = k.take<float>(N * L); t->dC1 = k.take<float>(N * L);
-  t->dxtab_enc = k.take<float>(Vt * 4 * L);
+  t->dxtab_enc = c->big_vocab ? nullptr : k.take<float>(Vt * 4 * L);
   t->dxtab_dec = k.take<float>((V + 1) * 4 * L);
   t->act_count = k.take<int32_t>(4);
   if (c->big_heads) {
@@ -771,9 +771,10 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
       launch_word_vecs_bwd(t->dwv, c->atts, io->input_seq, io->seq_length, mir(V_ENC_EMB), Td, T, N,
                            E, t->datts_wv, t->dE, s);
     }
-    {
+    if (!c->big_vocab) {
       // d embedding_mat (through word_vecs) = onehot(word)^T . dE over the active rows; it lands in
       // the encoder bucket, which is only finished in phase 1 -> side stream, joined with the rest
+      // (large vocabularies: dE is scattered in phase 1 together with the LSTM input's share)
       hipStream_t sd = t->fork(s);
       GemmTnArgs g1{};
       g1.A = nullptr; g1.lda = 0; g1.M = Vt; g1.a_onehot = io->input_seq;
@@ -878,7 +879,15 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
   {
     const int32_t* rows = t->act_rows;
     const int32_t* cnt = t->act_count;
-    {
+    if (c->big_vocab) {
+      // the layer-0 input weights and the embedding matrix straight from the batch's rows:
+      //   dW0[0:E] = emb[word_r]^T . dz0_r (+ db0);  dE_r += dz0_r . W0[0:E]^T;  demb[word_r] += dE_r
+      gemm_tn(c, s, mir(V_ENC_EMB), E, E, t->dz0_all, 4 * L, 4 * L, RT, G(V_ENC_W0), 4 * L,
+              io->input_seq, 1, nullptr, 0, rows, cnt, G(V_ENC_B0));
+      gemm_nt(c, s, t->dz0_all, 4 * L, RT, 4 * L, t->enc_W0xT_p, Ep, t->KpL4, E, t->dE, E, true);
+      ProfScope ps(c, F_BWD_MISC, (double)RT * E, 4.0 * 2 * RT * E, s);
+      launch_embed_scatter(t->dE, io->input_seq, rows, cnt, RT, E, G(V_ENC_EMB), s);
+    } else {
       GemmTnArgs g1{};
       g1.A = nullptr; g1.lda = 0; g1.M = Vt; g1.a_onehot = io->input_seq;
       g1.B = t->dz0_all; g1.ldb = 4 * L; g1.N = 4 * L; g1.R = RT; g1.C = t->dxtab_enc; g1.ldc = 4 * L;
@@ -892,9 +901,11 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
         {t->rec.eh1s, t->dz1_all, G(V_ENC_W1) + (size_t)L * 4 * L, nullptr}};
     gemm_tn_batch(c, s, 3, dw, L, L, 4 * L, 4 * L, RT, 4 * L, rows, cnt);
   }
-  gemm_tn(c, s, mir(V_ENC_EMB), E, E, t->dxtab_enc, 4 * L, 4 * L, Vt, G(V_ENC_W0), 4 * L,
-          nullptr, 1, nullptr, 0, nullptr, nullptr, G(V_ENC_B0));
-  gemm_nt(c, s, t->dxtab_enc, 4 * L, Vt, 4 * L, t->enc_W0xT_p, Ep, t->KpL4, E, G(V_ENC_EMB), E, true);
+  if (!c->big_vocab) {
+    gemm_tn(c, s, mir(V_ENC_EMB), E, E, t->dxtab_enc, 4 * L, 4 * L, Vt, G(V_ENC_W0), 4 * L,
+            nullptr, 1, nullptr, 0, nullptr, nullptr, G(V_ENC_B0));
+    gemm_nt(c, s, t->dxtab_enc, 4 * L, Vt, 4 * L, t->enc_W0xT_p, Ep, t->KpL4, E, G(V_ENC_EMB), E, true);
+  }
   {
     ProfScope ps(c, F_OPTIMISER, 3.0 * t->split, 4.0 * 3 * t->split, s);
     launch_grad_finish(io->grads, (const float* const*)t->mirrors_dev, t->var_off_dev, t->decay_dev,

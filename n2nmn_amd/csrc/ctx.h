@@ -149,6 +149,12 @@ struct n2nmn_ctx {
   PackBatch packs;                                   // every re-pack of a commit, one launch
   float *qpn_W1_p = nullptr, *qpn_W2_p = nullptr;    // PK packs of question_prior_net fc1 / fc2
   float *wans_sp_p = nullptr, *wans_de_p = nullptr;  // PK packs of fc_eltwise (large num_choices only)
+  // question vocabularies beyond 4096 words (models_vqa: 17742): the layer-0 input projection is a
+  // per-batch GEMM over the batch's own words (xproj [T][N][4L], rows addressed through iota)
+  // instead of a [num_vocab_txt][4L] table rebuilt at every weight commit
+  bool big_vocab = false;
+  float* xproj = nullptr;
+  int32_t* iota = nullptr;
   bool big_heads = false;                            // map_dim * num_choices beyond the fused head
   float* wtxt_pad[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   // walker text maps as a table: ew[ws][v] = encoder embedding_mat[v] . W_txt[ws]  ([V_txt][Mp]),

@@ -399,6 +399,8 @@ void launch_loss_rl(const LossRlArgs& a, hipStream_t s);
 void launch_loss(const float* scores, const int32_t* labels, const float* log_seq_prob, int N,
                  int C, float* dscores, float* losses, hipStream_t s, float* ds_pad = nullptr,
                  int Cp = 0);      // ds_pad [N][Cp]: zero-padded copy of dscores (GEMM operand)
+void launch_embed_scatter(const float* src, const int32_t* idx, const int32_t* rows,
+                          const int32_t* count, int max_rows, int ncols, float* dst, hipStream_t s);
 void launch_ew_mul(float* x, const float* m, size_t n, hipStream_t s);
 void launch_dropout_mult(float* out, size_t n, float keep_prob, unsigned long long seed,
                          unsigned long long offset, hipStream_t s);

@@ -821,6 +821,24 @@ __global__ void dropout_mult_kernel(float* __restrict__ out, size_t n, float kee
   }
 }
 
+// dst[idx[rows[i]]][:] += src[rows[i]][:] for i < *count: the embedding-matrix gradient from the
+// per-position embedding gradients (large vocabularies; the one-hot GEMM of the small-vocabulary
+// path would contract over the whole vocabulary).  One wave per row.
+__global__ __launch_bounds__(256) void embed_scatter_kernel(const float* __restrict__ src,
+                                                            const int32_t* __restrict__ idx,
+                                                            const int32_t* __restrict__ rows,
+                                                            const int32_t* __restrict__ count,
+                                                            int ncols, float* __restrict__ dst) {
+  const int n = *count;
+  const int lane = threadIdx.x & 63;
+  for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += gridDim.x * 4) {
+    const int r = rows[i];
+    const float* s = src + (size_t)r * ncols;
+    float* d = dst + (size_t)idx[r] * ncols;
+    for (int c = lane; c < ncols; c += 64) atomicAdd(d + c, s[c]);
+  }
+}
+
 // small elementwise helpers of the question-prior-net step (models_vqa/question_prior_net.py:22-27)
 __global__ void ew_mul_kernel(float* __restrict__ x, const float* __restrict__ m, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
@@ -1096,6 +1114,13 @@ void launch_loss(const float* scores, const int32_t* labels, const float* log_se
                  int C, float* dscores, float* losses, hipStream_t s, float* ds_pad, int Cp) {
   hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(256), 0, s, scores, labels, log_seq_prob, N, C,
                      dscores, losses, ds_pad, Cp);
+}
+
+void launch_embed_scatter(const float* src, const int32_t* idx, const int32_t* rows,
+                          const int32_t* count, int max_rows, int ncols, float* dst, hipStream_t s) {
+  if (max_rows <= 0) return;
+  hipLaunchKernelGGL(embed_scatter_kernel, dim3(std::min((max_rows + 3) / 4, 1024)), dim3(256), 0, s,
+                     src, idx, rows, count, ncols, dst);
 }
 
 static int ew_blocks(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 1024); }
