@@ -382,12 +382,15 @@ __global__ void pack_tiles_t_kernel(const float* __restrict__ W, int ld, int row
 // ---------------------------------------------------------------------------------------------
 constexpr int BW_WAVES = 8;
 constexpr int BW_THREADS = BW_WAVES * 64;
-constexpr int BW_MT = 1;                 // 16-row M tiles per workgroup
+// BW_MT = 16-row M tiles per workgroup: 1 at lstm_dim 512 (256 workgroups per step); 2 at lstm_dim
+// 1024, where the column tiles alone give 128 workgroups per job and every workgroup re-streams its
+// K x 16 weight tile (512 KB for layer 0) -- twice the rows per tile halve that L2 traffic
 
 struct LstmBwdJobs {
   LstmBwdJob j[2];
 };
 
+template <int BW_MT>
 __global__ __launch_bounds__(BW_THREADS) void lstm_bwd_step_kernel(LstmBwdJobs jobs, int N,
                                                                    int L) {
   const LstmBwdJob& jb = jobs.j[blockIdx.y];
@@ -455,6 +458,7 @@ __global__ __launch_bounds__(BW_THREADS) void lstm_bwd_step_kernel(LstmBwdJobs j
   // ---- epilogue: thread = (row, unit) ---------------------------------------------------------
   const int erow = tid >> 4, ul = tid & 15;
   const int n = row0 + erow;
+  static_assert(16 * 16 * BW_MT <= BW_THREADS, "one thread per (row, unit) of the tile");
   if (erow >= ROWS || n >= N) return;          // 16*ROWS threads own one (row, unit) each
   const int u = 16 * tile + ul;
   const size_t idx = (size_t)n * L + u;
@@ -1080,8 +1084,14 @@ void launch_lstm_bwd_step(const LstmBwdJob* jobs, int njobs, int N, int L, hipSt
     if (i < njobs) js.j[i] = jobs[i];
     else { js.j[i] = LstmBwdJob{}; js.j[i].active = 0; }
   }
-  dim3 grid(L / 16, njobs, (N + 16 * BW_MT - 1) / (16 * BW_MT));
-  hipLaunchKernelGGL(lstm_bwd_step_kernel, grid, dim3(BW_THREADS), 0, s, js, N, L);
+  // enough workgroups from the column tiles alone (lstm_dim >= 1024) -> 32-row tiles
+  if (L / 16 * njobs >= 128 && N > 16) {
+    dim3 grid(L / 16, njobs, (N + 31) / 32);
+    hipLaunchKernelGGL(lstm_bwd_step_kernel<2>, grid, dim3(BW_THREADS), 0, s, js, N, L);
+  } else {
+    dim3 grid(L / 16, njobs, (N + 15) / 16);
+    hipLaunchKernelGGL(lstm_bwd_step_kernel<1>, grid, dim3(BW_THREADS), 0, s, js, N, L);
+  }
 }
 
 void launch_dec_xidx(const int32_t* gt, int Td, int N, int go_row, int32_t* idx, hipStream_t s) {
