@@ -156,6 +156,12 @@ typedef struct {
    * launch with encoder_h_transform and q -- and n2nmn_walk_layouts can follow directly.  Only
    * n2nmn_decoder_forward / n2nmn_seq2seq_forward read it. */
   const float *image_feat;
+  /* optional inputs: dropout multipliers (0 or 1 / keep_prob, see n2nmn_dropout_multipliers) on
+   * the output of LSTM layer 0 of the encoder [T_enc, N, lstm_dim] / the decoder [T_dec, N, lstm_dim]
+   * (encoder_dropout / decoder_dropout = True, models_vqa/nmn3_netgen_att.py:17-44).  The policy-
+   * gradient scripts sample the layout from the network WITH dropout
+   * (exp_vqa/train_vqa_rl_gt_layout.py:34-35); the same buffers then go into n2nmn_train_io. */
+  const float *drop_enc0, *drop_dec0;
 } n2nmn_seq2seq_io;
 /* skip word_vecs / neg_entropy / log_seq_prob (one launch): for inference through
  * n2nmn_walk_layouts with attention maps, which derives the text maps from atts directly */

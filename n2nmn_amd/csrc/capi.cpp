@@ -180,6 +180,8 @@ static size_t carve_workspace(n2nmn_ctx* c, char* base) {
   c->ec0 = st + 4 * N * L; c->ec1 = st + 5 * N * L;
   // final encoder state in ORIGINAL row order (written at each row's last valid step)
   c->fc0 = st + 6 * N * L; c->fh0 = st + 7 * N * L; c->fc1 = st + 8 * N * L; c->fh1 = st + 9 * N * L;
+  if (d.variant == N2NMN_VARIANT_VQA)
+    for (int i = 0; i < 2; ++i) { c->ehd[i] = k.take<float>(N * L); c->dhd[i] = k.take<float>(N * L); }
   if (c->big_vocab) {
     c->xproj = k.take<float>(T * N * 4 * L);
     c->iota = k.take<int32_t>(T * N);
@@ -302,6 +304,8 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmAr
   const int T = io->T_enc, N = io->N, L = d.lstm_dim;
   N2_REQUIRE(T >= 1 && T <= d.T_encoder && N >= 1 && N <= d.N, N2NMN_ECAPACITY,
              "encoder_forward: T_enc / N exceed the context capacity");
+  N2_REQUIRE(!(io->drop_enc0 || io->drop_dec0) || c->ehd[0], N2NMN_EINVAL,
+             "seq2seq: LSTM dropout belongs to the models_vqa variant");
   launch_enc_prepare(io->seq_length, N, T, c->perm, c->nact, c->eh0[0], 10 * (size_t)d.N * L, s);
   const float* W0x_bias_table = c->enc_xtab;
   if (c->big_vocab) {
@@ -336,13 +340,13 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmAr
     j1.active = st >= 0;
     packed_state(c, j1);
     j1.A0 = c->eh0[st & 1]; j1.A1 = c->eh1[(st + 1) & 1]; j1.K = 2 * L; j1.Wp = c->enc_W1_t;
-    if (c->rec && c->rec->drop_enc0) {   // DropoutWrapper on layer 0's output (training, models_vqa)
+    if (io->drop_enc0) {                 // DropoutWrapper on layer 0's output (models_vqa)
       const size_t nl = (size_t)N * L;
       if (j0.active) {
-        j0.drop = c->rec->drop_enc0 + (size_t)k * nl; j0.h_drop = c->rec->ehd[k & 1];
-        j0.save_hd = c->rec->eh0d + (size_t)k * nl;
+        j0.drop = io->drop_enc0 + (size_t)k * nl; j0.h_drop = c->ehd[k & 1];
+        j0.save_hd = c->rec ? c->rec->eh0d + (size_t)k * nl : nullptr;
       }
-      j1.A0 = c->rec->ehd[st & 1];
+      j1.A0 = c->ehd[st & 1];
     }
     j1.xtab = nullptr; j1.xidx = nullptr; j1.bias = c->vars[V_ENC_B1].mirror;
     j1.c_in = c->ec1; j1.c_out = c->ec1; j1.ntiles = L / 4;
@@ -448,13 +452,13 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
       packed_state(c, j1);
       j1.A0 = c->dh0[st & 1]; j1.A1 = st == 0 ? c->fh1 : c->dh1[(st + 1) & 1];
       j1.K = 2 * L; j1.Wp = c->dec_W1_t; j1.ntiles = L / 4; j1.bias = c->vars[V_DEC_B1].mirror;
-      if (c->rec && c->rec->drop_dec0) {
+      if (io->drop_dec0) {
         const size_t nl = (size_t)N * L;
         if (j0.active) {
-          j0.drop = c->rec->drop_dec0 + (size_t)k * nl; j0.h_drop = c->rec->dhd[k & 1];
-          j0.save_hd = c->rec->dh0d + (size_t)k * nl;
+          j0.drop = io->drop_dec0 + (size_t)k * nl; j0.h_drop = c->dhd[k & 1];
+          j0.save_hd = c->rec ? c->rec->dh0d + (size_t)k * nl : nullptr;
         }
-        j1.A0 = c->rec->dhd[st & 1];
+        j1.A0 = c->dhd[st & 1];
       }
       j1.c_in = st == 0 ? c->fc1 : c->dc1; j1.c_out = c->dc1;
       j1.h_old = j1.A1; j1.h_new = c->dh1[st & 1];
@@ -546,6 +550,9 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
       j0.xtab = c->dec_xtab; j0.xidx = t == 0 ? nullptr : c->next_idx; j0.xidx_const = V;  // <go>
       j0.c_in = t == 0 ? c->fc0 : c->dc0; j0.c_out = c->dc0;
       j0.h_old = j0.A0; j0.h_new = c->dh0[t & 1];
+      if (io->drop_dec0) {             // sampling from the network with dropout (policy gradient)
+        j0.drop = io->drop_dec0 + (size_t)t * N * L; j0.h_drop = c->dhd[t & 1];
+      }
       {
         ProfScope ps(c, F_LSTM_DEC0, fl0, by0, s);
         launch_lstm_step(&j0, 1, N, L, 32, s);
@@ -554,7 +561,8 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
       j1.active = 1;
       packed_state(c, j1);
       j1.out_seq = c->dh1_rm;          // row-major copy of the top-layer h for dec_attn
-      j1.A0 = c->dh0[t & 1]; j1.A1 = t == 0 ? c->fh1 : c->dh1[(t + 1) & 1]; j1.K = 2 * L;
+      j1.A0 = io->drop_dec0 ? c->dhd[t & 1] : c->dh0[t & 1];
+      j1.A1 = t == 0 ? c->fh1 : c->dh1[(t + 1) & 1]; j1.K = 2 * L;
       j1.Wp = c->dec_W1_t; j1.ntiles = L / 4; j1.bias = c->vars[V_DEC_B1].mirror;
       j1.c_in = t == 0 ? c->fc1 : c->dc1; j1.c_out = c->dc1;
       j1.h_old = j1.A1; j1.h_new = c->dh1[t & 1];

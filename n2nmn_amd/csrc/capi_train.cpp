@@ -119,7 +119,6 @@ size_t carve_train(n2nmn_ctx* c, TrainState* t, char* base) {
   r.dh0s = k.take<float>((Td + 1) * N * L); r.dh1s = k.take<float>((Td + 1) * N * L);
   r.ctx = k.take<float>(Td * N * L);
   if (d.variant == N2NMN_VARIANT_VQA) {      // dropout on LSTM layer 0's output (models_vqa training)
-    for (int i = 0; i < 2; ++i) { r.ehd[i] = k.take<float>(N * L); r.dhd[i] = k.take<float>(N * L); }
     r.eh0d = k.take<float>(T * N * L);
     r.dh0d = k.take<float>(Td * N * L);
   }
@@ -516,7 +515,7 @@ int n2nmn_train_forward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* p
   const bool vqa = d.variant == N2NMN_VARIANT_VQA;
   N2_REQUIRE(vqa || !(io->drop_enc0 || io->drop_dec0 || io->drop_qpn_h || io->drop_qpn_fc1),
              N2NMN_EINVAL, "train_forward: dropout belongs to the models_vqa variant");
-  t->rec.drop_enc0 = io->drop_enc0; t->rec.drop_dec0 = io->drop_dec0;
+  sio.drop_enc0 = io->drop_enc0; sio.drop_dec0 = io->drop_dec0;
   c->rec = &t->rec;
   float* scores = io->scores ? io->scores : t->scores;
   // the hoisted conv_image GEMMs of the module network need only the image features: they run on
@@ -559,6 +558,12 @@ int n2nmn_train_forward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* p
       la.baseline_decay = io->baseline_decay; la.baseline = io->baseline; la.dscores = t->dscores;
       la.losses = io->losses; la.coef = t->rl_coef;
       launch_loss_rl(la, s);
+      if (t->ds_pad) {                 // padded copy for the batch GEMMs of the models_vqa heads
+        N2_HIP(hipMemsetAsync(t->ds_pad, 0, sizeof(float) * (size_t)N * t->Cp, s));
+        N2_HIP(hipMemcpy2DAsync(t->ds_pad, sizeof(float) * t->Cp, t->dscores,
+                                sizeof(float) * d.num_choices, sizeof(float) * d.num_choices, N,
+                                hipMemcpyDeviceToDevice, s));
+      }
     } else {
       launch_loss(t->scores, io->answer_labels, t->rec.lsp, N, d.num_choices, t->dscores, io->losses, s,
                   t->ds_pad, t->Cp);

@@ -107,10 +107,8 @@ struct TrainRec {
   float *lsp = nullptr;        // [N] log_seq_prob
   int32_t *valid_bits = nullptr;   // [Td][N] token validity of the forward (policy gradient)
   float *pooled = nullptr;     // [max_pool][2][D]
-  // dropout on the output of LSTM layer 0 (models_vqa training): multipliers of this step (inputs)
-  // and what the forward keeps: the dropped h0 the layer above consumed
-  const float *drop_enc0 = nullptr, *drop_dec0 = nullptr;   // [T][N][L], [Td][N][L]
-  float *ehd[2] = {nullptr, nullptr}, *dhd[2] = {nullptr, nullptr};   // packed state layout
+  // dropout on the output of LSTM layer 0 (models_vqa training): what the forward keeps is the
+  // dropped h0 the layer above consumed (operand of the W1 gradient)
   float *eh0d = nullptr, *dh0d = nullptr;                   // [T][N][L], [Td][N][L] row-major
 };
 struct TrainState;
@@ -152,6 +150,8 @@ struct n2nmn_ctx {
   // question vocabularies beyond 4096 words (models_vqa: 17742): the layer-0 input projection is a
   // per-batch GEMM over the batch's own words (xproj [T][N][4L], rows addressed through iota)
   // instead of a [num_vocab_txt][4L] table rebuilt at every weight commit
+  float *ehd[2] = {nullptr, nullptr}, *dhd[2] = {nullptr, nullptr};   // dropped layer-0 outputs
+                                                                      // (packed state layout)
   bool big_vocab = false;
   float* xproj = nullptr;
   int32_t* iota = nullptr;

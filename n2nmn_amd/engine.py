@@ -159,13 +159,15 @@ class Engine:
     def seq2seq(self, input_seq, seq_len, T_dec: Optional[int] = None, use_gt_layout: bool = False,
                 gt_layout=None, sample_uniforms=None, forced_tokens=None, debug: bool = False,
                 reuse_buffers: bool = True, phase: str = 'both', word_vecs: bool = True,
-                image_feat=None):
+                image_feat=None, dropout=None):
         """Phase 1.  input_seq [T,N] int32, seq_len [N] int32 (device tensors or anything
         convertible).  Returns a dict of device tensors named like the reference attributes
         (models_clevr/nmn3_netgen_att.py:305-322).  With reuse_buffers the outputs are views of
         engine-owned buffers that the next call overwrites.  image_feat (optional): the hoisted
         conv_image GEMMs of the batch are issued by this call too (n2nmn_seq2seq_io.image_feat) and
-        walk() / execute_tokens(conv_done=True) can follow directly."""
+        walk() / execute_tokens(conv_done=True) can follow directly.  dropout (optional, models_vqa):
+        (enc0, dec0) multiplier tensors [T, N, L] / [T_dec, N, L] for the output of LSTM layer 0
+        (n2nmn_seq2seq_io.drop_enc0 / drop_dec0), either may be None."""
         torch = _torch()
         d = self.dims
         seq = self._dev(input_seq, torch.int32)
@@ -204,6 +206,11 @@ class Engine:
             if phase == 'encoder':
                 raise ValueError('image_feat is read by the decoder half')
             io.image_feat = feat.data_ptr()
+        drops = tuple(self._dev(x, torch.float32) for x in (dropout or (None, None)))
+        if drops[0] is not None:
+            io.drop_enc0 = drops[0].data_ptr()
+        if drops[1] is not None:
+            io.drop_dec0 = drops[1].data_ptr()
         if not word_vecs:        # N2NMN_S2S_NO_WORD_VECS: word_vecs / neg_entropy / log_seq_prob not computed
             io.flags = 1
             for k in ('word_vecs', 'neg_entropy', 'log_seq_prob'):
@@ -211,7 +218,7 @@ class Engine:
         fn = {'both': self._lib.n2nmn_seq2seq_forward, 'encoder': self._lib.n2nmn_encoder_forward,
               'decoder': self._lib.n2nmn_decoder_forward}[phase]
         _lib.check(fn(self._ctx, C.byref(io), self.stream()))
-        out['_keepalive'] = (seq, lens, gt, uni, forced, feat)
+        out['_keepalive'] = (seq, lens, gt, uni, forced, feat, drops)
         out['_input_seq'], out['_seq_length'] = seq, lens
         return out
 

@@ -265,6 +265,7 @@ class VQATrainer(Trainer):
         self.seed = 0                # stream of n2nmn_dropout_multipliers; the offset advances
         self._drawn = 0
         self._mult = None
+        self._reuse = None
 
     def _multipliers(self, T, N, Td):
         """Reference-shaped {0, 1} keep masks -> multipliers (0 or 1 / keep_prob) in the context's
@@ -306,12 +307,39 @@ class VQATrainer(Trainer):
         b = dict(batch)
         b['image_feat_batch'] = self.vqa.features_with_coords(batch['image_feat_batch'])
         io, packed, validity = super()._io(b, gt_layout, objective)
-        self._mult = self._multipliers(io.T_enc, io.N, io.T_dec)
+        if self._reuse is None:
+            self._mult = self._multipliers(io.T_enc, io.N, io.T_dec)
+        else:                        # step_rl: the masks the layout was sampled under
+            self._mult, self._reuse = self._reuse, None
         for key, field in (('enc0', 'drop_enc0'), ('dec0', 'drop_dec0'), ('qpn_h', 'drop_qpn_h'),
                            ('qpn_fc1', 'drop_qpn_fc1')):
             if key in self._mult:
                 setattr(io, field, self._mult[key].data_ptr())
         return io, packed, validity
+
+    def step_rl(self, batch, sample_uniforms, lr=1e-4, update: bool = True):
+        """One iteration of exp_vqa/train_vqa_rl_gt_layout.py:150-196: the layout is sampled from the
+        network WITH this step's dropout masks (the reference samples inside the training graph),
+        fetched and assembled on the host, then the policy-gradient loss (:106-126, every layout
+        counted as valid like :112) is differentiated under the same masks."""
+        import torch
+        e = self.engine
+        seq = torch.as_tensor(batch['input_seq_batch'])
+        T, N = seq.shape
+        mult = self._multipliers(T, N, self.vqa.dims.T_decoder)
+        s2s = e.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], self.vqa.dims.T_decoder,
+                        sample_uniforms=sample_uniforms,
+                        dropout=(mult.get('enc0'), mult.get('dec0')))
+        tokens = s2s['predicted_tokens'].cpu().numpy()
+        self._reuse = mult
+        scale = self.forward_backward(batch, tokens, objective=1)
+        if update:
+            saved = self.hyper['lr']
+            self.hyper['lr'] = saved if lr is None else float(lr)
+            self.apply(scale)
+            self.hyper['lr'] = saved
+        validity = self._keep[6].cpu().numpy().astype(bool) if self._keep[6] is not None else None
+        return self.losses, tokens, validity
 
     def gradients_reference_shaped(self):
         """name -> numpy gradient in the reference's (unpadded) variable shape."""

@@ -464,7 +464,7 @@ def loss_and_grads_vqa(w, batch, T_dec, num_choices, gt_layout, masks=None, weig
     return losses, grads, extras
 
 
-def decoder_forward_tokens(w, enc, T_dec, tokens, token_validity):
+def decoder_forward_tokens(w, enc, T_dec, tokens, token_validity, drop0=None):
     """Decoder run on GIVEN tokens with the automaton's validity masks (constants: they depend on
     the tokens only): what the sampling decoder computed when it drew `tokens`
     (nmn3_netgen_att.py:175-312 with decoder_sampling=True), as a differentiable function of the
@@ -484,7 +484,7 @@ def decoder_forward_tokens(w, enc, T_dec, tokens, token_validity):
     atts, scores = [], []
     for t in range(T_dec):
         c0, h0 = _lstm_cell(x, c0, h0, W0, b0)
-        c1, h1 = _lstm_cell(h0, c1, h1, W1, b1)
+        c1, h1 = _lstm_cell(h0 if drop0 is None else h0 * (_t(drop0[t]) * 2.0), c1, h1, W1, b1)
         q = h1 @ Wa + ba
         e = torch.sum(torch.tanh(q[None] + eht) * v, dim=2, keepdim=True)
         att = torch.softmax(e, dim=0) * nf
@@ -506,25 +506,35 @@ def decoder_forward_tokens(w, enc, T_dec, tokens, token_validity):
 
 def train_forward_rl(wt, module_names, batch, T_dec, num_choices, tokens, token_validity, baseline,
                      invalid_expr_loss=0.5, lambda_entropy=0.005, weight_decay=5e-6,
-                     validity_override=None):
+                     validity_override=None, vqa_masks=None):
     """Loss of train_clevr_rl_gt_layout.py:107-129 for one batch whose layouts `tokens` were sampled
-    by the decoder.  baseline: python float (tf.Variable, not trainable)."""
-    enc = encoder_forward(wt, batch['input_seq_batch'], batch['seq_length_batch'])
-    dec = decoder_forward_tokens(wt, enc, T_dec, tokens, token_validity)
+    by the decoder.  baseline: python float (tf.Variable, not trainable).
+    vqa_masks (dict, possibly empty) selects the models_vqa network of
+    exp_vqa/train_vqa_rl_gt_layout.py:106-126 (same loss; module_names = VQA_MODULE_NAMES) with the
+    given dropout keep masks (enc0 / dec0 / qpn_h / qpn_fc1, see train_forward_vqa)."""
+    mk = vqa_masks or {}
+    enc = encoder_forward(wt, batch['input_seq_batch'], batch['seq_length_batch'], mk.get('enc0'))
+    dec = decoder_forward_tokens(wt, enc, T_dec, tokens, token_validity, mk.get('dec0'))
     exprs, validity = O.assemble(module_names, np.asarray(tokens))
     if validity_override is not None:           # expr_validity_batch is a placeholder (:86): the
         validity = np.asarray(validity_override, bool)   # loss sees whatever the caller feeds
     feat = _t(batch['image_feat_batch'])
+    if vqa_masks is not None:
+        feat = add_spatial_coordinate_map(feat)
     _MARGIN['min_gap'] = {}
     rows = []
     for n, e in enumerate(exprs):
         _MARGIN['example'] = n
         if validity[n]:
-            rows.append(eval_expr(wt, e, feat, dec['word_vecs'], num_choices))
+            rows.append(eval_expr_vqa(wt, e, feat, dec['word_vecs'], num_choices)
+                        if vqa_masks is not None else
+                        eval_expr(wt, e, feat, dec['word_vecs'], num_choices))
         else:                                   # INVALID_EXPR: zero logits (nmn3_model.py:146,155)
             rows.append(torch.zeros(num_choices, dtype=torch.float64))
     _MARGIN['example'] = None
     scores = torch.stack(rows)
+    if vqa_masks is not None:
+        scores = scores + question_prior_net(wt, enc['states'], mk.get('qpn_h'), mk.get('qpn_fc1'))
     labels = torch.as_tensor(np.asarray(batch['answer_label_batch'])).long()
     log_seq_prob = torch.sum(torch.log(dec['token_probs']), dim=0)
     ce = torch.logsumexp(scores, dim=1) - scores[torch.arange(len(labels)), labels]
@@ -542,13 +552,13 @@ def train_forward_rl(wt, module_names, batch, T_dec, num_choices, tokens, token_
 
 def loss_and_grads_rl(w, module_names, batch, T_dec, num_choices, tokens, token_validity, baseline,
                       invalid_expr_loss=0.5, lambda_entropy=0.005, weight_decay=5e-6,
-                      baseline_decay=0.99, validity_override=None):
+                      baseline_decay=0.99, validity_override=None, vqa_masks=None):
     """numpy in / numpy out; like loss_and_grads.  losses additionally hold 'new_baseline'
     (baseline + (1 - decay) * (avg_sample_loss - baseline), :120-122)."""
     wt = {k: _t(v).clone().requires_grad_(True) for k, v in w.items()}
     r = train_forward_rl(wt, module_names, batch, T_dec, num_choices, tokens, token_validity,
                          baseline, invalid_expr_loss, lambda_entropy, weight_decay,
-                         validity_override)
+                         validity_override, vqa_masks)
     inter = dict(word_vecs=r['dec']['word_vecs'], token_scores=r['dec']['token_scores'],
                  scores=r['scores'])
     for v in inter.values():

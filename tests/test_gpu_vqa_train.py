@@ -111,3 +111,54 @@ def test_drawn_masks_keep_about_half(setup):
     frac = float((m > 0).float().mean())
     assert 0.45 < frac < 0.55 and float(m.max()) == 2.0
     assert np.isfinite(t2n(tr.losses)[:2]).all()
+
+
+def _token_validity(asm, tokens, T_dec):
+    """[T_dec, N, V] masks of the automaton along the given token sequences
+    (nmn3_netgen_att.py:8-15,200-203)."""
+    from oracle import n2nmn_oracle as O
+    Td, N = tokens.shape
+    X = np.tile(np.array([[0, 0, T_dec]], np.int64), (N, 1))
+    out = np.zeros((Td, N, asm.P.shape[0]), bool)
+    for t in range(Td):
+        out[t] = O.valid_tokens(X, asm.W, asm.b)
+        X = X + asm.P[tokens[t]]
+    return out
+
+
+def test_vqa_policy_gradient_step_with_dropout_matches_oracle(setup):
+    """exp_vqa/train_vqa_rl_gt_layout.py:106-126: the layout is sampled from the network under this
+    step's dropout masks, then REINFORCE + entropy + answer loss through the same masks.  Oracle:
+    loss_and_grads_rl(vqa_masks=...) on the tokens the GPU sampled (its CLEVR form is pinned to the
+    reference's RL loss block, its models_vqa + dropout forward to the vqa_train fixture)."""
+    from oracle import n2nmn_oracle as O
+    from oracle import n2nmn_oracle_grad as G
+    d, batch, gt, eng, tr, w = setup
+    eng.load_weights(w)
+    masks = FC.vqa_dropout_masks(d)
+    tr.masks = masks
+    tr.baseline.fill_(1.25)
+    uni = np.random.default_rng(3).random((d.T_decoder, d.N)).astype(np.float32)
+    losses, tokens, validity = tr.step_rl(batch, uni, update=False)
+    losses = t2n(losses)
+    assert validity.all()
+    asm = eng.assembler
+    tv = _token_validity(asm, tokens, d.T_decoder)
+    assert tv[np.arange(d.T_decoder)[:, None], np.arange(d.N)[None], tokens].all()
+    w64 = {k: v.astype(np.float64) for k, v in w.items()}
+    ref_l, ref_g, ex = G.loss_and_grads_rl(w64, list(O.VQA_MODULE_NAMES), batch, d.T_decoder,
+                                           d.num_choices, tokens, tv, 1.25, weight_decay=0.0,
+                                           vqa_masks=masks)
+    assert_close('scores', t2n(tr.scores), ex['scores'], 1e-4)
+    for i, k in ((0, 'avg_sample_loss'), (1, 'policy_gradient_loss'), (3, 'total_loss'),
+                 (4, 'entropy_reg')):
+        assert abs(losses[i] - ref_l[k]) <= 1e-4 * max(1.0, abs(ref_l[k])), (k, losses[i], ref_l[k])
+    assert abs(float(t2n(tr.baseline)[0]) - ref_l['new_baseline']) <= 1e-5
+    grads = tr.gradients_reference_shaped()
+    bad = []
+    for k, want in ref_g.items():
+        tol = GRAD_RTOL * max(float(np.abs(want).max()), 1e-30) + 1e-7
+        err = float(np.abs(np.asarray(grads[k], np.float64) - want).max())
+        if not err <= tol:
+            bad.append('%s: %.3e > %.3e' % (k, err, tol))
+    assert not bad, '\n'.join(bad)
