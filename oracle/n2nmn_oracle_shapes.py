@@ -11,9 +11,11 @@ Restates `models_shapes/*` on top of the shared pieces of oracle/n2nmn_oracle.py
     (models_shapes/nmn3_modules.py:27-144)
   * data plumbing of exp_shapes/eval_shapes.py:60-114 (vocabularies, np.random.seed(3) shuffle,
     tokenisation, mean subtraction): `load_split`.
-PARITY STATUS: the float path of THIS variant is "parity unpinned" (models_shapes is not among the
-files run under the TF1 stand-in; models_clevr and models_vqa are); the data plumbing is pinned to
-the reference's own dataset files through tests/golden/shapes_golden.json.
+PARITY STATUS: PINNED -- the unmodified models_shapes/*.py (NMN3ModelAtt, shapes_convnet, the SHAPES
+assembler) run under the eager TF1/Fold stand-in (tests/golden/make_float_golden.py::case_shapes ->
+float_golden.npz `shapes_*`), and this module equals those outputs to 1e-10, variable names
+included (tests/test_oracle_vs_reference_code.py); the data plumbing is pinned to the reference's
+own dataset files through tests/golden/shapes_golden.json.
 """
 from __future__ import annotations
 
@@ -56,8 +58,12 @@ def variable_shapes(num_vocab_txt=14, num_vocab_nmn=5, d=DIMS):
                                ('TransformModule', 'conv_maps', (d['kernel_size'], d['kernel_size'], 1, M)),
                                ('TransformModule', 'text_fc', (E, M)), ('TransformModule', 'conv_eltwise', (M, 1)),
                                ('AnswerModule', 'fc_scores', (3, C))):
-        s[_MOD + scope + '/' + name + '/weights'] = shape
-        s[_MOD + scope + '/' + name + '/biases'] = (shape[-1],)
+        # td.ScopedLayer(modules.<X>Module, name_or_scope='<X>Module') opens the scope once and the
+        # module function opens it again (models_shapes/nmn3_model.py:60-80, nmn3_modules.py:27,62,
+        # 112): the variables the reference creates are layout_execution/<X>Module/<X>Module/...
+        # (checked by running the reference's model code, tests/test_oracle_vs_reference_code.py)
+        s[_MOD + scope + '/' + scope + '/' + name + '/weights'] = shape
+        s[_MOD + scope + '/' + scope + '/' + name + '/biases'] = (shape[-1],)
     return s
 
 
@@ -136,7 +142,8 @@ def _mw(w):
     out = {}
     for k, v in w.items():
         if k.startswith(_MOD):
-            out[O._MOD + k[len(_MOD):]] = v
+            scope, rest = k[len(_MOD):].split('/', 1)          # <X>Module/<X>Module/... -> <X>Module/...
+            out[O._MOD + rest] = v
     return out
 
 

@@ -138,3 +138,23 @@ def vqa_dropout_masks(d):
 def vqa_weights(d, dtype=np.float32):
     from n2nmn_amd.vqa import vqa_variable_shapes
     return synth.make_weights_from_shapes(vqa_variable_shapes(d), seed=WEIGHT_SEED, dtype=dtype)
+
+
+def shapes_setup():
+    """SHAPES case (BASELINE.json configs[0]): the 12 questions of tests/golden/shapes_golden.json
+    (the reference's own dataset files: images, text, ground-truth layouts) with seed-0 weights."""
+    import base64
+    import json
+    import os
+    from oracle import n2nmn_oracle_shapes as S
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'shapes_golden.json')) as f:
+        g = json.load(f)
+    img = np.frombuffer(base64.b64decode(g['images_u8_b64']), np.uint8).reshape(g['images_shape'])
+    mean = np.frombuffer(base64.b64decode(g['image_mean_b64']), np.float32).reshape(g['image_mean_shape'])
+    batch = dict(image_batch=(img.astype(np.float32) - mean).astype(np.float32),
+                 text_seq_batch=np.array(g['text_seq'], np.int32),
+                 seq_length_batch=np.array(g['seq_length'], np.int32))
+    gt = np.array(g['gt_layout'], np.int32)
+    w = synth.make_weights_from_shapes(S.variable_shapes(len(g['vocab']), len(g['layout_vocab'])),
+                                       seed=0, dtype=np.float64)
+    return S.DIMS, batch, gt, w, len(g['vocab']), len(g['layout_vocab'])

@@ -7,6 +7,7 @@ that execute every op eagerly on torch CPU tensors in float64, so the UNMODIFIED
 
     models_clevr/nmn3_model.py, nmn3_netgen_att.py, nmn3_modules.py, nmn3_assembler.py
     models_vqa/nmn3_model.py, nmn3_modules.py, question_prior_net.py (+ its nmn3_netgen_att.py)
+    models_shapes/nmn3_model.py, nmn3_modules.py, nmn3_netgen_att.py, nmn3_assembler.py, shapes_convnet.py
     util/cnn.py, util/empty_safe_conv.py
     the loss blocks of exp_clevr/train_clevr_gt_layout.py and train_clevr_rl_gt_layout.py
       (their source lines are exec'd from the checkout, not restated)
@@ -316,9 +317,40 @@ def case_vqa_train(out, meta):
     meta[key] = m
 
 
+def case_shapes(out, meta):
+    """models_shapes (BASELINE.json configs[0]): NMN3ModelAtt = shapes_convnet + the SHAPES layout
+    generator (no validity automaton, <eos> latch) + Find / Transform / And / Answer, on the 12
+    dataset questions of shapes_golden.json, free-running and with the ground-truth layouts."""
+    from models_shapes.nmn3_assembler import Assembler
+    from models_shapes.nmn3_model import NMN3ModelAtt
+    d, batch, gt, w, nv_txt, nv_nmn = FC.shapes_setup()
+    N = batch['image_batch'].shape[0]
+    for mode in ('greedy', 'gt'):
+        fresh_graph(w, N)
+        asm = Assembler(os.path.join(REF, 'exp_shapes/data/vocabulary_layout.txt'))
+        kw = dict(use_gt_layout=torch.tensor(True), gt_layout_batch=torch.as_tensor(gt)) \
+            if mode == 'gt' else {}
+        model = NMN3ModelAtt(T64(batch['image_batch']), torch.as_tensor(batch['text_seq_batch']),
+                             torch.as_tensor(batch['seq_length_batch']), T_decoder=d['T_decoder'],
+                             num_vocab_txt=nv_txt, embed_dim_txt=d['embed_dim_txt'],
+                             num_vocab_nmn=nv_nmn, embed_dim_nmn=d['embed_dim_nmn'],
+                             lstm_dim=d['lstm_dim'], num_layers=2, EOS_idx=asm.EOS_idx,
+                             encoder_dropout=False, decoder_dropout=False, decoder_sampling=False,
+                             num_choices=d['num_choices'], **kw)
+        key = 'shapes_' + mode
+        exprs, validity = asm.assemble(n(model.predicted_tokens))
+        scores = tf.Session().run(model.scores, feed_dict=model.compiler.build_feed_dict(exprs))
+        seq2seq_outputs(out, key, model)
+        out[key + '/image_feat_grid'] = n(model.image_feat_grid)
+        out[key + '/scores'] = n(scores)
+        out[key + '/validity'] = np.asarray(validity, bool)
+        meta[key] = dict(fold_batches=model.compiler.batch_sizes,
+                         variables=sorted(v.op.name for v in tf.trainable_variables()))
+
+
 def generate():
     out, meta = {}, {}
-    for fn in (case_greedy, case_gt, case_sampled, case_modules, case_vqa, case_vqa_train):
+    for fn in (case_greedy, case_gt, case_sampled, case_modules, case_vqa, case_vqa_train, case_shapes):
         fn(out, meta)
         print('%-14s done (%d arrays so far)' % (fn.__name__, len(out)), flush=True)
     out['meta_json'] = np.frombuffer(json.dumps(meta, sort_keys=True).encode(), np.uint8)

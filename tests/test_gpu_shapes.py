@@ -46,8 +46,8 @@ def test_shapes_fixture_batch_on_gpu():
     w = synth.make_weights(d, seed=1)                 # CLEVR-only variables: unused fillers
     mod = 'neural_module_network/layout_execution/'
     for k, v in sw.items():
-        if k.startswith(mod):
-            name = k[len(mod):].replace('AnswerModule/', 'ExistModule/')
+        if k.startswith(mod):          # <X>Module/<X>Module/... (the ScopedLayer naming of models_shapes)
+            name = k[len(mod):].split('/', 1)[1].replace('AnswerModule/', 'ExistModule/')
             w['neural_module_network/layout_execution/module_variables/' + name] = v
         elif 'image_feature_cnn' not in k:
             w[k] = v                                  # encoder / decoder: same names

@@ -194,6 +194,33 @@ def test_vqa_model(fx, mode):
             {'FindModule', 'TransformModule', 'AndModule', 'DescribeModule'}
 
 
+@pytest.mark.parametrize('mode', ['greedy', 'gt'])
+def test_shapes_model(fx, mode):
+    """models_shapes (configs[0]): convnet features, layout generator without the validity automaton,
+    Find / Transform / And / Answer; variable names as the reference's ScopedLayers create them."""
+    from oracle import n2nmn_oracle_shapes as S
+    z, meta = fx
+    d, batch, gt, w, nv_txt, nv_nmn = FC.shapes_setup()
+    key = 'shapes_' + mode
+    names = sorted(S.variable_shapes(nv_txt, nv_nmn))
+    if mode == 'gt':
+        assert meta[key]['variables'] == names
+    else:       # untrained free-running layouts are all invalid: no module was ever instantiated
+        assert set(meta[key]['variables']) < set(names)
+    kw = dict(use_gt_layout=True, gt_layout=gt) if mode == 'gt' else {}
+    r = S.forward(w, batch, **kw)
+    close('image_feat_grid', r['feat'], z[key + '/image_feat_grid'])
+    assert np.array_equal(r['dec']['predicted_tokens'], z[key + '/predicted_tokens'])
+    for name in ('token_probs', 'neg_entropy', 'word_vecs', 'atts'):
+        close(key + '/' + name, r['dec'][name], z[key + '/' + name])
+    assert np.array_equal(r['validity'], z[key + '/validity'])
+    close('scores', r['scores'], z[key + '/scores'])
+    if mode == 'gt':
+        assert r['validity'].all()
+        # the Fold stand-in batched the 12 questions' operators per depth
+        assert max(nb for _, _, nb in meta[key]['fold_batches']) >= 12
+
+
 def test_vqa_training_step_with_dropout(fx):
     """models_vqa with encoder / decoder / question-prior dropout + the loss block of
     exp_vqa/train_vqa_gt_layout.py: losses, logits, EVERY variable's gradient, one Adam step
