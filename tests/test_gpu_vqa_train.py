@@ -1,4 +1,5 @@
-"""models_vqa training step (exp_vqa/train_vqa_gt_layout.py) on the HIP path against numbers computed
+"""models_vqa training step (exp_vqa/train_vqa_gt_layout.py; train_vqa2_gt_layout.py differs only in
+max_iter and the data file) on the HIP path against numbers computed
 by the REFERENCE'S OWN CODE: tests/golden/float_golden.npz `vqa_train/*` = the unmodified
 models_vqa/*.py with encoder / decoder / question-prior dropout under the TF1 stand-in, the loss
 block of the training script, autograd gradients of every variable and one Adam step (float64).
