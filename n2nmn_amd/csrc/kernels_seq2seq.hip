@@ -153,6 +153,14 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_kernel(LstmJobs jobs, 
   const int gr = row0 + erow;
   const bool eact = tid < 4 * ROWS && gr < N;
   const int orow = (eact && jb.perm) ? jb.perm[gr] : gr;   // original row of state row gr
+  if (row0 >= nact && jb.mode == 0 && !jb.save_gates) {
+    // Every row of this tile is past its length (length-sorted encoder).  Such rows are never read
+    // again: the recurrence only contracts over rows of tiles that are still active, c is updated
+    // in place, and a row's final state was captured at its last valid step (fin_c / fin_h).  All
+    // that is left of dynamic_rnn's semantics (Appendix A.2) is the zero output row.
+    if (eact && jb.out_seq) jb.out_seq[(size_t)orow * L + 4 * tile + ul] = 0.f;
+    return;
+  }
   float add[4] = {0.f, 0.f, 0.f, 0.f};
   float c_old = 0.f, h_prev = 0.f;
   bool masked = false;
@@ -335,6 +343,10 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_wide_kernel(LstmJobs j
   const int gr = row0 + erow;
   const bool eact = tid < 8 * ROWS && gr < N;
   const int orow = (eact && jb.perm) ? jb.perm[gr] : gr;
+  if (row0 >= nact && !jb.save_gates) {        // see lstm_step_kernel: only the zero output row is left
+    if (eact && jb.out_seq) jb.out_seq[(size_t)orow * L + 4 * tile + ul] = 0.f;
+    return;
+  }
   float add[4] = {0.f, 0.f, 0.f, 0.f};
   float c_old = 0.f, h_prev = 0.f;
   bool masked = false;
