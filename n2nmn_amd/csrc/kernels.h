@@ -131,6 +131,9 @@ struct DecStepArgs {
   const float* q;          // [steps][N][L]   out . W_a + b_a
   const float* out;        // [steps][N][L]   top-layer h
   const float* eht;        // [T][N][L]
+  const float* eht_bias;   // [L] bias of encoder_h_transform, or nullptr.  Rows past a question's
+                           // length are fc(0) = this bias exactly (dynamic_rnn emits zero rows,
+                           // Appendix A.2), so the batched attention evaluates them once
   const float* eout;       // [T][N][L]
   const int32_t* seq_len;  // [N]
   const float* v;          // [L]

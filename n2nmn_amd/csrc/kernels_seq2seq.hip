@@ -715,12 +715,15 @@ __global__ __launch_bounds__(256) void dec_attn_multi_kernel(DecStepArgs a, int 
       }
     }
     constexpr int UNR = TS <= 2 ? 6 : 3;     // encoder rows of a wave in flight
-    for (int j0 = 0; j0 * NW + w < T; j0 += UNR) {
+    // rows past the question's length all equal the bias of encoder_h_transform: virtual row `len`
+    // stands for every one of them (evaluated once, copied to the others below)
+    const int Tv = (a.eht_bias && len < T) ? len + 1 : T;
+    for (int j0 = 0; j0 * NW + w < Tv; j0 += UNR) {
       float4 e4[UNR][KI];
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
-        const int tau = min(w + NW * (j0 + u), T - 1);
-        const float* er = a.eht + ((size_t)tau * N + n) * L;
+        const int tau = min(w + NW * (j0 + u), Tv - 1);
+        const float* er = (Tv != T && tau == len) ? a.eht_bias : a.eht + ((size_t)tau * N + n) * L;
 #pragma unroll
         for (int i = 0; i < KI; ++i)
           e4[u][i] = *reinterpret_cast<const float4*>(er + min(4 * lane + 256 * i, L - 4));
@@ -739,8 +742,15 @@ __global__ __launch_bounds__(256) void dec_attn_multi_kernel(DecStepArgs a, int 
                     v4[i].w * fast_tanh(q4[j][i].w + e4[u][i].w);
           }
           const float r = wave_sum(sacc);
-          if (lane == 0 && tau < T) es[j * Tp + tau] = r;
+          if (lane == 0 && tau < Tv) es[j * Tp + tau] = r;
         }
+      }
+    }
+    if (Tv != T && len + 1 < T) {
+      __syncthreads();
+      for (int i = tid; i < TS * (T - len - 1); i += NT) {
+        const int j = i / (T - len - 1), tau = len + 1 + i % (T - len - 1);
+        es[j * Tp + tau] = es[j * Tp + len];
       }
     }
   }
