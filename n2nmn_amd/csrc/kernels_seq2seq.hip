@@ -564,14 +564,17 @@ __global__ __launch_bounds__(NT) void dec_attn_kernel(DecStepArgs a) {
       }
     }
     constexpr int UNR = 4;
-    for (int j0 = 0; j0 * NW + w < T; j0 += UNR) {
+    // rows past the question's length all equal the bias of encoder_h_transform: virtual row `len`
+    // stands for every one of them (see dec_attn_multi_kernel)
+    const int Tv = (a.eht_bias && len < T) ? len + 1 : T;
+    for (int j0 = 0; j0 * NW + w < Tv; j0 += UNR) {
       float s[UNR];
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         const int tau = w + NW * (j0 + u);
         s[u] = 0.f;
-        if (tau < T) {
-          const float* er = a.eht + ((size_t)tau * N + n) * L;
+        if (tau < Tv) {
+          const float* er = (Tv != T && tau == len) ? a.eht_bias : a.eht + ((size_t)tau * N + n) * L;
 #pragma unroll
           for (int i = 0; i < MAXKI; ++i) {
             const int k = 4 * lane + 256 * i;
@@ -587,8 +590,12 @@ __global__ __launch_bounds__(NT) void dec_attn_kernel(DecStepArgs a) {
       for (int u = 0; u < UNR; ++u) {
         const int tau = w + NW * (j0 + u);
         const float r = wave_sum(s[u]);
-        if (lane == 0 && tau < T) es[tau] = r;
+        if (lane == 0 && tau < Tv) es[tau] = r;
       }
+    }
+    if (Tv != T && len + 1 < T) {
+      __syncthreads();
+      for (int tau = len + 1 + tid; tau < T; tau += NT) es[tau] = es[len];
     }
   }
   __syncthreads();
