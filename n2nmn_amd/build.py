@@ -44,9 +44,24 @@ def hipcc() -> str:
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
+    """Compile csrc/ into LIB.  Several processes may get here at once (one rank per GPU under
+    torch.distributed.run, all finding a stale library): an exclusive file lock serialises them, the
+    losers re-check staleness and return, and the library appears atomically (os.replace)."""
     if not force and not is_stale():
         return LIB
+    import fcntl
     os.makedirs(LIBDIR, exist_ok=True)
+    with open(os.path.join(LIBDIR, '.build.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not is_stale():
+                return LIB
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose: bool) -> str:
     objs = []
     procs = []
     objdir = os.path.join(LIBDIR, 'obj')
@@ -69,10 +84,16 @@ def build(force: bool = False, verbose: bool = True) -> str:
             sys.stderr.write('FAILED: %s\n%s\n' % (src, out.decode(errors='replace')))
     if failed:
         raise RuntimeError('hipcc failed')
-    cmd = [hipcc(), '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs
+    tmp = LIB + '.tmp.%d' % os.getpid()
+    cmd = [hipcc(), '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', tmp] + objs
     if verbose:
         print(' '.join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, LIB)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB
 
 
