@@ -672,6 +672,25 @@ def main():
                                        'region (an event pair around an EMPTY kernel reads %.2f us; '
                                        'for these kernels a pair reads ~1.5-2 us more than rocprofv3, '
                                        'profiles/)' % (kpass, ovh)}
+        if dom['kernel'].startswith('lstm_step(enc'):
+            # `achieved` counts the reference algorithm's work (dynamic_rnn evaluates the cell for
+            # every row of the batch at every step and selects afterwards); the length-sorted
+            # encoder skips the 16-row MFMA tiles that hold no active row, so the flops the kernel
+            # EXECUTED are fewer: report that rate too
+            L, Tn = d.lstm_dim, d.T_encoder
+            ex = 0.0
+            for b in buckets[:2]:
+                lens = np.sort(b.seq_length[:K * d.N].cpu().numpy())[::-1]
+                act = [int(np.count_nonzero(lens > t)) for t in range(Tn)]
+                r16 = [min(K * d.N, (a + 15) // 16 * 16) for a in act]
+                ex += sum(2.0 * 4 * L * (L * r16[k] if k < Tn else 0) +
+                          2.0 * 4 * L * (2 * L * r16[k - 1] if k >= 1 else 0) for k in range(Tn + 1))
+            ex /= min(2, len(buckets)) * (Tn + 1)             # per launch
+            out['roofline']['executed_achieved'] = round(ex / (dom['avg_us'] * 1e-6) / 1e12, 3)
+            out['roofline']['executed_frac'] = round(ex / (dom['avg_us'] * 1e-6) / 1e12 / dom['peak'], 4)
+            out['roofline']['executed_note'] = ('flops of the 16-row tiles that hold an active row '
+                                                '(lengths of this run); `achieved` / `frac` count every '
+                                                'row at every step like the reference')
         out['kernels'] = rows
         out['event_pair_overhead_us'] = round(ovh, 3)
         out['gpu_us_per_step'] = round(sum(r['us_per_step'] for r in rows), 1)
