@@ -128,6 +128,7 @@ static size_t carve_weights(n2nmn_ctx* c, char* base) {
   c->dec_W0x_p = k.take<float>((size_t)c->KpE * 4 * L);
   c->enc_xtab = c->big_vocab ? nullptr : k.take<float>(Vt * 4 * L);
   c->dec_xtab = k.take<float>((V + 1) * 4 * L);
+  c->enc_b0_t = k.take<float>(4 * L); c->dec_b0_t = k.take<float>(4 * L);
   c->enc_W0h_t = k.take<float>(L * 4 * L);
   c->enc_W1_t = k.take<float>(2 * L * 4 * L);
   c->dec_W0h_t = k.take<float>(L * 4 * L);
@@ -313,7 +314,7 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmAr
     GemmArgs g{};
     g.A = c->vars[V_ENC_EMB].mirror; g.lda = d.embed_dim_txt; g.M = T * N; g.K = d.embed_dim_txt;
     g.group_idx = io->input_seq; g.group_size = 1;
-    g.Bp = c->enc_W0x_p; g.Np = 4 * L; g.Kp = c->KpE; g.bias = c->vars[V_ENC_B0].mirror; g.N = 4 * L;
+    g.Bp = c->enc_W0x_p; g.Np = 4 * L; g.Kp = c->KpE; g.bias = c->enc_b0_t; g.N = 4 * L;
     g.C = c->xproj; g.ldc = 4 * L; g.n_store = 4 * L;
     ProfScope ps(c, F_GEMM_EHT, 2.0 * T * N * d.embed_dim_txt * 4.0 * L,
                  4.0 * ((double)T * N * (d.embed_dim_txt + 4.0 * L) + 4.0 * L * d.embed_dim_txt), s);
@@ -1007,8 +1008,12 @@ int n2nmn_commit_weights(n2nmn_ctx* c, n2nmn_stream stream) {
     PackBatch& pb = c->packs;
     auto has = [&](int id) { return c->vars[id].present; };
     // layer-0 input projections (rows [0,E) of the LSTM weights) -> PK, then the tables
-    pb.pk(m(V_ENC_W0), 4 * L, E, 4 * L, c->enc_W0x_p, c->KpE, 4 * L);
-    pb.pk(m(V_DEC_W0), 4 * L, E, 4 * L, c->dec_W0x_p, c->KpE, 4 * L);
+    // input halves of the layer-0 weights with the gate columns in tile order: the x-tables come out
+    // of their GEMMs in the order the step kernels read them (LstmJob::xtab)
+    pb.pk_gates(m(V_ENC_W0), 4 * L, E, L, c->enc_W0x_p, c->KpE);
+    pb.pk_gates(m(V_DEC_W0), 4 * L, E, L, c->dec_W0x_p, c->KpE);
+    pb.vec_gates(m(V_ENC_B0), L, c->enc_b0_t);
+    pb.vec_gates(m(V_DEC_B0), L, c->dec_b0_t);
     // recurrent parts -> gate-interleaved column tiles
     pb.tiles(m(V_ENC_W0), 4 * L, E, L, L / 4, L, c->enc_W0h_t);
     pb.tiles(m(V_ENC_W1), 4 * L, 0, 2 * L, L / 4, L, c->enc_W1_t);
@@ -1067,10 +1072,10 @@ int n2nmn_commit_weights(n2nmn_ctx* c, n2nmn_stream stream) {
   // xtab[v] = emb[v] . W_x + b : the whole input half of the layer-0 gate pre-activations
   GemmArgs g{};
   g.A = m(V_ENC_EMB); g.lda = E; g.M = d.num_vocab_txt; g.K = E; g.group_size = 1;
-  g.Bp = c->enc_W0x_p; g.Np = 4 * L; g.Kp = c->KpE; g.bias = m(V_ENC_B0); g.N = 4 * L;
+  g.Bp = c->enc_W0x_p; g.Np = 4 * L; g.Kp = c->KpE; g.bias = c->enc_b0_t; g.N = 4 * L;
   g.C = c->enc_xtab; g.ldc = 4 * L; g.n_store = 4 * L;
   if (!c->big_vocab) launch_gemm_pk(g, s);
-  g.A = c->dec_emb_cat; g.M = V + 1; g.Bp = c->dec_W0x_p; g.bias = m(V_DEC_B0); g.C = c->dec_xtab;
+  g.A = c->dec_emb_cat; g.M = V + 1; g.Bp = c->dec_W0x_p; g.bias = c->dec_b0_t; g.C = c->dec_xtab;
   launch_gemm_pk(g, s);
   for (int i = 0; i < 5; ++i) {        // ew[ws] = embedding_mat . W_txt[ws]  (walker text maps)
     if (!c->ew[i]) continue;

@@ -62,6 +62,10 @@ struct PackBatch {
   void pk_t(const float* src, int ld, int K, int N, float* dst, int Kp, int Np) {
     add(PJ_PK_T, src, dst, (size_t)Kp * Np, ld, K, N, Kp, Np);
   }
+  void pk_gates(const float* src, int ld, int K, int L, float* dst, int Kp) {
+    add(PJ_PK_GATES, src, dst, (size_t)Kp * 4 * L, ld, K, L);
+  }
+  void vec_gates(const float* src, int L, float* dst) { add(PJ_VEC_GATES, src, dst, (size_t)4 * L, L); }
   void tiles(const float* W, int ld, int row0, int K, int ntiles, int gate_L, float* dst) {
     add(PJ_TILES, W, dst, (size_t)ntiles * K * 16, ld, row0, K, gate_L);
   }
@@ -141,6 +145,7 @@ struct n2nmn_ctx {
 
   // packed weights / derived tables
   float *enc_W0x_p = nullptr, *dec_W0x_p = nullptr, *enc_xtab = nullptr, *dec_xtab = nullptr;
+  float *enc_b0_t = nullptr, *dec_b0_t = nullptr;    // layer-0 biases in the x-table's tile column order
   float *enc_W0h_t = nullptr, *enc_W1_t = nullptr, *dec_W0h_t = nullptr, *dec_W1_t = nullptr;
   float *eht_W_p = nullptr, *att_W_t = nullptr, *att_W_p = nullptr, *find_img_p = nullptr, *fsp_img_p = nullptr;
   float* dec_emb_cat = nullptr;

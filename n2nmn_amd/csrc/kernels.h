@@ -53,7 +53,7 @@ void launch_pack_tiles(const float* W, int ld, int row0, int K, int ntiles, int 
 
 // All operand re-packs of one weight commit in ONE launch: a job table (built once per context,
 // the pointers never change) replaces ~40 tiny pack / pad / copy launches per optimiser step.
-enum PackKind : int32_t { PJ_PK = 0, PJ_PK_T, PJ_TILES, PJ_TILES_T, PJ_PAD };
+enum PackKind : int32_t { PJ_PK = 0, PJ_PK_T, PJ_TILES, PJ_TILES_T, PJ_PAD, PJ_PK_GATES, PJ_VEC_GATES };
 struct PackJob {
   int32_t kind;
   int32_t p[7];            // PK / PK_T: ld, K, N, Kp, Np    TILES: ld, row0, K, gate_L
@@ -82,7 +82,9 @@ struct LstmJob {
   const float* Wp;        // packed tiles for this job
   int ntiles;             // number of 16-column tiles (LSTM: L/4; linear: Ncols/16)
   int mode;               // 0: LSTM cell epilogue; 1: plain linear  out = z + bias
-  const float* xtab;      // [V][4L] input-projection table incl. bias (layer 0) or nullptr
+  const float* xtab;      // [V][4L] input-projection table incl. bias (layer 0) or nullptr; columns in
+                          // TILE order: column 16 * tile + 4 * gate + unit holds gate `gate` of hidden
+                          // unit 4 * tile + unit, so the 16 values a 4-unit tile adds are one 64-byte line
   const int32_t* xidx;    // [N] row of xtab per batch row (layer 0) or nullptr
   int xidx_const;         // used when xidx == nullptr && xtab != nullptr (go embedding row)
   const float* bias;      // [4L] (layer 1) or nullptr

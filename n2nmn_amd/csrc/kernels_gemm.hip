@@ -277,6 +277,20 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
                                : -1;
         break;
       }
+      case PJ_PK_GATES: {     // PK pack whose output columns are in tile order (see LstmJob::xtab):
+        const uint32_t ld = jb.p[0], K = jb.p[1], L = jb.p[2], Np = 4 * L;   // n' = 16 tile + 4 gate + unit
+        const uint32_t kk = i & 3, r = i >> 2;
+        const uint32_t q = r / Np, n = r - q * Np;
+        const uint32_t kq = q * 4 + kk;
+        const uint32_t col = ((n >> 2) & 3) * L + 4 * (n >> 4) + (n & 3);
+        so = kq < K ? (int64_t)kq * ld + col : -1;
+        break;
+      }
+      case PJ_VEC_GATES: {    // a [4L] vector (bias) in the same column order
+        const uint32_t L = jb.p[0];
+        so = (int64_t)(((i >> 2) & 3) * L + 4 * (i >> 4) + (i & 3));
+        break;
+      }
       case PJ_TILES: {
         const uint32_t ld = jb.p[0], row0 = jb.p[1], K = jb.p[2], gate_L = jb.p[3];
         const uint32_t kk = i & 3, c = (i >> 2) & 15, r = i >> 6;

@@ -172,9 +172,9 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_kernel(LstmJobs jobs, 
       const int u = 4 * tile + ul;
       if (jb.xtab) {
         const int xi = jb.xidx ? jb.xidx[orow] : jb.xidx_const;
-        const float* xr = jb.xtab + (size_t)xi * 4 * L + u;
+        const float* xr = jb.xtab + (size_t)xi * 4 * L + 16 * tile + ul;   // tile column order
 #pragma unroll
-        for (int g = 0; g < 4; ++g) add[g] = xr[g * L];
+        for (int g = 0; g < 4; ++g) add[g] = xr[4 * g];
       } else {
 #pragma unroll
         for (int g = 0; g < 4; ++g) add[g] = jb.bias[g * L + u];
@@ -354,9 +354,9 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_wide_kernel(LstmJobs j
     const int u = 4 * tile + ul;
     if (jb.xtab) {
       const int xi = jb.xidx ? jb.xidx[orow] : jb.xidx_const;
-      const float* xr = jb.xtab + (size_t)xi * 4 * L + u;
+      const float* xr = jb.xtab + (size_t)xi * 4 * L + 16 * tile + ul;     // tile column order
 #pragma unroll
-      for (int g = 0; g < 4; ++g) add[g] = xr[g * L];
+      for (int g = 0; g < 4; ++g) add[g] = xr[4 * g];
     } else {
 #pragma unroll
       for (int g = 0; g < 4; ++g) add[g] = jb.bias[g * L + u];
