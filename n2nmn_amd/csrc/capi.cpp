@@ -392,10 +392,9 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmAr
   if (io->encoder_h_transformed)
     N2_HIP(hipMemcpyAsync(io->encoder_h_transformed, c->eht, nl * T, hipMemcpyDeviceToDevice, s));
   if (io->encoder_states) {
-    N2_HIP(hipMemcpyAsync(io->encoder_states, c->fc0, nl, hipMemcpyDeviceToDevice, s));
+    launch_unpack_h(c->fc0, io->encoder_states, N, L, d.N, s);       // c shares h's packed layout
     launch_unpack_h(c->fh0, io->encoder_states + (size_t)N * L, N, L, d.N, s);
-    N2_HIP(hipMemcpyAsync(io->encoder_states + (size_t)2 * N * L, c->fc1, nl,
-                          hipMemcpyDeviceToDevice, s));
+    launch_unpack_h(c->fc1, io->encoder_states + (size_t)2 * N * L, N, L, d.N, s);
     launch_unpack_h(c->fh1, io->encoder_states + (size_t)3 * N * L, N, L, d.N, s);
   }
   return check_launch("encoder_forward");

@@ -528,8 +528,8 @@ int n2nmn_train_forward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* p
   if (rc == N2NMN_OK) rc = encoder_impl(c, &sio, s);
   if (rc == N2NMN_OK) {
     // the decoder starts from the encoder's final state (nmn3_netgen_att.py:177)
-    (void)hipMemcpyAsync(t->rec.dc0s, c->fc0, sizeof(float) * nl, hipMemcpyDeviceToDevice, s);
-    (void)hipMemcpyAsync(t->rec.dc1s, c->fc1, sizeof(float) * nl, hipMemcpyDeviceToDevice, s);
+    launch_unpack_h(c->fc0, t->rec.dc0s, N, L, d.N, s);     // (the cell state is packed like h)
+    launch_unpack_h(c->fc1, t->rec.dc1s, N, L, d.N, s);
     launch_unpack_h(c->fh0, t->rec.dh0s, N, L, d.N, s);
     launch_unpack_h(c->fh1, t->rec.dh1s, N, L, d.N, s);
     rc = decoder_impl(c, &sio, s);

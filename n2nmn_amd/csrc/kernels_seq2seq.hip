@@ -180,10 +180,13 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_kernel(LstmJobs jobs, 
         for (int g = 0; g < 4; ++g) add[g] = jb.bias[g * L + u];
       }
       const size_t idx = (size_t)gr * L + u;
-      c_old = jb.c_in[idx];
+      // the cell state shares the k-interleaved layout of h: a tile's 64 rows x 4 units are one
+      // contiguous KB instead of 64 sixteen-byte pieces of 64 different lines
+      const size_t sidx = jb.hp_R > 0 ? ((size_t)tile * jb.hp_R + gr) * 4 + ul : idx;
+      c_old = jb.c_in[sidx];
       if (jb.seq_len && jb.t >= jb.seq_len[orow]) { // dynamic_rnn past the length (A.2)
         masked = true;
-        h_prev = jb.h_old[jb.hp_R > 0 ? ((size_t)tile * jb.hp_R + gr) * 4 + ul : idx];
+        h_prev = jb.h_old[sidx];
       }
     }
   }
@@ -247,8 +250,9 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_kernel(LstmJobs jobs, 
     float h_new = fast_tanh(c_new) * go;
     float o = h_new;
     if (masked) { c_new = c_old; h_new = h_prev; o = 0.f; }
-    jb.c_out[idx] = c_new;
-    jb.h_new[jb.hp_R > 0 ? ((size_t)tile * jb.hp_R + gr) * 4 + ul : idx] = h_new;
+    const size_t sidx = jb.hp_R > 0 ? ((size_t)tile * jb.hp_R + gr) * 4 + ul : idx;
+    jb.c_out[sidx] = c_new;
+    jb.h_new[sidx] = h_new;
     const size_t oidx = (size_t)orow * L + 4 * tile + ul;
     if (jb.save_gates) {          // training: keep what the cell backward needs (masked rows keep
       jb.save_gates[oidx] = make_float4(gi, gj, gf, go);   // finite values; their dz is zero)
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_kernel(LstmJobs jobs, 
       if (jb.save_hd) jb.save_hd[oidx] = hd;
     }
     if (jb.fin_c && jb.seq_len && jb.t == jb.seq_len[orow] - 1) {   // the row's last valid step
-      jb.fin_c[oidx] = c_new;
+      jb.fin_c[((size_t)tile * jb.hp_R + orow) * 4 + ul] = c_new;
       jb.fin_h[((size_t)tile * jb.hp_R + orow) * 4 + ul] = h_new;
     }
   }
@@ -362,10 +366,11 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_wide_kernel(LstmJobs j
       for (int g = 0; g < 4; ++g) add[g] = jb.bias[g * L + u];
     }
     const size_t idx = (size_t)gr * L + u;
-    c_old = jb.c_in[idx];
+    const size_t sidx = jb.hp_R > 0 ? ((size_t)tile * jb.hp_R + gr) * 4 + ul : idx;
+    c_old = jb.c_in[sidx];
     if (jb.seq_len && jb.t >= jb.seq_len[orow]) {
       masked = true;
-      h_prev = jb.h_old[jb.hp_R > 0 ? ((size_t)tile * jb.hp_R + gr) * 4 + ul : idx];
+      h_prev = jb.h_old[sidx];
     }
   }
 
@@ -412,8 +417,9 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_wide_kernel(LstmJobs j
     float h_new = fast_tanh(c_new) * go;
     float o = h_new;
     if (masked) { c_new = c_old; h_new = h_prev; o = 0.f; }
-    jb.c_out[idx] = c_new;
-    jb.h_new[jb.hp_R > 0 ? ((size_t)tile * jb.hp_R + gr) * 4 + ul : idx] = h_new;
+    const size_t sidx = jb.hp_R > 0 ? ((size_t)tile * jb.hp_R + gr) * 4 + ul : idx;
+    jb.c_out[sidx] = c_new;
+    jb.h_new[sidx] = h_new;
     const size_t oidx = (size_t)orow * L + 4 * tile + ul;
     if (jb.save_gates) {
       jb.save_gates[oidx] = make_float4(gi, gj, gf, go);
@@ -427,7 +433,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_wide_kernel(LstmJobs j
       if (jb.save_hd) jb.save_hd[oidx] = hd;
     }
     if (jb.fin_c && jb.seq_len && jb.t == jb.seq_len[orow] - 1) {
-      jb.fin_c[oidx] = c_new;
+      jb.fin_c[((size_t)tile * jb.hp_R + orow) * 4 + ul] = c_new;
       jb.fin_h[((size_t)tile * jb.hp_R + orow) * 4 + ul] = h_new;
     }
   }
