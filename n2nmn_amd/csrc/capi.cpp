@@ -129,6 +129,7 @@ static size_t carve_weights(n2nmn_ctx* c, char* base) {
   c->enc_xtab = c->big_vocab ? nullptr : k.take<float>(Vt * 4 * L);
   c->dec_xtab = k.take<float>((V + 1) * 4 * L);
   c->enc_b0_t = k.take<float>(4 * L); c->dec_b0_t = k.take<float>(4 * L);
+  c->enc_b1_t = k.take<float>(4 * L); c->dec_b1_t = k.take<float>(4 * L);
   c->enc_W0h_t = k.take<float>(L * 4 * L);
   c->enc_W1_t = k.take<float>(2 * L * 4 * L);
   c->dec_W0h_t = k.take<float>(L * 4 * L);
@@ -349,7 +350,7 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmAr
       }
       j1.A0 = c->ehd[st & 1];
     }
-    j1.xtab = nullptr; j1.xidx = nullptr; j1.bias = c->vars[V_ENC_B1].mirror;
+    j1.xtab = nullptr; j1.xidx = nullptr; j1.bias = c->enc_b1_t;
     j1.c_in = c->ec1; j1.c_out = c->ec1; j1.ntiles = L / 4;
     j1.h_old = c->eh1[(st + 1) & 1]; j1.h_new = c->eh1[st & 1];
     j1.out_seq = st >= 0 ? c->enc_out + (size_t)st * N * L : nullptr;
@@ -452,7 +453,7 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
       j1.active = st >= 0;
       packed_state(c, j1);
       j1.A0 = c->dh0[st & 1]; j1.A1 = st == 0 ? c->fh1 : c->dh1[(st + 1) & 1];
-      j1.K = 2 * L; j1.Wp = c->dec_W1_t; j1.ntiles = L / 4; j1.bias = c->vars[V_DEC_B1].mirror;
+      j1.K = 2 * L; j1.Wp = c->dec_W1_t; j1.ntiles = L / 4; j1.bias = c->dec_b1_t;
       if (io->drop_dec0) {
         const size_t nl = (size_t)N * L;
         if (j0.active) {
@@ -564,7 +565,7 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
       j1.out_seq = c->dh1_rm;          // row-major copy of the top-layer h for dec_attn
       j1.A0 = io->drop_dec0 ? c->dhd[t & 1] : c->dh0[t & 1];
       j1.A1 = t == 0 ? c->fh1 : c->dh1[(t + 1) & 1]; j1.K = 2 * L;
-      j1.Wp = c->dec_W1_t; j1.ntiles = L / 4; j1.bias = c->vars[V_DEC_B1].mirror;
+      j1.Wp = c->dec_W1_t; j1.ntiles = L / 4; j1.bias = c->dec_b1_t;
       j1.c_in = t == 0 ? c->fc1 : c->dc1; j1.c_out = c->dc1;
       j1.h_old = j1.A1; j1.h_new = c->dh1[t & 1];
       {
@@ -1013,6 +1014,8 @@ int n2nmn_commit_weights(n2nmn_ctx* c, n2nmn_stream stream) {
     pb.pk_gates(m(V_DEC_W0), 4 * L, E, L, c->dec_W0x_p, c->KpE);
     pb.vec_gates(m(V_ENC_B0), L, c->enc_b0_t);
     pb.vec_gates(m(V_DEC_B0), L, c->dec_b0_t);
+    pb.vec_gates(m(V_ENC_B1), L, c->enc_b1_t);
+    pb.vec_gates(m(V_DEC_B1), L, c->dec_b1_t);
     // recurrent parts -> gate-interleaved column tiles
     pb.tiles(m(V_ENC_W0), 4 * L, E, L, L / 4, L, c->enc_W0h_t);
     pb.tiles(m(V_ENC_W1), 4 * L, 0, 2 * L, L / 4, L, c->enc_W1_t);
@@ -1490,7 +1493,7 @@ int n2nmn_debug_lstm_bench(n2nmn_ctx* c, int variant, int rows_per_wg, int njobs
       j1 = LstmJob{};
       if (layout) packed_state(c, j1); else rowmajor_a(c, j1);
       j1.active = 1; j1.A0 = c->eh0[(k + 1) & 1]; j1.A1 = c->eh1[(k + 1) & 1]; j1.K = 2 * L;
-      j1.Wp = c->enc_W1_t; j1.ntiles = L / 4; j1.bias = c->vars[V_ENC_B1].mirror;
+      j1.Wp = c->enc_W1_t; j1.ntiles = L / 4; j1.bias = c->enc_b1_t;
       j1.c_in = c->ec1; j1.c_out = c->ec1; j1.h_old = j1.A1; j1.h_new = c->eh1[k & 1];
       j1.out_seq = c->enc_out;
       launch_lstm_step_dbg(jobs, njobs, N, L, rows_per_wg, variant, s);

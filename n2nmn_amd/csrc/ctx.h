@@ -146,6 +146,7 @@ struct n2nmn_ctx {
   // packed weights / derived tables
   float *enc_W0x_p = nullptr, *dec_W0x_p = nullptr, *enc_xtab = nullptr, *dec_xtab = nullptr;
   float *enc_b0_t = nullptr, *dec_b0_t = nullptr;    // layer-0 biases in the x-table's tile column order
+  float *enc_b1_t = nullptr, *dec_b1_t = nullptr;    // layer-1 biases, same order (LstmJob::bias)
   float *enc_W0h_t = nullptr, *enc_W1_t = nullptr, *dec_W0h_t = nullptr, *dec_W1_t = nullptr;
   float *eht_W_p = nullptr, *att_W_t = nullptr, *att_W_p = nullptr, *find_img_p = nullptr, *fsp_img_p = nullptr;
   float* dec_emb_cat = nullptr;

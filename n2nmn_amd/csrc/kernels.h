@@ -87,7 +87,7 @@ struct LstmJob {
                           // unit 4 * tile + unit, so the 16 values a 4-unit tile adds are one 64-byte line
   const int32_t* xidx;    // [N] row of xtab per batch row (layer 0) or nullptr
   int xidx_const;         // used when xidx == nullptr && xtab != nullptr (go embedding row)
-  const float* bias;      // [4L] (layer 1) or nullptr
+  const float* bias;      // [4L] (layer 1; LSTM cell jobs: in the tile column order of xtab) or nullptr
   const float* c_in;      // [N][L] previous cell state
   float* c_out;           // [N][L] new cell state (may alias c_in: each element has one owner)
   const float* h_old;     // [N][L] previous hidden state of THIS layer (copied when masked)

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_kernel(LstmJobs jobs, 
         for (int g = 0; g < 4; ++g) add[g] = xr[4 * g];
       } else {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) add[g] = jb.bias[g * L + u];
+        for (int g = 0; g < 4; ++g) add[g] = jb.bias[16 * tile + 4 * g + ul];   // tile order
       }
       const size_t idx = (size_t)gr * L + u;
       // the cell state shares the k-interleaved layout of h: a tile's 64 rows x 4 units are one
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_wide_kernel(LstmJobs j
       for (int g = 0; g < 4; ++g) add[g] = xr[4 * g];
     } else {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) add[g] = jb.bias[g * L + u];
+      for (int g = 0; g < 4; ++g) add[g] = jb.bias[16 * tile + 4 * g + ul];     // tile order
     }
     const size_t idx = (size_t)gr * L + u;
     const size_t sidx = jb.hp_R > 0 ? ((size_t)tile * jb.hp_R + gr) * 4 + ul : idx;
