@@ -370,6 +370,8 @@ int n2nmn_train_enable(n2nmn_ctx* c) {
   N2_REQUIRE(!c->big_heads || (vqa_variant && c->d.map_dim % 4 == 0), N2NMN_EINVAL,
              "train_enable: map_dim * num_choices beyond the fused answer head is built for models_vqa "
              "(map_dim a multiple of 4)");
+  N2_REQUIRE(!c->qpn_h || (c->d.qpn_hidden % 4 == 0 && c->d.lstm_dim % 2 == 0), N2NMN_EINVAL,
+             "train_enable: the question prior net's weight-gradient GEMMs need qpn_hidden % 4 == 0");
   if (c->train) return N2NMN_OK;
   N2_REQUIRE(c->d.num_vocab_nmn <= 15, N2NMN_EINVAL,
              "train_enable: num_vocab_nmn + <go> must fit 16 x-table rows");
