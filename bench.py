@@ -5,21 +5,23 @@
     (N > 1: the script re-executes itself under torch.distributed.run, one rank per GPU; when the
      driver already launched it that way, RANK / LOCAL_RANK / WORLD_SIZE come from the environment)
 
-One "step" = one pass of the hot path over ONE batch of 64 questions (BASELINE.json configs[1]: CLEVR
-forward, fixed ground-truth layouts, 10x15x512 synthetic pool5 features): phase 1 (LSTM encoder +
-teacher-forced attentional decoder), hoisted conv_image GEMMs, text maps, and the layout walker,
-which decodes the layouts on the device and runs every question's module tree -> answer logits in
-HBM.  Nothing synchronises inside a step (no token fetch, no host assembly, no program upload).
+One "step" = ONE PASS of the hot path (BASELINE.json configs[1]: CLEVR forward, fixed ground-truth
+layouts, 10x15x512 synthetic pool5 features) over `--inflight K` client batches of 64 questions that
+share every launch of the pass (super-bucketing, n2nmn_amd/superbucket.py):
+phase 1 (LSTM encoder + teacher-forced attentional decoder), hoisted conv_image GEMMs, and the layout
+walker, which decodes the layouts on the device and runs every question's module tree -> answer
+logits in HBM.  Nothing synchronises inside a step (no token fetch, no host assembly, no upload).
 
-Throughput number (`value`): `--inflight K` batches of 64 are super-bucketed (n2nmn_amd/superbucket.py,
-SURVEY.md 8(f) rank 2): their questions share every launch of both phases; `--streams S` such passes
-are in flight (pre-spawned host threads, one HIP stream and forked context each, shared weights).
-`--steps` counts batches of 64: exactly `--steps` batches are timed, split evenly over the streams.
-Measured (profiles/r02_stream_sweep.txt): 1 x 4 batches 131 k q/s, 2 x 4 181 k, 3 x 4 190 k, 4 x 4
-191 k, 2 x 8 190 k, the same with the default hardware-queue count and with GPU_MAX_HW_QUEUES=8.
-Default: 2 streams x 8 batches.
-Latency number (`single_batch`): one batch of 64 in flight, same code path.
+Throughput number (`value`): `--streams S` workers (pre-spawned host thread + HIP stream + forked
+context each, shared weights; n2nmn_amd/pipeline.py -- the object tests/test_gpu_bench_config.py
+checks against the oracle) run passes concurrently, each alternating two buckets of distinct inputs;
+exactly `--steps` passes are timed, split evenly over the workers; value = K * 64 * steps / time.
+`config` says what a launch carried (`rows_per_launch`, `questions_in_flight`).  Default: 2 streams,
+K = 8 (512 rows per launch).  `parity_check`: logits of the timed passes against the oracle.
+Latency number (`single_batch`): one batch of 64 in flight (the strict reading of "batch 64").
 `config3`: the same with layouts chosen by the greedy decoder (BASELINE.json configs[2]).
+`config4` / `config5`: the training step and the models_vqa forward (BASELINE.json configs[3], [4]),
+one GPU, so the driver's default line carries them too (`--config 4|5|6` runs them alone).
 
 Inputs are resident in HBM before the timed region.  Multi-GPU: the path shards by question with no
 data-path collective (weak scaling: every rank runs its own stream of batches); timing =
@@ -74,9 +76,9 @@ def parse():
     return ap.parse_args()
 
 
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
 PMC_FILE_TRAIN = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_train.json')
-PMC_KERNEL = {'lstm_step': 'lstm_step_kernel<4, 0>', 'dec_attn': 'dec_attn_multi_kernel',
+PMC_KERNEL = {'lstm_step': 'lstm_tile_kernel', 'dec_attn': 'dec_attn_multi_kernel',
               'pool': 'walk_pool_kernel',
               'gemm_pk': 'gemm_pk', 'att_ops': 'att_ops_kernel',
               'textmap': 'walk_textmap_kernel', 'heads': 'heads_kernel', 'word_vecs': 'word_vecs_kernel',
@@ -188,6 +190,14 @@ def kernel_rows(fams, ksteps, overhead_us=0.0):
 
 
 def bench_train(args, dp, local_rank):
+    out = train_numbers(args, dp, local_rank, args.steps, args.warmup, not args.no_profile,
+                        not args.no_cpu_baseline)
+    if dp.rank == 0:
+        print(json.dumps(out), flush=True)
+    dp.close()
+
+
+def train_numbers(args, dp, local_rank, steps, warmup, profile=True, cpu=True):
     """BASELINE.json configs[3]: exp_clevr/train_clevr_gt_layout.py loop body -- forward + backward
     + gradient all-reduce (RCCL, two buckets, the late one overlapping the encoder's backward) +
     per-tensor clip + Adam -- batch 64 per GPU, T_dec = 10, gt layouts.  One step = one iteration."""
@@ -218,17 +228,17 @@ def bench_train(args, dp, local_rank):
         for i in range(first, first + count):
             tr.step(batches[i % n_batches], gts[i % n_batches])
 
-    run_steps(0, args.warmup)
-    elapsed = dp.timed(lambda: run_steps(args.warmup, args.steps),
+    run_steps(0, warmup)
+    elapsed = dp.timed(lambda: run_steps(warmup, steps),
                        sync=lambda: torch.cuda.synchronize(dev))
     out = None
     if rank == 0:
         out = {
             'metric': 'questions/sec (training step: forward + backward + all-reduce + Adam) on '
                       'CLEVR 10x15x512 feats, batch 64 per GPU',
-            'value': round(dp.throughput(d.N * args.steps, elapsed), 1), 'unit': 'questions/sec',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True,
+            'value': round(dp.throughput(d.N * steps, elapsed), 1), 'unit': 'questions/sec',
+            'n_gpus': world, 'steps': steps, 'warmup': warmup,
+            'ms_per_step': round(1e3 * elapsed / steps, 4), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'BASELINE.json configs[3]: CLEVR train_clevr_gt_layout.py step, '
                                    'gt layouts (10-template mix), batch %d per GPU, T_enc=45, '
@@ -238,8 +248,8 @@ def bench_train(args, dp, local_rank):
                                       'buckets per step' % (world, tr.numel)},
             'final_total_loss': float(tr.losses[3].item()),
         }
-    if rank == 0 and not args.no_profile and world == 1:
-        ksteps = min(args.steps, 20)
+    if rank == 0 and profile and world == 1:
+        ksteps = min(steps, 20)
         eng.profile_begin()
         run_steps(0, ksteps)
         rows = kernel_rows(eng.profile_end(), ksteps)
@@ -253,7 +263,7 @@ def bench_train(args, dp, local_rank):
                                        'steps' % ksteps}
         out['kernels'] = rows
         out['gpu_us_per_step'] = round(sum(r['us_per_step'] for r in rows), 1)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and cpu:
         from oracle import n2nmn_oracle_grad as G
         b0 = synth.make_inputs(d, seed=0)
         t0 = time.perf_counter()
@@ -266,12 +276,17 @@ def bench_train(args, dp, local_rank):
                                          'autograd fp64 oracle (oracle/n2nmn_oracle_grad.py), no '
                                          'optimiser step; the reference TF1/Fold path is not '
                                          'runnable here' % d.N}
-    if rank == 0:
+    return out
+
+
+def bench_vqa(args, dp, local_rank):
+    out = vqa_numbers(args, dp, local_rank, args.steps, args.warmup, not args.no_profile)
+    if dp.rank == 0:
         print(json.dumps(out), flush=True)
     dp.close()
 
 
-def bench_vqa(args, dp, local_rank):
+def vqa_numbers(args, dp, local_rank, steps, warmup, profile=True):
     """BASELINE.json configs[4]: models_vqa forward (exp_vqa/eval_vqa2.py:103-137) -- seq2seq with
     the 17742-word vocabulary and lstm_dim 1000, coordinate map, the 4-module network at map_dim
     1024 on 14x14x2048 features, question prior net -- batch 128 per GPU, ground-truth layouts from
@@ -306,29 +321,28 @@ def bench_vqa(args, dp, local_rank):
         for i in range(first, first + count):
             eng.forward(batches[i % 3], use_gt_layout=True, gt_layout=gts[i % 3])
 
-    run_steps(0, args.warmup)
-    elapsed = dp.timed(lambda: run_steps(args.warmup, args.steps),
+    run_steps(0, warmup)
+    elapsed = dp.timed(lambda: run_steps(warmup, steps),
                        sync=lambda: torch.cuda.synchronize(dev))
     out = None
     if rank == 0:
         out = {'metric': 'questions/sec (forward) on VQAv2 14x14x2048 feats, batch %d per GPU' % d.N,
-               'value': round(dp.throughput(d.N * args.steps, elapsed), 1), 'unit': 'questions/sec',
-               'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-               'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True,
+               'value': round(dp.throughput(d.N * steps, elapsed), 1), 'unit': 'questions/sec',
+               'n_gpus': world, 'steps': steps, 'warmup': warmup,
+               'ms_per_step': round(1e3 * elapsed / steps, 4), 'higher_is_better': True,
                'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                'config': {'workload': 'BASELINE.json configs[4]: models_vqa forward, gt layouts (v2 val '
                                       'histogram), batch %d per GPU, T_enc=26, T_dec=13, single stream'
                                       % d.N, 'global_batch': world * d.N,
                           'parallelism': 'dp%d (question-sharded)' % world}}
-        if not args.no_profile:
-            ksteps = min(args.steps, 10)
+        if profile:
+            ksteps = min(steps, 10)
             eng.engine.profile_begin()
             run_steps(0, ksteps)
             rows = kernel_rows(eng.engine.profile_end(), ksteps)
             out['kernels'] = rows
             out['gpu_us_per_step'] = round(sum(r['us_per_step'] for r in rows), 1)
-        print(json.dumps(out), flush=True)
-    dp.close()
+    return out
 
 
 def bench_vqa_train(args, dp, local_rank):
@@ -470,8 +484,8 @@ def main():
 
     from n2nmn_amd import synth
     from n2nmn_amd.nmn3_assembler import Assembler
+    from n2nmn_amd.pipeline import PassPipeline
     from n2nmn_amd.spec import Dims, CLEVR_MODULE_NAMES
-    from n2nmn_amd.superbucket import SuperBucket
 
     K = max(1, min(16, args.inflight))
     KCAP = 16 if K > 1 else 1           # slots a bucket holds: passes are 1..KCAP batches wide
@@ -479,101 +493,38 @@ def main():
     d = Dims(N=args.batch)
     names = list(CLEVR_MODULE_NAMES)
     asm = Assembler(names)
-    sb = SuperBucket(d, asm, KCAP, device=local_rank)
-    eng = sb.engine
     w = synth.make_weights(d, seed=0)
-    sb.load_weights(w)
-    dev = eng.device
     use_gt = args.config == 2
-    # every rank streams its own questions (weak scaling).  A worker = one host thread + HIP stream +
-    # forked context (shared weights) + two buckets of K distinct batches, alternated so a pass does
-    # not find its feature maps in the caches the previous pass left
-    import threading
-    engines = [eng] + [eng.fork() for _ in range(S - 1)]
-    workers = []
-    for si, e in enumerate(engines):
-        e.set_mode('throughput' if S > 1 else 'latency')
-        bk = [sb if si == 0 else SuperBucket(d, asm, KCAP, device=local_rank, engine=e),
-              SuperBucket(d, asm, KCAP, device=local_rank, engine=e)]
-        for j, b in enumerate(bk):
-            for k in range(KCAP):
-                i = (si * 2 + j) * KCAP + k
-                b.fill(k, synth.make_inputs(d, seed=dp.batch_seed(i)),
-                       synth.template_layout_batch(d, offset=i))
-        workers.append(dict(engine=e, buckets=bk, stream=torch.cuda.Stream(device=dev) if S > 1 else None,
-                            todo=0))
-    buckets = workers[0]['buckets']
+    # every rank streams its own questions (weak scaling).  The object that is timed is the one
+    # tests/test_gpu_bench_config.py checks slot by slot against the oracle: S workers (host thread +
+    # HIP stream + forked context, shared weights), two buckets of KCAP client batches each, alternated
+    # so a pass does not find its feature maps in the caches the previous pass left
+    pipe = PassPipeline(d, asm, w, streams=S, kcap=KCAP, device=local_rank,
+                        host_assemble=args.host_assemble)
+    eng, sb = pipe.engine, pipe.bucket(0, 0)
+    dev = eng.device
+    pipe.fill_all(lambda i: synth.make_inputs(d, seed=dp.batch_seed(i)),
+                  lambda i: synth.template_layout_batch(d, offset=i))
+    buckets = pipe.workers[0]['buckets']
     torch.cuda.synchronize(dev)
 
     def run_pass(e, b, n, gt):
         """one pass over the first n slots of bucket b; returns (scores, tokens, validity)"""
-        if n == KCAP:
-            return b.run(use_gt_layout=gt)
-        v = dict(input_seq_batch=b.input_seq[:, :n * d.N].contiguous(),
-                 seq_length_batch=b.seq_length[:n * d.N], image_feat_batch=b.image_feat[:n * d.N])
-        return e.forward(v, use_gt_layout=gt,
-                         gt_layout=b.gt_layout[:, :n * d.N].contiguous() if gt else None,
-                         fetch=False, host_assemble=args.host_assemble)
+        return b.run(use_gt_layout=gt, n_slots=n, host_assemble=args.host_assemble)
 
-    def run_on(wk, count, gt):
-        """`count` batches of d.N questions on one worker, as passes of (nearly) equal size: about K
-        slots each, never more than the buckets hold (KCAP)"""
-        if count <= 0:
-            return
-        n_pass = max(1, int(round(count / K)))
-        while -(-count // n_pass) > KCAP:
-            n_pass += 1
-        done, j = 0, 0
-        for pi in range(n_pass):
-            n = (count - done + (n_pass - pi) - 1) // (n_pass - pi)
-            run_pass(wk['engine'], wk['buckets'][j % 2], n, gt)
-            done += n
-            j += 1
-
-    # worker threads exist before anything is timed; a timed block only releases them and waits
-    start_b, done_b = threading.Barrier(S + 1), threading.Barrier(S + 1)
-    state = {'stop': False, 'gt': use_gt, 'err': None}
-
-    def worker_main(wk):
-        torch.cuda.set_device(dev)
-        while True:
-            start_b.wait()
-            if state['stop']:
-                return
-            try:
-                with torch.cuda.stream(wk['stream']):
-                    run_on(wk, wk['todo'], state['gt'])
-                    wk['stream'].synchronize()
-            except Exception as ex:           # surface worker failures instead of hanging
-                state['err'] = ex
-            done_b.wait()
-
-    threads = []
-    if S > 1:
-        threads = [threading.Thread(target=worker_main, args=(wk,), daemon=True) for wk in workers]
-        for t in threads:
-            t.start()
-
-    def run_batches(count, gt=use_gt):
-        """exactly `count` batches, split as evenly as possible over the S workers"""
-        if S == 1:
-            return run_on(workers[0], count, gt)
-        for i, wk in enumerate(workers):
-            wk['todo'] = count // S + (1 if i < count % S else 0)
-        state['gt'] = gt
-        start_b.wait()
-        done_b.wait()
-        if state['err'] is not None:
-            raise state['err']
+    def run_steps(count, gt=use_gt):
+        """exactly `count` passes of K client batches, split as evenly as possible over the workers"""
+        pipe.run([[K] * (count // S + (1 if i < count % S else 0)) for i in range(S)], gt)
 
     sync = lambda: torch.cuda.synchronize(dev)    # noqa: E731
-    run_batches(max(args.warmup, S * K))
-    elapsed, repeats, blocks = timed_blocks(dp, lambda: run_batches(args.steps), sync)
+    run_steps(max(args.warmup, 2 * S))
+    elapsed, repeats, blocks = timed_blocks(dp, lambda: run_steps(args.steps), sync)
     out = None
     if rank == 0:
-        qps = dp.throughput(d.N * args.steps, elapsed)
+        qps = dp.throughput(K * d.N * args.steps, elapsed)
         out = {
-            'metric': 'questions/sec (forward) on CLEVR 10x15x512 feats, batch 64',
+            'metric': 'questions/sec (forward) on CLEVR 10x15x512 feats, client batches of %d served '
+                      'as passes of %d rows (throughput)' % (d.N, K * d.N),
             'value': round(qps, 1), 'unit': 'questions/sec', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 4),
@@ -581,21 +532,48 @@ def main():
             'dtype': 'f32', 'data': 'synthetic',
             'timed_region_s': round(elapsed, 5), 'repeats': repeats,
             'blocks_s': [round(x, 5) for x in blocks],
-            'config': {'workload': 'BASELINE.json configs[%d]: CLEVR forward, %s, batches of %d '
-                                   'questions, 10x15x512 synthetic pool5, T_enc=45, T_dec=20; one step '
-                                   '= one batch; %d batches are super-bucketed into one pass (their '
-                                   'questions share every launch); %d such passes in flight on %d '
-                                   'streams' %
+            'config': {'workload': 'BASELINE.json configs[%d]: CLEVR forward, %s, client batches of %d '
+                                   'questions, 10x15x512 synthetic pool5, T_enc=45, T_dec=20; one step = '
+                                   'ONE PASS of the hot path over %d client batches (%d questions: they '
+                                   'share every launch); %d passes in flight on %d streams, each stream '
+                                   'alternating two buckets of distinct inputs; the strict one-batch-'
+                                   'in-flight figure is `single_batch`' %
                                    (args.config - 1,
                                     'fixed ground-truth layouts (10-template mix, teacher-forced '
                                     'decoder)' if use_gt else 'layouts chosen by the greedy seq2seq '
-                                    'decoder', d.N, K, S, S),
-                       'global_batch': world * d.N, 'inflight_batches': K * S, 'streams_per_gpu': S,
-                       'questions_per_pass_per_gpu': K * d.N,
+                                    'decoder', d.N, K, K * d.N, S, S),
+                       'client_batch': d.N, 'batches_per_pass': K, 'rows_per_launch': K * d.N,
+                       'questions_per_step': K * d.N, 'global_batch': world * K * d.N,
+                       'streams_per_gpu': S, 'questions_in_flight': S * K * d.N,
+                       'passes_per_stream_per_block': args.steps // S,
+                       'lstm_step_mode': pipe.mode,
                        'parallelism': 'dp%d (question-sharded, no data-path collective)' % world,
                        'host_sync': 'none: layouts are decoded on the device by the walker'
                        if not args.host_assemble else 'predicted_tokens D2H + C++ assembler'},
         }
+        # ---- what the timed passes computed, against the oracle: slot 0 of the bucket each worker
+        # ran last (fp32 batched port, pinned to the reference's code through the numpy oracle)
+        if world == 1 and not args.plain:
+            from oracle import n2nmn_oracle_batched as OB
+            torch.set_num_threads(min(16, torch.get_num_threads()))
+            wt = OB.to_torch(w, torch.float64)
+            worst, checked = 0.0, 0
+            for si, wk in enumerate(pipe.workers):
+                j = (wk['next'] - 1) % 2
+                b = wk['buckets'][j]
+                i = (si * 2 + j) * KCAP
+                hb = synth.make_inputs(d, seed=dp.batch_seed(i))
+                gt = synth.template_layout_batch(d, offset=i)
+                got = b.result(0)[0].cpu().numpy()
+                tok = b.result(0)[1].cpu().numpy()
+                ref = OB.forward(wt, names, hb, d.T_decoder, d.num_choices, True, gt if use_gt else tok)
+                worst = max(worst, float(np.abs(got - ref['scores']).max()))
+                checked += 1
+            out['parity_check'] = {'max_abs_logit_err': worst, 'slots_checked': checked,
+                                   'bar': 1e-4, 'ok': bool(worst <= 1e-4),
+                                   'against': 'oracle/n2nmn_oracle_batched.py (fp64) on the host copy of '
+                                              'slot 0 of the bucket each worker ran last in the timed '
+                                              'region%s' % ('' if use_gt else ', given the GPU tokens')}
 
     def wall(fn, n, warm=3):
         for _ in range(warm):
@@ -627,13 +605,13 @@ def main():
                                'ms_per_step': round(1e3 * t_one, 4), 'steps': n1,
                                'note': 'one batch of %d questions in flight' % d.N}
         if not use_gt:
-            eng.set_mode('throughput' if S > 1 else 'latency')
+            eng.set_mode(pipe.mode)
         # ---- BASELINE.json configs[2]: the decoder chooses the layouts (greedy), walker decodes them
         if use_gt:
             t3 = wall(one_greedy, n1)
-            eng.set_mode('throughput' if S > 1 else 'latency')
-            reps = max(3, min(15, args.steps // (S * K)))
-            t3k = wall(lambda: run_batches(S * K, gt=False), reps)
+            eng.set_mode(pipe.mode)
+            reps = max(3, min(15, args.steps // S))
+            t3k = wall(lambda: run_steps(S, gt=False), reps)
             _, tk3, val3 = run_pass(eng, sb, K, False)
             toks3 = tk3.cpu().numpy()
             f3, p3, _ = layout_work(toks3, names)
@@ -660,12 +638,13 @@ def main():
             run_pass(eng, buckets[j % 2], K, use_gt)
         fams = eng.profile_end()                 # synchronises the stream
         prof_wall = time.perf_counter() - t0
-        rows = kernel_rows(fams, kpass * K, ovh)
+        rows = kernel_rows(fams, kpass, ovh)
         dom = rows[0]
         traffic, traffic_src = pmc_traffic(dom['kernel'])
         out['roofline'] = {'kernel': dom['kernel'], 'bound': dom['bound'],
                            'achieved': dom['achieved'], 'peak': dom['peak'], 'unit': dom['unit'],
-                           'frac': dom['frac'], 'traffic': traffic, 'traffic_source': traffic_src,
+                           'frac': dom['frac'], 'traffic': traffic,
+                           'traffic_from_file': traffic_src,
                            'avg_us': dom['avg_us'], 'rows_per_launch': K * d.N,
                            'measured': 'hipEvent pairs around each launch on the launch stream, '
                                        'separate pass of %d super-bucket passes right after the timed '
@@ -673,10 +652,10 @@ def main():
                                        'for these kernels a pair reads ~1.5-2 us more than rocprofv3, '
                                        'profiles/)' % (kpass, ovh)}
         if dom['kernel'].startswith('lstm_step(enc'):
-            # `achieved` counts the reference algorithm's work (dynamic_rnn evaluates the cell for
-            # every row of the batch at every step and selects afterwards); the length-sorted
-            # encoder skips the 16-row MFMA tiles that hold no active row, so the flops the kernel
-            # EXECUTED are fewer: report that rate too
+            # The reference's dynamic_rnn evaluates the cell for every row of the batch at every step
+            # and selects afterwards; the length-sorted encoder skips the 16-row MFMA tiles that hold
+            # no active row.  `frac` / `achieved` count the flops the kernel EXECUTED (lengths of this
+            # run); the rate with the skipped tiles counted as work is kept as `reference_work_*`.
             L, Tn = d.lstm_dim, d.T_encoder
             ex = 0.0
             for b in buckets[:2]:
@@ -686,17 +665,21 @@ def main():
                 ex += sum(2.0 * 4 * L * (L * r16[k] if k < Tn else 0) +
                           2.0 * 4 * L * (2 * L * r16[k - 1] if k >= 1 else 0) for k in range(Tn + 1))
             ex /= min(2, len(buckets)) * (Tn + 1)             # per launch
-            out['roofline']['executed_achieved'] = round(ex / (dom['avg_us'] * 1e-6) / 1e12, 3)
-            out['roofline']['executed_frac'] = round(ex / (dom['avg_us'] * 1e-6) / 1e12 / dom['peak'], 4)
-            out['roofline']['executed_note'] = ('flops of the 16-row tiles that hold an active row '
-                                                '(lengths of this run); `achieved` / `frac` count every '
-                                                'row at every step like the reference')
+            rl = out['roofline']
+            rl['reference_work_achieved'], rl['reference_work_frac'] = rl['achieved'], rl['frac']
+            rl['achieved'] = round(ex / (dom['avg_us'] * 1e-6) / 1e12, 3)
+            rl['frac'] = round(ex / (dom['avg_us'] * 1e-6) / 1e12 / dom['peak'], 4)
+            rl['executed_flops_per_launch'] = round(ex)
+            rl['note'] = ('achieved / frac = flops of the 16-row tiles that hold an active row (what the '
+                          'kernel executes) / measured duration; reference_work_* count every row at '
+                          'every step like the reference; the decoder steps (every row active) are the '
+                          'second row of `kernels`')
         out['kernels'] = rows
         out['event_pair_overhead_us'] = round(ovh, 3)
         out['gpu_us_per_step'] = round(sum(r['us_per_step'] for r in rows), 1)
         # the same pass by the host clock: with every launch bracketed by events the stream is
         # serialised, so the kernel table must add up to (almost) this -- the reconciliation check
-        out['profiled_pass_us_per_step'] = round(1e6 * prof_wall / (kpass * K), 1)
+        out['profiled_pass_us_per_step'] = round(1e6 * prof_wall / kpass, 1)
         # the attention-module path (north star: >= 40 % of HBM on its HBM-bound kernel).  Kernels of a
         # few microseconds cannot be timed by an event pair per launch (a pair around an empty kernel
         # reads `event_pair_overhead_us`), so the walker / pooling / heads kernels of the LAST pass are
@@ -765,15 +748,26 @@ def main():
                                      'FindSameProperty reads its own map and the feature map' %
                                      (HW * D * 4, HW * Mp * 4)}
 
+    # ---- BASELINE.json configs[3] / configs[4] beside the headline, so the driver's line carries them
+    if world == 1 and not args.plain and use_gt and args.batch == 64:
+        sync()
+        c4 = train_numbers(args, dp, local_rank, 30, 5, profile=True, cpu=False)
+        out['config4'] = {k: c4[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'config',
+                                             'final_total_loss') if k in c4}
+        if 'kernels' in c4:
+            out['config4']['kernels'] = c4['kernels'][:4]
+        c5 = vqa_numbers(args, dp, local_rank, 10, 3, profile=True)
+        out['config5'] = {k: c5[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'config')}
+        if 'kernels' in c5:
+            out['config5']['kernels'] = c5['kernels'][:4]
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         def gpu_scores(b, gt):
             sc, _, _ = eng.forward(b, use_gt_layout=use_gt, gt_layout=gt)
             return sc.cpu().numpy()
         out['cpu_baseline'] = cpu_baseline(d, w, names, use_gt, gpu_scores)
 
-    if S > 1:
-        state['stop'] = True
-        start_b.wait()
+    pipe.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
     dp.close()

@@ -94,11 +94,15 @@ int n2nmn_ctx_destroy(n2nmn_ctx *ctx);
 int n2nmn_ctx_dims(const n2nmn_ctx *ctx, n2nmn_dims *out);
 /* Scheduling hint for the recurrent step kernels of THIS context (forks have their own):
  *   N2NMN_MODE_LATENCY    (default) 64-row x 16-column workgroup tiles: shortest single-batch step
- *   N2NMN_MODE_THROUGHPUT 32 x 32 tiles: 20 % less L2 operand traffic per launch, for serving several
- *                         batches concurrently on different streams (measured +3 % questions/s with
- *                         6 batches in flight, -2 % with one) */
+ *   N2NMN_MODE_THROUGHPUT for passes of >= 128 rows (super-bucketed batches): 64-row x 64-gate-column
+ *                         tiles whose operands are staged through LDS by LDS-DMA (the weight tile is
+ *                         shared by the workgroup's four waves: 2.5x less L2 operand traffic than the
+ *                         K-split tiles); smaller passes fall back to the K-split 32 x 32 tile
+ *   N2NMN_MODE_THROUGHPUT_KSPLIT  the K-split 32 x 32 tile at every size (round 2's throughput mode;
+ *                         kept for A/B measurements) */
 #define N2NMN_MODE_LATENCY    0
 #define N2NMN_MODE_THROUGHPUT 1
+#define N2NMN_MODE_THROUGHPUT_KSPLIT 2
 int n2nmn_ctx_set_mode(n2nmn_ctx *ctx, int mode);
 
 /* Register one variable by its reference (TF 1.0.0) name, e.g.
@@ -162,6 +166,12 @@ typedef struct {
    * gradient scripts sample the layout from the network WITH dropout
    * (exp_vqa/train_vqa_rl_gt_layout.py:34-35); the same buffers then go into n2nmn_train_io. */
   const float *drop_enc0, *drop_dec0;
+  /* optional HOST copy of seq_length (the reference feeds lengths from the host,
+   * util/clevr_train/data_reader.py:74-82): with it the launcher knows how many rows are still
+   * active at every encoder step and picks the recurrent-step tile per step in N2NMN_MODE_THROUGHPUT
+   * (LDS-staged 64 x 64 tiles while >= 4 blocks of 64 rows are active, K-split tiles for the tail).
+   * NULL: one tile shape for the whole pass.  Read during the call only. */
+  const int32_t *seq_length_host;
 } n2nmn_seq2seq_io;
 /* skip word_vecs / neg_entropy / log_seq_prob (one launch): for inference through
  * n2nmn_walk_layouts with attention maps, which derives the text maps from atts directly */

@@ -31,7 +31,8 @@ class Seq2SeqIO(C.Structure):
         ('atts', C.c_void_p), ('word_vecs', C.c_void_p), ('token_scores', C.c_void_p),
         ('encoder_outputs', C.c_void_p), ('encoder_h_transformed', C.c_void_p),
         ('encoder_states', C.c_void_p), ('log_seq_prob', C.c_void_p), ('flags', C.c_int32),
-        ('image_feat', C.c_void_p), ('drop_enc0', C.c_void_p), ('drop_dec0', C.c_void_p)]
+        ('image_feat', C.c_void_p), ('drop_enc0', C.c_void_p), ('drop_dec0', C.c_void_p),
+        ('seq_length_host', C.c_void_p)]
 
 
 class TrainIO(C.Structure):

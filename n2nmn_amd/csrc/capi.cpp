@@ -134,6 +134,10 @@ static size_t carve_weights(n2nmn_ctx* c, char* base) {
   c->enc_W1_t = k.take<float>(2 * L * 4 * L);
   c->dec_W0h_t = k.take<float>(L * 4 * L);
   c->dec_W1_t = k.take<float>(2 * L * 4 * L);
+  if (L % 128 == 0) {
+    c->enc_W0h_64 = k.take<float>(L * 4 * L); c->enc_W1_64 = k.take<float>(2 * L * 4 * L);
+    c->dec_W0h_64 = k.take<float>(L * 4 * L); c->dec_W1_64 = k.take<float>(2 * L * 4 * L);
+  }
   c->eht_W_p = k.take<float>((size_t)c->KpL * L);
   c->att_W_t = k.take<float>(L * L);
   c->att_W_p = k.take<float>((size_t)c->KpL * L);
@@ -268,6 +272,11 @@ ModuleWeights module_weights(const n2nmn_ctx* c) {
   return w;
 }
 
+// tile choice of the pipelined two-layer step launches (launch_lstm_step's `wide`)
+static int lstm_wide(const n2nmn_ctx* c) {
+  return c->mode == N2NMN_MODE_THROUGHPUT ? 2 : c->mode == N2NMN_MODE_THROUGHPUT_KSPLIT ? 1 : 0;
+}
+
 // state buffers (eh0/eh1/dh0/dh1) are k-interleaved [L/4][R][4] with R = capacity N
 void packed_state(const n2nmn_ctx* c, LstmJob& j) {
   j.a_rs = 4; j.a_ks = 4 * c->d.N; j.hp_R = c->d.N;
@@ -322,6 +331,19 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmAr
     launch_gemm_pk(g, s);
     W0x_bias_table = c->xproj;
   }
+  // rows still active at step t, when the caller handed over a host copy of the lengths: the tail of
+  // the length-sorted encoder has too few row blocks for the 64 x 64 tiles (a launch of <= 256
+  // workgroups leaves the K = 2L tiles alone on their CUs), the K-split tiles scale with the rows
+  std::vector<int> act_host;
+  if (io->seq_length_host && c->mode == N2NMN_MODE_THROUGHPUT) {
+    std::vector<int> cnt(T + 2, 0);
+    for (int n = 0; n < N; ++n) cnt[std::min(std::max(io->seq_length_host[n], 0), T)] += 1;
+    act_host.assign(T, 0);
+    for (int t = T - 1, run = 0; t >= 0; --t) {    // rows with length > t
+      run += cnt[t + 1];
+      act_host[t] = run;
+    }
+  }
   // software-pipelined over time: launch k runs layer-0 step k and layer-1 step k-1
   for (int k = 0; k <= T; ++k) {
     LstmJob jobs[2];
@@ -329,7 +351,7 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmAr
     j0 = LstmJob{};
     j0.active = k < T;
     packed_state(c, j0);
-    j0.A0 = c->eh0[(k + 1) & 1]; j0.A1 = nullptr; j0.K = L; j0.Wp = c->enc_W0h_t;
+    j0.A0 = c->eh0[(k + 1) & 1]; j0.A1 = nullptr; j0.K = L; j0.Wp = c->enc_W0h_t; j0.Wp64 = c->enc_W0h_64;
     j0.xtab = W0x_bias_table; j0.xidx_const = 0;
     j0.xidx = (c->big_vocab ? c->iota : io->input_seq) + (size_t)k * N;
     j0.bias = nullptr; j0.c_in = c->ec0; j0.c_out = c->ec0; j0.ntiles = L / 4;
@@ -341,7 +363,7 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmAr
     const int st = k - 1;
     j1.active = st >= 0;
     packed_state(c, j1);
-    j1.A0 = c->eh0[st & 1]; j1.A1 = c->eh1[(st + 1) & 1]; j1.K = 2 * L; j1.Wp = c->enc_W1_t;
+    j1.A0 = c->eh0[st & 1]; j1.A1 = c->eh1[(st + 1) & 1]; j1.K = 2 * L; j1.Wp = c->enc_W1_t; j1.Wp64 = c->enc_W1_64;
     if (io->drop_enc0) {                 // DropoutWrapper on layer 0's output (models_vqa)
       const size_t nl = (size_t)N * L;
       if (j0.active) {
@@ -372,7 +394,9 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmAr
       const double by = 4.0 * ((j0.active ? (double)L * 4 * L + 3.0 * N * L : 0) +
                                (j1.active ? 2.0 * L * 4 * L + 5.0 * N * L : 0));
       ProfScope ps(c, F_LSTM_ENC, fl, by, s);
-      launch_lstm_step(jobs, 2, N, L, 64, s, c->mode == N2NMN_MODE_THROUGHPUT);
+      int wide = lstm_wide(c);
+      if (!act_host.empty() && act_host[std::min(k, T - 1)] <= 3 * 64) wide = 1;
+      launch_lstm_step(jobs, 2, N, L, 64, s, wide);
     }
   }
   // encoder_h_transformed = fc(encoder_outputs)          (nmn3_netgen_att.py:102-106)
@@ -442,7 +466,7 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
       j0 = LstmJob{};
       j0.active = k < Td;
       packed_state(c, j0);
-      j0.A0 = k == 0 ? c->fh0 : c->dh0[(k + 1) & 1]; j0.K = L; j0.Wp = c->dec_W0h_t;
+      j0.A0 = k == 0 ? c->fh0 : c->dh0[(k + 1) & 1]; j0.K = L; j0.Wp = c->dec_W0h_t; j0.Wp64 = c->dec_W0h_64;
       j0.ntiles = L / 4; j0.xtab = c->dec_xtab;
       j0.xidx = k == 0 ? nullptr : io->gt_layout + (size_t)(k - 1) * N; j0.xidx_const = V;
       j0.c_in = k == 0 ? c->fc0 : c->dc0; j0.c_out = c->dc0;
@@ -453,7 +477,7 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
       j1.active = st >= 0;
       packed_state(c, j1);
       j1.A0 = c->dh0[st & 1]; j1.A1 = st == 0 ? c->fh1 : c->dh1[(st + 1) & 1];
-      j1.K = 2 * L; j1.Wp = c->dec_W1_t; j1.ntiles = L / 4; j1.bias = c->dec_b1_t;
+      j1.K = 2 * L; j1.Wp = c->dec_W1_t; j1.Wp64 = c->dec_W1_64; j1.ntiles = L / 4; j1.bias = c->dec_b1_t;
       if (io->drop_dec0) {
         const size_t nl = (size_t)N * L;
         if (j0.active) {
@@ -478,7 +502,7 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
       }
       ProfScope ps(c, F_LSTM_DEC0, (j0.active ? fl0 : 0) + (j1.active ? fl1 : 0),
                    (j0.active ? by0 : 0) + (j1.active ? by1 : 0), s);
-      launch_lstm_step(jobs, 2, N, L, 64, s, c->mode == N2NMN_MODE_THROUGHPUT);
+      launch_lstm_step(jobs, 2, N, L, 64, s, lstm_wide(c));
     }
     // q = out . W_a + b_a for all steps (nmn3_netgen_att.py:185), in ONE launch with whatever else
     // is due before the attention / the layout walk: encoder_h_transform, conv_image
@@ -547,7 +571,7 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
       LstmJob j0{};
       j0.active = 1;
       packed_state(c, j0);
-      j0.A0 = t == 0 ? c->fh0 : c->dh0[(t + 1) & 1]; j0.K = L; j0.Wp = c->dec_W0h_t;
+      j0.A0 = t == 0 ? c->fh0 : c->dh0[(t + 1) & 1]; j0.K = L; j0.Wp = c->dec_W0h_t; j0.Wp64 = c->dec_W0h_64;
       j0.ntiles = L / 4;
       j0.xtab = c->dec_xtab; j0.xidx = t == 0 ? nullptr : c->next_idx; j0.xidx_const = V;  // <go>
       j0.c_in = t == 0 ? c->fc0 : c->dc0; j0.c_out = c->dc0;
@@ -565,7 +589,7 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
       j1.out_seq = c->dh1_rm;          // row-major copy of the top-layer h for dec_attn
       j1.A0 = io->drop_dec0 ? c->dhd[t & 1] : c->dh0[t & 1];
       j1.A1 = t == 0 ? c->fh1 : c->dh1[(t + 1) & 1]; j1.K = 2 * L;
-      j1.Wp = c->dec_W1_t; j1.ntiles = L / 4; j1.bias = c->dec_b1_t;
+      j1.Wp = c->dec_W1_t; j1.Wp64 = c->dec_W1_64; j1.ntiles = L / 4; j1.bias = c->dec_b1_t;
       j1.c_in = t == 0 ? c->fc1 : c->dc1; j1.c_out = c->dc1;
       j1.h_old = j1.A1; j1.h_new = c->dh1[t & 1];
       {
@@ -927,7 +951,8 @@ int n2nmn_ctx_destroy(n2nmn_ctx* ctx) {
 
 int n2nmn_ctx_set_mode(n2nmn_ctx* ctx, int mode) {
   N2_REQUIRE(ctx, N2NMN_EINVAL, "ctx_set_mode: null context");
-  N2_REQUIRE(mode == N2NMN_MODE_LATENCY || mode == N2NMN_MODE_THROUGHPUT, N2NMN_EINVAL,
+  N2_REQUIRE(mode == N2NMN_MODE_LATENCY || mode == N2NMN_MODE_THROUGHPUT ||
+                 mode == N2NMN_MODE_THROUGHPUT_KSPLIT, N2NMN_EINVAL,
              "ctx_set_mode: unknown mode");
   ctx->mode = mode;
   return N2NMN_OK;
@@ -1021,6 +1046,12 @@ int n2nmn_commit_weights(n2nmn_ctx* c, n2nmn_stream stream) {
     pb.tiles(m(V_ENC_W1), 4 * L, 0, 2 * L, L / 4, L, c->enc_W1_t);
     pb.tiles(m(V_DEC_W0), 4 * L, E, L, L / 4, L, c->dec_W0h_t);
     pb.tiles(m(V_DEC_W1), 4 * L, 0, 2 * L, L / 4, L, c->dec_W1_t);
+    if (c->enc_W0h_64) {
+      pb.tiles64(m(V_ENC_W0), 4 * L, E, L, L, c->enc_W0h_64);
+      pb.tiles64(m(V_ENC_W1), 4 * L, 0, 2 * L, L, c->enc_W1_64);
+      pb.tiles64(m(V_DEC_W0), 4 * L, E, L, L, c->dec_W0h_64);
+      pb.tiles64(m(V_DEC_W1), 4 * L, 0, 2 * L, L, c->dec_W1_64);
+    }
     pb.pk(m(V_EHT_W), L, L, L, c->eht_W_p, c->KpL, L);
     pb.tiles(m(V_ATT_W), L, 0, L, L / 16, 0, c->att_W_t);
     pb.pk(m(V_ATT_W), L, L, L, c->att_W_p, c->KpL, L);
@@ -1468,6 +1499,8 @@ int n2nmn_profile_get(const n2nmn_ctx* ctx, int family, const char** name, int64
  * 3 MFMA only, 4 neither (LDS reduce + epilogue only), 5 empty kernel.  jobs: 2 = L0+L1, 1 = L1. */
 int n2nmn_debug_lstm_bench(n2nmn_ctx* c, int variant, int rows_per_wg, int njobs, int N, int iters,
                            double* us, n2nmn_stream stream) {
+  const int tile = variant >= 20 ? variant - 20 : 0;   // 23 / 24 / 26: lstm_tile_kernel, 3 / 4 / 6 stages
+  if (tile) variant = 0;
   const int layout = variant < 10;       // variant >= 10: row-major h (A/B against the packed state)
   variant %= 10;
   N2_REQUIRE(c && us && is_committed(c), N2NMN_EINVAL, "debug_lstm_bench: bad argument");
@@ -1485,7 +1518,7 @@ int n2nmn_debug_lstm_bench(n2nmn_ctx* c, int variant, int rows_per_wg, int njobs
       LstmJob& j0 = jobs[njobs == 2 ? 0 : 1];
       j0 = LstmJob{};
       if (layout) packed_state(c, j0); else rowmajor_a(c, j0);
-      j0.active = 1; j0.A0 = c->eh0[(k + 1) & 1]; j0.K = L; j0.Wp = c->enc_W0h_t;
+      j0.active = 1; j0.A0 = c->eh0[(k + 1) & 1]; j0.K = L; j0.Wp = c->enc_W0h_t; j0.Wp64 = c->enc_W0h_64;
       j0.ntiles = L / 4; j0.xtab = c->big_vocab ? c->xproj : c->enc_xtab; j0.xidx = nullptr;
       j0.xidx_const = 1;
       j0.c_in = c->ec0; j0.c_out = c->ec0; j0.h_old = j0.A0; j0.h_new = c->eh0[k & 1];
@@ -1493,10 +1526,11 @@ int n2nmn_debug_lstm_bench(n2nmn_ctx* c, int variant, int rows_per_wg, int njobs
       j1 = LstmJob{};
       if (layout) packed_state(c, j1); else rowmajor_a(c, j1);
       j1.active = 1; j1.A0 = c->eh0[(k + 1) & 1]; j1.A1 = c->eh1[(k + 1) & 1]; j1.K = 2 * L;
-      j1.Wp = c->enc_W1_t; j1.ntiles = L / 4; j1.bias = c->enc_b1_t;
+      j1.Wp = c->enc_W1_t; j1.Wp64 = c->enc_W1_64; j1.ntiles = L / 4; j1.bias = c->enc_b1_t;
       j1.c_in = c->ec1; j1.c_out = c->ec1; j1.h_old = j1.A1; j1.h_new = c->eh1[k & 1];
       j1.out_seq = c->enc_out;
-      launch_lstm_step_dbg(jobs, njobs, N, L, rows_per_wg, variant, s);
+      if (tile) launch_lstm_step(jobs, njobs, N, L, rows_per_wg, s, tile);
+      else launch_lstm_step_dbg(jobs, njobs, N, L, rows_per_wg, variant, s);
     }
   }
   N2_HIP(hipEventRecord(e1, s));

@@ -69,6 +69,9 @@ struct PackBatch {
   void tiles(const float* W, int ld, int row0, int K, int ntiles, int gate_L, float* dst) {
     add(PJ_TILES, W, dst, (size_t)ntiles * K * 16, ld, row0, K, gate_L);
   }
+  void tiles64(const float* W, int ld, int row0, int K, int L, float* dst) {
+    add(PJ_TILES64, W, dst, (size_t)K * 4 * L, ld, row0, K, L);
+  }
   void tiles_t(const float* W, int ld, int row0, int L, float* dst, int Ktot, int k_off) {
     add(PJ_TILES_T, W, dst, (size_t)(L / 16) * L * 64, ld, row0, L, Ktot, k_off);
   }
@@ -148,6 +151,8 @@ struct n2nmn_ctx {
   float *enc_b0_t = nullptr, *dec_b0_t = nullptr;    // layer-0 biases in the x-table's tile column order
   float *enc_b1_t = nullptr, *dec_b1_t = nullptr;    // layer-1 biases, same order (LstmJob::bias)
   float *enc_W0h_t = nullptr, *enc_W1_t = nullptr, *dec_W0h_t = nullptr, *dec_W1_t = nullptr;
+  // the same four matrices as 16-unit tiles for lstm_tile_kernel (nullptr: lstm_dim % 128 != 0)
+  float *enc_W0h_64 = nullptr, *enc_W1_64 = nullptr, *dec_W0h_64 = nullptr, *dec_W1_64 = nullptr;
   float *eht_W_p = nullptr, *att_W_t = nullptr, *att_W_p = nullptr, *find_img_p = nullptr, *fsp_img_p = nullptr;
   float* dec_emb_cat = nullptr;
   PackBatch packs;                                   // every re-pack of a commit, one launch

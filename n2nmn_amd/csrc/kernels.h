@@ -53,11 +53,13 @@ void launch_pack_tiles(const float* W, int ld, int row0, int K, int ntiles, int 
 
 // All operand re-packs of one weight commit in ONE launch: a job table (built once per context,
 // the pointers never change) replaces ~40 tiny pack / pad / copy launches per optimiser step.
-enum PackKind : int32_t { PJ_PK = 0, PJ_PK_T, PJ_TILES, PJ_TILES_T, PJ_PAD, PJ_PK_GATES, PJ_VEC_GATES };
+enum PackKind : int32_t { PJ_PK = 0, PJ_PK_T, PJ_TILES, PJ_TILES_T, PJ_PAD, PJ_PK_GATES, PJ_VEC_GATES,
+                          PJ_TILES64 };
 struct PackJob {
   int32_t kind;
   int32_t p[7];            // PK / PK_T: ld, K, N, Kp, Np    TILES: ld, row0, K, gate_L
                            // TILES_T: ld, row0, L, Ktot, k_off    PAD: R, M, Mp
+                           // TILES64: ld, row0, K, L  (dst [L/16][K/4][64][4], column c = 16 gate + unit)
   const float* src;
   float* dst;
   uint32_t total;          // elements this job iterates over
@@ -80,6 +82,8 @@ struct LstmJob {
   int hp_R;               // > 0: h_old / h_new use the k-interleaved layout with R rows per k4
   int K;                  // L or 2L
   const float* Wp;        // packed tiles for this job
+  const float* Wp64;      // the same weights as 16-unit tiles [L/16][K/4][64][4] (column c = 16 * gate +
+                          // unit) for lstm_tile_kernel, or nullptr
   int ntiles;             // number of 16-column tiles (LSTM: L/4; linear: Ncols/16)
   int mode;               // 0: LSTM cell epilogue; 1: plain linear  out = z + bias
   const float* xtab;      // [V][4L] input-projection table incl. bias (layer 0) or nullptr; columns in
@@ -115,8 +119,12 @@ struct LstmJob {
 };
 // rows_per_wg: 64 (4 M-tiles per workgroup) or 32 (2 M-tiles; doubles the workgroups of a launch)
 // wide != 0: 32-row x 32-column workgroup tiles for LSTM cell jobs (throughput mode)
+// wide == 2: LDS-staged 64-row x 64-gate-column tiles (lstm_tile_kernel) where the jobs allow it
 void launch_lstm_step(const LstmJob* jobs, int njobs, int N, int L, int rows_per_wg,
                       hipStream_t s, int wide = 0);
+// lstm_tile_kernel (kernels_lstm_tile.hip): LSTM cell jobs on the packed state layout, K in {L, 2L}
+bool lstm_tile_supported(const LstmJob* jobs, int njobs, int L);
+void launch_lstm_tile(const LstmJob* jobs, int njobs, int N, int L, int stages, hipStream_t s);
 
 // Arguments of dec_attn_kernel.  Every per-step pointer is the slice of the FIRST step of the
 // launch; workgroup (n, ts) addresses element ts*N + n of it.

@@ -300,6 +300,14 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
         so = (int64_t)(row0 + 4 * k4 + kk) * ld + col;
         break;
       }
+      case PJ_TILES64: {      // 16-unit tiles of lstm_tile_kernel: [L/16][K/4][64][4], c = 16 * gate + unit
+        const uint32_t ld = jb.p[0], row0 = jb.p[1], K = jb.p[2], L = jb.p[3];
+        const uint32_t kk = i & 3, c = (i >> 2) & 63, r = i >> 8;
+        const uint32_t K4 = K >> 2;
+        const uint32_t j = r / K4, k4 = r - j * K4;
+        so = (int64_t)(row0 + 4 * k4 + kk) * ld + (c >> 4) * L + 16 * j + (c & 15);
+        break;
+      }
       case PJ_TILES_T: {
         const uint32_t ld = jb.p[0], row0 = jb.p[1], L = jb.p[2], Ktot = jb.p[3], k_off = jb.p[4];
         const uint32_t gi = i & 3, c = (i >> 2) & 15, r = i >> 6;

@@ -1004,6 +1004,10 @@ void launch_lstm_step(const LstmJob* jobs, int njobs, int N, int L, int rows_per
     cells = cells && jobs[i].mode == 0 && jobs[i].ntiles % 2 == 0 && (nch == 4 || nch == 8) &&
             jobs[i].K % (LSTM_WAVES * 16) == 0;
   }
+  if (wide >= 2 && N >= 128 && lstm_tile_supported(jobs, njobs, L)) {
+    launch_lstm_tile(jobs, njobs, N, L, wide >= 3 ? wide : 4, s);
+    return;
+  }
   if (wide && cells) {
     dim3 grid(nt / 2, njobs, (N + 31) / 32);
     hipLaunchKernelGGL(lstm_step_wide_kernel<2>, grid, dim3(LSTM_THREADS), 0, s, js, N, L);

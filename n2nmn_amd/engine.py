@@ -68,7 +68,7 @@ class Engine:
     def set_mode(self, mode: str):
         """'latency' (default) or 'throughput': workgroup tile shape of the recurrent step kernels
         (n2nmn_ctx_set_mode) -- use 'throughput' when several batches are in flight on forks."""
-        _lib.check(self._lib.n2nmn_ctx_set_mode(self._ctx, {'latency': 0, 'throughput': 1}[mode]))
+        _lib.check(self._lib.n2nmn_ctx_set_mode(self._ctx, {'latency': 0, 'throughput': 1, 'throughput_ksplit': 2}[mode]))
 
     def fork(self) -> 'Engine':
         """A sibling engine sharing this engine's weights with its own workspace, for running
@@ -159,15 +159,17 @@ class Engine:
     def seq2seq(self, input_seq, seq_len, T_dec: Optional[int] = None, use_gt_layout: bool = False,
                 gt_layout=None, sample_uniforms=None, forced_tokens=None, debug: bool = False,
                 reuse_buffers: bool = True, phase: str = 'both', word_vecs: bool = True,
-                image_feat=None, dropout=None):
+                image_feat=None, dropout=None, out_tokens=None, seq_len_host=None):
         """Phase 1.  input_seq [T,N] int32, seq_len [N] int32 (device tensors or anything
         convertible).  Returns a dict of device tensors named like the reference attributes
         (models_clevr/nmn3_netgen_att.py:305-322).  With reuse_buffers the outputs are views of
-        engine-owned buffers that the next call overwrites.  image_feat (optional): the hoisted
+        engine-owned buffers that the next call overwrites (out_tokens: a caller-owned contiguous
+        int32 [T_dec, N] device tensor for predicted_tokens instead).  image_feat (optional): the hoisted
         conv_image GEMMs of the batch are issued by this call too (n2nmn_seq2seq_io.image_feat) and
         walk() / execute_tokens(conv_done=True) can follow directly.  dropout (optional, models_vqa):
         (enc0, dec0) multiplier tensors [T, N, L] / [T_dec, N, L] for the output of LSTM layer 0
-        (n2nmn_seq2seq_io.drop_enc0 / drop_dec0), either may be None."""
+        (n2nmn_seq2seq_io.drop_enc0 / drop_dec0), either may be None.  seq_len_host (optional): a
+        host int32 copy of seq_len (n2nmn_seq2seq_io.seq_length_host: per-step tile choice)."""
         torch = _torch()
         d = self.dims
         seq = self._dev(input_seq, torch.int32)
@@ -184,6 +186,11 @@ class Engine:
             'word_vecs': mk('wv', (Td, N, d.embed_dim_txt), torch.float32),
             'log_seq_prob': mk('lsp', (N,), torch.float32),
         }
+        if out_tokens is not None:
+            if tuple(out_tokens.shape) != (Td, N) or out_tokens.dtype != torch.int32 or \
+                    not out_tokens.is_contiguous() or out_tokens.device != self.device:
+                raise ValueError('out_tokens must be a contiguous int32 [T_dec, N] tensor on the engine device')
+            out['predicted_tokens'] = out_tokens
         if debug:
             out['token_scores'] = mk('ts', (Td, N, d.num_vocab_nmn), torch.float32)
             out['encoder_outputs'] = mk('eo', (T, N, d.lstm_dim), torch.float32)
@@ -211,6 +218,15 @@ class Engine:
             io.drop_enc0 = drops[0].data_ptr()
         if drops[1] is not None:
             io.drop_dec0 = drops[1].data_ptr()
+        lens_host = None
+        if seq_len_host is not None:
+            lens_host = np.ascontiguousarray(np.asarray(seq_len_host), np.int32)
+            if lens_host.shape != (N,):
+                raise ValueError('seq_len_host must hold N lengths')
+            io.seq_length_host = lens_host.ctypes.data
+        elif isinstance(seq_len, np.ndarray):
+            lens_host = np.ascontiguousarray(seq_len, np.int32)
+            io.seq_length_host = lens_host.ctypes.data
         if not word_vecs:        # N2NMN_S2S_NO_WORD_VECS: word_vecs / neg_entropy / log_seq_prob not computed
             io.flags = 1
             for k in ('word_vecs', 'neg_entropy', 'log_seq_prob'):
@@ -284,9 +300,10 @@ class Engine:
                                                 self.stream()))
 
     def execute_tokens(self, tokens, image_feat, word_vecs, reuse_buffers: bool = True,
-                       conv_done: bool = False, atts=None):
+                       conv_done: bool = False, atts=None, out=None):
         """Phase 2 straight from DEVICE tokens [T_dec, N]: no token fetch, no host assembly, no
-        program upload.  Returns (scores [N, C], validity [N] int32) device tensors."""
+        program upload.  Returns (scores [N, C], validity [N] int32) device tensors; out = (scores,
+        validity): caller-owned contiguous tensors of those shapes to write instead."""
         torch = _torch()
         tok = self._dev(tokens, torch.int32)
         feat = self._dev(image_feat, torch.float32)
@@ -294,8 +311,15 @@ class Engine:
         Td, N = tok.shape
         mk = (lambda k, s, dt: self._buf(k, s, dt)) if reuse_buffers else \
             (lambda k, s, dt: torch.empty(s, dtype=dt, device=self.device))
-        scores = mk('wscores', (N, self.dims.num_choices), torch.float32)
-        validity = mk('wvalid', (N,), torch.int32)
+        if out is not None:
+            scores, validity = out
+            if tuple(scores.shape) != (N, self.dims.num_choices) or tuple(validity.shape) != (N,) or \
+                    scores.dtype != torch.float32 or validity.dtype != torch.int32 or \
+                    not (scores.is_contiguous() and validity.is_contiguous()):
+                raise ValueError('out = (float32 [N, C], int32 [N]) contiguous device tensors')
+        else:
+            scores = mk('wscores', (N, self.dims.num_choices), torch.float32)
+            validity = mk('wvalid', (N,), torch.int32)
         if not conv_done:
             self.conv_image(feat, tok, Td)
         # atts = (atts [T_dec, T_enc, N], input_seq [T_enc, N], seq_length [N]): text maps from the
@@ -375,14 +399,16 @@ class Engine:
     # ------------------------------------------------------------------------------------
     def forward(self, batch, T_dec: Optional[int] = None, use_gt_layout: bool = False,
                 gt_layout=None, sample_uniforms=None, host_assemble: bool = False,
-                fetch: bool = True):
+                fetch: bool = True, out=None):
         """The whole hot path of exp_clevr/eval_clevr.py:103-135 for one batch:
         phase 1 -> token fetch (the one host sync) -> C++ assemble/pack -> phase 2.
         Returns (scores device tensor, tokens numpy [T_dec,N], validity numpy [N]).
 
         Default (dimensions the walker supports): phase 1 -> n2nmn_execute_tokens; the layouts are
         decoded on the device, nothing synchronises between the phases, and with fetch=False the
-        tokens / validity are returned as device tensors (no synchronisation at all).
+        tokens / validity are returned as device tensors (no synchronisation at all); they are views
+        of engine-owned buffers the next call overwrites unless out = (scores [N, C] f32, tokens
+        [T_dec, N] i32, validity [N] i32) names caller-owned tensors (device path only).
         host_assemble=True keeps the reference's flow (token fetch, C++ Assembler, level scheduler).
 
         With use_gt_layout and a HOST gt_layout (numpy, as the reference's data reader delivers
@@ -411,17 +437,22 @@ class Engine:
             table = self.dims.num_vocab_txt <= 4096
             s2s = self.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], T_dec,
                                use_gt_layout, gt_dev, sample_uniforms, word_vecs=not table,
-                               image_feat=None if self.overlap_conv else feat)
+                               image_feat=None if self.overlap_conv else feat,
+                               out_tokens=None if out is None else out[1],
+                               seq_len_host=batch.get('seq_length_host'))
             if self.overlap_conv and not known:
                 self.conv_image(feat, s2s['predicted_tokens'], find=False, fsp=True)
             if self.overlap_conv:
                 cur.wait_event(self._side_ev)
             scores, validity = self.execute_tokens(
                 s2s['predicted_tokens'], feat, s2s.get('word_vecs'), conv_done=True,
-                atts=(s2s['atts'], s2s['_input_seq'], s2s['_seq_length']) if table else None)
+                atts=(s2s['atts'], s2s['_input_seq'], s2s['_seq_length']) if table else None,
+                out=None if out is None else (out[0], out[2]))
             if not fetch:
                 return scores, s2s['predicted_tokens'], validity
             return scores, s2s['predicted_tokens'].cpu().numpy(), validity.cpu().numpy().astype(bool)
+        if out is not None:
+            raise ValueError('out= needs the device path (walker dimensions, host_assemble=False)')
         if use_gt_layout and isinstance(gt_layout, np.ndarray):
             tokens = np.ascontiguousarray(gt_layout, np.int32)
             packed, validity = self.assembler.assemble_packed(tokens)

@@ -50,9 +50,17 @@ class SuperBucket:
         self.seq_length = torch.ones((N,), dtype=torch.int32, device=dev)
         self.image_feat = torch.zeros((N, d.H, d.W, d.D), dtype=torch.float32, device=dev)
         self.gt_layout = torch.zeros((d.T_decoder, N), dtype=torch.int32, device=dev)
+        # host copy of the lengths of the slots that were filled from host arrays (clients hand over
+        # host batches, util/clevr_train/data_reader.py:74-82): n2nmn_seq2seq_io.seq_length_host
+        self.seq_length_host = np.ones((N,), np.int32)
+        self._len_known = [False] * self.K
+        # results live in tensors of the bucket's own: two buckets may share one engine (a worker
+        # alternates between them), and the engine's reuse buffers belong to whoever ran last
+        self._res = {}
         self.scores = None
         self.validity = None
         self.tokens = None
+        self.n_run = 0
 
     def load_weights(self, weights):
         self.engine.load_weights(weights)
@@ -65,6 +73,7 @@ class SuperBucket:
     def slot(self, k: int):
         """Views a client writes its batch into (keys of util/clevr_train/data_reader.py:74-82)."""
         c = self._cols(k)
+        self._len_known[k] = False        # written behind our back: no host copy of the lengths
         return dict(input_seq_batch=self.input_seq[:, c], seq_length_batch=self.seq_length[c],
                     image_feat_batch=self.image_feat[c], gt_layout_batch=self.gt_layout[:, c])
 
@@ -75,22 +84,58 @@ class SuperBucket:
         v = self.slot(k)
         for key in ('input_seq_batch', 'seq_length_batch', 'image_feat_batch'):
             v[key].copy_(torch.as_tensor(batch[key]), non_blocking=True)
+        lens = batch['seq_length_batch']
+        self._len_known[k] = isinstance(lens, np.ndarray)
+        if self._len_known[k]:
+            self.seq_length_host[self._cols(k)] = lens
         if gt_layout is not None:
             v['gt_layout_batch'].copy_(torch.as_tensor(gt_layout), non_blocking=True)
 
-    def run(self, use_gt_layout: bool = False, sample_uniforms=None, T_dec: Optional[int] = None):
-        """One pass over all K slots.  Returns (scores [K*Nb, C], tokens [T_dec, K*Nb], validity
-        [K*Nb]) device tensors; nothing synchronises."""
-        batch = dict(input_seq_batch=self.input_seq, seq_length_batch=self.seq_length,
-                     image_feat_batch=self.image_feat)
-        self.scores, self.tokens, self.validity = self.engine.forward(
-            batch, T_dec=T_dec, use_gt_layout=use_gt_layout,
-            gt_layout=self.gt_layout if use_gt_layout else None, sample_uniforms=sample_uniforms,
-            fetch=False)
+    def _results(self, n: int, Td: int):
+        torch = _torch()
+        key = (n, Td)
+        r = self._res.get(key)
+        if r is None:
+            dev, rows = self.engine.device, n * self.Nb
+            r = (torch.empty((rows, self.dims.num_choices), dtype=torch.float32, device=dev),
+                 torch.empty((Td, rows), dtype=torch.int32, device=dev),
+                 torch.empty((rows,), dtype=torch.int32, device=dev))
+            self._res[key] = r
+        return r
+
+    def run(self, use_gt_layout: bool = False, sample_uniforms=None, T_dec: Optional[int] = None,
+            n_slots: Optional[int] = None, host_assemble: bool = False):
+        """One pass over the first n_slots slots (default: all K).  Returns (scores [n*Nb, C], tokens
+        [T_dec, n*Nb], validity [n*Nb]) device tensors owned by this bucket (one set per pass width,
+        overwritten by the next pass of that width); nothing synchronises."""
+        n = self.K if n_slots is None else int(n_slots)
+        if not 1 <= n <= self.K:
+            raise ValueError('n_slots %d out of range [1, %d]' % (n, self.K))
+        rows = n * self.Nb
+        Td = self.dims.T_decoder if T_dec is None else int(T_dec)
+        full = n == self.K
+        batch = dict(input_seq_batch=self.input_seq if full else self.input_seq[:, :rows].contiguous(),
+                     seq_length_batch=self.seq_length[:rows], image_feat_batch=self.image_feat[:rows])
+        if all(self._len_known[:n]):
+            batch['seq_length_host'] = self.seq_length_host[:rows]
+        gt = None
+        if use_gt_layout:
+            gt = self.gt_layout if full else self.gt_layout[:, :rows].contiguous()
+        if host_assemble or not self.engine.walk_supported():
+            self.scores, self.tokens, self.validity = self.engine.forward(
+                batch, T_dec=T_dec, use_gt_layout=use_gt_layout, gt_layout=gt,
+                sample_uniforms=sample_uniforms, fetch=False, host_assemble=True)
+        else:
+            self.scores, self.tokens, self.validity = self.engine.forward(
+                batch, T_dec=T_dec, use_gt_layout=use_gt_layout, gt_layout=gt,
+                sample_uniforms=sample_uniforms, fetch=False, out=self._results(n, Td))
+        self.n_run = n
         return self.scores, self.tokens, self.validity
 
     def result(self, k: int):
         """(scores [Nb, C], tokens [T_dec, Nb], validity [Nb]) views of slot k after run()."""
+        if not 0 <= k < self.n_run:
+            raise ValueError('slot %d was not part of the last pass (%d slots)' % (k, self.n_run))
         c = self._cols(k)
         return self.scores[c], self.tokens[:, c], self.validity[c]
 

@@ -72,7 +72,7 @@ def seq2seq(w, input_seq, seq_len, P, Wv, bv, T_dec, use_gt_layout=False, gt_lay
     X = torch.tensor([[0, 0, T_dec]]).repeat(N, 1)
     x = w[_DEC + 'go_embedding'].repeat(N, 1)
     gt = torch.as_tensor(np.asarray(gt_layout)).long() if gt_layout is not None else None
-    tokens, tprobs, atts = [], [], []
+    tokens, tprobs, atts, tscores, tvalid = [], [], [], [], []
     neg_ent = torch.zeros(N, dtype=dt)
     for t in range(T_dec):
         c0, h0 = _lstm(x, c0, h0, D0, d0)
@@ -97,11 +97,12 @@ def seq2seq(w, input_seq, seq_len, P, Wv, bv, T_dec, use_gt_layout=False, gt_lay
         neg_ent = neg_ent + (p * torch.log(torch.clamp(p + (1 - vm), min=1e-5))).sum(1)
         X = X + Pt[tok]
         x = demb[tok]
-        tokens.append(tok); atts.append(att)
+        tokens.append(tok); atts.append(att); tscores.append(sc); tvalid.append(valid)
     atts = torch.stack(atts)                               # [T_dec, T, N, 1]
     word_vecs = (atts * Emb[None]).sum(1)                  # [T_dec, N, E]
     return dict(predicted_tokens=torch.stack(tokens).to(torch.int32), token_probs=torch.stack(tprobs),
-                neg_entropy=neg_ent, atts=atts, word_vecs=word_vecs)
+                neg_entropy=neg_ent, atts=atts, word_vecs=word_vecs,
+                token_scores=torch.stack(tscores), token_validity=torch.stack(tvalid))
 
 
 def _fc(w, s, x):

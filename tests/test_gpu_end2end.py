@@ -146,6 +146,6 @@ def test_reference_shaped_session_loop(clevr_engine):
     assert scores_val.shape == (d.N, d.num_choices)
     # oracle on the same tokens
     ref = O.forward(w, NAMES, batch, d.T_decoder, d.num_choices, np.float64, forced_tokens=tokens)
-    assert_close('scores', scores_val, ref['scores'], 2e-4)
+    assert_close('scores', scores_val, ref['scores'], 1e-4)
     predictions = np.argmax(scores_val, axis=1)
     assert predictions.shape == (d.N,)
