@@ -78,10 +78,11 @@ def test_teacher_forced_passes_match_the_oracle_in_every_slot(pipe):
             c = slice(k * d.N, (k + 1) * d.N)
             worst = max(worst, assert_close('worker %d bucket %d slot %d' % (si, j, k), scores[c],
                                             ref['scores'][c], 1e-4))
-    # the same questions in another slot, bucket, worker and pass width: bit-identical logits
+    # the same questions in another slot, bucket and worker: the same logits up to the summation
+    # order of the recurrent step (the tile is chosen per step from the lengths of the whole pass)
     a = t2n(p.bucket(0, 0).result(0)[0])
     bb = t2n(p.bucket(1, 1).result(7)[0])
-    assert np.array_equal(a, bb)
+    assert_close('slot independence', a, bb, 2e-6)
     print('worst |logit - oracle| over %d slots: %.2e' % (sum(map(sum, WIDTHS)), worst))
 
 
