@@ -277,6 +277,12 @@ static int lstm_wide(const n2nmn_ctx* c) {
   return c->mode == N2NMN_MODE_THROUGHPUT ? 2 : c->mode == N2NMN_MODE_THROUGHPUT_KSPLIT ? 1 : 0;
 }
 
+// encoder steps with at most this many active rows use the K-split tiles (needs the host lengths)
+static int tile_min_rows() {
+  static const int v = [] { const char* e = getenv("N2NMN_TILE_MIN_ROWS"); return e ? atoi(e) : 192; }();
+  return v;
+}
+
 // state buffers (eh0/eh1/dh0/dh1) are k-interleaved [L/4][R][4] with R = capacity N
 void packed_state(const n2nmn_ctx* c, LstmJob& j) {
   j.a_rs = 4; j.a_ks = 4 * c->d.N; j.hp_R = c->d.N;
@@ -395,7 +401,7 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmAr
                                (j1.active ? 2.0 * L * 4 * L + 5.0 * N * L : 0));
       ProfScope ps(c, F_LSTM_ENC, fl, by, s);
       int wide = lstm_wide(c);
-      if (!act_host.empty() && act_host[std::min(k, T - 1)] <= 3 * 64) wide = 1;
+      if (!act_host.empty() && act_host[std::min(k, T - 1)] <= tile_min_rows()) wide = 1;
       launch_lstm_step(jobs, 2, N, L, 64, s, wide);
     }
   }

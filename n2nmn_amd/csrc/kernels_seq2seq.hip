@@ -2,6 +2,8 @@
 //
 // Reference semantics: models_clevr/nmn3_netgen_att.py:73-113 (encoder), :115-322 (decoder);
 // TF 1.0.0 BasicLSTMCell / dynamic_rnn / raw_rnn semantics per SURVEY.md Appendix A.1-A.3.
+#include <cstdlib>
+
 #include "device_utils.h"
 #include "kernels.h"
 
@@ -1005,7 +1007,8 @@ void launch_lstm_step(const LstmJob* jobs, int njobs, int N, int L, int rows_per
             jobs[i].K % (LSTM_WAVES * 16) == 0;
   }
   if (wide >= 2 && N >= 128 && lstm_tile_supported(jobs, njobs, L)) {
-    launch_lstm_tile(jobs, njobs, N, L, wide >= 3 ? wide : 4, s);
+    static const int stages = [] { const char* e = getenv("N2NMN_TILE_STAGES"); return e ? atoi(e) : 4; }();
+    launch_lstm_tile(jobs, njobs, N, L, wide >= 3 ? wide : stages, s);
     return;
   }
   if (wide && cells) {
