@@ -455,6 +455,7 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
   const double fl1 = 2.0 * N * 2 * L * 4 * L, by1 = 4.0 * (2.0 * L * 4 * L + 5.0 * N * L);
   DecStepArgs a{};
   a.eht = c->eht; a.eout = c->enc_out; a.seq_len = c->enc_len; a.v = c->vars[V_ATT_V].mirror;
+  a.order = c->perm;            // enc_prepare's length ranking of this pass's rows
   a.eht_bias = c->vars[V_EHT_B].mirror;
   a.Wy = c->vars[V_TOK_W].mirror; a.by = c->vars[V_TOK_B].mirror; a.P = c->P; a.Wv = c->Wv;
   a.bv = c->bv; a.use_gt = io->use_gt_layout; a.T = T; a.N = N; a.L = L; a.V = V;

@@ -66,4 +66,19 @@ __device__ __forceinline__ float block_reduce(float v, float* scratch) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// tanh / sigmoid on the hardware transcendentals: v_exp_f32 (2^x) and v_rcp_f32 (1 ulp).
+//   tanh(x) = 1 - 2 / (2^(2 x log2 e) + 1),  sigmoid(x) = 1 / (1 + 2^(-x log2 e))
+// Five / four VALU instructions, two of them quarter-rate.  (`__fdividef` / `__expf` compile to a full
+// IEEE division -- v_div_scale x2, v_rcp, four FMAs, v_div_fmas, v_div_fixup -- and an extra
+// multiply: 16 instructions per tanh, which made the decoder attention VALU-bound at twice the
+// cost.)  Absolute error <= ~3e-7 over the whole range, saturating cleanly to +-1 / 0 / 1 (2^x
+// overflows to +inf, whose reciprocal is 0): far inside the 1e-4 logit budget.
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float t = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+  return fmaf(-2.0f, __builtin_amdgcn_rcpf(t + 1.0f), 1.0f);
+}
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
+
 }  // namespace n2nmn

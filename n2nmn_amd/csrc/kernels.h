@@ -146,6 +146,9 @@ struct DecStepArgs {
                            // Appendix A.2), so the batched attention evaluates them once
   const float* eout;       // [T][N][L]
   const int32_t* seq_len;  // [N]
+  const int32_t* order;    // [N] questions by decreasing length (enc_prepare's perm) or nullptr: the
+                           // per-question kernel takes its workgroups' questions in this order, so the
+                           // dispatcher hands the longest questions out first (LPT schedule)
   const float* v;          // [L]
   const float* Wy;         // [2L][V]
   const float* by;         // [V]
@@ -376,6 +379,9 @@ struct DecBwdArgs {
   const float* atts;       // [Td][T][N]
   const float* datts_wv;   // [Td][T][N] gradient arriving through word_vecs
   const int32_t* seq_len;  // [N]
+  const int32_t* order;    // [N] questions by decreasing length (enc_prepare's perm) or nullptr: the
+                           // per-question kernel takes its workgroups' questions in this order, so the
+                           // dispatcher hands the longest questions out first (LPT schedule)
   const float* v;          // [L]
   const float* Wy;         // [2L][V]
   int T, N, L, V, Td;

@@ -39,13 +39,6 @@ namespace n2nmn {
 
 namespace {
 
-__device__ __forceinline__ float fast_tanh(float x) {
-  const float t = __expf(2.0f * x);
-  return 1.0f - __fdividef(2.0f, t + 1.0f);
-}
-__device__ __forceinline__ float fast_sigmoid(float x) {
-  return __fdividef(1.0f, 1.0f + __expf(-x));
-}
 
 constexpr int TILE_ROWS = 64, TILE_UNITS = 16, TILE_BK = 32;
 constexpr int TILE_WAVES = 8, TILE_THREADS = TILE_WAVES * 64;

@@ -2,6 +2,7 @@
 //
 // Reference semantics: models_clevr/nmn3_netgen_att.py:73-113 (encoder), :115-322 (decoder);
 // TF 1.0.0 BasicLSTMCell / dynamic_rnn / raw_rnn semantics per SURVEY.md Appendix A.1-A.3.
+#include <algorithm>
 #include <cstdlib>
 
 #include "device_utils.h"
@@ -11,15 +12,6 @@ namespace n2nmn {
 
 namespace {
 
-// tanh / sigmoid on the hardware exp (v_exp_f32): tanh(x) = 1 - 2/(e^{2x}+1).  Absolute error
-// <= ~2e-7 over the whole range (saturates cleanly to +-1), far inside the 1e-4 logit budget.
-__device__ __forceinline__ float fast_tanh(float x) {
-  const float t = __expf(2.0f * x);
-  return 1.0f - __fdividef(2.0f, t + 1.0f);
-}
-__device__ __forceinline__ float fast_sigmoid(float x) {
-  return __fdividef(1.0f, 1.0f + __expf(-x));
-}
 
 // ---------------------------------------------------------------------------------------------
 // lstm_step_kernel: one LSTM layer step (or two independent ones: grid.y = job).
@@ -866,6 +858,212 @@ __global__ __launch_bounds__(256) void dec_attn_multi_kernel(DecStepArgs a, int 
   }
 }
 
+// dec_attn_question_kernel: the teacher-forced attention of ONE question, ALL decoder steps, in one
+// 16-wave workgroup (nmn3_netgen_att.py:184-268 for every step at once).
+// dec_attn_multi_kernel gives a question to ceil(T_dec / 4) workgroups, each of which streams the
+// question's encoder rows again (PMC: 302 MB per 512-question launch for 94 MB of rows, 170 us).  Here
+//   * the question's encoder_h_transform rows (len x 2 KB <= 92 KB) are read from HBM/L2 ONCE into LDS;
+//   * the tanh scores e[j][tau] = sum_k v_k tanh(q_j,k + eht[tau,k]) -- the VALU-bound part, two
+//     transcendentals per (step, row, k) -- are spread over the 16 waves as 4 step groups x 4 row
+//     quarters: a wave keeps the query vectors of its 5 steps in registers and walks its rows in LDS;
+//   * the context vectors ctx[j] = sum_tau att[j][tau] eout[tau] are ONE small matrix product per
+//     question ([32 steps] x [len] x [L]) on the matrix cores (v_mfma_f32_32x32x2_f32): every wave owns
+//     32 (64) columns, its B fragments are the encoder_outputs rows straight from global memory, each
+//     element loaded exactly once, the attention weights come from LDS;
+//   * token logits, validity, probabilities and entropy as in the other two kernels (dec_token_tail).
+template <int KI>
+__global__ __launch_bounds__(1024) void dec_attn_question_kernel(DecStepArgs a, int nsteps) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NT = 1024, NW = 16, SPG = 5;
+  const int L = a.L, T = a.T, N = a.N, V = a.V;
+  const int Tp = (T + 3) & ~3;
+  float* eS = smem;                                          // [max(T, nsteps)][L]: eht rows, later ctx
+  float* es = eS + (size_t)(T > nsteps ? T : nsteps) * L;   // [32][Tp] scores -> attention weights
+  // work per question grows with its length (5..45 rows): the longest questions take the lowest
+  // workgroup ids, i.e. are dispatched first, and the short ones fill in behind them
+  const int n = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int len = min(max(a.seq_len[n], 0), T);
+  // rows past the question's length all equal the bias of encoder_h_transform: virtual row `len`
+  // stands for every one of them (evaluated once, copied to the others below)
+  const int Tv = (a.eht_bias && len < T) ? len + 1 : T;
+
+  // ---- 0. the question's rows -> LDS (16 KB per sweep of the workgroup), zero the score block -----
+  {
+    const int ncol = L / 4, total = Tv * ncol;
+    constexpr int SW = 3 * KI;                               // sweeps cover T * L <= 12 K * KI floats
+    float4 r4[SW];
+#pragma unroll
+    for (int u = 0; u < SW; ++u) {
+      const int i = min(tid + u * NT, total - 1);
+      const int row = i / ncol, c4 = i - row * ncol;
+      const float* er = (Tv != T && row == len) ? a.eht_bias : a.eht + ((size_t)row * N + n) * L;
+      r4[u] = *reinterpret_cast<const float4*>(er + 4 * c4);
+    }
+#pragma unroll
+    for (int u = 0; u < SW; ++u) {
+      const int i = tid + u * NT;
+      if (i < total) *reinterpret_cast<float4*>(eS + 4 * (size_t)i) = r4[u];
+    }
+    for (int i = tid; i < 32 * Tp; i += NT) es[i] = 0.f;
+  }
+  __syncthreads();
+  // ---- 1. e[j][tau] = sum_k v_k tanh(q_j,k + eht[tau, n, k])                          (:184-187)
+  {
+    const int sg = w >> 2, tq = w & 3;
+    const int j0 = sg * SPG;
+    float4 v4[KI], q4[SPG][KI];
+#pragma unroll
+    for (int i = 0; i < KI; ++i) {
+      const int k = 4 * lane + 256 * i;
+      v4[i] = *reinterpret_cast<const float4*>(a.v + k);
+#pragma unroll
+      for (int j = 0; j < SPG; ++j) {
+        const int jj = min(j0 + j, nsteps - 1);
+        q4[j][i] = *reinterpret_cast<const float4*>(a.q + ((size_t)jj * N + n) * L + k);
+      }
+    }
+    if (j0 < nsteps) {
+      for (int tau = tq; tau < Tv; tau += 8) {               // two rows of this quarter per trip
+        const int tau1 = tau + 4;
+        float4 e0[KI], e1[KI];
+#pragma unroll
+        for (int i = 0; i < KI; ++i) {
+          e0[i] = *reinterpret_cast<const float4*>(eS + (size_t)tau * L + 4 * lane + 256 * i);
+          e1[i] = *reinterpret_cast<const float4*>(eS + (size_t)min(tau1, Tv - 1) * L + 4 * lane + 256 * i);
+        }
+#pragma unroll
+        for (int j = 0; j < SPG; ++j) {
+          float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+          for (int i = 0; i < KI; ++i) {
+            s0 += v4[i].x * fast_tanh(q4[j][i].x + e0[i].x) + v4[i].y * fast_tanh(q4[j][i].y + e0[i].y) +
+                  v4[i].z * fast_tanh(q4[j][i].z + e0[i].z) + v4[i].w * fast_tanh(q4[j][i].w + e0[i].w);
+            s1 += v4[i].x * fast_tanh(q4[j][i].x + e1[i].x) + v4[i].y * fast_tanh(q4[j][i].y + e1[i].y) +
+                  v4[i].z * fast_tanh(q4[j][i].z + e1[i].z) + v4[i].w * fast_tanh(q4[j][i].w + e1[i].w);
+          }
+          const float r0 = wave_sum(s0), r1 = wave_sum(s1);
+          if (lane == 0 && j0 + j < nsteps) {
+            es[(j0 + j) * Tp + tau] = r0;
+            if (tau1 < Tv) es[(j0 + j) * Tp + tau1] = r1;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (Tv != T && len + 1 < T) {
+    const int rest = T - len - 1;
+    for (int i = tid; i < nsteps * rest; i += NT) {
+      const int j = i / rest, tau = len + 1 + i - j * rest;
+      es[j * Tp + tau] = es[j * Tp + len];
+    }
+    __syncthreads();
+  }
+  // ---- 2. softmax over ALL T rows, mask finished rows, renormalise                   (:190-191)
+  for (int j = w; j < nsteps; j += NW) {
+    float* ej = es + j * Tp;
+    float m = -INFINITY;
+    for (int tau = lane; tau < T; tau += 64) m = fmaxf(m, ej[tau]);
+    m = wave_max(m);
+    float sm = 0.f;
+    for (int tau = lane; tau < T; tau += 64) sm += expf(ej[tau] - m);
+    sm = wave_sum(sm);
+    float s2 = 0.f;
+    for (int tau = lane; tau < T; tau += 64) {
+      float p = expf(ej[tau] - m) / sm;
+      p = tau < len ? p : 0.f;
+      ej[tau] = p;
+      s2 += p;
+    }
+    s2 = wave_sum(s2);
+    float* arow = a.atts + (size_t)j * T * N;
+    for (int tau = lane; tau < T; tau += 64) {
+      const float att = ej[tau] / s2;
+      ej[tau] = att;
+      arow[(size_t)tau * N + n] = att;
+    }
+  }
+  __syncthreads();
+  // ---- 3. ctx[j] = sum_tau att[j][tau] * eout[tau, n, :]  on the matrix cores          (:193)
+  // D[step][col] += A[step][k] B[k][col], k = encoder row: lane l holds A[l % 32][l / 32] (LDS) and
+  // B[l / 32][l % 32] (global); rows >= nsteps of A are zero, weights of rows >= len are zero
+  {
+    float* ctxS = eS;                                        // every wave is done with the eht rows
+    const int li = lane & 31, kh = lane >> 5;
+    const int nm = (len + 1) >> 1;                           // MFMAs (2 encoder rows each)
+    for (int cb = 32 * w; cb < L; cb += 32 * NW) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const float* bcol = a.eout + (size_t)n * L + cb + li;
+      for (int m0 = 0; m0 < nm; m0 += 8) {
+        float bv[8], av[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int tau = min(2 * (m0 + u) + kh, T - 1);
+          bv[u] = bcol[(size_t)tau * N * L];
+          av[u] = es[li * Tp + min(2 * (m0 + u) + kh, Tp - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (m0 + u < nm) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+      }
+      // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (j < nsteps) {
+          ctxS[(size_t)j * L + cb + li] = acc[r];
+          if (a.ctx_out) a.ctx_out[((size_t)j * N + n) * L + cb + li] = acc[r];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- 4. token logits = [out, ctx] . W_y + b_y for all steps: one [32 x 2L] x [2L x 32] product on
+  // the matrix cores, K split over the 16 waves (a per-thread partial per (step, token) would cost 64
+  // wave reductions per wave and 4 steps -- as much VALU time as the tanh scores)       (:196-198)
+  {
+    const float* ctxS = eS;
+    float* part = eS + (size_t)nsteps * L;                   // [NW][nsteps][MAXV], behind the ctx rows
+    const int li = lane & 31, kh = lane >> 5;
+    const int kper = 2 * L / NW;                             // k range of this wave (64 at L = 512)
+    const int k0 = w * kper;
+    const int jr = min(li, nsteps - 1);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int m0 = 0; m0 < kper / 2; m0 += 8) {
+      float av[8], bv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = k0 + 2 * (m0 + u) + kh;
+        av[u] = k < L ? a.out[((size_t)jr * N + n) * L + k] : ctxS[(size_t)jr * L + k - L];
+        bv[u] = li < V ? a.Wy[(size_t)k * V + li] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+    }
+    if (li < MAXV) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = (r & 3) + 8 * (r >> 2) + 4 * kh;       // step (row of D), li = token (column)
+        if (j < nsteps) part[((size_t)w * nsteps + j) * MAXV + li] = acc[r];
+      }
+    }
+    __syncthreads();
+    for (int j = w; j < nsteps; j += NW) {
+      float sc = -INFINITY;
+      if (lane < V) {
+        sc = a.by[lane];
+        for (int ww = 0; ww < NW; ++ww) sc += part[((size_t)ww * nsteps + j) * MAXV + lane];
+      }
+      dec_token_tail(a, n, j, (size_t)j * N + n, sc, lane);
+    }
+  }
+}
+
 // perm[rank] = n with rows ranked by decreasing length (ties by index); n_active[t] = #{len > t}.
 // The same launch clears the recurrent state block (a separate memset node costs ~5 us on the
 // stream).
@@ -1104,7 +1302,29 @@ static void launch_dec_multi(const DecStepArgs& a, int nsteps, hipStream_t s) {
                      smem, s, a, nsteps);
 }
 
+template <int KI>
+static bool launch_dec_question(const DecStepArgs& a, int nsteps, hipStream_t s) {
+  const int Tp = (a.T + 3) & ~3;
+  const size_t smem = sizeof(float) * ((size_t)std::max(a.T, nsteps) * a.L + 32 * (size_t)Tp + 16 * 4 * MAXV);
+  if (smem > 150 * 1024 || (size_t)a.T * a.L > (size_t)3 * KI * 4096 ||
+      (size_t)nsteps * (a.L + 16 * MAXV) > (size_t)std::max(a.T, nsteps) * a.L) return false;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_question_kernel<KI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL((dec_attn_question_kernel<KI>), dim3(a.N), dim3(1024), smem, s, a, nsteps);
+  return true;
+}
+
 void launch_dec_attn(const DecStepArgs& a, int nsteps, hipStream_t s) {
+  // every step of a question in one workgroup: needs <= 20 steps (4 groups of 5), enough questions to
+  // fill the chip with one workgroup each, and the question's rows in LDS
+  static const int qk = [] { const char* e = getenv("N2NMN_DEC_ATTN_Q"); return e ? atoi(e) : 1; }();
+  if (qk && nsteps > 1 && nsteps <= 20 && a.N >= 128 && !a.uni && !a.forced && a.use_gt) {
+    if (a.L == 512 && launch_dec_question<2>(a, nsteps, s)) return;
+  }
   if (nsteps > 1 && a.L % 256 == 0 && a.L <= 1024) {
     // steps per workgroup: as many as keep >= ~2 workgroups per CU in the launch
     const int groups4 = (nsteps + 3) / 4;

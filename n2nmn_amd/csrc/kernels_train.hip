@@ -23,11 +23,6 @@ namespace n2nmn {
 
 namespace {
 
-__device__ __forceinline__ float fast_tanh(float x) {
-  const float t = __expf(2.0f * x);
-  return 1.0f - __fdividef(2.0f, t + 1.0f);
-}
-
 // ---------------------------------------------------------------------------------------------
 // gemm_tn: C[m][n] += sum_r A[row(r)][m] * B[r][n]
 // Workgroup tile (64 WT) x (64 WT), 4 waves (2x2), each wave WT x WT accumulators of one 32x32x2
