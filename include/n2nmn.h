@@ -295,6 +295,12 @@ int n2nmn_walk_layouts(n2nmn_ctx *ctx, const n2nmn_walk_batch *batches, int K, i
  * of all such questions (8 workgroups per question: the HBM-bound kernel of the attention-module
  * path), then fc_att + answer head.  -1 (default): 1 when a launch carries >= 128 questions. */
 int n2nmn_walk_set_defer_pool(n2nmn_ctx *ctx, int mode);
+/* Where the tree-independent work of n2nmn_walk_layouts runs when the text maps come from the
+ * attention tables: mode -1 (default) chip-wide launches ahead of the walker for passes of >= 128
+ * questions (walk_tmap_kernel: text maps of all nodes; walk_find_kernel: the Find / Filter epilogues,
+ * 4 workgroups per question streaming the conv_image map), 0 always inside the walker, 1 always
+ * chip-wide. */
+int n2nmn_walk_set_front_end(n2nmn_ctx *ctx, int mode);
 /* single batch: n2nmn_conv_image(FIND | FSP gated by tokens) + n2nmn_walk_layouts(K = 1) */
 int n2nmn_execute_tokens(n2nmn_ctx *ctx, const int32_t *tokens, int T_dec, int N,
                          const float *image_feat, const float *word_vecs, float *scores,

@@ -228,6 +228,7 @@ static size_t carve_workspace(n2nmn_ctx* c, char* base) {
   c->dev_tab = k.take<int32_t>(c->max_tab);
   c->walk_stats = k.take<unsigned long long>(WALK_STATS);
   c->wtmap = k.take<float>(Td * N * Mp);
+  c->watt = k.take<float>(Td * N * HWp);
   c->wpjob = k.take<int32_t>(N);
   c->wpw = k.take<float>(N * 2 * HWp);
   c->wptm = k.take<float>(N * Mp);
@@ -241,7 +242,8 @@ const char* kFamilyNames[F_COUNT] = {
   "lstm_step(linear q)", "dec_attn", "gemm_pk(encoder_h_transform)", "word_vecs", "textmap", "gemm_pk(conv_image)",
   "att_ops", "pool", "heads",
   "lstm_bwd_step", "gemm_tn(weight grads)", "backward misc (modules/attention/gemm_nt)",
-  "optimiser", "walk(layout walker)", "gemm_pkn(encoder_h_transform + q + conv_image)"};
+  "optimiser", "walk(layout walker)", "gemm_pkn(encoder_h_transform + q + conv_image)",
+  "walk_find(Find / Filter epilogues over the conv_image maps)", "walk_tmap(text maps from the attention tables)"};
 
 
 hipStream_t S(n2nmn_stream s) { return reinterpret_cast<hipStream_t>(s); }
@@ -1217,6 +1219,12 @@ int n2nmn_walk_set_defer_pool(n2nmn_ctx* c, int mode) {
   return N2NMN_OK;
 }
 
+int n2nmn_walk_set_front_end(n2nmn_ctx* c, int mode) {
+  N2_REQUIRE(c && mode >= -1 && mode <= 1, N2NMN_EINVAL, "walk_set_front_end: mode is -1, 0 or 1");
+  c->walk_pre_find = mode;
+  return N2NMN_OK;
+}
+
 int n2nmn_walk_supported(const n2nmn_ctx* c) {
   if (!c) return 0;
   const n2nmn_dims& d = c->d;
@@ -1290,6 +1298,7 @@ int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int
     a.b[k].tokens = b.tokens; a.b[k].feat = b.image_feat; a.b[k].word_vecs = b.word_vecs;
     a.b[k].scores = b.scores; a.b[k].validity = b.validity;
     a.b[k].mfind = owner->mfind; a.b[k].mfsp = owner->mfsp; a.b[k].tmap = owner->wtmap;
+    a.b[k].watt = owner->watt;
     a.b[k].pjob = owner->wpjob; a.b[k].pw = owner->wpw; a.b[k].ptm = owner->wptm;
     a.b[k].pooled = owner->wpooled; a.b[k].pfc = owner->wpfc;
   }
@@ -1313,6 +1322,22 @@ int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int
   // answer operators leave the walker and run as chip-wide launches of their own
   const int dp_env = c->walk_defer_pool;
   a.defer_pool = (dp_env < 0 ? K * N >= 128 : dp_env > 0) && walk_pool_supported(d.H, d.W, d.D);
+  // passes of many questions: the text maps and the Find / Filter epilogues run chip-wide before the
+  // walker, which then finds both in HBM (600 bytes per node) and keeps only the tree-dependent work
+  const int pf_env = c->walk_pre_find;
+  const bool pre = use_table && (pf_env < 0 ? K * N >= 128 : pf_env > 0);
+  if (pre) {
+    {
+      ProfScope ps(c, F_WALK_TMAP, 0.0, 0.0, s);
+      launch_walk_tmap(w, a, s);
+    }
+    {
+      ProfScope ps(c, F_WALK_FIND, 0.0, 0.0, s);   // bytes from the device counters (walk stats [8])
+      launch_walk_find(w, a, s);
+    }
+    a.pre_find = 1;
+    a.T_enc = 0;                 // the walker reads tmap instead of building the maps itself
+  }
   {
     ProfScope ps(c, F_WALK, 0.0, 0.0, s);     // work filled in from the device counters
     launch_walk(w, a, s);
@@ -1466,6 +1491,12 @@ int n2nmn_profile_end(n2nmn_ctx* ctx, n2nmn_stream stream) {
                  C = d.num_choices, KK = (double)d.kernel_size * d.kernel_size;
     const double n_find = (double)st[0], n_pool_in = (double)st[1], n_pool = (double)st[2],
                  n_text = (double)st[3], n_tr = (double)st[4], n_q = (double)st[5];
+    const double n_pre = (double)st[8];          // map passes of walk_find_kernel
+    if (n_pre > 0) {
+      ctx->prof_bytes[F_WALK_FIND] += 4.0 * n_pre * (HW * Mp + HW);
+      ctx->prof_flops[F_WALK_FIND] += n_pre * 5.0 * HW * M;
+      ctx->prof_bytes[F_WALK_TMAP] += 4.0 * n_text * Mp;
+    }
     ctx->prof_bytes[F_WALK] += 4.0 * (n_find * (HW * Mp + HW) + n_pool * HW * D + n_pool_in * HW +
                                       n_text * E + n_q * C) +
                                ctx->prof_launches[F_WALK] * 4.0 * (5 * E * M + 4 * D * M);

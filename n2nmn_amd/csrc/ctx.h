@@ -196,6 +196,7 @@ struct n2nmn_ctx {
 
   // module workspace
   float* wtmap = nullptr;                  // [T_dec][N][Mp] text maps of the walker path
+  float* watt = nullptr;                   // [N][T_dec][HWp] Find / Filter logits (walk_find_kernel)
   // deferred pooling of the walker path: job code, soft-max weights, text map, pooled features
   int32_t* wpjob = nullptr; float *wpw = nullptr, *wptm = nullptr, *wpooled = nullptr, *wpfc = nullptr;
   float *arena = nullptr, *tmap = nullptr, *pfc = nullptr, *mfind = nullptr, *mfsp = nullptr;
@@ -221,6 +222,7 @@ struct n2nmn_ctx {
   long prof_launches[24] = {0};
   WalkArgs last_walk{};                       // arguments of the last walker launch (debug replay)
   bool have_last_walk = false;
+  int walk_pre_find = -1;                     // -1 auto (>= 128 questions), 0 in the walker, 1 chip-wide
   int walk_defer_pool = -1;                   // -1 auto (>= 128 questions per launch), 0 never, 1 always
   double walk_jobs_deferred = 0;              // pooling jobs of the last profiled passes
   long long* walk_timeline = nullptr;         // n2nmn_debug_walk_timeline (caller-owned)
@@ -250,7 +252,8 @@ struct Carver {
 enum Family {
   F_LSTM_ENC = 0, F_LSTM_DEC0, F_LSTM_DEC1, F_LINEAR_Q, F_DEC_STEP, F_GEMM_EHT, F_WORD_VECS,
   F_TEXTMAP, F_CONV_IMAGE, F_ATT_OPS, F_POOL, F_HEADS,
-  F_LSTM_BWD, F_GEMM_TN, F_BWD_MISC, F_OPTIMISER, F_WALK, F_GEMM_MULTI, F_COUNT
+  F_LSTM_BWD, F_GEMM_TN, F_BWD_MISC, F_OPTIMISER, F_WALK, F_GEMM_MULTI, F_WALK_FIND, F_WALK_TMAP,
+  F_COUNT
 };
 extern const char* kFamilyNames[F_COUNT];
 

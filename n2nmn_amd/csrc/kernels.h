@@ -247,7 +247,9 @@ struct WalkBatch {
   const float* mfind;      // [N][HW][Mp] conv_image maps, FindModule weights
   const float* mfsp;       // [N][HW][Mp] conv_image maps, FindSamePropertyModule weights (only the
                            // images whose layout has a _FindSameProperty token are filled in)
-  float* tmap;             // [T][N][Mp] text maps (walk_textmap_kernel fills the rows that are read)
+  float* tmap;             // [T][N][Mp] text maps (walk_textmap_kernel / walk_tmap_kernel fill the rows that
+                           // are read)
+  float* watt;             // [N][T][HWp] Find / Filter logits written by walk_find_kernel (pre_find)
   // deferred pooling (WalkArgs::defer_pool): per question job code (0 none / op), soft-max weights
   // [N][2][HWp], text map [N][Mp], pooled features [N][2][D]
   int32_t* pjob; float* pw; float* ptm; float* pooled;
@@ -263,21 +265,27 @@ struct WalkArgs {
   const int32_t* token_op; // [V] device: op code of each layout token, -1 for <eos>
   int H, W, D, M, Mp, HWp, E, C, ksize;
   int defer_pool;          // root Describe / SameProperty -> walk_pool_kernel + walk_heads_kernel
+  int pre_find;            // Find / Filter logits come from walk_find_kernel (watt), text maps from tmap
   int T_enc, V_txt;        // T_enc > 0: text maps from ew[ws][seq] weighted by atts
   const float* ew[5];      // [V_txt][Mp] embedding_mat . W_txt[ws]
   // profiling only: [0] conv_image map reads (one per <= 4 Find / Filter nodes of a question, one per
   // FindSameProperty node), [1] pooled inputs, [2] pooling nodes, [3] text maps,
-  // [4] Transform nodes, [5] valid questions (atomic adds by thread 0 of each workgroup)
+  // [4] Transform nodes, [5] valid questions, [6] deferred pooling jobs, [7] their inputs,
+  // [8] map passes done by walk_find_kernel instead of the walker (atomic adds by thread 0)
   unsigned long long* stats;
   // debugging only: [question][WALK_MAX_T][4] shader-clock stamps of thread 0 per node
   // (start, after text map, after pooling + fc_att, end)
   long long* timeline;
 };
-constexpr int WALK_STATS = 8;
+constexpr int WALK_STATS = 10;
+constexpr int WALK_FIND_PARTS = 4;   // workgroups of walk_find_kernel per question (rows of the map)
 int walk_supported(int H, int W, int D, int M, int Mp, int HWp, int E, int C, int T, int ksize,
                    int T_enc);
 void launch_walk_textmap(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
 void launch_walk(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
+// chip-wide front end (table text maps, Find / Filter epilogues): see kernels_walk.hip
+void launch_walk_tmap(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
+void launch_walk_find(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
 void launch_walk_pool(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
 void launch_walk_heads(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
 int walk_pool_supported(int H, int W, int D);

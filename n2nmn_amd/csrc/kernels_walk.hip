@@ -535,10 +535,13 @@ __global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
       const int o = L.op[t] & 0xff;
       const bool f = o == N2NMN_OP_FIND || o == N2NMN_OP_FILTER || o == N2NMN_OP_FIND_SAME_PROPERTY;
       const bool p = o == N2NMN_OP_FIND_SAME_PROPERTY || o == N2NMN_OP_SAME_PROPERTY || o == N2NMN_OP_DESCRIBE;
-      cf += o == N2NMN_OP_FIND_SAME_PROPERTY; cp += p;      // cf: conv_image map READS (see below) cpi += p ? (o == N2NMN_OP_SAME_PROPERTY ? 2 : 1) : 0;
+      cf += o == N2NMN_OP_FIND_SAME_PROPERTY; cp += p;      // cf: conv_image map READS (see below)
+      cpi += p ? (o == N2NMN_OP_SAME_PROPERTY ? 2 : 1) : 0;
       ct += (f || p || o == N2NMN_OP_TRANSFORM); ctr += o == N2NMN_OP_TRANSFORM;
     }
-    cf += (unsigned long long)((L.n_find + 3) / 4);      // Find / Filter nodes share one pass per 4
+    // Find / Filter nodes share one pass over the map per 4: here, or in walk_find_kernel ([8])
+    const unsigned long long passes = (unsigned long long)((L.n_find + 3) / 4);
+    if (a.pre_find) atomicAdd(a.stats + 8, passes); else cf += passes;
     atomicAdd(a.stats + 0, cf); atomicAdd(a.stats + 1, cpi); atomicAdd(a.stats + 2, cp);
     atomicAdd(a.stats + 3, ct); atomicAdd(a.stats + 4, ctr); atomicAdd(a.stats + 5, 1ull);
     if (a.defer_pool && nn > 0) {
@@ -609,7 +612,16 @@ __global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
 
   // ---- Find / Filter epilogues of the whole question in ONE pass over the image's conv_image map
   // (walk_find_pass), off the dependent chain
-  {
+  if (a.pre_find) {
+    // walk_find_kernel streamed the maps chip-wide: the logits of this question's Find / Filter nodes
+    // are 600 bytes each in HBM
+    const float* src = B.watt + (size_t)n * T * HWp;
+    for (int i = tid0; i < L.n_find * HWp; i += WT) {
+      const int t = L.flist[i / HWp], r = i % HWp;
+      arena[(size_t)t * HWp + r] = src[(size_t)t * HWp + r];
+    }
+    __syncthreads();
+  } else {
     const float* Mbuf = B.mfind + (size_t)n * HW * Mp;
     for (int f0 = 0; f0 < L.n_find; f0 += 4) {
       const int nf = min(4, L.n_find - f0);
@@ -894,6 +906,183 @@ __global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
 namespace {
 
 // ---------------------------------------------------------------------------------------------
+// Chip-wide front end of the walker for passes of many questions (throughput mode): the two things
+// every question does that do NOT depend on its tree -- the text maps of its nodes and the Find /
+// Filter epilogues over the image's conv_image map -- leave the one-workgroup-per-question chain
+// (where they ran at one CU's pace: 13 % of HBM) and run as launches whose workgroups
+// fill the chip.
+//
+// walk_tmap_kernel: text maps of all nodes of a question from the decoder's attention and the
+// commit-time (embedding . W_txt) tables (see walk_kernel's pre-pass), one wave per node, written to
+// tmap[t][n][:].  One workgroup (4 waves) per question.
+// walk_find_kernel: att_f[r] = l2norm_c(M[r,c] * tmap_f[c]) . w_e + b_e (nmn3_modules.py:104-108,
+// Filter's find_result :129) for the Find / Filter nodes of a question, WALK_FIND_PARTS workgroups per
+// question, each streaming its rows of the map once for up to 4 nodes; logits to watt[n][t][:].
+// Both re-read the token column (20 ints) instead of sharing a decoded table: a Find-type node is a
+// token before the first <eos> whose operator is Find / Filter; for an invalid layout the rows they
+// write are never read.
+// ---------------------------------------------------------------------------------------------
+constexpr int FT = 256, FW = FT / 64;
+__global__ __launch_bounds__(FT) void walk_tmap_kernel(ModuleWeights w, WalkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ int ops[MAXT];
+  __shared__ int s_nn;
+  const int q = blockIdx.x;
+  const int kb = q / a.N, n = q - kb * a.N;
+  const WalkBatch& B = a.b[kb];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int T = a.T, Mp = a.Mp, Te = a.T_enc;
+  const int Tep = (Te + 3) & ~3;
+  int* seql = reinterpret_cast<int*>(smem);                 // [Tep]
+  float* attall = smem + Tep;                               // [T][Tep]
+  if (tid < T) {
+    const int tok = B.tokens[(size_t)tid * a.N + n];
+    ops[tid] = (tok < 0 || tok >= a.V) ? -1 : a.token_op[tok];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int nn = 0;
+    while (nn < T && ops[nn] >= 0) ++nn;
+    s_nn = nn;
+  }
+  const int qlen = min(max(B.seq_len[n], 0), Te);
+  for (int tau = tid; tau < Te; tau += FT) {
+    const int v = B.seq[(size_t)tau * a.N + n];
+    seql[tau] = min(max(v, 0), a.V_txt - 1);
+  }
+  __syncthreads();
+  const int nn = s_nn;
+  for (int i = tid; i < nn * Te; i += FT) {
+    const int t = i / Te, tau = i - t * Te;
+    attall[t * Tep + tau] = tau < qlen ? B.atts[((size_t)t * Te + tau) * a.N + n] : 0.f;
+  }
+  __syncthreads();
+  for (int t = wid; t < nn; t += FW) {
+    const int ws = text_ws_of(ops[t]);
+    if (ws < 0) continue;                                    // wave-uniform
+    const float* ewp = a.ew[ws];
+    const float* at = attall + t * Tep;
+    for (int cb = 0; cb < Mp; cb += 256) {
+      const unsigned col = (unsigned)min(cb + 4 * lane, Mp - 4);
+      float4 acc = *reinterpret_cast<const float4*>(w.btxt[ws] + col);
+      constexpr int RU = 16;
+      for (int tb = 0; tb < qlen; tb += RU) {
+        float4 r4[RU];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+          const int tau = min(tb + u, Te - 1);
+          r4[u] = *reinterpret_cast<const float4*>(ewp + ((unsigned)seql[tau] * (unsigned)Mp + col));
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+          const float av = tb + u < qlen ? at[tb + u] : 0.f;
+          acc.x += av * r4[u].x; acc.y += av * r4[u].y; acc.z += av * r4[u].z; acc.w += av * r4[u].w;
+        }
+      }
+      if (cb + 4 * lane < Mp)
+        *reinterpret_cast<float4*>(B.tmap + ((size_t)t * a.N + n) * Mp + col) = acc;
+    }
+  }
+}
+
+template <int CI, int NF>
+__device__ __forceinline__ void find_rows(int tid, const ModuleWeights& w, const float* Mbuf,
+                                          const float* const* ts, float* const* os, int r0, int r1,
+                                          int Mp) {
+  const int lane = tid & 63, wid = tid >> 6;
+  const float be = w.be[0][0];
+  float4 t4[NF][CI], e4[CI];
+#pragma unroll
+  for (int i = 0; i < CI; ++i) {
+    const int c = 4 * lane + 256 * i;
+    const bool ok = c < Mp;
+    e4[i] = ok ? *reinterpret_cast<const float4*>(w.we[0] + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+      t4[j][i] = ok ? *reinterpret_cast<const float4*>(ts[j] + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  constexpr int UNR = CI == 1 ? 10 : (CI == 2 ? 5 : 3);     // rows of a wave in flight
+  for (int rb = r0 + wid; rb < r1; rb += UNR * FW) {
+    float4 m4[UNR][CI];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const unsigned r = (unsigned)min(rb + u * FW, r1 - 1);
+#pragma unroll
+      for (int i = 0; i < CI; ++i) {
+        const unsigned c = (unsigned)min(4 * lane + 256 * i, Mp - 4);
+        m4[u][i] = *reinterpret_cast<const float4*>(Mbuf + (r * (unsigned)Mp + c));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int r = rb + u * FW;
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        float ss = 0.f, dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < CI; ++i) {
+          const float p0 = m4[u][i].x * t4[j][i].x, p1 = m4[u][i].y * t4[j][i].y,
+                      p2 = m4[u][i].z * t4[j][i].z, p3 = m4[u][i].w * t4[j][i].w;
+          ss += p0 * p0 + p1 * p1 + p2 * p2 + p3 * p3;
+          dot += p0 * e4[i].x + p1 * e4[i].y + p2 * e4[i].z + p3 * e4[i].w;
+        }
+        const float s2 = wave_sum(ss);
+        const float d2 = wave_sum(dot);
+        if (lane == 0 && r < r1) os[j][r] = d2 / sqrtf(fmaxf(s2, 1e-12f)) + be;
+      }
+    }
+  }
+}
+
+template <int CI>
+__global__ __launch_bounds__(FT) void walk_find_kernel(ModuleWeights w, WalkArgs a) {
+  __shared__ int flist[MAXT];
+  __shared__ int s_nf;
+  const int q = blockIdx.x;
+  const int kb = q / a.N, n = q - kb * a.N;
+  const WalkBatch& B = a.b[kb];
+  const int tid = threadIdx.x;
+  const int T = a.T, HW = a.H * a.W, Mp = a.Mp, HWp = a.HWp;
+  __shared__ int ops[MAXT];
+  if (tid < T) {                                    // the T token loads go out in parallel
+    const int tok = B.tokens[(size_t)tid * a.N + n];
+    ops[tid] = (tok < 0 || tok >= a.V) ? -1 : a.token_op[tok];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int nf = 0;
+    for (int t = 0; t < T; ++t) {
+      const int op = ops[t];
+      if (op < 0) break;
+      if (op == N2NMN_OP_FIND || op == N2NMN_OP_FILTER) flist[nf++] = t;
+    }
+    s_nf = nf;
+  }
+  __syncthreads();
+  const int nfind = s_nf;
+  if (nfind == 0) return;
+  const int rpp = (HW + WALK_FIND_PARTS - 1) / WALK_FIND_PARTS;
+  const int r0 = blockIdx.y * rpp, r1 = min(HW, r0 + rpp);
+  const float* Mbuf = B.mfind + (size_t)n * HW * Mp;
+  for (int f0 = 0; f0 < nfind; f0 += 4) {
+    const int nf = min(4, nfind - f0);
+    const float* ts[4];
+    float* os[4];
+    for (int j = 0; j < 4; ++j) {
+      const int t = flist[f0 + min(j, nf - 1)];
+      ts[j] = B.tmap + ((size_t)t * a.N + n) * Mp;
+      os[j] = B.watt + ((size_t)n * T + t) * HWp;
+    }
+    switch (nf) {
+      case 1: find_rows<CI, 1>(tid, w, Mbuf, ts, os, r0, r1, Mp); break;
+      case 2: find_rows<CI, 2>(tid, w, Mbuf, ts, os, r0, r1, Mp); break;
+      case 3: find_rows<CI, 3>(tid, w, Mbuf, ts, os, r0, r1, Mp); break;
+      default: find_rows<CI, 4>(tid, w, Mbuf, ts, os, r0, r1, Mp); break;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Deferred attention pooling (throughput mode): f_i = sum_hw a_i[hw] * feat[n, hw, :] for the
 // questions whose root is Describe / SameProperty (nmn3_modules.py:438-441,485-486) -- THE HBM-bound
 // kernel of the attention-module path: the [H*W, D] feature map (307 KB at CLEVR dims) is read once
@@ -1053,6 +1242,20 @@ void launch_walk_textmap(const ModuleWeights& w, const WalkArgs& a, hipStream_t 
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(walk_textmap_kernel, dim3((a.N + TMG - 1) / TMG, 5, a.T * a.K), dim3(WT), smem,
                      s, w, a);
+}
+
+void launch_walk_tmap(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) {
+  const int Tep = (a.T_enc + 3) & ~3;
+  const size_t smem = sizeof(float) * ((size_t)Tep + (size_t)a.T * Tep);
+  hipLaunchKernelGGL(walk_tmap_kernel, dim3(a.K * a.N), dim3(FT), smem, s, w, a);
+}
+
+void launch_walk_find(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) {
+  const dim3 grid(a.K * a.N, WALK_FIND_PARTS);
+  const int ci = (a.Mp + 255) / 256;
+  if (ci == 1) hipLaunchKernelGGL(walk_find_kernel<1>, grid, dim3(FT), 0, s, w, a);
+  else if (ci == 2) hipLaunchKernelGGL(walk_find_kernel<2>, grid, dim3(FT), 0, s, w, a);
+  else hipLaunchKernelGGL(walk_find_kernel<4>, grid, dim3(FT), 0, s, w, a);
 }
 
 void launch_walk(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) {

@@ -261,6 +261,11 @@ class Engine:
         chip-wide launches (n2nmn_walk_set_defer_pool)."""
         _lib.check(self._lib.n2nmn_walk_set_defer_pool(self._ctx, int(mode)))
 
+    def set_front_end(self, mode: int):
+        """-1 auto, 0 text maps / Find epilogues inside the walker, 1 as chip-wide launches ahead of it
+        (n2nmn_walk_set_front_end)."""
+        _lib.check(self._lib.n2nmn_walk_set_front_end(self._ctx, int(mode)))
+
     def walk_supported(self) -> bool:
         return bool(self._lib.n2nmn_walk_supported(self._ctx))
 

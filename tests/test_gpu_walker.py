@@ -207,3 +207,36 @@ def test_deferred_pooling_equals_inline_pooling(clevr_engine, seed):
         eng.set_defer_pool(-1)
     assert_close('deferred vs inline', out[1], out[0], 2e-5)
     assert_close('deferred vs oracle', out[1], ref['scores'], TOL)
+
+
+@pytest.mark.parametrize('seed', [1, 2, 3])
+def test_chip_wide_front_end_equals_in_walker_front_end(clevr_engine, seed):
+    """passes of many questions: walk_tmap_kernel (text maps from the attention tables) and
+    walk_find_kernel (Find / Filter epilogues, 4 workgroups per question) run ahead of the walker
+    (n2nmn_walk_set_front_end); same logits as the all-in-one walker and the oracle, on random deep
+    layouts (up to 4+ Find-type nodes), the template mix, and a batch with invalid layouts."""
+    eng, d, asm, w = clevr_engine
+    batch = synth.make_inputs(d, seed=60 + seed, min_len=1)
+    if seed == 2:
+        toks = synth.template_layout_batch(d, offset=3)
+    else:
+        toks = synth.random_valid_layouts(d, asm.P, asm.W, asm.b, seed=70 + seed, max_len=9)
+    if seed == 3:                                   # some invalid columns: zero logits, validity 0
+        toks = toks.copy()
+        toks[:, ::7] = asm.name2idx_dict['_Find']
+    ref = O.forward(w, NAMES, batch, d.T_decoder, d.num_choices, np.float64, forced_tokens=toks)
+    s2s = eng.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], forced_tokens=toks,
+                      reuse_buffers=False, word_vecs=False)
+    out, val = {}, {}
+    try:
+        for mode in (0, 1):
+            eng.set_front_end(mode)
+            sc, v = eng.execute_tokens(s2s['predicted_tokens'], batch['image_feat_batch'], None,
+                                       reuse_buffers=False,
+                                       atts=(s2s['atts'], s2s['_input_seq'], s2s['_seq_length']))
+            out[mode], val[mode] = t2n(sc).copy(), t2n(v).copy()
+    finally:
+        eng.set_front_end(-1)
+    assert np.array_equal(val[0], val[1]) and np.array_equal(val[1].astype(bool), ref['validity'])
+    assert_close('chip-wide vs in-walker front end', out[1], out[0], 2e-6)
+    assert_close('chip-wide front end vs oracle', out[1], ref['scores'], TOL)
