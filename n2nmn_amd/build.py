@@ -29,11 +29,34 @@ def _deps():
         [os.path.join(HERE, '..', 'include', 'n2nmn.h')]
 
 
+STAMP = os.path.join(LIBDIR, '.csrc.sha256')
+
+
+def source_digest() -> str:
+    """sha256 over the names and contents of everything the library is built from"""
+    import hashlib
+    h = hashlib.sha256()
+    for p in sorted(_deps()):
+        h.update(os.path.basename(p).encode() + b'\0')
+        with open(p, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def is_stale() -> bool:
+    """The library is stale when the sources it was built from are not the sources on disk.  Decided
+    by CONTENT (digest recorded next to the .so at build time), not by mtimes: a checkout or rsync that
+    does not preserve timestamps must not turn a working install into a rebuild -- or, on a box
+    without hipcc, into an import error.  Without a recorded digest (library from an older build)
+    the mtimes decide."""
     if not os.path.exists(LIB):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(p) > t for p in _deps())
+    try:
+        with open(STAMP) as f:
+            return f.read().strip() != source_digest()
+    except OSError:
+        t = os.path.getmtime(LIB)
+        return any(os.path.getmtime(p) > t for p in _deps())
 
 
 def hipcc() -> str:
@@ -51,7 +74,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return LIB
     import fcntl
     os.makedirs(LIBDIR, exist_ok=True)
-    with open(os.path.join(LIBDIR, '.build.lock'), 'w') as lock:
+    with open(os.path.join(LIBDIR, '.build.lock'), 'a') as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
             if not force and not is_stale():
@@ -88,9 +111,12 @@ def _build_locked(verbose: bool) -> str:
     cmd = [hipcc(), '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', tmp] + objs
     if verbose:
         print(' '.join(cmd), flush=True)
+    digest = source_digest()
     try:
         subprocess.check_call(cmd)
         os.replace(tmp, LIB)
+        with open(STAMP, 'w') as f:
+            f.write(digest + '\n')
     finally:
         if os.path.exists(tmp):
             os.remove(tmp)

@@ -530,17 +530,31 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
       gq.Bp = c->att_W_p; gq.Np = L; gq.Kp = c->KpL; gq.bias = c->vars[V_ATT_B].mirror; gq.N = L;
       gq.C = c->qbuf; gq.ldc = L; gq.n_store = L;
       fl += 2.0 * Td * N * L * L; by += 4.0 * ((double)L * L + 2.0 * Td * N * L);
-      const bool conv = io->image_feat && nl <= 2;
+      // the hoisted conv_image problems ride in this launch when the list has room (it holds four);
+      // otherwise they get a launch of their own below -- never dropped: the walker reads their maps
+      const bool conv = io->image_feat != nullptr;
+      const bool conv_here = conv && nl <= 2;
+      GemmArgs cvl[2];
+      double cfl = 0, cby = 0;
       if (conv) {
         const bool gate = root(c)->have_token_ops;
-        conv_image_problems(c, io->image_feat, N, gate ? io->gt_layout : nullptr, Td, list + nl);
-        nl += 2;
+        conv_image_problems(c, io->image_feat, N, gate ? io->gt_layout : nullptr, Td, cvl);
         const double HW = d.H * d.W, frac = gate ? 1.1 : 2.0;     // gated share: see n2nmn_conv_image
-        fl += frac * 2.0 * N * HW * d.D * d.map_dim;
-        by += frac * 4.0 * N * HW * (d.D + c->Mp) + 4.0 * d.D * d.map_dim;
+        cfl = frac * 2.0 * N * HW * d.D * d.map_dim;
+        cby = frac * 4.0 * N * HW * (d.D + c->Mp) + 4.0 * d.D * d.map_dim;
       }
-      ProfScope ps(c, nl > 1 ? F_GEMM_MULTI : F_LINEAR_Q, fl, by, s);
-      launch_gemm_pkn(list, nl, s);
+      if (conv_here) {
+        list[nl++] = cvl[0]; list[nl++] = cvl[1];
+        fl += cfl; by += cby;
+      }
+      {
+        ProfScope ps(c, nl > 1 ? F_GEMM_MULTI : F_LINEAR_Q, fl, by, s);
+        launch_gemm_pkn(list, nl, s);
+      }
+      if (conv && !conv_here) {
+        ProfScope ps(c, F_CONV_IMAGE, cfl, cby, s);
+        launch_gemm_pkn(cvl, 2, s);
+      }
     }
     a.q = c->qbuf; a.out = c->dec_h1_all; a.gt = io->gt_layout; a.uni = nullptr; a.forced = nullptr;
     a.tokens = tokens; a.tprobs = tprobs; a.ent_t = c->ent_t; a.atts = atts;

@@ -11,7 +11,17 @@
 // librccl is bound at run time (dlopen): the library keeps loading on hosts without RCCL, and inside
 // a PyTorch process it attaches to the librccl PyTorch already mapped instead of a second copy.
 #include <dlfcn.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// Build hosts without the RCCL headers: the handful of ABI-stable types and constants this file
+// needs (every function is bound with dlsym at run time anyway).
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat32 = 7 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+#endif
 
 #include <cstring>
 #include <mutex>
@@ -105,9 +115,16 @@ int n2nmn_comm_create(const void* unique_id_128, int rank, int world, int device
   }
   int lo = 0, hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-  N2_HIP(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi));   // collectives first
-  N2_HIP(hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));
-  for (auto& e : c->done) N2_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  // any failure from here on releases what exists already (communicator, stream, events)
+  hipError_t e = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi);   // collectives first
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
+  for (auto& ev : c->done)
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+  if (e != hipSuccess) {
+    set_last_error(std::string("comm_create: ") + hipGetErrorString(e));
+    (void)n2nmn_comm_destroy(c);
+    return N2NMN_EHIP;
+  }
   *out = c;
   return N2NMN_OK;
 }

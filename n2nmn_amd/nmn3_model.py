@@ -21,7 +21,7 @@ from .engine import Engine
 from .nmn3_assembler import PackedLayouts
 from .nmn3_modules import Modules
 from .nmn3_netgen_att import AttentionSeq2Seq, PHASE1_OUTPUTS
-from .runtime import Fetch, Placeholder, resolve, to_numpy
+from .runtime import Fetch, Placeholder, register_model, resolve, to_numpy
 from .spec import Dims, INVALID_EXPR
 
 
@@ -70,6 +70,7 @@ class NMN3Model:
         self.modules = Modules(image_feat_grid, None, num_choices, engine=engine)
         self.compiler = Compiler(assembler)
         self.scores = Fetch(self, 'scores', 2)
+        register_model(self)
 
     def load_weights(self, weights):
         self.engine.load_weights(weights)

@@ -57,6 +57,9 @@ class Session:
     """`sess.partial_run_setup(fetches, feeds)` then `sess.partial_run(h, fetch, feed_dict)`, as
     in exp_clevr/eval_clevr.py:105-132.  Returned values are numpy arrays, like TF's."""
 
+    def __init__(self):
+        self.last = {}           # name of the last fetch -> value returned (debugging aid)
+
     def partial_run_setup(self, fetches, feeds=None):
         return _Handle(fetches if isinstance(fetches, (list, tuple)) else [fetches], feeds or [])
 
@@ -72,11 +75,65 @@ class Session:
             if not isinstance(f, Fetch):
                 raise TypeError('cannot fetch %r' % (f,))
             out.append(f.owner._fetch(f, handle))
+            self.last[f.name] = out[-1]
         return out[0] if single else out
 
     def run(self, fetches, feed_dict=None):
         h = self.partial_run_setup(fetches, list((feed_dict or {}).keys()))
         return self.partial_run(h, fetches, feed_dict)
+
+
+# ---- the handful of `tf.*` names the reference's driver scripts use (exp_clevr/eval_clevr.py:15-19,
+# 72-75,90-91), so that a driver runs with `from n2nmn_amd.runtime import tf` in place of
+# `import tensorflow as tf` and nothing else changed -----------------------------------------------
+_MODELS = []          # models built since the last Saver.restore: what TF's default graph would hold
+
+
+def register_model(model):
+    _MODELS.append(model)
+
+
+class _Saver:
+    """tf.train.Saver: restore(sess, path) loads reference-named variables into every model built
+    so far -- from `path`.npz / `path` (an .npz of name -> array) or a TensorFlow V2 checkpoint
+    prefix (n2nmn_amd.tf_checkpoint)."""
+
+    def __init__(self, *args, **kwargs):
+        pass
+
+    def restore(self, sess, path):
+        import os
+        if os.path.exists(path + '.npz') or path.endswith('.npz'):
+            z = np.load(path if path.endswith('.npz') else path + '.npz')
+            weights = {k: z[k] for k in z.files}
+        else:
+            from . import tf_checkpoint
+            weights = tf_checkpoint.read_checkpoint(path, skip_missing=True)
+        if not _MODELS:
+            raise RuntimeError('Saver.restore: no model has been built')
+        for m in _MODELS:
+            m.load_weights(weights)
+
+    def save(self, sess, path, **kwargs):
+        raise NotImplementedError('the inference drop-in does not write TensorFlow checkpoints')
+
+
+class _Namespace:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def _config(**kwargs):
+    return _Namespace(**kwargs)
+
+
+tf = _Namespace(
+    Session=lambda config=None, **kw: Session(),
+    ConfigProto=_config, GPUOptions=_config,
+    placeholder=placeholder,
+    int32='int32', int64='int64', float32='float32', float64='float64', bool='bool',
+    train=_Namespace(Saver=_Saver),
+)
 
 
 def to_numpy(t):

@@ -119,8 +119,11 @@ class Trainer:
                  beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
                  max_grad_l2_norm: float = 10.0, dist=None, rccl: Optional[bool] = None):
         """dist: an initialised torch.distributed module (or None).  rccl: all-reduce through the
-        C-ABI's own RCCL communicator (default: whenever `dist` runs on the nccl backend; True
-        without `dist` builds a 1-rank communicator); False / gloo: torch.distributed collectives."""
+        C-ABI's own RCCL communicator (n2nmn_comm_* / n2nmn_allreduce_grads); False / gloo:
+        torch.distributed collectives.  Default: the C-ABI communicator for a 1-rank nccl group
+        (what could be run on hardware here); with more ranks torch.distributed's all_reduce unless
+        N2NMN_RCCL_BUCKETS=1 opts in -- the multi-rank path of the C-ABI communicator has never met a
+        second GPU (the gpurun boxes have one), so it must not be the silent default there."""
         torch = _torch()
         if engine._parent is not None:
             raise ValueError('train on the root engine, not on a fork')
@@ -143,7 +146,9 @@ class Trainer:
                                    device=engine.device)
         self.scores = None
         if rccl is None:
-            rccl = dist is not None and dist.get_backend() == 'nccl'
+            import os
+            rccl = dist is not None and dist.get_backend() == 'nccl' and \
+                (dist.get_world_size() == 1 or os.environ.get('N2NMN_RCCL_BUCKETS') == '1')
         self.buckets = RcclBuckets(engine, self.grads, dist) if rccl else \
             GradBuckets(self.grads, self.split, dist)
         self.iteration = 0

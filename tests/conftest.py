@@ -5,6 +5,10 @@ import sys
 import numpy as np
 import pytest
 
+# several tests import modules straight from the read-only reference checkout: never leave
+# __pycache__ directories behind in it
+sys.dont_write_bytecode = True
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

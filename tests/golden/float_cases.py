@@ -22,6 +22,9 @@ CLEVR_CASES = {
     'greedy': dict(N=6, T_enc=9, T_dec=8, seed=101, min_len=1),
     'gt': dict(N=12, T_enc=11, T_dec=10, seed=102, min_len=1),
     'sampled': dict(N=6, T_enc=9, T_dec=10, seed=103, min_len=2),
+    # BASELINE.json configs[1] / [2] at full size (exp_clevr/eval_clevr.py:27-37): separate fixture
+    # tests/golden/float_golden_full.npz (logits, tokens, validity only)
+    'full': dict(N=64, T_enc=45, T_dec=20, seed=106, min_len=5),
 }
 # two layouts that add the operators the ten SURVEY templates do not use (_Scene, _LessNum)
 EXTRA_LAYOUTS = (('_Scene', '_Find', '_LessNum'),

@@ -197,3 +197,55 @@ def test_vqa_model_matches_reference_code(fx, mode):
     assert np.array_equal(tokens, want_tok)
     assert np.array_equal(validity, z[key + '/validity'])
     assert_close(key + '/scores', t2n(scores), z[key + '/scores'], TOL)
+
+
+# ---- BASELINE size (exp_clevr/eval_clevr.py:27-37): N = 64, T_encoder = 45, T_decoder = 20 --------------
+GOLDEN_FULL = os.path.join(os.path.dirname(GOLDEN), 'float_golden_full.npz')
+
+
+def test_full_size_batch_matches_reference_code(clevr_engine):
+    """configs[1] and configs[2] at the size the metric is quoted on, against logits computed by the
+    reference's own model files (make_float_golden_full.py): single batch of 64, default mode."""
+    eng, d0, asm, w = clevr_engine
+    z = np.load(GOLDEN_FULL)
+    d, batch = FC.clevr_inputs('full')
+    gt = synth.template_layout_batch(d)
+    scores, tokens, validity = eng.forward(batch, use_gt_layout=True, gt_layout=gt)
+    assert np.array_equal(tokens, gt) and validity.all()
+    assert_close('gt scores', t2n(scores), z['gt/scores'], TOL)
+    # free-running decoder: the reference code's tokens forced in (SURVEY 8c), then the whole path
+    want_tok = z['greedy/predicted_tokens']
+    s2s = eng.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], forced_tokens=want_tok)
+    assert_close('token_probs', t2n(s2s['token_probs']), z['greedy/token_probs'], TOL)
+    packed, val = asm.assemble_packed(want_tok)
+    assert np.array_equal(val, z['greedy/validity'])
+    sc = eng.execute(packed, batch['image_feat_batch'], s2s['word_vecs'])
+    assert_close('greedy scores (reference tokens)', t2n(sc), z['greedy/scores'], TOL)
+    sc2, tok2, val2 = eng.forward(batch)
+    same = (tok2 == want_tok).all(axis=0)
+    assert same.mean() >= 0.9 and val2.all()
+    assert_close('greedy scores (free-running)', t2n(sc2)[same], z['greedy/scores'][same], TOL)
+
+
+def test_full_size_batch_in_a_throughput_pass_matches_reference_code():
+    """the same 64 questions as one slot of an 8-slot pass in 'throughput' mode (lstm_tile_kernel,
+    per-question decoder attention, chip-wide walker front end, deferred pooling): the path bench.py
+    times, against the reference code's logits"""
+    from n2nmn_amd.nmn3_assembler import Assembler
+    from n2nmn_amd.superbucket import SuperBucket
+    z = np.load(GOLDEN_FULL)
+    d, batch = FC.clevr_inputs('full')
+    gt = synth.template_layout_batch(d)
+    sb = SuperBucket(d, Assembler(list(CLEVR_MODULE_NAMES)), K=8)
+    sb.load_weights(FC.clevr_weights())
+    sb.engine.set_mode('throughput')
+    for k in range(8):
+        other = synth.make_inputs(d, seed=300 + k, min_len=1)
+        sb.fill(k, batch if k == 5 else other, gt if k == 5 else synth.template_layout_batch(d, offset=k))
+    sb.run(use_gt_layout=True)
+    assert_close('gt scores, slot 5 of 8', t2n(sb.result(5)[0]), z['gt/scores'], TOL)
+    sb.run(use_gt_layout=False)
+    sc, tok, val = [t2n(x) for x in sb.result(5)]
+    same = (tok == z['greedy/predicted_tokens']).all(axis=0)
+    assert same.mean() >= 0.9 and val.all()
+    assert_close('greedy scores, slot 5 of 8', sc[same], z['greedy/scores'][same], TOL)

@@ -254,3 +254,35 @@ def test_fixture_is_what_the_reference_code_computes_today():
     p = subprocess.run([sys.executable, gen, '--check'], capture_output=True, text=True,
                        env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'))
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+# ---- BASELINE size: N = 64, T_encoder = 45, T_decoder = 20 (exp_clevr/eval_clevr.py:27-37) ----------
+GOLDEN_FULL = os.path.join(os.path.dirname(GOLDEN), 'float_golden_full.npz')
+
+
+def test_full_size_forward_greedy_and_gt(w64):
+    """the oracle at the benchmarked size against the reference code's own logits and tokens
+    (tests/golden/float_golden_full.npz, make_float_golden_full.py)"""
+    from n2nmn_amd import synth
+    z = np.load(GOLDEN_FULL)
+    d, batch = FC.clevr_inputs('full')
+    assert (d.N, d.T_encoder, d.T_decoder) == (64, 45, 20)
+    r = O.forward(w64, FC.NAMES, batch, d.T_decoder, d.num_choices, np.float64)
+    assert np.array_equal(r['dec']['predicted_tokens'], z['greedy/predicted_tokens'])
+    assert np.array_equal(r['validity'], z['greedy/validity'])
+    close('full greedy scores', r['scores'], z['greedy/scores'])
+    close('full greedy token_probs', r['dec']['token_probs'], z['greedy/token_probs'])
+    gt = synth.template_layout_batch(d)
+    r = O.forward(w64, FC.NAMES, batch, d.T_decoder, d.num_choices, np.float64, use_gt_layout=True,
+                  gt_layout=gt)
+    close('full gt scores', r['scores'], z['gt/scores'])
+    close('full gt log_seq_prob', r['log_seq_prob'], z['gt/log_seq_prob'])
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/models_clevr'),
+                    reason='reference checkout not present (GPU box)')
+def test_full_size_fixture_is_what_the_reference_code_computes_today():
+    gen = os.path.join(os.path.dirname(GOLDEN), 'make_float_golden_full.py')
+    p = subprocess.run([sys.executable, gen, '--check'], capture_output=True, text=True,
+                       env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
