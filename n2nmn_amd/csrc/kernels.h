@@ -39,6 +39,10 @@ void launch_gemm_pk2(const GemmArgs& a0, const GemmArgs& a1, hipStream_t s);
 // up to four problems (no split-K) as one flat, XCD-ordered tile list
 struct GemmBatch { GemmArgs a[4]; int start[5]; };
 void launch_gemm_pkn(const GemmArgs* a, int n, hipStream_t s);
+// LDS-DMA-staged 128 x 128 tiles (kernels_gemm_dma.hip) for problems gemm_dma_supported() accepts;
+// launch_gemm_pkn / launch_gemm_pk route there when every problem of the launch qualifies
+bool gemm_dma_supported(const GemmArgs& a);
+void launch_gemm_dma(const GemmArgs* a, int n, hipStream_t s);
 
 // generic packer: dst PK layout <- src[k*ld + n] (k < K, n < N), zero padded
 void launch_pack_pk(const float* src, int ld, int K, int N, float* dst, int Kp, int Np,

@@ -20,6 +20,7 @@
 //   * register-staged double buffering: global loads of tile t+1 are in flight during the MFMAs
 //     of tile t; one barrier per k-tile.
 #include <algorithm>
+#include <cstdlib>
 
 #include "device_utils.h"
 #include "kernels.h"
@@ -363,7 +364,20 @@ void launch_gemm_pk2(const GemmArgs& a0, const GemmArgs& a1, hipStream_t s) {
   hipLaunchKernelGGL(gemm_pk2_kernel, dim3(gx, gy, 2), dim3(256), 0, s, a0, a1);
 }
 
+static bool use_gemm_dma(const GemmArgs* a, int n) {
+  static const int on = [] { const char* e = getenv("N2NMN_GEMM_DMA"); return e ? atoi(e) : 1; }();
+  if (!on) return false;
+  bool any = false;
+  for (int i = 0; i < n; ++i) {
+    if (a[i].M <= 0) continue;
+    if (!gemm_dma_supported(a[i])) return false;
+    any = true;
+  }
+  return any;
+}
+
 void launch_gemm_pkn(const GemmArgs* a, int n, hipStream_t s) {
+  if (use_gemm_dma(a, n)) { launch_gemm_dma(a, n, s); return; }
   GemmBatch b{};
   int tiles = 0, np = 0;
   for (int i = 0; i < n && np < 4; ++i) {
@@ -379,6 +393,7 @@ void launch_gemm_pkn(const GemmArgs* a, int n, hipStream_t s) {
 }
 
 void launch_gemm_pk(const GemmArgs& a, hipStream_t s) {
+  if (a.M >= 2048 && use_gemm_dma(&a, 1)) { launch_gemm_dma(&a, 1, s); return; }
   dim3 grid((a.n_store + BN - 1) / BN, (a.M + BM - 1) / BM, a.ksplit > 1 ? a.ksplit : 1);
   if (a.M <= 0) return;
   hipLaunchKernelGGL(gemm_pk_kernel, grid, dim3(256), 0, s, a);

@@ -12,9 +12,12 @@ TOL = 1e-4
 
 @pytest.mark.parametrize('M,N,K', [(64, 64, 32), (82, 2048, 300), (150, 250, 512), (1, 15, 4),
                                    (257, 130, 100), (2880, 512, 512), (19250, 250, 512),
-                                   (20011, 512, 300), (19200, 200, 64)])
+                                   (20011, 512, 300), (19200, 200, 64), (4100, 1024, 2064),
+                                   (2048, 100, 36), (2049, 384, 512)])
 def test_gemm_matches_fp64(clevr_engine, M, N, K):
-    """(tall cases included: conv_image at super-bucket sizes has M = 38400 and more)"""
+    """(tall cases included: conv_image at super-bucket sizes has M = 38400 and more.  M >= 2048 with
+    a packed width that is a multiple of 128 runs gemm_dma_kernel -- ragged last row tile, K tails
+    (300, 2064, 36: not multiples of the 32-k stage), models_vqa's 2064 x 1024 -- the rest gemm_pk)"""
     eng = clevr_engine[0]
     rng = np.random.default_rng(M * 7 + N)
     A = rng.standard_normal((M, K)).astype(np.float32)
