@@ -494,7 +494,8 @@ int n2nmn_debug_colsum(n2nmn_ctx *ctx, const float *src, int R, int ncols, int l
  * n2nmn_profile_* table carries on top of its kernel's duration. */
 int n2nmn_debug_event_overhead(n2nmn_ctx *ctx, int iters, double *us_pair, n2nmn_stream stream);
 /* Re-launch one kernel of the LAST n2nmn_walk_layouts call `iters` times back to back inside one HIP
- * event pair (which: 0 walker, 1 deferred pooling kernel, 2 heads kernel; | 0x10: one event pair PER
+ * event pair (which: 0 walker, 1 deferred pooling kernel, 2 heads kernel, 3 walk_find_kernel, 4
+ * walk_tmap_kernel; | 0x10: one event pair PER
  * launch instead, which measures what a pair adds to this kernel) and return the average
  * microseconds per launch: the live duration the roofline of short kernels is computed from (an
  * event pair around a single ~5 us launch reads ~4 us too much).  Inputs must still be alive. */

@@ -1350,6 +1350,7 @@ int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int
       launch_walk_find(w, a, s);
     }
     a.pre_find = 1;
+    c->last_walk_T_enc = a.T_enc;
     a.T_enc = 0;                 // the walker reads tmap instead of building the maps itself
   }
   {
@@ -1398,8 +1399,10 @@ int n2nmn_debug_event_overhead(n2nmn_ctx* c, int iters, double* us_pair, n2nmn_s
 int n2nmn_debug_walk_replay(n2nmn_ctx* c, int which, int iters, double* us_avg, n2nmn_stream stream) {
   N2_REQUIRE(c && us_avg && iters >= 1 && iters <= 10000, N2NMN_EINVAL, "debug_walk_replay: bad argument");
   N2_REQUIRE(c->have_last_walk, N2NMN_EINVAL, "debug_walk_replay: no walker launch to replay");
-  N2_REQUIRE(which == 0 || c->last_walk.defer_pool, N2NMN_EINVAL,
+  N2_REQUIRE(((which & 0xf) != 1 && (which & 0xf) != 2) || c->last_walk.defer_pool, N2NMN_EINVAL,
              "debug_walk_replay: the last launch did not defer its pooling jobs");
+  N2_REQUIRE((which & 0xf) < 3 || c->last_walk.pre_find, N2NMN_EINVAL,
+             "debug_walk_replay: the last launch ran its front end inside the walker");
   hipStream_t s = S(stream);
   ModuleWeights w = module_weights(c);
   WalkArgs a = c->last_walk;
@@ -1409,7 +1412,9 @@ int n2nmn_debug_walk_replay(n2nmn_ctx* c, int which, int iters, double* us_avg, 
   auto one = [&]() {
     if (which == 0) launch_walk(w, a, s);
     else if (which == 1) launch_walk_pool(w, a, s);
-    else launch_walk_heads(w, a, s);
+    else if (which == 2) launch_walk_heads(w, a, s);
+    else if (which == 3) launch_walk_find(w, a, s);
+    else { WalkArgs t = a; t.T_enc = c->last_walk_T_enc; launch_walk_tmap(w, t, s); }
   };
   for (int i = 0; i < 3; ++i) one();
   std::vector<hipEvent_t> ev(pairs ? 2 * (size_t)iters : 2);

@@ -222,6 +222,7 @@ struct n2nmn_ctx {
   long prof_launches[24] = {0};
   WalkArgs last_walk{};                       // arguments of the last walker launch (debug replay)
   bool have_last_walk = false;
+  int last_walk_T_enc = 0;                    // T_enc of the last chip-wide front end (debug replay)
   int walk_pre_find = -1;                     // -1 auto (>= 128 questions), 0 in the walker, 1 chip-wide
   int walk_defer_pool = -1;                   // -1 auto (>= 128 questions per launch), 0 never, 1 always
   double walk_jobs_deferred = 0;              // pooling jobs of the last profiled passes
