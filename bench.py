@@ -313,9 +313,11 @@ def vqa_numbers(args, dp, local_rank, steps, warmup, profile=True):
                             seq_length_batch=torch.as_tensor(lens).to(dev),
                             image_feat_batch=feat.to(dev)))
         order = rng.permutation(100)
-        gts.append(torch.as_tensor(np.array(
+        # host arrays, as the reference's data reader delivers gt_layout_batch: the program is
+        # assembled from them up front and nothing synchronises inside a step
+        gts.append(np.ascontiguousarray(np.array(
             [eng.assembler.module_list2tokens(mix[order[n % 100]], d.T_decoder) for n in range(d.N)],
-            np.int32).T).to(dev))
+            np.int32).T))
 
     def run_steps(first, count):
         for i in range(first, first + count):

@@ -204,12 +204,23 @@ class VQAEngine:
                 use_qpn: bool = True):
         """phase 1 -> token fetch -> assemble -> phase 2 (+ question prior).  Returns (scores device
         tensor [N, num_choices], tokens, validity) -- scores = scores_nmn + scores_qpn
-        (models_vqa/nmn3_model.py:106-114); the eval script's `scores[:, 0] = -1e10` is the caller's."""
+        (models_vqa/nmn3_model.py:106-114); the eval script's `scores[:, 0] = -1e10` is the caller's.
+
+        With use_gt_layout and a HOST gt_layout (numpy, as the reference's data reader delivers it,
+        util/vqa_train/data_reader.py) the predicted tokens ARE the ground-truth layout
+        (models_vqa/nmn3_netgen_att.py: teacher forcing), so the program is assembled from the host
+        copy up front and the call has no host synchronisation (no token fetch)."""
         e = self.engine
+        known = use_gt_layout and isinstance(gt_layout, np.ndarray) and forced_tokens is None
+        if known:
+            tokens = np.ascontiguousarray(gt_layout, np.int32)
+            packed, validity = self.assembler.assemble_packed(tokens)
+            gt_dev = e.upload_i32(tokens)
         s2s = e.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], self.dims.T_decoder,
-                        use_gt_layout, gt_layout, None, forced_tokens)
-        tokens = s2s['predicted_tokens'].cpu().numpy()
-        packed, validity = self.assembler.assemble_packed(tokens)
+                        use_gt_layout, gt_dev if known else gt_layout, None, forced_tokens)
+        if not known:
+            tokens = s2s['predicted_tokens'].cpu().numpy()
+            packed, validity = self.assembler.assemble_packed(tokens)
         feat_c = self.features_with_coords(batch['image_feat_batch'])
         scores = e.execute(packed, feat_c, s2s['word_vecs'])
         if use_qpn and self.dims.qpn_hidden > 0:
