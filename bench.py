@@ -216,7 +216,9 @@ def train_numbers(args, dp, local_rank, steps, warmup, profile=True, cpu=True):
     w = synth.make_weights(d, seed=0)          # identical replicas on every rank
     eng.load_weights(w)
     dev = eng.device
-    tr = Trainer(eng, dist=dp._dist)
+    # one rank: no process group on the data path at all (a 1-rank RCCL communicator would only add
+    # its start-up banner to this script's one-line stdout)
+    tr = Trainer(eng, dist=dp._dist if world > 1 else None)
     n_batches = 4
     batches, gts = [], []
     for i in range(n_batches):
