@@ -404,9 +404,19 @@ int n2nmn_grad_layout(const n2nmn_ctx *ctx, int variable, int64_t *offset, int64
 int n2nmn_train_forward(n2nmn_ctx *ctx, const n2nmn_train_io *io, n2nmn_program *p,
                         n2nmn_stream stream);
 /* phase 0: module network + decoder (zeroes io->grads first); phase 1: encoder.  Must follow
- * n2nmn_train_forward with the same io / program, in this order, on the same stream. */
+ * n2nmn_train_forward with the same io / program, in this order, on the same stream.
+ * The weight-gradient GEMMs are leaves of the backward graph and run on a library-owned side stream
+ * under the latency-bound chains (attention backward, both reverse-time recurrences).  By default
+ * each phase ends with `stream` waiting for them, so the bucket that phase completes is final in
+ * stream order.  phase = 0 | N2NMN_BWD_DEFER_JOIN skips that wait: the encoder's backward (phase 1)
+ * then starts while the decoder's weight gradients and the finish of the late bucket are still
+ * running; the late bucket is final for a stream only after n2nmn_train_join(ctx, that stream) --
+ * n2nmn_allreduce_grads does this itself -- or after phase 1, which always joins. */
+#define N2NMN_BWD_DEFER_JOIN 0x10
 int n2nmn_train_backward(n2nmn_ctx *ctx, const n2nmn_train_io *io, n2nmn_program *p, int phase,
                          n2nmn_stream stream);
+/* `stream` waits for everything n2nmn_train_backward has put on its side stream so far */
+int n2nmn_train_join(n2nmn_ctx *ctx, n2nmn_stream stream);
 /* out[i] = u_i < keep_prob ? 1 / keep_prob : 0 for i in [0, n), u_i the element offset + i of the
  * counter-based stream `seed` (tf.nn.dropout / DropoutWrapper draw from TF's RNG,
  * models_vqa/question_prior_net.py:22-26, models_vqa/nmn3_netgen_att.py:27): the multiplier buffers

@@ -112,6 +112,7 @@ SYMBOLS = [
     ('n2nmn_grad_layout', _I, [_P, _I, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ('n2nmn_train_forward', _I, [_P, C.POINTER(TrainIO), _P, _P]),
     ('n2nmn_train_backward', _I, [_P, C.POINTER(TrainIO), _P, _I, _P]),
+    ('n2nmn_train_join', _I, [_P, _P]),
     ('n2nmn_adam_step', _I, [_P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                              C.c_float, C.c_int64, _P]),
     ('n2nmn_dropout_multipliers', _I, [_P, C.c_int64, C.c_float, C.c_uint64, C.c_uint64, _P]),

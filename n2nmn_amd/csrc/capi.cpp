@@ -165,6 +165,7 @@ static size_t carve_weights(n2nmn_ctx* c, char* base) {
   for (int i = 0; i < 3; ++i) c->we_pad[i] = k.take<float>(Mp);
   for (int i = 0; i < 4; ++i) c->batt_pad[i] = k.take<float>(Mp);
   c->packs.dev = k.take<PackJob>(kMaxPackJobs);
+  c->packs_infer.dev = k.take<PackJob>(8);
   c->P = k.take<int32_t>(V * 3);
   c->Wv = k.take<int32_t>(3 * V * 4);
   c->bv = k.take<int32_t>(V * 4);
@@ -321,6 +322,7 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmAr
   N2_REQUIRE(is_committed(c), N2NMN_ENOWEIGHT, "encoder_forward: weights not committed");
   N2_REQUIRE(io && io->input_seq && io->seq_length, N2NMN_EINVAL, "encoder_forward: null input");
   const int T = io->T_enc, N = io->N, L = d.lstm_dim;
+  train_infer_wait(root(c), s);
   N2_REQUIRE(T >= 1 && T <= d.T_encoder && N >= 1 && N <= d.N, N2NMN_ECAPACITY,
              "encoder_forward: T_enc / N exceed the context capacity");
   N2_REQUIRE(!(io->drop_enc0 || io->drop_dec0) || c->ehd[0], N2NMN_EINVAL,
@@ -442,6 +444,7 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
   N2_REQUIRE(has_tables(c), N2NMN_ENOWEIGHT,
              "decoder_forward: validity tables (assembler P/W/b) not set");
   N2_REQUIRE(io, N2NMN_EINVAL, "decoder_forward: null io");
+  train_infer_wait(root(c), s);
   N2_REQUIRE(c->enc_T > 0 && io->N == c->enc_N && io->T_enc == c->enc_T, N2NMN_EINVAL,
              "decoder_forward: no matching encoder results in the context");
   const int T = c->enc_T, N = c->enc_N, L = d.lstm_dim, Td = io->T_dec, V = d.num_vocab_nmn;
@@ -1070,10 +1073,14 @@ int n2nmn_commit_weights(n2nmn_ctx* c, n2nmn_stream stream) {
     pb.tiles(m(V_DEC_W0), 4 * L, E, L, L / 4, L, c->dec_W0h_t);
     pb.tiles(m(V_DEC_W1), 4 * L, 0, 2 * L, L / 4, L, c->dec_W1_t);
     if (c->enc_W0h_64) {
-      pb.tiles64(m(V_ENC_W0), 4 * L, E, L, L, c->enc_W0h_64);
-      pb.tiles64(m(V_ENC_W1), 4 * L, 0, 2 * L, L, c->enc_W1_64);
-      pb.tiles64(m(V_DEC_W0), 4 * L, E, L, L, c->dec_W0h_64);
-      pb.tiles64(m(V_DEC_W1), 4 * L, 0, 2 * L, L, c->dec_W1_64);
+      // operands of lstm_tile_kernel (passes of >= 128 rows): a batch of their own -- a training step
+      // (64 rows) commits every iteration and never reads them, see below
+      PackBatch& pi = c->packs_infer;
+      pi.tiles64(m(V_ENC_W0), 4 * L, E, L, L, c->enc_W0h_64);
+      pi.tiles64(m(V_ENC_W1), 4 * L, 0, 2 * L, L, c->enc_W1_64);
+      pi.tiles64(m(V_DEC_W0), 4 * L, E, L, L, c->dec_W0h_64);
+      pi.tiles64(m(V_DEC_W1), 4 * L, 0, 2 * L, L, c->dec_W1_64);
+      N2_HIP(hipMemcpy(pi.dev, pi.jobs.data(), sizeof(PackJob) * pi.jobs.size(), hipMemcpyHostToDevice));
     }
     pb.pk(m(V_EHT_W), L, L, L, c->eht_W_p, c->KpL, L);
     pb.tiles(m(V_ATT_W), L, 0, L, L / 16, 0, c->att_W_t);
@@ -1133,14 +1140,22 @@ int n2nmn_commit_weights(n2nmn_ctx* c, n2nmn_stream stream) {
   if (!c->big_vocab) launch_gemm_pk(g, s);
   g.A = c->dec_emb_cat; g.M = V + 1; g.Bp = c->dec_W0x_p; g.bias = c->dec_b0_t; g.C = c->dec_xtab;
   launch_gemm_pk(g, s);
+  // What only inference reads -- the 64-column recurrent tiles of passes >= 128 rows and the
+  // walker's text-map tables -- is refreshed on the training step's side stream when the context
+  // trains (a commit per iteration: ~75 us that the next forward pass, the level path at 64 rows, would
+  // otherwise wait for); encoder / decoder / walker entry points wait for it (train_infer_wait).
+  hipStream_t si = train_infer_fork(c, s);
+  if (!c->packs_infer.jobs.empty())
+    launch_pack_jobs(c->packs_infer.dev, (int)c->packs_infer.jobs.size(), c->packs_infer.blocks, si);
   for (int i = 0; i < 5; ++i) {        // ew[ws] = embedding_mat . W_txt[ws]  (walker text maps)
     if (!c->ew[i]) continue;
     GemmArgs t{};
     t.A = m(V_ENC_EMB); t.lda = E; t.M = d.num_vocab_txt; t.K = E; t.group_size = 1;
     t.Bp = c->wtxt_pk[i]; t.Np = c->Mp; t.Kp = c->KpE; t.bias = nullptr; t.N = d.map_dim;
     t.C = c->ew[i]; t.ldc = c->Mp; t.n_store = c->Mp;
-    launch_gemm_pk(t, s);
+    launch_gemm_pk(t, si);
   }
+  train_infer_done(c, si);
   c->committed = true;
   c->commit_epoch++;
   c->enc_T = 0;
@@ -1292,6 +1307,7 @@ int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int
   N2_REQUIRE(T_dec >= 1 && T_dec <= d.T_decoder && T_dec <= WALK_MAX_T, N2NMN_ECAPACITY,
              "walk_layouts: T_dec > capacity");
   WalkArgs a{};
+  train_infer_wait(root(c), S(stream));
   const bool use_table = batches[0].atts != nullptr;
   N2_REQUIRE(!use_table || root(c)->ew[0], N2NMN_EINVAL,
              "walk_layouts: attention-table text maps need num_vocab_txt <= 4096");

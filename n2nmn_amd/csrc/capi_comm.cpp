@@ -144,6 +144,7 @@ int n2nmn_allreduce_grads(n2nmn_ctx* ctx, n2nmn_comm* comm, int bucket, float* g
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   N2_HIP(hipEventRecord(comm->fork, s));                   // the gradients of this bucket are final
   N2_HIP(hipStreamWaitEvent(comm->side, comm->fork, 0));
+  n2nmn::train_side_join(ctx, comm->side);                 // (N2NMN_BWD_DEFER_JOIN: leaves still in flight)
   N2_NCCL(rccl().AllReduce(p, p, n, ncclFloat32, ncclSum, comm->comm, comm->side));
   N2_HIP(hipEventRecord(comm->done[bucket], comm->side));
   comm->pending[bucket] = true;

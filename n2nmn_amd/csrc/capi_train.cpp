@@ -7,8 +7,10 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -28,7 +30,10 @@ struct TrainState {
         *dmfind = nullptr, *dmfsp = nullptr, *dwv = nullptr, *datts_wv = nullptr, *dE = nullptr, *de = nullptr,
         *dctx = nullptr, *dq = nullptr, *dout = nullptr, *dvp = nullptr, *deht = nullptr,
         *denc_out = nullptr;
-  float *dz0_all = nullptr, *dz1_all = nullptr;
+  float *dz0_all = nullptr, *dz1_all = nullptr;     // encoder: dz of every step, row-major
+  // the decoder's own (its weight-gradient GEMMs read them on the side stream while the encoder's
+  // reverse-time pass is already writing dz0_all / dz1_all)
+  float *ddz0_all = nullptr, *ddz1_all = nullptr;
   // models_vqa: large answer head and question prior net as batch GEMMs
   int Cp = 0;                         // num_choices rounded up to 4 (row stride of ds_pad)
   float *ds_pad = nullptr;            // [N][Cp] zero-padded dscores
@@ -42,6 +47,11 @@ struct TrainState {
   float *dxtab_enc = nullptr, *dxtab_dec = nullptr;
   int32_t* dec_xidx = nullptr;
   int32_t *act_rows = nullptr, *act_count = nullptr;   // encoder rows (t, n) with t < len[n]
+  // the same rows per time chunk (list ci at act_rows_ch + chunk_start[ci]*N, length act_count[1+ci]):
+  // the encoder's weight-gradient GEMMs follow its reverse-time recurrence chunk by chunk
+  int32_t* act_rows_ch = nullptr;
+  int chunk_start[4] = {0, 0, 0, 0};
+  bool deferred = false;              // phase 0 left its leaves on the side stream (n2nmn_train_join)
   // transposed operand packs (rebuilt after every weight commit)
   float *enc_Wt1 = nullptr, *enc_Wt0 = nullptr, *dec_Wt1 = nullptr, *dec_Wt0 = nullptr;
   float *eht_WT_p = nullptr, *att_WT_p = nullptr, *enc_W0xT_p = nullptr, *dec_W0xT_p = nullptr;
@@ -68,6 +78,8 @@ struct TrainState {
   static constexpr int kForkEvents = 16;
   hipEvent_t ev_fork[kForkEvents] = {};
   hipEvent_t ev_join = nullptr;
+  hipEvent_t infer_ev = nullptr;      // after the last commit's inference-only operand refresh
+  bool infer_pending = false;
   int fork_i = 0;
   bool overlap = true;
   // side stream runs everything enqueued on `main` so far before its next kernel
@@ -79,6 +91,15 @@ struct TrainState {
     (void)hipStreamWaitEvent(side, e, 0);
     return side;
   }
+  // workgroups a background GEMM may keep resident (launch_gemm_tn's max_resident): 3 per CU leave
+  // room for a whole workgroup of whatever the latency-bound chain launches next
+  int bg_wgs = 768;
+  // 1: the recurrences' weight gradients follow them on the side stream (decoder: after its last
+  // step, under the encoder's pass; encoder: chunk by chunk); 0: on the caller's stream after each
+  // recurrence (round 2's schedule).  N2NMN_TRAIN_SCHEDULE
+  int schedule = 1;
+  int chunk_pct[3] = {33, 0, 0};
+  int bg(hipStream_t s) const { return overlap && side && s == side ? bg_wgs : 0; }
   // `main` waits for everything enqueued on the side stream so far
   void join(hipStream_t main) {
     if (!overlap || !side) return;
@@ -87,6 +108,26 @@ struct TrainState {
   }
 };
 
+void train_side_join(n2nmn_ctx* c, hipStream_t waiter) {
+  if (c && c->train) c->train->join(waiter);
+}
+
+hipStream_t train_infer_fork(n2nmn_ctx* c, hipStream_t s) {
+  return c->train && c->train->infer_ev ? c->train->fork(s) : s;
+}
+
+void train_infer_done(n2nmn_ctx* c, hipStream_t side) {
+  TrainState* t = c->train;
+  if (!t || !t->infer_ev || !t->overlap || side != t->side) return;
+  (void)hipEventRecord(t->infer_ev, side);
+  t->infer_pending = true;
+}
+
+void train_infer_wait(const n2nmn_ctx* root, hipStream_t s) {
+  const TrainState* t = root->train;
+  if (t && t->infer_pending) (void)hipStreamWaitEvent(s, t->infer_ev, 0);
+}
+
 void train_state_destroy(TrainState* t) {
   if (!t) return;
   if (t->base) (void)hipFree(t->base);
@@ -94,6 +135,7 @@ void train_state_destroy(TrainState* t) {
   if (t->tab_ev) (void)hipEventDestroy(t->tab_ev);
   for (hipEvent_t e : t->ev_fork) if (e) (void)hipEventDestroy(e);
   if (t->ev_join) (void)hipEventDestroy(t->ev_join);
+  if (t->infer_ev) (void)hipEventDestroy(t->infer_ev);
   if (t->side) (void)hipStreamDestroy(t->side);
   delete t;
 }
@@ -108,7 +150,6 @@ size_t carve_train(n2nmn_ctx* c, TrainState* t, char* base) {
                V = d.num_vocab_nmn, Vt = d.num_vocab_txt, D = d.D, HW = (size_t)d.H * d.W,
                C = d.num_choices;
   const size_t Mp = c->Mp, HWp = c->HWp;
-  const size_t Tm = std::max(T, Td);
   Carver k(base);
   TrainRec& r = t->rec;
   r.eg0 = k.take<float4>(T * N * L); r.eg1 = k.take<float4>(T * N * L);
@@ -141,7 +182,7 @@ size_t carve_train(n2nmn_ctx* c, TrainState* t, char* base) {
   t->dC0 = k.take<float>(N * L); t->dC1 = k.take<float>(N * L);
   t->dxtab_enc = c->big_vocab ? nullptr : k.take<float>(Vt * 4 * L);
   t->dxtab_dec = k.take<float>((V + 1) * 4 * L);
-  t->act_count = k.take<int32_t>(4);
+  t->act_count = k.take<int32_t>(8);
   if (c->big_heads) {
     t->hb_en = k.take<float>(N * Mp);
     t->hb_sel = k.take<int32_t>(N);
@@ -172,14 +213,17 @@ size_t carve_train(n2nmn_ctx* c, TrainState* t, char* base) {
   t->dvp = k.take<float>(Td * N * L);
   t->deht = k.take<float>(T * N * L);
   t->denc_out = k.take<float>(T * N * L);
-  t->dz0_all = k.take<float>(Tm * N * 4 * L);
-  t->dz1_all = k.take<float>(Tm * N * 4 * L);
+  t->dz0_all = k.take<float>(T * N * 4 * L);
+  t->dz1_all = k.take<float>(T * N * 4 * L);
+  t->ddz0_all = k.take<float>(Td * N * 4 * L);
+  t->ddz1_all = k.take<float>(Td * N * 4 * L);
   for (int i = 0; i < 2; ++i) {
     t->dzk0[i] = k.take<float>(4 * L * N);
     t->dzk1[i] = k.take<float>(4 * L * N);
   }
   t->dec_xidx = k.take<int32_t>(Td * N);
   t->act_rows = k.take<int32_t>(T * N);
+  t->act_rows_ch = k.take<int32_t>(T * N);
   t->enc_Wt1 = k.take<float>(L * 4 * L); t->enc_Wt0 = k.take<float>(L * 8 * L);
   t->dec_Wt1 = k.take<float>(L * 4 * L); t->dec_Wt0 = k.take<float>(L * 8 * L);
   t->eht_WT_p = k.take<float>((size_t)c->KpL * L);
@@ -256,7 +300,7 @@ int gemm_tn(n2nmn_ctx* c, hipStream_t s, const float* A, int lda, int M, const f
   g.A = A; g.lda = lda; g.M = M; g.a_group_idx = a_idx; g.a_group_size = a_gs;
   g.B = B; g.ldb = ldb; g.N = N; g.b_sel = b_sel; g.b_sel_val = b_val; g.R = R; g.C = C; g.ldc = ldc;
   ProfScope ps(c, F_GEMM_TN, 2.0 * M * N * R, 4.0 * ((double)R * (M + N) + (double)M * N), s);
-  launch_gemm_tn(g, s);
+  launch_gemm_tn(g, s, c->train->bg(s));
   return N2NMN_OK;
 }
 
@@ -277,7 +321,7 @@ void gemm_tn_batch(n2nmn_ctx* c, hipStream_t s, int nprob, const TnProblem* pr, 
   g.A = pr[0].A; g.B = pr[0].B;
   ProfScope ps(c, F_GEMM_TN, 2.0 * M * N * R * nprob,
                4.0 * nprob * ((double)R * (M + N) + (double)M * N), s);
-  launch_gemm_tn(g, s);
+  launch_gemm_tn(g, s, c->train->bg(s));
 }
 
 // C (+)= A[M,K] . Bp   (NT GEMMs of the backward pass go through the forward gemm_pk kernel)
@@ -311,13 +355,27 @@ struct BpttArgs {
   const float* dout;            // [T][N][L] gradient arriving at the top layer's outputs
   const float *Wt0, *Wt1;
   const float* drop0;           // [T][N][L] dropout multipliers of layer 0's output, or nullptr
+  float *dz0_all, *dz1_all;     // [T][N][4L] out: dz of every step (operands of the weight gradients)
+  // length-sorted pass (encoder): the forward's row ranking and per-step active-row counts
+  const int32_t *perm, *nact;   // [N], [T], or nullptr
 };
 
-int run_bptt(n2nmn_ctx* c, const BpttArgs& a, hipStream_t s) {
+// after_step(t0): called after the launch that completes step t0 of BOTH layers (dz0 rows of t >= t0
+// and dz1 rows of t >= t0 - 1 are then enqueued on s)
+int run_bptt(n2nmn_ctx* c, const BpttArgs& a, hipStream_t s,
+             const std::function<void(int)>* after_step = nullptr) {
   TrainState* t = c->train;
   const int L = c->d.lstm_dim, R = c->d.N, N = a.N;
   const size_t nl = (size_t)N * L;
-  N2_HIP(hipMemsetAsync(t->dzk0[0], 0, sizeof(float) * 4 * (size_t)L * R, s));
+  if (a.perm) {
+    // row blocks outside their lengths never write their dz: all four ping-pong buffers start at zero
+    // (they are carved back to back: dzk0[0], dzk1[0], dzk0[1], dzk1[1])
+    char* b = reinterpret_cast<char*>(t->dzk0[0]);
+    char* e = reinterpret_cast<char*>(t->dzk1[1] + 4 * (size_t)L * R);
+    N2_HIP(hipMemsetAsync(b, 0, (size_t)(e - b), s));
+  } else {
+    N2_HIP(hipMemsetAsync(t->dzk0[0], 0, sizeof(float) * 4 * (size_t)L * R, s));
+  }
   const int last = a.T + (a.want_init_grad ? 1 : 0);
   for (int k = 0; k <= last; ++k) {
     LstmBwdJob jobs[2];
@@ -331,7 +389,8 @@ int run_bptt(n2nmn_ctx* c, const BpttArgs& a, hipStream_t s) {
     if (t1 >= 0) {
       j1.gates = a.g1 + (size_t)t1 * nl; j1.c_new = a.c1s + (size_t)(t1 + 1) * nl;
       j1.c_prev = a.c1s + (size_t)t1 * nl; j1.dout = a.dout + (size_t)t1 * nl;
-      j1.dz_rm = t->dz1_all + (size_t)t1 * N * 4 * L;
+      j1.dz_rm = a.dz1_all + (size_t)t1 * N * 4 * L;
+      if (a.perm) { j1.perm = a.perm; j1.n_act = a.nact + t1; }
     }
     LstmBwdJob& j0 = jobs[1];
     j0 = LstmBwdJob{};
@@ -342,14 +401,18 @@ int run_bptt(n2nmn_ctx* c, const BpttArgs& a, hipStream_t s) {
     if (t0 >= 0 && t0 < a.T) {
       j0.gates = a.g0 + (size_t)t0 * nl; j0.c_new = a.c0s + (size_t)(t0 + 1) * nl;
       j0.c_prev = a.c0s + (size_t)t0 * nl; j0.dout = nullptr;
-      j0.dz_rm = t->dz0_all + (size_t)t0 * N * 4 * L;
+      j0.dz_rm = a.dz0_all + (size_t)t0 * N * 4 * L;
       if (a.drop0) j0.drop = a.drop0 + (size_t)t0 * nl;
+      if (a.perm) { j0.perm = a.perm; j0.n_act = a.nact + t0; }
     }
     const double fl = 2.0 * N * L * ((j1.active && j1.gemm ? 4.0 * L : 0) + (j0.active ? 8.0 * L : 0));
     const double by = 4.0 * ((j1.active && j1.gemm ? 4.0 * L * L + 4.0 * N * L : 0) +
                              (j0.active ? 8.0 * L * L + 8.0 * N * L : 0) + 20.0 * N * L);
-    ProfScope ps(c, F_LSTM_BWD, fl, by, s);
-    launch_lstm_bwd_step(jobs, 2, N, L, s);
+    {
+      ProfScope ps(c, F_LSTM_BWD, fl, by, s);
+      launch_lstm_bwd_step(jobs, 2, N, L, s);
+    }
+    if (after_step && k >= 1 && t0 >= 0 && t0 < a.T) (*after_step)(t0);
   }
   return check_launch("train: bptt");
 }
@@ -429,8 +492,22 @@ int n2nmn_train_enable(n2nmn_ctx* c) {
     for (int i = 0; i < TrainState::kForkEvents; ++i)
       N2_HIP(hipEventCreateWithFlags(&t->ev_fork[i], hipEventDisableTiming));
     N2_HIP(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
+    N2_HIP(hipEventCreateWithFlags(&t->infer_ev, hipEventDisableTiming));
     const char* env = getenv("N2NMN_TRAIN_OVERLAP");
     t->overlap = !(env && env[0] == '0');
+    // models_vqa (lstm_dim 1024, 32-row backward tiles, GEMMs several times the size): its step
+    // measured 7.93 ms with unbounded background launches against 8.14 bounded (same box)
+    if (vqa_variant) t->bg_wgs = 0;
+    if (const char* e = getenv("N2NMN_TRAIN_BG_WGS")) t->bg_wgs = std::max(0, atoi(e));
+    if (const char* e = getenv("N2NMN_TRAIN_SCHEDULE")) t->schedule = atoi(e) != 0;
+    if (const char* e = getenv("N2NMN_TRAIN_CHUNKS")) {
+      int v[3] = {0, 0, 0};
+      const int got = sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]);
+      for (int i = 0; i < 3; ++i) {
+        const int hi = i == 0 ? 100 : t->chunk_pct[i - 1];
+        t->chunk_pct[i] = i < got ? std::min(std::max(v[i], 0), hi) : 0;
+      }
+    }
   }
   return N2NMN_OK;
 }
@@ -496,7 +573,9 @@ int n2nmn_train_forward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* p
   const int N = io->N, L = d.lstm_dim;
   const size_t nl = (size_t)N * L;
   if (t->pack_epoch != c->commit_epoch) {
-    rc = repack_transposed(c, s);
+    // only the backward pass reads the transposed packs: side stream (joined below, before the
+    // module network), off the forward's critical path
+    rc = repack_transposed(c, t->fork(s));
     if (rc != N2NMN_OK) return rc;
   }
   // slot 0 of the kept encoder sequences is the zero initial state.  Slot strides follow the actual
@@ -578,6 +657,8 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
                          n2nmn_stream stream) {
   int rc = check_train_io(c, io, pp, "train_backward");
   if (rc != N2NMN_OK) return rc;
+  const bool defer_join = (phase & N2NMN_BWD_DEFER_JOIN) != 0;
+  phase &= ~N2NMN_BWD_DEFER_JOIN;
   N2_REQUIRE(phase == 0 || phase == 1, N2NMN_EINVAL, "train_backward: phase must be 0 or 1");
   TrainState* t = c->train;
   Program& p = pp->prog;
@@ -711,7 +792,7 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
                 }
                 ProfScope ps(c, F_GEMM_TN, 2.0 * D * M * 2.0 * p.num_pool,
                              4.0 * (2.0 * p.num_pool * (D + Mp) + 4.0 * D * M), sd);
-                launch_gemm_tn(ga, sd);
+                launch_gemm_tn(ga, sd, t->bg(sd));
               }
             }
             if (l.kind == LK_TEXTMAP) {
@@ -734,7 +815,7 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
                 }
                 ProfScope ps(c, F_GEMM_TN, 2.0 * E * M * (double)p.num_text,
                              4.0 * (p.num_text * (double)(E + Mp) + 5.0 * E * M), sd);
-                launch_gemm_tn(ga, sd);
+                launch_gemm_tn(ga, sd, t->bg(sd));
               }
             } else {
               const bool fsp = l.kind == LK_CONV_FSP;
@@ -772,7 +853,13 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
     // ------------------------------- decoder ----------------------------------------------
     // rows (tau, n) inside the question's length: reduction index of every encoder-side weight
     // gradient (here the embedding gradient through word_vecs; in phase 1 the LSTM's)
-    launch_active_rows(io->seq_length, T, N, t->act_rows, t->act_count, s);
+    // chunk starts of the encoder's reverse-time pass (descending).  Every chunk is a launch that
+    // updates all of dW (fixed cost ~70 us whatever its rows), so there are few: by default
+    // [T/3, T) under the last third of the recurrence and [0, T/3) after it (N2NMN_TRAIN_CHUNKS =
+    // up to three descending percentages of T)
+    for (int i = 0; i < 4; ++i) t->chunk_start[i] = i < 3 ? T * t->chunk_pct[i] / 100 : 0;
+    launch_active_rows(io->seq_length, T, N, t->act_rows, t->act_count, t->act_rows_ch,
+                       t->chunk_start, s);
     {
       ProfScope ps(c, F_BWD_MISC, 4.0 * Td * T * N * E, 4.0 * N * (double)(2 * T * E + 2 * Td * E + 2 * Td * T), s);
       launch_word_vecs_bwd(t->dwv, c->atts, io->input_seq, io->seq_length, mir(V_ENC_EMB), Td, T, N,
@@ -788,7 +875,7 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
       g1.B = t->dE; g1.ldb = E; g1.N = E; g1.R = T * N; g1.C = G(V_ENC_EMB); g1.ldc = E;
       g1.row_idx = t->act_rows; g1.r_dev = t->act_count;
       ProfScope ps(c, F_GEMM_TN, 2.0 * Vt * (double)E * T * N, 4.0 * ((double)T * N * E + Vt * (double)E), sd);
-      launch_gemm_tn(g1, sd);
+      launch_gemm_tn(g1, sd, t->bg(sd));
     }
     DecBwdArgs a{};
     a.scores = t->rec.tscores; a.gt = io->gt_layout; a.q = c->qbuf; a.eht = c->eht;
@@ -827,41 +914,49 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
     ba.T = Td; ba.N = N; ba.want_init_grad = true; ba.seq_len = nullptr;
     ba.g0 = t->rec.dg0; ba.g1 = t->rec.dg1; ba.c0s = t->rec.dc0s; ba.c1s = t->rec.dc1s;
     ba.dout = t->dout; ba.Wt0 = t->dec_Wt0; ba.Wt1 = t->dec_Wt1; ba.drop0 = io->drop_dec0;
+    ba.dz0_all = t->ddz0_all; ba.dz1_all = t->ddz1_all;
     rc = run_bptt(c, ba, s);
     if (rc != N2NMN_OK) return rc;
     if (c->qpn_h)                    // dH now holds the decoder's gradient of the encoder's final h
       launch_qpn_dh_add(t->qpn_dh, io->drop_qpn_h, t->dH0, t->dH1, N, L, s);
-    launch_dec_xidx(io->gt_layout, Td, N, V, t->dec_xidx, s);
+    // Everything below is a leaf of the backward graph (input-table, embedding and recurrent weight
+    // gradients of the decoder, then the finish of the late bucket): side stream.  With
+    // N2NMN_BWD_DEFER_JOIN the caller's stream does not wait for it here -- the encoder's backward
+    // (phase 1) starts at once and the late bucket is final after n2nmn_train_join / phase 1.
+    hipStream_t sl = t->schedule ? t->fork(s) : s;
+    launch_dec_xidx(io->gt_layout, Td, N, V, t->dec_xidx, sl);
     // gradient of the input-projection table: dxtab = onehot(idx)^T . dz0  (one-hot gemm_tn)
     {
       GemmTnArgs g1{};
       g1.A = nullptr; g1.lda = 0; g1.M = V + 1; g1.a_onehot = t->dec_xidx;
-      g1.B = t->dz0_all; g1.ldb = 4 * L; g1.N = 4 * L; g1.R = RT; g1.C = t->dxtab_dec; g1.ldc = 4 * L;
-      ProfScope ps(c, F_GEMM_TN, 2.0 * (V + 1) * 4.0 * L * RT, 4.0 * ((double)RT * 4 * L + (V + 1) * 4.0 * L), s);
-      launch_gemm_tn(g1, s);
+      g1.B = t->ddz0_all; g1.ldb = 4 * L; g1.N = 4 * L; g1.R = RT; g1.C = t->dxtab_dec; g1.ldc = 4 * L;
+      ProfScope ps(c, F_GEMM_TN, 2.0 * (V + 1) * 4.0 * L * RT, 4.0 * ((double)RT * 4 * L + (V + 1) * 4.0 * L), sl);
+      launch_gemm_tn(g1, sl, t->bg(sl));
     }
-    gemm_tn(c, s, c->dec_emb_cat, E, E, t->dxtab_dec, 4 * L, 4 * L, V + 1, G(V_DEC_W0), 4 * L,
+    gemm_tn(c, sl, c->dec_emb_cat, E, E, t->dxtab_dec, 4 * L, 4 * L, V + 1, G(V_DEC_W0), 4 * L,
             nullptr, 1, nullptr, 0, nullptr, nullptr, G(V_DEC_B0));
-    gemm_nt(c, s, t->dxtab_dec, 4 * L, V, 4 * L, t->dec_W0xT_p, Ep, t->KpL4, E, G(V_DEC_EMB), E, true);
-    gemm_nt(c, s, t->dxtab_dec + (size_t)V * 4 * L, 4 * L, 1, 4 * L, t->dec_W0xT_p, Ep, t->KpL4, E,
+    gemm_nt(c, sl, t->dxtab_dec, 4 * L, V, 4 * L, t->dec_W0xT_p, Ep, t->KpL4, E, G(V_DEC_EMB), E, true);
+    gemm_nt(c, sl, t->dxtab_dec + (size_t)V * 4 * L, 4 * L, 1, 4 * L, t->dec_W0xT_p, Ep, t->KpL4, E,
             G(V_DEC_GO), E, true);
     {
       // the three recurrent weight gradients of the stack, one launch: W0 (h part) = h0(t-1)^T dz0,
       // W1 = [h0(t) ; h1(t-1)]^T dz1 (+ b1)
       const TnProblem dw[3] = {
-          {t->rec.dh0s, t->dz0_all, G(V_DEC_W0) + (size_t)E * 4 * L, nullptr},
+          {t->rec.dh0s, t->ddz0_all, G(V_DEC_W0) + (size_t)E * 4 * L, nullptr},
           // layer 1 saw layer 0's output through the dropout multipliers
-          {io->drop_dec0 ? t->rec.dh0d : t->rec.dh0s + (size_t)N * L, t->dz1_all, G(V_DEC_W1), G(V_DEC_B1)},
-          {t->rec.dh1s, t->dz1_all, G(V_DEC_W1) + (size_t)L * 4 * L, nullptr}};
-      gemm_tn_batch(c, s, 3, dw, L, L, 4 * L, 4 * L, RT, 4 * L);
+          {io->drop_dec0 ? t->rec.dh0d : t->rec.dh0s + (size_t)N * L, t->ddz1_all, G(V_DEC_W1), G(V_DEC_B1)},
+          {t->rec.dh1s, t->ddz1_all, G(V_DEC_W1) + (size_t)L * 4 * L, nullptr}};
+      gemm_tn_batch(c, sl, 3, dw, L, L, 4 * L, 4 * L, RT, 4 * L);
     }
-    t->join(s);                        // decoder + module gradients complete from here on
-    {
-      ProfScope ps(c, F_OPTIMISER, 3.0 * (t->total - t->split), 4.0 * 3 * (t->total - t->split), s);
+    if (!t->schedule) { t->join(s); }  // (module / projection gradients ran on the side stream)
+    {                                  // decoder + module gradients complete: finish the late bucket
+      ProfScope ps(c, F_OPTIMISER, 3.0 * (t->total - t->split), 4.0 * 3 * (t->total - t->split), sl);
       launch_grad_finish(io->grads, (const float* const*)t->mirrors_dev, t->var_off_dev, t->decay_dev,
                          t->segs_dev + t->nsegs_early, t->nsegs - t->nsegs_early, 1.0f,
-                         io->weight_decay, io->losses + 2, s);
+                         io->weight_decay, io->losses + 2, sl);
     }
+    t->deferred = defer_join && t->schedule;
+    if (!t->deferred) t->join(s);
     return check_launch("train_backward(0)");
   }
 
@@ -880,39 +975,63 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
   ba.T = T; ba.N = N; ba.want_init_grad = false; ba.seq_len = io->seq_length;
   ba.g0 = t->rec.eg0; ba.g1 = t->rec.eg1; ba.c0s = t->rec.ec0s; ba.c1s = t->rec.ec1s;
   ba.dout = t->denc_out; ba.Wt0 = t->enc_Wt0; ba.Wt1 = t->enc_Wt1; ba.drop0 = io->drop_enc0;
-  rc = run_bptt(c, ba, s);
-  if (rc != N2NMN_OK) return rc;
-  t->join(s);                          // W_eht gradient (side stream) done
-  {
-    const int32_t* rows = t->act_rows;
-    const int32_t* cnt = t->act_count;
+  ba.dz0_all = t->dz0_all; ba.dz1_all = t->dz1_all;
+  ba.perm = c->perm; ba.nact = c->nact;
+  // The weight-gradient GEMMs follow the recurrence chunk by chunk on the side stream: when the
+  // step that starts chunk ci has been enqueued, dz0 / dz1 of the chunk's rows are complete, and its
+  // GEMMs (reduction over the chunk's own list of active rows; C += with atomics or, single split,
+  // in stream order) run under the remaining steps.  Only the last, shortest chunk is left for after
+  // the recurrence.  (Round 2 ran all of it after the last step: 240 us of a 2.75 ms step.)
+  auto chunk_grads = [&](int ci) {
+    const int beg = t->chunk_start[ci], end = ci == 0 ? T : t->chunk_start[ci - 1];
+    if (end <= beg) return;
+    hipStream_t sd = t->schedule ? t->fork(s) : s;
+    const int32_t* rows = t->act_rows_ch + (size_t)beg * N;
+    const int32_t* cnt = t->act_count + 1 + ci;
+    const int Rc = (end - beg) * N;
     if (c->big_vocab) {
-      // the layer-0 input weights and the embedding matrix straight from the batch's rows:
-      //   dW0[0:E] = emb[word_r]^T . dz0_r (+ db0);  dE_r += dz0_r . W0[0:E]^T;  demb[word_r] += dE_r
-      gemm_tn(c, s, mir(V_ENC_EMB), E, E, t->dz0_all, 4 * L, 4 * L, RT, G(V_ENC_W0), 4 * L,
+      // the layer-0 input weights straight from the batch's rows: dW0[0:E] = emb[word_r]^T . dz0_r (+ db0)
+      gemm_tn(c, sd, mir(V_ENC_EMB), E, E, t->dz0_all, 4 * L, 4 * L, Rc, G(V_ENC_W0), 4 * L,
               io->input_seq, 1, nullptr, 0, rows, cnt, G(V_ENC_B0));
-      gemm_nt(c, s, t->dz0_all, 4 * L, RT, 4 * L, t->enc_W0xT_p, Ep, t->KpL4, E, t->dE, E, true);
-      ProfScope ps(c, F_BWD_MISC, (double)RT * E, 4.0 * 2 * RT * E, s);
-      launch_embed_scatter(t->dE, io->input_seq, rows, cnt, RT, E, G(V_ENC_EMB), s);
     } else {
       GemmTnArgs g1{};
       g1.A = nullptr; g1.lda = 0; g1.M = Vt; g1.a_onehot = io->input_seq;
-      g1.B = t->dz0_all; g1.ldb = 4 * L; g1.N = 4 * L; g1.R = RT; g1.C = t->dxtab_enc; g1.ldc = 4 * L;
+      g1.B = t->dz0_all; g1.ldb = 4 * L; g1.N = 4 * L; g1.R = Rc; g1.C = t->dxtab_enc; g1.ldc = 4 * L;
       g1.row_idx = rows; g1.r_dev = cnt;
-      ProfScope ps(c, F_GEMM_TN, 2.0 * Vt * 4.0 * L * RT, 4.0 * ((double)RT * 4 * L + Vt * 4.0 * L), s);
-      launch_gemm_tn(g1, s);
+      ProfScope ps(c, F_GEMM_TN, 2.0 * Vt * 4.0 * L * Rc, 4.0 * ((double)Rc * 4 * L + Vt * 4.0 * L), sd);
+      launch_gemm_tn(g1, sd, t->bg(sd));
     }
     const TnProblem dw[3] = {
         {t->rec.eh0s, t->dz0_all, G(V_ENC_W0) + (size_t)E * 4 * L, nullptr},
         {io->drop_enc0 ? t->rec.eh0d : t->rec.eh0s + (size_t)N * L, t->dz1_all, G(V_ENC_W1), G(V_ENC_B1)},
         {t->rec.eh1s, t->dz1_all, G(V_ENC_W1) + (size_t)L * 4 * L, nullptr}};
-    gemm_tn_batch(c, s, 3, dw, L, L, 4 * L, 4 * L, RT, 4 * L, rows, cnt);
+    gemm_tn_batch(c, sd, 3, dw, L, L, 4 * L, 4 * L, Rc, 4 * L, rows, cnt);
+  };
+  const std::function<void(int)> after_step = [&](int t0) {
+    for (int ci = 0; ci < 4; ++ci)
+      if (t0 == t->chunk_start[ci] && (ci == 0 || t->chunk_start[ci] != t->chunk_start[ci - 1]))
+        chunk_grads(ci);
+  };
+  rc = run_bptt(c, ba, s, t->schedule ? &after_step : nullptr);
+  if (rc != N2NMN_OK) return rc;
+  if (!t->schedule)
+    for (int ci = 0; ci < 4; ++ci)
+      if (ci == 0 || t->chunk_start[ci] != t->chunk_start[ci - 1]) chunk_grads(ci);
+  {
+    hipStream_t sd = t->schedule ? t->fork(s) : s;       // (in stream order after the chunks)
+    if (c->big_vocab) {
+      // dE_r += dz0_r . W0[0:E]^T;  demb[word_r] += dE_r   (large vocabularies: scattered)
+      gemm_nt(c, sd, t->dz0_all, 4 * L, RT, 4 * L, t->enc_W0xT_p, Ep, t->KpL4, E, t->dE, E, true);
+      ProfScope ps(c, F_BWD_MISC, (double)RT * E, 4.0 * 2 * RT * E, sd);
+      launch_embed_scatter(t->dE, io->input_seq, t->act_rows, t->act_count, RT, E, G(V_ENC_EMB), sd);
+    } else {
+      gemm_tn(c, sd, mir(V_ENC_EMB), E, E, t->dxtab_enc, 4 * L, 4 * L, Vt, G(V_ENC_W0), 4 * L,
+              nullptr, 1, nullptr, 0, nullptr, nullptr, G(V_ENC_B0));
+      gemm_nt(c, sd, t->dxtab_enc, 4 * L, Vt, 4 * L, t->enc_W0xT_p, Ep, t->KpL4, E, G(V_ENC_EMB), E, true);
+    }
   }
-  if (!c->big_vocab) {
-    gemm_tn(c, s, mir(V_ENC_EMB), E, E, t->dxtab_enc, 4 * L, 4 * L, Vt, G(V_ENC_W0), 4 * L,
-            nullptr, 1, nullptr, 0, nullptr, nullptr, G(V_ENC_B0));
-    gemm_nt(c, s, t->dxtab_enc, 4 * L, Vt, 4 * L, t->enc_W0xT_p, Ep, t->KpL4, E, G(V_ENC_EMB), E, true);
-  }
+  t->join(s);                          // every weight gradient (side stream) done
+  t->deferred = false;
   {
     ProfScope ps(c, F_OPTIMISER, 3.0 * t->split, 4.0 * 3 * t->split, s);
     launch_grad_finish(io->grads, (const float* const*)t->mirrors_dev, t->var_off_dev, t->decay_dev,
@@ -921,6 +1040,12 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
   launch_loss_total(io->losses, io->weight_decay,
                     io->objective == N2NMN_OBJ_POLICY_GRADIENT ? io->lambda_entropy : 0.f, s);
   return check_launch("train_backward(1)");
+}
+
+int n2nmn_train_join(n2nmn_ctx* c, n2nmn_stream stream) {
+  N2_REQUIRE(c && c->train, N2NMN_EINVAL, "train_join: call n2nmn_train_enable first");
+  c->train->join(S(stream));
+  return N2NMN_OK;
 }
 
 int n2nmn_dropout_multipliers(float* out, int64_t n, float keep_prob, uint64_t seed, uint64_t offset,

@@ -156,6 +156,7 @@ struct n2nmn_ctx {
   float *eht_W_p = nullptr, *att_W_t = nullptr, *att_W_p = nullptr, *find_img_p = nullptr, *fsp_img_p = nullptr;
   float* dec_emb_cat = nullptr;
   PackBatch packs;                                   // every re-pack of a commit, one launch
+  PackBatch packs_infer;                             // ... except what only inference reads (64-column tiles)
   float *qpn_W1_p = nullptr, *qpn_W2_p = nullptr;    // PK packs of question_prior_net fc1 / fc2
   float *wans_sp_p = nullptr, *wans_de_p = nullptr;  // PK packs of fc_eltwise (large num_choices only)
   // question vocabularies beyond 4096 words (models_vqa: 17742): the layer-0 input projection is a
@@ -292,6 +293,14 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmAr
 int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const GemmArgs* pre = nullptr,
                  int npre = 0);
 void train_state_destroy(TrainState* t);
+// `waiter` waits for the training step's side stream (weight-gradient GEMMs, late-bucket finish)
+void train_side_join(n2nmn_ctx* c, hipStream_t waiter);
+// inference-only operand refresh of a commit (capi.cpp: n2nmn_commit_weights): the stream it runs on
+// (the training step's side stream, ordered after `s`; `s` itself when the context does not train),
+// the marker after it, and the wait of whoever reads those operands
+hipStream_t train_infer_fork(n2nmn_ctx* c, hipStream_t s);
+void train_infer_done(n2nmn_ctx* c, hipStream_t side);
+void train_infer_wait(const n2nmn_ctx* root, hipStream_t s);
 enum { RP_PREP = 1, RP_CONV = 2, RP_REST = 4, RP_ALL = 7 };
 int run_program(n2nmn_ctx* c, Program& p, const float* feat, const float* word_vecs, int N_full,
                 float* scores, const float* ext0, const float* ext1, float* att_out,

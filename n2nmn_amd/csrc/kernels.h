@@ -338,11 +338,16 @@ struct GemmTnArgs {
   float* C_p[6];
   float* colsum_p[6];
   int bsel_p[6];
+  // set by the launcher: a launch that covers z slices [z_off, z_off + gridDim.z) of z_total
+  int z_off, z_total;
 };
-void launch_gemm_tn(const GemmTnArgs& a, hipStream_t s);
+// max_resident > 0: a background GEMM (side stream, beside a latency-bound chain on the caller's
+// stream): issued as consecutive launches of at most that many workgroups, so that the chain's
+// kernels always find room on every CU instead of queueing behind 1024 resident GEMM workgroups
+void launch_gemm_tn(const GemmTnArgs& a, hipStream_t s, int max_resident = 0);
 // rows[0 .. *count) = { t*N + n : t < seq_len[n] } in any order; count must be zero on entry
 void launch_active_rows(const int32_t* seq_len, int T, int N, int32_t* rows, int32_t* count,
-                        hipStream_t s);
+                        int32_t* rows_ch, const int* chunk_start, hipStream_t s);
 // dst[c] += sum_r src[r*ld + c] (rows filtered by sel[r] == sel_val when sel != nullptr)
 void launch_colsum(const float* src, int R, int ncols, int ld, const int32_t* sel, int sel_val,
                    float* dst, hipStream_t s);
@@ -376,6 +381,12 @@ struct LstmBwdJob {
   float* dz_rm;           // out: row-major [N][4L], reference column order g*L+u
   const float* drop;      // [N][L] dropout multipliers of THIS layer's output at step t (or nullptr):
                           // the gradient arriving through A0 (the layer above) is scaled by them
+  // length-sorted rows (encoder): GEMM row / dz_k row r is question perm[r] (everything indexed [N][..]
+  // above is indexed by question), and only rows r < *n_act are inside their length at step t -- a row
+  // block past that returns at once: its dz is zero (dz_k cleared at the start of the pass) and its
+  // carried dH / dC stay as they are.  nullptr: r is the question, every row block runs.
+  const int32_t* perm;
+  const int32_t* n_act;
 };
 void launch_lstm_bwd_step(const LstmBwdJob* jobs, int njobs, int N, int L, hipStream_t s);
 

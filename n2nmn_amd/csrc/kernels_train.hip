@@ -17,6 +17,8 @@
 #include <type_traits>
 
 #include "device_utils.h"
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace n2nmn {
@@ -53,7 +55,8 @@ __global__ __launch_bounds__(256, WT == 1 ? 4 : 2) void gemm_tn_kernel(const Gem
   int Rtot = a.R;
   // blockIdx.z = split * nprob + problem
   const int nprob = a.nprob > 0 ? a.nprob : 1;
-  const int zp = blockIdx.z % nprob, zsplit = blockIdx.z / nprob, nsplit = gridDim.z / nprob;
+  const int bz = blockIdx.z + a.z_off;
+  const int zp = bz % nprob, zsplit = bz / nprob, nsplit = a.z_total / nprob;
   // (the argument block is never written: a modified by-value struct is copied to scratch memory)
   const bool multi = a.nprob > 0;
   const float* const Ain = multi ? a.A_p[zp] : a.A;
@@ -289,12 +292,24 @@ __global__ __launch_bounds__(256) void zero_ranges_kernel(ZeroRanges z) {
   }
 }
 
+// rows (t, n) inside the question's length, as one compacted list and -- for the weight-gradient
+// GEMMs that follow the reverse-time recurrence chunk by chunk -- as one list per time chunk:
+// chunk ci covers t in [st[ci], st[ci-1]) (st descending, st[-1] = T, st[3] = 0), its list starts at
+// rows_ch + st[ci]*N and its length is count[1 + ci]
 __global__ void active_rows_kernel(const int32_t* __restrict__ seq_len, int T, int N,
-                                   int32_t* __restrict__ rows, int32_t* __restrict__ count) {
+                                   int32_t* __restrict__ rows, int32_t* __restrict__ count,
+                                   int32_t* __restrict__ rows_ch, int4 st) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < T * N) {
     const int t = i / N, n = i - t * N;
-    if (t < seq_len[n]) rows[atomicAdd(count, 1)] = i;
+    if (t < seq_len[n]) {
+      rows[atomicAdd(count, 1)] = i;
+      if (rows_ch) {
+        const int ci = t >= st.x ? 0 : t >= st.y ? 1 : t >= st.z ? 2 : 3;
+        const int beg = ci == 0 ? st.x : ci == 1 ? st.y : ci == 2 ? st.z : st.w;
+        rows_ch[(size_t)beg * N + atomicAdd(count + 1 + ci, 1)] = i;
+      }
+    }
   }
 }
 
@@ -375,27 +390,54 @@ __global__ void pack_tiles_t_kernel(const float* __restrict__ W, int ld, int row
 // block is a single 16-row M tile: 2 jobs x 32 column tiles x N/16 row blocks = 256 workgroups.  Layer 0's job contracts over [dz1_{t}; dz0_{t+1}] (K = 8L) so that the gradient
 // from the layer above and the recurrent gradient come out of ONE accumulation.
 // ---------------------------------------------------------------------------------------------
-constexpr int BW_WAVES = 8;
-constexpr int BW_THREADS = BW_WAVES * 64;
-// BW_MT = 16-row M tiles per workgroup: 1 at lstm_dim 512 (256 workgroups per step); 2 at lstm_dim
-// 1024, where the column tiles alone give 128 workgroups per job and every workgroup re-streams its
-// K x 16 weight tile (512 KB for layer 0) -- twice the rows per tile halve that L2 traffic
-
+// BW_WAVES = waves that split K (template parameter).  A step moves 96 MB from L2 to the CUs at
+// lstm_dim 512 / 64 rows (every workgroup streams its 16 rows x K of dz and its K x 16 weight tile: 4
+// flops per byte), which is what bounds it -- not the bytes in flight: 16 waves (256 KiB in flight per
+// CU) measured 12.3 us per step against 11.7 for 8 (round 3, N2NMN_BWD_WAVES).
 struct LstmBwdJobs {
   LstmBwdJob j[2];
 };
 
-template <int BW_MT>
-__global__ __launch_bounds__(BW_THREADS) void lstm_bwd_step_kernel(LstmBwdJobs jobs, int N,
-                                                                   int L) {
+template <int BW_MT, int BW_WAVES>
+__global__ __launch_bounds__(BW_WAVES * 64) void lstm_bwd_step_kernel(LstmBwdJobs jobs, int N,
+                                                                      int L) {
   const LstmBwdJob& jb = jobs.j[blockIdx.y];
   if (!jb.active) return;
+  constexpr int BW_THREADS = BW_WAVES * 64;
   __shared__ float part[BW_WAVES][16 * BW_MT][17];
   constexpr int ROWS = 16 * BW_MT;
   const int tile = blockIdx.x;
   const int row0 = blockIdx.z * ROWS;
+  if (jb.n_act && row0 >= *jb.n_act) return;     // no row of this block is inside its length at step t
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int ci = lane & 15, kg = lane >> 4;
+
+  // The cell backward's operands (thread = (row, unit) of the tile) are requested BEFORE the
+  // contraction: they were written by the forward pass long ago and come from HBM, a latency the
+  // k loop covers instead of the epilogue paying it after the barrier.
+  const int erow = tid >> 4, ul = tid & 15;
+  const int es = row0 + erow;                    // GEMM row (slot); en = the question in it
+  static_assert(16 * 16 * BW_MT <= BW_THREADS, "one thread per (row, unit) of the tile");
+  const bool epi = erow < ROWS && es < N;
+  const int en = epi ? (jb.perm ? jb.perm[es] : es) : 0;
+  const int eu = 16 * tile + ul;
+  const size_t idx = (size_t)en * L + eu;
+  const bool two_src = jb.drop && jb.A1;
+  float4 e_g = make_float4(0.f, 0.f, 0.f, 0.f);
+  float e_cn = 0.f, e_cp = 0.f, e_dC = 0.f, e_dH = 0.f, e_dout = 0.f, e_drop = 1.f;
+  int e_len = jb.T;
+  if (epi) {
+    if (jb.seq_len) e_len = jb.seq_len[en];
+    e_dH = jb.dH[idx];
+    if (two_src) e_drop = jb.drop[idx];
+    if (jb.cell) {
+      e_g = jb.gates[idx];
+      e_cn = jb.c_new[idx];
+      e_cp = jb.c_prev[idx];
+      e_dC = jb.dC[idx];
+      if (jb.dout) e_dout = jb.dout[idx];
+    }
+  }
 
   f32x4 acc[BW_MT];
 #pragma unroll
@@ -451,14 +493,10 @@ __global__ __launch_bounds__(BW_THREADS) void lstm_bwd_step_kernel(LstmBwdJobs j
   __syncthreads();
 
   // ---- epilogue: thread = (row, unit) ---------------------------------------------------------
-  const int erow = tid >> 4, ul = tid & 15;
-  const int n = row0 + erow;
-  static_assert(16 * 16 * BW_MT <= BW_THREADS, "one thread per (row, unit) of the tile");
-  if (erow >= ROWS || n >= N) return;          // 16*ROWS threads own one (row, unit) each
-  const int u = 16 * tile + ul;
-  const size_t idx = (size_t)n * L + u;
+  if (!epi) return;                            // 16*ROWS threads own one (row, unit) each
+  const int n = en, u = eu;
   float rec = 0.f;
-  if (jb.drop && jb.A1) {
+  if (two_src) {
     // waves [0, BW_WAVES/2) contracted A0 (the gradient from the layer above, which saw this
     // layer's output through the dropout multipliers), the rest A1 (this layer's own recurrence)
     float up = 0.f;
@@ -466,32 +504,32 @@ __global__ __launch_bounds__(BW_THREADS) void lstm_bwd_step_kernel(LstmBwdJobs j
     for (int ww = 0; ww < BW_WAVES / 2; ++ww) up += part[ww][erow][ul];
 #pragma unroll
     for (int ww = BW_WAVES / 2; ww < BW_WAVES; ++ww) rec += part[ww][erow][ul];
-    rec += up * jb.drop[idx];
+    rec += up * e_drop;
   } else {
 #pragma unroll
     for (int ww = 0; ww < BW_WAVES; ++ww) rec += part[ww][erow][ul];
   }
-  const int len = jb.seq_len ? jb.seq_len[n] : jb.T;
+  const int len = e_len;
   const bool m_next = jb.t + 1 >= len;            // step t+1 carried the state through
-  const float dh_state = rec + (m_next ? jb.dH[idx] : 0.f);
+  const float dh_state = rec + (m_next ? e_dH : 0.f);
   if (!jb.cell) {                                 // gradient of the initial hidden state
     jb.dH[idx] = dh_state;                        // (there is no step -1: its dz operand is zero)
-    *reinterpret_cast<float4*>(jb.dz_k + ((size_t)u * jb.R + n) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(jb.dz_k + ((size_t)u * jb.R + es) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
     return;
   }
   float4 dz = make_float4(0.f, 0.f, 0.f, 0.f);
   if (jb.t < len) {
-    const float dh = dh_state + (jb.dout ? jb.dout[idx] : 0.f);
-    const float4 g = jb.gates[idx];               // i, j, f, o
-    const float tc = fast_tanh(jb.c_new[idx]);
-    const float dc = jb.dC[idx] + dh * g.w * (1.f - tc * tc);
+    const float dh = dh_state + e_dout;
+    const float4 g = e_g;                         // i, j, f, o
+    const float tc = fast_tanh(e_cn);
+    const float dc = e_dC + dh * g.w * (1.f - tc * tc);
     dz.x = dc * g.y * g.x * (1.f - g.x);
     dz.y = dc * g.x * (1.f - g.y * g.y);
-    dz.z = dc * jb.c_prev[idx] * g.z * (1.f - g.z);
+    dz.z = dc * e_cp * g.z * (1.f - g.z);
     dz.w = dh * tc * g.w * (1.f - g.w);
     jb.dC[idx] = dc * g.z;
   }                                               // masked: dH / dC keep carrying
-  *reinterpret_cast<float4*>(jb.dz_k + ((size_t)u * jb.R + n) * 4) = dz;
+  *reinterpret_cast<float4*>(jb.dz_k + ((size_t)u * jb.R + es) * 4) = dz;
   float* zr = jb.dz_rm + (size_t)n * 4 * L + u;
   zr[0] = dz.x; zr[L] = dz.y; zr[2 * L] = dz.z; zr[3 * L] = dz.w;
 }
@@ -1018,8 +1056,9 @@ __global__ __launch_bounds__(256) void adam_kernel(const float* __restrict__ gra
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-void launch_gemm_tn(const GemmTnArgs& a, hipStream_t s) {
-  if (a.M <= 0 || a.N <= 0 || a.R <= 0) return;
+void launch_gemm_tn(const GemmTnArgs& a_in, hipStream_t s, int max_resident) {
+  if (a_in.M <= 0 || a_in.N <= 0 || a_in.R <= 0) return;
+  GemmTnArgs a = a_in;
   const int nprob = a.nprob > 0 ? a.nprob : 1;
   constexpr int TB = 64, BK = 32;
   const int gx = (a.N + TB - 1) / TB, gy = (a.M + TB - 1) / TB;
@@ -1032,8 +1071,15 @@ void launch_gemm_tn(const GemmTnArgs& a, hipStream_t s) {
   while (gx * gy * nprob * splits * 2 <= 1024 && nkt / (splits * 2) >= 4) splits *= 2;
   int r_per = ((nkt + splits - 1) / splits) * BK;
   splits = (a.R + r_per - 1) / r_per;
-  hipLaunchKernelGGL((gemm_tn_kernel<1, 32>), dim3(gx, gy, splits * nprob), dim3(256), 0, s, a,
-                     r_per);
+  const int Z = splits * nprob;
+  a.z_total = Z;
+  int z_per = Z;
+  if (max_resident > 0 && gx * gy * Z > max_resident) z_per = std::max(1, max_resident / (gx * gy));
+  for (int z0 = 0; z0 < Z; z0 += z_per) {
+    a.z_off = z0;
+    hipLaunchKernelGGL((gemm_tn_kernel<1, 32>), dim3(gx, gy, std::min(z_per, Z - z0)), dim3(256), 0, s,
+                       a, r_per);
+  }
 }
 
 void launch_zero_ranges(const ZeroRanges& z, hipStream_t s) {
@@ -1042,9 +1088,11 @@ void launch_zero_ranges(const ZeroRanges& z, hipStream_t s) {
 }
 
 void launch_active_rows(const int32_t* seq_len, int T, int N, int32_t* rows, int32_t* count,
-                        hipStream_t s) {
+                        int32_t* rows_ch, const int* chunk_start, hipStream_t s) {
+  const int4 st = chunk_start ? make_int4(chunk_start[0], chunk_start[1], chunk_start[2], chunk_start[3])
+                              : make_int4(0, 0, 0, 0);
   hipLaunchKernelGGL(active_rows_kernel, dim3((T * N + 255) / 256), dim3(256), 0, s, seq_len, T, N,
-                     rows, count);
+                     rows, count, chunk_start ? rows_ch : nullptr, st);
 }
 
 void launch_colsum(const float* src, int R, int ncols, int ld, const int32_t* sel, int sel_val,
@@ -1082,10 +1130,17 @@ void launch_lstm_bwd_step(const LstmBwdJob* jobs, int njobs, int N, int L, hipSt
   // enough workgroups from the column tiles alone (lstm_dim >= 1024) -> 32-row tiles
   if (L / 16 * njobs >= 128 && N > 16) {
     dim3 grid(L / 16, njobs, (N + 31) / 32);
-    hipLaunchKernelGGL(lstm_bwd_step_kernel<2>, grid, dim3(BW_THREADS), 0, s, js, N, L);
+    hipLaunchKernelGGL((lstm_bwd_step_kernel<2, 8>), grid, dim3(512), 0, s, js, N, L);
   } else {
+    static const int waves = [] {
+      const char* e = std::getenv("N2NMN_BWD_WAVES");
+      return e && std::atoi(e) == 16 ? 16 : 8;
+    }();
     dim3 grid(L / 16, njobs, (N + 15) / 16);
-    hipLaunchKernelGGL(lstm_bwd_step_kernel<1>, grid, dim3(BW_THREADS), 0, s, js, N, L);
+    if (waves == 16)
+      hipLaunchKernelGGL((lstm_bwd_step_kernel<1, 16>), grid, dim3(1024), 0, s, js, N, L);
+    else
+      hipLaunchKernelGGL((lstm_bwd_step_kernel<1, 8>), grid, dim3(512), 0, s, js, N, L);
   }
 }
 

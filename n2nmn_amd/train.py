@@ -24,6 +24,9 @@ def _torch():
     return torch
 
 
+BWD_DEFER_JOIN = 0x10          # include/n2nmn.h
+
+
 class GradBuckets:
     """Two-bucket all-reduce of a flat gradient vector (sum over ranks; the optimiser applies the
     1/world scale).  `late` = [split, numel) is ready first (decoder + modules), `early` =
@@ -207,7 +210,14 @@ class Trainer:
         io, packed, _ = self._io(batch, gt_layout, objective)
         s = self.engine.stream()
         _lib.check(self._lib.n2nmn_train_forward(self._ctx, C.byref(io), packed.handle, s))
-        _lib.check(self._lib.n2nmn_train_backward(self._ctx, C.byref(io), packed.handle, 0, s))
+        # the decoder's weight gradients and the finish of the late bucket stay on the library's side
+        # stream under the encoder's backward pass (N2NMN_BWD_DEFER_JOIN, include/n2nmn.h).  A
+        # torch.distributed all-reduce knows nothing of that stream: the caller's stream joins it first.
+        torch_reduce = reduce and isinstance(self.buckets, GradBuckets) and self.buckets.dist is not None
+        _lib.check(self._lib.n2nmn_train_backward(self._ctx, C.byref(io), packed.handle,
+                                                  0 | BWD_DEFER_JOIN, s))
+        if torch_reduce:
+            _lib.check(self._lib.n2nmn_train_join(self._ctx, s))
         if reduce:
             self.buckets.reduce_late()       # overlaps the encoder's backward pass
         _lib.check(self._lib.n2nmn_train_backward(self._ctx, C.byref(io), packed.handle, 1, s))

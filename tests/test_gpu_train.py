@@ -244,3 +244,54 @@ def test_training_api_errors(trainer_setup):
     gt_small = synth.template_layout_batch(Dims(T_decoder=10, N=8))
     with pytest.raises(ValueError):
         tr.forward_backward(batch, gt_small, reduce=False)
+
+
+SCHEDULES = {
+    # the round-2 schedule: every weight gradient after its recurrence, on the caller's stream
+    'leaves_after_recurrence': {'N2NMN_TRAIN_SCHEDULE': '0'},
+    # as many time chunks as the encoder's backward takes, unbounded background launches
+    'four_chunks_unbounded': {'N2NMN_TRAIN_CHUNKS': '60,40,20', 'N2NMN_TRAIN_BG_WGS': '0'},
+    # no side stream at all
+    'single_stream': {'N2NMN_TRAIN_OVERLAP': '0'},
+}
+
+
+@pytest.mark.parametrize('name', sorted(SCHEDULES))
+def test_every_backward_schedule_gives_the_same_gradients(monkeypatch, name):
+    """The weight-gradient GEMMs are leaves of the backward graph; where they run (side stream under
+    the encoder's reverse-time pass, chunk by chunk, or after it) is a schedule, not arithmetic.
+    Each schedule the library can be switched to (read at n2nmn_train_enable) against the oracle,
+    on the configuration-4 batch and on a ragged one (short questions: chunks without rows)."""
+    from n2nmn_amd.nmn3_assembler import Assembler
+    from n2nmn_amd.engine import Engine
+    from n2nmn_amd.train import Trainer
+    for k, v in SCHEDULES[name].items():
+        monkeypatch.setenv(k, v)
+    d = Dims(T_decoder=10)
+    asm = Assembler(NAMES)
+    eng = Engine(d, asm)
+    w = synth.make_weights(d, seed=0)
+    eng.load_weights(w)
+    tr = Trainer(eng, weight_decay=WD)
+    _check(tr, d, w, synth.make_inputs(d, seed=0), synth.template_layout_batch(d))
+    small = Dims(T_decoder=10, N=37, T_encoder=17)
+    _check(tr, d, w, synth.make_inputs(small, seed=7, min_len=1), synth.template_layout_batch(small, offset=3))
+    short = synth.make_inputs(d, seed=3, min_len=1)
+    short['seq_length_batch'] = np.minimum(short['seq_length_batch'], 4).astype(np.int32)
+    _check(tr, d, w, short, synth.template_layout_batch(d, offset=1))
+
+
+def test_backward_is_stable_over_repeated_steps(trainer_setup):
+    """The default schedule keeps the decoder's weight gradients in flight while the encoder's
+    reverse-time pass runs and starts the next forward pass right behind the optimiser: twenty
+    forward/backward passes over one batch, every one against the same oracle gradients (a buffer
+    shared by two phases, or a missing wait between two steps, shows up as an occasional mismatch)."""
+    tr, eng, d, asm, w = trainer_setup
+    batch = synth.make_inputs(d, seed=11)
+    gt = synth.template_layout_batch(d, offset=2)
+    _, _, _, ref_g, _ = _run(tr, d, w, batch, gt)
+    for it in range(20):
+        tr.forward_backward(batch, gt, reduce=False)
+        grads = {k: t2n(v) for k, v in tr.gradients().items()}
+        bad = [r for r in grad_report(grads, ref_g) if not r[3]]
+        assert not bad, 'iteration %d:\n%s' % (it, format_report(bad))
