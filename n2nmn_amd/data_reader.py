@@ -108,7 +108,8 @@ class _Loader:
             if out is not None and key in out:
                 a = out[key]
                 a = a[..., :nb] if key in ('input_seq_batch', 'gt_layout_batch') else a[:nb]
-                a[...] = 0
+                if key != 'image_feat_batch':    # (every image row is overwritten below)
+                    a[...] = 0
                 return a
             return np.zeros(shape, dtype)
 
@@ -237,6 +238,7 @@ class DataReader:
         cls = {'clevr': BatchLoaderClevr, 'vqa': BatchLoaderVqa}[variant]
         self.batch_loader = cls(self.imdb, self.data_params, self.rng)
         self._stop = threading.Event()
+        self._staging: Optional['queue.Queue'] = None     # free staging sets (use_staging)
         self.prefetch_queue: 'queue.Queue' = queue.Queue(maxsize=prefetch_num)
         self.prefetch_thread = threading.Thread(target=self._run_prefetch, daemon=True)
         self.prefetch_thread.start()
@@ -261,10 +263,36 @@ class DataReader:
                 continue
         return False
 
+    def use_staging(self, sets) -> 'queue.Queue':
+        """From now on the prefetch thread builds every batch directly inside one of `sets` (dicts of
+        preallocated -- e.g. pinned -- arrays for load_one_batch(out=...)), marks the batch with
+        batch['_staging'] = that dict, and waits for a free one when all are out.  The consumer hands
+        a set back with the returned queue's put() once it no longer reads it.  Needs more sets than
+        prefetch_num + whatever the consumer holds at a time."""
+        q: 'queue.Queue' = queue.Queue()
+        for st in sets:
+            q.put(st)
+        self._staging = q
+        return q
+
+    def _take_staging(self):
+        q = self._staging
+        while q is not None and not self._stop.is_set():
+            try:
+                return q.get(timeout=0.1)
+            except queue.Empty:
+                continue
+        return None
+
     def _run_prefetch(self):
         try:
             for ids in self.sample_order():
-                item = None if ids is None else self.batch_loader.load_one_batch(ids)
+                item = None
+                if ids is not None:
+                    st = self._take_staging()
+                    item = self.batch_loader.load_one_batch(ids, out=st)
+                    if st is not None:
+                        item['_staging'] = st
                 if not self._put(item):
                     return
         except Exception as e:           # surface loader errors in the consumer, not in a dead thread
@@ -320,12 +348,28 @@ class DeviceFeeder:
 
         def pinned(shape, dtype):
             return torch.empty(shape, dtype=dtype).pin_memory()
-        self.stage = [[dict(input_seq_batch=pinned((d.T_encoder, Nb), torch.int32),
-                            seq_length_batch=pinned((Nb,), torch.int32),
-                            image_feat_batch=pinned((Nb, bl.feat_H, bl.feat_W, bl.feat_D), torch.float32),
-                            gt_layout_batch=pinned((d.T_decoder, Nb), torch.int32)) for _ in range(K)]
-                      for _ in self.buckets]
-        self.copied = [torch.cuda.Event() for _ in self.buckets]    # staging set free again
+
+        def staging_set():
+            t = dict(input_seq_batch=pinned((d.T_encoder, Nb), torch.int32),
+                     seq_length_batch=pinned((Nb,), torch.int32),
+                     image_feat_batch=pinned((Nb, bl.feat_H, bl.feat_W, bl.feat_D), torch.float32),
+                     gt_layout_batch=pinned((d.T_decoder, Nb), torch.int32))
+            if not (use_gt_layout and getattr(bl, 'load_gt_layout', False)):
+                del t['gt_layout_batch']
+            st = {k: v.numpy() for k, v in t.items()}     # numpy views of the pinned storage
+            st['_pinned'] = t
+            return st
+        # The reader's prefetch thread builds each batch INSIDE a pinned staging set
+        # (load_one_batch(out=...)): the only host copy of the 20 MB of image features is np.load's,
+        # and the consumer thread only enqueues the H2D copies.  A set is out while it sits in the
+        # prefetch queue or belongs to a group whose copies may still be running.
+        nsets = len(self.buckets) * K + reader.prefetch_num + 2
+        self._free = reader.use_staging([staging_set() for _ in range(nsets)])
+        self._held = [[] for _ in self.buckets]                      # sets of each bucket's last group
+        # batches that were prefetched before use_staging (pageable): one staging set per slot
+        self.stage = [[None] * K for _ in self.buckets]
+        self._staging_set = staging_set
+        self.copied = [torch.cuda.Event() for _ in self.buckets]    # staging sets free again
         self.released = [torch.cuda.Event() for _ in self.buckets]  # bucket free again
         self._used = [False] * len(self.buckets)
 
@@ -343,7 +387,10 @@ class DeviceFeeder:
             s = g % len(self.buckets)
             bucket = self.buckets[s]
             if self._used[s]:
-                self.copied[s].synchronize()     # the copies reading this staging set are done
+                self.copied[s].synchronize()     # the copies reading this bucket's staging sets are done
+                for st in self._held[s]:
+                    self._free.put(st)
+                self._held[s] = []
                 self.copy_stream.wait_event(self.released[s])    # the bucket's last pass is done
             batches = []
             with torch.cuda.stream(self.copy_stream):
@@ -352,10 +399,19 @@ class DeviceFeeder:
                     if b is None:
                         break
                     nb = b['seq_length_batch'].shape[0]
-                    st, slot = self.stage[s][k], bucket.slot(k)
+                    slot = bucket.slot(k)
+                    st = b.pop('_staging', None)
+                    if st is not None:
+                        self._held[s].append(st)
+                    else:                        # prefetched before use_staging: copy it into a set
+                        if self.stage[s][k] is None:
+                            self.stage[s][k] = self._staging_set()
+                        st = self.stage[s][k]
+                        for key in keys:
+                            self._rows(st['_pinned'][key], key, nb).copy_(
+                                torch.from_numpy(np.ascontiguousarray(b[key])))
                     for key in keys:
-                        src = self._rows(st[key], key, nb)
-                        src.copy_(torch.from_numpy(np.ascontiguousarray(b[key])))
+                        src = self._rows(st['_pinned'][key], key, nb)
                         self._rows(slot[key], key, nb).copy_(src, non_blocking=True)
                     if nb < bucket.Nb:           # short last batch: the rest of the slot is padding
                         slot['seq_length_batch'][nb:].fill_(1)

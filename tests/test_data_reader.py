@@ -102,3 +102,39 @@ def test_golden_is_what_the_reference_loaders_produce_today(golden, tmp_path):
                    check=True, env=env, stdout=subprocess.DEVNULL)
     with open(os.path.join(HERE, 'golden', 'data_reader_golden.json')) as f:
         assert json.dumps(json.load(f), sort_keys=True) == before
+
+
+def test_batches_built_inside_staging_sets_equal_plain_batches(tmp_path):
+    """use_staging: the prefetch thread builds each batch inside a preallocated set (what
+    DeviceFeeder pins) -- same arrays as the plain reader, every batch's arrays are views of the set
+    it names, and the reader stalls (instead of overwriting) while every set is out."""
+    plain = _batches('clevr_plain', 'clevr', dict(shuffle=False, one_pass=True), {}, str(tmp_path))
+    imdb, params = DC.build(os.path.join(str(tmp_path), 'clevr_plain_staged'), 'clevr')
+    params = dict(params, assembler=_assembler('clevr', {}))
+    rd = R.DataReader(None, imdb=imdb, variant='clevr', prefetch_num=2, shuffle=False, one_pass=True,
+                      **params)
+    time_cap = 64
+    bl = rd.batch_loader
+
+    def staging_set():
+        return dict(input_seq_batch=np.full((bl.T_encoder, time_cap), -7, np.int32),
+                    seq_length_batch=np.full((time_cap,), -7, np.int32),
+                    image_feat_batch=np.full((time_cap, bl.feat_H, bl.feat_W, bl.feat_D), np.nan, np.float32))
+    sets = [staging_set() for _ in range(4)]
+    free = rd.use_staging(sets)
+    staged = []
+    it = rd.batches()
+    for b in it:
+        st = b.pop('_staging', None)
+        staged.append({k: (np.array(v) if isinstance(v, np.ndarray) else v) for k, v in b.items()})
+        if st is not None:
+            assert any(st is s for s in sets)
+            for k in ('input_seq_batch', 'seq_length_batch', 'image_feat_batch'):
+                assert np.shares_memory(b[k], st[k]), k
+            free.put(st)
+    rd.close()
+    assert len(staged) == len(plain)
+    for a, b in zip(plain, staged):
+        for k in ('input_seq_batch', 'seq_length_batch', 'image_feat_batch'):
+            assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), k
+        assert a['image_path_list'] == b['image_path_list']
