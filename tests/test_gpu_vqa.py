@@ -87,3 +87,31 @@ def test_vqa_rejects_clevr_only_operators(vqa_setup):
     att = torch.zeros((1, d.H, d.W, 1), device=e.device)
     with pytest.raises(KeyError):
         e.module_forward('_Count', [att], [0], [0], feat, wv)
+
+
+def test_vqa_pass_of_several_batches_equals_single_batches(vqa_setup):
+    """bench.py's config5.passes: several client batches in one launch of >= 128 rows, recurrent step
+    in 'throughput' mode (lstm_tile_kernel at lstm_dim 1024, gemm_dma_kernel on the 2064 -> 1024
+    conv_image).  Slot k of the pass against the same questions served alone by the (oracle-pinned)
+    single-batch engine of this module, and slot 0 against the oracle itself."""
+    eng, d, w = vqa_setup
+    K = 6                                        # 144 rows: tile kernel on (>= 128), ragged last block
+    big = vqa.VQADims(N=K * d.N)
+    eng_big = vqa.VQAEngine(big)
+    eng_big.load_weights(w)
+    eng_big.engine.set_mode('throughput')
+    parts = [_batch(d, 100 + k) for k in range(K)]
+    gts = [np.roll(_gt(eng, d), k, axis=1) for k in range(K)]
+    cat = dict(input_seq_batch=np.concatenate([p['input_seq_batch'] for p in parts], 1),
+               seq_length_batch=np.concatenate([p['seq_length_batch'] for p in parts]),
+               image_feat_batch=np.concatenate([p['image_feat_batch'] for p in parts], 0))
+    gt_cat = np.ascontiguousarray(np.concatenate(gts, 1))
+    scores, tokens, validity = eng_big.forward(cat, use_gt_layout=True, gt_layout=gt_cat)
+    assert validity.all() and np.array_equal(tokens, gt_cat)
+    got = t2n(scores).copy()
+    for k in range(K):
+        alone, _, _ = eng.forward(parts[k], use_gt_layout=True, gt_layout=np.ascontiguousarray(gts[k]))
+        assert_close('slot %d' % k, got[k * d.N:(k + 1) * d.N], t2n(alone), 2e-5)
+    ref = O.forward_vqa(w, parts[0], d.T_decoder, d.num_choices, np.float64, use_gt_layout=True,
+                        gt_layout=gts[0])
+    assert_close('slot 0 vs oracle', got[:d.N], ref['scores'], TOL)
