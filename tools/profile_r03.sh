@@ -21,8 +21,20 @@ python /root/repo/tools/rocprof_summary.py $(ls $O/r03_tr2x16/*/*.db | head -1) 
 CMD1="python /root/repo/bench.py --plain --streams 1 --inflight 1 --steps 100"
 rocprofv3 --kernel-trace --stats -d $O/r03_tr1 -- $CMD1 > /dev/null 2>&1
 python /root/repo/tools/rocprof_summary.py $(ls $O/r03_tr1/*/*.db | head -1) > $O/r03_kernel_stats_single_batch.txt
-rm -rf $O/r03_fetch $O/r03_write $O/r03_tr16 $O/r03_tr2x16 $O/r03_tr1
+# training step (BASELINE configs[3]): kernel summary and one step in start order with streams
+CMD4="python /root/repo/bench.py --config 4 --steps 20 --warmup 3 --no-cpu-baseline --no-profile"
+rocprofv3 --kernel-trace --stats -d $O/r03_tr4 -- $CMD4 > /dev/null 2>&1
+DB4=$(ls $O/r03_tr4/*/*.db | head -1)
+python /root/repo/tools/rocprof_summary.py $DB4 > $O/r03_train_kernel_stats.txt
+python /root/repo/tools/trace_step.py $DB4 adam_kernel > $O/r03_train_step_trace.txt
+rm -rf $O/r03_fetch $O/r03_write $O/r03_tr16 $O/r03_tr2x16 $O/r03_tr1 $O/r03_tr4
 cd /root/repo
+python bench.py --config 4 --steps 100 --warmup 10 > $O/r03_train_bench.json 2>/dev/null
+python bench.py --config 5 --steps 20 --warmup 3 --no-cpu-baseline > $O/r03_vqa_bench.json 2>/dev/null
+# the driver's multi-GPU launch form, one rank (full line incl. config4 / config5)
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 \
+    bench.py --gpus 1 --steps 20 --warmup 5 > $O/r03_bench_torchrun1.json 2> $O/r03_bench_torchrun1.err
+tail -c 400 $O/r03_bench_torchrun1.json
 python bench.py > $O/r03_bench.json 2> $O/r03_bench.err
 python bench.py --steps 20 --warmup 5 > $O/r03_bench_steps20.json 2>/dev/null
 tail -c 300 $O/r03_bench.err
