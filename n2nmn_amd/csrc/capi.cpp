@@ -607,7 +607,9 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
       }
       {
         ProfScope ps(c, F_LSTM_DEC0, fl0, by0, s);
-        launch_lstm_step(&j0, 1, N, L, 32, s);
+        // (throughput mode, >= 128 rows: the 64 x 64 LDS-DMA tiles, one round of 512 workgroups per
+        // layer -- the greedy decoder's two layers cannot share a launch, token t feeds layer 0 of t+1)
+        launch_lstm_step(&j0, 1, N, L, 32, s, lstm_wide(c));
       }
       LstmJob j1{};
       j1.active = 1;
@@ -620,7 +622,7 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
       j1.h_old = j1.A1; j1.h_new = c->dh1[t & 1];
       {
         ProfScope ps(c, F_LSTM_DEC1, fl1, by1, s);
-        launch_lstm_step(&j1, 1, N, L, 32, s);
+        launch_lstm_step(&j1, 1, N, L, 32, s, lstm_wide(c));
       }
       LstmJob jq{};                    // q = out . W_a + b_a            (nmn3_netgen_att.py:185)
       packed_state(c, jq);
