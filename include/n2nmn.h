@@ -482,6 +482,13 @@ int n2nmn_profile_end(n2nmn_ctx *ctx, n2nmn_stream stream);
 int n2nmn_profile_num_families(void);
 int n2nmn_profile_get(const n2nmn_ctx *ctx, int family, const char **name, int64_t *launches,
                       double *total_ms, double *flops, double *bytes);
+/* Node counters of the walker launches since n2nmn_profile_begin (valid after n2nmn_profile_end), the
+ * device-side source of the `walk(...)` family's algorithmic bytes / flops (the walker decodes its
+ * layouts on the device, so the host has no other way to know what it executed).  out[10]:
+ * [0] conv_image map passes inside the walker, [1] pooled attention inputs, [2] pooling nodes,
+ * [3] nodes with a text parameter, [4] Transform nodes, [5] valid questions, [6] pooling jobs handed to
+ * walk_pool_kernel, [7] their inputs, [8] map passes of walk_find_kernel, [9] reserved. */
+int n2nmn_debug_walk_stats(n2nmn_ctx *ctx, uint64_t *out10);
 
 /* Kernel-variant microbenchmark of the fused LSTM step (see csrc/capi.cpp); debugging aid. */
 int n2nmn_debug_lstm_bench(n2nmn_ctx *ctx, int variant, int rows_per_wg, int njobs, int N,

@@ -131,6 +131,7 @@ SYMBOLS = [
     ('n2nmn_profile_get', _I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_int64),
                                C.POINTER(C.c_double), C.POINTER(C.c_double),
                                C.POINTER(C.c_double)]),
+    ('n2nmn_debug_walk_stats', _I, [_P, C.POINTER(C.c_uint64)]),
     ('n2nmn_debug_lstm_bench', _I, [_P, _I, _I, _I, _I, _I, C.POINTER(C.c_double), _P]),
     ('n2nmn_debug_gemm_tn', _I, [_P, _P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P]),
     ('n2nmn_debug_colsum', _I, [_P, _P, _I, _I, _I, _P, _I, _P, _P]),

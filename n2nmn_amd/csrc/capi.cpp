@@ -1555,6 +1555,14 @@ int n2nmn_profile_end(n2nmn_ctx* ctx, n2nmn_stream stream) {
   return (int)ctx->prof_recs.size();
 }
 
+int n2nmn_debug_walk_stats(n2nmn_ctx* ctx, uint64_t* out10) {
+  N2_REQUIRE(ctx && out10, N2NMN_EINVAL, "debug_walk_stats: null argument");
+  static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "counter width");
+  N2_HIP(hipSetDevice(ctx->device));
+  N2_HIP(hipMemcpy(out10, ctx->walk_stats, sizeof(uint64_t) * WALK_STATS, hipMemcpyDeviceToHost));
+  return N2NMN_OK;
+}
+
 int n2nmn_profile_num_families(void) { return F_COUNT; }
 
 int n2nmn_profile_get(const n2nmn_ctx* ctx, int family, const char** name, int64_t* launches,

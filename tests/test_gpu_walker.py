@@ -240,3 +240,32 @@ def test_chip_wide_front_end_equals_in_walker_front_end(clevr_engine, seed):
     assert np.array_equal(val[0], val[1]) and np.array_equal(val[1].astype(bool), ref['validity'])
     assert_close('chip-wide vs in-walker front end', out[1], out[0], 2e-6)
     assert_close('chip-wide front end vs oracle', out[1], ref['scores'], TOL)
+
+
+def test_walker_node_counters_equal_the_layouts_executed(clevr_engine):
+    """The profiler's algorithmic bytes / flops of the walker come from node counters the profiled
+    launches accumulate on the device (n2nmn_debug_walk_stats).  They must equal what the layouts
+    contain -- round 2 shipped with the pooled-input counter commented out (always 0)."""
+    import ctypes as C
+    from n2nmn_amd import _lib
+    eng, d, asm, w = clevr_engine
+    batch = synth.make_inputs(d, seed=5)
+    gt = synth.random_valid_layouts(d, asm.P, asm.W, asm.b, seed=4, max_len=7)
+    eng.profile_begin()
+    _, tokens, validity = eng.forward(batch, use_gt_layout=True, gt_layout=gt)
+    eng.profile_end()
+    assert validity.all()
+    st = (C.c_uint64 * 10)()
+    _lib.check(eng._lib.n2nmn_debug_walk_stats(eng._ctx, st))
+    idx = {n: i for i, n in enumerate(NAMES)}
+    t = np.asarray(tokens)
+    cnt = lambda *names: sum(int((t == idx[k]).sum()) for k in names)
+    pool = cnt('_FindSameProperty', '_SameProperty', '_Describe')
+    text = cnt('_Find', '_Filter', '_FindSameProperty', '_SameProperty', '_Describe', '_Transform')
+    find_passes = sum((int(np.isin(t[:, i], [idx['_Find'], idx['_Filter']]).sum()) + 3) // 4
+                      for i in range(t.shape[1]))
+    assert st[5] == t.shape[1]                                     # valid questions
+    assert st[2] == pool                                           # pooling nodes
+    assert st[1] == pool + cnt('_SameProperty')                    # pooled attention inputs
+    assert st[3] == text and st[4] == cnt('_Transform')
+    assert st[0] + st[8] == cnt('_FindSameProperty') + find_passes  # conv_image map passes
