@@ -322,7 +322,9 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmAr
   N2_REQUIRE(is_committed(c), N2NMN_ENOWEIGHT, "encoder_forward: weights not committed");
   N2_REQUIRE(io && io->input_seq && io->seq_length, N2NMN_EINVAL, "encoder_forward: null input");
   const int T = io->T_enc, N = io->N, L = d.lstm_dim;
-  train_infer_wait(root(c), s);
+  // (a context that trains refreshes the 64-column tiles of lstm_tile_kernel on its side stream: only
+  // a pass that can reach that kernel waits for them -- a training forward, 64 rows, must not)
+  if (lstm_wide(c) >= 2 && N >= 128) train_infer_wait(root(c), s);
   N2_REQUIRE(T >= 1 && T <= d.T_encoder && N >= 1 && N <= d.N, N2NMN_ECAPACITY,
              "encoder_forward: T_enc / N exceed the context capacity");
   N2_REQUIRE(!(io->drop_enc0 || io->drop_dec0) || c->ehd[0], N2NMN_EINVAL,
@@ -444,7 +446,7 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
   N2_REQUIRE(has_tables(c), N2NMN_ENOWEIGHT,
              "decoder_forward: validity tables (assembler P/W/b) not set");
   N2_REQUIRE(io, N2NMN_EINVAL, "decoder_forward: null io");
-  train_infer_wait(root(c), s);
+  if (lstm_wide(c) >= 2 && io->N >= 128) train_infer_wait(root(c), s);
   N2_REQUIRE(c->enc_T > 0 && io->N == c->enc_N && io->T_enc == c->enc_T, N2NMN_EINVAL,
              "decoder_forward: no matching encoder results in the context");
   const int T = c->enc_T, N = c->enc_N, L = d.lstm_dim, Td = io->T_dec, V = d.num_vocab_nmn;
