@@ -165,6 +165,7 @@ static size_t carve_weights(n2nmn_ctx* c, char* base) {
   for (int i = 0; i < 3; ++i) c->we_pad[i] = k.take<float>(Mp);
   for (int i = 0; i < 4; ++i) c->batt_pad[i] = k.take<float>(Mp);
   c->packs.dev = k.take<PackJob>(kMaxPackJobs);
+  c->packs_rest.dev = k.take<PackJob>(kMaxPackJobs);
   c->packs_infer.dev = k.take<PackJob>(8);
   c->P = k.take<int32_t>(V * 3);
   c->Wv = k.take<int32_t>(3 * V * 4);
@@ -446,7 +447,7 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
   N2_REQUIRE(has_tables(c), N2NMN_ENOWEIGHT,
              "decoder_forward: validity tables (assembler P/W/b) not set");
   N2_REQUIRE(io, N2NMN_EINVAL, "decoder_forward: null io");
-  if (lstm_wide(c) >= 2 && io->N >= 128) train_infer_wait(root(c), s);
+  train_infer_wait(root(c), s);        // (a context that trains packs the decoder's operands on its side stream)
   N2_REQUIRE(c->enc_T > 0 && io->N == c->enc_N && io->T_enc == c->enc_T, N2NMN_EINVAL,
              "decoder_forward: no matching encoder results in the context");
   const int T = c->enc_T, N = c->enc_N, L = d.lstm_dim, Td = io->T_dec, V = d.num_vocab_nmn;
@@ -674,6 +675,7 @@ int qpn_forward(n2nmn_ctx* c, int N, float* scores, const float* drop_h, const f
   const n2nmn_dims& d = c->d;
   const int L = d.lstm_dim, Hq = d.qpn_hidden, C = d.num_choices;
   const n2nmn_ctx* r = root(c);
+  train_infer_wait(r, s);
   // h_concat = [h of layer 0, h of layer 1]  (question_prior_net.py:14-20), row-major [N][2L]
   launch_unpack_h2(c->fh0, c->fh1, c->qpn_h, N, L, d.N, s);
   if (drop_h) launch_ew_mul(c->qpn_h, drop_h, (size_t)N * 2 * L, s);
@@ -702,6 +704,7 @@ int run_program(n2nmn_ctx* c, Program& p, const float* feat, const float* word_v
   // forward runs them on its side stream beside the encoder); RP_REST = everything else
   const n2nmn_dims& d = c->d;
   const bool do_prep = stages & RP_PREP, do_conv = stages & RP_CONV, do_rest = stages & RP_REST;
+  if (do_conv || do_rest) train_infer_wait(root(c), s);
   N2_REQUIRE(is_committed(c), N2NMN_ENOWEIGHT, "execute_program: weights not committed");
   N2_REQUIRE(N_full >= 1 && N_full <= d.N, N2NMN_ECAPACITY, "execute_program: N_full > capacity");
   const int nn = (int)p.dev_nodes.size();
@@ -1025,6 +1028,7 @@ int n2nmn_set_weight(n2nmn_ctx* ctx, const char* name, const float* data, const 
   }
   // the copy into the context-owned mirror is issued here on the NULL stream so the caller's
   // buffer is only referenced during this call
+  train_infer_host_wait(ctx);          // (an optimiser step's second half may still be updating it)
   N2_HIP(hipMemcpy(v.mirror, data, sizeof(float) * v.numel, hipMemcpyDeviceToDevice));
   v.set = true;
   ctx->committed = false;
@@ -1046,6 +1050,16 @@ int n2nmn_set_validity_tables(n2nmn_ctx* ctx, const int32_t* P_host, const int32
 }
 
 int n2nmn_commit_weights(n2nmn_ctx* c, n2nmn_stream stream) {
+  return commit_weights_on(c, S(stream), S(stream));
+}
+
+// The commit in two halves.  `s`: every operand the ENCODER reads (its packed weights, biases, the
+// input-projection table, encoder_h_transform) -- all functions of the encoder's variables only.
+// `rest`: the decoder's and the module network's operands, then what only inference reads.  A training
+// step hands its side stream as `rest` (n2nmn_adam_step): the next forward pass starts its encoder
+// while those are still being packed; decoder / module network / walker entry points wait for the
+// marker behind them (train_infer_wait).  rest == s: one stream, the order below.
+extern "C++" int n2nmn::commit_weights_on(n2nmn_ctx* c, hipStream_t s, hipStream_t rest) {
   N2_REQUIRE(c, N2NMN_EINVAL, "commit_weights: null context");
   N2_REQUIRE(!c->parent, N2NMN_EINVAL, "commit_weights: commit through the root context");
   for (const Var& v : c->vars)
@@ -1053,29 +1067,29 @@ int n2nmn_commit_weights(n2nmn_ctx* c, n2nmn_stream stream) {
       set_last_error("commit_weights: variable never set: " + v.name);
       return N2NMN_ENOWEIGHT;
     }
-  hipStream_t s = S(stream);
   const n2nmn_dims& d = c->d;
   const int L = d.lstm_dim, E = d.embed_dim_txt, M = d.map_dim, V = d.num_vocab_nmn, Mp = c->Mp;
   auto m = [&](int id) { return c->vars[id].mirror; };
   // every operand re-pack of the commit is one job of ONE launch (the job table is built and
   // uploaded on the first commit; pointers and shapes never change afterwards)
   if (!c->packs.uploaded) {
-    PackBatch& pb = c->packs;
+    PackBatch& pb = c->packs;            // functions of the encoder's variables only
+    PackBatch& pr = c->packs_rest;       // everything else
     auto has = [&](int id) { return c->vars[id].present; };
     // layer-0 input projections (rows [0,E) of the LSTM weights) -> PK, then the tables
     // input halves of the layer-0 weights with the gate columns in tile order: the x-tables come out
     // of their GEMMs in the order the step kernels read them (LstmJob::xtab)
     pb.pk_gates(m(V_ENC_W0), 4 * L, E, L, c->enc_W0x_p, c->KpE);
-    pb.pk_gates(m(V_DEC_W0), 4 * L, E, L, c->dec_W0x_p, c->KpE);
+    pr.pk_gates(m(V_DEC_W0), 4 * L, E, L, c->dec_W0x_p, c->KpE);
     pb.vec_gates(m(V_ENC_B0), L, c->enc_b0_t);
-    pb.vec_gates(m(V_DEC_B0), L, c->dec_b0_t);
+    pr.vec_gates(m(V_DEC_B0), L, c->dec_b0_t);
     pb.vec_gates(m(V_ENC_B1), L, c->enc_b1_t);
-    pb.vec_gates(m(V_DEC_B1), L, c->dec_b1_t);
+    pr.vec_gates(m(V_DEC_B1), L, c->dec_b1_t);
     // recurrent parts -> gate-interleaved column tiles
     pb.tiles(m(V_ENC_W0), 4 * L, E, L, L / 4, L, c->enc_W0h_t);
     pb.tiles(m(V_ENC_W1), 4 * L, 0, 2 * L, L / 4, L, c->enc_W1_t);
-    pb.tiles(m(V_DEC_W0), 4 * L, E, L, L / 4, L, c->dec_W0h_t);
-    pb.tiles(m(V_DEC_W1), 4 * L, 0, 2 * L, L / 4, L, c->dec_W1_t);
+    pr.tiles(m(V_DEC_W0), 4 * L, E, L, L / 4, L, c->dec_W0h_t);
+    pr.tiles(m(V_DEC_W1), 4 * L, 0, 2 * L, L / 4, L, c->dec_W1_t);
     if (c->enc_W0h_64) {
       // operands of lstm_tile_kernel (passes of >= 128 rows): a batch of their own -- a training step
       // (64 rows) commits every iteration and never reads them, see below
@@ -1087,54 +1101,52 @@ int n2nmn_commit_weights(n2nmn_ctx* c, n2nmn_stream stream) {
       N2_HIP(hipMemcpy(pi.dev, pi.jobs.data(), sizeof(PackJob) * pi.jobs.size(), hipMemcpyHostToDevice));
     }
     pb.pk(m(V_EHT_W), L, L, L, c->eht_W_p, c->KpL, L);
-    pb.tiles(m(V_ATT_W), L, 0, L, L / 16, 0, c->att_W_t);
-    pb.pk(m(V_ATT_W), L, L, L, c->att_W_p, c->KpL, L);
-    pb.pk(m(V_FIND_IMG_W), M, d.D, M, c->find_img_p, c->KpD, Mp);
-    pb.pk(m(V_FSP_IMG_W), M, d.D, M, c->fsp_img_p, c->KpD, Mp);
-    pb.pad(m(V_DEC_EMB), V, E, c->dec_emb_cat, E);
-    pb.pad(m(V_DEC_GO), 1, E, c->dec_emb_cat + (size_t)V * E, E);
+    pr.tiles(m(V_ATT_W), L, 0, L, L / 16, 0, c->att_W_t);
+    pr.pk(m(V_ATT_W), L, L, L, c->att_W_p, c->KpL, L);
+    pr.pk(m(V_FIND_IMG_W), M, d.D, M, c->find_img_p, c->KpD, Mp);
+    pr.pk(m(V_FSP_IMG_W), M, d.D, M, c->fsp_img_p, c->KpD, Mp);
+    pr.pad(m(V_DEC_EMB), V, E, c->dec_emb_cat, E);
+    pr.pad(m(V_DEC_GO), 1, E, c->dec_emb_cat + (size_t)V * E, E);
     // zero-padded copies of the [M] vectors / [.., M] matrices read with float4 lanes
     const int wes[3] = {V_FIND_E_W, V_FSP_E_W, V_TR_E_W};
     for (int i = 0; i < 3; ++i)
-      if (has(wes[i])) pb.pad(m(wes[i]), 1, M, c->we_pad[i], Mp);
+      if (has(wes[i])) pr.pad(m(wes[i]), 1, M, c->we_pad[i], Mp);
     if (has(V_TR_MAPS_W)) {          // k-major [KK + 1 (+pad)][Mq] operand of the walker's MFMA Transform
       const int KK = d.kernel_size * d.kernel_size, Mq = round_up(M, 16);
-      pb.pad(m(V_TR_MAPS_W), KK, M, c->tr_At, Mq);
-      pb.pad(m(V_TR_MAPS_B), 1, M, c->tr_At + (size_t)KK * Mq, Mq);
+      pr.pad(m(V_TR_MAPS_W), KK, M, c->tr_At, Mq);
+      pr.pad(m(V_TR_MAPS_B), 1, M, c->tr_At + (size_t)KK * Mq, Mq);
     }
     const int txs[5] = {V_FIND_TXT_W, V_FSP_TXT_W, V_TR_TXT_W, V_SP_TXT_W, V_DE_TXT_W};
     for (int i = 0; i < 5; ++i) {
       if (!has(txs[i])) continue;
-      pb.pad(m(txs[i]), E, M, c->wtxt_pad[i], Mp);
-      pb.pad(m(txs[i] + 1), 1, M, c->btxt_pad[i], Mp);
-      if (c->wtxt_pk[i]) pb.pk(m(txs[i]), M, E, M, c->wtxt_pk[i], c->KpE, Mp);
+      pr.pad(m(txs[i]), E, M, c->wtxt_pad[i], Mp);
+      pr.pad(m(txs[i] + 1), 1, M, c->btxt_pad[i], Mp);
+      if (c->wtxt_pk[i]) pr.pk(m(txs[i]), M, E, M, c->wtxt_pk[i], c->KpE, Mp);
     }
     const int ats[4] = {V_FSP_ATT_W, V_SP_ATT0_W, V_SP_ATT1_W, V_DE_ATT_W};
     for (int i = 0; i < 4; ++i)
-      if (has(ats[i])) pb.pad(m(ats[i]), d.D, M, c->watt_pad[i], Mp);
+      if (has(ats[i])) pr.pad(m(ats[i]), d.D, M, c->watt_pad[i], Mp);
     const int bas[4] = {V_FSP_ATT_B, V_SP_ATT0_B, V_SP_ATT1_B, V_DE_ATT_B};
     for (int i = 0; i < 4; ++i)
-      if (has(bas[i])) pb.pad(m(bas[i]), 1, M, c->batt_pad[i], Mp);
+      if (has(bas[i])) pr.pad(m(bas[i]), 1, M, c->batt_pad[i], Mp);
     if (c->big_heads) {
       const int Kp = round_up(M, 32), Np = round_up(d.num_choices, 64);
-      pb.pk(m(V_DE_E_W), d.num_choices, M, d.num_choices, c->wans_de_p, Kp, Np);
-      if (c->wans_sp_p) pb.pk(m(V_SP_E_W), d.num_choices, M, d.num_choices, c->wans_sp_p, Kp, Np);
+      pr.pk(m(V_DE_E_W), d.num_choices, M, d.num_choices, c->wans_de_p, Kp, Np);
+      if (c->wans_sp_p) pr.pk(m(V_SP_E_W), d.num_choices, M, d.num_choices, c->wans_sp_p, Kp, Np);
     }
     if (c->qpn_W1_p) {
-      pb.pk(m(V_QPN_W1), d.qpn_hidden, 2 * L, d.qpn_hidden, c->qpn_W1_p, round_up(2 * L, 32),
+      pr.pk(m(V_QPN_W1), d.qpn_hidden, 2 * L, d.qpn_hidden, c->qpn_W1_p, round_up(2 * L, 32),
             round_up(d.qpn_hidden, 64));
-      pb.pk(m(V_QPN_W2), d.num_choices, d.qpn_hidden, d.num_choices, c->qpn_W2_p,
+      pr.pk(m(V_QPN_W2), d.num_choices, d.qpn_hidden, d.num_choices, c->qpn_W2_p,
             round_up(d.qpn_hidden, 32), round_up(d.num_choices, 64));
     }
-    N2_REQUIRE((int)pb.jobs.size() <= kMaxPackJobs, N2NMN_ECAPACITY, "commit_weights: pack job table");
+    N2_REQUIRE((int)pb.jobs.size() <= kMaxPackJobs && (int)pr.jobs.size() <= kMaxPackJobs,
+               N2NMN_ECAPACITY, "commit_weights: pack job table");
     N2_HIP(hipMemcpy(pb.dev, pb.jobs.data(), sizeof(PackJob) * pb.jobs.size(), hipMemcpyHostToDevice));
+    N2_HIP(hipMemcpy(pr.dev, pr.jobs.data(), sizeof(PackJob) * pr.jobs.size(), hipMemcpyHostToDevice));
     pb.uploaded = true;
   }
-  {
-    const int KK = d.kernel_size * d.kernel_size, KD = (KK + 1 + 3) & ~3, Mq = round_up(d.map_dim, 16);
-    if (KD > KK + 1)
-      N2_HIP(hipMemsetAsync(c->tr_At + (size_t)(KK + 1) * Mq, 0, sizeof(float) * (size_t)(KD - KK - 1) * Mq, s));
-  }
+  // ---- what the encoder reads: on `s` ------------------------------------------------------------
   launch_pack_jobs(c->packs.dev, (int)c->packs.jobs.size(), c->packs.blocks, s);
   // xtab[v] = emb[v] . W_x + b : the whole input half of the layer-0 gate pre-activations
   GemmArgs g{};
@@ -1142,13 +1154,22 @@ int n2nmn_commit_weights(n2nmn_ctx* c, n2nmn_stream stream) {
   g.Bp = c->enc_W0x_p; g.Np = 4 * L; g.Kp = c->KpE; g.bias = c->enc_b0_t; g.N = 4 * L;
   g.C = c->enc_xtab; g.ldc = 4 * L; g.n_store = 4 * L;
   if (!c->big_vocab) launch_gemm_pk(g, s);
+  // ---- the decoder's and the module network's operands: on `rest` ---------------------------------
+  {
+    const int KK = d.kernel_size * d.kernel_size, KD = (KK + 1 + 3) & ~3, Mq = round_up(d.map_dim, 16);
+    if (KD > KK + 1)
+      N2_HIP(hipMemsetAsync(c->tr_At + (size_t)(KK + 1) * Mq, 0, sizeof(float) * (size_t)(KD - KK - 1) * Mq, rest));
+  }
+  launch_pack_jobs(c->packs_rest.dev, (int)c->packs_rest.jobs.size(), c->packs_rest.blocks, rest);
   g.A = c->dec_emb_cat; g.M = V + 1; g.Bp = c->dec_W0x_p; g.bias = c->dec_b0_t; g.C = c->dec_xtab;
-  launch_gemm_pk(g, s);
-  // What only inference reads -- the 64-column recurrent tiles of passes >= 128 rows and the
-  // walker's text-map tables -- is refreshed on the training step's side stream when the context
-  // trains (a commit per iteration: ~75 us that the next forward pass, the level path at 64 rows, would
-  // otherwise wait for); encoder / decoder / walker entry points wait for it (train_infer_wait).
+  launch_gemm_pk(g, rest);
+  // ---- what only inference reads -- the 64-column recurrent tiles of passes >= 128 rows and the
+  // walker's text-map tables (embedding_mat . W_txt: they read the ENCODER's embedding, which `s`
+  // has just updated, hence the fork from `s` here) -- behind the rest on the training step's side
+  // stream when the context trains; encoder (tile kernel only) / decoder / module network / walker
+  // entry points wait for the marker behind it (train_infer_wait).
   hipStream_t si = train_infer_fork(c, s);
+  if (rest != s && si != rest) si = rest;      // (training without a side stream: everything on `s`)
   if (!c->packs_infer.jobs.empty())
     launch_pack_jobs(c->packs_infer.dev, (int)c->packs_infer.jobs.size(), c->packs_infer.blocks, si);
   for (int i = 0; i < 5; ++i) {        // ew[ws] = embedding_mat . W_txt[ws]  (walker text maps)
@@ -1276,6 +1297,7 @@ int n2nmn_conv_image(n2nmn_ctx* c, const float* image_feat, int N, int which,
              "conv_image: gating by tokens needs n2nmn_set_token_ops and T_dec");
   const int HW = d.H * d.W;
   hipStream_t s = S(stream);
+  train_infer_wait(root(c), s);
   const double dHW = HW, dD = d.D, dM = d.map_dim, dMp = c->Mp;
   GemmArgs ga[2];
   conv_image_problems(c, image_feat, N, tokens, T_dec, ga);

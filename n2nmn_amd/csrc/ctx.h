@@ -156,6 +156,8 @@ struct n2nmn_ctx {
   float *eht_W_p = nullptr, *att_W_t = nullptr, *att_W_p = nullptr, *find_img_p = nullptr, *fsp_img_p = nullptr;
   float* dec_emb_cat = nullptr;
   PackBatch packs;                                   // every re-pack of a commit, one launch
+  PackBatch packs_rest;                              // ... (packs: what the ENCODER reads; packs_rest: the
+                                                     // decoder's and the module network's operands)
   PackBatch packs_infer;                             // ... except what only inference reads (64-column tiles)
   float *qpn_W1_p = nullptr, *qpn_W2_p = nullptr;    // PK packs of question_prior_net fc1 / fc2
   float *wans_sp_p = nullptr, *wans_de_p = nullptr;  // PK packs of fc_eltwise (large num_choices only)
@@ -301,6 +303,10 @@ void train_side_join(n2nmn_ctx* c, hipStream_t waiter);
 hipStream_t train_infer_fork(n2nmn_ctx* c, hipStream_t s);
 void train_infer_done(n2nmn_ctx* c, hipStream_t side);
 void train_infer_wait(const n2nmn_ctx* root, hipStream_t s);
+void train_infer_host_wait(const n2nmn_ctx* root);   // same, blocking the host (null-stream copies)
+// n2nmn_commit_weights with the decoder's / module network's / inference-only operands on `rest`
+// (== s: everything in stream order, the public entry point)
+int commit_weights_on(n2nmn_ctx* c, hipStream_t s, hipStream_t rest);
 enum { RP_PREP = 1, RP_CONV = 2, RP_REST = 4, RP_ALL = 7 };
 int run_program(n2nmn_ctx* c, Program& p, const float* feat, const float* word_vecs, int N_full,
                 float* scores, const float* ext0, const float* ext1, float* att_out,

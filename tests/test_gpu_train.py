@@ -295,3 +295,33 @@ def test_backward_is_stable_over_repeated_steps(trainer_setup):
         grads = {k: t2n(v) for k, v in tr.gradients().items()}
         bad = [r for r in grad_report(grads, ref_g) if not r[3]]
         assert not bad, 'iteration %d:\n%s' % (it, format_report(bad))
+
+
+def test_inference_right_after_an_optimiser_step_sees_the_new_weights(trainer_setup):
+    """n2nmn_adam_step updates and re-packs the decoder's and the module network's variables on the
+    library's side stream while the caller's stream is already free for the next encoder pass.  An
+    inference call issued straight after it (no synchronisation in between) must use the NEW weights
+    everywhere: compared with a fresh engine loaded from the trainer's weights, in the default mode
+    (walker) and through the level path."""
+    from n2nmn_amd.engine import Engine
+    tr, eng, d, asm, w = trainer_setup
+    eng.load_weights(w)
+    batch = synth.make_inputs(d, seed=21)
+    gt = synth.template_layout_batch(d, offset=4)
+    probe = synth.make_inputs(d, seed=22)
+    gt_probe = synth.template_layout_batch(d, offset=5)
+    for it in range(3):
+        tr.step(batch, gt)
+        got, _, _ = eng.forward(probe, use_gt_layout=True, gt_layout=gt_probe)     # no sync before it
+        got = t2n(got).copy()
+        packed, _ = asm.assemble_packed(gt_probe)
+        s2s = eng.seq2seq(probe['input_seq_batch'], probe['seq_length_batch'], use_gt_layout=True,
+                          gt_layout=gt_probe)
+        lvl = t2n(eng.execute(packed, probe['image_feat_batch'], s2s['word_vecs'])).copy()
+        fresh = Engine(d, asm)
+        fresh.load_weights({k: t2n(v) for k, v in tr.get_weights().items()})
+        want, _, _ = fresh.forward(probe, use_gt_layout=True, gt_layout=gt_probe)
+        want = t2n(want)
+        assert_close('walker path, iteration %d' % it, got, want, 2e-6)
+        assert_close('level path, iteration %d' % it, lvl, want, 2e-5)
+    eng.load_weights(w)

@@ -26,7 +26,7 @@ CMD4="python /root/repo/bench.py --config 4 --steps 20 --warmup 3 --no-cpu-basel
 rocprofv3 --kernel-trace --stats -d $O/r03_tr4 -- $CMD4 > /dev/null 2>&1
 DB4=$(ls $O/r03_tr4/*/*.db | head -1)
 python /root/repo/tools/rocprof_summary.py $DB4 > $O/r03_train_kernel_stats.txt
-python /root/repo/tools/trace_step.py $DB4 adam_kernel > $O/r03_train_step_trace.txt
+python /root/repo/tools/trace_step.py $DB4 grad_sqnorm > $O/r03_train_step_trace.txt
 rm -rf $O/r03_fetch $O/r03_write $O/r03_tr16 $O/r03_tr2x16 $O/r03_tr1 $O/r03_tr4
 cd /root/repo
 python bench.py --config 4 --steps 100 --warmup 10 > $O/r03_train_bench.json 2>/dev/null

@@ -26,7 +26,7 @@ N2NMN_TRAIN_SCHEDULE=${TRACE_SCHEDULE:-1} rocprofv3 --kernel-trace -d /tmp/p4 -o
     --no-cpu-baseline --no-profile > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT
 db=$(find /tmp/p4 -name '*.db' | head -1)
-python tools/trace_step.py $db adam_kernel > gpurun_out/train_step_trace.txt
+python tools/trace_step.py $db grad_sqnorm > gpurun_out/train_step_trace.txt
 python tools/rocprof_summary.py $db > gpurun_out/train_kernel_stats.txt 2>&1
 tail -1 gpurun_out/train_step_trace.txt
 head -12 gpurun_out/train_kernel_stats.txt
