@@ -325,3 +325,21 @@ def test_inference_right_after_an_optimiser_step_sees_the_new_weights(trainer_se
         assert_close('walker path, iteration %d' % it, got, want, 2e-6)
         assert_close('level path, iteration %d' % it, lvl, want, 2e-5)
     eng.load_weights(w)
+
+
+def test_gradients_at_128_rows_in_throughput_mode():
+    """A training batch of 128 in 'throughput' mode takes the recurrent steps of its forward pass
+    through lstm_tile_kernel (whose training epilogue keeps gates / cell / hidden sequences in the
+    ORIGINAL row order and does not skip finished row blocks) and its backward through 8 row blocks per
+    job: same parity bar as the reference's batch of 64."""
+    from n2nmn_amd.nmn3_assembler import Assembler
+    from n2nmn_amd.engine import Engine
+    from n2nmn_amd.train import Trainer
+    d = Dims(N=128, T_decoder=10)
+    asm = Assembler(NAMES)
+    eng = Engine(d, asm)
+    w = synth.make_weights(d, seed=0)
+    eng.load_weights(w)
+    eng.set_mode('throughput')
+    tr = Trainer(eng, weight_decay=WD)
+    _check(tr, d, w, synth.make_inputs(d, seed=31, min_len=1), synth.template_layout_batch(d, offset=6))
