@@ -196,6 +196,8 @@ static size_t carve_workspace(n2nmn_ctx* c, char* base) {
   }
   c->perm = k.take<int32_t>(N);
   c->nact = k.take<int32_t>(T + 1);
+  c->enc_rows = k.take<int32_t>(T * N);
+  c->enc_rows_n = k.take<int32_t>(4);
   float* ds = k.take<float>(6 * N * L);
   c->dh0[0] = ds; c->dh0[1] = ds + N * L; c->dh1[0] = ds + 2 * N * L; c->dh1[1] = ds + 3 * N * L;
   c->dc0 = ds + 4 * N * L; c->dc1 = ds + 5 * N * L;
@@ -330,7 +332,14 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmAr
              "encoder_forward: T_enc / N exceed the context capacity");
   N2_REQUIRE(!(io->drop_enc0 || io->drop_dec0) || c->ehd[0], N2NMN_EINVAL,
              "seq2seq: LSTM dropout belongs to the models_vqa variant");
-  launch_enc_prepare(io->seq_length, N, T, c->perm, c->nact, c->eh0[0], 10 * (size_t)d.N * L, s);
+  // encoder_h_transform over the rows inside their question's length only (44 % of T*N are past it at
+  // the eval mix; every reader of `eht` takes the bias vector for those: DecStepArgs::eht_bias) -- when
+  // the GEMM rides in the decoder's launch of a large pass and nobody was promised the full matrix
+  static const bool eht_rows_on = [] { const char* e = getenv("N2NMN_EHT_ROWS"); return !e || atoi(e) != 0; }();
+  const bool eht_rows = eht_rows_on && defer_eht && !c->rec && (size_t)T * N >= 8192;
+  launch_enc_prepare(io->seq_length, N, T, c->perm, c->nact, c->eh0[0], 10 * (size_t)d.N * L, s,
+                     eht_rows ? c->enc_rows_n : nullptr);
+  if (eht_rows) launch_enc_rows(io->seq_length, T, N, c->enc_rows, c->enc_rows_n, s);
   const float* W0x_bias_table = c->enc_xtab;
   if (c->big_vocab) {
     // x . W_x + b of the batch's own words: one GEMM whose A rows are gathered by word index
@@ -417,6 +426,9 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmAr
   g.A = c->enc_out; g.lda = L; g.M = T * N; g.K = L; g.group_idx = nullptr; g.group_size = 1;
   g.Bp = c->eht_W_p; g.Np = L; g.Kp = c->KpL; g.bias = c->vars[V_EHT_B].mirror; g.N = L;
   g.C = c->eht; g.ldc = L; g.n_store = L;
+  if (eht_rows) {
+    g.group_idx = c->enc_rows; g.group_size = 1; g.c_row_idx = c->enc_rows; g.m_dev = c->enc_rows_n;
+  }
   if (defer_eht) {
     *defer_eht = g;
   } else {

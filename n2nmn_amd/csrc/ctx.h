@@ -189,6 +189,7 @@ struct n2nmn_ctx {
   float *dh0[2] = {nullptr, nullptr}, *dh1[2] = {nullptr, nullptr}, *dc0 = nullptr, *dc1 = nullptr;
   float *fc0 = nullptr, *fh0 = nullptr, *fc1 = nullptr, *fh1 = nullptr;
   int32_t *perm = nullptr, *nact = nullptr;
+  int32_t *enc_rows = nullptr, *enc_rows_n = nullptr;   // rows (t, n) inside their length, and how many
   float *qpn_h = nullptr, *qpn_hid = nullptr;        // [N][2L] concat of final h, [N][qpn_hidden]
   float *enc_out = nullptr, *eht = nullptr, *qbuf = nullptr, *dec_h1_all = nullptr, *ent_t = nullptr, *dh1_rm = nullptr;
   int32_t *state = nullptr, *next_idx = nullptr, *tokens = nullptr;

@@ -32,6 +32,11 @@ struct GemmArgs {
   // contains a token whose op code is gate_op.  gate_tokens [gate_T][gate_N] device.
   const int32_t* gate_tokens; const int32_t* gate_token_op;
   int gate_T, gate_N, gate_V, gate_op, gate_rows;
+  // optional row count on the device: only rows [0, min(M, *m_dev)) exist (M bounds the launch
+  // geometry; row tiles past the count return at once).  With group_idx / c_row_idx = a compacted row
+  // list this is "the GEMM over the listed rows": encoder_h_transform over the rows inside their
+  // question's length.
+  const int32_t* m_dev;
 };
 void launch_gemm_pk(const GemmArgs& a, hipStream_t s);
 // two problems (no split-K) in one launch
@@ -183,8 +188,12 @@ void launch_dec_attn(const DecStepArgs& a, int nsteps, hipStream_t s);
 void launch_dec_init(int32_t* state, int N, int T_dec, hipStream_t s);
 // perm = rows sorted by decreasing length (stable); n_active[t] = #{n : seq_len[n] > t}, t < T
 // also zeroes `zero_floats` floats at `zero` (multiple of 4; the recurrent state block) in the same launch
+// rows[0 .. *count) = { t*N + n : t < seq_len[n] } in any order (*count must be 0 on entry:
+// launch_enc_prepare clears it)
+void launch_enc_rows(const int32_t* seq_len, int T, int N, int32_t* rows, int32_t* count,
+                     hipStream_t s);
 void launch_enc_prepare(const int32_t* seq_len, int N, int T, int32_t* perm, int32_t* n_active,
-                        float* zero, size_t zero_floats, hipStream_t s);
+                        float* zero, size_t zero_floats, hipStream_t s, int32_t* zero_int = nullptr);
 
 // word_vecs[t][n][:] = sum_tau atts[t][tau][n] * emb[seq[tau][n]][:];  log_seq_prob
 void launch_word_vecs(const float* atts, const int32_t* seq, const float* emb, int T_dec,

@@ -39,11 +39,13 @@ __device__ __forceinline__ void gemm_pk_body(const GemmArgs& a, const int bz, co
   const int lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int m0 = by * BM, n0 = bx * BN;
+  const int M = a.m_dev ? min(a.M, *a.m_dev) : a.M;      // (rows that exist: GemmArgs::m_dev)
+  if (m0 >= M) return;
   if (a.gate_tokens) {        // uniform early exit: none of this tile's images needs the map
     __shared__ int need;
     if (tid == 0) need = 0;
     __syncthreads();
-    const int g0 = m0 / a.gate_rows, g1 = min(m0 + BM - 1, a.M - 1) / a.gate_rows;
+    const int g0 = m0 / a.gate_rows, g1 = min(m0 + BM - 1, M - 1) / a.gate_rows;
     const int per = a.gate_T;
     if (tid < (g1 - g0 + 1) * per) {
       const int g = g0 + tid / per, t = tid % per;
@@ -60,14 +62,14 @@ __device__ __forceinline__ void gemm_pk_body(const GemmArgs& a, const int bz, co
   const int a_row0 = tid >> 3, a_row1 = (tid + 256) >> 3;
   const int a_k40 = tid & 7, a_k41 = a_k40;
   auto src_row = [&](int r) {
-    int src = r < a.M ? r : 0;
+    int src = r < M ? r : 0;
     if (a.group_idx) {
       const int g = src / a.group_size;
       src = a.group_idx[g] * a.group_size + (src - g * a.group_size);
     }
     return src;
   };
-  const bool a_ok0 = m0 + a_row0 < a.M, a_ok1 = m0 + a_row1 < a.M;
+  const bool a_ok0 = m0 + a_row0 < M, a_ok1 = m0 + a_row1 < M;
   const float* a_ptr0 = a.A + (size_t)src_row(m0 + a_row0) * a.lda;
   const float* a_ptr1 = a.A + (size_t)src_row(m0 + a_row1) * a.lda;
   const int b_k40 = tid >> 6, b_k41 = (tid + 256) >> 6, b_n0 = tid & 63, b_n1 = b_n0;
@@ -155,7 +157,7 @@ __device__ __forceinline__ void gemm_pk_body(const GemmArgs& a, const int bz, co
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-      if (row < a.M) {
+      if (row < M) {
         float val = (col < a.N) ? acc[r] + bias : 0.f;
         if (a.relu) val = fmaxf(val, 0.f);
         int orow = row;

@@ -58,11 +58,13 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& a, const int bx, c
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 1, wn = w & 1;
   const int m0 = by * DM, n0 = bx * DN;
+  const int M = a.m_dev ? min(a.M, *a.m_dev) : a.M;      // (rows that exist: GemmArgs::m_dev)
+  if (m0 >= M) return;
   if (a.gate_tokens) {        // uniform early exit: none of this tile's images needs the map
     __shared__ int need;
     if (tid == 0) need = 0;
     __syncthreads();
-    const int g0 = m0 / a.gate_rows, g1 = min(m0 + DM - 1, a.M - 1) / a.gate_rows;
+    const int g0 = m0 / a.gate_rows, g1 = min(m0 + DM - 1, M - 1) / a.gate_rows;
     const int per = a.gate_T;
     for (int i = tid; i < (g1 - g0 + 1) * per; i += DMA_THREADS) {
       const int g = g0 + i / per, t = i % per;
@@ -82,7 +84,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& a, const int bx, c
   for (int u = 0; u < 2; ++u) {
     const int row = 16 * w + 8 * u + (lane >> 3);
     int gm = m0 + row;
-    gm = gm < a.M ? gm : a.M - 1;
+    gm = gm < M ? gm : M - 1;
     if (a.group_idx) {
       const int g = gm / a.group_size;
       gm = a.group_idx[g] * a.group_size + (gm - g * a.group_size);
@@ -169,7 +171,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& a, const int bx, c
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-      if (row < a.M) {
+      if (row < M) {
         float val = (col < a.N) ? acc[t][r] + bias : 0.f;
         if (a.relu) val = fmaxf(val, 0.f);
         int orow = row;

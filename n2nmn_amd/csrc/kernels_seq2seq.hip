@@ -566,7 +566,8 @@ __global__ __launch_bounds__(NT) void dec_attn_kernel(DecStepArgs a) {
     constexpr int UNR = 4;
     // rows past the question's length all equal the bias of encoder_h_transform: virtual row `len`
     // stands for every one of them (see dec_attn_multi_kernel)
-    const int Tv = (a.eht_bias && len < T) ? len + 1 : T;
+    const bool virt = a.eht_bias && len < T;      // row `len` is the bias vector, not a row of eht
+    const int Tv = virt ? len + 1 : T;
     for (int j0 = 0; j0 * NW + w < Tv; j0 += UNR) {
       float s[UNR];
 #pragma unroll
@@ -574,7 +575,7 @@ __global__ __launch_bounds__(NT) void dec_attn_kernel(DecStepArgs a) {
         const int tau = w + NW * (j0 + u);
         s[u] = 0.f;
         if (tau < Tv) {
-          const float* er = (Tv != T && tau == len) ? a.eht_bias : a.eht + ((size_t)tau * N + n) * L;
+          const float* er = (virt && tau == len) ? a.eht_bias : a.eht + ((size_t)tau * N + n) * L;
 #pragma unroll
           for (int i = 0; i < MAXKI; ++i) {
             const int k = 4 * lane + 256 * i;
@@ -593,7 +594,7 @@ __global__ __launch_bounds__(NT) void dec_attn_kernel(DecStepArgs a) {
         if (lane == 0 && tau < Tv) es[tau] = r;
       }
     }
-    if (Tv != T && len + 1 < T) {
+    if (virt && len + 1 < T) {
       __syncthreads();
       for (int tau = len + 1 + tid; tau < T; tau += NT) es[tau] = es[len];
     }
@@ -724,13 +725,14 @@ __global__ __launch_bounds__(256) void dec_attn_multi_kernel(DecStepArgs a, int 
     constexpr int UNR = TS <= 2 ? 6 : 3;     // encoder rows of a wave in flight
     // rows past the question's length all equal the bias of encoder_h_transform: virtual row `len`
     // stands for every one of them (evaluated once, copied to the others below)
-    const int Tv = (a.eht_bias && len < T) ? len + 1 : T;
+    const bool virt = a.eht_bias && len < T;      // row `len` is the bias vector, not a row of eht
+    const int Tv = virt ? len + 1 : T;
     for (int j0 = 0; j0 * NW + w < Tv; j0 += UNR) {
       float4 e4[UNR][KI];
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         const int tau = min(w + NW * (j0 + u), Tv - 1);
-        const float* er = (Tv != T && tau == len) ? a.eht_bias : a.eht + ((size_t)tau * N + n) * L;
+        const float* er = (virt && tau == len) ? a.eht_bias : a.eht + ((size_t)tau * N + n) * L;
 #pragma unroll
         for (int i = 0; i < KI; ++i)
           e4[u][i] = *reinterpret_cast<const float4*>(er + min(4 * lane + 256 * i, L - 4));
@@ -753,7 +755,7 @@ __global__ __launch_bounds__(256) void dec_attn_multi_kernel(DecStepArgs a, int 
         }
       }
     }
-    if (Tv != T && len + 1 < T) {
+    if (virt && len + 1 < T) {
       __syncthreads();
       for (int i = tid; i < TS * (T - len - 1); i += NT) {
         const int j = i / (T - len - 1), tau = len + 1 + i % (T - len - 1);
@@ -886,7 +888,8 @@ __global__ __launch_bounds__(1024) void dec_attn_question_kernel(DecStepArgs a, 
   const int len = min(max(a.seq_len[n], 0), T);
   // rows past the question's length all equal the bias of encoder_h_transform: virtual row `len`
   // stands for every one of them (evaluated once, copied to the others below)
-  const int Tv = (a.eht_bias && len < T) ? len + 1 : T;
+  const bool virt = a.eht_bias && len < T;      // row `len` is the bias vector, not a row of eht
+  const int Tv = virt ? len + 1 : T;
 
   // ---- 0. the question's rows -> LDS (16 KB per sweep of the workgroup), zero the score block -----
   {
@@ -897,7 +900,7 @@ __global__ __launch_bounds__(1024) void dec_attn_question_kernel(DecStepArgs a, 
     for (int u = 0; u < SW; ++u) {
       const int i = min(tid + u * NT, total - 1);
       const int row = i / ncol, c4 = i - row * ncol;
-      const float* er = (Tv != T && row == len) ? a.eht_bias : a.eht + ((size_t)row * N + n) * L;
+      const float* er = (virt && row == len) ? a.eht_bias : a.eht + ((size_t)row * N + n) * L;
       r4[u] = *reinterpret_cast<const float4*>(er + 4 * c4);
     }
 #pragma unroll
@@ -952,7 +955,7 @@ __global__ __launch_bounds__(1024) void dec_attn_question_kernel(DecStepArgs a, 
     }
   }
   __syncthreads();
-  if (Tv != T && len + 1 < T) {
+  if (virt && len + 1 < T) {
     const int rest = T - len - 1;
     for (int i = tid; i < nsteps * rest; i += NT) {
       const int j = i / rest, tau = len + 1 + i - j * rest;
@@ -1071,8 +1074,10 @@ constexpr int PREP_MAXN = 1024;
 __global__ __launch_bounds__(256) void enc_prepare_kernel(const int32_t* __restrict__ seq_len,
                                                           int N, int T, int32_t* __restrict__ perm,
                                                           int32_t* __restrict__ n_active,
-                                                          float4* __restrict__ zero, size_t zero4) {
+                                                          float4* __restrict__ zero, size_t zero4,
+                                                          int32_t* __restrict__ zero_int) {
   const int tid = threadIdx.x;
+  if (zero_int && blockIdx.x == 0 && tid == 0) *zero_int = 0;     // counter of enc_rows_kernel
   for (size_t i = (size_t)blockIdx.x * 256 + tid; i < zero4; i += (size_t)gridDim.x * 256)
     zero[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   // ranks and active-row counts are spread over the workgroups too (one workgroup needed 81 us for
@@ -1122,6 +1127,24 @@ __global__ __launch_bounds__(256) void enc_prepare_kernel(const int32_t* __restr
     const float tot = block_reduce<0>(c, scratch);
     if (tid == 0) n_active[t] = (int)(tot + 0.5f);
   }
+}
+
+// rows[0 .. *count) = the (t, n) rows inside their question's length, one atomic per wave
+__global__ __launch_bounds__(256) void enc_rows_kernel(const int32_t* __restrict__ seq_len, int T, int N,
+                                                       int32_t* __restrict__ rows,
+                                                       int32_t* __restrict__ count) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  bool act = false;
+  if (i < T * N) {
+    const int t = i / N, n = i - t * N;
+    act = t < seq_len[n];
+  }
+  const unsigned long long m = __ballot(act);
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  if (lane == 0 && m) base = atomicAdd(count, __builtin_popcountll(m));
+  base = __shfl(base, 0, 64);
+  if (act) rows[base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = i;
 }
 
 __global__ void dec_init_kernel(int32_t* state, int N, int T_dec) {
@@ -1350,13 +1373,19 @@ void launch_dec_attn(const DecStepArgs& a, int nsteps, hipStream_t s) {
     hipLaunchKernelGGL(dec_attn_kernel<1024>, dim3(a.N, 1), dim3(1024), smem, s, a);
 }
 
+void launch_enc_rows(const int32_t* seq_len, int T, int N, int32_t* rows, int32_t* count,
+                     hipStream_t s) {
+  hipLaunchKernelGGL(enc_rows_kernel, dim3((T * N + 255) / 256), dim3(256), 0, s, seq_len, T, N, rows,
+                     count);
+}
+
 void launch_enc_prepare(const int32_t* seq_len, int N, int T, int32_t* perm, int32_t* n_active,
-                        float* zero, size_t zero_floats, hipStream_t s) {
+                        float* zero, size_t zero_floats, hipStream_t s, int32_t* zero_int) {
   const size_t z4 = zero_floats / 4;             // the state block is a multiple of 4 floats
   int blocks = zero ? (int)std::min<size_t>(256, (z4 + 1023) / 1024 + 1) : 1;
   blocks = std::max(blocks, std::min(64, (N + 255) / 256 + T / 4));
   hipLaunchKernelGGL(enc_prepare_kernel, dim3(blocks), dim3(256), 0, s, seq_len, N, T, perm, n_active,
-                     reinterpret_cast<float4*>(zero), zero ? z4 : 0);
+                     reinterpret_cast<float4*>(zero), zero ? z4 : 0, zero_int);
 }
 
 void launch_dec_init(int32_t* state, int N, int T_dec, hipStream_t s) {

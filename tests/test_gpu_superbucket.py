@@ -93,3 +93,41 @@ def test_slot_bounds(bucket):
     sb, d, w = bucket
     with pytest.raises(ValueError):
         sb.slot(3)
+
+
+def test_encoder_h_transform_over_listed_rows_never_reads_a_stale_row(bucket):
+    """Passes of >= 8192 (t, question) rows compute encoder_h_transform only for the rows inside their
+    question's length (a compacted row list, GemmArgs::m_dev); the rest of the buffer keeps whatever
+    an EARLIER pass left there.  Nothing may read it: a pass over batch Y right after a pass over an
+    unrelated batch X must give, bit for bit, what a fresh bucket gives for Y -- including the lengths
+    at the edges of the attention kernels' 'row len is the bias vector' rule (T - 1 used to read the
+    real row T - 1), with ground-truth and with greedy layouts."""
+    from n2nmn_amd.superbucket import SuperBucket
+    sb, d, w = bucket
+    T = d.T_encoder
+    xs = [synth.make_inputs(d, seed=300 + k) for k in range(3)]
+    ys = []
+    for k in range(3):
+        y = synth.make_inputs(d, seed=310 + k, min_len=1)
+        lens = y['seq_length_batch'].copy()
+        lens[:8] = [T, T - 1, T - 2, 1, 2, T, T - 1, 1]
+        seq = y['input_seq_batch'].copy()
+        seq[np.arange(T)[:, None] >= lens[None, :]] = 0
+        ys.append(dict(y, seq_length_batch=lens, input_seq_batch=seq))
+    gts = [synth.template_layout_batch(d, offset=k) for k in range(3)]
+    fresh = SuperBucket(d, sb.engine.assembler, K=3)
+    fresh.load_weights(w)
+    for use_gt in (True, False):
+        for k in range(3):
+            sb.fill(k, xs[k], gts[k] if use_gt else None)
+        sb.run(use_gt_layout=use_gt)
+        for k in range(3):
+            sb.fill(k, ys[k], gts[k] if use_gt else None)
+            fresh.fill(k, ys[k], gts[k] if use_gt else None)
+        sb.run(use_gt_layout=use_gt)
+        fresh.run(use_gt_layout=use_gt)
+        for k in range(3):
+            a, b = sb.result(k), fresh.result(k)
+            assert np.array_equal(t2n(a[1]), t2n(b[1])), (use_gt, k, 'tokens')
+            assert np.array_equal(t2n(a[0]), t2n(b[0])), (use_gt, k, 'logits')
+            assert np.isfinite(t2n(a[0])).all()
