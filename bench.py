@@ -25,8 +25,9 @@ one GPU, so the driver's default line carries them too (`--config 4|5|6` runs th
 
 Inputs are resident in HBM before the timed region.  Multi-GPU: the path shards by question with no
 data-path collective (weak scaling: every rank runs its own stream of batches); timing =
-barrier + synchronize on both sides, max over ranks.  A timed window shorter than 50 ms is repeated
-and the median block is reported (`timed_region_s`, `repeats`).
+barrier + synchronize on both sides, max over ranks.  The block of `--steps` passes is repeated until
+the blocks span 0.3 s (at least three) and the median block is reported (`timed_region_s`, `repeats`,
+`blocks_s`, `value_min_max`).
 
 Prints ONE JSON line on rank 0.
 """
@@ -249,6 +250,9 @@ def train_numbers(args, dp, local_rank, steps, warmup, profile=True, cpu=True):
                        'parallelism': 'dp%d: flat fp32 gradient (%d floats), 2 RCCL all-reduce '
                                       'buckets per step' % (world, tr.numel)},
             'final_total_loss': float(tr.losses[3].item()),
+            # which all-reduce ran, and over how many ranks BY THE COMMUNICATOR'S OWN ACCOUNT (an
+            # all-reduce of ones at construction + n2nmn_comm_world), not WORLD_SIZE
+            'bucket_impl': tr.bucket_impl, 'rccl_ranks': tr.rccl_ranks,
         }
     if rank == 0 and profile and world == 1:
         ksteps = min(steps, 20)
@@ -456,13 +460,16 @@ def ensure_world(args, argv):
     os.execvp(cmd[0], cmd)
 
 
-def timed_blocks(dp, run, sync, min_window_s=0.05, max_repeats=9):
-    """dp.timed(run) once; a window shorter than min_window_s is too noisy to headline, so the same
-    block is repeated and the MEDIAN block time is used.  Returns (seconds, repeats, all blocks)."""
+def timed_blocks(dp, run, sync, min_window_s=0.3, max_repeats=15):
+    """dp.timed(run) -- exactly `--steps` steps between barrier + synchronize -- is one BLOCK.  A single
+    short block (20 passes = 68 ms) is too noisy to headline, so blocks are repeated until at least
+    three have run and together they span min_window_s; the MEDIAN block is reported, with the
+    fastest and the slowest beside it.  Returns (median seconds, repeats, all blocks)."""
     blocks = [dp.timed(run, sync)]
-    if blocks[0] < min_window_s:
-        while len(blocks) < max_repeats:
-            blocks.append(dp.timed(run, sync))
+    while len(blocks) < max_repeats and (len(blocks) < 3 or sum(blocks) < min_window_s):
+        if blocks[0] >= min_window_s and len(blocks) >= 1:
+            break                                  # one block is already a long window
+        blocks.append(dp.timed(run, sync))
     s = sorted(blocks)
     return s[len(s) // 2], len(blocks), blocks
 
@@ -551,16 +558,22 @@ def main():
             'dtype': 'f32', 'data': 'synthetic',
             'timed_region_s': round(elapsed, 5), 'repeats': repeats,
             'blocks_s': [round(x, 5) for x in blocks],
-            'config': {'workload': 'BASELINE.json configs[%d]: CLEVR forward, %s, client batches of %d '
-                                   'questions, 10x15x512 synthetic pool5, T_enc=45, T_dec=20; one step = '
-                                   'ONE PASS of the hot path over %d client batches (%d questions: they '
-                                   'share every launch); %d passes in flight on %d streams, each stream '
-                                   'alternating two buckets of distinct inputs; the strict one-batch-'
-                                   'in-flight figure is `single_batch`' %
-                                   (args.config - 1,
-                                    'fixed ground-truth layouts (10-template mix, teacher-forced '
-                                    'decoder)' if use_gt else 'layouts chosen by the greedy seq2seq '
-                                    'decoder', d.N, K, K * d.N, S, S),
+            'timed_window_s': round(sum(blocks), 4),
+            'value_min_max': [round(dp.throughput(K * d.N * args.steps, max(blocks)), 1),
+                              round(dp.throughput(K * d.N * args.steps, min(blocks)), 1)],
+            'config': {'workload': 'BASELINE.json configs[%d]: CLEVR forward, %s layouts, 10x15x512 feats, '
+                                   '%d x batch %d per pass, %d streams' %
+                                   (args.config - 1, 'gt' if use_gt else 'greedy-decoder', K, d.N, S),
+                       'note': 'client batches of %d questions, synthetic pool5, T_enc=45, T_dec=20; one '
+                               'step = ONE PASS of the hot path over %d client batches (%d questions: they '
+                               'share every launch); %d passes in flight on %d streams, each stream '
+                               'alternating two buckets of distinct inputs; `value` = median of `repeats` '
+                               'blocks of exactly `steps` passes (`value_min_max` = slowest / fastest '
+                               'block); layouts: %s; the strict one-batch-in-flight figure is '
+                               '`single_batch`' %
+                               (d.N, K, K * d.N, S, S,
+                                'fixed ground-truth layouts (10-template mix, teacher-forced decoder)'
+                                if use_gt else 'chosen by the greedy seq2seq decoder'),
                        'client_batch': d.N, 'batches_per_pass': K, 'rows_per_launch': K * d.N,
                        'questions_per_step': K * d.N, 'global_batch': world * K * d.N,
                        'streams_per_gpu': S, 'questions_in_flight': S * K * d.N,
@@ -623,6 +636,19 @@ def main():
         out['single_batch'] = {'value': round(d.N / t_one, 1), 'unit': 'questions/sec',
                                'ms_per_step': round(1e3 * t_one, 4), 'steps': n1,
                                'note': 'one batch of %d questions in flight' % d.N}
+        if not args.no_profile:
+            # the strict batch-64 reading of the metric, kernel by kernel: the R = 64 recurrent step
+            eng.profile_begin()
+            for _ in range(10):
+                (one_gt if use_gt else one_greedy)()
+            r1 = kernel_rows(eng.profile_end(), 10)
+            if r1:
+                out['single_batch']['roofline'] = {k: r1[0][k] for k in (
+                    'kernel', 'bound', 'avg_us', 'launches_per_step', 'us_per_step', 'achieved', 'peak',
+                    'unit', 'frac')}
+                out['single_batch']['roofline']['rows_per_launch'] = d.N
+                out['single_batch']['kernels'] = r1[:4]
+                out['single_batch']['launches_per_step'] = round(sum(r['launches_per_step'] for r in r1), 1)
         if not use_gt:
             eng.set_mode(pipe.mode)
         # ---- BASELINE.json configs[2]: the decoder chooses the layouts (greedy), walker decodes them

@@ -188,8 +188,9 @@ static size_t carve_workspace(n2nmn_ctx* c, char* base) {
   c->ec0 = st + 4 * N * L; c->ec1 = st + 5 * N * L;
   // final encoder state in ORIGINAL row order (written at each row's last valid step)
   c->fc0 = st + 6 * N * L; c->fh0 = st + 7 * N * L; c->fc1 = st + 8 * N * L; c->fh1 = st + 9 * N * L;
-  if (d.variant == N2NMN_VARIANT_VQA)
-    for (int i = 0; i < 2; ++i) { c->ehd[i] = k.take<float>(N * L); c->dhd[i] = k.take<float>(N * L); }
+  // dropped copies of the layer-0 outputs (encoder_dropout / decoder_dropout: DropoutWrapper on
+  // every layer but the last, nmn3_netgen_att.py:17-44 of both model families)
+  for (int i = 0; i < 2; ++i) { c->ehd[i] = k.take<float>(N * L); c->dhd[i] = k.take<float>(N * L); }
   if (c->big_vocab) {
     c->xproj = k.take<float>(T * N * 4 * L);
     c->iota = k.take<int32_t>(T * N);
@@ -330,8 +331,6 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmAr
   if (lstm_wide(c) >= 2 && N >= 128) train_infer_wait(root(c), s);
   N2_REQUIRE(T >= 1 && T <= d.T_encoder && N >= 1 && N <= d.N, N2NMN_ECAPACITY,
              "encoder_forward: T_enc / N exceed the context capacity");
-  N2_REQUIRE(!(io->drop_enc0 || io->drop_dec0) || c->ehd[0], N2NMN_EINVAL,
-             "seq2seq: LSTM dropout belongs to the models_vqa variant");
   // encoder_h_transform over the rows inside their question's length only (44 % of T*N are past it at
   // the eval mix; every reader of `eht` takes the bias vector for those: DecStepArgs::eht_bias) -- when
   // the GEMM rides in the decoder's launch of a large pass and nobody was promised the full matrix
@@ -345,7 +344,7 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmAr
     // x . W_x + b of the batch's own words: one GEMM whose A rows are gathered by word index
     GemmArgs g{};
     g.A = c->vars[V_ENC_EMB].mirror; g.lda = d.embed_dim_txt; g.M = T * N; g.K = d.embed_dim_txt;
-    g.group_idx = io->input_seq; g.group_size = 1;
+    g.group_idx = io->input_seq; g.group_size = 1; g.src_rows = d.num_vocab_txt;
     g.Bp = c->enc_W0x_p; g.Np = 4 * L; g.Kp = c->KpE; g.bias = c->enc_b0_t; g.N = 4 * L;
     g.C = c->xproj; g.ldc = 4 * L; g.n_store = 4 * L;
     ProfScope ps(c, F_GEMM_EHT, 2.0 * T * N * d.embed_dim_txt * 4.0 * L,
@@ -427,7 +426,15 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmAr
   g.Bp = c->eht_W_p; g.Np = L; g.Kp = c->KpL; g.bias = c->vars[V_EHT_B].mirror; g.N = L;
   g.C = c->eht; g.ldc = L; g.n_store = L;
   if (eht_rows) {
-    g.group_idx = c->enc_rows; g.group_size = 1; g.c_row_idx = c->enc_rows; g.m_dev = c->enc_rows_n;
+    g.group_idx = c->enc_rows; g.group_size = 1; g.src_rows = T * N;
+    g.c_row_idx = c->enc_rows; g.m_dev = c->enc_rows_n;
+  }
+  c->eht_partial = eht_rows;
+  c->eht_listed_rows = -1;
+  if (eht_rows && io->seq_length_host) {        // what the launch really computes, for the profile counters
+    long rows = 0;
+    for (int n = 0; n < N; ++n) rows += std::min(std::max(io->seq_length_host[n], 0), T);
+    c->eht_listed_rows = rows;
   }
   if (defer_eht) {
     *defer_eht = g;
@@ -439,8 +446,10 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmAr
   const size_t nl = sizeof(float) * (size_t)N * L;
   if (io->encoder_outputs)
     N2_HIP(hipMemcpyAsync(io->encoder_outputs, c->enc_out, nl * T, hipMemcpyDeviceToDevice, s));
-  if (io->encoder_h_transformed)
+  if (io->encoder_h_transformed) {
+    N2_REQUIRE(!c->eht_partial, N2NMN_EINVAL, "encoder_forward: encoder_h_transformed copy of a partial matrix");
     N2_HIP(hipMemcpyAsync(io->encoder_h_transformed, c->eht, nl * T, hipMemcpyDeviceToDevice, s));
+  }
   if (io->encoder_states) {
     launch_unpack_h(c->fc0, io->encoder_states, N, L, d.N, s);       // c shares h's packed layout
     launch_unpack_h(c->fh0, io->encoder_states + (size_t)N * L, N, L, d.N, s);
@@ -476,7 +485,9 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
   DecStepArgs a{};
   a.eht = c->eht; a.eout = c->enc_out; a.seq_len = c->enc_len; a.v = c->vars[V_ATT_V].mirror;
   a.order = c->perm;            // enc_prepare's length ranking of this pass's rows
-  a.eht_bias = c->vars[V_EHT_B].mirror;
+  a.eht_bias = c->vars[V_EHT_B].mirror;      // rows past a question's length: the bias, never `eht`
+  N2_REQUIRE(!c->eht_partial || (a.eht_bias && !c->rec), N2NMN_EINVAL,
+             "decoder_forward: partial encoder_h_transform without the bias substitution");
   a.Wy = c->vars[V_TOK_W].mirror; a.by = c->vars[V_TOK_B].mirror; a.P = c->P; a.Wv = c->Wv;
   a.bv = c->bv; a.use_gt = io->use_gt_layout; a.T = T; a.N = N; a.L = L; a.V = V;
   a.state = c->state;
@@ -539,8 +550,10 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
       double fl = 0, by = 0;
       for (int i = 0; i < npre && nl < 2; ++i) {
         list[nl++] = pre[i];
-        fl += 2.0 * pre[i].M * pre[i].K * pre[i].N;
-        by += 4.0 * ((double)pre[i].M * (pre[i].K + pre[i].N) + (double)pre[i].K * pre[i].N);
+        // (a listed-row problem computes *m_dev rows, not M: counted when the host knows the lengths)
+        const double rows = pre[i].m_dev && c->eht_listed_rows >= 0 ? (double)c->eht_listed_rows : pre[i].M;
+        fl += 2.0 * rows * pre[i].K * pre[i].N;
+        by += 4.0 * (rows * (pre[i].K + pre[i].N) + (double)pre[i].K * pre[i].N);
       }
       GemmArgs& gq = list[nl++];
       gq = GemmArgs{};
@@ -596,8 +609,9 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
       double fl = 0, by = 0;
       for (int i = 0; i < npre && nl < 3; ++i) {
         list[nl++] = pre[i];
-        fl += 2.0 * pre[i].M * pre[i].K * pre[i].N;
-        by += 4.0 * ((double)pre[i].M * (pre[i].K + pre[i].N) + (double)pre[i].K * pre[i].N);
+        const double rows = pre[i].m_dev && c->eht_listed_rows >= 0 ? (double)c->eht_listed_rows : pre[i].M;
+        fl += 2.0 * rows * pre[i].K * pre[i].N;
+        by += 4.0 * (rows * (pre[i].K + pre[i].N) + (double)pre[i].K * pre[i].N);
       }
       if (io->image_feat) {
         list[nl++] = cv[0];
@@ -785,7 +799,7 @@ int run_program(n2nmn_ctx* c, Program& p, const float* feat, const float* word_v
         const bool fsp = l.kind == LK_CONV_FSP;
         GemmArgs g{};
         g.A = feat; g.lda = d.D; g.M = l.count * HW; g.K = d.D;
-        g.group_idx = c->dev_tab + l.offset; g.group_size = HW;
+        g.group_idx = c->dev_tab + l.offset; g.group_size = HW; g.src_rows = N_full * HW;
         g.Bp = fsp ? c->fsp_img_p : c->find_img_p; g.Np = c->Mp; g.Kp = c->KpD;
         g.bias = c->vars[fsp ? V_FSP_IMG_B : V_FIND_IMG_B].mirror; g.N = d.map_dim;
         g.C = fsp ? c->mfsp : c->mfind; g.ldc = c->Mp; g.n_store = c->Mp;

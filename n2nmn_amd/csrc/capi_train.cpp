@@ -883,6 +883,8 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
       ProfScope ps(c, F_GEMM_TN, 2.0 * Vt * (double)E * T * N, 4.0 * ((double)T * N * E + Vt * (double)E), sd);
       launch_gemm_tn(g1, sd, t->bg(sd));
     }
+    N2_REQUIRE(!c->eht_partial, N2NMN_EINVAL,
+               "train_backward: the forward left a partial encoder_h_transform (listed-row GEMM)");
     DecBwdArgs a{};
     a.scores = t->rec.tscores; a.gt = io->gt_layout; a.q = c->qbuf; a.eht = c->eht;
     a.eout = c->enc_out; a.atts = c->atts; a.datts_wv = t->datts_wv; a.seq_len = io->seq_length;
@@ -1106,6 +1108,9 @@ int n2nmn_adam_step(n2nmn_ctx* c, const float* grads, float grad_scale, float lr
 
 int n2nmn_train_reset_optimizer(n2nmn_ctx* c, n2nmn_stream stream) {
   N2_REQUIRE(c && c->train, N2NMN_EINVAL, "train_reset_optimizer: training not enabled");
+  // the late half of the previous Adam update (decoder / module variables with their m, v) may still
+  // be running on the library's side stream: the memsets below are ordered behind it
+  c->train->join(S(stream));
   N2_HIP(hipMemsetAsync(c->train->m, 0, sizeof(float) * (size_t)c->train->total, S(stream)));
   N2_HIP(hipMemsetAsync(c->train->v, 0, sizeof(float) * (size_t)c->train->total, S(stream)));
   return N2NMN_OK;

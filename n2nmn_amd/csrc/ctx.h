@@ -192,6 +192,11 @@ struct n2nmn_ctx {
   int32_t *enc_rows = nullptr, *enc_rows_n = nullptr;   // rows (t, n) inside their length, and how many
   float *qpn_h = nullptr, *qpn_hid = nullptr;        // [N][2L] concat of final h, [N][qpn_hidden]
   float *enc_out = nullptr, *eht = nullptr, *qbuf = nullptr, *dec_h1_all = nullptr, *ent_t = nullptr, *dh1_rm = nullptr;
+  // `eht` rows (tau, n) with tau >= len[n] were NOT computed by the last encoder pass (listed-row GEMM,
+  // encoder_impl): they hold whatever an earlier pass left.  Every reader must take the
+  // encoder_h_transform bias for them (DecStepArgs::eht_bias) or refuse a partial matrix.
+  bool eht_partial = false;
+  long eht_listed_rows = -1;   // rows of that listed-row GEMM when the host knows the lengths (profile figures)
   int32_t *state = nullptr, *next_idx = nullptr, *tokens = nullptr;
   float *tprobs = nullptr, *negent = nullptr, *atts = nullptr, *word_vecs = nullptr;
   int enc_T = 0, enc_N = 0;            // shape of the encoder results currently held

@@ -2,6 +2,19 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel, and launchers are
+// called from several host threads (PassPipeline workers): set it once per (kernel, device) with an
+// atomic bit per device ordinal instead of a process-wide `static bool`.
+#include <atomic>
+inline void ensure_dynamic_lds(const void* kernel, int bytes, std::atomic<uint64_t>& done) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return;
+  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  done.fetch_or(bit, std::memory_order_release);
+}
+
 namespace n2nmn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

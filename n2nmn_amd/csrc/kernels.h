@@ -19,6 +19,9 @@ struct GemmArgs {
   const float* A; int lda; int M; int K;
   const int32_t* group_idx; int group_size;   // optional row-group gather: logical row r reads
                                               // source row group_idx[r/gs]*gs + r%gs
+  int src_rows;                               // with group_idx: rows of the SOURCE table A (the gathered
+                                              // row is not bounded by M); 0 = unknown (kernels that
+                                              // need the bound -- 32-bit offsets -- then refuse)
   const float* Bp; int Np; int Kp;
   const float* bias; int N;
   float* C; int ldc; int n_store;

@@ -202,8 +202,12 @@ __global__ __launch_bounds__(DMA_THREADS) void gemm_dma_kernel(GemmBatch b) {
 }  // namespace
 
 bool gemm_dma_supported(const GemmArgs& a) {
+  // A is addressed with 32-bit byte offsets from its base: the bound is on the rows that can be
+  // READ -- with a row gather (group_idx) those of the source table, which M does not bound
+  const size_t a_rows = a.group_idx ? (size_t)a.src_rows : (size_t)a.M;
+  if (a.group_idx && a.src_rows <= 0) return false;
   return a.M >= DM && a.Np % DN == 0 && a.Kp % DK == 0 && a.K % 4 == 0 && a.K >= 4 && a.lda % 4 == 0 &&
-         a.ksplit <= 1 && (size_t)a.M * a.lda * 4 < ((size_t)1 << 32) &&
+         a.ksplit <= 1 && a_rows * a.lda * 4 < ((size_t)1 << 32) &&
          (size_t)a.Kp * a.Np * 4 < ((size_t)1 << 32) && (!a.gate_tokens || a.gate_T <= 64);
 }
 
@@ -219,12 +223,8 @@ void launch_gemm_dma(const GemmArgs* a, int n, hipStream_t s) {
   }
   if (!np) return;
   for (int i = np; i <= 4; ++i) b.start[i] = tiles;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DSTAGE);
-    attr = true;
-  }
+  static std::atomic<uint64_t> attr{0};
+  ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_dma_kernel), 2 * DSTAGE, attr);
   hipLaunchKernelGGL(gemm_dma_kernel, dim3((tiles + 63) / 64 * 64), dim3(DMA_THREADS), 2 * DSTAGE, s, b);
 }
 

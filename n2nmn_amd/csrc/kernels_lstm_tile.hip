@@ -342,13 +342,9 @@ __global__ __launch_bounds__(TILE_THREADS) void lstm_tile_kernel(LstmJobs2 jobs,
 
 template <int NS, int DBG = 0>
 void launch_tile(const LstmJobs2& js, int njobs, int N, int L, hipStream_t s) {
-  static bool attr_set = false;
+  static std::atomic<uint64_t> attr{0};
   const int lds = NS * STAGE_BYTES;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_tile_kernel<NS, DBG>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
+  ensure_dynamic_lds(reinterpret_cast<const void*>(&lstm_tile_kernel<NS, DBG>), lds, attr);
   const int nrb = (N + TILE_ROWS - 1) / TILE_ROWS;
   const int grid = njobs * nrb * (L / TILE_UNITS);
   hipLaunchKernelGGL((lstm_tile_kernel<NS, DBG>), dim3(grid), dim3(TILE_THREADS), lds, s, js, N, L,

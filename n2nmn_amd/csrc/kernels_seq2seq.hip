@@ -1339,12 +1339,8 @@ static bool launch_dec_question(const DecStepArgs& a, int nsteps, hipStream_t s)
   const size_t smem = sizeof(float) * ((size_t)std::max(a.T, nsteps) * a.L + 32 * (size_t)Tp + 16 * 4 * MAXV);
   if (smem > 150 * 1024 || (size_t)a.T * a.L > (size_t)3 * KI * 4096 ||
       (size_t)nsteps * (a.L + 16 * MAXV) > (size_t)std::max(a.T, nsteps) * a.L) return false;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_question_kernel<KI>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    attr = true;
-  }
+  static std::atomic<uint64_t> attr{0};
+  ensure_dynamic_lds(reinterpret_cast<const void*>(dec_attn_question_kernel<KI>), 150 * 1024, attr);
   hipLaunchKernelGGL((dec_attn_question_kernel<KI>), dim3(a.N), dim3(1024), smem, s, a, nsteps);
   return true;
 }

@@ -415,6 +415,15 @@ class DeviceFeeder:
                         self._rows(slot[key], key, nb).copy_(src, non_blocking=True)
                     if nb < bucket.Nb:           # short last batch: the rest of the slot is padding
                         slot['seq_length_batch'][nb:].fill_(1)
+                    # Lifetime of what the consumer sees in group.batches: a batch built inside a
+                    # pinned staging set holds numpy VIEWS of it, and the set goes back to the prefetch
+                    # thread when this bucket is reused (len(buckets) groups later).  The small arrays
+                    # (tokens, lengths, layouts: a few KB) are therefore copied out here, so a consumer
+                    # may keep them for logging or accumulation; only the 20 MB `image_feat_batch`
+                    # stays an alias, valid until the group after next is requested.
+                    for key in ('input_seq_batch', 'seq_length_batch', 'gt_layout_batch'):
+                        if key in b and isinstance(b[key], np.ndarray) and not b[key].flags.owndata:
+                            b[key] = np.array(b[key])
                     batches.append(b)
                 ev = torch.cuda.Event()
                 ev.record(self.copy_stream)

@@ -23,7 +23,8 @@ class AttentionSeq2Seq:
     def __init__(self, input_seq_batch, seq_length_batch, T_decoder, num_vocab_txt, embed_dim_txt,
                  num_vocab_nmn, embed_dim_nmn, lstm_dim, num_layers, assembler, encoder_dropout,
                  decoder_dropout, decoder_sampling, use_gt_layout=None, gt_layout_batch=None,
-                 scope='encoder_decoder', reuse=None, engine: Engine = None, sample_seed: int = 0):
+                 scope='encoder_decoder', reuse=None, engine: Engine = None, sample_seed: int = 0,
+                 dropout_seed: int = 0):
         if engine is None:
             raise ValueError('AttentionSeq2Seq needs engine=Engine(...)')
         d = engine.dims
@@ -35,9 +36,16 @@ class AttentionSeq2Seq:
                 raise ValueError('%s=%r differs from the engine dims (%r)' % (k, v, getattr(d, k)))
         if T_decoder > d.T_decoder:
             raise ValueError('T_decoder exceeds the engine capacity')
-        if encoder_dropout or decoder_dropout:
-            # inactive in every CLEVR config of the reference (train_clevr_gt_layout.py:31-32)
-            raise NotImplementedError('LSTM dropout is not on the CLEVR hot path')
+        # encoder_dropout / decoder_dropout: DropoutWrapper(output_keep_prob=0.5) on the output of every
+        # LSTM layer but the last (:17-44) -> multipliers on layer 0's output, handed to the C-ABI as
+        # n2nmn_seq2seq_io.drop_enc0 / drop_dec0.  (Inactive in every CLEVR script of the reference,
+        # train_clevr_gt_layout.py:31-32, but part of the constructor contract.)
+        self.keep_prob = 0.5
+        self.dropout_masks = None      # {'enc0': [T_enc, N, L], 'dec0': [T_dec, N, L]} {0,1} keep masks
+        #                                for the next run (tests: TF's RNG stream is not reproducible);
+        #                                None: drawn by n2nmn_dropout_multipliers (seed, offset)
+        self.dropout_seed = dropout_seed
+        self._drawn = 0
         self.engine = engine
         self.T_decoder = T_decoder
         self.encoder_num_vocab = num_vocab_txt
@@ -76,8 +84,32 @@ class AttentionSeq2Seq:
                 self._gen.manual_seed(self._seed)
             n = torch.as_tensor(seq).shape[1]
             uni = torch.rand((self.T_decoder, n), generator=self._gen, device=self.engine.device)
+        drop = None
+        if self.encoder_dropout or self.decoder_dropout:
+            T, n = torch.as_tensor(seq).shape
+            drop = (self._multipliers('enc0', (T, n, self.lstm_dim)) if self.encoder_dropout else None,
+                    self._multipliers('dec0', (self.T_decoder, n, self.lstm_dim))
+                    if self.decoder_dropout else None)
         return self.engine.seq2seq(seq, lens, self.T_decoder, use_gt, gt, uni, forced_tokens,
-                                   debug=debug)
+                                   debug=debug, dropout=drop)
+
+    def _multipliers(self, key, shape):
+        """0 or 1 / keep_prob per element of layer 0's output: from the masks a test supplied, or
+        from the library's counter-based generator (a fresh stretch of its stream per run)."""
+        import numpy as np
+        import torch
+        from . import _lib
+        e = self.engine
+        if self.dropout_masks is not None:
+            keep = torch.as_tensor(np.asarray(self.dropout_masks[key], np.float32), device=e.device)
+            if tuple(keep.shape) != tuple(shape):
+                raise ValueError('dropout mask %s: shape %s, expected %s' % (key, tuple(keep.shape), shape))
+            return (keep / self.keep_prob).contiguous()
+        m = torch.empty(shape, dtype=torch.float32, device=e.device)
+        _lib.check(e._lib.n2nmn_dropout_multipliers(m.data_ptr(), m.numel(), self.keep_prob,
+                                                    self.dropout_seed, self._drawn, e.stream()))
+        self._drawn += m.numel()
+        return m
 
     def _fetch(self, f, handle):
         from .runtime import to_numpy

@@ -84,6 +84,29 @@ class RcclBuckets:
         _lib.check(self._lib.n2nmn_comm_create(uid, self.rank, self._world, engine.device.index,
                                                C.byref(self._comm)))
         torch.cuda.synchronize(engine.device)
+        self.verified_world = self._self_test()
+
+    def _self_test(self) -> int:
+        """One all-reduce of both buckets over a buffer of ones, through the very calls a step uses:
+        every element must come back as the number of ranks.  Proves at construction that the
+        communicator spans `world` ranks (the figure bench.py prints as `rccl_ranks`) instead of
+        assuming it from WORLD_SIZE; leaves the gradient buffer zeroed."""
+        torch = _torch()
+        self.flat.fill_(1.0)
+        self.reduce_late()
+        self.reduce_early()
+        self.wait()
+        torch.cuda.synchronize(self.engine.device)
+        lo, hi = float(self.flat.min().item()), float(self.flat.max().item())
+        self.flat.zero_()
+        if lo != hi or int(lo) != self.comm_world():
+            raise RuntimeError('RCCL self-test: all-reduce of ones over %d ranks returned [%g, %g]' %
+                               (self._world, lo, hi))
+        return int(lo)
+
+    def comm_world(self) -> int:
+        """ranks of the C-ABI communicator as the library reports them (n2nmn_comm_world)"""
+        return int(_lib.check(self._lib.n2nmn_comm_world(self._comm)))
 
     @property
     def world(self) -> int:
@@ -113,6 +136,17 @@ class RcclBuckets:
             pass
 
 
+def default_rccl(dist) -> bool:
+    """Which all-reduce a Trainer uses when the caller does not say: the C-ABI communicator
+    (side-stream all-reduce under the encoder's backward pass) on every nccl (= RCCL) group, one
+    rank or many -- tests/test_gpu_rccl_multi.py checks gradient equality across ranks on it wherever
+    a node has >= 2 devices, and its constructor proves the rank count with an all-reduce of ones.
+    N2NMN_RCCL_BUCKETS=0 selects torch.distributed's all_reduce instead; gloo groups always use it."""
+    import os
+    return dist is not None and dist.get_backend() == 'nccl' and \
+        os.environ.get('N2NMN_RCCL_BUCKETS', '1') != '0'
+
+
 class Trainer:
     """One model replica on one GPU.  `step(batch, gt_layout)` = one iteration of
     train_clevr_gt_layout.py: returns the losses of that iteration (device tensor of 4 floats:
@@ -123,10 +157,8 @@ class Trainer:
                  max_grad_l2_norm: float = 10.0, dist=None, rccl: Optional[bool] = None):
         """dist: an initialised torch.distributed module (or None).  rccl: all-reduce through the
         C-ABI's own RCCL communicator (n2nmn_comm_* / n2nmn_allreduce_grads); False / gloo:
-        torch.distributed collectives.  Default: the C-ABI communicator for a 1-rank nccl group
-        (what could be run on hardware here); with more ranks torch.distributed's all_reduce unless
-        N2NMN_RCCL_BUCKETS=1 opts in -- the multi-rank path of the C-ABI communicator has never met a
-        second GPU (the gpurun boxes have one), so it must not be the silent default there."""
+        torch.distributed collectives.  Default: the C-ABI communicator on every nccl group
+        (N2NMN_RCCL_BUCKETS=0 opts out); `bucket_impl` / `rccl_ranks` say what a trainer runs on."""
         torch = _torch()
         if engine._parent is not None:
             raise ValueError('train on the root engine, not on a fork')
@@ -149,11 +181,12 @@ class Trainer:
                                    device=engine.device)
         self.scores = None
         if rccl is None:
-            import os
-            rccl = dist is not None and dist.get_backend() == 'nccl' and \
-                (dist.get_world_size() == 1 or os.environ.get('N2NMN_RCCL_BUCKETS') == '1')
+            rccl = default_rccl(dist)
         self.buckets = RcclBuckets(engine, self.grads, dist) if rccl else \
             GradBuckets(self.grads, self.split, dist)
+        self.bucket_impl = 'n2nmn_comm (C-ABI RCCL communicator, library side stream)' if rccl else \
+            ('torch.distributed.all_reduce (%s)' % dist.get_backend() if dist is not None else 'none (one process)')
+        self.rccl_ranks = self.buckets.verified_world if rccl else None
         self.iteration = 0
         _lib.check(self._lib.n2nmn_train_reset_optimizer(self._ctx, engine.stream()))
         self.layout: Dict[str, tuple] = {}

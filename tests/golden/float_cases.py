@@ -59,6 +59,14 @@ def gt_layouts(d: Dims) -> np.ndarray:
     return np.ascontiguousarray(np.array(cols, np.int32).T)
 
 
+def clevr_dropout_masks(d: Dims, seed: int = 108):
+    """{0, 1} keep masks (keep_prob 0.5) of DropoutWrapper on the output of LSTM layer 0, per step:
+    'enc0' [T_enc, N, L], 'dec0' [T_dec, N, L] (models_clevr/nmn3_netgen_att.py:17-44)."""
+    rng = np.random.default_rng(seed)
+    return dict(enc0=(rng.random((d.T_encoder, d.N, d.lstm_dim)) < 0.5).astype(np.float32),
+                dec0=(rng.random((d.T_decoder, d.N, d.lstm_dim)) < 0.5).astype(np.float32))
+
+
 def sample_uniforms(d: Dims, seed: int = 7) -> np.ndarray:
     return np.random.default_rng(seed).random((d.T_decoder, d.N))
 

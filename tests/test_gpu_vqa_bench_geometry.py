@@ -1,0 +1,150 @@
+"""BASELINE.json configs[4] at the geometry bench.py TIMES (VERDICT r3 "weak" item 1): the models_vqa
+forward (exp_vqa/eval_vqa2.py:27-39,103-137) with N = 128 questions per batch in latency mode
+(`config5`) and as ONE pass of 8 client batches x 128 = 1024 rows in 'throughput' mode
+(`config5.passes`: lstm_tile_kernel at lstm_dim 1024 over 16 row blocks, gemm_dma_kernel on the
+2064 -> 1024 conv_image, device-side row lists) -- teacher-forced and greedy.
+
+The fp64 oracle is too slow for 1024 rows of 14x14x2050 features, and questions are independent
+(SURVEY.md 8e), so the FULL pass runs on the GPU and a seeded subset of its rows -- first / last row of
+a slot, slot boundaries, the longest and the shortest question -- is compared with the oracle run on
+exactly those questions (logits <= 1e-4; greedy tokens under the top-2-margin rule of SURVEY.md 8c,
+logits given the GPU's tokens).  Every slot of the pass is additionally compared with the same 128
+questions served alone by the single-batch engine."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import n2nmn_oracle as O
+from n2nmn_amd import synth, vqa
+from util import assert_close, greedy_tokens_under_margin_rule, t2n
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+CLIENT = 128
+# exp_vqa/data/v2_gt_layout_val2014_new_parse.npy histogram -- bench.py's mix
+MIX = (['_Find', '_Find', '_And', '_Describe'],) * 46 + (['_Find', '_Describe'],) * 43 + \
+      (['_Find', '_Transform', '_Describe'],) * 9 + \
+      (['_Find', '_Transform', '_Find', '_And', '_Describe'],) * 2
+
+
+@pytest.fixture(scope='module')
+def setup():
+    d = vqa.VQADims(N=CLIENT)
+    eng = vqa.VQAEngine(d)
+    w = synth.make_weights_from_shapes(vqa.vqa_variable_shapes(d), seed=0)
+    eng.load_weights(w)
+    return eng, d, w
+
+
+def _part(d, eng, seed):
+    """one client batch of 128 questions (host arrays) + its ground-truth layouts"""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(1, d.T_encoder + 1, size=CLIENT).astype(np.int32)
+    lens[3], lens[CLIENT - 2] = d.T_encoder, 1                    # the extremes are always present
+    seq = rng.integers(0, d.num_vocab_txt, size=(d.T_encoder, CLIENT)).astype(np.int32)
+    seq[np.arange(d.T_encoder)[:, None] >= lens[None, :]] = 0
+    feat = np.maximum(rng.standard_normal((CLIENT, d.H, d.W, d.D), dtype=np.float32), 0)
+    order = rng.permutation(100)
+    gt = np.ascontiguousarray(np.array(
+        [eng.assembler.module_list2tokens(MIX[order[n % 100]], d.T_decoder) for n in range(CLIENT)],
+        np.int32).T)
+    return dict(input_seq_batch=seq, seq_length_batch=lens, image_feat_batch=feat), gt
+
+
+def _rows(batch, gt, rows):
+    sub = dict(input_seq_batch=np.ascontiguousarray(batch['input_seq_batch'][:, rows]),
+               seq_length_batch=np.ascontiguousarray(batch['seq_length_batch'][rows]),
+               image_feat_batch=np.ascontiguousarray(batch['image_feat_batch'][rows]))
+    return sub, (None if gt is None else np.ascontiguousarray(gt[:, rows]))
+
+
+def _check_greedy_tokens(d, tokens, ref_dec, what):
+    return len(greedy_tokens_under_margin_rule(tokens, ref_dec, what))
+
+
+def test_latency_mode_batch_of_128(setup):
+    """`config5` of the bench line: one batch of 128, default (latency) recurrent step."""
+    eng, d, w = setup
+    batch, gt = _part(d, eng, 40)
+    rows = [0, 3, 17, 63, 64, 100, CLIENT - 2, CLIENT - 1]
+    scores, tokens, validity = eng.forward(batch, use_gt_layout=True, gt_layout=gt)
+    assert np.array_equal(tokens, gt) and validity.all()
+    got = t2n(scores).copy()
+    sub, gts = _rows(batch, gt, rows)
+    ref = O.forward_vqa(w, sub, d.T_decoder, d.num_choices, np.float64, use_gt_layout=True, gt_layout=gts)
+    assert ref['validity'].all()
+    assert_close('gt layouts, rows %s' % rows, got[rows], ref['scores'], TOL)
+    # free-running decoder (token fetch + host assembly on this path)
+    scores, tokens, validity = eng.forward(batch)
+    got = t2n(scores).copy()
+    assert validity.all()
+    free = O.forward_vqa(w, sub, d.T_decoder, d.num_choices, np.float64)
+    _check_greedy_tokens(d, tokens[:, rows], free['dec'], 'latency mode')
+    forced = O.forward_vqa(w, sub, d.T_decoder, d.num_choices, np.float64,
+                           forced_tokens=np.ascontiguousarray(tokens[:, rows]))
+    assert_close('greedy layouts (GPU tokens), rows %s' % rows, got[rows], forced['scores'], TOL)
+
+
+def test_throughput_pass_of_8_client_batches(setup):
+    """`config5.passes`: 8 client batches of 128 as ONE pass of 1024 rows in 'throughput' mode."""
+    eng, d, w = setup
+    K = 8
+    big = vqa.VQADims(N=K * CLIENT)
+    eng_big = vqa.VQAEngine(big)
+    eng_big.load_weights(w)
+    eng_big.engine.set_mode('throughput')
+    dev = eng_big.engine.device
+    parts = [_part(d, eng, 200 + k) for k in range(K)]
+    feat = torch.empty((K * CLIENT, d.H, d.W, d.D), dtype=torch.float32, device=dev)
+    for k, (p, _) in enumerate(parts):
+        feat[k * CLIENT:(k + 1) * CLIENT] = torch.as_tensor(p['image_feat_batch']).to(dev)
+    cat = dict(input_seq_batch=np.concatenate([p['input_seq_batch'] for p, _ in parts], 1),
+               seq_length_batch=np.concatenate([p['seq_length_batch'] for p, _ in parts]),
+               image_feat_batch=feat)
+    gt_cat = np.ascontiguousarray(np.concatenate([g for _, g in parts], 1))
+    # the rows VERDICT r3 names + the extremes of two slots + one row per 16-row block boundary
+    rows = sorted({0, 127, 128, 511, 1023, 3, 126, 5 * CLIENT + 3, 5 * CLIENT + 126, 15, 16, 1008})
+
+    def oracle_rows(gt=None, forced=None):
+        sub = dict(input_seq_batch=np.ascontiguousarray(cat['input_seq_batch'][:, rows]),
+                   seq_length_batch=np.ascontiguousarray(cat['seq_length_batch'][rows]),
+                   image_feat_batch=np.stack([parts[r // CLIENT][0]['image_feat_batch'][r % CLIENT]
+                                              for r in rows]))
+        return O.forward_vqa(w, sub, d.T_decoder, d.num_choices, np.float64, use_gt_layout=gt is not None,
+                             gt_layout=gt, forced_tokens=forced)
+
+    # ---- teacher-forced (the timed configuration)
+    scores, tokens, validity = eng_big.forward(cat, use_gt_layout=True, gt_layout=gt_cat)
+    assert validity.all() and np.array_equal(tokens, gt_cat)
+    got = t2n(scores).copy()
+    assert np.isfinite(got).all()
+    ref = oracle_rows(gt=np.ascontiguousarray(gt_cat[:, rows]))
+    assert_close('pass of 1024 rows vs oracle, rows %s' % rows, got[rows], ref['scores'], TOL)
+    worst = 0.0
+    for k, (p, g) in enumerate(parts):
+        alone, _, _ = eng.forward(p, use_gt_layout=True, gt_layout=g)
+        worst = max(worst, assert_close('slot %d of 8 vs the same batch alone' % k,
+                                        got[k * CLIENT:(k + 1) * CLIENT], t2n(alone), 2e-5))
+    print('worst |slot - alone| over 8 slots: %.2e' % worst)
+
+    # ---- greedy decoder chooses the layouts
+    scores, tokens, validity = eng_big.forward(cat)
+    got = t2n(scores).copy()
+    assert validity.all() and np.isfinite(got).all()
+    free = oracle_rows()
+    _check_greedy_tokens(d, tokens[:, rows], free['dec'], 'throughput pass')
+    forced = oracle_rows(forced=np.ascontiguousarray(tokens[:, rows]))
+    assert_close('greedy pass (GPU tokens) vs oracle, rows %s' % rows, got[rows], forced['scores'], TOL)
+    P, Wv, bv = O.build_validity_mats(list(vqa.VQA_MODULE_NAMES))
+    for k, (p, g) in enumerate(parts):
+        alone, tok1, _ = eng.forward(p)
+        c = slice(k * CLIENT, (k + 1) * CLIENT)
+        same = (tokens[:, c] == tok1).all(axis=0)
+        assert_close('greedy slot %d of 8 vs alone (equal layouts)' % k, got[c][same], t2n(alone)[same], 2e-5)
+        diff = np.nonzero(~same)[0]
+        if diff.size:          # different summation orders may flip a layout only at a near-tie
+            sub, _ = _rows(p, None, diff)
+            enc = O.encoder_forward(w, sub['input_seq_batch'], sub['seq_length_batch'], np.float64)
+            dec = O.decoder_forward(w, enc, P, Wv, bv, d.T_decoder, np.float64)
+            _check_greedy_tokens(d, tokens[:, c][:, diff], dec, 'pass, slot %d' % k)
+            _check_greedy_tokens(d, tok1[:, diff], dec, 'alone, slot %d' % k)
