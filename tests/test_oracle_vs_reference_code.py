@@ -286,3 +286,40 @@ def test_full_size_fixture_is_what_the_reference_code_computes_today():
     p = subprocess.run([sys.executable, gen, '--check'], capture_output=True, text=True,
                        env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'))
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+# ---- models_clevr with LSTM dropout (encoder_dropout = decoder_dropout = True) ------------------------
+GOLDEN_DROPOUT = os.path.join(os.path.dirname(GOLDEN), 'float_golden_dropout.npz')
+
+
+def test_clevr_dropout_fixture_holds_what_the_gpu_test_reads():
+    """tests/test_gpu_reference_fixture.py::test_clevr_face_with_lstm_dropout_matches_reference_code
+    compares the HIP path with this fixture directly; here: its keys, shapes, and that the recorded
+    masks moved the result by several times the 1e-4 parity bar (a face that ignored the flags fails)."""
+    z = np.load(GOLDEN_DROPOUT)
+    d, batch = FC.clevr_inputs('gt')
+    for mode in ('greedy', 'gt'):
+        assert z[mode + '/predicted_tokens'].shape == (d.T_decoder, d.N)
+        assert z[mode + '/scores'].shape == (d.N, d.num_choices) and z[mode + '/validity'].all()
+    assert np.array_equal(z['gt/predicted_tokens'], FC.gt_layouts(d))
+    assert float(z['gt/log_seq_prob_without_dropout_maxdiff']) > 5e-4
+    m = FC.clevr_dropout_masks(d)
+    assert m['enc0'].shape == (d.T_encoder, d.N, d.lstm_dim) and 0.45 < m['enc0'].mean() < 0.55
+    # the autograd oracle's teacher-forced seq2seq takes the same masks: log_seq_prob must agree
+    import torch
+    w = {k: torch.as_tensor(v.astype(np.float64)) for k, v in FC.clevr_weights().items()}
+    enc = G.encoder_forward(w, batch['input_seq_batch'], batch['seq_length_batch'], drop0=m['enc0'])
+    dec = G.decoder_forward_gt(w, enc, d.T_decoder, FC.gt_layouts(d), drop0=m['dec0'])
+    tp = dec['token_probs'].detach().numpy()
+    close('gt token_probs with dropout (autograd oracle)', tp, z['gt/token_probs'], 1e-9)
+    close('gt log_seq_prob with dropout (autograd oracle)', np.sum(np.log(tp), axis=0),
+          z['gt/log_seq_prob'], 1e-9)
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/models_clevr'),
+                    reason='reference checkout not present (GPU box)')
+def test_clevr_dropout_fixture_is_what_the_reference_code_computes_today():
+    gen = os.path.join(os.path.dirname(GOLDEN), 'make_float_golden_dropout.py')
+    p = subprocess.run([sys.executable, gen, '--check'], capture_output=True, text=True,
+                       env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
