@@ -824,7 +824,7 @@ def main():
         sync()
         c4 = train_numbers(args, dp, local_rank, 30, 5, profile=True, cpu=False)
         out['config4'] = {k: c4[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'config',
-                                             'final_total_loss') if k in c4}
+                                             'final_total_loss', 'bucket_impl', 'rccl_ranks') if k in c4}
         if 'kernels' in c4:
             out['config4']['kernels'] = c4['kernels'][:4]
         c5 = vqa_numbers(args, dp, local_rank, 10, 3, profile=True)
