@@ -301,6 +301,16 @@ int n2nmn_walk_set_defer_pool(n2nmn_ctx *ctx, int mode);
  * 4 workgroups per question streaming the conv_image map), 0 always inside the walker, 1 always
  * chip-wide. */
 int n2nmn_walk_set_front_end(n2nmn_ctx *ctx, int mode);
+/* Staged walker.  When a launch runs both of the above chip-wide (front end AND deferred pooling: passes
+ * of >= 128 questions by default), the tree-dependent rest leaves the one-workgroup-per-question walker
+ * as well: walk_tmap_kernel decodes every layout once (nmn3_assembler.py:153-222) and lists the
+ * _Transform / _FindSameProperty nodes whose input subtree holds no other such node; walk_heavy_kernel
+ * runs each of them as a job of its own (one workgroup per node, the walker's operator code);
+ * walk_light_kernel (one small workgroup per question) evaluates the remaining And / Or / Filter / Scene
+ * nodes and the answer operator (nmn3_modules.py:60-72,113-132,218-400) or hands the root to the
+ * deferred pooling; questions with nested _Transform / _FindSameProperty nodes stay with the
+ * one-workgroup walker.  mode -1 (default): on; 0: off (the walker serves every question). */
+int n2nmn_walk_set_staged(n2nmn_ctx *ctx, int mode);
 /* single batch: n2nmn_conv_image(FIND | FSP gated by tokens) + n2nmn_walk_layouts(K = 1) */
 int n2nmn_execute_tokens(n2nmn_ctx *ctx, const int32_t *tokens, int T_dec, int N,
                          const float *image_feat, const float *word_vecs, float *scores,

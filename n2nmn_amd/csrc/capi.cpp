@@ -239,6 +239,11 @@ static size_t carve_workspace(n2nmn_ctx* c, char* base) {
   c->wptm = k.take<float>(N * Mp);
   c->wpooled = k.take<float>(N * 2 * (size_t)d.D);
   c->wpfc = k.take<float>(N * 2 * WALK_POOL_PARTS * Mp);
+  c->wprog = k.take<WalkProg>(N);
+  c->whcap = (int)std::min<size_t>((size_t)WALK_MAX_BATCHES * N * 4, (size_t)1 << 20);
+  c->whjobs = k.take<int32_t>((size_t)c->whcap);
+  c->wfblist = k.take<int32_t>((size_t)WALK_MAX_BATCHES * N);
+  c->wcnt = k.take<int32_t>(8);
   return align_up(k.off, 256);
 }
 
@@ -904,6 +909,7 @@ static int finish_create(n2nmn_ctx* c, n2nmn_ctx* parent) {
     return N2NMN_EHIP;
   }
   carve_workspace(c, c->ws_base);
+  N2_HIP(hipMemset(c->wcnt, 0, sizeof(int32_t) * 8));      // the staged walker's two counter sets
   if (c->iota) {
     std::vector<int32_t> io((size_t)c->d.T_encoder * c->d.N);
     for (size_t i = 0; i < io.size(); ++i) io[i] = (int32_t)i;
@@ -1305,6 +1311,12 @@ int n2nmn_walk_set_front_end(n2nmn_ctx* c, int mode) {
   return N2NMN_OK;
 }
 
+int n2nmn_walk_set_staged(n2nmn_ctx* c, int mode) {
+  N2_REQUIRE(c && mode >= -1 && mode <= 1, N2NMN_EINVAL, "walk_set_staged: mode is -1, 0 or 1");
+  c->walk_staged = mode;
+  return N2NMN_OK;
+}
+
 int n2nmn_walk_supported(const n2nmn_ctx* c) {
   if (!c) return 0;
   const n2nmn_dims& d = c->d;
@@ -1383,6 +1395,7 @@ int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int
     a.b[k].watt = owner->watt;
     a.b[k].pjob = owner->wpjob; a.b[k].pw = owner->wpw; a.b[k].ptm = owner->wptm;
     a.b[k].pooled = owner->wpooled; a.b[k].pfc = owner->wpfc;
+    a.b[k].prog = owner->wprog;
   }
   a.K = K; a.N = N; a.T = T_dec; a.V = d.num_vocab_nmn; a.token_op = root(c)->token_op;
   a.H = d.H; a.W = d.W; a.D = d.D; a.M = d.map_dim; a.Mp = c->Mp; a.HWp = c->HWp;
@@ -1408,6 +1421,18 @@ int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int
   // walker, which then finds both in HBM (600 bytes per node) and keeps only the tree-dependent work
   const int pf_env = c->walk_pre_find;
   const bool pre = use_table && (pf_env < 0 ? K * N >= 128 : pf_env > 0);
+  // staged walker: with both of the above the tree-dependent work leaves the one-workgroup-per-question
+  // chain too (kernels_walk.hip: walk_heavy_kernel / walk_light_kernel); N2NMN_WALK_STAGED=0 keeps the
+  // round-3 walker
+  static const bool staged_env = [] { const char* e = getenv("N2NMN_WALK_STAGED"); return !e || atoi(e) != 0; }();
+  const bool staged = pre && a.defer_pool && staged_env && c->walk_staged != 0 &&
+                      K * N < (1 << 22) && T_dec <= 255;
+  if (staged) {
+    a.staged = 1;
+    a.hjobs = c->whjobs; a.fblist = c->wfblist; a.hcap = c->whcap;
+    a.cnt = c->wcnt + 4 * c->walk_parity; a.cnt_next = c->wcnt + 4 * (c->walk_parity ^ 1);
+    c->walk_parity ^= 1;
+  }
   if (pre) {
     {
       ProfScope ps(c, F_WALK_TMAP, 0.0, 0.0, s);
@@ -1423,7 +1448,11 @@ int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int
   }
   {
     ProfScope ps(c, F_WALK, 0.0, 0.0, s);     // work filled in from the device counters
-    launch_walk(w, a, s);
+    if (a.staged) {
+      launch_walk_heavy(w, a, s);
+      launch_walk_light(w, a, s);
+    }
+    launch_walk(w, a, s);                     // staged: only the questions listed as nested
   }
   c->last_walk = a;
   c->have_last_walk = true;
@@ -1478,7 +1507,10 @@ int n2nmn_debug_walk_replay(n2nmn_ctx* c, int which, int iters, double* us_avg, 
   const bool pairs = (which & 0x10) != 0;       // one event pair PER launch (calibrates the pair cost)
   which &= 0xf;
   auto one = [&]() {
-    if (which == 0) launch_walk(w, a, s);
+    if (which == 0) {
+      if (a.staged) { launch_walk_heavy(w, a, s); launch_walk_light(w, a, s); }
+      launch_walk(w, a, s);
+    }
     else if (which == 1) launch_walk_pool(w, a, s);
     else if (which == 2) launch_walk_heads(w, a, s);
     else if (which == 3) launch_walk_find(w, a, s);

@@ -208,6 +208,12 @@ struct n2nmn_ctx {
   float* watt = nullptr;                   // [N][T_dec][HWp] Find / Filter logits (walk_find_kernel)
   // deferred pooling of the walker path: job code, soft-max weights, text map, pooled features
   int32_t* wpjob = nullptr; float *wpw = nullptr, *wptm = nullptr, *wpooled = nullptr, *wpfc = nullptr;
+  // staged walker (kernels.h WalkArgs::staged): decoded layouts of this context's questions, and -- for
+  // the launches this context issues -- the job lists and the two counter sets (used alternately)
+  WalkProg* wprog = nullptr;
+  int32_t *whjobs = nullptr, *wfblist = nullptr, *wcnt = nullptr;
+  int whcap = 0, walk_parity = 0;
+  int walk_staged = -1;                       // -1 auto (with the chip-wide front end + deferred pooling), 0 off
   float *arena = nullptr, *tmap = nullptr, *pfc = nullptr, *mfind = nullptr, *mfsp = nullptr;
   float* ev_out = nullptr;
   int32_t* ev_rows = nullptr;

@@ -274,7 +274,21 @@ struct WalkBatch {
   const float* atts;       // [T][T_enc][N]
   const int32_t* seq;      // [T_enc][N]
   const int32_t* seq_len;  // [N]
+  // staged walker (WalkArgs::staged): the decoded layout of every question, written by
+  // walk_tmap_kernel (which becomes the pass's "plan" step), read by walk_heavy / walk_light
+  struct WalkProg* prog;   // [N]
 };
+// One question's decoded layout (nmn3_assembler.py:153-222 on the device).  op: n2nmn_op of node t
+// | 0x80 for answer-type nodes; in0 / in1: input nodes or -1; hd: "heavy depth" = the largest number of
+// Transform / FindSameProperty nodes on a path from a leaf up to and including the node; lo: first
+// node of the node's subtree (a subtree is a contiguous token range in Reverse-Polish order).
+struct WalkProg {
+  int32_t nn, valid, fallback, nheavy;
+  uint8_t op[WALK_MAX_T];
+  int8_t in0[WALK_MAX_T], in1[WALK_MAX_T];
+  uint8_t hd[WALK_MAX_T], lo[WALK_MAX_T];
+};
+static_assert(sizeof(WalkProg) == 16 + 5 * WALK_MAX_T && sizeof(WalkProg) % 16 == 0, "WalkProg layout");
 struct WalkArgs {
   WalkBatch b[WALK_MAX_BATCHES];
   int K, N, T, V;
@@ -284,6 +298,19 @@ struct WalkArgs {
   int pre_find;            // Find / Filter logits come from walk_find_kernel (watt), text maps from tmap
   int T_enc, V_txt;        // T_enc > 0: text maps from ew[ws][seq] weighted by atts
   const float* ew[5];      // [V_txt][Mp] embedding_mat . W_txt[ws]
+  // staged walker (passes of many questions, throughput mode): the tree-dependent work leaves the
+  // one-workgroup-per-question chain.  walk_tmap_kernel decodes every layout (prog), lists the
+  // Transform / FindSameProperty nodes whose input subtree holds no other such node (hjobs: they run
+  // chip-wide in walk_heavy_kernel, one workgroup per node) and the questions with deeper nesting
+  // (fblist: the one-workgroup walker serves those as before); walk_light_kernel finishes the others.
+  // cnt[0] = heavy jobs, cnt[1] = fallback questions.
+  int staged;
+  int32_t* hjobs;          // [hcap] (question << 8) | node
+  int32_t* fblist;         // [K * N] flat question indices
+  int32_t* cnt;            // [4] this pass's counters
+  int32_t* cnt_next;       // [4] the other set: walk_heads_kernel zeroes it for the next pass (this pass's
+                           // set stays readable for n2nmn_debug_walk_replay)
+  int hcap;
   // profiling only: [0] conv_image map reads (one per <= 4 Find / Filter nodes of a question, one per
   // FindSameProperty node), [1] pooled inputs, [2] pooling nodes, [3] text maps,
   // [4] Transform nodes, [5] valid questions, [6] deferred pooling jobs, [7] their inputs,
@@ -302,6 +329,8 @@ void launch_walk(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
 // chip-wide front end (table text maps, Find / Filter epilogues): see kernels_walk.hip
 void launch_walk_tmap(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
 void launch_walk_find(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
+void launch_walk_heavy(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
+void launch_walk_light(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
 void launch_walk_pool(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
 void launch_walk_heads(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
 int walk_pool_supported(int H, int W, int D);

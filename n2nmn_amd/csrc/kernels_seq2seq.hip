@@ -1129,6 +1129,64 @@ __global__ __launch_bounds__(256) void enc_prepare_kernel(const int32_t* __restr
   }
 }
 
+// The same ranking as a stable counting sort (lengths are small integers): N <= 1024 questions,
+// T <= 63.  enc_prepare_kernel compares every question with every other one (O(N^2): 27 us at 1024
+// questions, 0.7 % of a pass); here ONE 1024-thread workgroup (block 0) ranks them in a few LDS passes
+// while the other workgroups clear the state block:
+//   1. thread i clamps its length l_i to [0, T]; per wave, the lanes holding equal lengths are found
+//      with six ballots (one per bit of l), which gives the lane's rank among the equal lengths of its
+//      wave and the wave's count per length;
+//   2. cnt[w][l] -> exclusive prefix over the waves per length, totals per length, and
+//      start[l] = #{lengths > l} (descending order);
+//   3. perm[start[l_i] + (equal lengths in earlier waves) + (equal lengths in earlier lanes)] = i --
+//      ties by index, exactly enc_prepare_kernel's order; n_active[t] = #{l > t} = start[t].
+__global__ __launch_bounds__(1024) void enc_prepare_sort_kernel(const int32_t* __restrict__ seq_len,
+                                                                int N, int T, int32_t* __restrict__ perm,
+                                                                int32_t* __restrict__ n_active,
+                                                                float4* __restrict__ zero, size_t zero4,
+                                                                int32_t* __restrict__ zero_int) {
+  const int tid = threadIdx.x;
+  if (blockIdx.x != 0 || gridDim.x == 1) {
+    const size_t nb = gridDim.x == 1 ? 1 : gridDim.x - 1, b = gridDim.x == 1 ? 0 : blockIdx.x - 1;
+    for (size_t i = b * 1024 + tid; i < zero4; i += nb * 1024) zero[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (blockIdx.x != 0) return;
+  }
+  if (zero_int && tid == 0) *zero_int = 0;                 // counter of enc_rows_kernel
+  __shared__ int cnt[16][64];                              // [wave][length]: equal lengths per wave
+  __shared__ int start[64];                                // #{lengths > l}
+  const int lane = tid & 63, w = tid >> 6;
+  const bool have = tid < N;
+  const int l = have ? min(max(seq_len[tid], 0), T) : 0;
+  cnt[w][lane] = 0;
+  __syncthreads();
+  unsigned long long eq = __ballot(have);
+#pragma unroll
+  for (int b = 0; b < 6; ++b) {
+    const unsigned long long m = __ballot(have && ((l >> b) & 1));
+    eq &= ((l >> b) & 1) ? m : ~m;
+  }
+  const int before = __builtin_popcountll(eq & ((1ull << lane) - 1ull));
+  if (have && before == 0) cnt[w][l] = __builtin_popcountll(eq);   // first lane of its class
+  __syncthreads();
+  // exclusive prefix over the waves, per length: thread (w, lane = length)
+  int pre = 0;
+  for (int q = 0; q < w; ++q) pre += cnt[q][lane];
+  int tot = pre;
+  for (int q = w; q < 16; ++q) tot += cnt[q][lane];
+  __syncthreads();
+  cnt[w][lane] = pre;
+  if (w == 0) start[lane] = tot;                            // totals per length, for now
+  __syncthreads();
+  int s2 = 0;                                               // start[l] = sum of totals of lengths > l
+  if (tid < 64)
+    for (int k = tid + 1; k < 64; ++k) s2 += start[k];
+  __syncthreads();
+  if (tid < 64) start[tid] = s2;
+  __syncthreads();
+  if (have) perm[start[l] + cnt[w][l] + before] = tid;
+  if (tid < T) n_active[tid] = start[tid];
+}
+
 // rows[0 .. *count) = the (t, n) rows inside their question's length; one atomic per workgroup of 1024
 // candidates (one per wave took 10 us at 46 K rows: 720 atomics on one address)
 __global__ __launch_bounds__(1024) void enc_rows_kernel(const int32_t* __restrict__ seq_len, int T, int N,
@@ -1386,6 +1444,14 @@ void launch_enc_rows(const int32_t* seq_len, int T, int N, int32_t* rows, int32_
 void launch_enc_prepare(const int32_t* seq_len, int N, int T, int32_t* perm, int32_t* n_active,
                         float* zero, size_t zero_floats, hipStream_t s, int32_t* zero_int) {
   const size_t z4 = zero_floats / 4;             // the state block is a multiple of 4 floats
+  static const bool sort_on = [] { const char* e = getenv("N2NMN_ENC_PREPARE_SORT"); return !e || atoi(e) != 0; }();
+  if (sort_on && N <= 1024 && T <= 63) {
+    // block 0 ranks, the others clear the state block (16 KB per workgroup and trip)
+    const int zb = zero ? (int)std::min<size_t>(255, (z4 + 4095) / 4096) : 0;
+    hipLaunchKernelGGL(enc_prepare_sort_kernel, dim3(1 + zb), dim3(1024), 0, s, seq_len, N, T, perm,
+                       n_active, reinterpret_cast<float4*>(zero), zero ? z4 : 0, zero_int);
+    return;
+  }
   int blocks = zero ? (int)std::min<size_t>(256, (z4 + 1023) / 1024 + 1) : 1;
   blocks = std::max(blocks, std::min(64, (N + 255) / 256 + T / 4));
   hipLaunchKernelGGL(enc_prepare_kernel, dim3(blocks), dim3(256), 0, s, seq_len, N, T, perm, n_active,

@@ -446,7 +446,11 @@ template <int CI>
 __global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ WalkLds L;
-  const int q = blockIdx.x;
+  int q = blockIdx.x;
+  if (a.staged) {              // staged passes: only the questions the plan listed as nested
+    if (q >= a.cnt[1]) return;
+    q = a.fblist[q];
+  }
   const int kb = q / a.N, n = q - kb * a.N;
   const WalkBatch& B = a.b[kb];
   const int tid0 = threadIdx.x;
@@ -923,10 +927,63 @@ namespace {
 // write are never read.
 // ---------------------------------------------------------------------------------------------
 constexpr int FT = 256, FW = FT / 64;
+
+// Reverse-Polish decode of one layout by ONE thread (nmn3_assembler.py:153-222, the walker's stack
+// machine: same checks in the same order), plus what the staged walker needs per node: heavy depth
+// and subtree start.  tok_op[t] = op code of token t, -1 for <eos>, -2 for a token out of range.
+__device__ inline void plan_layout(const int* tok_op, int T, WalkProg& P, int* stack) {
+  int sp = 0, nn = 0, ok = 1;
+  bool has_eos = false;
+  for (int t = 0; t < T; ++t) {
+    if (tok_op[t] == -2) ok = 0;
+    if (tok_op[t] < 0) has_eos = true;
+  }
+  if (!has_eos) ok = 0;
+  int maxhd = 0, nheavy = 0;
+  for (int t = 0; ok && t < T; ++t) {
+    const int op = tok_op[t];
+    if (op < 0) break;
+    int k;
+    bool ans;
+    switch (op) {
+      case N2NMN_OP_SCENE: case N2NMN_OP_FIND: k = 0; ans = false; break;
+      case N2NMN_OP_FILTER: case N2NMN_OP_FIND_SAME_PROPERTY: case N2NMN_OP_TRANSFORM:
+        k = 1; ans = false; break;
+      case N2NMN_OP_AND: case N2NMN_OP_OR: k = 2; ans = false; break;
+      case N2NMN_OP_EXIST: case N2NMN_OP_COUNT: case N2NMN_OP_DESCRIBE: k = 1; ans = true; break;
+      case N2NMN_OP_EQUAL_NUM: case N2NMN_OP_MORE_NUM: case N2NMN_OP_LESS_NUM:
+      case N2NMN_OP_SAME_PROPERTY: k = 2; ans = true; break;
+      default: k = -1; ans = false; break;
+    }
+    if (k < 0 || sp < k) { ok = 0; break; }
+    int i0 = -1, i1 = -1;
+    for (int j = k - 1; j >= 0; --j) {
+      const int top = stack[--sp];
+      if (P.op[top] & 0x80) { ok = 0; break; }
+      (j == 0 ? i0 : i1) = top;
+    }
+    if (!ok) break;
+    const bool heavy = op == N2NMN_OP_TRANSFORM || op == N2NMN_OP_FIND_SAME_PROPERTY;
+    int hd = heavy ? 1 : 0, lo = t;
+    if (i0 >= 0) { hd += P.hd[i0]; lo = P.lo[i0]; }
+    if (i1 >= 0) hd = max(hd, (int)P.hd[i1] + (heavy ? 1 : 0));
+    P.op[t] = (uint8_t)(op | (ans ? 0x80 : 0)); P.in0[t] = (int8_t)i0; P.in1[t] = (int8_t)i1;
+    P.hd[t] = (uint8_t)hd; P.lo[t] = (uint8_t)lo;
+    maxhd = max(maxhd, hd); nheavy += heavy;
+    stack[sp++] = t;
+    nn = t + 1;
+  }
+  if (ok && (sp != 1 || !(P.op[stack[0]] & 0x80))) ok = 0;
+  P.nn = nn; P.valid = ok; P.nheavy = nheavy;
+  P.fallback = ok && maxhd >= 2;          // nested Transform / FindSameProperty: the one-workgroup walker
+}
+
 __global__ __launch_bounds__(FT) void walk_tmap_kernel(ModuleWeights w, WalkArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int ops[MAXT];
   __shared__ int s_nn;
+  __shared__ __attribute__((aligned(16))) WalkProg P;
+  __shared__ int stack[MAXT];
   const int q = blockIdx.x;
   const int kb = q / a.N, n = q - kb * a.N;
   const WalkBatch& B = a.b[kb];
@@ -937,13 +994,28 @@ __global__ __launch_bounds__(FT) void walk_tmap_kernel(ModuleWeights w, WalkArgs
   float* attall = smem + Tep;                               // [T][Tep]
   if (tid < T) {
     const int tok = B.tokens[(size_t)tid * a.N + n];
-    ops[tid] = (tok < 0 || tok >= a.V) ? -1 : a.token_op[tok];
+    ops[tid] = (tok < 0 || tok >= a.V) ? -2 : a.token_op[tok];
   }
   __syncthreads();
   if (tid == 0) {
     int nn = 0;
     while (nn < T && ops[nn] >= 0) ++nn;
     s_nn = nn;
+    if (a.staged) {
+      // the pass's plan: decode once, list the chip-wide jobs (see WalkArgs::staged)
+      plan_layout(ops, T, P, stack);
+      if (P.valid && !P.fallback) {
+        for (int t = 0; t < P.nn; ++t) {
+          const int o = P.op[t] & 0x7f;
+          if ((o == N2NMN_OP_TRANSFORM || o == N2NMN_OP_FIND_SAME_PROPERTY) && P.hd[t] == 1) {
+            const int j = atomicAdd(a.cnt + 0, 1);
+            if (j < a.hcap) a.hjobs[j] = (q << 8) | t;
+          }
+        }
+      } else if (P.valid) {
+        a.fblist[atomicAdd(a.cnt + 1, 1)] = q;
+      }
+    }
   }
   const int qlen = min(max(B.seq_len[n], 0), Te);
   for (int tau = tid; tau < Te; tau += FT) {
@@ -951,6 +1023,11 @@ __global__ __launch_bounds__(FT) void walk_tmap_kernel(ModuleWeights w, WalkArgs
     seql[tau] = min(max(v, 0), a.V_txt - 1);
   }
   __syncthreads();
+  if (a.staged) {                                           // 176 bytes per question
+    const int4* src = reinterpret_cast<const int4*>(&P);
+    int4* dst = reinterpret_cast<int4*>(B.prog + n);
+    if (tid < (int)(sizeof(WalkProg) / 16)) dst[tid] = src[tid];
+  }
   const int nn = s_nn;
   for (int i = tid; i < nn * Te; i += FT) {
     const int t = i / Te, tau = i - t * Te;
@@ -985,10 +1062,34 @@ __global__ __launch_bounds__(FT) void walk_tmap_kernel(ModuleWeights w, WalkArgs
   }
 }
 
-template <int CI, int NF>
+// rows of a wave in flight per batch (CI float4 column groups each)
+template <int CI> struct FindUnroll { static constexpr int value = CI == 1 ? 10 : (CI == 2 ? 5 : 3); };
+
+// the map rows [rb, rb + UNR * FW) of this wave (row = rb + u * FW), 16 bytes per lane and column group
+template <int CI> struct FindRows { float4 v[FindUnroll<CI>::value][CI]; };
+template <int CI>
+__device__ __forceinline__ FindRows<CI> find_load(const float* Mbuf, int rb, int r1, int lane, int Mp) {
+  constexpr int UNR = FindUnroll<CI>::value;
+  FindRows<CI> m;
+#pragma unroll
+  for (int u = 0; u < UNR; ++u) {
+    const unsigned r = (unsigned)min(rb + u * FW, r1 - 1);
+#pragma unroll
+    for (int i = 0; i < CI; ++i) {
+      const unsigned c = (unsigned)min(4 * lane + 256 * i, Mp - 4);
+      m.v[u][i] = *reinterpret_cast<const float4*>(Mbuf + (r * (unsigned)Mp + c));
+    }
+  }
+  return m;
+}
+
+// `pre` holds the first batch of this wave's rows (rows r0 + wid + u * FW), requested by the caller
+// BEFORE it knew the layout (use_pre): the token -> op -> text-map chain of dependent loads then runs
+// under the stream of map rows instead of in front of it.
+template <int CI, int NF, bool ONE>
 __device__ __forceinline__ void find_rows(int tid, const ModuleWeights& w, const float* Mbuf,
                                           const float* const* ts, float* const* os, int r0, int r1,
-                                          int Mp) {
+                                          int Mp, const FindRows<CI> pre) {
   const int lane = tid & 63, wid = tid >> 6;
   const float be = w.be[0][0];
   float4 t4[NF][CI], e4[CI];
@@ -1001,18 +1102,11 @@ __device__ __forceinline__ void find_rows(int tid, const ModuleWeights& w, const
     for (int j = 0; j < NF; ++j)
       t4[j][i] = ok ? *reinterpret_cast<const float4*>(ts[j] + c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  constexpr int UNR = CI == 1 ? 10 : (CI == 2 ? 5 : 3);     // rows of a wave in flight
+  constexpr int UNR = FindUnroll<CI>::value;
   for (int rb = r0 + wid; rb < r1; rb += UNR * FW) {
-    float4 m4[UNR][CI];
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const unsigned r = (unsigned)min(rb + u * FW, r1 - 1);
-#pragma unroll
-      for (int i = 0; i < CI; ++i) {
-        const unsigned c = (unsigned)min(4 * lane + 256 * i, Mp - 4);
-        m4[u][i] = *reinterpret_cast<const float4*>(Mbuf + (r * (unsigned)Mp + c));
-      }
-    }
+    // the first batch of a wave's rows was requested by the caller before it knew the layout (ONE:
+    // that batch is all of them -- r1 - r0 <= UNR * FW, checked by the launcher)
+    const FindRows<CI> m = (ONE || rb == r0 + wid) ? pre : find_load<CI>(Mbuf, rb, r1, lane, Mp);
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int r = rb + u * FW;
@@ -1021,8 +1115,8 @@ __device__ __forceinline__ void find_rows(int tid, const ModuleWeights& w, const
         float ss = 0.f, dot = 0.f;
 #pragma unroll
         for (int i = 0; i < CI; ++i) {
-          const float p0 = m4[u][i].x * t4[j][i].x, p1 = m4[u][i].y * t4[j][i].y,
-                      p2 = m4[u][i].z * t4[j][i].z, p3 = m4[u][i].w * t4[j][i].w;
+          const float p0 = m.v[u][i].x * t4[j][i].x, p1 = m.v[u][i].y * t4[j][i].y,
+                      p2 = m.v[u][i].z * t4[j][i].z, p3 = m.v[u][i].w * t4[j][i].w;
           ss += p0 * p0 + p1 * p1 + p2 * p2 + p3 * p3;
           dot += p0 * e4[i].x + p1 * e4[i].y + p2 * e4[i].z + p3 * e4[i].w;
         }
@@ -1034,7 +1128,7 @@ __device__ __forceinline__ void find_rows(int tid, const ModuleWeights& w, const
   }
 }
 
-template <int CI>
+template <int CI, bool ONE>
 __global__ __launch_bounds__(FT) void walk_find_kernel(ModuleWeights w, WalkArgs a) {
   __shared__ int flist[MAXT];
   __shared__ int s_nf;
@@ -1043,6 +1137,15 @@ __global__ __launch_bounds__(FT) void walk_find_kernel(ModuleWeights w, WalkArgs
   const WalkBatch& B = a.b[kb];
   const int tid = threadIdx.x;
   const int T = a.T, HW = a.H * a.W, Mp = a.Mp, HWp = a.HWp;
+  const int rpp = (HW + WALK_FIND_PARTS - 1) / WALK_FIND_PARTS;
+  const int r0 = blockIdx.y * rpp, r1 = min(HW, r0 + rpp);
+  const float* Mbuf = B.mfind + (size_t)n * HW * Mp;
+  // This workgroup's rows of the image's conv_image map do not depend on the layout: their loads go
+  // out FIRST (every valid layout but a Scene-only one reads them), and the dependent chain
+  // tokens -> op codes -> text maps runs while they are in flight
+  const bool have_rows = r0 < r1;
+  const FindRows<CI> pre = find_load<CI>(Mbuf, r0 + (tid >> 6), have_rows ? r1 : r0 + 1, tid & 63, Mp);
+  __builtin_amdgcn_sched_barrier(0);
   __shared__ int ops[MAXT];
   if (tid < T) {                                    // the T token loads go out in parallel
     const int tok = B.tokens[(size_t)tid * a.N + n];
@@ -1060,10 +1163,7 @@ __global__ __launch_bounds__(FT) void walk_find_kernel(ModuleWeights w, WalkArgs
   }
   __syncthreads();
   const int nfind = s_nf;
-  if (nfind == 0) return;
-  const int rpp = (HW + WALK_FIND_PARTS - 1) / WALK_FIND_PARTS;
-  const int r0 = blockIdx.y * rpp, r1 = min(HW, r0 + rpp);
-  const float* Mbuf = B.mfind + (size_t)n * HW * Mp;
+  if (nfind == 0 || !have_rows) return;
   for (int f0 = 0; f0 < nfind; f0 += 4) {
     const int nf = min(4, nfind - f0);
     const float* ts[4];
@@ -1074,10 +1174,10 @@ __global__ __launch_bounds__(FT) void walk_find_kernel(ModuleWeights w, WalkArgs
       os[j] = B.watt + ((size_t)n * T + t) * HWp;
     }
     switch (nf) {
-      case 1: find_rows<CI, 1>(tid, w, Mbuf, ts, os, r0, r1, Mp); break;
-      case 2: find_rows<CI, 2>(tid, w, Mbuf, ts, os, r0, r1, Mp); break;
-      case 3: find_rows<CI, 3>(tid, w, Mbuf, ts, os, r0, r1, Mp); break;
-      default: find_rows<CI, 4>(tid, w, Mbuf, ts, os, r0, r1, Mp); break;
+      case 1: find_rows<CI, 1, ONE>(tid, w, Mbuf, ts, os, r0, r1, Mp, pre); break;
+      case 2: find_rows<CI, 2, ONE>(tid, w, Mbuf, ts, os, r0, r1, Mp, pre); break;
+      case 3: find_rows<CI, 3, ONE>(tid, w, Mbuf, ts, os, r0, r1, Mp, pre); break;
+      default: find_rows<CI, 4, ONE>(tid, w, Mbuf, ts, os, r0, r1, Mp, pre); break;
     }
   }
 }
@@ -1151,10 +1251,112 @@ __global__ __launch_bounds__(256) void walk_pool_kernel(WalkArgs a) {
   }
 }
 
-// fc_att, l2-normalised product with the text map, fc_eltwise of the deferred questions
-// (nmn3_modules.py:442-450, 487-493): one workgroup per question, same arithmetic as the walker's
-// in-line path.  (Folding a partial fc_att into walk_pool_kernel was measured: pool 10.0 -> 15.7 us,
-// heads 26.1 -> 10.3 us per 256-question launch; kept apart so the pooling kernel is a pure stream.)
+// fc_att of the deferred pooling jobs (nmn3_modules.py:442-446, 487-490), grouped: every job of one
+// weight set multiplies its pooled feature vector with the same [D, Mp] matrix (512 KB at CLEVR
+// dimensions).  One workgroup per job pulled that matrix from L2 once per job (309 jobs: 158 MB, 34 us
+// per 1024 questions); here a workgroup takes HG jobs of ONE weight set -- ranked by scanning the job
+// codes of the launch, as walk_textmap_kernel does -- and every weight row it fetches meets HG vectors.
+// Weight sets: y = 0 Describe (fc_att of input 0), 1 / 2 SameProperty input 0 / input 1.  The K-split,
+// the order of the partial sums and the bias-first reduction are fc_pad's, so a row equals what the
+// one-workgroup-per-job kernel computed.  Rows go to pfc[n][input][Mp].
+constexpr int HG = 4;
+__global__ __launch_bounds__(WT) void walk_fcatt_kernel(ModuleWeights w, WalkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ int wcount[WW];
+  __shared__ int sel[HG];
+  if (a.staged && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    a.cnt_next[0] = 0; a.cnt_next[1] = 0;      // the NEXT staged pass starts from empty lists
+  }
+  const int g = blockIdx.x, y = blockIdx.y;
+  const int want = y == 0 ? N2NMN_OP_DESCRIBE : N2NMN_OP_SAME_PROPERTY;
+  const int which = y == 2 ? 1 : 0;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int D = a.D, Mp = a.Mp, QN = a.K * a.N;
+  // ---- rank the questions of the launch whose job uses this weight set
+  int base = 0;
+  for (int q0 = 0; q0 < QN; q0 += WT) {
+    const int q = q0 + tid;
+    bool hit = false;
+    if (q < QN) {
+      const int kb = q / a.N;
+      hit = a.b[kb].pjob[q - kb * a.N] == want;
+    }
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) wcount[wid] = __builtin_popcountll(m);
+    __syncthreads();
+    int before = base, all = 0;
+    for (int i = 0; i < WW; ++i) { if (i < wid) before += wcount[i]; all += wcount[i]; }
+    const int rank = before + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+    if (hit && rank >= HG * g && rank < HG * g + HG) sel[rank - HG * g] = q;
+    base += all;
+    __syncthreads();
+    if (base >= HG * g + HG) break;               // (uniform) this workgroup's jobs are all known
+  }
+  const int cnt = min(HG, base - HG * g);
+  if (cnt <= 0) return;
+  float* x = smem;                                // [HG][D]
+  float* part = x + (size_t)HG * D;               // [WW][HG][256]
+  for (int i = tid; i < HG * D; i += WT) {
+    const int j = i / D, k = i - j * D;
+    float v = 0.f;
+    if (j < cnt) {
+      const int q = sel[j], kb = q / a.N, n = q - kb * a.N;
+      v = a.b[kb].pooled[((size_t)n * 2 + which) * D + k];
+    }
+    x[i] = v;
+  }
+  __syncthreads();
+  const int wi = y == 0 ? 3 : y;                  // ModuleWeights::Watt: FSP, SameProperty 0 / 1, Describe
+  const float* Wp = w.Watt[wi];
+  const float* bm = w.batt[wi];
+  const int kper = (D + WW - 1) / WW;
+  const int k0 = wid * kper, k1 = min(D, k0 + kper);
+  constexpr int KU = 16;
+  for (int cb = 0; cb < Mp; cb += 256) {
+    float4 acc[HG];
+#pragma unroll
+    for (int j = 0; j < HG; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned col = (unsigned)min(cb + 4 * lane, Mp - 4);
+    for (int kq = k0; kq < k1; kq += KU) {
+      float4 w4[KU];
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        const unsigned k = (unsigned)min(kq + u, k1 - 1);
+        w4[u] = *reinterpret_cast<const float4*>(Wp + (k * (unsigned)Mp + col));
+      }
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        if (kq + u < k1) {
+#pragma unroll
+          for (int j = 0; j < HG; ++j) {
+            const float xv = x[j * D + kq + u];
+            acc[j].x += xv * w4[u].x; acc[j].y += xv * w4[u].y; acc[j].z += xv * w4[u].z;
+            acc[j].w += xv * w4[u].w;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < HG; ++j)
+      *reinterpret_cast<float4*>(part + ((size_t)(wid * HG + j) * 256) + 4 * lane) = acc[j];
+    __syncthreads();
+    for (int i = tid; i < HG * 256; i += WT) {
+      const int j = i >> 8, c = i & 255;
+      if (j < cnt && cb + c < Mp) {
+        float r = bm[cb + c];
+#pragma unroll
+        for (int qq = 0; qq < WW; ++qq) r += part[(size_t)(qq * HG + j) * 256 + c];
+        const int q = sel[j], kb = q / a.N, n = q - kb * a.N;
+        a.b[kb].pfc[((size_t)n * 2 + which) * Mp + cb + c] = r;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// l2-normalised product with the text map and fc_eltwise of the deferred questions
+// (nmn3_modules.py:447-450, 491-493): one workgroup per question, the walker's in-line arithmetic, on
+// the fc_att rows walk_fcatt_kernel left in pfc.
 __global__ __launch_bounds__(WT) void walk_heads_kernel(ModuleWeights w, WalkArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int q = blockIdx.x;
@@ -1162,23 +1364,15 @@ __global__ __launch_bounds__(WT) void walk_heads_kernel(ModuleWeights w, WalkArg
   const WalkBatch& B = a.b[kb];
   const int op = B.pjob[n];
   if (op == 0) return;
-  const int D = a.D, M = a.M, Mp = a.Mp, C = a.C;
+  const int M = a.M, Mp = a.Mp, C = a.C;
   const int tid = threadIdx.x;
-  float* pooled = smem;                  // [2][D]
-  float* am0 = pooled + 2 * (size_t)D;   // [Mp]
-  float* am1 = am0 + Mp;
-  float* tm = am1 + Mp;
-  float* ev = tm + Mp;
+  float* ev = smem;                      // [Mp]
   float* rs = ev + Mp;                   // [32]
-  float* scr = rs + 32;                  // [WW][256] | [WT]
+  float* scr = rs + 32;                  // [WT]
   const bool same = op == N2NMN_OP_SAME_PROPERTY;
-  const int nin = same ? 2 : 1;
-  const float* pg = B.pooled + (size_t)n * 2 * D;
-  for (int i = tid; i < nin * D; i += WT) pooled[i] = pg[i];
-  for (int c = tid; c < Mp; c += WT) tm[c] = B.ptm[(size_t)n * Mp + c];
-  __syncthreads();
-  fc_pad<32>(tid, pooled, D, w.Watt[same ? 1 : 3], w.batt[same ? 1 : 3], Mp, am0, scr, nullptr);
-  if (same) fc_pad<32>(tid, pooled + D, D, w.Watt[2], w.batt[2], Mp, am1, scr, nullptr);
+  const float* am0 = B.pfc + (size_t)n * 2 * Mp;
+  const float* am1 = am0 + Mp;
+  const float* tm = B.ptm + (size_t)n * Mp;
   float lss = 0.f;
   for (int c = tid; c < Mp; c += WT) {
     float v = 0.f;
@@ -1199,6 +1393,361 @@ __global__ __launch_bounds__(WT) void walk_heads_kernel(ModuleWeights w, WalkArg
 
 }  // namespace
 
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// Staged walker, passes of many questions (WalkArgs::staged).  What is left of a question's tree once
+// the text maps and the Find / Filter epilogues run chip-wide falls into two classes:
+//   heavy  Transform (2.3 MFLOP of fp32 MFMA) and FindSameProperty (a 307 KB feature pool, a 512 KB
+//          fc_att stream and a 154 KB map epilogue): microseconds each on one CU;
+//   light  And / Or / Filter's min / Scene, the answer operators (a few hundred flops on 150-float
+//          maps) and the soft-max of the deferred pooling roots.
+// In the one-workgroup-per-question walker the heavy nodes sat on each question's chain with one
+// 235-VGPR workgroup per CU (four rounds of 256 questions per 1024: 100 us, 7 % of HBM).  Here
+//   walk_heavy_kernel  runs every heavy node whose input subtree holds no other heavy node as a job of
+//                      its own (list built by walk_tmap_kernel's plan step): the workgroup evaluates
+//                      the (light) input subtree from the Find / Filter logits in `watt`, runs the
+//                      operator with the walker's own device code, and writes the map to watt[n][t];
+//   walk_light_kernel  one workgroup per question: every remaining node from `watt`, the answer
+//                      logits or the deferred-pooling tables;
+//   walk_kernel        only for the questions the plan listed as nested (fblist), as before.
+// Same arithmetic, operator by operator, as walk_kernel (shared device functions / copied statement
+// by statement), so a question's logits do not depend on which path served it.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_prog(int tid, const WalkProg* src, WalkProg& P) {
+  const int4* s4 = reinterpret_cast<const int4*>(src);
+  int4* d4 = reinterpret_cast<int4*>(&P);
+  if (tid < (int)(sizeof(WalkProg) / 16)) d4[tid] = s4[tid];
+}
+
+// nodes [lo, hi] of a question into the LDS arena: rows that exist in `watt` (Find, Filter's
+// find_result, and -- when `heavy_too` -- the Transform / FindSameProperty maps walk_heavy_kernel wrote)
+// are fetched with every load in flight, then the light operators run in token order
+__device__ __forceinline__ void eval_light_range(int tid, const WalkProg& P, int lo, int hi,
+                                                 const float* watt_q, float* arena, int HW, int HWp,
+                                                 bool heavy_too) {
+  const int cnt = hi - lo + 1;
+  for (int i = tid; i < cnt * HWp; i += WT) {
+    const int t = lo + i / HWp, r = i - (i / HWp) * HWp;
+    const int o = P.op[t] & 0x7f;
+    const bool mat = o == N2NMN_OP_FIND || o == N2NMN_OP_FILTER ||
+                     (heavy_too && (o == N2NMN_OP_TRANSFORM || o == N2NMN_OP_FIND_SAME_PROPERTY));
+    if (mat && r < HW) arena[(size_t)t * HWp + r] = watt_q[(size_t)t * HWp + r];
+  }
+  __syncthreads();
+  for (int t = lo; t <= hi; ++t) {
+    const int o = P.op[t] & 0x7f;
+    float* outp = arena + (size_t)t * HWp;
+    const float* in0 = P.in0[t] >= 0 ? arena + (size_t)P.in0[t] * HWp : nullptr;
+    const float* in1 = P.in1[t] >= 0 ? arena + (size_t)P.in1[t] * HWp : nullptr;
+    bool wrote = true;
+    switch (o) {
+      case N2NMN_OP_SCENE:                                       // :60-72
+        for (int r = tid; r < HW; r += WT) outp[r] = 3.0f;
+        break;
+      case N2NMN_OP_AND:                                         // :218-236
+        for (int r = tid; r < HW; r += WT) outp[r] = fminf(in0[r], in1[r]);
+        break;
+      case N2NMN_OP_OR:                                          // :238-256
+        for (int r = tid; r < HW; r += WT) outp[r] = fmaxf(in0[r], in1[r]);
+        break;
+      case N2NMN_OP_FILTER:                                      // And(input_0, find_result) :129-130
+        for (int r = tid; r < HW; r += WT) outp[r] = fminf(in0[r], outp[r]);
+        break;
+      default: wrote = false; break;
+    }
+    if (wrote) __syncthreads();                                  // (uniform: o is the same for all)
+  }
+}
+
+// FindSameProperty of one node (nmn3_modules.py:134-183): soft-max pooling of the image features
+// under the input map, fc_att, then the Find-type epilogue over the operator's own conv_image map --
+// walk_kernel's statements for this operator.
+template <int CI>
+__device__ __forceinline__ void heavy_fsp(int tid, const ModuleWeights& w, const WalkArgs& a,
+                                          const float* feat, const float* Mbuf, const float* in0,
+                                          const float* tml, float* outp, float* am0, float* pooled,
+                                          float* sa0, float* rs, float* scr) {
+  const int HW = a.H * a.W, D = a.D, Mp = a.Mp;
+  const int ncol = D / 4, nrow = WT / ncol;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int lc = tid % ncol, lr = tid / ncol;
+  constexpr int PR = WALK_POOL_ROWS;
+  float4 fr[PR];
+  const int myrows = lr < nrow ? (HW - lr + nrow - 1) / nrow : 0;
+  {
+    const unsigned rowstep = (unsigned)(nrow * D);
+    unsigned off = (unsigned)(lr * D + 4 * lc);
+    const unsigned last = (unsigned)(((myrows > 0 ? lr + (myrows - 1) * nrow : 0)) * D + 4 * lc);
+#pragma unroll
+    for (int qq = 0; qq < PR; ++qq) {
+      fr[qq] = *reinterpret_cast<const float4*>(feat + min(off, last));
+      off += rowstep;
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  {                                                      // soft-max over the H*W logits (:170-172)
+    float lm = -INFINITY;
+    for (int r = tid; r < HW; r += WT) lm = fmaxf(lm, in0[r]);
+    const float mx = wg_reduce<1>(lm, rs);
+    float ls = 0.f;
+    for (int r = tid; r < HW; r += WT) {
+      const float ex = expf(in0[r] - mx);
+      sa0[r] = ex;
+      ls += ex;
+    }
+    const float sum = wg_reduce<0>(ls, rs);
+    for (int r = tid; r < HW; r += WT) sa0[r] = sa0[r] / sum;
+  }
+  __syncthreads();
+  float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float* stage = scr;                                    // [nrow][2][D] (walk_kernel's layout)
+  if (lr < nrow) {
+#pragma unroll
+    for (int qq = 0; qq < PR; ++qq) {
+      if (qq < myrows) {
+        const int r = lr + qq * nrow;
+        const float w0 = sa0[r];
+        acc0.x += w0 * fr[qq].x; acc0.y += w0 * fr[qq].y; acc0.z += w0 * fr[qq].z; acc0.w += w0 * fr[qq].w;
+      }
+    }
+    *reinterpret_cast<float4*>(stage + (size_t)(lr * 2 + 0) * D + 4 * lc) = acc0;
+  }
+  __syncthreads();
+  for (int i = tid; i < D; i += WT) {
+    float sacc = 0.f;
+    for (int qq = 0; qq < nrow; ++qq) sacc += stage[(size_t)(qq * 2) * D + i];
+    pooled[i] = sacc;
+  }
+  __syncthreads();
+  fc_pad<32>(tid, pooled, D, w.Watt[0], w.batt[0], Mp, am0, scr, nullptr);     // :173-176
+  __syncthreads();
+  const float be = w.be[1][0];
+  float4 t4[CI], e4[CI];
+#pragma unroll
+  for (int i = 0; i < CI; ++i) {
+    const int c = 4 * lane + 256 * i;
+    if (c < Mp) {
+      t4[i] = *reinterpret_cast<const float4*>(tml + c);
+      e4[i] = *reinterpret_cast<const float4*>(w.we[1] + c);
+      const float4 a4 = *reinterpret_cast<const float4*>(am0 + c);
+      t4[i].x *= a4.x; t4[i].y *= a4.y; t4[i].z *= a4.z; t4[i].w *= a4.w;
+    } else {
+      t4[i] = make_float4(0.f, 0.f, 0.f, 0.f); e4[i] = t4[i];
+    }
+  }
+  constexpr int UNR = CI == 1 ? 19 : (CI == 2 ? 10 : 5);
+  for (int rb = wid; rb < HW; rb += UNR * WW) {
+    float4 m4[UNR][CI];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const unsigned r = (unsigned)min(rb + u * WW, HW - 1);
+#pragma unroll
+      for (int i = 0; i < CI; ++i) {
+        const unsigned c = (unsigned)min(4 * lane + 256 * i, Mp - 4);
+        m4[u][i] = *reinterpret_cast<const float4*>(Mbuf + (r * (unsigned)Mp + c));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int r = rb + u * WW;
+      float ss = 0.f, dot = 0.f;
+#pragma unroll
+      for (int i = 0; i < CI; ++i) {
+        const float p0 = m4[u][i].x * t4[i].x, p1 = m4[u][i].y * t4[i].y,
+                    p2 = m4[u][i].z * t4[i].z, p3 = m4[u][i].w * t4[i].w;
+        ss += p0 * p0 + p1 * p1 + p2 * p2 + p3 * p3;
+        dot += p0 * e4[i].x + p1 * e4[i].y + p2 * e4[i].z + p3 * e4[i].w;
+      }
+      const float s2 = wave_sum(ss);
+      const float d2 = wave_sum(dot);
+      if (lane == 0 && r < HW) outp[r] = d2 / sqrtf(fmaxf(s2, 1e-12f)) + be;   // l2_normalize eps (A.4)
+    }
+  }
+  __syncthreads();
+}
+
+template <int CI>
+__global__ __launch_bounds__(WT) void walk_heavy_kernel(ModuleWeights w, WalkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ __attribute__((aligned(16))) WalkProg P;
+  const int HW = a.H * a.W, D = a.D, Mp = a.Mp, HWp = a.HWp, T = a.T;
+  float* arena = smem;                                 // [T][HWp]
+  float* tml = arena + (size_t)T * HWp;                // [Mp] text map of the node
+  float* am0 = tml + Mp;                               // [Mp] fc_att
+  float* pooled = am0 + Mp;                            // [D]
+  float* sa0 = pooled + D;                             // [HWp]
+  float* rs = sa0 + HWp;                               // [32]
+  float* scr = rs + 32;                                // operator scratch (walk_lds_floats's maximum)
+  const int njobs = min(*a.cnt, a.hcap);
+  for (int j = blockIdx.x; j < njobs; j += gridDim.x) {
+    // the opaque copy keeps one operator's address arithmetic from being hoisted across the other
+    // (see walk_kernel)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int job = a.hjobs[j];
+    const int q = job >> 8, t = job & 0xff;
+    if (q < 0 || q >= a.K * a.N || t >= T) continue;                 // (a stale list entry)
+    const int kb = q / a.N, n = q - kb * a.N;
+    const WalkBatch& B = a.b[kb];
+    __syncthreads();                                   // the previous job's readers of P / LDS are done
+    load_prog(tid, B.prog + n, P);
+    __syncthreads();
+    const int o = P.op[t] & 0x7f;
+    const bool heavy = o == N2NMN_OP_TRANSFORM || o == N2NMN_OP_FIND_SAME_PROPERTY;
+    if (!P.valid || P.fallback || t >= P.nn || !heavy || P.hd[t] != 1 || P.in0[t] < 0) continue;
+    const int i0 = P.in0[t];
+    {                                                   // text map of the node (walk_tmap_kernel's row)
+      const float* src = B.tmap + ((size_t)t * a.N + n) * Mp;
+      for (int c = 4 * tid; c < Mp; c += 4 * WT)
+        *reinterpret_cast<float4*>(tml + c) = *reinterpret_cast<const float4*>(src + c);
+    }
+    const float* watt_q = B.watt + (size_t)n * T * HWp;
+    eval_light_range(tid, P, P.lo[i0], i0, watt_q, arena, HW, HWp, false);
+    const float* in0 = arena + (size_t)i0 * HWp;
+    float* outp = arena + (size_t)t * HWp;
+    if (o == N2NMN_OP_TRANSFORM) {                      // :185-216
+      if (a.ksize == 5) walk_transform<5>(tid, w, a, in0, tml, outp, scr, nullptr);
+      else walk_transform<3>(tid, w, a, in0, tml, outp, scr, nullptr);
+    } else {
+      heavy_fsp<CI>(tid, w, a, B.feat + (size_t)n * HW * D, B.mfsp + (size_t)n * HW * Mp, in0, tml,
+                    outp, am0, pooled, sa0, rs, scr);
+    }
+    float* dst = B.watt + ((size_t)n * T + t) * HWp;
+    for (int r = tid; r < HW; r += WT) dst[r] = outp[r];
+  }
+}
+
+__global__ __launch_bounds__(WT) void walk_light_kernel(ModuleWeights w, WalkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ __attribute__((aligned(16))) WalkProg P;
+  const int q = blockIdx.x;
+  const int kb = q / a.N, n = q - kb * a.N;
+  const WalkBatch& B = a.b[kb];
+  const int tid = threadIdx.x;
+  const int HW = a.H * a.W, Mp = a.Mp, HWp = a.HWp, T = a.T, C = a.C;
+  float* arena = smem;                                 // [T][HWp]
+  float* rs = arena + (size_t)T * HWp;                 // [32]
+  float* scr = rs + 32;                                // answer features + fc_out partial sums
+  load_prog(tid, B.prog + n, P);
+  __syncthreads();
+  if (P.valid && P.fallback) return;                   // walk_kernel serves this question (fblist)
+  float* srow = B.scores + (size_t)n * C;
+  if (tid == 0 && B.validity) B.validity[n] = P.valid;
+  if (tid == 0) B.pjob[n] = 0;
+  if (!P.valid) {                                      // INVALID_EXPR: zero logits (nmn3_model.py:146,155)
+    for (int c = tid; c < C; c += WT) srow[c] = 0.f;
+    return;
+  }
+  const int nn = P.nn;
+  if (a.stats && tid == 0) {                           // the counters walk_kernel keeps (profiling only)
+    unsigned long long cf = 0, cpi = 0, cp = 0, ct = 0, ctr = 0, nfind = 0;
+    for (int t = 0; t < nn; ++t) {
+      const int o = P.op[t] & 0x7f;
+      const bool f = o == N2NMN_OP_FIND || o == N2NMN_OP_FILTER || o == N2NMN_OP_FIND_SAME_PROPERTY;
+      const bool p = o == N2NMN_OP_FIND_SAME_PROPERTY || o == N2NMN_OP_SAME_PROPERTY || o == N2NMN_OP_DESCRIBE;
+      cf += o == N2NMN_OP_FIND_SAME_PROPERTY; cp += p;
+      cpi += p ? (o == N2NMN_OP_SAME_PROPERTY ? 2 : 1) : 0;
+      ct += (f || p || o == N2NMN_OP_TRANSFORM); ctr += o == N2NMN_OP_TRANSFORM;
+      nfind += o == N2NMN_OP_FIND || o == N2NMN_OP_FILTER;
+    }
+    atomicAdd(a.stats + 8, (nfind + 3) / 4);
+    atomicAdd(a.stats + 0, cf); atomicAdd(a.stats + 1, cpi); atomicAdd(a.stats + 2, cp);
+    atomicAdd(a.stats + 3, ct); atomicAdd(a.stats + 4, ctr); atomicAdd(a.stats + 5, 1ull);
+    const int ro = P.op[nn - 1] & 0x7f;
+    if (ro == N2NMN_OP_DESCRIBE || ro == N2NMN_OP_SAME_PROPERTY) {
+      atomicAdd(a.stats + 6, 1ull); atomicAdd(a.stats + 7, ro == N2NMN_OP_SAME_PROPERTY ? 2ull : 1ull);
+    }
+  }
+  // every attention node of the tree: the root is the only answer node (a valid layout)
+  eval_light_range(tid, P, 0, nn - 2, B.watt + (size_t)n * T * HWp, arena, HW, HWp, true);
+  const int t = nn - 1;
+  const int op = P.op[t] & 0x7f;
+  const float* in0 = P.in0[t] >= 0 ? arena + (size_t)P.in0[t] * HWp : nullptr;
+  const float* in1 = P.in1[t] >= 0 ? arena + (size_t)P.in1[t] * HWp : nullptr;
+  if (op == N2NMN_OP_DESCRIBE || op == N2NMN_OP_SAME_PROPERTY) {
+    // deferred pooling root: soft-max weights, text map and job code for walk_pool / walk_heads
+    // (:432-437,482-484) -- walk_kernel's statements
+    const int nin = op == N2NMN_OP_SAME_PROPERTY ? 2 : 1;
+    float* pw = B.pw + (size_t)n * 2 * HWp;
+    for (int i = 0; i < nin; ++i) {
+      const float* src = i == 0 ? in0 : in1;
+      float lm = -INFINITY;
+      for (int r = tid; r < HW; r += WT) lm = fmaxf(lm, src[r]);
+      const float mx = wg_reduce<1>(lm, rs);
+      float ls = 0.f;
+      for (int r = tid; r < HW; r += WT) ls += expf(src[r] - mx);
+      const float sum = wg_reduce<0>(ls, rs);
+      for (int r = tid; r < HW; r += WT) pw[i * HWp + r] = expf(src[r] - mx) / sum;
+    }
+    float* ptm = B.ptm + (size_t)n * Mp;
+    const float* tsrc = B.tmap + ((size_t)t * a.N + n) * Mp;
+    for (int c = tid; c < Mp; c += WT) ptm[c] = tsrc[c];
+    if (tid == 0) B.pjob[n] = op;
+    return;
+  }
+  // Exist (:258-280), Count (:282-304), EqualNum / MoreNum / LessNum (:306-400)
+  float* x = scr;                                  // up to 2*HW + 4 features
+  float* red = x + ((2 * HW + 4 + 3) & ~3);
+  const int nin = (op == N2NMN_OP_EXIST || op == N2NMN_OP_COUNT) ? 1 : 2;
+  float mn[2], mx[2], sm[2];
+  for (int i = 0; i < nin; ++i) {
+    const float* src = i == 0 ? in0 : in1;
+    float lmn = INFINITY, lmx = -INFINITY, lsm = 0.f;
+    for (int r = tid; r < HW; r += WT) {
+      const float v = src[r];
+      x[i * (HW + 2) + r] = v;                     // row-major y*W + x flatten (:297)
+      lmn = fminf(lmn, v); lmx = fmaxf(lmx, v); lsm += v;
+    }
+    mn[i] = wg_reduce<2>(lmn, rs);
+    mx[i] = wg_reduce<1>(lmx, rs);
+    sm[i] = wg_reduce<0>(lsm, rs);
+  }
+  __syncthreads();
+  int F, wi;
+  if (op == N2NMN_OP_EXIST) {
+    if (tid == 0) { x[0] = mn[0]; x[1] = sm[0] / (float)HW; x[2] = mx[0]; }
+    F = 3; wi = 0;
+  } else if (op == N2NMN_OP_COUNT) {
+    if (tid == 0) { x[HW] = mn[0]; x[HW + 1] = mx[0]; }
+    F = HW + 2; wi = 1;
+  } else {
+    if (tid == 0) {
+      x[HW] = mn[0]; x[HW + 1] = mx[0];
+      x[2 * HW + 2] = mn[1]; x[2 * HW + 3] = mx[1];
+    }
+    F = 2 * HW + 4;
+    wi = op == N2NMN_OP_EQUAL_NUM ? 2 : (op == N2NMN_OP_MORE_NUM ? 3 : 4);
+  }
+  __syncthreads();
+  fc_out(tid, x, F, w.Wans[wi], w.bans[wi], C, srow, red);
+}
+
+}  // namespace
+
+void launch_walk_heavy(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) {
+  const size_t smem = sizeof(float) * walk_lds_floats(a.T, a.HWp, a.Mp, a.E, a.D, a.M, a.ksize,
+                                                      a.H, a.W, a.C, 0);
+  // a persistent grid over the job list: two workgroups per CU's worth of ids, each takes jobs
+  // id, id + grid, ... (the list length lives on the device)
+  const int grid = std::min(512, std::max(1, a.hcap));
+  auto go = [&](auto kern, std::atomic<uint64_t>& done) {
+    if (smem > 64 * 1024) ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)smem, done);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WT), smem, s, w, a);
+  };
+  static std::atomic<uint64_t> d1{0}, d2{0}, d4{0};
+  const int ci = (a.Mp + 255) / 256;
+  if (ci == 1) go(walk_heavy_kernel<1>, d1);
+  else if (ci == 2) go(walk_heavy_kernel<2>, d2);
+  else go(walk_heavy_kernel<4>, d4);
+}
+
+void launch_walk_light(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) {
+  const int HW = a.H * a.W;
+  const size_t smem = sizeof(float) * ((size_t)a.T * a.HWp + 32 + (size_t)((2 * HW + 4 + 3) & ~3) + WT);
+  hipLaunchKernelGGL(walk_light_kernel, dim3(a.K * a.N), dim3(WT), smem, s, w, a);
+}
+
 void launch_walk_pool(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) {
   const int Dp = a.D / POOLP, nrow = 256 / (Dp / 4);
   const size_t smem = sizeof(float) * (2 * (size_t)a.HWp + (size_t)nrow * 2 * Dp);
@@ -1207,9 +1756,14 @@ void launch_walk_pool(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) 
 }
 
 void launch_walk_heads(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) {
-  const size_t scr = std::max<size_t>((size_t)WW * 256, WT);
-  const size_t smem = sizeof(float) * (2 * (size_t)a.D + 4 * (size_t)a.Mp + 32 + scr);
-  hipLaunchKernelGGL(walk_heads_kernel, dim3(a.K * a.N), dim3(WT), smem, s, w, a);
+  // fc_att of all deferred jobs, grouped by weight set, then the heads (one small workgroup each)
+  const int QN = a.K * a.N;
+  const size_t fsm = sizeof(float) * ((size_t)HG * a.D + (size_t)WW * HG * 256);
+  static std::atomic<uint64_t> done{0};
+  if (fsm > 64 * 1024) ensure_dynamic_lds(reinterpret_cast<const void*>(walk_fcatt_kernel), (int)fsm, done);
+  hipLaunchKernelGGL(walk_fcatt_kernel, dim3((QN + HG - 1) / HG, 3), dim3(WT), fsm, s, w, a);
+  const size_t smem = sizeof(float) * ((size_t)a.Mp + 32 + WT);
+  hipLaunchKernelGGL(walk_heads_kernel, dim3(QN), dim3(WT), smem, s, w, a);
 }
 
 int walk_pool_supported(int H, int W, int D) {
@@ -1253,9 +1807,15 @@ void launch_walk_tmap(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) 
 void launch_walk_find(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) {
   const dim3 grid(a.K * a.N, WALK_FIND_PARTS);
   const int ci = (a.Mp + 255) / 256;
-  if (ci == 1) hipLaunchKernelGGL(walk_find_kernel<1>, grid, dim3(FT), 0, s, w, a);
-  else if (ci == 2) hipLaunchKernelGGL(walk_find_kernel<2>, grid, dim3(FT), 0, s, w, a);
-  else hipLaunchKernelGGL(walk_find_kernel<4>, grid, dim3(FT), 0, s, w, a);
+  const int rpp = (a.H * a.W + WALK_FIND_PARTS - 1) / WALK_FIND_PARTS;      // rows of a workgroup
+  if (ci == 1) {
+    if (rpp <= FindUnroll<1>::value * FW) hipLaunchKernelGGL((walk_find_kernel<1, true>), grid, dim3(FT), 0, s, w, a);
+    else hipLaunchKernelGGL((walk_find_kernel<1, false>), grid, dim3(FT), 0, s, w, a);
+  } else if (ci == 2) {
+    hipLaunchKernelGGL((walk_find_kernel<2, false>), grid, dim3(FT), 0, s, w, a);
+  } else {
+    hipLaunchKernelGGL((walk_find_kernel<4, false>), grid, dim3(FT), 0, s, w, a);
+  }
 }
 
 void launch_walk(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) {

@@ -266,6 +266,12 @@ class Engine:
         (n2nmn_walk_set_front_end)."""
         _lib.check(self._lib.n2nmn_walk_set_front_end(self._ctx, int(mode)))
 
+    def set_staged(self, mode: int):
+        """-1 / 1: with the chip-wide front end and deferred pooling, Transform / FindSameProperty nodes
+        run as chip-wide jobs and a light per-question kernel finishes the tree; 0: the one-workgroup
+        walker serves every question (n2nmn_walk_set_staged)."""
+        _lib.check(self._lib.n2nmn_walk_set_staged(self._ctx, int(mode)))
+
     def walk_supported(self) -> bool:
         return bool(self._lib.n2nmn_walk_supported(self._ctx))
 

@@ -269,3 +269,82 @@ def test_walker_node_counters_equal_the_layouts_executed(clevr_engine):
     assert st[1] == pool + cnt('_SameProperty')                    # pooled attention inputs
     assert st[3] == text and st[4] == cnt('_Transform')
     assert st[0] + st[8] == cnt('_FindSameProperty') + find_passes  # conv_image map passes
+
+
+@pytest.mark.parametrize('seed', [1, 2, 3, 4])
+def test_staged_walker_equals_the_one_workgroup_walker(clevr_engine, seed):
+    """passes of many questions (n2nmn_walk_set_staged): the plan step of walk_tmap_kernel decodes every
+    layout on the device, walk_heavy_kernel runs the Transform / FindSameProperty nodes over light input
+    subtrees as chip-wide jobs, walk_light_kernel finishes the tree, and questions with NESTED
+    Transform / FindSameProperty nodes stay with walk_kernel.  Same logits and validity as the
+    one-workgroup walker (same operator code: 2e-6) and the oracle, on the template mix (every staged
+    operator, no nesting), random layouts (shallow: mostly staged; deep: mostly the fall-back list), and
+    a batch with invalid columns."""
+    eng, d, asm, w = clevr_engine
+    batch = synth.make_inputs(d, seed=160 + seed, min_len=1)
+    if seed == 2:
+        toks = synth.template_layout_batch(d, offset=5)
+    else:
+        toks = synth.random_valid_layouts(d, asm.P, asm.W, asm.b, seed=170 + seed,
+                                          max_len=5 if seed == 1 else 12)
+    if seed == 3:                                   # some invalid columns: zero logits, validity 0
+        toks = toks.copy()
+        toks[:, ::5] = asm.name2idx_dict['_Find']
+    names = asm.module_names
+    heavy = np.isin(toks, [asm.name2idx_dict['_Transform'], asm.name2idx_dict['_FindSameProperty']])
+    print('layouts with a Transform / FindSameProperty node: %d of %d (with two or more: %d)' %
+          (int(heavy.any(0).sum()), d.N, int((heavy.sum(0) >= 2).sum())))
+    ref = O.forward(w, NAMES, batch, d.T_decoder, d.num_choices, np.float64, forced_tokens=toks)
+    s2s = eng.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], forced_tokens=toks,
+                      reuse_buffers=False, word_vecs=False)
+    out, val = {}, {}
+    try:
+        eng.set_front_end(1)
+        eng.set_defer_pool(1)
+        for mode in (0, 1, 1):                      # twice staged: the job lists must start empty again
+            eng.set_staged(mode)
+            sc, v = eng.execute_tokens(s2s['predicted_tokens'], batch['image_feat_batch'], None,
+                                       reuse_buffers=False,
+                                       atts=(s2s['atts'], s2s['_input_seq'], s2s['_seq_length']))
+            if mode in out:
+                assert np.array_equal(out[mode], t2n(sc)), 'second staged pass differs from the first'
+            out[mode], val[mode] = t2n(sc).copy(), t2n(v).copy()
+    finally:
+        eng.set_front_end(-1)
+        eng.set_defer_pool(-1)
+        eng.set_staged(-1)
+    assert np.array_equal(val[0], val[1]) and np.array_equal(val[1].astype(bool), ref['validity'])
+    assert_close('staged vs one-workgroup walker', out[1], out[0], 2e-6)
+    assert_close('staged walker vs oracle', out[1], ref['scores'], TOL)
+
+
+def test_staged_walker_node_counters(clevr_engine):
+    """the profiler's node counters (n2nmn_debug_walk_stats) under the staged walker: every question is
+    counted once, by walk_light_kernel or -- nested layouts -- by walk_kernel."""
+    import ctypes as C
+    from n2nmn_amd import _lib
+    eng, d, asm, w = clevr_engine
+    batch = synth.make_inputs(d, seed=9)
+    gt = synth.random_valid_layouts(d, asm.P, asm.W, asm.b, seed=8, max_len=9)
+    try:
+        eng.set_front_end(1)
+        eng.set_defer_pool(1)
+        eng.profile_begin()
+        _, tokens, validity = eng.forward(batch, use_gt_layout=True, gt_layout=gt)
+        eng.profile_end()
+    finally:
+        eng.set_front_end(-1)
+        eng.set_defer_pool(-1)
+    assert validity.all()
+    st = (C.c_uint64 * 10)()
+    _lib.check(eng._lib.n2nmn_debug_walk_stats(eng._ctx, st))
+    idx = {n: i for i, n in enumerate(NAMES)}
+    t = np.asarray(tokens)
+    cnt = lambda *names: sum(int((t == idx[k]).sum()) for k in names)
+    pool = cnt('_FindSameProperty', '_SameProperty', '_Describe')
+    find_passes = sum((int(np.isin(t[:, i], [idx['_Find'], idx['_Filter']]).sum()) + 3) // 4
+                      for i in range(t.shape[1]))
+    assert st[5] == t.shape[1]
+    assert st[2] == pool and st[1] == pool + cnt('_SameProperty')
+    assert st[4] == cnt('_Transform')
+    assert st[0] + st[8] == cnt('_FindSameProperty') + find_passes
