@@ -1434,6 +1434,7 @@ int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int
     c->walk_parity ^= 1;
   }
   if (pre) {
+    a.pre_find = 1;
     {
       ProfScope ps(c, F_WALK_TMAP, 0.0, 0.0, s);
       launch_walk_tmap(w, a, s);
@@ -1442,7 +1443,6 @@ int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int
       ProfScope ps(c, F_WALK_FIND, 0.0, 0.0, s);   // bytes from the device counters (walk stats [8])
       launch_walk_find(w, a, s);
     }
-    a.pre_find = 1;
     c->last_walk_T_enc = a.T_enc;
     a.T_enc = 0;                 // the walker reads tmap instead of building the maps itself
   }
@@ -1514,7 +1514,7 @@ int n2nmn_debug_walk_replay(n2nmn_ctx* c, int which, int iters, double* us_avg, 
     else if (which == 1) launch_walk_pool(w, a, s);
     else if (which == 2) launch_walk_heads(w, a, s);
     else if (which == 3) launch_walk_find(w, a, s);
-    else { WalkArgs t = a; t.T_enc = c->last_walk_T_enc; launch_walk_tmap(w, t, s); }
+    else { WalkArgs t = a; t.T_enc = c->last_walk_T_enc; t.staged = 0; launch_walk_tmap(w, t, s); }   // (no list appends)
   };
   for (int i = 0; i < 3; ++i) one();
   std::vector<hipEvent_t> ev(pairs ? 2 * (size_t)iters : 2);

@@ -41,6 +41,22 @@ __device__ __forceinline__ float wave_sum(float v) {
   v += dpp_f<0x143, 0xC>(0.f, v);    // row_bcast31 -> rows 2, 3
   return readlane63(v);
 }
+// Two wave sums for the price of (almost) one: the upper half of `x` and the lower half of `y` change
+// places (v_permlane32_swap), one add folds both 64-lane sums into 32 lanes each -- x in lanes 0-31, y
+// in lanes 32-63 -- and five DPP steps finish both at once.  Summation order differs from wave_sum's.
+__device__ __forceinline__ void wave_sum2(float x, float y, float& sx, float& sy) {
+  // (the builtin, not inline asm: hipcc then pads the VALU-write -> permlane-read hazard itself)
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  // r[0] = (x[0:31], y[0:31]), r[1] = (x[32:63], y[32:63])
+  float v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  v += dpp_f<0xB1, 0xF>(0.f, v);     // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E, 0xF>(0.f, v);     // quad_perm [2,3,0,1]
+  v += dpp_f<0x141, 0xF>(0.f, v);    // row_half_mirror
+  v += dpp_f<0x140, 0xF>(0.f, v);    // row_mirror: every lane holds its 16-lane row's sum
+  v += dpp_f<0x142, 0xA>(0.f, v);    // row_bcast15 -> rows 1, 3: lanes 16-31 = sum x, lanes 48-63 = sum y
+  sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+  sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 __device__ __forceinline__ float wave_max(float v) {
   v = fmaxf(v, dpp_f<0xB1, 0xF>(v, v));
   v = fmaxf(v, dpp_f<0x4E, 0xF>(v, v));

@@ -128,6 +128,17 @@ struct LstmJob {
   const float* drop;      // nullptr: no dropout
   float* h_drop;          // h * drop in the layout of h_new (the next layer's A0)
   float* save_hd;         // [N][L] row-major copy of it (training: operand of the W1 gradient)
+  // split-operand bf16 mode (lstm_tile3_kernel, kernels_lstm_tile3.hip): every fp32 state buffer above
+  // that a recurrent step READS as an MFMA operand has a companion of three bf16 planes
+  // [3][L/8][R][8] (x = hi + mid + lo exactly); the step that writes a state writes its planes too.
+  // All nullptr: the job runs on the exact-fp32 kernels.
+  const uint16_t* A0b;    // planes of A0 / A1
+  const uint16_t* A1b;
+  uint16_t* h_new_b;      // planes of h_new, fin_h, h_drop (nullptr where the fp32 pointer is)
+  uint16_t* fin_h_b;
+  uint16_t* h_drop_b;
+  const uint16_t* Wb3;    // the job's weights as three bf16 planes per 16-unit tile:
+                          // [L/16][K/32][3 planes][4 gates][64 lanes][8]
 };
 // rows_per_wg: 64 (4 M-tiles per workgroup) or 32 (2 M-tiles; doubles the workgroups of a launch)
 // wide != 0: 32-row x 32-column workgroup tiles for LSTM cell jobs (throughput mode)
@@ -137,6 +148,14 @@ void launch_lstm_step(const LstmJob* jobs, int njobs, int N, int L, int rows_per
 // lstm_tile_kernel (kernels_lstm_tile.hip): LSTM cell jobs on the packed state layout, K in {L, 2L}
 bool lstm_tile_supported(const LstmJob* jobs, int njobs, int L);
 void launch_lstm_tile(const LstmJob* jobs, int njobs, int N, int L, int stages, hipStream_t s);
+// lstm_tile3_kernel (kernels_lstm_tile3.hip): the same step on bf16 MFMAs over three-way split operands
+// (6 cross products, fp32 accumulate): opt-in mode N2NMN_MODE_THROUGHPUT_BF16X3
+bool lstm_tile3_supported(const LstmJob* jobs, int njobs, int L);
+void launch_lstm_tile3(const LstmJob* jobs, int njobs, int N, int L, hipStream_t s, int variant = 0);
+// dst[L/16][K/32][3][4][64][8] bf16 planes of W[row0 + k][gate * L + unit] (k < K), see LstmJob::Wb3
+void launch_pack_tiles64_b3(const float* W, int ld, int row0, int K, int L, uint16_t* dst, hipStream_t s);
+// planes [3][L/8][R][8] of a k-interleaved fp32 state buffer [L/4][R][4] (tests / debug entry points)
+void launch_split_state_b3(const float* h, int L, int R, uint16_t* planes, hipStream_t s);
 
 // Arguments of dec_attn_kernel.  Every per-step pointer is the slice of the FIRST step of the
 // launch; workgroup (n, ts) addresses element ts*N + n of it.
@@ -283,12 +302,13 @@ struct WalkBatch {
 // Transform / FindSameProperty nodes on a path from a leaf up to and including the node; lo: first
 // node of the node's subtree (a subtree is a contiguous token range in Reverse-Polish order).
 struct WalkProg {
-  int32_t nn, valid, fallback, nheavy;
+  int32_t nn, valid, fallback, nfind;
   uint8_t op[WALK_MAX_T];
   int8_t in0[WALK_MAX_T], in1[WALK_MAX_T];
   uint8_t hd[WALK_MAX_T], lo[WALK_MAX_T];
+  uint8_t flist[WALK_MAX_T];   // the nfind nodes that read the FindModule conv_image map (Find, Filter)
 };
-static_assert(sizeof(WalkProg) == 16 + 5 * WALK_MAX_T && sizeof(WalkProg) % 16 == 0, "WalkProg layout");
+static_assert(sizeof(WalkProg) == 16 + 6 * WALK_MAX_T && sizeof(WalkProg) % 16 == 0, "WalkProg layout");
 struct WalkArgs {
   WalkBatch b[WALK_MAX_BATCHES];
   int K, N, T, V;
@@ -303,7 +323,8 @@ struct WalkArgs {
   // Transform / FindSameProperty nodes whose input subtree holds no other such node (hjobs: they run
   // chip-wide in walk_heavy_kernel, one workgroup per node) and the questions with deeper nesting
   // (fblist: the one-workgroup walker serves those as before); walk_light_kernel finishes the others.
-  // cnt[0] = heavy jobs, cnt[1] = fallback questions.
+  // cnt[0] = Transform jobs (hjobs[0 ..)), cnt[1] = fallback questions, cnt[2] = FindSameProperty jobs
+  // (hjobs[hcap / 2 ..): the long jobs, handed out first).
   int staged;
   int32_t* hjobs;          // [hcap] (question << 8) | node
   int32_t* fblist;         // [K * N] flat question indices

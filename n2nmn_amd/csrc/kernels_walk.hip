@@ -105,12 +105,22 @@ __device__ __forceinline__ void fc_out(int tid, const float* x, int F,
   const int c = tid % C, sl = tid / C;
   float s0 = 0.f, s1 = 0.f;
   if (sl < nsl) {
-    int f = sl;
-    for (; f + nsl < F; f += 2 * nsl) {
-      s0 += x[f] * Wm[(size_t)f * C + c];
-      s1 += x[f + nsl] * Wm[(size_t)(f + nsl) * C + c];
+    // the thread's weights go out in groups of FU loads before the first multiply (a loop that loads
+    // and accumulates pays an L2 round trip per trip: 9 for CountModule's 152 features, a third of a
+    // question's whole chain).  Same sums in the same order: even trips into s0, odd trips into s1.
+    constexpr int FU = 10;
+    for (int f0 = sl; f0 < F; f0 += FU * nsl) {
+      float wv[FU];
+#pragma unroll
+      for (int u = 0; u < FU; ++u) wv[u] = Wm[(size_t)min(f0 + u * nsl, F - 1) * C + c];
+#pragma unroll
+      for (int u = 0; u < FU; ++u) {
+        const int f = f0 + u * nsl;
+        if (f < F) {
+          if (u & 1) s1 += x[f] * wv[u]; else s0 += x[f] * wv[u];
+        }
+      }
     }
-    if (f < F) s0 += x[f] * Wm[(size_t)f * C + c];
     red[sl * C + c] = s0 + s1;
   }
   __syncthreads();
@@ -203,10 +213,13 @@ __device__ __forceinline__ void walk_transform(int tid, const ModuleWeights& w, 
     kone[sI] = k == KK ? 1.f : 0.f;
   }
   int poff[PTMAX];
+  const float invW = 1.0f / (float)W;
 #pragma unroll
   for (int pt = 0; pt < PTMAX; ++pt) {
     const int p = min(16 * pt + ci, HW - 1);
-    const int y = p / W;
+    int y = (int)(((float)p + 0.5f) * invW);       // p / W without the 40-instruction integer division
+    y -= y * W > p;                                // (exact for these small values; the fix-ups make it so)
+    y += (y + 1) * W <= p;
     poff[pt] = y * PW + (p - y * W);
   }
   __syncthreads();
@@ -253,16 +266,19 @@ __device__ __forceinline__ void walk_transform(int tid, const ModuleWeights& w, 
       }
     }
   }
-  // a pixel's channels sit in the four 16-lane rows of the wave: fold them, then across waves
+  // a pixel's channels sit in the four 16-lane rows of the wave: fold them, then across waves.  Two
+  // half / row exchanges in registers (v_permlane32_swap, v_permlane16_swap) fold BOTH sums at once --
+  // sum of squares ends up in lanes 0-15, the dot product in lanes 32-47 -- where four __shfl_xor per
+  // pixel tile were four ds_bpermute round trips through the LDS hardware (40 per node).  The four
+  // rows are summed as (row0 + row2) + (row1 + row3).
 #pragma unroll
   for (int pt = 0; pt < PTMAX; ++pt) {
-    float s2 = ssp[pt], d2 = dtp[pt];
-    s2 += __shfl_xor(s2, 16, 64); d2 += __shfl_xor(d2, 16, 64);
-    s2 += __shfl_xor(s2, 32, 64); d2 += __shfl_xor(d2, 32, 64);
-    if (kg == 0 && pt < Pt) {
-      red[((size_t)wid * Pq + 16 * pt + ci) * 2] = s2;
-      red[((size_t)wid * Pq + 16 * pt + ci) * 2 + 1] = d2;
-    }
+    const auto h = __builtin_amdgcn_permlane32_swap(__float_as_uint(ssp[pt]), __float_as_uint(dtp[pt]),
+                                                    false, false);
+    float v = __uint_as_float(h[0]) + __uint_as_float(h[1]);
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    if ((kg & 1) == 0 && pt < Pt) red[((size_t)wid * Pq + 16 * pt + ci) * 2 + (kg >> 1)] = v;
   }
   __syncthreads();
   if (tl && threadIdx.x == 0) tl[2] = clock64();       // debug timeline: MFMA phase done
@@ -931,15 +947,19 @@ constexpr int FT = 256, FW = FT / 64;
 // Reverse-Polish decode of one layout by ONE thread (nmn3_assembler.py:153-222, the walker's stack
 // machine: same checks in the same order), plus what the staged walker needs per node: heavy depth
 // and subtree start.  tok_op[t] = op code of token t, -1 for <eos>, -2 for a token out of range.
-__device__ inline void plan_layout(const int* tok_op, int T, WalkProg& P, int* stack) {
-  int sp = 0, nn = 0, ok = 1;
+// The loop is a chain of dependent LDS accesses, so it is built to need ONE LDS round trip per node:
+// a node's attributes are one packed word (op | answer << 7 | hd << 8 | lo << 16), the two topmost stack
+// entries live in registers, and the stack proper is only read back behind a two-input operator.
+__device__ inline void plan_layout(const int* tok_op, int T, WalkProg& P, int* stack, unsigned* word) {
+  int nn = 0, ok = 1;
   bool has_eos = false;
   for (int t = 0; t < T; ++t) {
     if (tok_op[t] == -2) ok = 0;
     if (tok_op[t] < 0) has_eos = true;
   }
   if (!has_eos) ok = 0;
-  int maxhd = 0, nheavy = 0;
+  int maxhd = 0, nf = 0;
+  int sp = 0, a = -1, b = -1;              // stack depth; a = top, b = second (stack[0 .. sp - 3] in LDS)
   for (int t = 0; ok && t < T; ++t) {
     const int op = tok_op[t];
     if (op < 0) break;
@@ -955,26 +975,30 @@ __device__ inline void plan_layout(const int* tok_op, int T, WalkProg& P, int* s
       case N2NMN_OP_SAME_PROPERTY: k = 2; ans = true; break;
       default: k = -1; ans = false; break;
     }
-    if (k < 0 || sp < k) { ok = 0; break; }
+    if (k < 0 || sp < k) { ok = 0; break; }                      // 'not enough input for ...'
     int i0 = -1, i1 = -1;
-    for (int j = k - 1; j >= 0; --j) {
-      const int top = stack[--sp];
-      if (P.op[top] & 0x80) { ok = 0; break; }
-      (j == 0 ? i0 : i1) = top;
-    }
-    if (!ok) break;
+    unsigned w0 = 0, w1 = 0;
+    if (k == 1) { i0 = a; w0 = word[a]; }
+    else if (k == 2) { i1 = a; i0 = b; w1 = word[a]; w0 = word[b]; }
+    if ((w0 | w1) & 0x80u) { ok = 0; break; }                    // 'input incompatible for ...'
     const bool heavy = op == N2NMN_OP_TRANSFORM || op == N2NMN_OP_FIND_SAME_PROPERTY;
     int hd = heavy ? 1 : 0, lo = t;
-    if (i0 >= 0) { hd += P.hd[i0]; lo = P.lo[i0]; }
-    if (i1 >= 0) hd = max(hd, (int)P.hd[i1] + (heavy ? 1 : 0));
+    if (i0 >= 0) { hd += (int)((w0 >> 8) & 0xff); lo = (int)((w0 >> 16) & 0xff); }
+    if (i1 >= 0) hd = max(hd, (int)((w1 >> 8) & 0xff) + (heavy ? 1 : 0));
+    word[t] = (unsigned)op | (ans ? 0x80u : 0u) | ((unsigned)hd << 8) | ((unsigned)lo << 16);
     P.op[t] = (uint8_t)(op | (ans ? 0x80 : 0)); P.in0[t] = (int8_t)i0; P.in1[t] = (int8_t)i1;
     P.hd[t] = (uint8_t)hd; P.lo[t] = (uint8_t)lo;
-    maxhd = max(maxhd, hd); nheavy += heavy;
-    stack[sp++] = t;
+    if (op == N2NMN_OP_FIND || op == N2NMN_OP_FILTER) P.flist[nf++] = (uint8_t)t;
+    maxhd = max(maxhd, hd);
+    // pop k, push t
+    if (k == 0) { if (sp >= 2) stack[sp - 2] = b; b = a; a = t; }
+    else if (k == 1) { a = t; }
+    else { a = t; b = sp >= 3 ? stack[sp - 3] : -1; }
+    sp += 1 - k;
     nn = t + 1;
   }
-  if (ok && (sp != 1 || !(P.op[stack[0]] & 0x80))) ok = 0;
-  P.nn = nn; P.valid = ok; P.nheavy = nheavy;
+  if (ok && (sp != 1 || !(word[a] & 0x80u))) ok = 0;             // stack size / result type
+  P.nn = nn; P.valid = ok; P.nfind = nf;
   P.fallback = ok && maxhd >= 2;          // nested Transform / FindSameProperty: the one-workgroup walker
 }
 
@@ -984,6 +1008,7 @@ __global__ __launch_bounds__(FT) void walk_tmap_kernel(ModuleWeights w, WalkArgs
   __shared__ int s_nn;
   __shared__ __attribute__((aligned(16))) WalkProg P;
   __shared__ int stack[MAXT];
+  __shared__ unsigned word[MAXT];
   const int q = blockIdx.x;
   const int kb = q / a.N, n = q - kb * a.N;
   const WalkBatch& B = a.b[kb];
@@ -1001,21 +1026,8 @@ __global__ __launch_bounds__(FT) void walk_tmap_kernel(ModuleWeights w, WalkArgs
     int nn = 0;
     while (nn < T && ops[nn] >= 0) ++nn;
     s_nn = nn;
-    if (a.staged) {
-      // the pass's plan: decode once, list the chip-wide jobs (see WalkArgs::staged)
-      plan_layout(ops, T, P, stack);
-      if (P.valid && !P.fallback) {
-        for (int t = 0; t < P.nn; ++t) {
-          const int o = P.op[t] & 0x7f;
-          if ((o == N2NMN_OP_TRANSFORM || o == N2NMN_OP_FIND_SAME_PROPERTY) && P.hd[t] == 1) {
-            const int j = atomicAdd(a.cnt + 0, 1);
-            if (j < a.hcap) a.hjobs[j] = (q << 8) | t;
-          }
-        }
-      } else if (P.valid) {
-        a.fblist[atomicAdd(a.cnt + 1, 1)] = q;
-      }
-    }
+    // the pass's plan: every layout is decoded once, here (walk_find / walk_heavy / walk_light read it)
+    if (a.pre_find) plan_layout(ops, T, P, stack, word);
   }
   const int qlen = min(max(B.seq_len[n], 0), Te);
   for (int tau = tid; tau < Te; tau += FT) {
@@ -1023,7 +1035,7 @@ __global__ __launch_bounds__(FT) void walk_tmap_kernel(ModuleWeights w, WalkArgs
     seql[tau] = min(max(v, 0), a.V_txt - 1);
   }
   __syncthreads();
-  if (a.staged) {                                           // 176 bytes per question
+  if (a.pre_find) {                                         // 208 bytes per question
     const int4* src = reinterpret_cast<const int4*>(&P);
     int4* dst = reinterpret_cast<int4*>(B.prog + n);
     if (tid < (int)(sizeof(WalkProg) / 16)) dst[tid] = src[tid];
@@ -1060,6 +1072,27 @@ __global__ __launch_bounds__(FT) void walk_tmap_kernel(ModuleWeights w, WalkArgs
         *reinterpret_cast<float4*>(B.tmap + ((size_t)t * a.N + n) * Mp + col) = acc;
     }
   }
+  // the chip-wide job lists of the staged walker (WalkArgs::staged) -- last, so that the returning
+  // atomics (an L2 round trip each) delay nothing: Transform jobs from hjobs[0], FindSameProperty jobs
+  // (the long ones, handed out first by walk_heavy_kernel) from hjobs[hcap / 2]
+  if (a.staged && tid == 0 && P.valid) {
+    if (P.fallback) {
+      a.fblist[atomicAdd(a.cnt + 1, 1)] = q;
+    } else {
+      const int half = a.hcap / 2;
+      for (int t = 0; t < P.nn; ++t) {
+        const int o = P.op[t] & 0x7f;
+        if (P.hd[t] != 1) continue;
+        if (o == N2NMN_OP_TRANSFORM) {
+          const int j = atomicAdd(a.cnt + 0, 1);
+          if (j < half) a.hjobs[j] = (q << 8) | t;
+        } else if (o == N2NMN_OP_FIND_SAME_PROPERTY) {
+          const int j = atomicAdd(a.cnt + 2, 1);
+          if (j < half) a.hjobs[half + j] = (q << 8) | t;
+        }
+      }
+    }
+  }
 }
 
 // rows of a wave in flight per batch (CI float4 column groups each)
@@ -1084,8 +1117,7 @@ __device__ __forceinline__ FindRows<CI> find_load(const float* Mbuf, int rb, int
 }
 
 // `pre` holds the first batch of this wave's rows (rows r0 + wid + u * FW), requested by the caller
-// BEFORE it knew the layout (use_pre): the token -> op -> text-map chain of dependent loads then runs
-// under the stream of map rows instead of in front of it.
+// before anything else.
 template <int CI, int NF, bool ONE>
 __device__ __forceinline__ void find_rows(int tid, const ModuleWeights& w, const float* Mbuf,
                                           const float* const* ts, float* const* os, int r0, int r1,
@@ -1104,8 +1136,7 @@ __device__ __forceinline__ void find_rows(int tid, const ModuleWeights& w, const
   }
   constexpr int UNR = FindUnroll<CI>::value;
   for (int rb = r0 + wid; rb < r1; rb += UNR * FW) {
-    // the first batch of a wave's rows was requested by the caller before it knew the layout (ONE:
-    // that batch is all of them -- r1 - r0 <= UNR * FW, checked by the launcher)
+    // ONE: the first batch is all of this wave's rows (r1 - r0 <= UNR * FW, checked by the launcher)
     const FindRows<CI> m = (ONE || rb == r0 + wid) ? pre : find_load<CI>(Mbuf, rb, r1, lane, Mp);
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
@@ -1120,18 +1151,20 @@ __device__ __forceinline__ void find_rows(int tid, const ModuleWeights& w, const
           ss += p0 * p0 + p1 * p1 + p2 * p2 + p3 * p3;
           dot += p0 * e4[i].x + p1 * e4[i].y + p2 * e4[i].z + p3 * e4[i].w;
         }
-        const float s2 = wave_sum(ss);
-        const float d2 = wave_sum(dot);
+        float s2, d2;
+        wave_sum2(ss, dot, s2, d2);              // both 64-lane sums in one DPP sequence
         if (lane == 0 && r < r1) os[j][r] = d2 / sqrtf(fmaxf(s2, 1e-12f)) + be;
       }
     }
   }
 }
 
+// The question's layout comes from the pass's plan (WalkProg written by walk_tmap_kernel): a scalar
+// load of the Find / Filter node list instead of the chain tokens -> op codes -> scan behind two
+// barriers, which every one of the 4 x questions workgroups used to run IN FRONT of its map stream.
+// The rows of the image's conv_image map do not depend on the layout at all: their loads go out first.
 template <int CI, bool ONE>
 __global__ __launch_bounds__(FT) void walk_find_kernel(ModuleWeights w, WalkArgs a) {
-  __shared__ int flist[MAXT];
-  __shared__ int s_nf;
   const int q = blockIdx.x;
   const int kb = q / a.N, n = q - kb * a.N;
   const WalkBatch& B = a.b[kb];
@@ -1139,37 +1172,19 @@ __global__ __launch_bounds__(FT) void walk_find_kernel(ModuleWeights w, WalkArgs
   const int T = a.T, HW = a.H * a.W, Mp = a.Mp, HWp = a.HWp;
   const int rpp = (HW + WALK_FIND_PARTS - 1) / WALK_FIND_PARTS;
   const int r0 = blockIdx.y * rpp, r1 = min(HW, r0 + rpp);
+  if (r0 >= r1) return;
   const float* Mbuf = B.mfind + (size_t)n * HW * Mp;
-  // This workgroup's rows of the image's conv_image map do not depend on the layout: their loads go
-  // out FIRST (every valid layout but a Scene-only one reads them), and the dependent chain
-  // tokens -> op codes -> text maps runs while they are in flight
-  const bool have_rows = r0 < r1;
-  const FindRows<CI> pre = find_load<CI>(Mbuf, r0 + (tid >> 6), have_rows ? r1 : r0 + 1, tid & 63, Mp);
-  __builtin_amdgcn_sched_barrier(0);
-  __shared__ int ops[MAXT];
-  if (tid < T) {                                    // the T token loads go out in parallel
-    const int tok = B.tokens[(size_t)tid * a.N + n];
-    ops[tid] = (tok < 0 || tok >= a.V) ? -1 : a.token_op[tok];
-  }
-  __syncthreads();
-  if (tid == 0) {
-    int nf = 0;
-    for (int t = 0; t < T; ++t) {
-      const int op = ops[t];
-      if (op < 0) break;
-      if (op == N2NMN_OP_FIND || op == N2NMN_OP_FILTER) flist[nf++] = t;
-    }
-    s_nf = nf;
-  }
-  __syncthreads();
-  const int nfind = s_nf;
-  if (nfind == 0 || !have_rows) return;
+  const WalkProg* P = B.prog + n;                    // uniform address: scalar loads
+  const int nfind = P->valid ? P->nfind : 0;
+  const FindRows<CI> pre = find_load<CI>(Mbuf, r0 + (tid >> 6), r1, tid & 63, Mp);
+  if (nfind == 0) return;
   for (int f0 = 0; f0 < nfind; f0 += 4) {
     const int nf = min(4, nfind - f0);
     const float* ts[4];
     float* os[4];
+#pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int t = flist[f0 + min(j, nf - 1)];
+      const int t = P->flist[f0 + min(j, nf - 1)];
       ts[j] = B.tmap + ((size_t)t * a.N + n) * Mp;
       os[j] = B.watt + ((size_t)n * T + t) * HWp;
     }
@@ -1255,19 +1270,20 @@ __global__ __launch_bounds__(256) void walk_pool_kernel(WalkArgs a) {
 // weight set multiplies its pooled feature vector with the same [D, Mp] matrix (512 KB at CLEVR
 // dimensions).  One workgroup per job pulled that matrix from L2 once per job (309 jobs: 158 MB, 34 us
 // per 1024 questions); here a workgroup takes HG jobs of ONE weight set -- ranked by scanning the job
-// codes of the launch, as walk_textmap_kernel does -- and every weight row it fetches meets HG vectors.
-// Weight sets: y = 0 Describe (fc_att of input 0), 1 / 2 SameProperty input 0 / input 1.  The K-split,
-// the order of the partial sums and the bias-first reduction are fc_pad's, so a row equals what the
-// one-workgroup-per-job kernel computed.  Rows go to pfc[n][input][Mp].
-constexpr int HG = 4;
+// codes of the launch, as walk_textmap_kernel does -- and 64 of the Mp columns, so every weight row it
+// fetches meets HG vectors, a workgroup's share of the matrix is 128 KB, and all of it is in flight at
+// once: 32 k-groups x 16 column lanes, D / 32 rows per thread.
+// Weight sets: y = 0 Describe (fc_att of input 0), 1 / 2 SameProperty input 0 / input 1.
+// Rows go to pfc[n][input][Mp].
+constexpr int HG = 4, FCW = 64, FKG = WT / (FCW / 4);          // jobs, columns, k-groups per workgroup
 __global__ __launch_bounds__(WT) void walk_fcatt_kernel(ModuleWeights w, WalkArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int wcount[WW];
   __shared__ int sel[HG];
-  if (a.staged && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-    a.cnt_next[0] = 0; a.cnt_next[1] = 0;      // the NEXT staged pass starts from empty lists
+  if (a.staged && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+    a.cnt_next[0] = 0; a.cnt_next[1] = 0; a.cnt_next[2] = 0;   // the NEXT staged pass starts from empty lists
   }
-  const int g = blockIdx.x, y = blockIdx.y;
+  const int g = blockIdx.x, y = blockIdx.y, c0 = blockIdx.z * FCW;
   const int want = y == 0 ? N2NMN_OP_DESCRIBE : N2NMN_OP_SAME_PROPERTY;
   const int which = y == 2 ? 1 : 0;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1295,7 +1311,7 @@ __global__ __launch_bounds__(WT) void walk_fcatt_kernel(ModuleWeights w, WalkArg
   const int cnt = min(HG, base - HG * g);
   if (cnt <= 0) return;
   float* x = smem;                                // [HG][D]
-  float* part = x + (size_t)HG * D;               // [WW][HG][256]
+  float* part = x + (size_t)HG * D;               // [FKG][HG][FCW]
   for (int i = tid; i < HG * D; i += WT) {
     const int j = i / D, k = i - j * D;
     float v = 0.f;
@@ -1305,52 +1321,53 @@ __global__ __launch_bounds__(WT) void walk_fcatt_kernel(ModuleWeights w, WalkArg
     }
     x[i] = v;
   }
-  __syncthreads();
   const int wi = y == 0 ? 3 : y;                  // ModuleWeights::Watt: FSP, SameProperty 0 / 1, Describe
   const float* Wp = w.Watt[wi];
   const float* bm = w.batt[wi];
-  const int kper = (D + WW - 1) / WW;
-  const int k0 = wid * kper, k1 = min(D, k0 + kper);
+  const int cl = tid & (FCW / 4 - 1), kg = tid / (FCW / 4);
+  const int kper = (D + FKG - 1) / FKG;
+  const int k0 = kg * kper, k1 = min(D, k0 + kper);
+  const unsigned col = (unsigned)(c0 + 4 * cl);   // (Mp % 64 == 0: every column of the part exists)
   constexpr int KU = 16;
-  for (int cb = 0; cb < Mp; cb += 256) {
-    float4 acc[HG];
+  float4 acc[HG];
 #pragma unroll
-    for (int j = 0; j < HG; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const unsigned col = (unsigned)min(cb + 4 * lane, Mp - 4);
-    for (int kq = k0; kq < k1; kq += KU) {
-      float4 w4[KU];
+  for (int j = 0; j < HG; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 w4[KU];
+  auto fetch = [&](int kq) {
 #pragma unroll
-      for (int u = 0; u < KU; ++u) {
-        const unsigned k = (unsigned)min(kq + u, k1 - 1);
-        w4[u] = *reinterpret_cast<const float4*>(Wp + (k * (unsigned)Mp + col));
-      }
+    for (int u = 0; u < KU; ++u) {
+      const unsigned k = (unsigned)min(kq + u, max(k1 - 1, 0));
+      w4[u] = *reinterpret_cast<const float4*>(Wp + (k * (unsigned)Mp + col));
+    }
+  };
+  fetch(k0);                                      // the first rows are in flight ...
+  __syncthreads();                                // ... while x completes
+  for (int kq = k0; kq < k1; kq += KU) {
+    if (kq != k0) fetch(kq);
 #pragma unroll
-      for (int u = 0; u < KU; ++u) {
-        if (kq + u < k1) {
+    for (int u = 0; u < KU; ++u) {
+      if (kq + u < k1) {
 #pragma unroll
-          for (int j = 0; j < HG; ++j) {
-            const float xv = x[j * D + kq + u];
-            acc[j].x += xv * w4[u].x; acc[j].y += xv * w4[u].y; acc[j].z += xv * w4[u].z;
-            acc[j].w += xv * w4[u].w;
-          }
+        for (int j = 0; j < HG; ++j) {
+          const float xv = x[j * D + kq + u];
+          acc[j].x += xv * w4[u].x; acc[j].y += xv * w4[u].y; acc[j].z += xv * w4[u].z;
+          acc[j].w += xv * w4[u].w;
         }
       }
     }
+  }
 #pragma unroll
-    for (int j = 0; j < HG; ++j)
-      *reinterpret_cast<float4*>(part + ((size_t)(wid * HG + j) * 256) + 4 * lane) = acc[j];
-    __syncthreads();
-    for (int i = tid; i < HG * 256; i += WT) {
-      const int j = i >> 8, c = i & 255;
-      if (j < cnt && cb + c < Mp) {
-        float r = bm[cb + c];
-#pragma unroll
-        for (int qq = 0; qq < WW; ++qq) r += part[(size_t)(qq * HG + j) * 256 + c];
-        const int q = sel[j], kb = q / a.N, n = q - kb * a.N;
-        a.b[kb].pfc[((size_t)n * 2 + which) * Mp + cb + c] = r;
-      }
+  for (int j = 0; j < HG; ++j)
+    *reinterpret_cast<float4*>(part + ((size_t)(kg * HG + j) * FCW) + 4 * cl) = acc[j];
+  __syncthreads();
+  for (int i = tid; i < HG * FCW; i += WT) {
+    const int j = i / FCW, c = i - j * FCW;
+    if (j < cnt) {
+      float r = bm[c0 + c];
+      for (int qq = 0; qq < FKG; ++qq) r += part[(size_t)(qq * HG + j) * FCW + c];
+      const int q = sel[j], kb = q / a.N, n = q - kb * a.N;
+      a.b[kb].pfc[((size_t)n * 2 + which) * Mp + c0 + c] = r;
     }
-    __syncthreads();
   }
 }
 
@@ -1467,7 +1484,7 @@ template <int CI>
 __device__ __forceinline__ void heavy_fsp(int tid, const ModuleWeights& w, const WalkArgs& a,
                                           const float* feat, const float* Mbuf, const float* in0,
                                           const float* tml, float* outp, float* am0, float* pooled,
-                                          float* sa0, float* rs, float* scr) {
+                                          float* sa0, float* rs, float* scr, long long* tl) {
   const int HW = a.H * a.W, D = a.D, Mp = a.Mp;
   const int ncol = D / 4, nrow = WT / ncol;
   const int lane = tid & 63, wid = tid >> 6;
@@ -1520,8 +1537,10 @@ __device__ __forceinline__ void heavy_fsp(int tid, const ModuleWeights& w, const
     pooled[i] = sacc;
   }
   __syncthreads();
+  if (tl && threadIdx.x == 0) tl[1] = clock64();
   fc_pad<32>(tid, pooled, D, w.Watt[0], w.batt[0], Mp, am0, scr, nullptr);     // :173-176
   __syncthreads();
+  if (tl && threadIdx.x == 0) tl[2] = clock64();
   const float be = w.be[1][0];
   float4 t4[CI], e4[CI];
 #pragma unroll
@@ -1579,13 +1598,17 @@ __global__ __launch_bounds__(WT) void walk_heavy_kernel(ModuleWeights w, WalkArg
   float* sa0 = pooled + D;                             // [HWp]
   float* rs = sa0 + HWp;                               // [32]
   float* scr = rs + 32;                                // operator scratch (walk_lds_floats's maximum)
-  const int njobs = min(*a.cnt, a.hcap);
-  for (int j = blockIdx.x; j < njobs; j += gridDim.x) {
+  // two lists: FindSameProperty jobs (a 307 KB pool + a 512 KB fc_att stream + a 154 KB epilogue at one
+  // CU's pace: the long ones) are handed out first, Transform jobs behind them -- longest processing
+  // time first keeps the last round of the persistent grid short
+  const int half = a.hcap / 2;
+  const int nfsp = min(a.cnt[2], half), ntr = min(a.cnt[0], half);
+  for (int j = blockIdx.x; j < nfsp + ntr; j += gridDim.x) {
     // the opaque copy keeps one operator's address arithmetic from being hoisted across the other
     // (see walk_kernel)
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
-    const int job = a.hjobs[j];
+    const int job = j < nfsp ? a.hjobs[half + j] : a.hjobs[j - nfsp];
     const int q = job >> 8, t = job & 0xff;
     if (q < 0 || q >= a.K * a.N || t >= T) continue;                 // (a stale list entry)
     const int kb = q / a.N, n = q - kb * a.N;
@@ -1597,6 +1620,10 @@ __global__ __launch_bounds__(WT) void walk_heavy_kernel(ModuleWeights w, WalkArg
     const bool heavy = o == N2NMN_OP_TRANSFORM || o == N2NMN_OP_FIND_SAME_PROPERTY;
     if (!P.valid || P.fallback || t >= P.nn || !heavy || P.hd[t] != 1 || P.in0[t] < 0) continue;
     const int i0 = P.in0[t];
+    // debug timeline (n2nmn_debug_walk_timeline): [0] job start, [1] operands ready (Transform) / pooled
+    // (FindSameProperty), [2] matrix phase / fc_att done, [3] map written
+    long long* tl = a.timeline ? a.timeline + ((size_t)q * MAXT + t) * 4 : nullptr;
+    if (tl && threadIdx.x == 0) tl[0] = clock64();
     {                                                   // text map of the node (walk_tmap_kernel's row)
       const float* src = B.tmap + ((size_t)t * a.N + n) * Mp;
       for (int c = 4 * tid; c < Mp; c += 4 * WT)
@@ -1607,14 +1634,15 @@ __global__ __launch_bounds__(WT) void walk_heavy_kernel(ModuleWeights w, WalkArg
     const float* in0 = arena + (size_t)i0 * HWp;
     float* outp = arena + (size_t)t * HWp;
     if (o == N2NMN_OP_TRANSFORM) {                      // :185-216
-      if (a.ksize == 5) walk_transform<5>(tid, w, a, in0, tml, outp, scr, nullptr);
-      else walk_transform<3>(tid, w, a, in0, tml, outp, scr, nullptr);
+      if (a.ksize == 5) walk_transform<5>(tid, w, a, in0, tml, outp, scr, tl);
+      else walk_transform<3>(tid, w, a, in0, tml, outp, scr, tl);
     } else {
       heavy_fsp<CI>(tid, w, a, B.feat + (size_t)n * HW * D, B.mfsp + (size_t)n * HW * Mp, in0, tml,
-                    outp, am0, pooled, sa0, rs, scr);
+                    outp, am0, pooled, sa0, rs, scr, tl);
     }
     float* dst = B.watt + ((size_t)n * T + t) * HWp;
     for (int r = tid; r < HW; r += WT) dst[r] = outp[r];
+    if (tl && threadIdx.x == 0) tl[3] = clock64();
   }
 }
 
@@ -1629,6 +1657,9 @@ __global__ __launch_bounds__(WT) void walk_light_kernel(ModuleWeights w, WalkArg
   float* arena = smem;                                 // [T][HWp]
   float* rs = arena + (size_t)T * HWp;                 // [32]
   float* scr = rs + 32;                                // answer features + fc_out partial sums
+  // debug timeline: row MAXT - 1 of the question: [0] start, [1] tree evaluated, [3] end
+  long long* tl = a.timeline ? a.timeline + ((size_t)q * MAXT + (MAXT - 1)) * 4 : nullptr;
+  if (tl && tid == 0) tl[0] = clock64();
   load_prog(tid, B.prog + n, P);
   __syncthreads();
   if (P.valid && P.fallback) return;                   // walk_kernel serves this question (fblist)
@@ -1661,6 +1692,7 @@ __global__ __launch_bounds__(WT) void walk_light_kernel(ModuleWeights w, WalkArg
   }
   // every attention node of the tree: the root is the only answer node (a valid layout)
   eval_light_range(tid, P, 0, nn - 2, B.watt + (size_t)n * T * HWp, arena, HW, HWp, true);
+  if (tl && tid == 0) tl[1] = clock64();
   const int t = nn - 1;
   const int op = P.op[t] & 0x7f;
   const float* in0 = P.in0[t] >= 0 ? arena + (size_t)P.in0[t] * HWp : nullptr;
@@ -1684,6 +1716,7 @@ __global__ __launch_bounds__(WT) void walk_light_kernel(ModuleWeights w, WalkArg
     const float* tsrc = B.tmap + ((size_t)t * a.N + n) * Mp;
     for (int c = tid; c < Mp; c += WT) ptm[c] = tsrc[c];
     if (tid == 0) B.pjob[n] = op;
+    if (tl && tid == 0) tl[3] = clock64();
     return;
   }
   // Exist (:258-280), Count (:282-304), EqualNum / MoreNum / LessNum (:306-400)
@@ -1720,7 +1753,9 @@ __global__ __launch_bounds__(WT) void walk_light_kernel(ModuleWeights w, WalkArg
     wi = op == N2NMN_OP_EQUAL_NUM ? 2 : (op == N2NMN_OP_MORE_NUM ? 3 : 4);
   }
   __syncthreads();
+  if (tl && tid == 0) tl[2] = clock64();
   fc_out(tid, x, F, w.Wans[wi], w.bans[wi], C, srow, red);
+  if (tl && tid == 0) tl[3] = clock64();
 }
 
 }  // namespace
@@ -1758,10 +1793,10 @@ void launch_walk_pool(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) 
 void launch_walk_heads(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) {
   // fc_att of all deferred jobs, grouped by weight set, then the heads (one small workgroup each)
   const int QN = a.K * a.N;
-  const size_t fsm = sizeof(float) * ((size_t)HG * a.D + (size_t)WW * HG * 256);
+  const size_t fsm = sizeof(float) * ((size_t)HG * a.D + (size_t)FKG * HG * FCW);
   static std::atomic<uint64_t> done{0};
   if (fsm > 64 * 1024) ensure_dynamic_lds(reinterpret_cast<const void*>(walk_fcatt_kernel), (int)fsm, done);
-  hipLaunchKernelGGL(walk_fcatt_kernel, dim3((QN + HG - 1) / HG, 3), dim3(WT), fsm, s, w, a);
+  hipLaunchKernelGGL(walk_fcatt_kernel, dim3((QN + HG - 1) / HG, 3, a.Mp / FCW), dim3(WT), fsm, s, w, a);
   const size_t smem = sizeof(float) * ((size_t)a.Mp + 32 + WT);
   hipLaunchKernelGGL(walk_heads_kernel, dim3(QN), dim3(WT), smem, s, w, a);
 }
