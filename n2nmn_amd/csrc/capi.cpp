@@ -137,6 +137,8 @@ static size_t carve_weights(n2nmn_ctx* c, char* base) {
   if (L % 128 == 0) {
     c->enc_W0h_64 = k.take<float>(L * 4 * L); c->enc_W1_64 = k.take<float>(2 * L * 4 * L);
     c->dec_W0h_64 = k.take<float>(L * 4 * L); c->dec_W1_64 = k.take<float>(2 * L * 4 * L);
+    c->enc_W0h_b3 = k.take<uint16_t>(3 * L * 4 * L); c->enc_W1_b3 = k.take<uint16_t>(3 * 2 * L * 4 * L);
+    c->dec_W0h_b3 = k.take<uint16_t>(3 * L * 4 * L); c->dec_W1_b3 = k.take<uint16_t>(3 * 2 * L * 4 * L);
   }
   c->eht_W_p = k.take<float>((size_t)c->KpL * L);
   c->att_W_t = k.take<float>(L * L);
@@ -183,14 +185,18 @@ static size_t carve_workspace(n2nmn_ctx* c, char* base) {
   const size_t Mp = c->Mp, HWp = c->HWp;
   Carver k(base);
   // recurrent state: one contiguous block so the encoder can clear it with one memset
-  float* st = k.take<float>(10 * N * L);
+  // (block A and its bf16 planes are one allocation: enc_prepare clears both with one range)
+  float* st = k.take<float>(25 * N * L);
+  c->st_A = st; c->hb_A = reinterpret_cast<uint16_t*>(st + 10 * N * L);
   c->eh0[0] = st; c->eh0[1] = st + N * L; c->eh1[0] = st + 2 * N * L; c->eh1[1] = st + 3 * N * L;
   c->ec0 = st + 4 * N * L; c->ec1 = st + 5 * N * L;
   // final encoder state in ORIGINAL row order (written at each row's last valid step)
   c->fc0 = st + 6 * N * L; c->fh0 = st + 7 * N * L; c->fc1 = st + 8 * N * L; c->fh1 = st + 9 * N * L;
   // dropped copies of the layer-0 outputs (encoder_dropout / decoder_dropout: DropoutWrapper on
   // every layer but the last, nmn3_netgen_att.py:17-44 of both model families)
-  for (int i = 0; i < 2; ++i) { c->ehd[i] = k.take<float>(N * L); c->dhd[i] = k.take<float>(N * L); }
+  float* stb = k.take<float>(25 * N * L);         // block B (10 N L floats) + its planes
+  c->st_B = stb; c->hb_B = reinterpret_cast<uint16_t*>(stb + 10 * N * L);
+  for (int i = 0; i < 2; ++i) { c->ehd[i] = stb + (size_t)i * N * L; c->dhd[i] = stb + (size_t)(2 + i) * N * L; }
   if (c->big_vocab) {
     c->xproj = k.take<float>(T * N * 4 * L);
     c->iota = k.take<int32_t>(T * N);
@@ -199,7 +205,7 @@ static size_t carve_workspace(n2nmn_ctx* c, char* base) {
   c->nact = k.take<int32_t>(T + 1);
   c->enc_rows = k.take<int32_t>(T * N);
   c->enc_rows_n = k.take<int32_t>(4);
-  float* ds = k.take<float>(6 * N * L);
+  float* ds = c->st_B + 4 * N * L;                // decoder states: inside block B
   c->dh0[0] = ds; c->dh0[1] = ds + N * L; c->dh1[0] = ds + 2 * N * L; c->dh1[1] = ds + 3 * N * L;
   c->dc0 = ds + 4 * N * L; c->dc1 = ds + 5 * N * L;
   c->enc_out = k.take<float>(T * N * L);
@@ -286,7 +292,8 @@ ModuleWeights module_weights(const n2nmn_ctx* c) {
 
 // tile choice of the pipelined two-layer step launches (launch_lstm_step's `wide`)
 static int lstm_wide(const n2nmn_ctx* c) {
-  return c->mode == N2NMN_MODE_THROUGHPUT ? 2 : c->mode == N2NMN_MODE_THROUGHPUT_KSPLIT ? 1 : 0;
+  return (c->mode == N2NMN_MODE_THROUGHPUT || c->mode == N2NMN_MODE_THROUGHPUT_BF16X3) ? 2
+         : c->mode == N2NMN_MODE_THROUGHPUT_KSPLIT ? 1 : 0;
 }
 
 // encoder steps with at most this many active rows use the K-split tiles (needs the host lengths)
@@ -296,6 +303,25 @@ static int tile_min_rows() {
 }
 
 // state buffers (eh0/eh1/dh0/dh1) are k-interleaved [L/4][R][4] with R = capacity N
+// split-operand bf16 mode of a pass of N rows (a training forward keeps the exact kernels)
+static bool lstm_b3(const n2nmn_ctx* c, int N) {
+  return c->mode == N2NMN_MODE_THROUGHPUT_BF16X3 && N >= 128 && !c->rec && root(c)->b3_on && c->enc_W0h_b3;
+}
+static uint16_t* planes_of(const n2nmn_ctx* c, const float* p) {
+  const size_t n = (size_t)10 * c->d.N * c->d.lstm_dim;
+  if (p >= c->st_A && p < c->st_A + n) return c->hb_A + 3 * (size_t)(p - c->st_A);
+  if (p >= c->st_B && p < c->st_B + n) return c->hb_B + 3 * (size_t)(p - c->st_B);
+  return nullptr;
+}
+// plane companions of a job's state buffers and weights (LstmJob::A0b ...)
+static void attach_planes(const n2nmn_ctx* c, LstmJob& j) {
+  j.A0b = planes_of(c, j.A0); j.A1b = j.A1 ? planes_of(c, j.A1) : nullptr;
+  j.h_new_b = planes_of(c, j.h_new); j.fin_h_b = j.fin_h ? planes_of(c, j.fin_h) : nullptr;
+  j.h_drop_b = j.h_drop ? planes_of(c, j.h_drop) : nullptr;
+  j.Wb3 = j.Wp64 == c->enc_W0h_64 ? c->enc_W0h_b3 : j.Wp64 == c->enc_W1_64 ? c->enc_W1_b3 :
+          j.Wp64 == c->dec_W0h_64 ? c->dec_W0h_b3 : j.Wp64 == c->dec_W1_64 ? c->dec_W1_b3 : nullptr;
+}
+
 void packed_state(const n2nmn_ctx* c, LstmJob& j) {
   j.a_rs = 4; j.a_ks = 4 * c->d.N; j.hp_R = c->d.N;
 }
@@ -341,7 +367,8 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmAr
   // the GEMM rides in the decoder's launch of a large pass and nobody was promised the full matrix
   static const bool eht_rows_on = [] { const char* e = getenv("N2NMN_EHT_ROWS"); return !e || atoi(e) != 0; }();
   const bool eht_rows = eht_rows_on && defer_eht && !c->rec && (size_t)T * N >= 8192;
-  launch_enc_prepare(io->seq_length, N, T, c->perm, c->nact, c->eh0[0], 10 * (size_t)d.N * L, s,
+  const bool b3 = lstm_b3(c, N);      // (with the planes of block A behind it, see carve_workspace)
+  launch_enc_prepare(io->seq_length, N, T, c->perm, c->nact, c->eh0[0], (b3 ? 25 : 10) * (size_t)d.N * L, s,
                      eht_rows ? c->enc_rows_n : nullptr);
   if (eht_rows) launch_enc_rows(io->seq_length, T, N, c->enc_rows, c->enc_rows_n, s);
   const float* W0x_bias_table = c->enc_xtab;
@@ -361,6 +388,8 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmAr
   // the length-sorted encoder has too few row blocks for the 64 x 64 tiles (a launch of <= 256
   // workgroups leaves the K = 2L tiles alone on their CUs), the K-split tiles scale with the rows
   std::vector<int> act_host;
+  // (not in the split-operand mode: a row's final state must reach the decoder with its bf16 planes,
+  // which only lstm_tile3_kernel writes)
   if (io->seq_length_host && c->mode == N2NMN_MODE_THROUGHPUT) {
     std::vector<int> cnt(T + 2, 0);
     for (int n = 0; n < N; ++n) cnt[std::min(std::max(io->seq_length_host[n], 0), T)] += 1;
@@ -422,7 +451,13 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmAr
       ProfScope ps(c, F_LSTM_ENC, fl, by, s);
       int wide = lstm_wide(c);
       if (!act_host.empty() && act_host[std::min(k, T - 1)] <= tile_min_rows()) wide = 1;
-      launch_lstm_step(jobs, 2, N, L, 64, s, wide);
+      if (b3) {
+        attach_planes(c, j0); attach_planes(c, j1);
+        N2_REQUIRE(lstm_tile3_supported(jobs, 2, L), N2NMN_EINVAL, "encoder_forward: bf16x3 mode: unsupported job");
+        launch_lstm_tile3(jobs, 2, N, L, s);
+      } else {
+        launch_lstm_step(jobs, 2, N, L, 64, s, wide);
+      }
     }
   }
   // encoder_h_transformed = fc(encoder_outputs)          (nmn3_netgen_att.py:102-106)
@@ -545,7 +580,13 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
       }
       ProfScope ps(c, F_LSTM_DEC0, (j0.active ? fl0 : 0) + (j1.active ? fl1 : 0),
                    (j0.active ? by0 : 0) + (j1.active ? by1 : 0), s);
-      launch_lstm_step(jobs, 2, N, L, 64, s, lstm_wide(c));
+      if (lstm_b3(c, N)) {
+        attach_planes(c, j0); attach_planes(c, j1);
+        N2_REQUIRE(lstm_tile3_supported(jobs, 2, L), N2NMN_EINVAL, "decoder_forward: bf16x3 mode: unsupported job");
+        launch_lstm_tile3(jobs, 2, N, L, s);
+      } else {
+        launch_lstm_step(jobs, 2, N, L, 64, s, lstm_wide(c));
+      }
     }
     // q = out . W_a + b_a for all steps (nmn3_netgen_att.py:185), in ONE launch with whatever else
     // is due before the attention / the layout walk: encoder_h_transform, conv_image
@@ -643,7 +684,13 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
         ProfScope ps(c, F_LSTM_DEC0, fl0, by0, s);
         // (throughput mode, >= 128 rows: the 64 x 64 LDS-DMA tiles, one round of 512 workgroups per
         // layer -- the greedy decoder's two layers cannot share a launch, token t feeds layer 0 of t+1)
-        launch_lstm_step(&j0, 1, N, L, 32, s, lstm_wide(c));
+        if (lstm_b3(c, N)) {
+          attach_planes(c, j0);
+          N2_REQUIRE(lstm_tile3_supported(&j0, 1, L), N2NMN_EINVAL, "decoder_forward: bf16x3 mode: unsupported job");
+          launch_lstm_tile3(&j0, 1, N, L, s);
+        } else {
+          launch_lstm_step(&j0, 1, N, L, 32, s, lstm_wide(c));
+        }
       }
       LstmJob j1{};
       j1.active = 1;
@@ -656,7 +703,13 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
       j1.h_old = j1.A1; j1.h_new = c->dh1[t & 1];
       {
         ProfScope ps(c, F_LSTM_DEC1, fl1, by1, s);
-        launch_lstm_step(&j1, 1, N, L, 32, s, lstm_wide(c));
+        if (lstm_b3(c, N)) {
+          attach_planes(c, j1);
+          N2_REQUIRE(lstm_tile3_supported(&j1, 1, L), N2NMN_EINVAL, "decoder_forward: bf16x3 mode: unsupported job");
+          launch_lstm_tile3(&j1, 1, N, L, s);
+        } else {
+          launch_lstm_step(&j1, 1, N, L, 32, s, lstm_wide(c));
+        }
       }
       LstmJob jq{};                    // q = out . W_a + b_a            (nmn3_netgen_att.py:185)
       packed_state(c, jq);
@@ -1014,11 +1067,35 @@ int n2nmn_ctx_destroy(n2nmn_ctx* ctx) {
   return N2NMN_OK;
 }
 
+// the four recurrent weight matrices as three bf16 planes per 16-unit tile (lstm_tile3_kernel)
+static void pack_b3(n2nmn_ctx* r, hipStream_t s) {
+  const int L = r->d.lstm_dim, E0 = r->d.embed_dim_txt, E1 = r->d.embed_dim_nmn;
+  launch_pack_tiles64_b3(r->vars[V_ENC_W0].mirror, 4 * L, E0, L, L, r->enc_W0h_b3, s);
+  launch_pack_tiles64_b3(r->vars[V_ENC_W1].mirror, 4 * L, 0, 2 * L, L, r->enc_W1_b3, s);
+  launch_pack_tiles64_b3(r->vars[V_DEC_W0].mirror, 4 * L, E1, L, L, r->dec_W0h_b3, s);
+  launch_pack_tiles64_b3(r->vars[V_DEC_W1].mirror, 4 * L, 0, 2 * L, L, r->dec_W1_b3, s);
+}
+
 int n2nmn_ctx_set_mode(n2nmn_ctx* ctx, int mode) {
   N2_REQUIRE(ctx, N2NMN_EINVAL, "ctx_set_mode: null context");
   N2_REQUIRE(mode == N2NMN_MODE_LATENCY || mode == N2NMN_MODE_THROUGHPUT ||
-                 mode == N2NMN_MODE_THROUGHPUT_KSPLIT, N2NMN_EINVAL,
-             "ctx_set_mode: unknown mode");
+                 mode == N2NMN_MODE_THROUGHPUT_KSPLIT || mode == N2NMN_MODE_THROUGHPUT_BF16X3,
+             N2NMN_EINVAL, "ctx_set_mode: unknown mode");
+  if (mode == N2NMN_MODE_THROUGHPUT_BF16X3) {
+    N2_REQUIRE(ctx->enc_W0h_b3, N2NMN_EINVAL, "ctx_set_mode: bf16x3 needs lstm_dim % 128 == 0");
+    n2nmn_ctx* r = ctx->parent ? ctx->parent : ctx;
+    if (!r->b3_on) {
+      // from now on every commit packs the split weights too; if weights are committed already, now
+      // (a configuration call: it may wait for the device)
+      r->b3_on = true;
+      if (r->committed) {
+        N2_HIP(hipSetDevice(r->device));
+        N2_HIP(hipDeviceSynchronize());
+        pack_b3(r, nullptr);
+        N2_HIP(hipDeviceSynchronize());
+      }
+    }
+  }
   ctx->mode = mode;
   return N2NMN_OK;
 }
@@ -1204,6 +1281,7 @@ extern "C++" int n2nmn::commit_weights_on(n2nmn_ctx* c, hipStream_t s, hipStream
   if (rest != s && si != rest) si = rest;      // (training without a side stream: everything on `s`)
   if (!c->packs_infer.jobs.empty())
     launch_pack_jobs(c->packs_infer.dev, (int)c->packs_infer.jobs.size(), c->packs_infer.blocks, si);
+  if (c->b3_on && c->enc_W0h_b3) pack_b3(c, si);
   for (int i = 0; i < 5; ++i) {        // ew[ws] = embedding_mat . W_txt[ws]  (walker text maps)
     if (!c->ew[i]) continue;
     GemmArgs t{};
@@ -1664,6 +1742,12 @@ int n2nmn_profile_get(const n2nmn_ctx* ctx, int family, const char** name, int64
  * 3 MFMA only, 4 neither (LDS reduce + epilogue only), 5 empty kernel.  jobs: 2 = L0+L1, 1 = L1. */
 int n2nmn_debug_lstm_bench(n2nmn_ctx* c, int variant, int rows_per_wg, int njobs, int N, int iters,
                            double* us, n2nmn_stream stream) {
+  // 100 + v: lstm_tile3_kernel (split-operand bf16), v = 0 shipped (3 stages), 4 four stages, 13 no DMA,
+  // 23 no MFMA, 33 DMA + barriers only; needs n2nmn_ctx_set_mode(..., N2NMN_MODE_THROUGHPUT_BF16X3) first
+  const int tile3 = variant >= 100 ? variant - 100 : -1;
+  if (tile3 >= 0) variant = 0;
+  N2_REQUIRE(tile3 < 0 || (c && root(c)->b3_on && c->enc_W0h_b3), N2NMN_EINVAL,
+             "debug_lstm_bench: set the bf16x3 mode first");
   const int tile = variant >= 20 ? variant - 20 : 0;   // 23 / 24 / 26: lstm_tile_kernel, 3 / 4 / 6 stages
   if (tile) variant = 0;
   const int layout = variant < 10;       // variant >= 10: row-major h (A/B against the packed state)
@@ -1675,7 +1759,7 @@ int n2nmn_debug_lstm_bench(n2nmn_ctx* c, int variant, int rows_per_wg, int njobs
   hipEvent_t e0, e1;
   N2_HIP(hipEventCreate(&e0));
   N2_HIP(hipEventCreate(&e1));
-  N2_HIP(hipMemsetAsync(c->eh0[0], 0, sizeof(float) * 6 * (size_t)c->d.N * L, s));
+  N2_HIP(hipMemsetAsync(c->eh0[0], 0, sizeof(float) * (tile3 >= 0 ? 25 : 6) * (size_t)c->d.N * L, s));
   for (int rep = 0; rep < 2; ++rep) {
     if (rep == 1) N2_HIP(hipEventRecord(e0, s));
     for (int k = 0; k < (rep == 0 ? 5 : iters); ++k) {
@@ -1694,7 +1778,11 @@ int n2nmn_debug_lstm_bench(n2nmn_ctx* c, int variant, int rows_per_wg, int njobs
       j1.Wp = c->enc_W1_t; j1.Wp64 = c->enc_W1_64; j1.ntiles = L / 4; j1.bias = c->enc_b1_t;
       j1.c_in = c->ec1; j1.c_out = c->ec1; j1.h_old = j1.A1; j1.h_new = c->eh1[k & 1];
       j1.out_seq = c->enc_out;
-      if (tile) launch_lstm_step(jobs, njobs, N, L, rows_per_wg, s, tile);
+      if (tile3 >= 0) {
+        for (int i = 0; i < 2; ++i) { attach_planes(c, jobs[i]); jobs[i].save_gates = nullptr; }
+        if (!lstm_tile3_supported(jobs, njobs, L)) { set_last_error("debug_lstm_bench: tile3 unsupported"); return N2NMN_EINVAL; }
+        launch_lstm_tile3(jobs, njobs, N, L, s, tile3);
+      } else if (tile) launch_lstm_step(jobs, njobs, N, L, rows_per_wg, s, tile);
       else launch_lstm_step_dbg(jobs, njobs, N, L, rows_per_wg, variant, s);
     }
   }

@@ -153,6 +153,10 @@ struct n2nmn_ctx {
   float *enc_W0h_t = nullptr, *enc_W1_t = nullptr, *dec_W0h_t = nullptr, *dec_W1_t = nullptr;
   // the same four matrices as 16-unit tiles for lstm_tile_kernel (nullptr: lstm_dim % 128 != 0)
   float *enc_W0h_64 = nullptr, *enc_W1_64 = nullptr, *dec_W0h_64 = nullptr, *dec_W1_64 = nullptr;
+  // ... and as three bf16 planes per tile for lstm_tile3_kernel (N2NMN_MODE_THROUGHPUT_BF16X3; packed by
+  // a commit once the mode has been requested on the root or a fork: b3_on)
+  uint16_t *enc_W0h_b3 = nullptr, *enc_W1_b3 = nullptr, *dec_W0h_b3 = nullptr, *dec_W1_b3 = nullptr;
+  bool b3_on = false;
   float *eht_W_p = nullptr, *att_W_t = nullptr, *att_W_p = nullptr, *find_img_p = nullptr, *fsp_img_p = nullptr;
   float* dec_emb_cat = nullptr;
   PackBatch packs;                                   // every re-pack of a commit, one launch
@@ -165,6 +169,12 @@ struct n2nmn_ctx {
   // per-batch GEMM over the batch's own words (xproj [T][N][4L], rows addressed through iota)
   // instead of a [num_vocab_txt][4L] table rebuilt at every weight commit
   float *ehd[2] = {nullptr, nullptr}, *dhd[2] = {nullptr, nullptr};   // dropped layer-0 outputs
+  // split-operand bf16 mode: bf16 planes [3][L/8][N][8] of every fp32 state buffer a recurrent step reads
+  // as an MFMA operand.  Block A = the 10 N L floats from eh0[0] (encoder states + final states), block B =
+  // ehd / dhd / decoder states (10 N L floats from ehd[0]); planes of float offset o of a block start at
+  // uint16 offset 3 o of its plane block (hb_A directly behind block A: one clear covers both)
+  float *st_A = nullptr, *st_B = nullptr;
+  uint16_t *hb_A = nullptr, *hb_B = nullptr;
                                                                       // (packed state layout)
   bool big_vocab = false;
   float* xproj = nullptr;

@@ -197,6 +197,9 @@ __device__ __forceinline__ void walk_transform(int tid, const ModuleWeights& w, 
 #pragma unroll
     for (int sI = 0; sI < NS; ++sI) af[sI] = w.trA[(4 * sI + kg) * Mq + 16 * ct0 + ci];
   }
+  // w_e of this lane's 4 channel rows of the first tile (zero padded to Mp >= Mq: one 16-byte read, no
+  // bounds branch), requested with them
+  float4 wev = *reinterpret_cast<const float4*>(w.we[2] + 16 * min(cw, Mt - 1) + 4 * kg);
   for (int i = tid; i <= PH * PW; i += WT) {
     const int y = i / PW - PAD, x = i % PW - PAD;
     xin[i] = (i < PH * PW && y >= 0 && y < H && x >= 0 && x < W) ? in0[y * W + x] : 0.f;
@@ -234,13 +237,20 @@ __device__ __forceinline__ void walk_transform(int tid, const ModuleWeights& w, 
 #pragma unroll
     for (int pt = 0; pt < PTMAX; ++pt) xf[sI][pt] = xin[poff[pt] + koff[sI]] * kmask[sI] + kone[sI];
   for (int ct = cw; ct < Mt; ct += WW) {
-    // text map and w_e of this lane's 4 channel rows: both are zero padded to Mp >= Mq, so one
-    // 16-byte read each and no bounds branch (four branchy scalar loads here serialised four global
-    // round trips per channel tile: 18 k of the node's 22 k clocks)
     const float4 tmv = *reinterpret_cast<const float4*>(tm + 16 * ct + 4 * kg);
-    const float4 wev = *reinterpret_cast<const float4*>(w.we[2] + 16 * ct + 4 * kg);
     const float tm4[4] = {tmv.x, tmv.y, tmv.z, tmv.w};
     const float tw4[4] = {tmv.x * wev.x, tmv.y * wev.y, tmv.z * wev.z, tmv.w * wev.w};
+    // the NEXT tile's operands from L2 go out before this tile's MFMAs, not behind them: the round trip
+    // (~1-2 k clocks) then runs under 70 MFMAs instead of in front of the next tile (the timeline had
+    // the matrix phase at 17.7 k clocks for 9 k clocks of MFMA issue)
+    float afn[NS];
+    float4 wen = wev;
+    const bool more = ct + WW < Mt;
+    if (more) {
+#pragma unroll
+      for (int sI = 0; sI < NS; ++sI) afn[sI] = w.trA[(4 * sI + kg) * Mq + 16 * (ct + WW) + ci];
+      wen = *reinterpret_cast<const float4*>(w.we[2] + 16 * (ct + WW) + 4 * kg);
+    }
     f32x4 acc[PTMAX];
 #pragma unroll
     for (int pt = 0; pt < PTMAX; ++pt) acc[pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -251,11 +261,6 @@ __device__ __forceinline__ void walk_transform(int tid, const ModuleWeights& w, 
         acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[sI], xf[sI][pt], acc[pt], 0, 0, 0);
       }
     }
-    // next channel tile's A fragments (if any) while the MFMAs drain
-    if (ct + WW < Mt) {
-#pragma unroll
-      for (int sI = 0; sI < NS; ++sI) af[sI] = w.trA[(4 * sI + kg) * Mq + 16 * (ct + WW) + ci];
-    }
 #pragma unroll
     for (int pt = 0; pt < PTMAX; ++pt) {
 #pragma unroll
@@ -264,6 +269,11 @@ __device__ __forceinline__ void walk_transform(int tid, const ModuleWeights& w, 
         ssp[pt] += v * v;
         dtp[pt] += tw4[r] * acc[pt][r];
       }
+    }
+    if (more) {
+#pragma unroll
+      for (int sI = 0; sI < NS; ++sI) af[sI] = afn[sI];
+      wev = wen;
     }
   }
   // a pixel's channels sit in the four 16-lane rows of the wave: fold them, then across waves.  Two
