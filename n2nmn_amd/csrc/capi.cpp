@@ -249,7 +249,8 @@ static size_t carve_workspace(n2nmn_ctx* c, char* base) {
   c->whcap = (int)std::min<size_t>((size_t)WALK_MAX_BATCHES * N * 4, (size_t)1 << 20);
   c->whjobs = k.take<int32_t>((size_t)c->whcap);
   c->wfblist = k.take<int32_t>((size_t)WALK_MAX_BATCHES * N);
-  c->wcnt = k.take<int32_t>(8);
+  c->wcnt = k.take<int32_t>(16);
+  c->wplist = k.take<int32_t>((size_t)2 * WALK_MAX_BATCHES * N);
   return align_up(k.off, 256);
 }
 
@@ -962,7 +963,7 @@ static int finish_create(n2nmn_ctx* c, n2nmn_ctx* parent) {
     return N2NMN_EHIP;
   }
   carve_workspace(c, c->ws_base);
-  N2_HIP(hipMemset(c->wcnt, 0, sizeof(int32_t) * 8));      // the staged walker's two counter sets
+  N2_HIP(hipMemset(c->wcnt, 0, sizeof(int32_t) * 16));     // the walker's two counter sets
   if (c->iota) {
     std::vector<int32_t> io((size_t)c->d.T_encoder * c->d.N);
     for (size_t i = 0; i < io.size(); ++i) io[i] = (int32_t)i;
@@ -1505,11 +1506,16 @@ int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int
   static const bool staged_env = [] { const char* e = getenv("N2NMN_WALK_STAGED"); return !e || atoi(e) != 0; }();
   const bool staged = pre && a.defer_pool && staged_env && c->walk_staged != 0 &&
                       K * N < (1 << 22) && T_dec <= 255;
+  if (a.defer_pool) {
+    // the per-pass counters (two sets, used alternately: walk_fcatt_kernel clears the other one) and the
+    // pooled-root job lists
+    a.cnt = c->wcnt + 8 * c->walk_parity; a.cnt_next = c->wcnt + 8 * (c->walk_parity ^ 1);
+    c->walk_parity ^= 1;
+    a.plist = c->wplist; a.pcap = WALK_MAX_BATCHES * d.N;
+  }
   if (staged) {
     a.staged = 1;
     a.hjobs = c->whjobs; a.fblist = c->wfblist; a.hcap = c->whcap;
-    a.cnt = c->wcnt + 4 * c->walk_parity; a.cnt_next = c->wcnt + 4 * (c->walk_parity ^ 1);
-    c->walk_parity ^= 1;
   }
   if (pre) {
     a.pre_find = 1;
@@ -1586,8 +1592,10 @@ int n2nmn_debug_walk_replay(n2nmn_ctx* c, int which, int iters, double* us_avg, 
   which &= 0xf;
   auto one = [&]() {
     if (which == 0) {
-      if (a.staged) { launch_walk_heavy(w, a, s); launch_walk_light(w, a, s); }
-      launch_walk(w, a, s);
+      WalkArgs t = a;
+      t.plist = nullptr;                 // (a replay must not append the pooled roots to the lists again)
+      if (t.staged) { launch_walk_heavy(w, t, s); launch_walk_light(w, t, s); }
+      launch_walk(w, t, s);
     }
     else if (which == 1) launch_walk_pool(w, a, s);
     else if (which == 2) launch_walk_heads(w, a, s);
@@ -1742,9 +1750,10 @@ int n2nmn_profile_get(const n2nmn_ctx* ctx, int family, const char** name, int64
  * 3 MFMA only, 4 neither (LDS reduce + epilogue only), 5 empty kernel.  jobs: 2 = L0+L1, 1 = L1. */
 int n2nmn_debug_lstm_bench(n2nmn_ctx* c, int variant, int rows_per_wg, int njobs, int N, int iters,
                            double* us, n2nmn_stream stream) {
-  // 100 + v: lstm_tile3_kernel (split-operand bf16), v = 0 shipped (3 stages), 4 four stages, 13 no DMA,
-  // 23 no MFMA, 33 DMA + barriers only; needs n2nmn_ctx_set_mode(..., N2NMN_MODE_THROUGHPUT_BF16X3) first
-  const int tile3 = variant >= 100 ? variant - 100 : -1;
+  // 1000 + v: lstm_tile3_kernel (split-operand bf16), v = 0 shipped, else <row groups><variant><stages>
+  // (kernels_lstm_tile3.hip launch_lstm_tile3: 403 / 404 64-row workgroups, 803 / 804 128-row, x1x no DMA,
+  // x2x no MFMA, x3x DMA + barriers only); needs n2nmn_ctx_set_mode(..., N2NMN_MODE_THROUGHPUT_BF16X3) first
+  const int tile3 = variant >= 1000 ? variant - 1000 : -1;
   if (tile3 >= 0) variant = 0;
   N2_REQUIRE(tile3 < 0 || (c && root(c)->b3_on && c->enc_W0h_b3), N2NMN_EINVAL,
              "debug_lstm_bench: set the bf16x3 mode first");

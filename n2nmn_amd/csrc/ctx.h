@@ -221,7 +221,7 @@ struct n2nmn_ctx {
   // staged walker (kernels.h WalkArgs::staged): decoded layouts of this context's questions, and -- for
   // the launches this context issues -- the job lists and the two counter sets (used alternately)
   WalkProg* wprog = nullptr;
-  int32_t *whjobs = nullptr, *wfblist = nullptr, *wcnt = nullptr;
+  int32_t *whjobs = nullptr, *wfblist = nullptr, *wcnt = nullptr, *wplist = nullptr;
   int whcap = 0, walk_parity = 0;
   int walk_staged = -1;                       // -1 auto (with the chip-wide front end + deferred pooling), 0 off
   float *arena = nullptr, *tmap = nullptr, *pfc = nullptr, *mfind = nullptr, *mfsp = nullptr;

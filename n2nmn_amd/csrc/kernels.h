@@ -328,10 +328,14 @@ struct WalkArgs {
   int staged;
   int32_t* hjobs;          // [hcap] (question << 8) | node
   int32_t* fblist;         // [K * N] flat question indices
-  int32_t* cnt;            // [4] this pass's counters
+  int32_t* cnt;            // [8] this pass's counters (cnt[3] / cnt[4]: deferred Describe / SameProperty jobs)
   int32_t* cnt_next;       // [4] the other set: walk_heads_kernel zeroes it for the next pass (this pass's
                            // set stays readable for n2nmn_debug_walk_replay)
   int hcap;
+  // deferred pooling (defer_pool): the questions whose root pools, listed per operator by whoever
+  // writes pjob (walk_light_kernel / walk_kernel): plist[0 .. pcap) Describe, plist[pcap ..) SameProperty
+  int32_t* plist;
+  int pcap;
   // profiling only: [0] conv_image map reads (one per <= 4 Find / Filter nodes of a question, one per
   // FindSameProperty node), [1] pooled inputs, [2] pooling nodes, [3] text maps,
   // [4] Transform nodes, [5] valid questions, [6] deferred pooling jobs, [7] their inputs,

@@ -47,12 +47,17 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 
-constexpr int T3_ROWS = 64, T3_UNITS = 16, T3_BK = 32;
-constexpr int T3_WAVES = 8, T3_THREADS = T3_WAVES * 64;
-constexpr int T3_H_IMAGE = 3 * 4 * 1024;            // planes x row groups x 1 KiB
+constexpr int T3_UNITS = 16, T3_BK = 32;
 constexpr int T3_W_IMAGE = 3 * 4 * 1024;            // planes x gates x 1 KiB
-constexpr int T3_STAGE = T3_H_IMAGE + T3_W_IMAGE;   // 24 KiB
-constexpr int T3_PIECES = 3;                        // LDS-DMA instructions per wave and stage (24 / 8)
+// RG = row groups of 16 rows per workgroup (4: 64 rows, 8 waves; 8: 128 rows, 16 waves -- the weight
+// planes of a stage then serve twice the rows: 36 KiB per 128 rows instead of 2 x 24 KiB)
+template <int RG> struct T3 {
+  static constexpr int ROWS = 16 * RG, WAVES = 2 * RG, THREADS = WAVES * 64;
+  static constexpr int H_IMAGE = 3 * RG * 1024;     // planes x row groups x 1 KiB
+  static constexpr int STAGE = H_IMAGE + T3_W_IMAGE;
+  static constexpr int NPIECE = 3 * RG + 12;        // LDS-DMA instructions per stage
+  static constexpr int PBASE = NPIECE / WAVES, PEXTRA = NPIECE % WAVES;   // per wave; waves < PEXTRA one more
+};
 
 struct LstmJobs3 {
   LstmJob j[2];
@@ -100,10 +105,13 @@ __device__ __forceinline__ void store_planes(uint16_t* planes, size_t plane_elem
 }
 
 // VAR (n2nmn_debug_lstm_bench only): 1 = no DMA, 2 = no MFMA, 3 = DMA + barriers only
-template <int NS, int VAR = 0>
-__global__ __launch_bounds__(T3_THREADS, 2) void lstm_tile3_kernel(LstmJobs3 jobs, int N, int L, int nrb,
-                                                                   int njobs) {
+template <int NS, int RG, int VAR = 0>
+__global__ __launch_bounds__(T3<RG>::THREADS, RG == 4 ? 2 : 1) void lstm_tile3_kernel(LstmJobs3 jobs, int N,
+                                                                                      int L, int nrb,
+                                                                                      int njobs) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
+  constexpr int T3_ROWS = T3<RG>::ROWS, T3_H_IMAGE = T3<RG>::H_IMAGE, T3_STAGE = T3<RG>::STAGE;
+  constexpr int PMAX = T3<RG>::PBASE + (T3<RG>::PEXTRA ? 1 : 0);
   const int ntile = L / T3_UNITS;
   // ---- id -> (job, row block, column tile): as lstm_tile_kernel (dense over the active row blocks,
   // the K = 2L job first, column tile fastest so that tile % 8 is the workgroup's XCD)
@@ -135,7 +143,7 @@ __global__ __launch_bounds__(T3_THREADS, 2) void lstm_tile3_kernel(LstmJobs3 job
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = w & 3, gp = w >> 2;                // row group of the wave, and its gate pair
+  const int wr = w % RG, gp = w / RG;               // row group of the wave, and its gate pair
   const int row0 = rb * T3_ROWS;
   const int R = jb.hp_R;
   const int nact = jb.n_active ? *jb.n_active : N;
@@ -158,24 +166,24 @@ __global__ __launch_bounds__(T3_THREADS, 2) void lstm_tile3_kernel(LstmJobs3 job
   const int K = jb.K, nst = K / T3_BK;
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
   const uint32_t plane_bytes = (uint32_t)(L / 8) * (uint32_t)R * 16u;      // one plane of a state buffer
-  // this wave's three pieces of every stage: piece id pc = w, w + 8, w + 16 of 24
-  //   pc < 12: h plane p = pc / 4 of row group pc % 4;   pc >= 12: weight plane (pc - 12) / 4, gate % 4
-  uint32_t pbase[T3_PIECES], pstep[T3_PIECES], plds[T3_PIECES];
-  bool pish[T3_PIECES];
+  // this wave's pieces of every stage: piece ids pc = w, w + WAVES, ... < NPIECE
+  //   pc < 3 RG: h plane p = pc / RG of row group pc % RG;   pc >= 3 RG: weight plane (pc - 3 RG) / 4, gate % 4
+  uint32_t pbase[PMAX], pstep[PMAX], plds[PMAX];
+  bool pish[PMAX];
   const uint32_t wtile = (uint32_t)ct * (uint32_t)nst * (uint32_t)T3_W_IMAGE;
 #pragma unroll
-  for (int i = 0; i < T3_PIECES; ++i) {
-    const int pc = w + 8 * i;
-    pish[i] = pc < 12;
-    if (pc < 12) {
-      const int p = pc >> 2, rg = pc & 3;
+  for (int i = 0; i < PMAX; ++i) {
+    const int pc = min(w + T3<RG>::WAVES * i, T3<RG>::NPIECE - 1);
+    pish[i] = pc < 3 * RG;
+    if (pc < 3 * RG) {
+      const int p = pc / RG, rg = pc % RG;
       const int arow = min(row0 + 16 * rg + (lane & 15), N - 1);
       // k8 group (lane >> 4) of the stage, row arow: 16 bytes
       pbase[i] = (uint32_t)p * plane_bytes + ((uint32_t)(lane >> 4) * (uint32_t)R + (uint32_t)arow) * 16u;
       pstep[i] = 4u * (uint32_t)R * 16u;                        // four k8 groups per stage
       plds[i] = (uint32_t)pc * 1024u;
     } else {
-      const int idx = pc - 12;
+      const int idx = pc - 3 * RG;
       pbase[i] = wtile + (uint32_t)idx * 1024u + (uint32_t)lane * 16u;
       pstep[i] = (uint32_t)T3_W_IMAGE;
       plds[i] = (uint32_t)T3_H_IMAGE + (uint32_t)idx * 1024u;
@@ -185,19 +193,27 @@ __global__ __launch_bounds__(T3_THREADS, 2) void lstm_tile3_kernel(LstmJobs3 job
   const uint16_t* const A1p = jb.A1b;
   const uint16_t* const Wp = jb.Wb3;
   const int sL = L / T3_BK;                           // stages that read A0 (the rest read A1)
-  auto issue = [&](int s) {
+  auto issue = [&](auto np_tag, int s) {
+    constexpr int NP = decltype(np_tag)::value;
     const uint32_t slot = lds0 + (uint32_t)(s % NS) * T3_STAGE;
     const bool lo = s < sL;
     const uint32_t sh = (uint32_t)(lo ? s : s - sL);
 #pragma unroll
-    for (int i = 0; i < T3_PIECES; ++i) {
+    for (int i = 0; i < NP; ++i) {
       if (pish[i]) glds16b(lo ? A0p : A1p, pbase[i] + sh * pstep[i], slot + plds[i]);
       else glds16b(Wp, pbase[i] + (uint32_t)s * pstep[i], slot + plds[i]);
     }
   };
+  // waves below PEXTRA issue one piece more per stage than the others: the counted waits differ, so
+  // the stage loop exists per piece count (wave-uniform choice)
+  const bool extra = w < T3<RG>::PEXTRA;
 #pragma unroll
-  for (int s = 0; s < NS - 1; ++s)
-    if (VAR != 1) issue(s);
+  for (int s = 0; s < NS - 1; ++s) {
+    if (VAR != 1) {
+      if (extra) issue(std::integral_constant<int, PMAX>{}, s);
+      else issue(std::integral_constant<int, T3<RG>::PBASE>{}, s);
+    }
+  }
 
   // ---- epilogue operands (waves of gate pair 0 own the cell update): fetched under the DMA prologue
   int orow = grc;
@@ -232,7 +248,7 @@ __global__ __launch_bounds__(T3_THREADS, 2) void lstm_tile3_kernel(LstmJobs3 job
   auto fetch = [&](Grp& g, int slot) {
     const uint4* st = S0 + slot * (T3_STAGE / 16);
 #pragma unroll
-    for (int p = 0; p < 3; ++p) g.h[p] = st[(p * 4 + wr) * 64];
+    for (int p = 0; p < 3; ++p) g.h[p] = st[(p * RG + wr) * 64];
 #pragma unroll
     for (int gi = 0; gi < 2; ++gi)
 #pragma unroll
@@ -258,46 +274,52 @@ __global__ __launch_bounds__(T3_THREADS, 2) void lstm_tile3_kernel(LstmJobs3 job
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, hh, c, 0, 0, 0);
     acc[gi] = c;
   };
-  auto sync_stage = [&](int next) {
-    const int behind = nst - 1 - next;             // stages after `next`
-    if (behind >= NS - 3) wait_vm3<T3_PIECES * (NS - 3)>();
-    else wait_vm3<0>();
-    __builtin_amdgcn_s_barrier();
-  };
 #define N3_PIN() __builtin_amdgcn_sched_barrier(0)
-  // One step: the 12 MFMAs of stage `cur` (in registers); woven in: the refill of the slot behind and
-  // the LDS reads of stage `next`
-  auto step = [&](auto work_tag, const Grp& cur, Grp& nxt, int next, bool more) {
+  auto stages = [&](auto work_tag, auto np_tag) {
     constexpr bool WORK = decltype(work_tag)::value;
-    const int refill = next + NS - 2;
-    const bool dma = more && refill < nst && VAR != 1;
-    if (more) sync_stage(next);
-    if (WORK) { mma_gate(cur, 0); N3_PIN(); }
-    if (dma) issue(refill);
-    if (WORK) {
-      N3_PIN();
-      if (more) fetch(nxt, next % NS);
-      N3_PIN();
-      mma_gate(cur, 1);
-    }
-  };
-  auto stages = [&](auto work_tag) {
-    constexpr bool WORK = decltype(work_tag)::value;
-    wait_vm3<T3_PIECES * (NS - 2)>();              // stage 0 (the oldest of the NS - 1 in flight)
+    constexpr int NP = decltype(np_tag)::value;
+    auto sync_stage = [&](int next) {
+      const int behind = nst - 1 - next;             // stages after `next`
+      if (behind >= NS - 3) wait_vm3<NP * (NS - 3)>();
+      else wait_vm3<0>();
+      __builtin_amdgcn_s_barrier();
+    };
+    // One step: the 12 MFMAs of stage `cur` (in registers); woven in: the refill of the slot behind and
+    // the LDS reads of stage `next`
+    auto step = [&](const Grp& cur, Grp& nxt, int next, bool more) {
+      const int refill = next + NS - 2;
+      const bool dma = more && refill < nst && VAR != 1;
+      if (more) sync_stage(next);
+      if (WORK) { mma_gate(cur, 0); N3_PIN(); }
+      if (dma) issue(np_tag, refill);
+      if (WORK) {
+        N3_PIN();
+        if (more) fetch(nxt, next % NS);
+        N3_PIN();
+        mma_gate(cur, 1);
+      }
+    };
+    wait_vm3<NP * (NS - 2)>();                     // stage 0 (the oldest of the NS - 1 in flight)
     __builtin_amdgcn_s_barrier();
     Grp P{}, Q{};
     if (WORK) fetch(P, 0);
     int i = 0;
     for (; i + 2 < nst; i += 2) {                  // nst is even: two stages per trip, P / Q static
-      step(work_tag, P, Q, i + 1, true);
-      step(work_tag, Q, P, i + 2, true);
+      step(P, Q, i + 1, true);
+      step(Q, P, i + 2, true);
     }
-    step(work_tag, P, Q, i + 1, true);             // the last two stages
-    step(work_tag, Q, P, 0, false);
+    step(P, Q, i + 1, true);                       // the last two stages
+    step(Q, P, 0, false);
   };
 #undef N3_PIN
-  if (wact && VAR != 3) stages(std::true_type{});
-  else stages(std::false_type{});
+  const bool work = wact && VAR != 3;
+  if (T3<RG>::PEXTRA && extra) {
+    if (work) stages(std::true_type{}, std::integral_constant<int, PMAX>{});
+    else stages(std::false_type{}, std::integral_constant<int, PMAX>{});
+  } else {
+    if (work) stages(std::true_type{}, std::integral_constant<int, T3<RG>::PBASE>{});
+    else stages(std::false_type{}, std::integral_constant<int, T3<RG>::PBASE>{});
+  }
 
   // ---- the gate pairs meet: waves 4-7 park f, o in LDS (every DMA has landed, every stage has been
   // read: the ring is free), waves 0-3 take them ------------------------------------------------------
@@ -392,15 +414,15 @@ __global__ __launch_bounds__(256) void split_state_b3_kernel(const float* __rest
   }
 }
 
-template <int NS, int VAR = 0>
+template <int NS, int RG, int VAR = 0>
 void launch_tile3(const LstmJobs3& js, int njobs, int N, int L, hipStream_t s) {
   static std::atomic<uint64_t> attr{0};
-  const int lds = NS * T3_STAGE;
-  ensure_dynamic_lds(reinterpret_cast<const void*>(&lstm_tile3_kernel<NS, VAR>), lds, attr);
-  const int nrb = (N + T3_ROWS - 1) / T3_ROWS;
+  const int lds = NS * T3<RG>::STAGE;
+  ensure_dynamic_lds(reinterpret_cast<const void*>(&lstm_tile3_kernel<NS, RG, VAR>), lds, attr);
+  const int nrb = (N + T3<RG>::ROWS - 1) / T3<RG>::ROWS;
   const int grid = njobs * nrb * (L / T3_UNITS);
-  hipLaunchKernelGGL((lstm_tile3_kernel<NS, VAR>), dim3(grid), dim3(T3_THREADS), lds, s, js, N, L, nrb,
-                     njobs);
+  hipLaunchKernelGGL((lstm_tile3_kernel<NS, RG, VAR>), dim3(grid), dim3(T3<RG>::THREADS), lds, s, js, N, L,
+                     nrb, njobs);
 }
 
 }  // namespace
@@ -426,12 +448,21 @@ void launch_lstm_tile3(const LstmJob* jobs, int njobs, int N, int L, hipStream_t
     if (i < njobs) js.j[i] = jobs[i];
     else { js.j[i] = LstmJob{}; js.j[i].active = 0; }
   }
+  // default: 128-row workgroups (16 waves, 4 stages of 36 KiB) when the launch has at least two
+  // 128-row blocks per job; variants (n2nmn_debug_lstm_bench): 4xx = 64-row workgroups
+  static const int dflt = [] { const char* e = getenv("N2NMN_TILE3_VARIANT"); return e ? atoi(e) : 0; }();
+  if (variant == 0) variant = dflt ? dflt : (N >= 256 ? 804 : 403);
   switch (variant) {
-    case 4: launch_tile3<4>(js, njobs, N, L, s); break;
-    case 13: launch_tile3<3, 1>(js, njobs, N, L, s); break;     // debug variants of the 3-stage kernel
-    case 23: launch_tile3<3, 2>(js, njobs, N, L, s); break;
-    case 33: launch_tile3<3, 3>(js, njobs, N, L, s); break;
-    default: launch_tile3<3>(js, njobs, N, L, s); break;
+    case 404: launch_tile3<4, 4>(js, njobs, N, L, s); break;
+    case 413: launch_tile3<3, 4, 1>(js, njobs, N, L, s); break;     // debug variants: no DMA
+    case 423: launch_tile3<3, 4, 2>(js, njobs, N, L, s); break;     // no MFMA
+    case 433: launch_tile3<3, 4, 3>(js, njobs, N, L, s); break;     // DMA + barriers only
+    case 803: launch_tile3<3, 8>(js, njobs, N, L, s); break;
+    case 804: launch_tile3<4, 8>(js, njobs, N, L, s); break;
+    case 814: launch_tile3<4, 8, 1>(js, njobs, N, L, s); break;
+    case 824: launch_tile3<4, 8, 2>(js, njobs, N, L, s); break;
+    case 834: launch_tile3<4, 8, 3>(js, njobs, N, L, s); break;
+    default: launch_tile3<3, 4>(js, njobs, N, L, s); break;         // 403
   }
 }
 

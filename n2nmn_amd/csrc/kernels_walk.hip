@@ -723,7 +723,14 @@ __global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
       }
       float* ptm = B.ptm + (size_t)n * Mp;
       for (int c = tid; c < Mp; c += WT) ptm[c] = tml[c];
-      if (tid == 0) B.pjob[n] = op;
+      if (tid == 0) {
+        B.pjob[n] = op;
+        if (a.plist) {                                 // the job lists walk_fcatt_kernel works from
+          const int ty = op == N2NMN_OP_SAME_PROPERTY ? 1 : 0;
+          const int j = atomicAdd(a.cnt + 3 + ty, 1);
+          if (j < a.pcap) a.plist[ty * a.pcap + j] = q;
+        }
+      }
       break;                                           // the root is the last node
     }
     if (pools) {
@@ -1279,58 +1286,29 @@ __global__ __launch_bounds__(256) void walk_pool_kernel(WalkArgs a) {
 // fc_att of the deferred pooling jobs (nmn3_modules.py:442-446, 487-490), grouped: every job of one
 // weight set multiplies its pooled feature vector with the same [D, Mp] matrix (512 KB at CLEVR
 // dimensions).  One workgroup per job pulled that matrix from L2 once per job (309 jobs: 158 MB, 34 us
-// per 1024 questions); here a workgroup takes HG jobs of ONE weight set -- ranked by scanning the job
-// codes of the launch, as walk_textmap_kernel does -- and 64 of the Mp columns, so every weight row it
+// per 1024 questions); here a workgroup takes HG jobs of ONE weight set -- from the per-operator job lists
+// that walk_light_kernel / walk_kernel append to when they hand a root over (WalkArgs::plist; scanning
+// the launch's job codes per workgroup cost more than the products) -- and 64 of the Mp columns, so every weight row it
 // fetches meets HG vectors, a workgroup's share of the matrix is 128 KB, and all of it is in flight at
 // once: 32 k-groups x 16 column lanes, D / 32 rows per thread.
 // Weight sets: y = 0 Describe (fc_att of input 0), 1 / 2 SameProperty input 0 / input 1.
 // Rows go to pfc[n][input][Mp].
 constexpr int HG = 4, FCW = 64, FKG = WT / (FCW / 4);          // jobs, columns, k-groups per workgroup
+constexpr int FC_GROUPS = 96;                                  // job groups of the persistent grid
 __global__ __launch_bounds__(WT) void walk_fcatt_kernel(ModuleWeights w, WalkArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  __shared__ int wcount[WW];
-  __shared__ int sel[HG];
-  if (a.staged && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
-    a.cnt_next[0] = 0; a.cnt_next[1] = 0; a.cnt_next[2] = 0;   // the NEXT staged pass starts from empty lists
-  }
-  const int g = blockIdx.x, y = blockIdx.y, c0 = blockIdx.z * FCW;
-  const int want = y == 0 ? N2NMN_OP_DESCRIBE : N2NMN_OP_SAME_PROPERTY;
+  const int y = blockIdx.y, c0 = blockIdx.z * FCW;
+  const int ty = y == 0 ? 0 : 1;                  // list: Describe / SameProperty
   const int which = y == 2 ? 1 : 0;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int D = a.D, Mp = a.Mp, QN = a.K * a.N;
-  // ---- rank the questions of the launch whose job uses this weight set
-  int base = 0;
-  for (int q0 = 0; q0 < QN; q0 += WT) {
-    const int q = q0 + tid;
-    bool hit = false;
-    if (q < QN) {
-      const int kb = q / a.N;
-      hit = a.b[kb].pjob[q - kb * a.N] == want;
-    }
-    const unsigned long long m = __ballot(hit);
-    if (lane == 0) wcount[wid] = __builtin_popcountll(m);
-    __syncthreads();
-    int before = base, all = 0;
-    for (int i = 0; i < WW; ++i) { if (i < wid) before += wcount[i]; all += wcount[i]; }
-    const int rank = before + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-    if (hit && rank >= HG * g && rank < HG * g + HG) sel[rank - HG * g] = q;
-    base += all;
-    __syncthreads();
-    if (base >= HG * g + HG) break;               // (uniform) this workgroup's jobs are all known
+  const int njob = min(a.cnt[3 + ty], a.pcap);    // (uniform: scalar load)
+  if (blockIdx.x == 0 && y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+    // the NEXT pass starts from empty lists (this pass's set stays readable for replays)
+    for (int i = 0; i < 5; ++i) a.cnt_next[i] = 0;
   }
-  const int cnt = min(HG, base - HG * g);
-  if (cnt <= 0) return;
+  const int tid = threadIdx.x;
+  const int D = a.D, Mp = a.Mp;
   float* x = smem;                                // [HG][D]
   float* part = x + (size_t)HG * D;               // [FKG][HG][FCW]
-  for (int i = tid; i < HG * D; i += WT) {
-    const int j = i / D, k = i - j * D;
-    float v = 0.f;
-    if (j < cnt) {
-      const int q = sel[j], kb = q / a.N, n = q - kb * a.N;
-      v = a.b[kb].pooled[((size_t)n * 2 + which) * D + k];
-    }
-    x[i] = v;
-  }
   const int wi = y == 0 ? 3 : y;                  // ModuleWeights::Watt: FSP, SameProperty 0 / 1, Describe
   const float* Wp = w.Watt[wi];
   const float* bm = w.batt[wi];
@@ -1339,45 +1317,59 @@ __global__ __launch_bounds__(WT) void walk_fcatt_kernel(ModuleWeights w, WalkArg
   const int k0 = kg * kper, k1 = min(D, k0 + kper);
   const unsigned col = (unsigned)(c0 + 4 * cl);   // (Mp % 64 == 0: every column of the part exists)
   constexpr int KU = 16;
-  float4 acc[HG];
+  const int32_t* list = a.plist + (size_t)ty * a.pcap;
+  for (int g = blockIdx.x; HG * g < njob; g += gridDim.x) {
+    const int cnt = min(HG, njob - HG * g);
+    float4 w4[KU];
+    auto fetch = [&](int kq) {
 #pragma unroll
-  for (int j = 0; j < HG; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 w4[KU];
-  auto fetch = [&](int kq) {
-#pragma unroll
-    for (int u = 0; u < KU; ++u) {
-      const unsigned k = (unsigned)min(kq + u, max(k1 - 1, 0));
-      w4[u] = *reinterpret_cast<const float4*>(Wp + (k * (unsigned)Mp + col));
+      for (int u = 0; u < KU; ++u) {
+        const unsigned k = (unsigned)min(kq + u, max(k1 - 1, 0));
+        w4[u] = *reinterpret_cast<const float4*>(Wp + (k * (unsigned)Mp + col));
+      }
+    };
+    fetch(k0);                                    // the first weight rows are in flight ...
+    for (int i = tid; i < HG * D; i += WT) {      // ... while the pooled vectors of the jobs arrive
+      const int j = i / D, k = i - j * D;
+      float v = 0.f;
+      if (j < cnt) {
+        const int q = list[HG * g + j], kb = q / a.N, n = q - kb * a.N;
+        v = a.b[kb].pooled[((size_t)n * 2 + which) * D + k];
+      }
+      x[i] = v;
     }
-  };
-  fetch(k0);                                      // the first rows are in flight ...
-  __syncthreads();                                // ... while x completes
-  for (int kq = k0; kq < k1; kq += KU) {
-    if (kq != k0) fetch(kq);
+    __syncthreads();
+    float4 acc[HG];
 #pragma unroll
-    for (int u = 0; u < KU; ++u) {
-      if (kq + u < k1) {
+    for (int j = 0; j < HG; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int kq = k0; kq < k1; kq += KU) {
+      if (kq != k0) fetch(kq);
 #pragma unroll
-        for (int j = 0; j < HG; ++j) {
-          const float xv = x[j * D + kq + u];
-          acc[j].x += xv * w4[u].x; acc[j].y += xv * w4[u].y; acc[j].z += xv * w4[u].z;
-          acc[j].w += xv * w4[u].w;
+      for (int u = 0; u < KU; ++u) {
+        if (kq + u < k1) {
+#pragma unroll
+          for (int j = 0; j < HG; ++j) {
+            const float xv = x[j * D + kq + u];
+            acc[j].x += xv * w4[u].x; acc[j].y += xv * w4[u].y; acc[j].z += xv * w4[u].z;
+            acc[j].w += xv * w4[u].w;
+          }
         }
       }
     }
-  }
 #pragma unroll
-  for (int j = 0; j < HG; ++j)
-    *reinterpret_cast<float4*>(part + ((size_t)(kg * HG + j) * FCW) + 4 * cl) = acc[j];
-  __syncthreads();
-  for (int i = tid; i < HG * FCW; i += WT) {
-    const int j = i / FCW, c = i - j * FCW;
-    if (j < cnt) {
-      float r = bm[c0 + c];
-      for (int qq = 0; qq < FKG; ++qq) r += part[(size_t)(qq * HG + j) * FCW + c];
-      const int q = sel[j], kb = q / a.N, n = q - kb * a.N;
-      a.b[kb].pfc[((size_t)n * 2 + which) * Mp + c0 + c] = r;
+    for (int j = 0; j < HG; ++j)
+      *reinterpret_cast<float4*>(part + ((size_t)(kg * HG + j) * FCW) + 4 * cl) = acc[j];
+    __syncthreads();
+    for (int i = tid; i < HG * FCW; i += WT) {
+      const int j = i / FCW, c = i - j * FCW;
+      if (j < cnt) {
+        float r = bm[c0 + c];
+        for (int qq = 0; qq < FKG; ++qq) r += part[(size_t)(qq * HG + j) * FCW + c];
+        const int q = list[HG * g + j], kb = q / a.N, n = q - kb * a.N;
+        a.b[kb].pfc[((size_t)n * 2 + which) * Mp + c0 + c] = r;
+      }
     }
+    __syncthreads();                              // x / part are reused by the next group
   }
 }
 
@@ -1707,25 +1699,43 @@ __global__ __launch_bounds__(WT) void walk_light_kernel(ModuleWeights w, WalkArg
   const int op = P.op[t] & 0x7f;
   const float* in0 = P.in0[t] >= 0 ? arena + (size_t)P.in0[t] * HWp : nullptr;
   const float* in1 = P.in1[t] >= 0 ? arena + (size_t)P.in1[t] * HWp : nullptr;
+  const int lane = tid & 63, wid = tid >> 6;
   if (op == N2NMN_OP_DESCRIBE || op == N2NMN_OP_SAME_PROPERTY) {
     // deferred pooling root: soft-max weights, text map and job code for walk_pool / walk_heads
-    // (:432-437,482-484) -- walk_kernel's statements
+    // (:432-437,482-484).  A map has H*W = 150 values: ONE wave reduces it in registers (three values
+    // per lane, DPP wave reductions) -- the block-wide reductions of walk_kernel cost two barriers and
+    // an LDS round trip each, 6 k clocks of a 11 k clock question (tools/staged_timeline.py)
     const int nin = op == N2NMN_OP_SAME_PROPERTY ? 2 : 1;
     float* pw = B.pw + (size_t)n * 2 * HWp;
-    for (int i = 0; i < nin; ++i) {
-      const float* src = i == 0 ? in0 : in1;
-      float lm = -INFINITY;
-      for (int r = tid; r < HW; r += WT) lm = fmaxf(lm, src[r]);
-      const float mx = wg_reduce<1>(lm, rs);
+    if (wid < nin) {                                   // wave 0: input 0, wave 1: input 1
+      const float* src = wid == 0 ? in0 : in1;
+      float v[3], lm = -INFINITY;
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int r = lane + 64 * u;
+        v[u] = r < HW ? src[r] : -INFINITY;
+        lm = fmaxf(lm, v[u]);
+      }
+      const float mx = wave_max(lm);
       float ls = 0.f;
-      for (int r = tid; r < HW; r += WT) ls += expf(src[r] - mx);
-      const float sum = wg_reduce<0>(ls, rs);
-      for (int r = tid; r < HW; r += WT) pw[i * HWp + r] = expf(src[r] - mx) / sum;
+#pragma unroll
+      for (int u = 0; u < 3; ++u) { v[u] = lane + 64 * u < HW ? expf(v[u] - mx) : 0.f; ls += v[u]; }
+      const float sum = wave_sum(ls);
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+        if (lane + 64 * u < HW) pw[wid * HWp + lane + 64 * u] = v[u] / sum;
     }
     float* ptm = B.ptm + (size_t)n * Mp;
     const float* tsrc = B.tmap + ((size_t)t * a.N + n) * Mp;
     for (int c = tid; c < Mp; c += WT) ptm[c] = tsrc[c];
-    if (tid == 0) B.pjob[n] = op;
+    if (tid == 0) {
+      B.pjob[n] = op;
+      if (a.plist) {                                   // the job lists walk_fcatt_kernel works from
+        const int ty = op == N2NMN_OP_SAME_PROPERTY ? 1 : 0;
+        const int j = atomicAdd(a.cnt + 3 + ty, 1);
+        if (j < a.pcap) a.plist[ty * a.pcap + j] = q;
+      }
+    }
     if (tl && tid == 0) tl[3] = clock64();
     return;
   }
@@ -1733,31 +1743,34 @@ __global__ __launch_bounds__(WT) void walk_light_kernel(ModuleWeights w, WalkArg
   float* x = scr;                                  // up to 2*HW + 4 features
   float* red = x + ((2 * HW + 4 + 3) & ~3);
   const int nin = (op == N2NMN_OP_EXIST || op == N2NMN_OP_COUNT) ? 1 : 2;
-  float mn[2], mx[2], sm[2];
-  for (int i = 0; i < nin; ++i) {
-    const float* src = i == 0 ? in0 : in1;
+  // min / max / sum of each input by ONE wave (see above); it also writes the features
+  if (wid < nin) {
+    const float* src = wid == 0 ? in0 : in1;
     float lmn = INFINITY, lmx = -INFINITY, lsm = 0.f;
-    for (int r = tid; r < HW; r += WT) {
-      const float v = src[r];
-      x[i * (HW + 2) + r] = v;                     // row-major y*W + x flatten (:297)
-      lmn = fminf(lmn, v); lmx = fmaxf(lmx, v); lsm += v;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int r = lane + 64 * u;
+      if (r < HW) {
+        const float v = src[r];
+        x[wid * (HW + 2) + r] = v;                   // row-major y*W + x flatten (:297)
+        lmn = fminf(lmn, v); lmx = fmaxf(lmx, v); lsm += v;
+      }
     }
-    mn[i] = wg_reduce<2>(lmn, rs);
-    mx[i] = wg_reduce<1>(lmx, rs);
-    sm[i] = wg_reduce<0>(lsm, rs);
+    const float mn = wave_min(lmn), mx = wave_max(lmx), sm = wave_sum(lsm);
+    if (lane == 0) { rs[4 * wid] = mn; rs[4 * wid + 1] = mx; rs[4 * wid + 2] = sm; }
   }
   __syncthreads();
   int F, wi;
   if (op == N2NMN_OP_EXIST) {
-    if (tid == 0) { x[0] = mn[0]; x[1] = sm[0] / (float)HW; x[2] = mx[0]; }
+    if (tid == 0) { const float mn = rs[0], mx = rs[1], sm = rs[2]; x[0] = mn; x[1] = sm / (float)HW; x[2] = mx; }
     F = 3; wi = 0;
   } else if (op == N2NMN_OP_COUNT) {
-    if (tid == 0) { x[HW] = mn[0]; x[HW + 1] = mx[0]; }
+    if (tid == 0) { x[HW] = rs[0]; x[HW + 1] = rs[1]; }
     F = HW + 2; wi = 1;
   } else {
     if (tid == 0) {
-      x[HW] = mn[0]; x[HW + 1] = mx[0];
-      x[2 * HW + 2] = mn[1]; x[2 * HW + 3] = mx[1];
+      x[HW] = rs[0]; x[HW + 1] = rs[1];
+      x[2 * HW + 2] = rs[4]; x[2 * HW + 3] = rs[5];
     }
     F = 2 * HW + 4;
     wi = op == N2NMN_OP_EQUAL_NUM ? 2 : (op == N2NMN_OP_MORE_NUM ? 3 : 4);
@@ -1806,7 +1819,8 @@ void launch_walk_heads(const ModuleWeights& w, const WalkArgs& a, hipStream_t s)
   const size_t fsm = sizeof(float) * ((size_t)HG * a.D + (size_t)FKG * HG * FCW);
   static std::atomic<uint64_t> done{0};
   if (fsm > 64 * 1024) ensure_dynamic_lds(reinterpret_cast<const void*>(walk_fcatt_kernel), (int)fsm, done);
-  hipLaunchKernelGGL(walk_fcatt_kernel, dim3((QN + HG - 1) / HG, 3, a.Mp / FCW), dim3(WT), fsm, s, w, a);
+  const int groups = std::min(FC_GROUPS, (QN + HG - 1) / HG);
+  hipLaunchKernelGGL(walk_fcatt_kernel, dim3(groups, 3, a.Mp / FCW), dim3(WT), fsm, s, w, a);
   const size_t smem = sizeof(float) * ((size_t)a.Mp + 32 + WT);
   hipLaunchKernelGGL(walk_heads_kernel, dim3(QN), dim3(WT), smem, s, w, a);
 }

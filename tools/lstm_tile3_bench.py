@@ -17,9 +17,12 @@ eng = Engine(d, Assembler(list(CLEVR_MODULE_NAMES)))
 eng.load_weights(synth.make_weights(Dims(), seed=0))
 eng.set_mode('throughput_bf16x3')
 names = {24: 'fp32 LDS tile, 4 stages', 34: 'fp32 tile, no DMA', 44: 'fp32 tile, no MFMA',
-         100: 'bf16x3 tile, 3 stages', 104: 'bf16x3 tile, 4 stages', 113: 'bf16x3, no DMA',
-         123: 'bf16x3, no MFMA', 133: 'bf16x3, DMA + barriers only'}
-VARIANTS = [int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else [24, 100, 104, 113, 123, 133, 24, 100]
+         1403: 'bf16x3 64 rows, 3 stages', 1404: 'bf16x3 64 rows, 4 stages', 1413: 'bf16x3 64 rows, no DMA',
+         1423: 'bf16x3 64 rows, no MFMA', 1433: 'bf16x3 64 rows, DMA only',
+         1803: 'bf16x3 128 rows, 3 stages', 1804: 'bf16x3 128 rows, 4 stages', 1814: 'bf16x3 128 rows, no DMA',
+         1824: 'bf16x3 128 rows, no MFMA', 1834: 'bf16x3 128 rows, DMA only'}
+VARIANTS = [int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else \
+    [24, 1403, 1803, 1804, 1814, 1824, 1834, 24, 1403, 1804]
 GF = {N: 2.0 * N * 4 * 512 * (512 + 1024) / 1e9 for N in (128, 256, 512, 1024)}
 for N in ([int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else (1024, 512, 256)):
     for v in VARIANTS:
