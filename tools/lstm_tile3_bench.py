@@ -20,9 +20,11 @@ names = {24: 'fp32 LDS tile, 4 stages', 34: 'fp32 tile, no DMA', 44: 'fp32 tile,
          1403: 'bf16x3 64 rows, 3 stages', 1404: 'bf16x3 64 rows, 4 stages', 1413: 'bf16x3 64 rows, no DMA',
          1423: 'bf16x3 64 rows, no MFMA', 1433: 'bf16x3 64 rows, DMA only',
          1803: 'bf16x3 128 rows, 3 stages', 1804: 'bf16x3 128 rows, 4 stages', 1814: 'bf16x3 128 rows, no DMA',
-         1824: 'bf16x3 128 rows, no MFMA', 1834: 'bf16x3 128 rows, DMA only'}
+         1824: 'bf16x3 128 rows, no MFMA', 1834: 'bf16x3 128 rows, DMA only',
+         1903: 'bf16x3 128x128, 3 stages', 1913: 'bf16x3 128x128, no DMA', 1923: 'bf16x3 128x128, no MFMA',
+         1933: 'bf16x3 128x128, DMA only'}
 VARIANTS = [int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else \
-    [24, 1403, 1803, 1804, 1814, 1824, 1834, 24, 1403, 1804]
+    [24, 1804, 1903, 1913, 1923, 1933, 24, 1804, 1903]
 GF = {N: 2.0 * N * 4 * 512 * (512 + 1024) / 1e9 for N in (128, 256, 512, 1024)}
 for N in ([int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else (1024, 512, 256)):
     for v in VARIANTS:
