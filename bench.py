@@ -72,6 +72,10 @@ def parse():
     ap.add_argument('--plain', action='store_true',
                     help='only the timed throughput region (no single_batch / config3 / per-kernel pass / '
                          'cpu baseline): the command the rocprofv3 traces in profiles/ are taken from')
+    ap.add_argument('--lstm-mode', default=None, choices=(None, 'throughput', 'throughput_bf16x3'),
+                    help="recurrent-step mode of the timed passes; 'throughput_bf16x3' = the opt-in "
+                         "split-operand bf16 mode (NOT the headline: `dtype` then reads 'bf16x3 (fp32-"
+                         "equivalent)'; the default line reports it under the `bf16x3` key)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     return ap.parse_args()
@@ -526,7 +530,7 @@ def main():
     # HIP stream + forked context, shared weights), two buckets of KCAP client batches each, alternated
     # so a pass does not find its feature maps in the caches the previous pass left
     pipe = PassPipeline(d, asm, w, streams=S, kcap=KCAP, device=local_rank,
-                        host_assemble=args.host_assemble)
+                        host_assemble=args.host_assemble, mode=args.lstm_mode if KCAP > 1 else None)
     eng, sb = pipe.engine, pipe.bucket(0, 0)
     dev = eng.device
     pipe.fill_all(lambda i: synth.make_inputs(d, seed=dp.batch_seed(i)),
@@ -555,7 +559,8 @@ def main():
             'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': 'f32' if pipe.mode != 'throughput_bf16x3' else 'bf16x3 (fp32-equivalent split operands)',
+            'data': 'synthetic',
             'timed_region_s': round(elapsed, 5), 'repeats': repeats,
             'blocks_s': [round(x, 5) for x in blocks],
             'timed_window_s': round(sum(blocks), 4),
@@ -671,6 +676,39 @@ def main():
                 'layouts': {'valid_fraction': float(val3.float().mean().item()),
                             'find_type_nodes_per_question': round(f3 / toks3.shape[1], 2),
                             'pooling_nodes_per_question': round(p3 / toks3.shape[1], 2)}}
+
+    # ---- opt-in split-operand bf16 mode (N2NMN_MODE_THROUGHPUT_BF16X3): the same passes with the
+    # recurrent contraction on bf16 MFMAs over three-way split operands, its logits against the oracle.
+    # Reported beside the headline, never as the headline (include/n2nmn.h).
+    if rank == 0 and not args.plain and use_gt and K > 1 and pipe.mode == 'throughput':
+        try:
+            for wk in pipe.workers:
+                wk['engine'].set_mode('throughput_bf16x3')
+            reps3 = max(3, min(15, args.steps // S))
+            t3x = wall(lambda: run_steps(S), reps3)
+            from oracle import n2nmn_oracle_batched as OB
+            torch.set_num_threads(min(16, torch.get_num_threads()))
+            wt = OB.to_torch(w, torch.float64)
+            worst3 = 0.0
+            for si, wk in enumerate(pipe.workers):
+                j = (wk['next'] - 1) % 2
+                b = wk['buckets'][j]
+                i = (si * 2 + j) * KCAP
+                hb = synth.make_inputs(d, seed=dp.batch_seed(i))
+                gt = synth.template_layout_batch(d, offset=i)
+                ref = OB.forward(wt, names, hb, d.T_decoder, d.num_choices, True, gt)
+                worst3 = max(worst3, float(np.abs(b.result(0)[0].cpu().numpy() - ref['scores']).max()))
+            out['bf16x3'] = {
+                'mode': "N2NMN_MODE_THROUGHPUT_BF16X3 (opt-in; `python bench.py --lstm-mode throughput_bf16x3`): "
+                        'recurrent contraction on v_mfma_f32_16x16x32_bf16 over three-way split operands, '
+                        '6 cross products, fp32 accumulate (csrc/kernels_lstm_tile3.hip)',
+                'value': round(S * K * d.N / t3x, 1), 'unit': 'questions/sec',
+                'ms_per_step': round(1e3 * t3x / S, 4), 'vs_f32_value': round(S * K * d.N / t3x / qps, 4),
+                'max_abs_logit_err': worst3, 'bar': 1e-4, 'ok': bool(worst3 <= 1e-4),
+                'against': 'oracle/n2nmn_oracle_batched.py (fp64), slot 0 of the bucket each worker ran last'}
+        finally:
+            for wk in pipe.workers:
+                wk['engine'].set_mode(pipe.mode)
 
     # ---- per-kernel roofline: HIP events around every launch, separate pass right after
     if rank == 0 and not args.no_profile:
