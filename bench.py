@@ -300,7 +300,7 @@ def bench_vqa(args, dp, local_rank):
     dp.close()
 
 
-def vqa_numbers(args, dp, local_rank, steps, warmup, profile=True, batches_per_pass=1):
+def vqa_numbers(args, dp, local_rank, steps, warmup, profile=True, batches_per_pass=1, lstm_mode=None):
     """BASELINE.json configs[4]: models_vqa forward (exp_vqa/eval_vqa2.py:103-137) -- seq2seq with
     the 17742-word vocabulary and lstm_dim 1000, coordinate map, the 4-module network at map_dim
     1024 on 14x14x2048 features, question prior net -- batch 128 per GPU, ground-truth layouts from
@@ -316,7 +316,7 @@ def vqa_numbers(args, dp, local_rank, steps, warmup, profile=True, batches_per_p
     eng = vqa.VQAEngine(d, device=local_rank)
     w = synth.make_weights_from_shapes(vqa.vqa_variable_shapes(d), seed=0)
     eng.load_weights(w)
-    mode = os.environ.get('N2NMN_VQA_MODE') or ('throughput' if batches_per_pass > 1 else None)
+    mode = lstm_mode or os.environ.get('N2NMN_VQA_MODE') or ('throughput' if batches_per_pass > 1 else None)
     if mode:
         eng.engine.set_mode(mode)
     dev = eng.engine.device
@@ -698,12 +698,14 @@ def main():
                 gt = synth.template_layout_batch(d, offset=i)
                 ref = OB.forward(wt, names, hb, d.T_decoder, d.num_choices, True, gt)
                 worst3 = max(worst3, float(np.abs(b.result(0)[0].cpu().numpy() - ref['scores']).max()))
+            t3g = wall(lambda: run_steps(S, gt=False), max(3, reps3 // 2))
             out['bf16x3'] = {
                 'mode': "N2NMN_MODE_THROUGHPUT_BF16X3 (opt-in; `python bench.py --lstm-mode throughput_bf16x3`): "
                         'recurrent contraction on v_mfma_f32_16x16x32_bf16 over three-way split operands, '
                         '6 cross products, fp32 accumulate (csrc/kernels_lstm_tile3.hip)',
                 'value': round(S * K * d.N / t3x, 1), 'unit': 'questions/sec',
                 'ms_per_step': round(1e3 * t3x / S, 4), 'vs_f32_value': round(S * K * d.N / t3x / qps, 4),
+                'config3_super_bucket_value': round(S * K * d.N / t3g, 1),
                 'max_abs_logit_err': worst3, 'bar': 1e-4, 'ok': bool(worst3 <= 1e-4),
                 'against': 'oracle/n2nmn_oracle_batched.py (fp64), slot 0 of the bucket each worker ran last'}
         finally:
@@ -875,6 +877,13 @@ def main():
         out['config5']['passes'] = {k: c5p[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'config')}
         del c5p
         torch.cuda.empty_cache()
+        if 'bf16x3' in out:          # the opt-in split-operand mode on the models_vqa passes (lstm_dim 1024)
+            c5b = vqa_numbers(args, dp, local_rank, 4, 2, profile=False, batches_per_pass=8,
+                              lstm_mode='throughput_bf16x3')
+            out['bf16x3']['config5_passes'] = {'value': c5b['value'], 'ms_per_step': c5b['ms_per_step'],
+                                               'vs_f32_value': round(c5b['value'] / out['config5']['passes']['value'], 4)}
+            del c5b
+            torch.cuda.empty_cache()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         def gpu_scores(b, gt):

@@ -389,9 +389,9 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmAr
   // the length-sorted encoder has too few row blocks for the 64 x 64 tiles (a launch of <= 256
   // workgroups leaves the K = 2L tiles alone on their CUs), the K-split tiles scale with the rows
   std::vector<int> act_host;
-  // (not in the split-operand mode: a row's final state must reach the decoder with its bf16 planes,
-  // which only lstm_tile3_kernel writes)
-  if (io->seq_length_host && c->mode == N2NMN_MODE_THROUGHPUT) {
+  // (the split-operand mode too: the K-split kernels write the bf16 planes of the states they produce
+  // when a job carries plane pointers, so a row's final state reaches the decoder with its planes)
+  if (io->seq_length_host && (c->mode == N2NMN_MODE_THROUGHPUT || c->mode == N2NMN_MODE_THROUGHPUT_BF16X3)) {
     std::vector<int> cnt(T + 2, 0);
     for (int n = 0; n < N; ++n) cnt[std::min(std::max(io->seq_length_host[n], 0), T)] += 1;
     act_host.assign(T, 0);
@@ -454,8 +454,12 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmAr
       if (!act_host.empty() && act_host[std::min(k, T - 1)] <= tile_min_rows()) wide = 1;
       if (b3) {
         attach_planes(c, j0); attach_planes(c, j1);
-        N2_REQUIRE(lstm_tile3_supported(jobs, 2, L), N2NMN_EINVAL, "encoder_forward: bf16x3 mode: unsupported job");
-        launch_lstm_tile3(jobs, 2, N, L, s);
+        if (wide == 1) {              // tail of the length-sorted encoder: exact-fp32 K-split tiles (+ planes)
+          launch_lstm_step(jobs, 2, N, L, 64, s, 1);
+        } else {
+          N2_REQUIRE(lstm_tile3_supported(jobs, 2, L), N2NMN_EINVAL, "encoder_forward: bf16x3 mode: unsupported job");
+          launch_lstm_tile3(jobs, 2, N, L, s);
+        }
       } else {
         launch_lstm_step(jobs, 2, N, L, 64, s, wide);
       }

@@ -110,4 +110,41 @@ __device__ __forceinline__ float fast_sigmoid(float x) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
 }
 
+
+// ---- split-operand bf16 (kernels_lstm_tile3.hip): an fp32 value as the exact sum of three bf16 ----------
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+// x = hi + mid + lo, each a bf16 (round to nearest even; the two subtractions are exact)
+__device__ __forceinline__ void split3(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+  const f32x2v v = {x0, x1};
+  const bf16x2 h = __builtin_convertvector(v, bf16x2);
+  hi = __builtin_bit_cast(uint32_t, h);
+  const f32x2v r1 = {x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u)};
+  const bf16x2 m = __builtin_convertvector(r1, bf16x2);
+  mid = __builtin_bit_cast(uint32_t, m);
+  const f32x2v r2 = {r1[0] - __uint_as_float(mid << 16), r1[1] - __uint_as_float(mid & 0xffff0000u)};
+  const bf16x2 l = __builtin_convertvector(r2, bf16x2);
+  lo = __builtin_bit_cast(uint32_t, l);
+}
+
+// the three planes of four consecutive hidden units (a float4 of the state) -> 8 bytes per plane
+__device__ __forceinline__ void store_planes(uint16_t* planes, size_t plane_elems, size_t off, float4 h) {
+  uint32_t a[3], b[3];
+  split3(h.x, h.y, a[0], a[1], a[2]);
+  split3(h.z, h.w, b[0], b[1], b[2]);
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+    *reinterpret_cast<uint2*>(planes + (size_t)p * plane_elems + off) = make_uint2(a[p], b[p]);
+}
+
+
+// one element (hidden unit `unit` of state row `row`) of the planes [3][L/8][R][8] of a state buffer
+__device__ __forceinline__ void store_plane1(uint16_t* planes, int L, int R, int unit, int row, float x) {
+  uint32_t hi, mid, lo;
+  split3(x, 0.f, hi, mid, lo);
+  const size_t plane_elems = (size_t)(L / 8) * R * 8;
+  const size_t off = ((size_t)(unit >> 3) * R + row) * 8 + (unit & 7);
+  planes[off] = (uint16_t)hi; planes[plane_elems + off] = (uint16_t)mid; planes[2 * plane_elems + off] = (uint16_t)lo;
+}
+
 }  // namespace n2nmn

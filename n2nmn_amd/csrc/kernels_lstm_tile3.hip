@@ -44,8 +44,6 @@ namespace n2nmn {
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2v __attribute__((ext_vector_type(2)));
 
 constexpr int T3_UNITS = 16, T3_BK = 32;
 constexpr int T3_W_IMAGE = 3 * 4 * 1024;            // planes x gates x 1 KiB
@@ -79,29 +77,6 @@ __device__ __forceinline__ void glds16b(const void* base, uint32_t voff, uint32_
 template <int N>
 __device__ __forceinline__ void wait_vm3() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// x = hi + mid + lo, each a bf16 (round to nearest even; the two subtractions are exact)
-__device__ __forceinline__ void split3(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
-  const f32x2v v = {x0, x1};
-  const bf16x2 h = __builtin_convertvector(v, bf16x2);
-  hi = __builtin_bit_cast(uint32_t, h);
-  const f32x2v r1 = {x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u)};
-  const bf16x2 m = __builtin_convertvector(r1, bf16x2);
-  mid = __builtin_bit_cast(uint32_t, m);
-  const f32x2v r2 = {r1[0] - __uint_as_float(mid << 16), r1[1] - __uint_as_float(mid & 0xffff0000u)};
-  const bf16x2 l = __builtin_convertvector(r2, bf16x2);
-  lo = __builtin_bit_cast(uint32_t, l);
-}
-
-// the three planes of four consecutive hidden units (a float4 of the state) -> 8 bytes per plane
-__device__ __forceinline__ void store_planes(uint16_t* planes, size_t plane_elems, size_t off, float4 h) {
-  uint32_t a[3], b[3];
-  split3(h.x, h.y, a[0], a[1], a[2]);
-  split3(h.z, h.w, b[0], b[1], b[2]);
-#pragma unroll
-  for (int p = 0; p < 3; ++p)
-    *reinterpret_cast<uint2*>(planes + (size_t)p * plane_elems + off) = make_uint2(a[p], b[p]);
 }
 
 // VAR (n2nmn_debug_lstm_bench only): 1 = no DMA, 2 = no MFMA, 3 = DMA + barriers only
@@ -639,6 +614,274 @@ void launch_tile3w(const LstmJobs3& js, int njobs, int N, int L, hipStream_t s) 
                      njobs);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// lstm_tile3r_kernel: 128 rows x 64 gate columns per workgroup, h read as fp32 and split IN REGISTERS.
+// What the variants above measured: with h travelling as three bf16 planes (6 bytes per element) the
+// L2 -> LDS stream and the waves' LDS reads are as long as the matrix work, and the two do not overlap
+// well enough.  A wave that owns 16 rows and ALL FOUR gates of the tile's 16 units is the only consumer
+// of its rows' h inside the workgroup, so it can split them itself without doing anybody else's work:
+//   * h comes in as the fp32 state it already is ([L/4][R][4]: 4 bytes per element, 16 KiB per stage of
+//     128 rows instead of 24) -- a stage is 28 KiB instead of 36, the state planes in HBM are not needed;
+//   * per stage a lane splits its 8 values (44 VALU instructions, under 24 MFMAs = 384 matrix clocks);
+//   * 2 + 12 ds_read_b128 per 24 MFMAs (0.58 KiB per MFMA instead of 0.75), no gate exchange;
+//   * 8 waves, ring of 5 stages (140 KiB): three stages of look-ahead instead of two.
+// ---------------------------------------------------------------------------------------------------
+constexpr int TR_ROWS = 128, TR_WAVES = 8, TR_THREADS = TR_WAVES * 64;
+constexpr int TR_H_IMAGE = 8 * TR_ROWS * 16;                  // [k4 = 8][row][4 floats] = 16 KiB
+constexpr int TR_STAGE = TR_H_IMAGE + T3_W_IMAGE;              // 28 KiB
+constexpr int TR_NPIECE = TR_STAGE / 1024, TR_PBASE = TR_NPIECE / TR_WAVES, TR_PEXTRA = TR_NPIECE % TR_WAVES;
+
+// 8 fp32 values (two float4 = k 8 kq .. 8 kq + 7 of one row) -> the three bf16 planes of an MFMA operand
+__device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& hi, uint4& mid, uint4& lo) {
+  split3(a.x, a.y, hi.x, mid.x, lo.x);
+  split3(a.z, a.w, hi.y, mid.y, lo.y);
+  split3(b.x, b.y, hi.z, mid.z, lo.z);
+  split3(b.z, b.w, hi.w, mid.w, lo.w);
+}
+
+template <int NS, int VAR = 0>
+__global__ __launch_bounds__(TR_THREADS, 1) void lstm_tile3r_kernel(LstmJobs3 jobs, int N, int L, int nrb,
+                                                                    int njobs) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  constexpr int PMAX = TR_PBASE + (TR_PEXTRA ? 1 : 0);
+  const int ntile = L / T3_UNITS;
+  int nab[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const LstmJob& jq = jobs.j[j];
+    int n = 0;
+    if (j < njobs && jq.active) {
+      const int na = jq.n_active ? *jq.n_active : N;
+      n = (min(max(na, 0), N) + TR_ROWS - 1) / TR_ROWS;
+    }
+    nab[j] = n;
+  }
+  int rem = blockIdx.x / ntile;
+  const int ct = blockIdx.x - rem * ntile;
+  int jsel = -1, rb = 0;
+  bool zero_fill = false;
+#pragma unroll
+  for (int j = 1; j >= 0; --j)
+    if (jsel < 0) { if (rem < nab[j]) { jsel = j; rb = rem; } else rem -= nab[j]; }
+#pragma unroll
+  for (int j = 1; j >= 0; --j)
+    if (jsel < 0 && j < njobs && jobs.j[j].active && jobs.j[j].out_seq) {
+      if (rem < nrb - nab[j]) { jsel = j; rb = nab[j] + rem; zero_fill = true; } else rem -= nrb - nab[j];
+    }
+  if (jsel < 0) return;
+  const LstmJob& jb = jobs.j[jsel];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // = 16-row group of the wave
+  const int row0 = rb * TR_ROWS;
+  const int R = jb.hp_R;
+  const int nact = jb.n_active ? *jb.n_active : N;
+  const int lr = lane & 15, q = lane >> 4;
+  const int gr = row0 + 16 * w + lr;
+  const bool eact = gr < N;
+  const int grc = eact ? gr : N - 1;
+  const int t4 = 4 * ct + q;
+  if (zero_fill) {
+    if (eact) {
+      const int zr = jb.perm ? jb.perm[grc] : grc;
+      *reinterpret_cast<float4*>(jb.out_seq + (size_t)zr * L + 4 * t4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return;
+  }
+
+  // ---- operand stream: 28 pieces of 1 KiB per stage; wave w moves pieces w, w + 8, ... ---------------
+  //   pc < 16: k4 slab pc / 2 of the h stage, rows 64 (pc % 2) ..;  pc >= 16: weight plane, gate
+  const int K = jb.K, nst = K / T3_BK;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  uint32_t pbase[PMAX], pstep[PMAX], plds[PMAX];
+  bool pish[PMAX];
+  const uint32_t wtile = (uint32_t)ct * (uint32_t)nst * (uint32_t)T3_W_IMAGE;
+#pragma unroll
+  for (int i = 0; i < PMAX; ++i) {
+    const int pc = min(w + TR_WAVES * i, TR_NPIECE - 1);
+    pish[i] = pc < 16;
+    if (pc < 16) {
+      const int s4 = pc >> 1, rh = pc & 1;
+      const int arow = min(row0 + 64 * rh + lane, N - 1);
+      pbase[i] = ((uint32_t)s4 * (uint32_t)R + (uint32_t)arow) * 16u;
+      pstep[i] = 8u * (uint32_t)R * 16u;                        // eight k4 slabs per stage
+      plds[i] = ((uint32_t)s4 * TR_ROWS + 64u * (uint32_t)rh) * 16u;
+    } else {
+      const int idx = pc - 16;
+      pbase[i] = wtile + (uint32_t)idx * 1024u + (uint32_t)lane * 16u;
+      pstep[i] = (uint32_t)T3_W_IMAGE;
+      plds[i] = (uint32_t)TR_H_IMAGE + (uint32_t)idx * 1024u;
+    }
+  }
+  const float* const A0p = jb.A0;
+  const float* const A1p = jb.A1;
+  const uint16_t* const Wp = jb.Wb3;
+  const int sL = L / T3_BK;
+  auto issue = [&](auto np_tag, int s) {
+    constexpr int NP = decltype(np_tag)::value;
+    const uint32_t slot = lds0 + (uint32_t)(s % NS) * TR_STAGE;
+    const bool lo = s < sL;
+    const uint32_t sh = (uint32_t)(lo ? s : s - sL);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      if (pish[i]) glds16b(lo ? A0p : A1p, pbase[i] + sh * pstep[i], slot + plds[i]);
+      else glds16b(Wp, pbase[i] + (uint32_t)s * pstep[i], slot + plds[i]);
+    }
+  };
+  const bool extra = w < TR_PEXTRA;
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) {
+    if (VAR != 1) {
+      if (extra) issue(std::integral_constant<int, PMAX>{}, s);
+      else issue(std::integral_constant<int, TR_PBASE>{}, s);
+    }
+  }
+
+  // ---- epilogue operands: fetched under the DMA prologue -------------------------------------------
+  int orow = grc;
+  if (jb.perm) orow = jb.perm[grc];
+  const float* ar;
+  if (jb.xtab) {
+    const int xi = jb.xidx ? jb.xidx[orow] : jb.xidx_const;
+    ar = jb.xtab + (size_t)xi * 4 * L + 16 * t4;
+  } else {
+    ar = jb.bias + 16 * t4;
+  }
+  float4 add[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) add[g] = *reinterpret_cast<const float4*>(ar + 4 * g);
+  const size_t sidx = ((size_t)t4 * R + grc) * 4;
+  const float4 c_old = *reinterpret_cast<const float4*>(jb.c_in + sidx);
+  const bool masked = jb.seq_len && jb.t >= jb.seq_len[orow];      // dynamic_rnn past the length (A.2)
+  float4 h_prev = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (masked) h_prev = *reinterpret_cast<const float4*>(jb.h_old + sidx);
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool wact = row0 + 16 * w < nact;
+
+  // raw operands of a stage: the lane's 8 fp32 h values + 4 gates x 3 weight planes (56 VGPRs)
+  struct Raw { float4 ha, hb; uint4 wq[4][3]; };
+  const char* const S0 = smem;
+  auto fetch = [&](Raw& o, int slot) {
+    const char* st = S0 + (size_t)slot * TR_STAGE;
+    const float4* hs = reinterpret_cast<const float4*>(st) + 16 * w + lr;
+    o.ha = hs[(2 * q) * TR_ROWS];
+    o.hb = hs[(2 * q + 1) * TR_ROWS];
+    const uint4* ws = reinterpret_cast<const uint4*>(st + TR_H_IMAGE) + lane;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) o.wq[g][p] = ws[(p * 4 + g) * 64];
+  };
+  auto mma = [&](const Raw& o, const uint4 (&hq)[3], int t) {
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // weight plane, h plane
+    if (VAR == 2) {
+      asm volatile("" ::"v"(o.wq[0][0].x), "v"(o.wq[3][2].w), "v"(o.wq[1][1].y), "v"(o.wq[2][1].z),
+                   "v"(hq[0].x), "v"(hq[2].w));
+      return;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, o.wq[g][PA[t]]),
+                                                       __builtin_bit_cast(bf16x8, hq[PB[t]]), acc[g], 0, 0, 0);
+  };
+#define NR_PIN() __builtin_amdgcn_sched_barrier(0)
+  auto stages = [&](auto work_tag, auto np_tag) {
+    constexpr bool WORK = decltype(work_tag)::value;
+    constexpr int NP = decltype(np_tag)::value;
+    auto sync_stage = [&](int next) {
+      const int behind = nst - 1 - next;             // stages after `next`
+      if (behind >= NS - 3) wait_vm3<NP * (NS - 3)>();
+      else if (NS > 4 && behind == NS - 4) wait_vm3<NP * (NS > 4 ? NS - 4 : 0)>();
+      else if (NS > 5 && behind == NS - 5) wait_vm3<NP * (NS > 5 ? NS - 5 : 0)>();
+      else wait_vm3<0>();
+      __builtin_amdgcn_s_barrier();
+    };
+    // `hq` = the split planes of stage `cur`'s h (made while the PREVIOUS stage's MFMAs ran)
+    auto step = [&](const Raw& cur, const uint4 (&hq)[3], Raw& nxt, uint4 (&hqn)[3], int next, bool more) {
+      const int refill = next + NS - 2;
+      const bool dma = more && refill < nst && VAR != 1;
+      if (more) sync_stage(next);
+      if (WORK) { mma(cur, hq, 0); NR_PIN(); }
+      if (dma) issue(np_tag, refill);
+      if (WORK) {
+        NR_PIN();
+        if (more) fetch(nxt, next % NS);
+        NR_PIN();
+        mma(cur, hq, 1); mma(cur, hq, 2);
+        if (more) split8(nxt.ha, nxt.hb, hqn[0], hqn[1], hqn[2]);      // VALU under the MFMAs
+        mma(cur, hq, 3); mma(cur, hq, 4); mma(cur, hq, 5);
+      }
+    };
+    wait_vm3<NP * (NS - 2)>();                     // stage 0 (the oldest of the NS - 1 in flight)
+    __builtin_amdgcn_s_barrier();
+    Raw P{}, Q{};
+    uint4 hp[3] = {}, hqq[3] = {};
+    if (WORK) { fetch(P, 0); split8(P.ha, P.hb, hp[0], hp[1], hp[2]); }
+    int i = 0;
+    for (; i + 2 < nst; i += 2) {                  // nst is even: two stages per trip, P / Q static
+      step(P, hp, Q, hqq, i + 1, true);
+      step(Q, hqq, P, hp, i + 2, true);
+    }
+    step(P, hp, Q, hqq, i + 1, true);              // the last two stages
+    step(Q, hqq, P, hp, 0, false);
+  };
+#undef NR_PIN
+  const bool work = wact && VAR != 3;
+  if (extra) {
+    if (work) stages(std::true_type{}, std::integral_constant<int, PMAX>{});
+    else stages(std::false_type{}, std::integral_constant<int, PMAX>{});
+  } else {
+    if (work) stages(std::true_type{}, std::integral_constant<int, TR_PBASE>{});
+    else stages(std::false_type{}, std::integral_constant<int, TR_PBASE>{});
+  }
+  if (!eact) return;
+
+  // ---- cell update: lane = (row, 4 units), acc[g][r] = z of gate g, unit 4q + r ------------------
+  float cn[4], hn[4];
+  const float co[4] = {c_old.x, c_old.y, c_old.z, c_old.w};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float zi = acc[0][r] + (r == 0 ? add[0].x : r == 1 ? add[0].y : r == 2 ? add[0].z : add[0].w);
+    const float zj = acc[1][r] + (r == 0 ? add[1].x : r == 1 ? add[1].y : r == 2 ? add[1].z : add[1].w);
+    const float zf = acc[2][r] + (r == 0 ? add[2].x : r == 1 ? add[2].y : r == 2 ? add[2].z : add[2].w);
+    const float zo = acc[3][r] + (r == 0 ? add[3].x : r == 1 ? add[3].y : r == 2 ? add[3].z : add[3].w);
+    const float gi = fast_sigmoid(zi), gj = fast_tanh(zj), gf = fast_sigmoid(zf + 1.0f), go = fast_sigmoid(zo);
+    cn[r] = co[r] * gf + gi * gj;
+    hn[r] = fast_tanh(cn[r]) * go;
+  }
+  float4 c4 = make_float4(cn[0], cn[1], cn[2], cn[3]);
+  float4 h4 = make_float4(hn[0], hn[1], hn[2], hn[3]);
+  float4 o4 = h4;
+  if (masked) { c4 = c_old; h4 = h_prev; o4 = make_float4(0.f, 0.f, 0.f, 0.f); }
+  *reinterpret_cast<float4*>(jb.c_out + sidx) = c4;
+  *reinterpret_cast<float4*>(jb.h_new + sidx) = h4;
+  const size_t oidx = (size_t)orow * L + 4 * t4;
+  if (jb.out_seq) *reinterpret_cast<float4*>(jb.out_seq + oidx) = o4;
+  if (jb.h_drop) {
+    const float4 dm = *reinterpret_cast<const float4*>(jb.drop + oidx);
+    *reinterpret_cast<float4*>(jb.h_drop + sidx) = make_float4(h4.x * dm.x, h4.y * dm.y, h4.z * dm.z, h4.w * dm.w);
+  }
+  if (jb.fin_c && jb.seq_len && jb.t == jb.seq_len[orow] - 1) {   // the row's last valid step
+    const size_t fidx = ((size_t)t4 * R + orow) * 4;
+    *reinterpret_cast<float4*>(jb.fin_c + fidx) = c4;
+    *reinterpret_cast<float4*>(jb.fin_h + fidx) = h4;
+  }
+}
+
+template <int NS, int VAR = 0>
+void launch_tile3r(const LstmJobs3& js, int njobs, int N, int L, hipStream_t s) {
+  static std::atomic<uint64_t> attr{0};
+  const int lds = NS * TR_STAGE;
+  ensure_dynamic_lds(reinterpret_cast<const void*>(&lstm_tile3r_kernel<NS, VAR>), lds, attr);
+  const int nrb = (N + TR_ROWS - 1) / TR_ROWS;
+  const int grid = njobs * nrb * (L / T3_UNITS);
+  hipLaunchKernelGGL((lstm_tile3r_kernel<NS, VAR>), dim3(grid), dim3(TR_THREADS), lds, s, js, N, L, nrb,
+                     njobs);
+}
+
 // weights -> three bf16 planes in fragment order (see the header): one thread per 16-byte fragment
 __global__ __launch_bounds__(256) void pack_tiles64_b3_kernel(const float* __restrict__ W, int ld, int row0,
                                                               int K, int L, uint16_t* __restrict__ dst) {
@@ -716,12 +959,21 @@ void launch_lstm_tile3(const LstmJob* jobs, int njobs, int N, int L, hipStream_t
   // default: 128-row workgroups (16 waves, 4 stages of 36 KiB) when the launch has at least two
   // 128-row blocks per job; variants (n2nmn_debug_lstm_bench): 4xx = 64-row workgroups
   static const int dflt = [] { const char* e = getenv("N2NMN_TILE3_VARIANT"); return e ? atoi(e) : 0; }();
+  // shipped: 128-row x 64-column workgroups of 16 waves (4 x 36 KiB) from 256 rows on, 64-row workgroups
+  // below.  Measured and kept as variants only (profiles/r04_notes.md section 2): 128 x 128 (903) and the
+  // register-split form (705) -- both run 8 waves per CU and lose to two-waves-per-SIMD bubbles what
+  // their smaller streams gain.
   if (variant == 0) variant = dflt ? dflt : (N >= 256 ? 804 : 403);
   switch (variant) {
     case 404: launch_tile3<4, 4>(js, njobs, N, L, s); break;
     case 413: launch_tile3<3, 4, 1>(js, njobs, N, L, s); break;     // debug variants: no DMA
     case 423: launch_tile3<3, 4, 2>(js, njobs, N, L, s); break;     // no MFMA
     case 433: launch_tile3<3, 4, 3>(js, njobs, N, L, s); break;     // DMA + barriers only
+    case 705: launch_tile3r<5>(js, njobs, N, L, s); break;          // 128 x 64, fp32 h split in registers
+    case 704: launch_tile3r<4>(js, njobs, N, L, s); break;
+    case 715: launch_tile3r<5, 1>(js, njobs, N, L, s); break;
+    case 725: launch_tile3r<5, 2>(js, njobs, N, L, s); break;
+    case 735: launch_tile3r<5, 3>(js, njobs, N, L, s); break;
     case 903: launch_tile3w<3>(js, njobs, N, L, s); break;          // 128 x 128 workgroups
     case 913: launch_tile3w<3, 1>(js, njobs, N, L, s); break;
     case 923: launch_tile3w<3, 2>(js, njobs, N, L, s); break;

@@ -247,6 +247,9 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_kernel(LstmJobs jobs, 
     const size_t sidx = jb.hp_R > 0 ? ((size_t)tile * jb.hp_R + gr) * 4 + ul : idx;
     jb.c_out[sidx] = c_new;
     jb.h_new[sidx] = h_new;
+    // split-operand bf16 mode: the tail steps of a pass run here (exact fp32) but later steps / the decoder
+    // read the bf16 planes of what they write
+    if (jb.h_new_b && jb.hp_R > 0) store_plane1(jb.h_new_b, L, jb.hp_R, 4 * tile + ul, gr, h_new);
     const size_t oidx = (size_t)orow * L + 4 * tile + ul;
     if (jb.save_gates) {          // training: keep what the cell backward needs (masked rows keep
       jb.save_gates[oidx] = make_float4(gi, gj, gf, go);   // finite values; their dz is zero)
@@ -257,11 +260,13 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_kernel(LstmJobs jobs, 
     if (jb.h_drop) {              // dropped copy of the OUTPUT for the layer above
       const float hd = h_new * jb.drop[oidx];
       jb.h_drop[jb.hp_R > 0 ? ((size_t)tile * jb.hp_R + gr) * 4 + ul : idx] = hd;
+      if (jb.h_drop_b && jb.hp_R > 0) store_plane1(jb.h_drop_b, L, jb.hp_R, 4 * tile + ul, gr, hd);
       if (jb.save_hd) jb.save_hd[oidx] = hd;
     }
     if (jb.fin_c && jb.seq_len && jb.t == jb.seq_len[orow] - 1) {   // the row's last valid step
       jb.fin_c[((size_t)tile * jb.hp_R + orow) * 4 + ul] = c_new;
       jb.fin_h[((size_t)tile * jb.hp_R + orow) * 4 + ul] = h_new;
+      if (jb.fin_h_b) store_plane1(jb.fin_h_b, L, jb.hp_R, 4 * tile + ul, orow, h_new);
     }
   }
 }
@@ -414,6 +419,9 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_wide_kernel(LstmJobs j
     const size_t sidx = jb.hp_R > 0 ? ((size_t)tile * jb.hp_R + gr) * 4 + ul : idx;
     jb.c_out[sidx] = c_new;
     jb.h_new[sidx] = h_new;
+    // split-operand bf16 mode: the tail steps of a pass run here (exact fp32) but later steps / the decoder
+    // read the bf16 planes of what they write
+    if (jb.h_new_b && jb.hp_R > 0) store_plane1(jb.h_new_b, L, jb.hp_R, 4 * tile + ul, gr, h_new);
     const size_t oidx = (size_t)orow * L + 4 * tile + ul;
     if (jb.save_gates) {
       jb.save_gates[oidx] = make_float4(gi, gj, gf, go);
@@ -424,11 +432,13 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_wide_kernel(LstmJobs j
     if (jb.h_drop) {              // dropped copy of the OUTPUT for the layer above
       const float hd = h_new * jb.drop[oidx];
       jb.h_drop[jb.hp_R > 0 ? ((size_t)tile * jb.hp_R + gr) * 4 + ul : idx] = hd;
+      if (jb.h_drop_b && jb.hp_R > 0) store_plane1(jb.h_drop_b, L, jb.hp_R, 4 * tile + ul, gr, hd);
       if (jb.save_hd) jb.save_hd[oidx] = hd;
     }
     if (jb.fin_c && jb.seq_len && jb.t == jb.seq_len[orow] - 1) {
       jb.fin_c[((size_t)tile * jb.hp_R + orow) * 4 + ul] = c_new;
       jb.fin_h[((size_t)tile * jb.hp_R + orow) * 4 + ul] = h_new;
+      if (jb.fin_h_b) store_plane1(jb.fin_h_b, L, jb.hp_R, 4 * tile + ul, orow, h_new);
     }
   }
 }

@@ -236,6 +236,10 @@ __device__ __forceinline__ void walk_transform(int tid, const ModuleWeights& w, 
   for (int sI = 0; sI < NS; ++sI)
 #pragma unroll
     for (int pt = 0; pt < PTMAX; ++pt) xf[sI][pt] = xin[poff[pt] + koff[sI]] * kmask[sI] + kone[sI];
+  // (debug timeline, second row of the node = row t + 16: [0] B fragments built, [1] / [2] first / last
+  // channel tile of wave 0 done, [3] folds done)
+  long long* tl2 = tl ? tl + 16 * 4 : nullptr;
+  if (tl2 && threadIdx.x == 0) tl2[0] = clock64();
   for (int ct = cw; ct < Mt; ct += WW) {
     const float4 tmv = *reinterpret_cast<const float4*>(tm + 16 * ct + 4 * kg);
     const float tm4[4] = {tmv.x, tmv.y, tmv.z, tmv.w};
@@ -275,6 +279,7 @@ __device__ __forceinline__ void walk_transform(int tid, const ModuleWeights& w, 
       for (int sI = 0; sI < NS; ++sI) af[sI] = afn[sI];
       wev = wen;
     }
+    if (tl2 && threadIdx.x == 0) tl2[ct == cw ? 1 : 2] = clock64();
   }
   // a pixel's channels sit in the four 16-lane rows of the wave: fold them, then across waves.  Two
   // half / row exchanges in registers (v_permlane32_swap, v_permlane16_swap) fold BOTH sums at once --
@@ -290,6 +295,7 @@ __device__ __forceinline__ void walk_transform(int tid, const ModuleWeights& w, 
     v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
     if ((kg & 1) == 0 && pt < Pt) red[((size_t)wid * Pq + 16 * pt + ci) * 2 + (kg >> 1)] = v;
   }
+  if (tl2 && threadIdx.x == 0) tl2[3] = clock64();
   __syncthreads();
   if (tl && threadIdx.x == 0) tl[2] = clock64();       // debug timeline: MFMA phase done
   const float be = w.be[2][0];

@@ -22,7 +22,9 @@ names = {24: 'fp32 LDS tile, 4 stages', 34: 'fp32 tile, no DMA', 44: 'fp32 tile,
          1803: 'bf16x3 128 rows, 3 stages', 1804: 'bf16x3 128 rows, 4 stages', 1814: 'bf16x3 128 rows, no DMA',
          1824: 'bf16x3 128 rows, no MFMA', 1834: 'bf16x3 128 rows, DMA only',
          1903: 'bf16x3 128x128, 3 stages', 1913: 'bf16x3 128x128, no DMA', 1923: 'bf16x3 128x128, no MFMA',
-         1933: 'bf16x3 128x128, DMA only'}
+         1933: 'bf16x3 128x128, DMA only',
+         1705: 'bf16x3 128x64 reg-split, 5 st', 1704: 'bf16x3 128x64 reg-split, 4 st',
+         1715: 'reg-split, no DMA', 1725: 'reg-split, no MFMA', 1735: 'reg-split, DMA only'}
 VARIANTS = [int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else \
     [24, 1804, 1903, 1913, 1923, 1933, 24, 1804, 1903]
 GF = {N: 2.0 * N * 4 * 512 * (512 + 1024) / 1e9 for N in (128, 256, 512, 1024)}

@@ -57,6 +57,14 @@ def main():
                 if a and e:
                     rows.append((b - a, c - b, e - c, e - a))
         report('heavy ' + op, rows, labels)
+    rows = []
+    for q in range(Q):
+        for tt in np.nonzero(toks[:, q] == idx['_Transform'])[0]:
+            a, b, c, e = t[q, tt]
+            x0, x1, x2, x3 = t[q, tt + 16]
+            if a and e and x0:
+                rows.append((x0 - b, x1 - x0, x2 - x1, x3 - x2, c - x3))
+    report('Transform matrix phase', rows, ('B frags', 'tile 0', 'tile 1', 'folds', 'barrier'))
     starts = t[:, :, 0][t[:, :, 0] > 0]
     heavy = [(q, tt) for q in range(Q) for tt in range(31) if t[q, tt, 0] and t[q, tt, 3]]
     if heavy:
