@@ -18,81 +18,30 @@ oracle's.
 
 The checkout exists only in the build container and the GPU only on the gpurun box, so the compute
 behind the drop-in's Python face is the CPU oracle here (tests/oracle_engine.py, a test double that
-replaces n2nmn_amd.engine.Engine for this test only); the same loop over the HIP engine runs on the
-GPU in tests/test_gpu_end2end.py::test_reference_shaped_session_loop."""
+replaces n2nmn_amd.engine.Engine for this test only).  What the script ASKED of the drop-in -- constructor
+keywords, every partial_run with its feeds -- is recorded (tests/golden/eval_driver_trace.npz, checked here
+against a fresh recording) and replayed on the same drop-in objects over the HIP engine on the GPU box:
+tests/test_gpu_eval_driver_trace.py."""
 import os
-import runpy
-import shutil
 import sys
-import types
 
 import numpy as np
 import pytest
 
 from oracle import n2nmn_oracle as O
-from n2nmn_amd import synth
-from n2nmn_amd.spec import Dims
 
-REF = '/root/reference'
-SCRIPT = os.path.join(REF, 'exp_clevr', 'eval_clevr.py')
-pytestmark = pytest.mark.skipif(not os.path.exists(SCRIPT), reason='reference checkout not present')
+import eval_driver_common as EC
 
-
-def _module(name, **attrs):
-    m = types.ModuleType(name)
-    m.__dict__.update(attrs)
-    return m
+pytestmark = pytest.mark.skipif(not os.path.exists(EC.SCRIPT), reason='reference checkout not present')
 
 
 def test_eval_clevr_script_runs_unmodified_against_the_drop_in(tmp_path, monkeypatch):
-    sys.dont_write_bytecode = True
-    from n2nmn_amd import data_reader, nmn3_assembler, nmn3_model, runtime
+    from n2nmn_amd import data_reader
     from oracle_engine import OracleEngine
-    d = Dims()
-    # ---- scratch tree shaped like the reference's working directory ------------------------------
-    data = tmp_path / 'exp_clevr' / 'data'
-    (data / 'imdb').mkdir(parents=True)
-    for f in ('vocabulary_clevr.txt', 'vocabulary_layout.txt', 'answers_clevr.txt'):
-        shutil.copy(os.path.join(REF, 'exp_clevr', 'data', f), data / f)      # data files, scratch only
-    words = [l.strip() for l in open(data / 'vocabulary_clevr.txt')]
-    answers = [l.strip() for l in open(data / 'answers_clevr.txt')]
-    assert (len(words), len(answers)) == (d.num_vocab_txt, d.num_choices)
-    rng = np.random.default_rng(5)
-    n_q = 70                                            # one full batch of 64 and a short one of 6
-    feat_dir = tmp_path / 'feat'
-    feat_dir.mkdir()
-    imdb = []
-    for i in range(n_q):
-        fp = str(feat_dir / ('%03d.npy' % i))
-        np.save(fp, np.maximum(rng.standard_normal((1, d.H, d.W, d.D)), 0).astype(np.float32))
-        L = int(rng.integers(3, d.T_encoder + 1))
-        imdb.append(dict(image_path='CLEVR_syn_%06d.png' % i, feature_path=fp,
-                         question_tokens=[words[int(rng.integers(0, len(words)))] for _ in range(L)],
-                         answer=answers[int(rng.integers(0, len(answers)))],
-                         gt_layout_tokens=list(synth.CLEVR_LAYOUT_TEMPLATES[i % 10])))
-    np.save(data / 'imdb' / 'imdb_syn.npy', np.array(imdb, dtype=object), allow_pickle=True)
-    w = synth.make_weights(d, seed=0)
-    snap = tmp_path / 'exp_clevr' / 'tfmodel' / 'exp0'
-    snap.mkdir(parents=True)
-    np.savez(snap / '00050000.npz', **w)
-
-    # ---- the drop-in answers the driver's imports ---------------------------------------------------
-    monkeypatch.setattr(nmn3_model, 'Engine', OracleEngine)
-    monkeypatch.setattr(runtime, '_MODELS', [])
-    for name, mod in {
-        'tensorflow': _module('tensorflow', **runtime.tf.__dict__),
-        'models_clevr': _module('models_clevr'),
-        'models_clevr.nmn3_assembler': _module('models_clevr.nmn3_assembler', Assembler=nmn3_assembler.Assembler),
-        'models_clevr.nmn3_model': _module('models_clevr.nmn3_model', NMN3Model=nmn3_model.NMN3Model),
-        'util': _module('util'), 'util.clevr_train': _module('util.clevr_train'),
-        'util.clevr_train.data_reader': _module('util.clevr_train.data_reader',
-                                                DataReader=data_reader.DataReader),
-    }.items():
-        monkeypatch.setitem(sys.modules, name, mod)
-    monkeypatch.setattr(sys, 'argv', ['eval_clevr.py', '--exp_name', 'exp0', '--snapshot_name', '00050000',
-                                      '--test_split', 'syn'])
-    monkeypatch.chdir(tmp_path)
-    g = runpy.run_path(SCRIPT, run_name='__main__')         # the reference's file, every line of it
+    rec = EC.SessionRecorder(EC.Dims())
+    # the reference's file, every line of it (scratch tree + import map: tests/eval_driver_common.py)
+    g, d, data, words, answers, w = EC.run_reference_script(tmp_path, monkeypatch, OracleEngine, rec)
+    n_q = EC.N_QUESTIONS
 
     # ---- what the script computed ---------------------------------------------------------------------
     model, sess, asm = g['nmn3_model_tst'], g['sess'], g['assembler']
@@ -116,3 +65,10 @@ def test_eval_clevr_script_runs_unmodified_against_the_drop_in(tmp_path, monkeyp
     assert np.array_equal(sess.last['predicted_tokens'], last['dec']['predicted_tokens'])
     result = open(tmp_path / 'exp_clevr' / 'results' / 'exp0' / '00050000.syn.txt').read()
     assert 'answer accuracy' in result and 'layout validity = 1.0' in result
+
+    # ---- the committed recording of this run (replayed over the HIP engine on the GPU box:
+    # tests/test_gpu_eval_driver_trace.py) is still what the reference's script does -------------------
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import make_eval_driver_trace as MT
+    z = np.load(MT.OUT)
+    assert MT.same(MT.pack_trace(rec, written, answers), {k: z[k] for k in z.files}) is None
