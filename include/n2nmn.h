@@ -320,10 +320,20 @@ int n2nmn_walk_set_front_end(n2nmn_ctx *ctx, int mode);
  * deferred pooling; questions with nested _Transform / _FindSameProperty nodes stay with the
  * one-workgroup walker.  mode -1 (default): on; 0: off (the walker serves every question). */
 int n2nmn_walk_set_staged(n2nmn_ctx *ctx, int mode);
-/* single batch: n2nmn_conv_image(FIND | FSP gated by tokens) + n2nmn_walk_layouts(K = 1) */
+/* Phase 2 straight from DEVICE tokens (no token fetch, no host assembly): replaces Assembler.assemble +
+ * td.Compiler.build_feed_dict + the second partial_run (exp_clevr/eval_clevr.py:121-132,
+ * exp_vqa/eval_vqa2.py:103-137).  n2nmn_conv_image(FIND | FSP gated by tokens), then
+ *   - dimensions the layout walker covers (n2nmn_walk_supported): n2nmn_walk_layouts(K = 1);
+ *   - any other (models_vqa): the level path of n2nmn_execute_program with the program assembled and
+ *     level-scheduled ON THE DEVICE (sched_kernel): every level of the capacity T_dec gets its three
+ *     persistent-grid launches, which read their work tables and lengths from HBM; nothing is read back.
+ *     (n2nmn_set_tokens_via_levels(ctx, 1) or N2NMN_TOKENS_VIA_LEVELS=1 forces this form for every
+ *     variant: the scheduler's cross-check against the walker and the host assembler.)
+ * scores [N][num_choices] (INVALID_EXPR rows zero), validity [N] (expr_validity_array) or NULL. */
 int n2nmn_execute_tokens(n2nmn_ctx *ctx, const int32_t *tokens, int T_dec, int N,
                          const float *image_feat, const float *word_vecs, float *scores,
                          int32_t *validity, n2nmn_stream stream);
+int n2nmn_set_tokens_via_levels(n2nmn_ctx *ctx, int on);
 
 /* models_vqa: out[n,h,w,:] = [feat[n,h,w,0:D0], x(w), y(h), 0...]  with x = linspace(-1,1,W)[w],
  * y = linspace(-1,1,H)[h]  (add_spatial_coordinate_map, models_vqa/nmn3_modules.py:11-31).

@@ -105,6 +105,7 @@ SYMBOLS = [
     ('n2nmn_conv_image', _I, [_P, _P, _I, _I, _P, _I, _P]),
     ('n2nmn_walk_layouts', _I, [_P, C.POINTER(WalkBatch), _I, _I, _I, _I, _P]),
     ('n2nmn_execute_tokens', _I, [_P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    ('n2nmn_set_tokens_via_levels', _I, [_P, _I]),
     ('n2nmn_add_coords', _I, [_P, _P, _I, _I, _P, _P]),
     ('n2nmn_question_prior_add', _I, [_P, _I, _P, _P]),
     ('n2nmn_train_enable', _I, [_P]),

@@ -237,6 +237,7 @@ static size_t carve_workspace(n2nmn_ctx* c, char* base) {
   }
   c->dev_nodes = k.take<DevNode>(c->max_nodes);
   c->dev_tab = k.take<int32_t>(c->max_tab);
+  c->dsched = k.take<int32_t>(2 * (1 + 3 * SCHED_MAX_T) + 8);
   c->walk_stats = k.take<unsigned long long>(WALK_STATS);
   c->wtmap = k.take<float>(Td * N * Mp);
   c->watt = k.take<float>(Td * N * HWp);
@@ -941,6 +942,93 @@ int run_program(n2nmn_ctx* c, Program& p, const float* feat, const float* word_v
   return check_launch("execute_program");
 }
 
+
+// The level path with the program assembled and scheduled ON THE DEVICE (sched_kernel): what
+// n2nmn_execute_program does for a host-assembled program, for layouts that exist only as device
+// tokens -- models_vqa (no layout walker for its dimensions) and, as a cross-check of the scheduler,
+// any other variant.  Nothing is read back: every level of the capacity (T_dec) gets its three
+// persistent-grid launches, which find their work tables and lengths in HBM; the Describe /
+// SameProperty fc_eltwise of a large answer vocabulary runs once, as a GEMM over the questions, after
+// the last level.  (models_vqa/nmn3_model.py:55-121, exp_vqa/eval_vqa2.py:103-137.)
+int run_tokens_levels(n2nmn_ctx* c, const int32_t* tokens, int T_dec, int N, const float* feat,
+                      const float* word_vecs, float* scores, int32_t* validity, hipStream_t s) {
+  const n2nmn_dims& d = c->d;
+  N2_REQUIRE(is_committed(c), N2NMN_ENOWEIGHT, "execute_tokens: weights not committed");
+  N2_REQUIRE(root(c)->have_token_ops, N2NMN_EINVAL, "execute_tokens: call n2nmn_set_token_ops first");
+  N2_REQUIRE(N >= 1 && N <= d.N, N2NMN_ECAPACITY, "execute_tokens: N > capacity");
+  N2_REQUIRE(T_dec >= 1 && T_dec <= d.T_decoder && T_dec <= SCHED_MAX_T, N2NMN_ECAPACITY,
+             "execute_tokens: T_dec > capacity");
+  train_infer_wait(root(c), s);
+  const int HW = d.H * d.W, C = d.num_choices, levels = T_dec;
+  N2_HIP(hipMemsetAsync(scores, 0, sizeof(float) * (size_t)N * C, s));   // INVALID_EXPR rows stay zero
+  SchedArgs sa{};
+  sa.tokens = tokens; sa.token_op = root(c)->token_op; sa.T = T_dec; sa.N = N; sa.V = d.num_vocab_nmn;
+  sa.levels = levels; sa.nodes = c->dev_nodes; sa.tab = c->dev_tab; sa.tab_cap = c->max_tab;
+  sa.dsched = c->dsched; sa.validity = validity;
+  sa.ev_rows = c->big_heads ? c->ev_rows : nullptr; sa.ev_stride = c->max_pool;
+  sa.overflow = c->dsched + 2 * (1 + 3 * SCHED_MAX_T);
+  {
+    ProfScope ps(c, F_WALK_TMAP, 0.0, 0.0, s);
+    launch_sched(sa, s);
+  }
+  ModuleWeights w = module_weights(c);
+  ModuleBuffers b{};
+  b.nodes = c->dev_nodes; b.tab = c->dev_tab; b.arena = c->arena; b.tmap = c->tmap;
+  b.pfc = c->pfc; b.mfind = c->mfind; b.mfsp = c->mfsp; b.feat = feat; b.word_vecs = word_vecs;
+  b.scores = scores; b.N_full = N; b.H = d.H; b.W = d.W; b.D = d.D; b.M = d.map_dim;
+  b.pooled = nullptr;
+  b.vqa = d.variant == N2NMN_VARIANT_VQA;
+  b.ev_out = c->big_heads ? c->ev_out : nullptr; b.ev_rows = c->ev_rows; b.ev_stride = c->max_pool;
+  b.Mp = c->Mp; b.wl_cap = d.map_dim * C <= 10240 ? d.map_dim * C : 0; b.E = d.embed_dim_txt; b.C = C;
+  b.HWp = c->HWp; b.ksize = d.kernel_size;
+  b.dsched = c->dsched; b.ev_by_q = 1;
+  const double dE = d.embed_dim_txt, dM = d.map_dim, dD = d.D, dHW = HW, dC = C, dMp = c->Mp;
+  // grids: enough workgroups to fill the chip several times over, never more than the work can be
+  const int g_text = std::min((N * T_dec + TM_GROUP - 1) / TM_GROUP + 5, 1024);
+  const int g_att = std::min(N * T_dec * FIND_PARTS, 4096);
+  const int g_pool = std::min(N * ((T_dec + 1) / 2) * POOL_PARTS, 2048);
+  const int g_head = std::min(N, 1024);
+  // (profile lines of this path count what a question of the reference's layout mix does: two text
+  // maps, 1.6 Find-type epilogues, 1.1 pooling jobs -- the work is not known on the host)
+  {
+    ProfScope ps(c, F_TEXTMAP, 2.0 * 2.6 * N * dE * dM, 4.0 * (0.33 * N * dE * dM + 2.6 * N * (dE + dMp)), s);
+    launch_textmap(w, b, 0, g_text, s, 0);
+  }
+  if (c->big_heads) N2_HIP(hipMemsetAsync(c->ev_out, 0, sizeof(float) * (size_t)N * c->Mp, s));
+  for (int l = 0; l < levels; ++l) {
+    {
+      ProfScope ps(c, F_ATT_OPS, l == 0 ? 1.6 * N * 5.0 * dHW * dM : 0.0,
+                   l == 0 ? 1.6 * N * 4.0 * (dHW * dMp + 2 * dMp + dHW) : 0.0, s);
+      launch_att_ops(w, b, 0, l == 0 ? g_att : std::min(g_att, 2048), s, 1 + 3 * l);
+    }
+    {
+      ProfScope ps(c, F_POOL, l == 0 ? 1.1 * N * (2.0 * dHW * dD + 2.0 * dD * dM) : 0.0,
+                   l == 0 ? 4.0 * dD * dM + 1.1 * N * 4.0 * (dHW * dD + dHW + POOL_PARTS * dMp) : 0.0, s);
+      launch_pool(w, b, 0, g_pool, s, 2 + 3 * l);
+    }
+    {
+      ProfScope ps(c, F_HEADS, l == 0 ? N * (2.0 * dM * dC + 8.0 * dM) : 0.0,
+                   l == 0 ? 4.0 * (N * (2.0 * POOL_PARTS * dMp + dMp + dC) + dM * dC) : 0.0, s);
+      launch_heads(w, b, 0, g_head, s, 3 + 3 * l);
+    }
+  }
+  if (c->big_heads) {     // fc_eltwise over the questions: Describe rows, then SameProperty rows
+    const n2nmn_ctx* r = root(c);
+    for (int which = 0; which < 2; ++which) {
+      if (which == 1 && !r->wans_sp_p) continue;
+      GemmArgs g{};
+      g.A = c->ev_out; g.lda = c->Mp; g.M = N; g.K = d.map_dim; g.group_size = 1;
+      g.Bp = which == 0 ? r->wans_de_p : r->wans_sp_p; g.Np = round_up(C, 64);
+      g.Kp = round_up(d.map_dim, 32);
+      g.bias = c->vars[which == 0 ? V_DE_E_B : V_SP_E_B].mirror; g.N = C; g.C = scores;
+      g.ldc = C; g.n_store = C; g.c_row_idx = c->ev_rows + which * c->max_pool;
+      ProfScope ps(c, F_HEADS, 2.0 * N * dM * dC, 4.0 * (N * (dMp + dC) + dM * dC), s);
+      launch_gemm_pk(g, s);
+    }
+  }
+  return check_launch("execute_tokens (device-scheduled levels)");
+}
+
 static int finish_create(n2nmn_ctx* c, n2nmn_ctx* parent) {
   hipError_t e = hipSetDevice(c->device);
   if (e != hipSuccess) { set_last_error(std::string("hipSetDevice: ") + hipGetErrorString(e)); return N2NMN_EHIP; }
@@ -1027,7 +1115,7 @@ int n2nmn_ctx_create(const n2nmn_dims* dims, int device, n2nmn_ctx** out) {
   c->max_nodes = d.N * std::max(d.T_decoder, 4);
   c->max_text = c->max_nodes;
   c->max_pool = c->max_nodes;
-  c->max_tab = c->max_nodes * 16 + 4096;
+  c->max_tab = c->max_nodes * 28 + 4096;      // A: 16 + B: 8 + C: 1 + text-map groups: 10/8 ints per node at most
   c->big_heads = (size_t)d.map_dim * d.num_choices > 65536;
   c->big_vocab = d.num_vocab_txt > 4096;
   int rc = finish_create(c, nullptr);
@@ -1642,10 +1730,20 @@ int n2nmn_execute_tokens(n2nmn_ctx* c, const int32_t* tokens, int T_dec, int N,
   int rc = n2nmn_conv_image(c, image_feat, N, N2NMN_CONV_FIND | N2NMN_CONV_FSP, tokens, T_dec,
                             stream);
   if (rc != N2NMN_OK) return rc;
+  // dimensions outside the walker's tiling (models_vqa): the level path, scheduled on the device
+  static const bool force_levels = [] { const char* e = getenv("N2NMN_TOKENS_VIA_LEVELS"); return e && atoi(e) != 0; }();
+  if (!n2nmn_walk_supported(c) || force_levels || c->tokens_via_levels)
+    return run_tokens_levels(c, tokens, T_dec, N, image_feat, word_vecs, scores, validity, S(stream));
   n2nmn_walk_batch b{};
   b.ctx = c; b.tokens = tokens; b.image_feat = image_feat; b.word_vecs = word_vecs;
   b.scores = scores; b.validity = validity;
   return n2nmn_walk_layouts(c, &b, 1, T_dec, 0, N, stream);
+}
+
+int n2nmn_set_tokens_via_levels(n2nmn_ctx* c, int on) {
+  N2_REQUIRE(c, N2NMN_EINVAL, "set_tokens_via_levels: null context");
+  c->tokens_via_levels = on != 0;
+  return N2NMN_OK;
 }
 
 int n2nmn_add_coords(n2nmn_ctx* c, const float* feat, int N, int D0, float* out,

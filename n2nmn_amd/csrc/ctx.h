@@ -229,6 +229,8 @@ struct n2nmn_ctx {
   int32_t* ev_rows = nullptr;
   DevNode* dev_nodes = nullptr;
   int32_t* dev_tab = nullptr;
+  bool tokens_via_levels = false;   // n2nmn_set_tokens_via_levels
+  int32_t* dsched = nullptr;   // device-scheduled level path: (offset, count) per launch slot, then the overflow flag
   int max_tab = 0;
 
   n2nmn_program* scratch_prog = nullptr;   // used by n2nmn_module_forward

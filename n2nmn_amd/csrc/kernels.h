@@ -261,6 +261,9 @@ struct ModuleBuffers {
   float* ev_out;          // [count][Mp] or nullptr (fused fc)
   int32_t* ev_rows;       // [2][max_pool]: result row of entry i for Describe / SameProperty, or -1
   int ev_stride;          // max_pool
+  // device-scheduled launches (sched_kernel): (offset, count) per launch slot, or nullptr
+  const int32_t* dsched;
+  int ev_by_q;            // ev_out row = the question (one fc_eltwise GEMM after the last level)
 };
 
 // ---- layout walker (kernels_walk.hip): one workgroup runs one question's whole module network
@@ -363,14 +366,38 @@ int walk_pool_supported(int H, int W, int D);
 // out[n,h,w,:] = [feat[n,h,w,:D0], linspace(-1,1,W)[w], linspace(-1,1,H)[h], 0 ...]
 void launch_add_coords(const float* feat, int N, int H, int W, int D0, int D, float* out,
                        hipStream_t s);
+// dl < 0: host-scheduled launch, `count` work items at `tab_off` (one workgroup each).  dl >= 0:
+// device-scheduled, `count` is the size of a persistent grid and the items are
+// b.tab[b.dsched[2 dl] ...), b.dsched[2 dl + 1] of them.
 void launch_textmap(const ModuleWeights& w, const ModuleBuffers& b, int tab_off, int count,
-                    hipStream_t s);
+                    hipStream_t s, int dl = -1);
 void launch_att_ops(const ModuleWeights& w, const ModuleBuffers& b, int tab_off, int count,
-                    hipStream_t s);
+                    hipStream_t s, int dl = -1);
 void launch_pool(const ModuleWeights& w, const ModuleBuffers& b, int tab_off, int count,
-                 hipStream_t s);
+                 hipStream_t s, int dl = -1);
 void launch_heads(const ModuleWeights& w, const ModuleBuffers& b, int tab_off, int count,
-                  hipStream_t s);
+                  hipStream_t s, int dl = -1);
+
+// Layout assembler + level scheduler ON THE DEVICE (the host's assemble_tokens + schedule of
+// schedule.cpp; nmn3_assembler.py:153-222): tokens [T][N] -> nodes (node id = n * T + t = its text-map
+// row, pooling slot and attention-map row; conv_image row = n), the work tables of every stage of
+// every level and their (offset, count) pairs.  Launch slots: 0 = text maps, 1 + 3 L + {0, 1, 2} =
+// stage A / B / C of level L < levels.
+struct SchedArgs {
+  const int32_t* tokens;     // [T][N]
+  const int32_t* token_op;   // [V] n2nmn_op of a token, < 0 = <eos>
+  int T, N, V, levels;
+  DevNode* nodes;            // [N * T]
+  int32_t* tab;              // work tables
+  int tab_cap;
+  int32_t* dsched;           // [(1 + 3 levels)][2]
+  int32_t* validity;         // [N] or nullptr
+  int32_t* ev_rows;          // [2][ev_stride]: answer row of question n for Describe / SameProperty roots (or -1)
+  int ev_stride;
+  int32_t* overflow;         // set to 1 when the tables did not fit (nothing is launched wrongly: counts are 0)
+};
+constexpr int SCHED_MAX_T = 32;
+void launch_sched(const SchedArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // training step (exp_clevr/train_clevr_gt_layout.py:104-130): kernels_train.hip

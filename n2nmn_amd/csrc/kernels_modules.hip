@@ -105,10 +105,9 @@ __device__ void fc_lds(const float* x, int F, const float* __restrict__ Wm,
 // A workgroup handles up to TM_GROUP nodes that share a weight set, so the [E, M] weight stream
 // is read once per group.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MT) void textmap_kernel(ModuleWeights w, ModuleBuffers b,
-                                                     int tab_off) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int* tab = b.tab + tab_off + blockIdx.x * (2 + TM_GROUP);
+__device__ void textmap_item(const ModuleWeights& w, const ModuleBuffers& b, int tab_off, int item,
+                             float* smem) {
+  const int* tab = b.tab + tab_off + item * (2 + TM_GROUP);
   const int ws = tab[0], cnt = tab[1];
   const int E = b.E, Mp = b.Mp;
   float* wv = smem;                       // [TM_GROUP][E]
@@ -171,6 +170,22 @@ __global__ __launch_bounds__(MT) void textmap_kernel(ModuleWeights w, ModuleBuff
       }
     }
   }
+}
+
+// Every module kernel runs its work items in a loop: a host-scheduled launch (schedule.cpp) has one
+// workgroup per item; a device-scheduled one (sched_kernel below: the tables and their lengths exist
+// only in HBM) is a persistent grid that reads (offset, count) of launch slot `dl` from b.dsched.
+#define N2_ITEM_LOOP(BODY)                                                        \
+  extern __shared__ __attribute__((aligned(16))) float smem[];                   \
+  if (dl >= 0) { tab_off = b.dsched[2 * dl]; count = b.dsched[2 * dl + 1]; }     \
+  for (int item = blockIdx.x; item < count; item += gridDim.x) {                 \
+    BODY(w, b, tab_off, item, smem);                                             \
+    __syncthreads();                                                             \
+  }
+
+__global__ __launch_bounds__(MT) void textmap_kernel(ModuleWeights w, ModuleBuffers b, int tab_off,
+                                                     int count, int dl) {
+  N2_ITEM_LOOP(textmap_item)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -379,10 +394,9 @@ __device__ void light_answer(const ModuleWeights& w, const ModuleBuffers& b, con
          light_wl_cap(HW, C));
 }
 
-__global__ __launch_bounds__(MT) void att_ops_kernel(ModuleWeights w, ModuleBuffers b,
-                                                     int tab_off) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int* e = b.tab + tab_off + blockIdx.x * 4;
+__device__ void att_ops_item(const ModuleWeights& w, const ModuleBuffers& b, int tab_off, int item,
+                             float* smem) {
+  const int* e = b.tab + tab_off + item * 4;
   const int node_id = e[0], part = e[1], nparts = e[2];
   const DevNode nd = b.nodes[node_id];
   const int HW = b.H * b.W;
@@ -414,6 +428,11 @@ __global__ __launch_bounds__(MT) void att_ops_kernel(ModuleWeights w, ModuleBuff
   }
 }
 
+__global__ __launch_bounds__(MT) void att_ops_kernel(ModuleWeights w, ModuleBuffers b, int tab_off,
+                                                     int count, int dl) {
+  N2_ITEM_LOOP(att_ops_item)
+}
+
 // ---------------------------------------------------------------------------------------------
 // pool: a = softmax_HW(att logits);  f = sum_hw a[hw] * feat[n, hw, :]  (the HBM-bound read of
 // the [H*W, D] feature map), then this part's slice of fc_att:  pfc[part, c] = f[c0:c0+Dp] .
@@ -422,9 +441,9 @@ __global__ __launch_bounds__(MT) void att_ops_kernel(ModuleWeights w, ModuleBuff
 // channel column and strides over rows (8 rows in flight per workgroup -> ~19 independent 16-B
 // loads per thread).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MT) void pool_kernel(ModuleWeights w, ModuleBuffers b, int tab_off) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int* e = b.tab + tab_off + blockIdx.x * 2;
+__device__ void pool_item(const ModuleWeights& w, const ModuleBuffers& b, int tab_off, int item,
+                          float* smem) {
+  const int* e = b.tab + tab_off + item * 2;
   const int node_id = e[0], part = e[1];
   const DevNode nd = b.nodes[node_id];
   const int HW = b.H * b.W, D = b.D, Mp = b.Mp;
@@ -539,14 +558,19 @@ __global__ __launch_bounds__(MT) void pool_kernel(ModuleWeights w, ModuleBuffers
   }
 }
 
+__global__ __launch_bounds__(MT) void pool_kernel(ModuleWeights w, ModuleBuffers b, int tab_off, int count,
+                                                  int dl) {
+  N2_ITEM_LOOP(pool_item)
+}
+
 // ---------------------------------------------------------------------------------------------
 // heads: Describe  scores = l2norm(tmap * a) . W_e + b          (:479-493)
 //        SameProperty  scores = l2norm(a0 * tmap * a1) . W_e + b (:424-450)
 // a = b_att + sum of the POOL_PARTS partial fc_att rows of stage B.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MT) void heads_kernel(ModuleWeights w, ModuleBuffers b, int tab_off) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int node_id = b.tab[tab_off + blockIdx.x];
+__device__ void heads_item(const ModuleWeights& w, const ModuleBuffers& b, int tab_off, int item,
+                           float* smem) {
+  const int node_id = b.tab[tab_off + item];
   const DevNode nd = b.nodes[node_id];
   const int M = b.M, Mp = b.Mp, C = b.C;
   float* ev = smem;                 // [Mp]
@@ -575,10 +599,13 @@ __global__ __launch_bounds__(MT) void heads_kernel(ModuleWeights w, ModuleBuffer
   const float ss = block_reduce<0>(lss, scratch);
   const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
   if (b.ev_out) {          // large answer vocabulary: fc_eltwise runs as a GEMM over the launch
-    for (int c = threadIdx.x; c < Mp; c += MT) b.ev_out[(size_t)blockIdx.x * Mp + c] = ev[c] * inv;
-    if (threadIdx.x == 0) {
-      b.ev_rows[blockIdx.x] = same ? -1 : nd.out_row;
-      b.ev_rows[b.ev_stride + blockIdx.x] = same ? nd.out_row : -1;
+    // (device-scheduled: ONE GEMM over the questions after the last level, row = question; the row
+    // lists were written by sched_kernel)
+    const int er = b.ev_by_q ? nd.out_row : item;
+    for (int c = threadIdx.x; c < Mp; c += MT) b.ev_out[(size_t)er * Mp + c] = ev[c] * inv;
+    if (threadIdx.x == 0 && !b.ev_by_q) {
+      b.ev_rows[item] = same ? -1 : nd.out_row;
+      b.ev_rows[b.ev_stride + item] = same ? nd.out_row : -1;
     }
     return;
   }
@@ -587,6 +614,11 @@ __global__ __launch_bounds__(MT) void heads_kernel(ModuleWeights w, ModuleBuffer
   const int wi = same ? 5 : 6;
   fc_lds(ev, M, w.Wans[wi], w.bans[wi], C, b.scores + (size_t)nd.out_row * C, partial, wl,
          b.wl_cap);
+}
+
+__global__ __launch_bounds__(MT) void heads_kernel(ModuleWeights w, ModuleBuffers b, int tab_off, int count,
+                                                   int dl) {
+  N2_ITEM_LOOP(heads_item)
 }
 
 // models_vqa/nmn3_modules.py:11-31: tf.linspace(-1., 1., n)[i] = -1 + i * (2 / (n - 1))
@@ -605,6 +637,204 @@ __global__ void add_coords_kernel(const float* __restrict__ feat, int N, int H, 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// sched_kernel: the layout assembler and the level scheduler on the device (SchedArgs).  ONE
+// workgroup; thread i decodes questions i, i + 1024, ...  Three passes with the counters in LDS:
+// count the work items of every (stage, level) and text-map weight set, prefix them into table
+// offsets (thread 0), place the items with LDS cursors.  The order of the items inside a table is
+// whatever the atomics give; no result depends on it (every item writes its own rows).
+// ---------------------------------------------------------------------------------------------
+constexpr int SCHED_THREADS = 1024;
+
+__device__ __forceinline__ int dev_arity(int op) {        // nmn3_assembler.py:9-24 (schedule.cpp op_arity)
+  switch (op) {
+    case N2NMN_OP_SCENE: case N2NMN_OP_FIND: return 0;
+    case N2NMN_OP_FILTER: case N2NMN_OP_FIND_SAME_PROPERTY: case N2NMN_OP_TRANSFORM:
+    case N2NMN_OP_EXIST: case N2NMN_OP_COUNT: case N2NMN_OP_DESCRIBE: return 1;
+    case N2NMN_OP_AND: case N2NMN_OP_OR: case N2NMN_OP_EQUAL_NUM: case N2NMN_OP_MORE_NUM:
+    case N2NMN_OP_LESS_NUM: case N2NMN_OP_SAME_PROPERTY: return 2;
+    default: return -1;
+  }
+}
+__device__ __forceinline__ bool dev_is_answer(int op) {   // nmn3_assembler.py:26-41
+  return op == N2NMN_OP_EXIST || op == N2NMN_OP_COUNT || op == N2NMN_OP_EQUAL_NUM ||
+         op == N2NMN_OP_MORE_NUM || op == N2NMN_OP_LESS_NUM || op == N2NMN_OP_SAME_PROPERTY ||
+         op == N2NMN_OP_DESCRIBE;
+}
+__device__ __forceinline__ bool dev_is_pool(int op) {
+  return op == N2NMN_OP_FIND_SAME_PROPERTY || op == N2NMN_OP_SAME_PROPERTY || op == N2NMN_OP_DESCRIBE;
+}
+__device__ __forceinline__ int dev_text_set(int op) {     // schedule.cpp text_weight_set
+  switch (op) {
+    case N2NMN_OP_FIND: case N2NMN_OP_FILTER: return 0;
+    case N2NMN_OP_FIND_SAME_PROPERTY: return 1;
+    case N2NMN_OP_TRANSFORM: return 2;
+    case N2NMN_OP_SAME_PROPERTY: return 3;
+    case N2NMN_OP_DESCRIBE: return 4;
+    default: return -1;
+  }
+}
+
+struct SchedLayout {          // one question's decoded layout (thread-private)
+  int nn;                     // nodes are the token positions [0, nn) when valid
+  bool valid;
+  int8_t op[SCHED_MAX_T], in0[SCHED_MAX_T], in1[SCHED_MAX_T], level[SCHED_MAX_T];
+};
+
+// nmn3_assembler.py:153-222 / schedule.cpp assemble_tokens + the level rule of schedule()
+__device__ void sched_decode(const SchedArgs& a, int n, SchedLayout& q) {
+  q.nn = 0; q.valid = false;
+  bool has_eos = false;
+  for (int t = 0; t < a.T; ++t) {
+    const int tok = a.tokens[(size_t)t * a.N + n];
+    if (tok < 0 || tok >= a.V || a.token_op[tok] < 0) has_eos = true;    // (out of range: treated as <eos>)
+  }
+  if (!has_eos) return;                                    // :172-173
+  int8_t stack[SCHED_MAX_T], outl[SCHED_MAX_T];
+  int sp = 0, nn = 0;
+  for (int t = 0; t < a.T; ++t) {
+    const int tok = a.tokens[(size_t)t * a.N + n];
+    const int op = (tok < 0 || tok >= a.V) ? -1 : a.token_op[tok];
+    if (op < 0) break;                                     // <eos>
+    const int k = dev_arity(op);
+    if (k < 0 || sp < k) return;                           // :189-191
+    int in0 = -1, in1 = -1, in_max = -1;
+    for (int j = k - 1; j >= 0; --j) {                     // :194-199 input_{k-1} = stack top
+      const int top = stack[--sp];
+      if (dev_is_answer(q.op[top])) return;
+      (j == 0 ? in0 : in1) = top;
+      in_max = max(in_max, (int)outl[top]);
+    }
+    int lvl;
+    if (k == 0) { lvl = 0; outl[t] = 0; }
+    else if (dev_is_pool(op)) { lvl = max(in_max, 0); outl[t] = op == N2NMN_OP_FIND_SAME_PROPERTY ? lvl + 1 : lvl; }
+    else { lvl = in_max + 1; outl[t] = lvl; }
+    q.op[t] = (int8_t)op; q.in0[t] = (int8_t)in0; q.in1[t] = (int8_t)in1; q.level[t] = (int8_t)lvl;
+    stack[sp++] = (int8_t)t;
+    nn = t + 1;
+  }
+  if (sp != 1 || !dev_is_answer(q.op[stack[0]])) return;   // :205-211
+  q.nn = nn; q.valid = true;
+}
+
+__global__ __launch_bounds__(SCHED_THREADS) void sched_kernel(SchedArgs a) {
+  __shared__ int cnt[3][SCHED_MAX_T + 2], off[3][SCHED_MAX_T + 2], cur[3][SCHED_MAX_T + 2];
+  __shared__ int tcnt[5], tbase[5], tcur[5], ngroups, fits;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 3 * (SCHED_MAX_T + 2); i += SCHED_THREADS) { (&cnt[0][0])[i] = 0; (&cur[0][0])[i] = 0; }
+  if (tid < 5) { tcnt[tid] = 0; tcur[tid] = 0; }
+  __syncthreads();
+  // ---- pass 1: nodes, validity, counts --------------------------------------------------------------
+  SchedLayout q;
+  for (int n = tid; n < a.N; n += SCHED_THREADS) {
+    sched_decode(a, n, q);
+    if (a.validity) a.validity[n] = q.valid ? 1 : 0;
+    int root_op = -1;
+    for (int t = 0; t < a.T; ++t) {
+      DevNode d;
+      d.op = -1; d.t = t; d.n = n; d.in0 = d.in1 = -1; d.out_row = -1;
+      d.tslot = d.pslot = d.mslot = -1; d.level = -1;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) d.pad[i] = 0;
+      if (q.valid && t < q.nn) {
+        const int op = q.op[t], lvl = q.level[t], id0 = n * a.T;
+        d.op = op; d.level = lvl;
+        d.in0 = q.in0[t] >= 0 ? id0 + q.in0[t] : -1;
+        d.in1 = q.in1[t] >= 0 ? id0 + q.in1[t] : -1;
+        d.out_row = t == q.nn - 1 ? n : -1;               // the last node is the root (stack size 1)
+        if (t == q.nn - 1) root_op = op;
+        const int ws = dev_text_set(op);
+        if (ws >= 0) { d.tslot = id0 + t; atomicAdd(&tcnt[ws], 1); }
+        if (dev_is_pool(op)) d.pslot = id0 + t;
+        if (op == N2NMN_OP_FIND || op == N2NMN_OP_FILTER || op == N2NMN_OP_FIND_SAME_PROPERTY) d.mslot = n;
+        // stage A items
+        if (op == N2NMN_OP_FIND_SAME_PROPERTY) atomicAdd(&cnt[0][lvl + 1], FIND_PARTS);
+        else if (!dev_is_pool(op))
+          atomicAdd(&cnt[0][lvl], (op == N2NMN_OP_FIND || op == N2NMN_OP_FILTER) ? FIND_PARTS
+                                  : op == N2NMN_OP_TRANSFORM ? TRANSFORM_PARTS : 1);
+        if (dev_is_pool(op)) atomicAdd(&cnt[1][lvl], POOL_PARTS);
+        if (op == N2NMN_OP_DESCRIBE || op == N2NMN_OP_SAME_PROPERTY) atomicAdd(&cnt[2][lvl], 1);
+      }
+      a.nodes[(size_t)n * a.T + t] = d;
+    }
+    if (a.ev_rows) {
+      a.ev_rows[n] = root_op == N2NMN_OP_DESCRIBE ? n : -1;
+      a.ev_rows[a.ev_stride + n] = root_op == N2NMN_OP_SAME_PROPERTY ? n : -1;
+    }
+  }
+  __syncthreads();
+  // ---- offsets ------------------------------------------------------------------------------------------
+  if (tid == 0) {
+    int g = 0;
+    for (int ws = 0; ws < 5; ++ws) { tbase[ws] = g; g += (tcnt[ws] + TM_GROUP - 1) / TM_GROUP; }
+    ngroups = g;
+    int o = g * (2 + TM_GROUP);
+    bool ok = true;
+    for (int l = 0; l <= SCHED_MAX_T; ++l) {
+      off[0][l] = o; o += 4 * cnt[0][l];
+      off[1][l] = o; o += 2 * cnt[1][l];
+      off[2][l] = o; o += cnt[2][l];
+      if (l >= a.levels && (cnt[0][l] | cnt[1][l] | cnt[2][l])) ok = false;   // deeper than the launches
+    }
+    if (o > a.tab_cap) ok = false;
+    fits = ok;
+    if (!ok && a.overflow) *a.overflow = 1;
+    a.dsched[0] = 0; a.dsched[1] = ok ? g : 0;
+    for (int l = 0; l < a.levels; ++l)
+      for (int st = 0; st < 3; ++st) {
+        a.dsched[2 * (1 + 3 * l + st)] = off[st][l];
+        a.dsched[2 * (1 + 3 * l + st) + 1] = ok ? cnt[st][l] : 0;
+      }
+  }
+  __syncthreads();
+  if (!fits) return;
+  // ---- pass 2: place ----------------------------------------------------------------------------------------
+  for (int n = tid; n < a.N; n += SCHED_THREADS) {
+    if (a.N > SCHED_THREADS) sched_decode(a, n, q);       // (one question per thread: still in registers)
+    if (!q.valid) continue;
+    for (int t = 0; t < q.nn; ++t) {
+      const int op = q.op[t], lvl = q.level[t], id = n * a.T + t;
+      const int ws = dev_text_set(op);
+      if (ws >= 0) {
+        const int k = atomicAdd(&tcur[ws], 1);
+        a.tab[(tbase[ws] + k / TM_GROUP) * (2 + TM_GROUP) + 2 + k % TM_GROUP] = id;
+      }
+      int parts = 0, la = lvl;
+      if (op == N2NMN_OP_FIND_SAME_PROPERTY) { parts = FIND_PARTS; la = lvl + 1; }
+      else if (!dev_is_pool(op))
+        parts = (op == N2NMN_OP_FIND || op == N2NMN_OP_FILTER) ? FIND_PARTS
+                : op == N2NMN_OP_TRANSFORM ? TRANSFORM_PARTS : 1;
+      if (parts) {
+        const int k = atomicAdd(&cur[0][la], parts);
+        for (int p = 0; p < parts; ++p) {
+          int* e = a.tab + off[0][la] + 4 * (k + p);
+          e[0] = id; e[1] = p; e[2] = parts; e[3] = 0;
+        }
+      }
+      if (dev_is_pool(op)) {
+        const int k = atomicAdd(&cur[1][lvl], POOL_PARTS);
+        for (int p = 0; p < POOL_PARTS; ++p) {
+          int* e = a.tab + off[1][lvl] + 2 * (k + p);
+          e[0] = id; e[1] = p;
+        }
+      }
+      if (op == N2NMN_OP_DESCRIBE || op == N2NMN_OP_SAME_PROPERTY)
+        a.tab[off[2][lvl] + atomicAdd(&cur[2][lvl], 1)] = id;
+    }
+  }
+  __syncthreads();
+  // text-map group headers: [weight set, nodes in the group], unused node slots = -1
+  for (int g = tid; g < ngroups; g += SCHED_THREADS) {
+    int ws = 0;
+    while (ws < 4 && g >= tbase[ws + 1]) ++ws;
+    const int c = min(TM_GROUP, tcnt[ws] - TM_GROUP * (g - tbase[ws]));
+    int* e = a.tab + g * (2 + TM_GROUP);
+    e[0] = ws; e[1] = c;
+    for (int j = c; j < TM_GROUP; ++j) e[2 + j] = -1;
+  }
+}
+
 }  // namespace
 
 void launch_add_coords(const float* feat, int N, int H, int W, int D0, int D, float* out,
@@ -614,14 +844,18 @@ void launch_add_coords(const float* feat, int N, int H, int W, int D0, int D, fl
   hipLaunchKernelGGL(add_coords_kernel, dim3(blocks), dim3(256), 0, s, feat, N, H, W, D0, D, out);
 }
 
+void launch_sched(const SchedArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(sched_kernel, dim3(1), dim3(SCHED_THREADS), 0, s, a);
+}
+
 void launch_textmap(const ModuleWeights& w, const ModuleBuffers& b, int tab_off, int count,
-                    hipStream_t s) {
+                    hipStream_t s, int dl) {
   const size_t smem = sizeof(float) * ((size_t)TM_GROUP * b.E + 4 * TM_GROUP * 256);
-  hipLaunchKernelGGL(textmap_kernel, dim3(count), dim3(MT), smem, s, w, b, tab_off);
+  hipLaunchKernelGGL(textmap_kernel, dim3(count), dim3(MT), smem, s, w, b, tab_off, count, dl);
 }
 
 void launch_att_ops(const ModuleWeights& w, const ModuleBuffers& b, int tab_off, int count,
-                    hipStream_t s) {
+                    hipStream_t s, int dl) {
   const int HW = b.H * b.W;
   const int pad = b.ksize / 2;
   const int KK = b.ksize * b.ksize;
@@ -635,22 +869,22 @@ void launch_att_ops(const ModuleWeights& w, const ModuleBuffers& b, int tab_off,
   if (smem > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(att_ops_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(att_ops_kernel, dim3(count), dim3(MT), smem, s, w, b, tab_off);
+  hipLaunchKernelGGL(att_ops_kernel, dim3(count), dim3(MT), smem, s, w, b, tab_off, count, dl);
 }
 
 void launch_pool(const ModuleWeights& w, const ModuleBuffers& b, int tab_off, int count,
-                 hipStream_t s) {
+                 hipStream_t s, int dl) {
   const int HW = b.H * b.W, Dp = b.D / POOL_PARTS;
   const int nrow = MT / (Dp / 4);
   const size_t stage = std::max<size_t>((size_t)nrow * 2 * Dp, 1024);
   const size_t smem = sizeof(float) * (2 * (size_t)((HW + 3) & ~3) + 16 + 2 * Dp + stage);
-  hipLaunchKernelGGL(pool_kernel, dim3(count), dim3(MT), smem, s, w, b, tab_off);
+  hipLaunchKernelGGL(pool_kernel, dim3(count), dim3(MT), smem, s, w, b, tab_off, count, dl);
 }
 
 void launch_heads(const ModuleWeights& w, const ModuleBuffers& b, int tab_off, int count,
-                  hipStream_t s) {
+                  hipStream_t s, int dl) {
   const size_t smem = sizeof(float) * ((size_t)b.Mp + 16 + 256 + (size_t)b.wl_cap);
-  hipLaunchKernelGGL(heads_kernel, dim3(count), dim3(MT), smem, s, w, b, tab_off);
+  hipLaunchKernelGGL(heads_kernel, dim3(count), dim3(MT), smem, s, w, b, tab_off, count, dl);
 }
 
 }  // namespace n2nmn

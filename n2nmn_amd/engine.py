@@ -43,6 +43,7 @@ class Engine:
         # default: measured on MI355X the chip-filling recurrent steps slow down by more than the
         # GEMMs take (0.882 ms per batch overlapped vs 0.812 ms in line, profiles/r02_notes.md)
         self.overlap_conv = os.environ.get('N2NMN_OVERLAP_CONV', '0') == '1'
+        self.tokens_via_levels = os.environ.get('N2NMN_TOKENS_VIA_LEVELS', '0') not in ('', '0')
         self._parent = _parent
         if _parent is not None:
             _lib.check(self._lib.n2nmn_ctx_fork(_parent._ctx, C.byref(self._ctx)))
@@ -76,6 +77,11 @@ class Engine:
             mode = 'throughput_bf16x3'
         self.mode = mode
         _lib.check(self._lib.n2nmn_ctx_set_mode(self._ctx, {'latency': 0, 'throughput': 1, 'throughput_ksplit': 2, 'throughput_bf16x3': 3}[mode]))
+
+    def set_tokens_via_levels(self, on: bool):
+        """execute_tokens through the device-scheduled level path even where the layout walker applies."""
+        self.tokens_via_levels = bool(on)
+        _lib.check(self._lib.n2nmn_set_tokens_via_levels(self._ctx, int(bool(on))))
 
     def fork(self) -> 'Engine':
         """A sibling engine sharing this engine's weights with its own workspace, for running
@@ -338,6 +344,13 @@ class Engine:
         else:
             scores = mk('wscores', (N, self.dims.num_choices), torch.float32)
             validity = mk('wvalid', (N,), torch.int32)
+        if not self.walk_supported() or self.tokens_via_levels:
+            # no layout walker for these dimensions (models_vqa): the level path, assembled and scheduled on
+            # the device (n2nmn_execute_tokens); the conv_image GEMMs are part of the call
+            _lib.check(self._lib.n2nmn_execute_tokens(self._ctx, tok.data_ptr(), Td, N, feat.data_ptr(),
+                                                      wv.data_ptr(), scores.data_ptr(), validity.data_ptr(),
+                                                      self.stream()))
+            return scores, validity
         if not conv_done:
             self.conv_image(feat, tok, Td)
         # atts = (atts [T_dec, T_enc, N], input_seq [T_enc, N], seq_length [N]): text maps from the

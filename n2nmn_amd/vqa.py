@@ -201,15 +201,21 @@ class VQAEngine:
         return self._feat_c
 
     def forward(self, batch, use_gt_layout: bool = False, gt_layout=None, forced_tokens=None,
-                use_qpn: bool = True):
-        """phase 1 -> token fetch -> assemble -> phase 2 (+ question prior).  Returns (scores device
-        tensor [N, num_choices], tokens, validity) -- scores = scores_nmn + scores_qpn
-        (models_vqa/nmn3_model.py:106-114); the eval script's `scores[:, 0] = -1e10` is the caller's.
+                use_qpn: bool = True, host_assemble: bool = False, fetch: bool = True):
+        """phase 1 -> phase 2 (+ question prior).  Returns (scores device tensor [N, num_choices], tokens,
+        validity) -- scores = scores_nmn + scores_qpn (models_vqa/nmn3_model.py:106-114); the eval
+        script's `scores[:, 0] = -1e10` is the caller's.
+
+        Layouts the decoder chooses (or a DEVICE gt_layout): phase 2 runs straight from the device
+        tokens -- n2nmn_execute_tokens assembles and level-schedules the program on the device -- so
+        nothing synchronises between the phases; with fetch=False tokens / validity come back as
+        device tensors (no synchronisation at all).  host_assemble=True keeps the reference's flow
+        (token fetch, C++ Assembler, host level scheduler: exp_vqa/eval_vqa2.py:118-131).
 
         With use_gt_layout and a HOST gt_layout (numpy, as the reference's data reader delivers it,
         util/vqa_train/data_reader.py) the predicted tokens ARE the ground-truth layout
         (models_vqa/nmn3_netgen_att.py: teacher forcing), so the program is assembled from the host
-        copy up front and the call has no host synchronisation (no token fetch)."""
+        copy up front and the call has no host synchronisation either."""
         e = self.engine
         known = use_gt_layout and isinstance(gt_layout, np.ndarray) and forced_tokens is None
         if known:
@@ -218,14 +224,21 @@ class VQAEngine:
             gt_dev = e.upload_i32(tokens)
         s2s = e.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], self.dims.T_decoder,
                         use_gt_layout, gt_dev if known else gt_layout, None, forced_tokens)
-        if not known:
-            tokens = s2s['predicted_tokens'].cpu().numpy()
-            packed, validity = self.assembler.assemble_packed(tokens)
         feat_c = self.features_with_coords(batch['image_feat_batch'])
-        scores = e.execute(packed, feat_c, s2s['word_vecs'])
+        if known or host_assemble:
+            if not known:
+                tokens = s2s['predicted_tokens'].cpu().numpy()
+                packed, validity = self.assembler.assemble_packed(tokens)
+            scores = e.execute(packed, feat_c, s2s['word_vecs'])
+        else:
+            scores, validity = e.execute_tokens(s2s['predicted_tokens'], feat_c, s2s['word_vecs'])
+            tokens = s2s['predicted_tokens']
         if use_qpn and self.dims.qpn_hidden > 0:
             _lib.check(e._lib.n2nmn_question_prior_add(e._ctx, scores.shape[0], scores.data_ptr(),
                                                        e.stream()))
+        if not (known or host_assemble) and fetch:
+            tokens = tokens.cpu().numpy()
+            validity = validity.cpu().numpy().astype(bool)
         return scores, tokens, validity
 
 
