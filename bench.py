@@ -295,12 +295,18 @@ def bench_vqa(args, dp, local_rank):
         p = vqa_numbers(args, dp, local_rank, max(3, args.steps // 8), 2, False, batches_per_pass=8)
         if dp.rank == 0:
             out['passes'] = {k: p[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'config')}
+        pd = vqa_numbers(args, dp, local_rank, max(3, args.steps // 8), 2, not args.no_profile, batches_per_pass=8,
+                         device_layouts=True)
+        if dp.rank == 0:
+            out['passes_device_layouts'] = {k: pd[k] for k in ('value', 'ms_per_step', 'steps', 'host_sync', 'kernels')
+                                            if k in pd}
     if dp.rank == 0:
         print(json.dumps(out), flush=True)
     dp.close()
 
 
-def vqa_numbers(args, dp, local_rank, steps, warmup, profile=True, batches_per_pass=1, lstm_mode=None):
+def vqa_numbers(args, dp, local_rank, steps, warmup, profile=True, batches_per_pass=1, lstm_mode=None,
+                device_layouts=False):
     """BASELINE.json configs[4]: models_vqa forward (exp_vqa/eval_vqa2.py:103-137) -- seq2seq with
     the 17742-word vocabulary and lstm_dim 1000, coordinate map, the 4-module network at map_dim
     1024 on 14x14x2048 features, question prior net -- batch 128 per GPU, ground-truth layouts from
@@ -339,9 +345,14 @@ def vqa_numbers(args, dp, local_rank, steps, warmup, profile=True, batches_per_p
             [eng.assembler.module_list2tokens(mix[order[n % 100]], d.T_decoder) for n in range(d.N)],
             np.int32).T))
 
+    gts_dev = [torch.as_tensor(g).to(dev) for g in gts]
+
     def run_steps(first, count):
         for i in range(first, first + count):
-            eng.forward(batches[i % 3], use_gt_layout=True, gt_layout=gts[i % 3])
+            if device_layouts:
+                eng.forward(batches[i % 3], use_gt_layout=True, gt_layout=gts_dev[i % 3], fetch=False)
+            else:
+                eng.forward(batches[i % 3], use_gt_layout=True, gt_layout=gts[i % 3])
 
     run_steps(0, warmup)
     elapsed = dp.timed(lambda: run_steps(warmup, steps),
@@ -356,12 +367,15 @@ def vqa_numbers(args, dp, local_rank, steps, warmup, profile=True, batches_per_p
                'ms_per_step': round(1e3 * elapsed / steps, 4), 'higher_is_better': True,
                'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                'config': {'workload': 'BASELINE.json configs[4]: models_vqa forward, gt layouts (v2 val '
-                                      'histogram), %s, T_enc=26, T_dec=13, single stream, host-assembled '
-                                      'programs (no device walker for these dimensions)' % label,
+                                      'histogram), %s, T_enc=26, T_dec=13, single stream, %s' % (
+                                          label, 'layouts as device tokens: assembled + level-scheduled on the GPU'
+                                          if device_layouts else 'layouts as host arrays: program assembled up front'),
                           'client_batch': client, 'batches_per_pass': batches_per_pass,
                           'rows_per_launch': d.N, 'lstm_step_mode': mode or 'latency',
                           'global_batch': world * d.N,
-                          'parallelism': 'dp%d (question-sharded)' % world}}
+                          'parallelism': 'dp%d (question-sharded)' % world},
+               'host_sync': 'none: tokens never leave the GPU between the phases (n2nmn_execute_tokens)'
+               if device_layouts else 'none: gt_layout_batch is a host array, the program is assembled before phase 1'}
         if profile:
             ksteps = min(steps, 10)
             eng.engine.profile_begin()
@@ -868,7 +882,7 @@ def main():
         if 'kernels' in c4:
             out['config4']['kernels'] = c4['kernels'][:4]
         c5 = vqa_numbers(args, dp, local_rank, 10, 3, profile=True)
-        out['config5'] = {k: c5[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'config')}
+        out['config5'] = {k: c5[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'config', 'host_sync')}
         if 'kernels' in c5:
             out['config5']['kernels'] = c5['kernels'][:4]
         del c5
@@ -876,6 +890,20 @@ def main():
         c5p = vqa_numbers(args, dp, local_rank, 4, 2, profile=False, batches_per_pass=8)
         out['config5']['passes'] = {k: c5p[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'config')}
         del c5p
+        torch.cuda.empty_cache()
+        # the same workload with the layouts as DEVICE tokens (a decoder-chosen layout is one): program
+        # assembly and level scheduling on the GPU, nothing fetched between the phases
+        c5d = vqa_numbers(args, dp, local_rank, 10, 3, profile=True, device_layouts=True)
+        out['config5']['device_layouts'] = {k: c5d[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'host_sync')}
+        if 'kernels' in c5d:
+            out['config5']['device_layouts']['kernels'] = c5d['kernels'][:5]
+        del c5d
+        torch.cuda.empty_cache()
+        c5dp = vqa_numbers(args, dp, local_rank, 4, 2, profile=True, batches_per_pass=8, device_layouts=True)
+        out['config5']['device_layouts']['passes'] = {k: c5dp[k] for k in ('value', 'ms_per_step', 'steps')}
+        if 'kernels' in c5dp:
+            out['config5']['device_layouts']['passes']['kernels'] = c5dp['kernels'][:6]
+        del c5dp
         torch.cuda.empty_cache()
         if 'bf16x3' in out:          # the opt-in split-operand mode on the models_vqa passes (lstm_dim 1024)
             c5b = vqa_numbers(args, dp, local_rank, 4, 2, profile=False, batches_per_pass=8,

@@ -261,7 +261,8 @@ const char* kFamilyNames[F_COUNT] = {
   "att_ops", "pool", "heads",
   "lstm_bwd_step", "gemm_tn(weight grads)", "backward misc (modules/attention/gemm_nt)",
   "optimiser", "walk(layout walker)", "gemm_pkn(encoder_h_transform + q + conv_image)",
-  "walk_find(Find / Filter epilogues over the conv_image maps)", "walk_tmap(text maps from the attention tables)"};
+  "walk_find(Find / Filter epilogues over the conv_image maps)", "walk_tmap(text maps from the attention tables)",
+  "sched(layout assembler + level scheduler on the device)"};
 
 
 hipStream_t S(n2nmn_stream s) { return reinterpret_cast<hipStream_t>(s); }
@@ -968,7 +969,7 @@ int run_tokens_levels(n2nmn_ctx* c, const int32_t* tokens, int T_dec, int N, con
   sa.ev_rows = c->big_heads ? c->ev_rows : nullptr; sa.ev_stride = c->max_pool;
   sa.overflow = c->dsched + 2 * (1 + 3 * SCHED_MAX_T);
   {
-    ProfScope ps(c, F_WALK_TMAP, 0.0, 0.0, s);
+    ProfScope ps(c, F_SCHED, 0.0, 0.0, s);
     launch_sched(sa, s);
   }
   ModuleWeights w = module_weights(c);

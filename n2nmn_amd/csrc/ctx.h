@@ -281,7 +281,7 @@ enum Family {
   F_LSTM_ENC = 0, F_LSTM_DEC0, F_LSTM_DEC1, F_LINEAR_Q, F_DEC_STEP, F_GEMM_EHT, F_WORD_VECS,
   F_TEXTMAP, F_CONV_IMAGE, F_ATT_OPS, F_POOL, F_HEADS,
   F_LSTM_BWD, F_GEMM_TN, F_BWD_MISC, F_OPTIMISER, F_WALK, F_GEMM_MULTI, F_WALK_FIND, F_WALK_TMAP,
-  F_COUNT
+  F_SCHED, F_COUNT
 };
 extern const char* kFamilyNames[F_COUNT];
 

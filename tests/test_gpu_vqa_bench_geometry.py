@@ -2,7 +2,8 @@
 forward (exp_vqa/eval_vqa2.py:27-39,103-137) with N = 128 questions per batch in latency mode
 (`config5`) and as ONE pass of 8 client batches x 128 = 1024 rows in 'throughput' mode
 (`config5.passes`: lstm_tile_kernel at lstm_dim 1024 over 16 row blocks, gemm_dma_kernel on the
-2064 -> 1024 conv_image, device-side row lists) -- teacher-forced and greedy.
+2064 -> 1024 conv_image, device-side row lists) -- teacher-forced (layouts as host arrays and as device tokens) and
+greedy (phase 2 assembled and level-scheduled on the device, no token fetch).
 
 The fp64 oracle is too slow for 1024 rows of 14x14x2050 features, and questions are independent
 (SURVEY.md 8e), so the FULL pass runs on the GPU and a seeded subset of its rows -- first / last row of
@@ -74,7 +75,7 @@ def test_latency_mode_batch_of_128(setup):
     ref = O.forward_vqa(w, sub, d.T_decoder, d.num_choices, np.float64, use_gt_layout=True, gt_layout=gts)
     assert ref['validity'].all()
     assert_close('gt layouts, rows %s' % rows, got[rows], ref['scores'], TOL)
-    # free-running decoder (token fetch + host assembly on this path)
+    # free-running decoder: phase 2 straight from the device tokens (sched_kernel + level launches)
     scores, tokens, validity = eng.forward(batch)
     got = t2n(scores).copy()
     assert validity.all()
@@ -126,6 +127,11 @@ def test_throughput_pass_of_8_client_batches(setup):
         worst = max(worst, assert_close('slot %d of 8 vs the same batch alone' % k,
                                         got[k * CLIENT:(k + 1) * CLIENT], t2n(alone), 2e-5))
     print('worst |slot - alone| over 8 slots: %.2e' % worst)
+    # the same layouts as DEVICE tokens (`config5.device_layouts`): assembled and scheduled on the GPU
+    sd, td, vd = eng_big.forward(cat, use_gt_layout=True, gt_layout=torch.as_tensor(gt_cat).to(dev))
+    assert vd.all() and np.array_equal(td, gt_cat)
+    assert_close('device-assembled vs host-assembled pass', t2n(sd), got, 2e-5)
+    assert_close('device-assembled pass vs oracle, rows %s' % rows, t2n(sd)[rows], ref['scores'], TOL)
 
     # ---- greedy decoder chooses the layouts
     scores, tokens, validity = eng_big.forward(cat)
