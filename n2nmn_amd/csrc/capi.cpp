@@ -984,11 +984,12 @@ int run_tokens_levels(n2nmn_ctx* c, const int32_t* tokens, int T_dec, int N, con
   b.HWp = c->HWp; b.ksize = d.kernel_size;
   b.dsched = c->dsched; b.ev_by_q = 1;
   const double dE = d.embed_dim_txt, dM = d.map_dim, dD = d.D, dHW = HW, dC = C, dMp = c->Mp;
-  // grids: enough workgroups to fill the chip several times over, never more than the work can be
+  // persistent grids: level 0 carries every Find epilogue and most pooling jobs; deeper levels hold a
+  // fraction of the questions (or nothing: an empty launch costs its workgroups' start-up only)
   const int g_text = std::min((N * T_dec + TM_GROUP - 1) / TM_GROUP + 5, 1024);
-  const int g_att = std::min(N * T_dec * FIND_PARTS, 4096);
-  const int g_pool = std::min(N * ((T_dec + 1) / 2) * POOL_PARTS, 2048);
-  const int g_head = std::min(N, 1024);
+  auto g_att = [&](int l) { return l == 0 ? std::min(std::max(2 * N * FIND_PARTS, 256), 4096) : std::min(std::max(2 * N, 128), 1024); };
+  auto g_pool = [&](int l) { return l <= 1 ? std::min(std::max(N * POOL_PARTS, 256), 2048) : std::min(std::max(N, 128), 512); };
+  const int g_head = std::min(std::max(N, 64), 512);
   // (profile lines of this path count what a question of the reference's layout mix does: two text
   // maps, 1.6 Find-type epilogues, 1.1 pooling jobs -- the work is not known on the host)
   {
@@ -1000,12 +1001,12 @@ int run_tokens_levels(n2nmn_ctx* c, const int32_t* tokens, int T_dec, int N, con
     {
       ProfScope ps(c, F_ATT_OPS, l == 0 ? 1.6 * N * 5.0 * dHW * dM : 0.0,
                    l == 0 ? 1.6 * N * 4.0 * (dHW * dMp + 2 * dMp + dHW) : 0.0, s);
-      launch_att_ops(w, b, 0, l == 0 ? g_att : std::min(g_att, 2048), s, 1 + 3 * l);
+      launch_att_ops(w, b, 0, g_att(l), s, 1 + 3 * l);
     }
     {
       ProfScope ps(c, F_POOL, l == 0 ? 1.1 * N * (2.0 * dHW * dD + 2.0 * dD * dM) : 0.0,
                    l == 0 ? 4.0 * dD * dM + 1.1 * N * 4.0 * (dHW * dD + dHW + POOL_PARTS * dMp) : 0.0, s);
-      launch_pool(w, b, 0, g_pool, s, 2 + 3 * l);
+      launch_pool(w, b, 0, g_pool(l), s, 2 + 3 * l);
     }
     {
       ProfScope ps(c, F_HEADS, l == 0 ? N * (2.0 * dM * dC + 8.0 * dM) : 0.0,

@@ -688,14 +688,14 @@ __device__ void sched_decode(const SchedArgs& a, int n, SchedLayout& q) {
   bool has_eos = false;
   for (int t = 0; t < a.T; ++t) {
     const int tok = a.tokens[(size_t)t * a.N + n];
-    if (tok < 0 || tok >= a.V || a.token_op[tok] < 0) has_eos = true;    // (out of range: treated as <eos>)
+    if (tok < 0 || tok >= a.V) return;                     // garbage token: not a layout (as the walker)
+    if (a.token_op[tok] < 0) has_eos = true;
   }
   if (!has_eos) return;                                    // :172-173
   int8_t stack[SCHED_MAX_T], outl[SCHED_MAX_T];
   int sp = 0, nn = 0;
   for (int t = 0; t < a.T; ++t) {
-    const int tok = a.tokens[(size_t)t * a.N + n];
-    const int op = (tok < 0 || tok >= a.V) ? -1 : a.token_op[tok];
+    const int op = a.token_op[a.tokens[(size_t)t * a.N + n]];
     if (op < 0) break;                                     // <eos>
     const int k = dev_arity(op);
     if (k < 0 || sp < k) return;                           // :189-191

@@ -151,3 +151,29 @@ def test_vqa_random_token_matrices_with_invalid_layouts(vqa_setup):
         assert np.all(dev[~val_h] == 0.0)
         n_bad += int((~val_h).sum()); n_ok += int(val_h.sum())
     assert n_bad >= 10 and n_ok >= 2 * d.N
+
+
+def test_scheduler_with_more_questions_than_threads():
+    """sched_kernel is ONE workgroup of 1024 threads: with more questions a thread decodes several and
+    re-decodes them for the placement pass.  1100 questions on the CLEVR dimensions, all 13 operators."""
+    import torch
+    from n2nmn_amd.engine import Engine
+    from n2nmn_amd.nmn3_assembler import Assembler
+    from n2nmn_amd.spec import Dims
+    d = Dims(N=1100)
+    asm = Assembler(NAMES)
+    eng = Engine(d, asm)
+    eng.load_weights(synth.make_weights(d, seed=0))
+    eng.set_tokens_via_levels(True)
+    batch = synth.make_inputs(d, seed=77)
+    toks = synth.random_valid_layouts(d, asm.P, asm.W, asm.b, seed=900, max_len=7)
+    toks[:, 5] = asm.EOS_idx                                # an empty layout: invalid (stack size 0)
+    toks[0, 1030] = asm.name2idx_dict['_And']               # stack underflow in a question of the second round
+    s2s = eng.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], d.T_decoder, forced_tokens=toks)
+    feat = torch.as_tensor(batch['image_feat_batch']).to(eng.device)
+    dev, val_d = eng.execute_tokens(s2s['predicted_tokens'], feat, s2s['word_vecs'])
+    packed, val_h = asm.assemble_packed(toks)
+    host = t2n(eng.execute(packed, feat, s2s['word_vecs']))
+    assert not val_h[5] and not val_h[1030] and val_h.sum() >= d.N - 2
+    assert np.array_equal(t2n(val_d).astype(bool), val_h)
+    assert np.array_equal(t2n(dev), host)
