@@ -81,13 +81,16 @@ def parse():
     return ap.parse_args()
 
 
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r04_pmc_traffic.json')
+if not os.path.exists(PMC_FILE):
+    PMC_FILE = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
 PMC_FILE_TRAIN = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_train.json')
 PMC_KERNEL = {'lstm_step': 'lstm_tile_kernel', 'dec_attn': 'dec_attn_question_kernel',
               'pool': 'walk_pool_kernel', 'walk_find': 'walk_find_kernel', 'walk_tmap': 'walk_tmap_kernel',
               'gemm_pkn': 'gemm_dma_kernel', 'gemm_pk': 'gemm_pk', 'att_ops': 'att_ops_kernel',
               'textmap': 'walk_textmap_kernel', 'heads': 'heads_kernel', 'word_vecs': 'word_vecs_kernel',
-              'walk(': 'walk_kernel',
+              # the staged walker: Transform / FindSameProperty jobs + the per-question rest + the fall-back launch
+              'walk(': ('walk_heavy_kernel', 'walk_light_kernel', 'walk_kernel'),
               'lstm_bwd_step': 'lstm_bwd_step_kernel', 'gemm_tn': 'gemm_tn_kernel',
               'optimiser': 'adam_kernel'}
 
@@ -99,9 +102,10 @@ def pmc_traffic(family, path=None):
     try:
         data = json.load(open(path or PMC_FILE))['kernels']
         for prefix, kname in PMC_KERNEL.items():
-            hit = [k for k in data if k.startswith(kname)]       # (template arguments vary)
+            names = kname if isinstance(kname, tuple) else (kname,)
+            hit = [k for n in names for k in data if k.startswith(n)][:len(names)]   # (template arguments vary)
             if family.startswith(prefix) and hit:
-                return data[hit[0]]['hbm_bytes_per_launch'], \
+                return sum(data[k]['hbm_bytes_per_launch'] for k in hit), \
                     'profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)' % \
                     os.path.basename(path or PMC_FILE)
     except Exception:
