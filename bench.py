@@ -202,7 +202,7 @@ def bench_train(args, dp, local_rank):
     out = train_numbers(args, dp, local_rank, args.steps, args.warmup, not args.no_profile,
                         not args.no_cpu_baseline)
     if dp.rank == 0:
-        print(json.dumps(out), flush=True)
+        emit_line(json.dumps(out))
     dp.close()
 
 
@@ -305,7 +305,7 @@ def bench_vqa(args, dp, local_rank):
             out['passes_device_layouts'] = {k: pd[k] for k in ('value', 'ms_per_step', 'steps', 'host_sync', 'kernels')
                                             if k in pd}
     if dp.rank == 0:
-        print(json.dumps(out), flush=True)
+        emit_line(json.dumps(out))
     dp.close()
 
 
@@ -446,7 +446,7 @@ def bench_vqa_train(args, dp, local_rank):
             rows = kernel_rows(eng.engine.profile_end(), ksteps)
             out['kernels'] = rows
             out['gpu_us_per_step'] = round(sum(r['us_per_step'] for r in rows), 1)
-        print(json.dumps(out), flush=True)
+        emit_line(json.dumps(out))
     dp.close()
 
 
@@ -459,6 +459,25 @@ def spawn_command(args, argv):
     return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
             '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
             '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+
+
+_RESULT_FD = None
+
+
+def own_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries print there too (RCCL's version banner at
+    communicator creation, under torch.distributed.run): from here on file descriptor 1 points at
+    stderr and the result line goes to the saved descriptor."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_line(line):
+    sys.stdout.flush()
+    os.write(_RESULT_FD if _RESULT_FD is not None else 1, (line + '\n').encode())
 
 
 def ensure_world(args, argv):
@@ -512,6 +531,7 @@ def main():
     if args.plain:
         args.no_profile = args.no_cpu_baseline = True
     ensure_world(args, sys.argv[1:])
+    own_stdout()
     import numpy as np
     import torch
 
@@ -925,7 +945,7 @@ def main():
 
     pipe.close()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit_line(json.dumps(out))
     dp.close()
 
 
