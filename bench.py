@@ -515,6 +515,33 @@ def timed_blocks(dp, run, sync, min_window_s=0.3, max_repeats=15):
     return s[len(s) // 2], len(blocks), blocks
 
 
+def nesting_histogram(tokens, names):
+    """how deep Transform / FindSameProperty nodes nest per layout (index = depth, value = layouts): the
+    staged walker lists up to four levels, deeper layouts go to its one-workgroup fall-back"""
+    import numpy as np
+    from n2nmn_amd.spec import MODULE_INPUT_NUM
+    idx = {n: i for i, n in enumerate(names)}
+    heavy = {idx['_Transform'], idx['_FindSameProperty']}
+    eos = idx['<eos>']
+    hist = {}
+    for col in np.asarray(tokens).T:
+        stack, deepest, ok = [], 0, True
+        for tok in col:
+            if tok == eos:
+                break
+            k = MODULE_INPUT_NUM[names[int(tok)]]
+            if len(stack) < k:
+                ok = False
+                break
+            ins = [stack.pop() for _ in range(k)]
+            hd = max(ins, default=0) + (1 if int(tok) in heavy else 0)
+            deepest = max(deepest, hd)
+            stack.append(hd)
+        if ok:
+            hist[deepest] = hist.get(deepest, 0) + 1
+    return [hist.get(i, 0) for i in range(max(hist, default=0) + 1)]
+
+
 def layout_work(tokens, names):
     """(Find-type nodes, pooling nodes, pooled inputs) of a [T, N] token array"""
     import numpy as np
@@ -713,7 +740,8 @@ def main():
                 'unit': 'questions/sec',
                 'layouts': {'valid_fraction': float(val3.float().mean().item()),
                             'find_type_nodes_per_question': round(f3 / toks3.shape[1], 2),
-                            'pooling_nodes_per_question': round(p3 / toks3.shape[1], 2)}}
+                            'pooling_nodes_per_question': round(p3 / toks3.shape[1], 2),
+                            'transform_nesting_histogram': nesting_histogram(toks3, names)}}
 
     # ---- opt-in split-operand bf16 mode (N2NMN_MODE_THROUGHPUT_BF16X3): the same passes with the
     # recurrent contraction on bf16 MFMAs over three-way split operands, its logits against the oracle.
@@ -723,7 +751,8 @@ def main():
             for wk in pipe.workers:
                 wk['engine'].set_mode('throughput_bf16x3')
             reps3 = max(3, min(15, args.steps // S))
-            t3x = wall(lambda: run_steps(S), reps3)
+            t_est = wall(lambda: run_steps(S), 3)           # (also: the first passes after the mode switch)
+            t3x = wall(lambda: run_steps(S), max(reps3, min(200, int(0.3 / max(t_est, 1e-4)) + 1)))   # >= 0.3 s
             from oracle import n2nmn_oracle_batched as OB
             torch.set_num_threads(min(16, torch.get_num_threads()))
             wt = OB.to_torch(w, torch.float64)

@@ -247,10 +247,19 @@ static size_t carve_workspace(n2nmn_ctx* c, char* base) {
   c->wpooled = k.take<float>(N * 2 * (size_t)d.D);
   c->wpfc = k.take<float>(N * 2 * WALK_POOL_PARTS * Mp);
   c->wprog = k.take<WalkProg>(N);
-  c->whcap = (int)std::min<size_t>((size_t)WALK_MAX_BATCHES * N * 4, (size_t)1 << 20);
-  c->whjobs = k.take<int32_t>((size_t)c->whcap);
+  // job lists of the staged walker: a region per nesting level (kernels.h, WalkArgs::hoff), sized for the
+  // worst case -- at most T / (lv + 2) nodes of level lv per question, per operator
+  {
+    size_t off = 0;
+    for (int lv = 0; lv < WALK_HLEVELS; ++lv) {
+      c->whoff[lv] = (int)off;
+      off += (size_t)2 * WALK_MAX_BATCHES * N * (WALK_MAX_T / (lv + 2));
+    }
+    c->whoff[WALK_HLEVELS] = (int)off;
+    c->whjobs = k.take<int32_t>(off);
+  }
   c->wfblist = k.take<int32_t>((size_t)WALK_MAX_BATCHES * N);
-  c->wcnt = k.take<int32_t>(16);
+  c->wcnt = k.take<int32_t>(2 * WALK_CNT);
   c->wplist = k.take<int32_t>((size_t)2 * WALK_MAX_BATCHES * N);
   return align_up(k.off, 256);
 }
@@ -1057,7 +1066,16 @@ static int finish_create(n2nmn_ctx* c, n2nmn_ctx* parent) {
     return N2NMN_EHIP;
   }
   carve_workspace(c, c->ws_base);
-  N2_HIP(hipMemset(c->wcnt, 0, sizeof(int32_t) * 16));     // the walker's two counter sets
+  N2_HIP(hipMemset(c->wcnt, 0, sizeof(int32_t) * 2 * WALK_CNT));     // the walker's two counter sets
+  // (the staged walker reports its deepest nesting through one host-mapped word: no copy, no sync)
+  if (hipHostMalloc(reinterpret_cast<void**>(&c->walk_hint_host), 64, hipHostMallocMapped) == hipSuccess) {
+    c->walk_hint_host[0] = 0;
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&c->walk_hint_dev), c->walk_hint_host, 0) != hipSuccess)
+      c->walk_hint_dev = nullptr;
+  } else {
+    (void)hipGetLastError();
+    c->walk_hint_host = nullptr;
+  }
   if (c->iota) {
     std::vector<int32_t> io((size_t)c->d.T_encoder * c->d.N);
     for (size_t i = 0; i < io.size(); ++i) io[i] = (int32_t)i;
@@ -1156,6 +1174,7 @@ int n2nmn_ctx_destroy(n2nmn_ctx* ctx) {
     if (ctx->stage_ev[i]) (void)hipEventDestroy(ctx->stage_ev[i]);
   }
   for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
+  if (ctx->walk_hint_host) (void)hipHostFree(ctx->walk_hint_host);
   if (ctx->train) train_state_destroy(ctx->train);
   n2nmn_program_destroy(ctx->scratch_prog);
   delete ctx;
@@ -1603,13 +1622,28 @@ int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int
   if (a.defer_pool) {
     // the per-pass counters (two sets, used alternately: walk_fcatt_kernel clears the other one) and the
     // pooled-root job lists
-    a.cnt = c->wcnt + 8 * c->walk_parity; a.cnt_next = c->wcnt + 8 * (c->walk_parity ^ 1);
+    a.cnt = c->wcnt + WALK_CNT * c->walk_parity; a.cnt_next = c->wcnt + WALK_CNT * (c->walk_parity ^ 1);
     c->walk_parity ^= 1;
     a.plist = c->wplist; a.pcap = WALK_MAX_BATCHES * d.N;
   }
   if (staged) {
     a.staged = 1;
-    a.hjobs = c->whjobs; a.fblist = c->wfblist; a.hcap = c->whcap;
+    a.hjobs = c->whjobs; a.fblist = c->wfblist;
+    for (int i = 0; i <= WALK_HLEVELS; ++i) a.hoff[i] = c->whoff[i];
+    // How many nesting levels of Transform / FindSameProperty get a launch of their own: as deep as the
+    // last two passes went (the kernels leave that in a host-mapped word; whatever has arrived is read,
+    // nothing waits).  A layout nested deeper than this pass launches is served by the one-workgroup
+    // walker -- same logits -- so the hint steers speed only.  The CLEVR template mix never nests:
+    // one launch.
+    int seen = 0;
+    if (c->walk_hint_host) {
+      seen = *reinterpret_cast<volatile int32_t*>(c->walk_hint_host);
+      a.hint = c->walk_hint_dev;
+    }
+    static const int lv_env = [] { const char* e = getenv("N2NMN_WALK_LEVELS"); return e ? atoi(e) : 0; }();
+    const int want = lv_env > 0 ? lv_env : std::max(seen, c->walk_hint_prev);
+    c->walk_hint_prev = seen;
+    a.hlevels = std::min(std::max(want, 1), WALK_HLEVELS);
   }
   if (pre) {
     a.pre_find = 1;
@@ -1627,10 +1661,11 @@ int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int
   {
     ProfScope ps(c, F_WALK, 0.0, 0.0, s);     // work filled in from the device counters
     if (a.staged) {
-      launch_walk_heavy(w, a, s);
+      for (int lv = 0; lv < a.hlevels; ++lv) { a.hlevel = lv; launch_walk_heavy(w, a, s); }
+      a.hlevel = 0;
       launch_walk_light(w, a, s);
     }
-    launch_walk(w, a, s);                     // staged: only the questions listed as nested
+    launch_walk(w, a, s);                     // staged: only the questions listed as nested too deep
   }
   c->last_walk = a;
   c->have_last_walk = true;
@@ -1688,7 +1723,10 @@ int n2nmn_debug_walk_replay(n2nmn_ctx* c, int which, int iters, double* us_avg, 
     if (which == 0) {
       WalkArgs t = a;
       t.plist = nullptr;                 // (a replay must not append the pooled roots to the lists again)
-      if (t.staged) { launch_walk_heavy(w, t, s); launch_walk_light(w, t, s); }
+      if (t.staged) {
+        for (int lv = 0; lv < t.hlevels; ++lv) { t.hlevel = lv; launch_walk_heavy(w, t, s); }
+        launch_walk_light(w, t, s);
+      }
       launch_walk(w, t, s);
     }
     else if (which == 1) launch_walk_pool(w, a, s);

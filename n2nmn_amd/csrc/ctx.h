@@ -222,7 +222,10 @@ struct n2nmn_ctx {
   // the launches this context issues -- the job lists and the two counter sets (used alternately)
   WalkProg* wprog = nullptr;
   int32_t *whjobs = nullptr, *wfblist = nullptr, *wcnt = nullptr, *wplist = nullptr;
-  int whcap = 0, walk_parity = 0;
+  int whoff[WALK_HLEVELS + 1] = {0}, walk_parity = 0;
+  int32_t* walk_hint_host = nullptr;   // host-mapped word the staged walker reports its deepest nesting in
+  int32_t* walk_hint_dev = nullptr;
+  int walk_hint_prev = 0;
   int walk_staged = -1;                       // -1 auto (with the chip-wide front end + deferred pooling), 0 off
   float *arena = nullptr, *tmap = nullptr, *pfc = nullptr, *mfind = nullptr, *mfsp = nullptr;
   float* ev_out = nullptr;

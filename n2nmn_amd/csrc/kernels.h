@@ -273,6 +273,8 @@ constexpr int WALK_THREADS = 512;
 constexpr int WALK_POOL_ROWS = 38;   // feature rows a thread keeps in flight (H*W / (512 / (D/4)))
 constexpr int WALK_MAX_T = 32;
 constexpr int WALK_MAX_BATCHES = 16;
+constexpr int WALK_HLEVELS = 24;     // nesting levels of Transform / FindSameProperty the staged walker lists
+constexpr int WALK_CNT = 64;         // counters per set (WalkArgs::cnt)
 constexpr int WALK_POOL_PARTS = 8;    // channel parts of a deferred pooling job (walk_pool_kernel)
 constexpr int WALK_POOLK_ROWS = 10;   // feature rows a walk_pool_kernel thread keeps in flight
 constexpr int WALK_MAX_PIXEL_GROUPS = 3;   // H*W <= 192 (64-pixel groups a Transform wave holds)
@@ -326,15 +328,23 @@ struct WalkArgs {
   // Transform / FindSameProperty nodes whose input subtree holds no other such node (hjobs: they run
   // chip-wide in walk_heavy_kernel, one workgroup per node) and the questions with deeper nesting
   // (fblist: the one-workgroup walker serves those as before); walk_light_kernel finishes the others.
-  // cnt[0] = Transform jobs (hjobs[0 ..)), cnt[1] = fallback questions, cnt[2] = FindSameProperty jobs
-  // (hjobs[hcap / 2 ..): the long jobs, handed out first).
+  // cnt[0] = Transform jobs of level 0, cnt[1] = fallback questions, cnt[2] = FindSameProperty jobs of
+  // level 0, cnt[3], cnt[4] = pooled roots (Describe / SameProperty), cnt[5] = deepest nesting seen in the
+  // pass, cnt[6 + 2 lv + kind] = jobs of level lv >= 1 (kind 0 Transform, 1 FindSameProperty).
+  // A node's level = number of Transform / FindSameProperty nodes below it in its own subtree; level lv
+  // runs in the lv-th walk_heavy launch (its inputs of lower levels are in `watt` by then).  Nodes of one
+  // level have disjoint subtrees of >= lv + 2 tokens, so a level holds at most T / (lv + 2) of them per
+  // question: hjobs[hoff[lv] .. hoff[lv + 1]) is level lv, first half Transform, second half
+  // FindSameProperty.
   int staged;
-  int32_t* hjobs;          // [hcap] (question << 8) | node
+  int32_t* hjobs;          // (question << 8) | node
   int32_t* fblist;         // [K * N] flat question indices
-  int32_t* cnt;            // [8] this pass's counters (cnt[3] / cnt[4]: deferred Describe / SameProperty jobs)
-  int32_t* cnt_next;       // [4] the other set: walk_heads_kernel zeroes it for the next pass (this pass's
+  int32_t* cnt;            // [WALK_CNT] this pass's counters (cnt[3] / cnt[4]: deferred Describe / SameProperty jobs)
+  int32_t* cnt_next;       // [WALK_CNT] the other set: walk_fcatt_kernel zeroes it for the next pass (this pass's
                            // set stays readable for n2nmn_debug_walk_replay)
-  int hcap;
+  int hoff[WALK_HLEVELS + 1];
+  int hlevels, hlevel;     // levels listed by this pass's plan (deeper nesting: fall-back list); level of this launch
+  int32_t* hint;           // host-mapped word: deepest nesting of the pass (written once, by walk_fcatt_kernel)
   // deferred pooling (defer_pool): the questions whose root pools, listed per operator by whoever
   // writes pjob (walk_light_kernel / walk_kernel): plist[0 .. pcap) Describe, plist[pcap ..) SameProperty
   int32_t* plist;

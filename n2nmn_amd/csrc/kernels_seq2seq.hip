@@ -692,6 +692,131 @@ __global__ __launch_bounds__(NT) void dec_attn_kernel(DecStepArgs a) {
   }
 }
 
+// Sequential decoding (greedy / sampled, one launch per step): one workgroup of 16 waves per question.
+// ONE pass over the question's encoder rows: wave w takes rows w, w + 16, ... below the question's length
+// and loads a row of eht AND the same row of the encoder outputs together (two independent streams, one
+// memory round trip), keeping a running
+// (max, sum, weighted row sum).  The reference's attention -- soft-max over ALL T rows, mask, renormalise
+// (:190-191) -- is exp(e - m) / sum over the rows inside the length for ANY m, so the rows past the length
+// are never touched, the attention needs no second pass over the rows, and the 16 partial states meet in
+// LDS.  (dec_attn_kernel<1024>, the form this replaces, made three dependent passes: scores of all rows,
+// soft-max by one wave, context; 60 us per 1024 questions against 44.)
+template <int KI>
+__global__ __launch_bounds__(1024, 2) void dec_attn_seq_kernel(DecStepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NT = 1024, NW = NT / 64;
+  const int L = a.L, T = a.T, N = a.N, V = a.V;
+  const int Tp = (T + 3) & ~3;
+  float* outs = smem;                 // [L]
+  float* ctx = outs + L;              // [L]
+  float* ctxp = ctx + L;              // [NW][L] partial contexts
+  float* es = ctxp + (size_t)NW * L;  // [Tp] raw scores of the rows inside the length
+  float* ms = es + Tp;                // [NW][2] running (max, sum) of each wave, then [2 NW ..] merge weights
+  float* red = ms + 4 * NW;           // [NW][MAXV]
+  const int n = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int len = min(max(a.seq_len[n], 0), T);
+  const size_t tn = n;                              // (one step per launch: step offset 0)
+  const float* qrow = a.q + tn * L;
+  const float* orow = a.out + tn * L;
+  for (int k = tid; k < L; k += NT) outs[k] = orow[k];
+
+  float4 v4[KI], q4[KI];
+#pragma unroll
+  for (int i = 0; i < KI; ++i) {
+    const int k = 4 * lane + 256 * i;
+    v4[i] = *reinterpret_cast<const float4*>(a.v + k);
+    q4[i] = *reinterpret_cast<const float4*>(qrow + k);
+  }
+  const size_t rstride = (size_t)N * L;
+  const float* eb = a.eht + (size_t)n * L + 4 * lane;
+  const float* ob = a.eout + (size_t)n * L + 4 * lane;
+  float4 e4[KI], o4[KI], acc[KI];
+#pragma unroll
+  for (int i = 0; i < KI; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float m_run = -INFINITY, s_run = 0.f;
+  // (a wave has ceil(len / 16) <= 3 rows, 1.1 on average: no software pipelining -- the registers it
+  // would take cost the second workgroup per CU)
+  for (int tau = w; tau < len; tau += NW) {
+#pragma unroll
+    for (int i = 0; i < KI; ++i) {
+      e4[i] = *reinterpret_cast<const float4*>(eb + (size_t)tau * rstride + 256 * i);
+      o4[i] = *reinterpret_cast<const float4*>(ob + (size_t)tau * rstride + 256 * i);
+    }
+    float sacc = 0.f;                               // e[tau] = sum_k v_k tanh(q_k + eht[tau, n, k])   (:184-187)
+#pragma unroll
+    for (int i = 0; i < KI; ++i)
+      sacc += v4[i].x * fast_tanh(q4[i].x + e4[i].x) + v4[i].y * fast_tanh(q4[i].y + e4[i].y) +
+              v4[i].z * fast_tanh(q4[i].z + e4[i].z) + v4[i].w * fast_tanh(q4[i].w + e4[i].w);
+    const float sc = wave_sum(sacc);
+    if (lane == 0) es[tau] = sc;
+    const float mn = fmaxf(m_run, sc);
+    const float scale = expf(m_run - mn), p = expf(sc - mn);     // (first row: exp(-inf) = 0)
+#pragma unroll
+    for (int i = 0; i < KI; ++i) {
+      acc[i].x = acc[i].x * scale + p * o4[i].x; acc[i].y = acc[i].y * scale + p * o4[i].y;
+      acc[i].z = acc[i].z * scale + p * o4[i].z; acc[i].w = acc[i].w * scale + p * o4[i].w;
+    }
+    s_run = s_run * scale + p;
+    m_run = mn;
+  }
+#pragma unroll
+  for (int i = 0; i < KI; ++i)
+    *reinterpret_cast<float4*>(ctxp + (size_t)w * L + 4 * lane + 256 * i) = acc[i];
+  if (lane == 0) { ms[2 * w] = m_run; ms[2 * w + 1] = s_run; }
+  // this thread's row of W_y (2 L = 1024 rows = one per thread) is requested now: it arrives under the
+  // merge below instead of in front of the token logits
+  float wy[MAXV];
+  {
+    const float* wr = a.Wy + (size_t)min(tid, 2 * L - 1) * V;
+#pragma unroll
+    for (int s = 0; s < MAXV; ++s) wy[s] = s < V ? wr[s] : 0.f;
+  }
+  __syncthreads();
+  // ---- the partial states meet: weight of wave w = exp(m_w - M) / S                       (:190-193)
+  if (w == 0) {
+    const float mw = lane < NW ? ms[2 * lane] : -INFINITY;
+    const float sw = lane < NW ? ms[2 * lane + 1] : 0.f;
+    const float M = wave_max(mw);
+    const float ew = lane < NW && sw > 0.f ? expf(mw - M) : 0.f;
+    const float S = wave_sum(sw * ew);
+    if (lane < NW) ms[2 * NW + lane] = ew / S;
+    if (lane == 0) { ms[3 * NW] = M; ms[3 * NW + 1] = 1.0f / S; }
+  }
+  __syncthreads();
+  {
+    const float M = ms[3 * NW], rS = ms[3 * NW + 1];
+    float* arow = a.atts;
+    for (int t = tid; t < T; t += NT) arow[(size_t)t * N + n] = t < len ? expf(es[t] - M) * rS : 0.f;
+    for (int k = tid; k < L; k += NT) {
+      float c = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < NW; ++ww) c += ms[2 * NW + ww] * ctxp[(size_t)ww * L + k];
+      ctx[k] = c;
+      if (a.ctx_out) a.ctx_out[tn * L + k] = c;
+    }
+  }
+  __syncthreads();
+  // ---- token logits = [out, ctx] . W_y + b_y                                              (:196-198)
+  {
+    const float x = tid < L ? outs[tid] : (tid < 2 * L ? ctx[tid - L] : 0.f);
+#pragma unroll
+    for (int s = 0; s < MAXV; ++s) {
+      const float r = wave_sum(x * wy[s]);
+      if (lane == 0) red[w * MAXV + s] = r;
+    }
+  }
+  __syncthreads();
+  if (w == 0) {
+    float sc = -INFINITY;
+    if (lane < V) {
+      sc = a.by[lane];
+      for (int ww = 0; ww < NW; ++ww) sc += red[ww * MAXV + lane];
+    }
+    dec_token_tail(a, n, 0, tn, sc, lane);
+  }
+}
+
 // All decoder steps are known up front (teacher forcing / given tokens): one workgroup handles TS
 // steps of one question, so each encoder row (eht and encoder_outputs, 2 KB each) is loaded ONCE for
 // TS query vectors instead of once per step -- the single-step grid re-read 184 KB per (question,
@@ -1439,10 +1564,19 @@ void launch_dec_attn(const DecStepArgs& a, int nsteps, hipStream_t s) {
   nsplit = nsplit < 1 ? 1 : (nsplit > 8 ? 8 : nsplit);
   const size_t smem = sizeof(float) * ((2 + (size_t)nsplit) * a.L + ((a.T + 3) & ~3) +
                                        (size_t)(nt / 64) * MAXV + 16);
-  if (nsteps > 1)
+  if (nsteps > 1) {
     hipLaunchKernelGGL(dec_attn_kernel<256>, dim3(a.N, nsteps), dim3(256), smem, s, a);
-  else
-    hipLaunchKernelGGL(dec_attn_kernel<1024>, dim3(a.N, 1), dim3(1024), smem, s, a);
+    return;
+  }
+  // one step per launch (greedy / sampled decoding): the one-pass form; N2NMN_DEC_ATTN_SEQ=0 keeps the
+  // three-pass kernel
+  static const bool seq_on = [] { const char* e = getenv("N2NMN_DEC_ATTN_SEQ"); return !e || atoi(e) != 0; }();
+  if (seq_on && a.L == 512) {       // (lstm_dim 1024 needs 128 VGPRs in this form: one workgroup per CU)
+    const size_t sm = sizeof(float) * ((2 + 16) * (size_t)a.L + ((a.T + 3) & ~3) + 4 * 16 + 16 * MAXV + 16);
+    hipLaunchKernelGGL(dec_attn_seq_kernel<2>, dim3(a.N), dim3(1024), sm, s, a);
+    return;
+  }
+  hipLaunchKernelGGL(dec_attn_kernel<1024>, dim3(a.N, 1), dim3(1024), smem, s, a);
 }
 
 void launch_enc_rows(const int32_t* seq_len, int T, int N, int32_t* rows, int32_t* count,

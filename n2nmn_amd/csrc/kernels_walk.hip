@@ -479,9 +479,10 @@ __global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ WalkLds L;
   int q = blockIdx.x;
-  if (a.staged) {              // staged passes: only the questions the plan listed as nested
+  if (a.staged) {              // staged passes: only the questions the plan listed as nested too deep
     if (q >= a.cnt[1]) return;
     q = a.fblist[q];
+    if (a.stats && threadIdx.x == 0) atomicAdd(a.stats + 9, 1ull);
   }
   const int kb = q / a.N, n = q - kb * a.N;
   const WalkBatch& B = a.b[kb];
@@ -973,7 +974,7 @@ constexpr int FT = 256, FW = FT / 64;
 // The loop is a chain of dependent LDS accesses, so it is built to need ONE LDS round trip per node:
 // a node's attributes are one packed word (op | answer << 7 | hd << 8 | lo << 16), the two topmost stack
 // entries live in registers, and the stack proper is only read back behind a two-input operator.
-__device__ inline void plan_layout(const int* tok_op, int T, WalkProg& P, int* stack, unsigned* word) {
+__device__ inline int plan_layout(const int* tok_op, int T, WalkProg& P, int* stack, unsigned* word) {
   int nn = 0, ok = 1;
   bool has_eos = false;
   for (int t = 0; t < T; ++t) {
@@ -1022,7 +1023,8 @@ __device__ inline void plan_layout(const int* tok_op, int T, WalkProg& P, int* s
   }
   if (ok && (sp != 1 || !(word[a] & 0x80u))) ok = 0;             // stack size / result type
   P.nn = nn; P.valid = ok; P.nfind = nf;
-  P.fallback = ok && maxhd >= 2;          // nested Transform / FindSameProperty: the one-workgroup walker
+  P.fallback = ok && maxhd >= 2;          // (the caller decides: nesting deeper than the levels it lists)
+  return ok ? maxhd : 0;
 }
 
 __global__ __launch_bounds__(FT) void walk_tmap_kernel(ModuleWeights w, WalkArgs a) {
@@ -1050,7 +1052,14 @@ __global__ __launch_bounds__(FT) void walk_tmap_kernel(ModuleWeights w, WalkArgs
     while (nn < T && ops[nn] >= 0) ++nn;
     s_nn = nn;
     // the pass's plan: every layout is decoded once, here (walk_find / walk_heavy / walk_light read it)
-    if (a.pre_find) plan_layout(ops, T, P, stack, word);
+    if (a.pre_find) {
+      const int deepest = plan_layout(ops, T, P, stack, word);
+      // nesting of Transform / FindSameProperty up to the levels this pass launches is listed level by
+      // level; deeper layouts go to the one-workgroup walker (and the host, told through cnt[11], launches
+      // more levels for the passes that follow)
+      P.fallback = P.valid && deepest > max(a.hlevels, 1);
+      if (a.staged && deepest >= 2) atomicMax(a.cnt + 5, deepest);
+    }
   }
   const int qlen = min(max(B.seq_len[n], 0), Te);
   for (int tau = tid; tau < Te; tau += FT) {
@@ -1096,23 +1105,20 @@ __global__ __launch_bounds__(FT) void walk_tmap_kernel(ModuleWeights w, WalkArgs
     }
   }
   // the chip-wide job lists of the staged walker (WalkArgs::staged) -- last, so that the returning
-  // atomics (an L2 round trip each) delay nothing: Transform jobs from hjobs[0], FindSameProperty jobs
-  // (the long ones, handed out first by walk_heavy_kernel) from hjobs[hcap / 2]
+  // atomics (an L2 round trip each) delay nothing: one list per (nesting level, operator); a level's
+  // FindSameProperty jobs (the long ones) are handed out first by walk_heavy_kernel
   if (a.staged && tid == 0 && P.valid) {
     if (P.fallback) {
       a.fblist[atomicAdd(a.cnt + 1, 1)] = q;
     } else {
-      const int half = a.hcap / 2;
       for (int t = 0; t < P.nn; ++t) {
         const int o = P.op[t] & 0x7f;
-        if (P.hd[t] != 1) continue;
-        if (o == N2NMN_OP_TRANSFORM) {
-          const int j = atomicAdd(a.cnt + 0, 1);
-          if (j < half) a.hjobs[j] = (q << 8) | t;
-        } else if (o == N2NMN_OP_FIND_SAME_PROPERTY) {
-          const int j = atomicAdd(a.cnt + 2, 1);
-          if (j < half) a.hjobs[half + j] = (q << 8) | t;
-        }
+        const int kind = o == N2NMN_OP_TRANSFORM ? 0 : (o == N2NMN_OP_FIND_SAME_PROPERTY ? 1 : -1);
+        const int lv = (int)P.hd[t] - 1;
+        if (kind < 0 || lv < 0 || lv >= WALK_HLEVELS) continue;
+        const int cap = (a.hoff[lv + 1] - a.hoff[lv]) / 2;
+        const int j = atomicAdd(a.cnt + (lv == 0 ? 2 * kind : 6 + 2 * lv + kind), 1);
+        if (j < cap) a.hjobs[a.hoff[lv] + kind * cap + j] = (q << 8) | t;
       }
     }
   }
@@ -1309,7 +1315,8 @@ __global__ __launch_bounds__(WT) void walk_fcatt_kernel(ModuleWeights w, WalkArg
   const int njob = min(a.cnt[3 + ty], a.pcap);    // (uniform: scalar load)
   if (blockIdx.x == 0 && y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
     // the NEXT pass starts from empty lists (this pass's set stays readable for replays)
-    for (int i = 0; i < 5; ++i) a.cnt_next[i] = 0;
+    for (int i = 0; i < WALK_CNT; ++i) a.cnt_next[i] = 0;
+    if (a.hint) *a.hint = a.cnt[5];                // deepest nesting of this pass, for the host (no sync)
   }
   const int tid = threadIdx.x;
   const int D = a.D, Mp = a.Mp;
@@ -1609,14 +1616,18 @@ __global__ __launch_bounds__(WT) void walk_heavy_kernel(ModuleWeights w, WalkArg
   // two lists: FindSameProperty jobs (a 307 KB pool + a 512 KB fc_att stream + a 154 KB epilogue at one
   // CU's pace: the long ones) are handed out first, Transform jobs behind them -- longest processing
   // time first keeps the last round of the persistent grid short
-  const int half = a.hcap / 2;
-  const int nfsp = min(a.cnt[2], half), ntr = min(a.cnt[0], half);
+  const int lv = a.hlevel;
+  const int ctr = lv == 0 ? 0 : 6 + 2 * lv, cfs = lv == 0 ? 2 : 7 + 2 * lv;
+  const int cap = (a.hoff[lv + 1] - a.hoff[lv]) / 2;
+  const int nfsp = min(a.cnt[cfs], cap), ntr = min(a.cnt[ctr], cap);
+  const int32_t* jtr = a.hjobs + a.hoff[lv];
+  const int32_t* jfs = jtr + cap;
   for (int j = blockIdx.x; j < nfsp + ntr; j += gridDim.x) {
     // the opaque copy keeps one operator's address arithmetic from being hoisted across the other
     // (see walk_kernel)
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
-    const int job = j < nfsp ? a.hjobs[half + j] : a.hjobs[j - nfsp];
+    const int job = j < nfsp ? jfs[j] : jtr[j - nfsp];
     const int q = job >> 8, t = job & 0xff;
     if (q < 0 || q >= a.K * a.N || t >= T) continue;                 // (a stale list entry)
     const int kb = q / a.N, n = q - kb * a.N;
@@ -1626,7 +1637,7 @@ __global__ __launch_bounds__(WT) void walk_heavy_kernel(ModuleWeights w, WalkArg
     __syncthreads();
     const int o = P.op[t] & 0x7f;
     const bool heavy = o == N2NMN_OP_TRANSFORM || o == N2NMN_OP_FIND_SAME_PROPERTY;
-    if (!P.valid || P.fallback || t >= P.nn || !heavy || P.hd[t] != 1 || P.in0[t] < 0) continue;
+    if (!P.valid || P.fallback || t >= P.nn || !heavy || P.hd[t] != lv + 1 || P.in0[t] < 0) continue;
     const int i0 = P.in0[t];
     // debug timeline (n2nmn_debug_walk_timeline): [0] job start, [1] operands ready (Transform) / pooled
     // (FindSameProperty), [2] matrix phase / fc_att done, [3] map written
@@ -1638,7 +1649,8 @@ __global__ __launch_bounds__(WT) void walk_heavy_kernel(ModuleWeights w, WalkArg
         *reinterpret_cast<float4*>(tml + c) = *reinterpret_cast<const float4*>(src + c);
     }
     const float* watt_q = B.watt + (size_t)n * T * HWp;
-    eval_light_range(tid, P, P.lo[i0], i0, watt_q, arena, HW, HWp, false);
+    // (level >= 1: the Transform / FindSameProperty maps of the lower levels inside the subtree are in watt)
+    eval_light_range(tid, P, P.lo[i0], i0, watt_q, arena, HW, HWp, lv > 0);
     const float* in0 = arena + (size_t)i0 * HWp;
     float* outp = arena + (size_t)t * HWp;
     if (o == N2NMN_OP_TRANSFORM) {                      // :185-216
@@ -1794,7 +1806,7 @@ void launch_walk_heavy(const ModuleWeights& w, const WalkArgs& a, hipStream_t s)
                                                       a.H, a.W, a.C, 0);
   // a persistent grid over the job list: two workgroups per CU's worth of ids, each takes jobs
   // id, id + grid, ... (the list length lives on the device)
-  const int grid = std::min(512, std::max(1, a.hcap));
+  const int grid = std::min(512, std::max(1, (a.hoff[a.hlevel + 1] - a.hoff[a.hlevel]) / 2));
   auto go = [&](auto kern, std::atomic<uint64_t>& done) {
     if (smem > 64 * 1024) ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)smem, done);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WT), smem, s, w, a);
