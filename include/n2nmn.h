@@ -313,12 +313,14 @@ int n2nmn_walk_set_front_end(n2nmn_ctx *ctx, int mode);
 /* Staged walker.  When a launch runs both of the above chip-wide (front end AND deferred pooling: passes
  * of >= 128 questions by default), the tree-dependent rest leaves the one-workgroup-per-question walker
  * as well: walk_tmap_kernel decodes every layout once (nmn3_assembler.py:153-222) and lists the
- * _Transform / _FindSameProperty nodes whose input subtree holds no other such node; walk_heavy_kernel
- * runs each of them as a job of its own (one workgroup per node, the walker's operator code);
- * walk_light_kernel (one small workgroup per question) evaluates the remaining And / Or / Filter / Scene
- * nodes and the answer operator (nmn3_modules.py:60-72,113-132,218-400) or hands the root to the
- * deferred pooling; questions with nested _Transform / _FindSameProperty nodes stay with the
- * one-workgroup walker.  mode -1 (default): on; 0: off (the walker serves every question). */
+ * _Transform / _FindSameProperty nodes by nesting level (level = such nodes below it in its own subtree);
+ * walk_heavy_kernel runs each of them as a job of its own (one workgroup per node, the walker's operator
+ * code), one launch per level; walk_light_kernel (one small workgroup per question) evaluates the remaining
+ * And / Or / Filter / Scene nodes and the answer operator (nmn3_modules.py:60-72,113-132,218-400) or hands
+ * the root to the deferred pooling.  How many level launches a pass gets follows the deepest nesting the
+ * previous two passes showed (a host-mapped word, never waited for); layouts nested deeper than that stay
+ * with the one-workgroup walker -- same operators, logits equal within 2e-6.  The CLEVR template mix never
+ * nests: one launch.  mode -1 (default): on; 0: off (the walker serves every question). */
 int n2nmn_walk_set_staged(n2nmn_ctx *ctx, int mode);
 /* Phase 2 straight from DEVICE tokens (no token fetch, no host assembly): replaces Assembler.assemble +
  * td.Compiler.build_feed_dict + the second partial_run (exp_clevr/eval_clevr.py:121-132,
