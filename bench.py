@@ -854,8 +854,8 @@ def main():
             us_walk = eng.walk_replay_us(0, 20)
             walk_bytes = wrow[0]['achieved'] * 1e9 * wrow[0]['avg_us'] * 1e-6 if wrow else 0.0
             frow = [r for r in rows if r['kernel'].startswith('walk_find')]
-            att.append({'kernel': 'walk_kernel (layout walker: %sfeatures and map under FindSameProperty%s; '
-                                  'everything that depends on the tree)' %
+            att.append({'kernel': 'walker = walk_heavy + walk_light + fall-back walk_kernel launches (%sfeatures and '
+                                  'map under FindSameProperty%s; everything that depends on the tree)' %
                                   ('' if frow else 'conv_image maps under every Find-type node, ',
                                    '' if deferred else ' / Describe / SameProperty'),
                         'bound': 'latency' if frow else 'hbm', 'avg_us': round(us_walk, 3),
@@ -916,7 +916,7 @@ def main():
                 'byte_weighted': {'bytes': round(path_bytes), 'us': round(path_us, 2),
                                   'achieved': round(path_bytes / path_us / 1e3, 1), 'unit': 'GB/s',
                                   'frac': round(path_bytes / path_us / 1e3 / HBM_PEAK_GBS, 4),
-                                  'kernels': 'walk_pool + walk_find + walk_kernel'},
+                                  'kernels': 'walk_pool + walk_find + walker (walk_heavy + walk_light + fall-back walk_kernel)'},
                 'measured': 'each kernel of the last pass replayed back to back inside one HIP event '
                             'pair, average per launch (inputs of one pass stay L2/MALL-warm across the '
                             'replays: see profiles/ for the cold rocprofv3 numbers)',
