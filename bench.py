@@ -725,8 +725,11 @@ def main():
         if use_gt:
             t3 = wall(one_greedy, n1)
             eng.set_mode(pipe.mode)
-            reps = max(3, min(15, args.steps // S))
-            t3k = wall(lambda: run_steps(S, gt=False), reps)
+            # (blocks of `steps` passes like the headline: a call per pass would put the workers' hand-over
+            # between every two passes)
+            npass = max(args.steps, 2 * S)
+            t_est = wall(lambda: run_steps(npass, gt=False), 1, warm=1)
+            t3k = wall(lambda: run_steps(npass, gt=False), max(3, min(15, int(0.3 / max(t_est, 1e-4)) + 1)), warm=0) * S / npass
             _, tk3, val3 = run_pass(eng, sb, K, False)
             toks3 = tk3.cpu().numpy()
             f3, p3, _ = layout_work(toks3, names)
@@ -751,8 +754,9 @@ def main():
             for wk in pipe.workers:
                 wk['engine'].set_mode('throughput_bf16x3')
             reps3 = max(3, min(15, args.steps // S))
-            t_est = wall(lambda: run_steps(S), 3)           # (also: the first passes after the mode switch)
-            t3x = wall(lambda: run_steps(S), max(reps3, min(200, int(0.3 / max(t_est, 1e-4)) + 1)))   # >= 0.3 s
+            npass = max(args.steps, 2 * S)
+            t_est = wall(lambda: run_steps(npass), 1, warm=1)       # (also: the first passes after the mode switch)
+            t3x = wall(lambda: run_steps(npass), max(3, min(15, int(0.3 / max(t_est, 1e-4)) + 1)), warm=0) * S / npass
             from oracle import n2nmn_oracle_batched as OB
             torch.set_num_threads(min(16, torch.get_num_threads()))
             wt = OB.to_torch(w, torch.float64)
@@ -765,7 +769,7 @@ def main():
                 gt = synth.template_layout_batch(d, offset=i)
                 ref = OB.forward(wt, names, hb, d.T_decoder, d.num_choices, True, gt)
                 worst3 = max(worst3, float(np.abs(b.result(0)[0].cpu().numpy() - ref['scores']).max()))
-            t3g = wall(lambda: run_steps(S, gt=False), max(3, reps3 // 2))
+            t3g = wall(lambda: run_steps(npass, gt=False), 3, warm=1) * S / npass
             out['bf16x3'] = {
                 'mode': "N2NMN_MODE_THROUGHPUT_BF16X3 (opt-in; `python bench.py --lstm-mode throughput_bf16x3`): "
                         'recurrent contraction on v_mfma_f32_16x16x32_bf16 over three-way split operands, '
