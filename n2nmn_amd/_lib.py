@@ -170,6 +170,13 @@ def lib():
                     % (_build.LIB, e))
             import warnings
             warnings.warn('n2nmn_amd: loading a STALE %s (rebuild failed: %s)' % (_build.LIB, e))
+    # PyTorch's bundled HIP runtime must be the process's: loaded after this library's own dependency
+    # (the system libamdhip64) it would be a second runtime, and this library's would see no device
+    # (build() followed by smoke() in one process did that)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(_build.LIB)
     for name, res, args in SYMBOLS:
         fn = getattr(L, name)       # AttributeError if the .so does not export the symbol
