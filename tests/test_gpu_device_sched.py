@@ -177,3 +177,35 @@ def test_scheduler_with_more_questions_than_threads():
     assert not val_h[5] and not val_h[1030] and val_h.sum() >= d.N - 2
     assert np.array_equal(t2n(val_d).astype(bool), val_h)
     assert np.array_equal(t2n(dev), host)
+
+
+def test_vqa_scheduler_edges_deepest_chain_single_question_and_all_invalid(vqa_setup):
+    """The launch sequence is sized by the capacity (T_dec levels x 3 stages): a chain that uses every level
+    (_Find, eleven _Transform, _Describe: the Transform epilogue of level l runs in stage A of level l + 1),
+    a batch of ONE question, and a batch in which no layout is valid (every table empty, zero logits)."""
+    import torch
+    eng, d, w = vqa_setup
+    e, asm = eng.engine, eng.assembler
+    batch = _batch(d, 13)
+    feat_c = eng.features_with_coords(batch['image_feat_batch'])
+    s2s = e.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], d.T_decoder)
+    deep = ['_Find'] + ['_Transform'] * (d.T_decoder - 2) + ['_Describe']          # 13 tokens: no <eos> at all
+    ok_deep = ['_Find'] + ['_Transform'] * (d.T_decoder - 3) + ['_Describe']       # 12 tokens + <eos>
+    toks = np.array([asm.module_list2tokens(ok_deep, d.T_decoder)] * d.N, np.int32).T.copy()
+    toks[:, 1] = [asm.name2idx_dict[m] for m in deep]                                # 'cannot find <eos>'
+    toks[:, 2] = asm.module_list2tokens(['_Find', '_Describe'], d.T_decoder)
+    packed, val_h = asm.assemble_packed(toks)
+    assert not val_h[1] and val_h[0] and val_h[2]
+    host = t2n(e.execute(packed, feat_c, s2s['word_vecs'])).copy()
+    dev, val_d = e.execute_tokens(torch.as_tensor(toks).to(e.device), feat_c, s2s['word_vecs'])
+    assert np.array_equal(t2n(val_d).astype(bool), val_h)
+    assert np.array_equal(t2n(dev), host) and np.all(host[1] == 0.0) and np.abs(host[0]).max() > 0
+    # one question
+    one = np.ascontiguousarray(toks[:, :1])
+    dev1, val1 = e.execute_tokens(torch.as_tensor(one).to(e.device), feat_c[:1], s2s['word_vecs'][:, :1].contiguous())
+    assert t2n(val1).all() and np.array_equal(t2n(dev1)[0], host[0])
+    # nothing valid: Describe needs an input
+    bad = np.full((d.T_decoder, d.N), asm.EOS_idx, np.int32)
+    bad[0] = asm.name2idx_dict['_Describe']
+    dev0, val0 = e.execute_tokens(torch.as_tensor(bad).to(e.device), feat_c, s2s['word_vecs'])
+    assert not t2n(val0).any() and np.all(t2n(dev0) == 0.0)

@@ -169,3 +169,33 @@ def test_throughput_mode_tiles(clevr_engine, n, seed):
     from n2nmn_amd import _lib
     with pytest.raises(ValueError):
         _lib.check(eng._lib.n2nmn_ctx_set_mode(eng._ctx, 7))
+
+
+def test_sequential_decoder_attention_at_wave_boundaries(clevr_engine):
+    """dec_attn_seq_kernel (greedy / sampled decoding, one launch per step): wave w of a question's
+    workgroup takes the encoder rows w, w + 16, ... below the question's length and the 16 running
+    soft-max states meet in LDS -- lengths 1, 2, T and every multiple of 16 +- 1; the attention of the
+    rows past the length is exactly 0 and the rows inside sum to 1 (nmn3_netgen_att.py:190-191)."""
+    eng, d, asm, w = clevr_engine
+    T = d.T_encoder
+    lens = np.array([1, 2, 3, 15, 16, 17, 31, 32, 33, T - 1, T, T, 1, 16, 32, 8] * 4, np.int32)[:d.N]
+    batch = synth.make_inputs(d, seed=21, n=len(lens), min_len=1)
+    seq = batch['input_seq_batch'].copy()
+    seq[np.arange(T)[:, None] >= lens[None, :]] = 0
+    batch = dict(batch, seq_length_batch=lens, input_seq_batch=seq)
+    enc = _oracle_enc(w, batch)
+    dec = O.decoder_forward(w, enc, asm.P, asm.W, asm.b, d.T_decoder, np.float64)
+    out = eng.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], debug=True,
+                      forced_tokens=dec['predicted_tokens'])
+    _check_decoder(out, dec, d)
+    atts = t2n(out['atts'])                                      # [T_dec, T_enc, N]
+    past = np.arange(T)[None, :, None] >= lens[None, None, :]
+    assert np.all(atts[np.broadcast_to(past, atts.shape)] == 0.0)
+    assert np.abs(atts.sum(axis=1) - 1.0).max() < 1e-5
+    # free-running: every layout valid, tokens under the near-tie rule
+    free = eng.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'])
+    tok = t2n(free['predicted_tokens'])
+    _, validity = asm.assemble_packed(tok)
+    assert validity.all()
+    from util import greedy_tokens_under_margin_rule
+    greedy_tokens_under_margin_rule(tok, dec, 'wave-boundary lengths')
