@@ -359,7 +359,7 @@ struct WalkArgs {
   long long* timeline;
 };
 constexpr int WALK_STATS = 10;
-constexpr int WALK_FIND_PARTS = 4;   // workgroups of walk_find_kernel per question (rows of the map)
+constexpr int WALK_FIND_PARTS = 8;   // workgroups of walk_find_kernel per question (rows of the map)
 int walk_supported(int H, int W, int D, int M, int Mp, int HWp, int E, int C, int T, int ksize,
                    int T_enc);
 void launch_walk_textmap(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);

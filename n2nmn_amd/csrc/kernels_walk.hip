@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__(FT) void walk_tmap_kernel(ModuleWeights w, WalkArgs
 }
 
 // rows of a wave in flight per batch (CI float4 column groups each)
-template <int CI> struct FindUnroll { static constexpr int value = CI == 1 ? 10 : (CI == 2 ? 5 : 3); };
+template <int CI> struct FindUnroll { static constexpr int value = CI == 1 ? 5 : (CI == 2 ? 5 : 3); };
 
 // the map rows [rb, rb + UNR * FW) of this wave (row = rb + u * FW), 16 bytes per lane and column group
 template <int CI> struct FindRows { float4 v[FindUnroll<CI>::value][CI]; };
@@ -1193,7 +1193,7 @@ __device__ __forceinline__ void find_rows(int tid, const ModuleWeights& w, const
 // barriers, which every one of the 4 x questions workgroups used to run IN FRONT of its map stream.
 // The rows of the image's conv_image map do not depend on the layout at all: their loads go out first.
 template <int CI, bool ONE>
-__global__ __launch_bounds__(FT) void walk_find_kernel(ModuleWeights w, WalkArgs a) {
+__global__ __launch_bounds__(FT, (CI == 1 ? 8 : 1)) void walk_find_kernel(ModuleWeights w, WalkArgs a) {
   const int q = blockIdx.x;
   const int kb = q / a.N, n = q - kb * a.N;
   const WalkBatch& B = a.b[kb];
@@ -1207,22 +1207,21 @@ __global__ __launch_bounds__(FT) void walk_find_kernel(ModuleWeights w, WalkArgs
   const int nfind = P->valid ? P->nfind : 0;
   const FindRows<CI> pre = find_load<CI>(Mbuf, r0 + (tid >> 6), r1, tid & 63, Mp);
   if (nfind == 0) return;
-  for (int f0 = 0; f0 < nfind; f0 += 4) {
-    const int nf = min(4, nfind - f0);
-    const float* ts[4];
-    float* os[4];
+  // two nodes per sweep over the rows (they sit in registers): the live state of a sweep -- two text maps,
+  // two (sum of squares, dot) pairs per row -- leaves room for five waves per SIMD without spills; four
+  // nodes per sweep took 127 VGPRs
+  for (int f0 = 0; f0 < nfind; f0 += 2) {
+    const int nf = min(2, nfind - f0);
+    const float* ts[2];
+    float* os[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 2; ++j) {
       const int t = P->flist[f0 + min(j, nf - 1)];
       ts[j] = B.tmap + ((size_t)t * a.N + n) * Mp;
       os[j] = B.watt + ((size_t)n * T + t) * HWp;
     }
-    switch (nf) {
-      case 1: find_rows<CI, 1, ONE>(tid, w, Mbuf, ts, os, r0, r1, Mp, pre); break;
-      case 2: find_rows<CI, 2, ONE>(tid, w, Mbuf, ts, os, r0, r1, Mp, pre); break;
-      case 3: find_rows<CI, 3, ONE>(tid, w, Mbuf, ts, os, r0, r1, Mp, pre); break;
-      default: find_rows<CI, 4, ONE>(tid, w, Mbuf, ts, os, r0, r1, Mp, pre); break;
-    }
+    if (nf == 1) find_rows<CI, 1, ONE>(tid, w, Mbuf, ts, os, r0, r1, Mp, pre);
+    else find_rows<CI, 2, ONE>(tid, w, Mbuf, ts, os, r0, r1, Mp, pre);
   }
 }
 
