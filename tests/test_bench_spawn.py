@@ -42,3 +42,17 @@ def test_world_size_must_agree_with_gpus():
     p = _run({'WORLD_SIZE': '4', 'RANK': '0', 'LOCAL_RANK': '0'}, '--gpus', '2')
     assert p.returncode != 0
     assert 'WORLD_SIZE=4' in p.stderr
+
+
+def test_stdout_carries_only_the_result_line():
+    """The driver parses ONE JSON line from stdout; RCCL prints its version banner to stdout when a
+    communicator is created (under torch.distributed.run).  bench.own_stdout() points file descriptor 1 at
+    stderr and keeps the original for emit_line()."""
+    import subprocess
+    code = ("import os, sys; sys.path.insert(0, %r); import bench; bench.own_stdout(); "
+            "print('library noise'); os.write(1, b'raw noise on fd 1\\n'); bench.emit_line('{\"value\": 1}')"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == '{"value": 1}\n'
+    assert 'library noise' in r.stderr and 'raw noise on fd 1' in r.stderr
