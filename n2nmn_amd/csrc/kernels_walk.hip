@@ -1435,15 +1435,17 @@ namespace {
 //          maps) and the soft-max of the deferred pooling roots.
 // In the one-workgroup-per-question walker the heavy nodes sat on each question's chain with one
 // 235-VGPR workgroup per CU (four rounds of 256 questions per 1024: 100 us, 7 % of HBM).  Here
-//   walk_heavy_kernel  runs every heavy node whose input subtree holds no other heavy node as a job of
-//                      its own (list built by walk_tmap_kernel's plan step): the workgroup evaluates
-//                      the (light) input subtree from the Find / Filter logits in `watt`, runs the
+//   walk_heavy_kernel  runs every heavy node as a job of its own, one launch per NESTING LEVEL (level =
+//                      heavy nodes below the node in its own subtree; lists per level and operator built
+//                      by walk_tmap_kernel's plan step): the workgroup evaluates the node's input subtree
+//                      from the Find / Filter logits and the lower levels' maps in `watt`, runs the
 //                      operator with the walker's own device code, and writes the map to watt[n][t];
 //   walk_light_kernel  one workgroup per question: every remaining node from `watt`, the answer
 //                      logits or the deferred-pooling tables;
-//   walk_kernel        only for the questions the plan listed as nested (fblist), as before.
+//   walk_kernel        only for the questions nested deeper than the pass launches levels for (fblist;
+//                      the level count follows the previous passes: n2nmn_walk_layouts).
 // Same arithmetic, operator by operator, as walk_kernel (shared device functions / copied statement
-// by statement), so a question's logits do not depend on which path served it.
+// by statement); the answer heads reduce in another order (logits within 2e-6 between the paths).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void load_prog(int tid, const WalkProg* src, WalkProg& P) {
   const int4* s4 = reinterpret_cast<const int4*>(src);
