@@ -139,6 +139,11 @@ static size_t carve_weights(n2nmn_ctx* c, char* base) {
     c->dec_W0h_64 = k.take<float>(L * 4 * L); c->dec_W1_64 = k.take<float>(2 * L * 4 * L);
     c->enc_W0h_b3 = k.take<uint16_t>(3 * L * 4 * L); c->enc_W1_b3 = k.take<uint16_t>(3 * 2 * L * 4 * L);
     c->dec_W0h_b3 = k.take<uint16_t>(3 * L * 4 * L); c->dec_W1_b3 = k.take<uint16_t>(3 * 2 * L * 4 * L);
+    c->eht_W_b3 = k.take<uint16_t>(3 * (size_t)c->KpL * L); c->att_W_b3 = k.take<uint16_t>(3 * (size_t)c->KpL * L);
+    if (Mp % 128 == 0) {
+      c->find_img_b3 = k.take<uint16_t>(3 * (size_t)c->KpD * Mp);
+      c->fsp_img_b3 = k.take<uint16_t>(3 * (size_t)c->KpD * Mp);
+    }
   }
   c->eht_W_p = k.take<float>((size_t)c->KpL * L);
   c->att_W_t = k.take<float>(L * L);
@@ -353,6 +358,7 @@ static void conv_image_problems(n2nmn_ctx* c, const float* image_feat, int N, co
     g = GemmArgs{};
     g.A = image_feat; g.lda = d.D; g.M = N * HW; g.K = d.D; g.group_size = HW;
     g.Bp = fsp ? c->fsp_img_p : c->find_img_p; g.Np = c->Mp; g.Kp = c->KpD;
+    if (lstm_b3(c, N)) g.Bp3 = fsp ? c->fsp_img_b3 : c->find_img_b3;       // (opt-in mode: gemm_dma3_kernel)
     g.bias = c->vars[fsp ? V_FSP_IMG_B : V_FIND_IMG_B].mirror; g.N = d.map_dim;
     g.C = fsp ? c->mfsp : c->mfind; g.ldc = c->Mp; g.n_store = c->Mp;
     if (fsp && tokens) {
@@ -480,6 +486,7 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmAr
   GemmArgs g{};
   g.A = c->enc_out; g.lda = L; g.M = T * N; g.K = L; g.group_idx = nullptr; g.group_size = 1;
   g.Bp = c->eht_W_p; g.Np = L; g.Kp = c->KpL; g.bias = c->vars[V_EHT_B].mirror; g.N = L;
+  if (b3) g.Bp3 = c->eht_W_b3;
   g.C = c->eht; g.ldc = L; g.n_store = L;
   if (eht_rows) {
     g.group_idx = c->enc_rows; g.group_size = 1; g.src_rows = T * N;
@@ -621,6 +628,7 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
       gq = GemmArgs{};
       gq.A = c->dec_h1_all; gq.lda = L; gq.M = Td * N; gq.K = L; gq.group_size = 1;
       gq.Bp = c->att_W_p; gq.Np = L; gq.Kp = c->KpL; gq.bias = c->vars[V_ATT_B].mirror; gq.N = L;
+      if (lstm_b3(c, N)) gq.Bp3 = c->att_W_b3;
       gq.C = c->qbuf; gq.ldc = L; gq.n_store = L;
       fl += 2.0 * Td * N * L * L; by += 4.0 * ((double)L * L + 2.0 * Td * N * L);
       // the hoisted conv_image problems ride in this launch when the list has room (it holds four);
@@ -1188,6 +1196,15 @@ static void pack_b3(n2nmn_ctx* r, hipStream_t s) {
   launch_pack_tiles64_b3(r->vars[V_ENC_W1].mirror, 4 * L, 0, 2 * L, L, r->enc_W1_b3, s);
   launch_pack_tiles64_b3(r->vars[V_DEC_W0].mirror, 4 * L, E1, L, L, r->dec_W0h_b3, s);
   launch_pack_tiles64_b3(r->vars[V_DEC_W1].mirror, 4 * L, 0, 2 * L, L, r->dec_W1_b3, s);
+  // the PK-packed GEMM weights of a pass (they are packed earlier in the same commit)
+  if (r->eht_W_b3) {
+    launch_pack_pk_b3(r->eht_W_p, r->KpL, L, r->eht_W_b3, s);
+    launch_pack_pk_b3(r->att_W_p, r->KpL, L, r->att_W_b3, s);
+  }
+  if (r->find_img_b3) {
+    launch_pack_pk_b3(r->find_img_p, r->KpD, r->Mp, r->find_img_b3, s);
+    launch_pack_pk_b3(r->fsp_img_p, r->KpD, r->Mp, r->fsp_img_b3, s);
+  }
 }
 
 int n2nmn_ctx_set_mode(n2nmn_ctx* ctx, int mode) {
@@ -1952,17 +1969,28 @@ int n2nmn_debug_gemm(n2nmn_ctx* ctx, const float* A, const float* B, const float
   N2_REQUIRE(ctx && A && B && C, N2NMN_EINVAL, "debug_gemm: null argument");
   N2_REQUIRE(M > 0 && N > 0 && K > 0 && K % 4 == 0, N2NMN_EINVAL,
              "debug_gemm: K must be a positive multiple of 4");
-  const int Kp = round_up(K, 32), Np = round_up(N, 64);
+  // N2NMN_DEBUG_GEMM_B3=1 (read per call): the split-operand bf16 form (gemm_dma3_kernel)
+  const char* e3 = getenv("N2NMN_DEBUG_GEMM_B3");
+  const bool b3 = e3 && atoi(e3) > 0;
+  const int Kp = round_up(K, 32), Np = round_up(N, b3 ? 128 : 64);
   float* Bp = nullptr;
+  uint16_t* Bp3 = nullptr;
   N2_HIP(hipMalloc(reinterpret_cast<void**>(&Bp), sizeof(float) * (size_t)Kp * Np));
   hipStream_t s = S(stream);
   launch_pack_pk(B, N, K, N, Bp, Kp, Np, s);
   GemmArgs g{};
   g.A = A; g.lda = K; g.M = M; g.K = K; g.group_size = 1; g.Bp = Bp; g.Np = Np; g.Kp = Kp;
   g.bias = bias; g.N = N; g.C = C; g.ldc = N; g.n_store = N;
-  launch_gemm_pk(g, s);
+  if (b3) {
+    N2_HIP(hipMalloc(reinterpret_cast<void**>(&Bp3), sizeof(uint16_t) * 3 * (size_t)Kp * Np));
+    launch_pack_pk_b3(Bp, Kp, Np, Bp3, s);
+    g.Bp3 = Bp3;
+  }
+  const int reps = e3 && atoi(e3) < 0 ? -atoi(e3) : 1;       // (negative: fp32 form, that many launches)
+  for (int i = 0; i < (b3 ? atoi(e3) : reps); ++i) launch_gemm_pk(g, s);
   N2_HIP(hipStreamSynchronize(s));       // debug entry only: Bp is freed right away
   N2_HIP(hipFree(Bp));
+  if (Bp3) N2_HIP(hipFree(Bp3));
   return check_launch("debug_gemm");
 }
 

@@ -156,6 +156,8 @@ struct n2nmn_ctx {
   // ... and as three bf16 planes per tile for lstm_tile3_kernel (N2NMN_MODE_THROUGHPUT_BF16X3; packed by
   // a commit once the mode has been requested on the root or a fork: b3_on)
   uint16_t *enc_W0h_b3 = nullptr, *enc_W1_b3 = nullptr, *dec_W0h_b3 = nullptr, *dec_W1_b3 = nullptr;
+  // ... and of the PK-packed GEMM weights (gemm_dma3_kernel): encoder_h_transform, W_a, the two conv_image sets
+  uint16_t *eht_W_b3 = nullptr, *att_W_b3 = nullptr, *find_img_b3 = nullptr, *fsp_img_b3 = nullptr;
   bool b3_on = false;
   float *eht_W_p = nullptr, *att_W_t = nullptr, *att_W_p = nullptr, *find_img_p = nullptr, *fsp_img_p = nullptr;
   float* dec_emb_cat = nullptr;

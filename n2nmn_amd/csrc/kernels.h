@@ -23,6 +23,8 @@ struct GemmArgs {
                                               // row is not bounded by M); 0 = unknown (kernels that
                                               // need the bound -- 32-bit offsets -- then refuse)
   const float* Bp; int Np; int Kp;
+  const uint16_t* Bp3;                        // optional: Bp as three bf16 planes (launch_pack_pk_b3): the
+                                              // launch may run as split-operand bf16 (gemm_dma3_kernel)
   const float* bias; int N;
   float* C; int ldc; int n_store;
   int accumulate;                             // != 0: C += A.B (+ bias) instead of C = ...
@@ -51,6 +53,11 @@ void launch_gemm_pkn(const GemmArgs* a, int n, hipStream_t s);
 // launch_gemm_pkn / launch_gemm_pk route there when every problem of the launch qualifies
 bool gemm_dma_supported(const GemmArgs& a);
 void launch_gemm_dma(const GemmArgs* a, int n, hipStream_t s);
+// the same contraction on bf16 MFMAs over three-way split operands (kernels_gemm_dma3.hip; opt-in mode
+// N2NMN_MODE_THROUGHPUT_BF16X3): problems that carry Bp3.  dst: 3 * Kp * Np bf16.
+bool gemm_dma3_supported(const GemmArgs& a);
+void launch_gemm_dma3(const GemmArgs* a, int n, hipStream_t s);
+void launch_pack_pk_b3(const float* Bp, int Kp, int Np, uint16_t* dst, hipStream_t s);
 
 // generic packer: dst PK layout <- src[k*ld + n] (k < K, n < N), zero padded
 void launch_pack_pk(const float* src, int ld, int K, int N, float* dst, int Kp, int Np,

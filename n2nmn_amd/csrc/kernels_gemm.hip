@@ -382,7 +382,22 @@ static bool use_gemm_dma(const GemmArgs* a, int n) {
   return tiles >= min_tiles;
 }
 
+// split-operand bf16 form of a launch: every problem carries its weight planes (the caller sets Bp3 only in
+// the opt-in mode) and fits the kernel
+static bool use_gemm_dma3(const GemmArgs* a, int n) {
+  static const int on = [] { const char* e = getenv("N2NMN_GEMM_DMA3"); return e ? atoi(e) : 1; }();
+  if (!on) return false;
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    if (a[i].M <= 0) continue;
+    if (!gemm_dma3_supported(a[i])) return false;
+    tiles += ((a[i].M + 63) / 64) * ((a[i].n_store + 127) / 128);
+  }
+  return tiles >= 256;
+}
+
 void launch_gemm_pkn(const GemmArgs* a, int n, hipStream_t s) {
+  if (use_gemm_dma3(a, n)) { launch_gemm_dma3(a, n, s); return; }
   if (use_gemm_dma(a, n)) { launch_gemm_dma(a, n, s); return; }
   GemmBatch b{};
   int tiles = 0, np = 0;
@@ -399,6 +414,7 @@ void launch_gemm_pkn(const GemmArgs* a, int n, hipStream_t s) {
 }
 
 void launch_gemm_pk(const GemmArgs& a, hipStream_t s) {
+  if (use_gemm_dma3(&a, 1)) { launch_gemm_dma3(&a, 1, s); return; }
   if (use_gemm_dma(&a, 1)) { launch_gemm_dma(&a, 1, s); return; }
   dim3 grid((a.n_store + BN - 1) / BN, (a.M + BM - 1) / BM, a.ksplit > 1 ? a.ksplit : 1);
   if (a.M <= 0) return;

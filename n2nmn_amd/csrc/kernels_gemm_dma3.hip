@@ -1,0 +1,259 @@
+// gemm_dma3_kernel: the dense contractions of a pass (encoder_h_transform, the decoder's W_a projection,
+// the hoisted conv_image 1x1 convolutions: see kernels_gemm_dma.hip) in the OPT-IN split-operand bf16 mode
+// (N2NMN_MODE_THROUGHPUT_BF16X3, kernels_lstm_tile3.hip): x = hi + mid + lo exactly (three bf16, round to
+// nearest, exact residuals), 6 of the 9 cross products on v_mfma_f32_16x16x32_bf16, fp32 accumulate.
+//
+//   * B (weights) is split ONCE per commit (pack_pk_b3_kernel) into fragment-ordered planes
+//     [K/32][Np/128][3 planes][8 column tiles][64 lanes][8 bf16]: a stage of a 128-column tile is 24
+//     contiguous KiB, moved by LDS-DMA and read back as it lies (ds_read_b128 per plane and column tile);
+//   * A (activations: image features, encoder outputs, decoder outputs) stays fp32 in HBM and reaches LDS
+//     by LDS-DMA exactly as in gemm_dma_kernel (row-major [row][8 chunks of 16 B], swizzled on the source
+//     side); a wave reads the 8 consecutive k of its row (two chunks), splits them in registers (5.5 VALU
+//     instructions per element, once per 24 MFMAs) and feeds the matrix cores directly -- a pre-split A
+//     would cost an extra pass over the activations;
+//   * workgroup tile 64 rows x 128 columns, 8 waves (4 row tiles x 2 column halves), two stages of 32 KiB:
+//     two workgroups per CU.  A wave: 1 A fragment (3 planes), 4 column tiles x 3 planes of B, 24 MFMAs
+//     per 32 k.
+// Gather / scatter / device row count / token gate as in gemm_dma_kernel.
+#include <algorithm>
+
+#include "device_utils.h"
+#include "kernels.h"
+
+namespace n2nmn {
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int M3 = 64, N3 = 128, K3 = 32;
+constexpr int G3_THREADS = 512;
+constexpr int A3_IMAGE = M3 * K3 * 4;                    // 8 KiB fp32
+constexpr int B3_IMAGE = 3 * N3 * K3 * 2;                // 24 KiB: [plane][column tile][lane][16 B]
+constexpr int G3_STAGE = A3_IMAGE + B3_IMAGE;            // 32 KiB
+
+__device__ __forceinline__ void glds16_3(const void* base, uint32_t voff, uint32_t lds) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(base), "s"(lds)
+      : "memory");
+}
+
+__device__ __forceinline__ void gemm_dma3_body(const GemmArgs& a, const int bx, const int by) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  const int m0 = by * M3, n0 = bx * N3;
+  const int M = a.m_dev ? min(a.M, *a.m_dev) : a.M;      // (rows that exist: GemmArgs::m_dev)
+  if (m0 >= M) return;
+  if (a.gate_tokens) {        // uniform early exit: none of this tile's images needs the map
+    // (every wave evaluates the same predicate: no LDS word, the two stages are all of this kernel's LDS)
+    const int g0 = m0 / a.gate_rows, g1 = min(m0 + M3 - 1, M - 1) / a.gate_rows;
+    const int per = a.gate_T;
+    bool need = false;
+    for (int i = lane; i < (g1 - g0 + 1) * per; i += 64) {
+      const int g = g0 + i / per, t = i % per;
+      const int tok = a.gate_tokens[(size_t)t * a.gate_N + g];
+      need |= tok >= 0 && tok < a.gate_V && a.gate_token_op[tok] == a.gate_op;
+    }
+    if (!__any(need)) return;
+  }
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const int nst = a.Kp / K3;
+
+  // ---- DMA roles: wave w moves A rows [8w, 8w + 8) (one piece of 8 rows x 128 B) and pieces 3w .. 3w + 2
+  // of the stage's 24 KiB of B planes ---------------------------------------------------------------
+  uint32_t a_off, a_sw;
+  {
+    const int row = 8 * w + (lane >> 3);
+    int gm = m0 + row;
+    gm = gm < M ? gm : M - 1;
+    if (a.group_idx) {
+      const int g = gm / a.group_size;
+      gm = a.group_idx[g] * a.group_size + (gm - g * a.group_size);
+    }
+    a_off = (uint32_t)gm * (uint32_t)a.lda * 4u;
+    a_sw = (uint32_t)((lane & 7) ^ ((row >> 1) & 7));      // chunk this lane fetches
+  }
+  const float* const Ap = a.A;
+  const uint16_t* const Bp = a.Bp3;
+  const uint32_t b_tile = (uint32_t)bx * (uint32_t)B3_IMAGE + (uint32_t)(3 * w) * 1024u + (uint32_t)lane * 16u;
+  const uint32_t b_slab = (uint32_t)(a.Np / N3) * (uint32_t)B3_IMAGE;       // bytes per 32 k of B planes
+  const int Klast = a.K - 4;
+  auto issue = [&](int s) {
+    const uint32_t st = lds0 + (uint32_t)(s & 1) * G3_STAGE;
+    // columns past K (Kp padding) meet zero weights: any finite in-bounds value will do
+    const int k = min(s * K3 + 4 * (int)a_sw, Klast);
+    glds16_3(Ap, a_off + (uint32_t)k * 4u, st + (uint32_t)(8 * w) * 128u);
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+      glds16_3(Bp, b_tile + (uint32_t)s * b_slab + (uint32_t)u * 1024u,
+               st + A3_IMAGE + (uint32_t)(3 * w + u) * 1024u);
+  };
+
+  // ---- fragment addressing: MFMA 16x16x32 -- lane holds 8 consecutive k (k group lane >> 4) of row /
+  // column lane & 15 ----------------------------------------------------------------------------------
+  const int li = lane & 15, kg = lane >> 4;
+  const int arow = wm * 16 + li;
+  const uint32_t a_base = (uint32_t)arow * 128u;
+  const uint32_t a_x = (uint32_t)((arow >> 1) & 7);
+  const uint32_t a_c0 = (((uint32_t)(2 * kg)) ^ a_x) << 4, a_c1 = (((uint32_t)(2 * kg + 1)) ^ a_x) << 4;
+  // B planes of this wave's column half: [plane][column tile 4 wn + ct][lane][16 B]
+  const uint32_t b_base = (uint32_t)A3_IMAGE + (uint32_t)(4 * wn) * 1024u + (uint32_t)lane * 16u;
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  struct BFrag { uint4 p[3]; };
+  auto read_b = [&](const char* st, int ct) {
+    BFrag f;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      f.p[p] = *reinterpret_cast<const uint4*>(st + b_base + (uint32_t)(p * 8 + ct) * 1024u);
+    return f;
+  };
+
+  issue(0);
+  for (int s = 0; s < nst; ++s) {
+    // this wave's pieces of stage s have landed; after the barrier everyone's have, and everyone is
+    // done reading stage s - 1, whose buffer the DMA of stage s + 1 refills under this stage's MFMAs
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (s + 1 < nst) issue(s + 1);
+    const char* st = smem + (size_t)(s & 1) * G3_STAGE;
+    const float4 x0 = *reinterpret_cast<const float4*>(st + a_base + a_c0);
+    const float4 x1 = *reinterpret_cast<const float4*>(st + a_base + a_c1);
+    BFrag P = read_b(st, 0);
+    // the fp32 A fragment as three bf16 planes (x = hi + mid + lo exactly)
+    uint32_t ah[4], am[4], al[4];
+    split3(x0.x, x0.y, ah[0], am[0], al[0]);
+    split3(x0.z, x0.w, ah[1], am[1], al[1]);
+    split3(x1.x, x1.y, ah[2], am[2], al[2]);
+    split3(x1.z, x1.w, ah[3], am[3], al[3]);
+    const bf16x8 Ah = __builtin_bit_cast(bf16x8, make_uint4(ah[0], ah[1], ah[2], ah[3]));
+    const bf16x8 Am = __builtin_bit_cast(bf16x8, make_uint4(am[0], am[1], am[2], am[3]));
+    const bf16x8 Al = __builtin_bit_cast(bf16x8, make_uint4(al[0], al[1], al[2], al[3]));
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      BFrag Q;
+      if (ct + 1 < 4) Q = read_b(st, ct + 1);
+      __builtin_amdgcn_sched_barrier(0);       // (left alone, hipcc sinks the reads below the MFMAs)
+      const bf16x8 Bh = __builtin_bit_cast(bf16x8, P.p[0]), Bm = __builtin_bit_cast(bf16x8, P.p[1]),
+                   Bl = __builtin_bit_cast(bf16x8, P.p[2]);
+      f32x4 c = acc[ct];
+      // the six products: small terms first, the leading term last
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bm, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bh, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bm, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh, c, 0, 0, 0);
+      acc[ct] = c;
+      if (ct + 1 < 4) P = Q;
+    }
+  }
+
+  // ---- epilogue: C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + r -----------------
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    const int col = n0 + wn * 64 + 16 * ct + li;
+    if (col >= a.n_store) continue;
+    const float bias = (a.bias && col < a.N) ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + wm * 16 + 4 * kg + r;
+      if (row < M) {
+        float val = (col < a.N) ? acc[ct][r] + bias : 0.f;
+        if (a.relu) val = fmaxf(val, 0.f);
+        int orow = row;
+        if (a.c_row_idx) {
+          orow = a.c_row_idx[row];
+          if (orow < 0) continue;
+        }
+        float* dst = a.C + (size_t)orow * a.ldc + col;
+        *dst = a.accumulate ? *dst + val : val;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(G3_THREADS, 4) void gemm_dma3_kernel(GemmBatch b) {
+  // consecutive workgroup ids go round-robin over the 8 XCDs: runs of 8 consecutive list positions
+  // (column tiles of neighbouring row tiles, which share their A rows) execute on ONE XCD, the runs rotate
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int t = (((slot >> 3) << 3) + xcd) * 8 + (slot & 7);
+  if (t >= b.start[4]) return;
+  const int p = (t >= b.start[1]) + (t >= b.start[2]) + (t >= b.start[3]);
+  const GemmArgs& a = b.a[p];
+  const int local = t - b.start[p];
+  const int gx = (a.n_store + N3 - 1) / N3;
+  gemm_dma3_body(a, local % gx, local / gx);
+}
+
+// PK pack [Kp/4][Np][4] fp32 (zero padded) -> planes [Kp/32][Np/128][3][8][64][8] bf16
+__global__ __launch_bounds__(256) void pack_pk_b3_kernel(const float* __restrict__ Bp, int Kp, int Np,
+                                                         uint16_t* __restrict__ dst) {
+  const size_t total = (size_t)(Kp / 32) * (Np / 128) * 8 * 64;        // fragments per plane
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63), ct = (int)((i >> 6) & 7);
+    const size_t r = i >> 9;
+    const int nt = (int)(r % (Np / 128)), kt = (int)(r / (Np / 128));
+    const int n = 128 * nt + 16 * ct + (lane & 15), k0 = 32 * kt + 8 * (lane >> 4);
+    uint32_t pl[3][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = k0 + 2 * e;                                          // k, k + 1: same k4 group
+      const float x0 = Bp[((size_t)(k >> 2) * Np + n) * 4 + (k & 3)];
+      const float x1 = Bp[((size_t)(k >> 2) * Np + n) * 4 + (k & 3) + 1];
+      split3(x0, x1, pl[0][e], pl[1][e], pl[2][e]);
+    }
+    const size_t base = ((size_t)kt * (Np / 128) + nt) * 3;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      *reinterpret_cast<uint4*>(dst + (((base + p) * 8 + ct) * 64 + lane) * 8) =
+          make_uint4(pl[p][0], pl[p][1], pl[p][2], pl[p][3]);
+  }
+}
+
+}  // namespace
+
+bool gemm_dma3_supported(const GemmArgs& a) {
+  const size_t a_rows = a.group_idx ? (size_t)a.src_rows : (size_t)a.M;
+  if (!a.Bp3 || (a.group_idx && a.src_rows <= 0)) return false;
+  return a.M >= M3 && a.Np % N3 == 0 && a.Kp % K3 == 0 && a.K % 4 == 0 && a.K >= 4 && a.lda % 4 == 0 &&
+         a.ksplit <= 1 && a_rows * a.lda * 4 < ((size_t)1 << 32) &&
+         (size_t)a.Kp * a.Np * 6 < ((size_t)1 << 32) && (!a.gate_tokens || a.gate_T <= 64);
+}
+
+void launch_gemm_dma3(const GemmArgs* a, int n, hipStream_t s) {
+  GemmBatch b{};
+  int tiles = 0, np = 0;
+  for (int i = 0; i < n && np < 4; ++i) {
+    if (a[i].M <= 0) continue;
+    b.a[np] = a[i];
+    b.start[np] = tiles;
+    tiles += ((a[i].n_store + N3 - 1) / N3) * ((a[i].M + M3 - 1) / M3);
+    ++np;
+  }
+  if (!np) return;
+  for (int i = np; i <= 4; ++i) b.start[i] = tiles;
+  static std::atomic<uint64_t> attr{0};
+  ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_dma3_kernel), 2 * G3_STAGE, attr);
+  hipLaunchKernelGGL(gemm_dma3_kernel, dim3((tiles + 63) / 64 * 64), dim3(G3_THREADS), 2 * G3_STAGE, s, b);
+}
+
+void launch_pack_pk_b3(const float* Bp, int Kp, int Np, uint16_t* dst, hipStream_t s) {
+  const size_t total = (size_t)(Kp / 32) * (Np / 128) * 8 * 64;
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
+  hipLaunchKernelGGL(pack_pk_b3_kernel, dim3(blocks), dim3(256), 0, s, Bp, Kp, Np, dst);
+}
+
+}  // namespace n2nmn

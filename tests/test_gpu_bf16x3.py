@@ -123,3 +123,33 @@ def test_bf16x3_encoder_states_and_decoder_outputs():
     free = eng.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'])
     dec = O.decoder_forward(w, ref_enc, P, Wv, bv, d.T_decoder, np.float64)
     greedy_tokens_under_margin_rule(t2n(free['predicted_tokens']), dec, 'bf16x3 greedy')
+
+
+@pytest.mark.parametrize('M,N,K', [(1000, 250, 300), (4096, 512, 512), (2500, 1024, 2064)])
+def test_split_operand_gemm_is_as_accurate_as_the_fp32_gemm(clevr_engine, M, N, K):
+    """gemm_dma3_kernel (the mode's dense contractions: fp32 activations split in registers, weights split
+    at commit, 6 bf16 products, fp32 accumulate) through n2nmn_debug_gemm: against torch fp64, and against
+    the error of the exact-fp32 kernels on the same operands (ragged sizes, K not a multiple of 32, the
+    models_vqa conv_image shape)."""
+    import os
+    import torch
+    from n2nmn_amd import _lib
+    eng = clevr_engine[0]
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn((M, K), generator=g) * (0.2 + 3 * torch.rand((M, 1), generator=g))).to(eng.device)
+    B = (torch.randn((K, N), generator=g) / K ** 0.5).to(eng.device)
+    bias = torch.randn((N,), generator=g).to(eng.device)
+    ref = (A.double() @ B.double() + bias.double()).cpu().numpy()
+    err = {}
+    try:
+        for mode, env in (('fp32', '-1'), ('bf16x3', '1')):
+            os.environ['N2NMN_DEBUG_GEMM_B3'] = env
+            out = torch.full((M, N), float('nan'), device=eng.device)
+            _lib.check(eng._lib.n2nmn_debug_gemm(eng._ctx, A.data_ptr(), B.data_ptr(), bias.data_ptr(),
+                                                 out.data_ptr(), M, N, K, eng.stream()))
+            err[mode] = float(np.abs(out.cpu().numpy() - ref).max())
+    finally:
+        os.environ.pop('N2NMN_DEBUG_GEMM_B3', None)
+    scale = float(np.abs(ref).max())
+    assert err['bf16x3'] <= 4e-6 * scale, err
+    assert err['bf16x3'] <= 2.0 * err['fp32'] + 1e-7, err
