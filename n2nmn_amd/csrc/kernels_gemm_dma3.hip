@@ -26,11 +26,16 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int M3 = 64, N3 = 128, K3 = 32;
+// MT = 16-row tiles per wave: workgroup tile 64 MT rows x 128 columns (MT = 2: every B fragment read from
+// LDS serves two row tiles -- the 64-row tile spends as long reading LDS as on the matrix cores)
+constexpr int N3 = 128, K3 = 32;
 constexpr int G3_THREADS = 512;
-constexpr int A3_IMAGE = M3 * K3 * 4;                    // 8 KiB fp32
 constexpr int B3_IMAGE = 3 * N3 * K3 * 2;                // 24 KiB: [plane][column tile][lane][16 B]
-constexpr int G3_STAGE = A3_IMAGE + B3_IMAGE;            // 32 KiB
+template <int MT> struct G3 {
+  static constexpr int M = 64 * MT;
+  static constexpr int A_IMAGE = M * K3 * 4;             // 8 KiB fp32 per 64 rows
+  static constexpr int STAGE = A_IMAGE + B3_IMAGE;       // 32 / 40 KiB
+};
 
 __device__ __forceinline__ void glds16_3(const void* base, uint32_t voff, uint32_t lds) {
   uint32_t keep;
@@ -45,7 +50,9 @@ __device__ __forceinline__ void glds16_3(const void* base, uint32_t voff, uint32
       : "memory");
 }
 
+template <int MT>
 __device__ __forceinline__ void gemm_dma3_body(const GemmArgs& a, const int bx, const int by) {
+  constexpr int M3 = G3<MT>::M, A3_IMAGE = G3<MT>::A_IMAGE, G3_STAGE = G3<MT>::STAGE;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -70,17 +77,18 @@ __device__ __forceinline__ void gemm_dma3_body(const GemmArgs& a, const int bx, 
 
   // ---- DMA roles: wave w moves A rows [8w, 8w + 8) (one piece of 8 rows x 128 B) and pieces 3w .. 3w + 2
   // of the stage's 24 KiB of B planes ---------------------------------------------------------------
-  uint32_t a_off, a_sw;
-  {
-    const int row = 8 * w + (lane >> 3);
+  uint32_t a_off[MT], a_sw[MT];
+#pragma unroll
+  for (int u = 0; u < MT; ++u) {
+    const int row = 8 * (w + 8 * u) + (lane >> 3);
     int gm = m0 + row;
     gm = gm < M ? gm : M - 1;
     if (a.group_idx) {
       const int g = gm / a.group_size;
       gm = a.group_idx[g] * a.group_size + (gm - g * a.group_size);
     }
-    a_off = (uint32_t)gm * (uint32_t)a.lda * 4u;
-    a_sw = (uint32_t)((lane & 7) ^ ((row >> 1) & 7));      // chunk this lane fetches
+    a_off[u] = (uint32_t)gm * (uint32_t)a.lda * 4u;
+    a_sw[u] = (uint32_t)((lane & 7) ^ ((row >> 1) & 7));      // chunk this lane fetches
   }
   const float* const Ap = a.A;
   const uint16_t* const Bp = a.Bp3;
@@ -90,8 +98,11 @@ __device__ __forceinline__ void gemm_dma3_body(const GemmArgs& a, const int bx, 
   auto issue = [&](int s) {
     const uint32_t st = lds0 + (uint32_t)(s & 1) * G3_STAGE;
     // columns past K (Kp padding) meet zero weights: any finite in-bounds value will do
-    const int k = min(s * K3 + 4 * (int)a_sw, Klast);
-    glds16_3(Ap, a_off + (uint32_t)k * 4u, st + (uint32_t)(8 * w) * 128u);
+#pragma unroll
+    for (int u = 0; u < MT; ++u) {
+      const int k = min(s * K3 + 4 * (int)a_sw[u], Klast);
+      glds16_3(Ap, a_off[u] + (uint32_t)k * 4u, st + (uint32_t)(8 * (w + 8 * u)) * 128u);
+    }
 #pragma unroll
     for (int u = 0; u < 3; ++u)
       glds16_3(Bp, b_tile + (uint32_t)s * b_slab + (uint32_t)u * 1024u,
@@ -101,15 +112,21 @@ __device__ __forceinline__ void gemm_dma3_body(const GemmArgs& a, const int bx, 
   // ---- fragment addressing: MFMA 16x16x32 -- lane holds 8 consecutive k (k group lane >> 4) of row /
   // column lane & 15 ----------------------------------------------------------------------------------
   const int li = lane & 15, kg = lane >> 4;
-  const int arow = wm * 16 + li;
-  const uint32_t a_base = (uint32_t)arow * 128u;
-  const uint32_t a_x = (uint32_t)((arow >> 1) & 7);
-  const uint32_t a_c0 = (((uint32_t)(2 * kg)) ^ a_x) << 4, a_c1 = (((uint32_t)(2 * kg + 1)) ^ a_x) << 4;
+  uint32_t a_c0[MT], a_c1[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int arow = (wm * MT + t) * 16 + li;
+    const uint32_t a_x = (uint32_t)((arow >> 1) & 7);
+    a_c0[t] = (uint32_t)arow * 128u + ((((uint32_t)(2 * kg)) ^ a_x) << 4);
+    a_c1[t] = (uint32_t)arow * 128u + ((((uint32_t)(2 * kg + 1)) ^ a_x) << 4);
+  }
   // B planes of this wave's column half: [plane][column tile 4 wn + ct][lane][16 B]
   const uint32_t b_base = (uint32_t)A3_IMAGE + (uint32_t)(4 * wn) * 1024u + (uint32_t)lane * 16u;
-  f32x4 acc[4];
+  f32x4 acc[MT][4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   struct BFrag { uint4 p[3]; };
   auto read_b = [&](const char* st, int ct) {
@@ -128,18 +145,26 @@ __device__ __forceinline__ void gemm_dma3_body(const GemmArgs& a, const int bx, 
     __builtin_amdgcn_s_barrier();
     if (s + 1 < nst) issue(s + 1);
     const char* st = smem + (size_t)(s & 1) * G3_STAGE;
-    const float4 x0 = *reinterpret_cast<const float4*>(st + a_base + a_c0);
-    const float4 x1 = *reinterpret_cast<const float4*>(st + a_base + a_c1);
+    float4 x0[MT], x1[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      x0[t] = *reinterpret_cast<const float4*>(st + a_c0[t]);
+      x1[t] = *reinterpret_cast<const float4*>(st + a_c1[t]);
+    }
     BFrag P = read_b(st, 0);
-    // the fp32 A fragment as three bf16 planes (x = hi + mid + lo exactly)
-    uint32_t ah[4], am[4], al[4];
-    split3(x0.x, x0.y, ah[0], am[0], al[0]);
-    split3(x0.z, x0.w, ah[1], am[1], al[1]);
-    split3(x1.x, x1.y, ah[2], am[2], al[2]);
-    split3(x1.z, x1.w, ah[3], am[3], al[3]);
-    const bf16x8 Ah = __builtin_bit_cast(bf16x8, make_uint4(ah[0], ah[1], ah[2], ah[3]));
-    const bf16x8 Am = __builtin_bit_cast(bf16x8, make_uint4(am[0], am[1], am[2], am[3]));
-    const bf16x8 Al = __builtin_bit_cast(bf16x8, make_uint4(al[0], al[1], al[2], al[3]));
+    // the fp32 A fragments as three bf16 planes (x = hi + mid + lo exactly)
+    bf16x8 Ah[MT], Am[MT], Al[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      uint32_t ah[4], am[4], al[4];
+      split3(x0[t].x, x0[t].y, ah[0], am[0], al[0]);
+      split3(x0[t].z, x0[t].w, ah[1], am[1], al[1]);
+      split3(x1[t].x, x1[t].y, ah[2], am[2], al[2]);
+      split3(x1[t].z, x1[t].w, ah[3], am[3], al[3]);
+      Ah[t] = __builtin_bit_cast(bf16x8, make_uint4(ah[0], ah[1], ah[2], ah[3]));
+      Am[t] = __builtin_bit_cast(bf16x8, make_uint4(am[0], am[1], am[2], am[3]));
+      Al[t] = __builtin_bit_cast(bf16x8, make_uint4(al[0], al[1], al[2], al[3]));
+    }
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
       BFrag Q;
@@ -147,15 +172,18 @@ __device__ __forceinline__ void gemm_dma3_body(const GemmArgs& a, const int bx, 
       __builtin_amdgcn_sched_barrier(0);       // (left alone, hipcc sinks the reads below the MFMAs)
       const bf16x8 Bh = __builtin_bit_cast(bf16x8, P.p[0]), Bm = __builtin_bit_cast(bf16x8, P.p[1]),
                    Bl = __builtin_bit_cast(bf16x8, P.p[2]);
-      f32x4 c = acc[ct];
-      // the six products: small terms first, the leading term last
-      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bm, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bh, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bm, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh, c, 0, 0, 0);
-      acc[ct] = c;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        f32x4 c = acc[t][ct];
+        // the six products: small terms first, the leading term last
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al[t], Bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[t], Bl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am[t], Bm, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am[t], Bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[t], Bm, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[t], Bh, c, 0, 0, 0);
+        acc[t][ct] = c;
+      }
       if (ct + 1 < 4) P = Q;
     }
   }
@@ -167,23 +195,26 @@ __device__ __forceinline__ void gemm_dma3_body(const GemmArgs& a, const int bx, 
     if (col >= a.n_store) continue;
     const float bias = (a.bias && col < a.N) ? a.bias[col] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = m0 + wm * 16 + 4 * kg + r;
-      if (row < M) {
-        float val = (col < a.N) ? acc[ct][r] + bias : 0.f;
-        if (a.relu) val = fmaxf(val, 0.f);
-        int orow = row;
-        if (a.c_row_idx) {
-          orow = a.c_row_idx[row];
-          if (orow < 0) continue;
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + (wm * MT + t) * 16 + 4 * kg + r;
+        if (row < M) {
+          float val = (col < a.N) ? acc[t][ct][r] + bias : 0.f;
+          if (a.relu) val = fmaxf(val, 0.f);
+          int orow = row;
+          if (a.c_row_idx) {
+            orow = a.c_row_idx[row];
+            if (orow < 0) continue;
+          }
+          float* dst = a.C + (size_t)orow * a.ldc + col;
+          *dst = a.accumulate ? *dst + val : val;
         }
-        float* dst = a.C + (size_t)orow * a.ldc + col;
-        *dst = a.accumulate ? *dst + val : val;
       }
-    }
   }
 }
 
+template <int MT>
 __global__ __launch_bounds__(G3_THREADS, 4) void gemm_dma3_kernel(GemmBatch b) {
   // consecutive workgroup ids go round-robin over the 8 XCDs: runs of 8 consecutive list positions
   // (column tiles of neighbouring row tiles, which share their A rows) execute on ONE XCD, the runs rotate
@@ -194,7 +225,7 @@ __global__ __launch_bounds__(G3_THREADS, 4) void gemm_dma3_kernel(GemmBatch b) {
   const GemmArgs& a = b.a[p];
   const int local = t - b.start[p];
   const int gx = (a.n_store + N3 - 1) / N3;
-  gemm_dma3_body(a, local % gx, local / gx);
+  gemm_dma3_body<MT>(a, local % gx, local / gx);
 }
 
 // PK pack [Kp/4][Np][4] fp32 (zero padded) -> planes [Kp/32][Np/128][3][8][64][8] bf16
@@ -228,12 +259,14 @@ __global__ __launch_bounds__(256) void pack_pk_b3_kernel(const float* __restrict
 bool gemm_dma3_supported(const GemmArgs& a) {
   const size_t a_rows = a.group_idx ? (size_t)a.src_rows : (size_t)a.M;
   if (!a.Bp3 || (a.group_idx && a.src_rows <= 0)) return false;
-  return a.M >= M3 && a.Np % N3 == 0 && a.Kp % K3 == 0 && a.K % 4 == 0 && a.K >= 4 && a.lda % 4 == 0 &&
+  return a.M >= 64 && a.Np % N3 == 0 && a.Kp % K3 == 0 && a.K % 4 == 0 && a.K >= 4 && a.lda % 4 == 0 &&
          a.ksplit <= 1 && a_rows * a.lda * 4 < ((size_t)1 << 32) &&
          (size_t)a.Kp * a.Np * 6 < ((size_t)1 << 32) && (!a.gate_tokens || a.gate_T <= 64);
 }
 
-void launch_gemm_dma3(const GemmArgs* a, int n, hipStream_t s) {
+template <int MT>
+static void launch3(const GemmArgs* a, int n, hipStream_t s) {
+  constexpr int M3 = G3<MT>::M;
   GemmBatch b{};
   int tiles = 0, np = 0;
   for (int i = 0; i < n && np < 4; ++i) {
@@ -246,8 +279,18 @@ void launch_gemm_dma3(const GemmArgs* a, int n, hipStream_t s) {
   if (!np) return;
   for (int i = np; i <= 4; ++i) b.start[i] = tiles;
   static std::atomic<uint64_t> attr{0};
-  ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_dma3_kernel), 2 * G3_STAGE, attr);
-  hipLaunchKernelGGL(gemm_dma3_kernel, dim3((tiles + 63) / 64 * 64), dim3(G3_THREADS), 2 * G3_STAGE, s, b);
+  ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_dma3_kernel<MT>), 2 * G3<MT>::STAGE, attr);
+  hipLaunchKernelGGL(gemm_dma3_kernel<MT>, dim3((tiles + 63) / 64 * 64), dim3(G3_THREADS), 2 * G3<MT>::STAGE, s, b);
+}
+
+void launch_gemm_dma3(const GemmArgs* a, int n, hipStream_t s) {
+  // 128-row tiles when they still cover the chip a few times over (N2NMN_GEMM_DMA3_MT overrides)
+  static const int mt_env = [] { const char* e = getenv("N2NMN_GEMM_DMA3_MT"); return e ? atoi(e) : 0; }();
+  int tiles128 = 0;
+  for (int i = 0; i < n; ++i)
+    if (a[i].M > 0) tiles128 += ((a[i].n_store + N3 - 1) / N3) * ((a[i].M + 127) / 128);
+  const int mt = mt_env ? mt_env : (tiles128 >= 1024 ? 2 : 1);
+  if (mt == 2) launch3<2>(a, n, s); else launch3<1>(a, n, s);
 }
 
 void launch_pack_pk_b3(const float* Bp, int Kp, int Np, uint16_t* dst, hipStream_t s) {
