@@ -883,6 +883,7 @@ int run_program(n2nmn_ctx* c, Program& p, const float* feat, const float* word_v
         g.A = feat; g.lda = d.D; g.M = l.count * HW; g.K = d.D;
         g.group_idx = c->dev_tab + l.offset; g.group_size = HW; g.src_rows = N_full * HW;
         g.Bp = fsp ? c->fsp_img_p : c->find_img_p; g.Np = c->Mp; g.Kp = c->KpD;
+        if (lstm_b3(c, N_full)) g.Bp3 = fsp ? c->fsp_img_b3 : c->find_img_b3;   // (opt-in mode: gemm_dma3_kernel)
         g.bias = c->vars[fsp ? V_FSP_IMG_B : V_FIND_IMG_B].mirror; g.N = d.map_dim;
         g.C = fsp ? c->mfsp : c->mfind; g.ldc = c->Mp; g.n_store = c->Mp;
         ProfScope ps(c, F_CONV_IMAGE, 2.0 * l.count * dHW * dD * dM,
