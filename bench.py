@@ -44,8 +44,10 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 L2_PEAK_GBS = 34500.0       # MI355X_MICROARCH.md: aggregate L2 bandwidth (8 XCDs)
-L2_FAMILIES = ('dec_attn',) # re-reads the encoder rows of a question from L2/MALL (PMC: 17 MB of
-                            # HBM traffic for 236 MB of algorithmic bytes per launch)
+# dec_attn re-reads the encoder rows of a question from L2/MALL (PMC: 17 MB of HBM traffic for 236 MB of
+# algorithmic bytes per launch); the answer heads / fc_att groups and the text-map kernels stream weight
+# matrices and tables that live in L2
+L2_FAMILIES = ('dec_attn', 'heads', 'walk_tmap', 'textmap')
 MFMA_F32_PEAK_TF = 157.3    # MI355X_MICROARCH.md: fp32-input MFMA dense peak
 MFMA_FAMILIES = ('lstm_step', 'gemm_pk', 'lstm_bwd_step', 'gemm_tn')
 
@@ -614,13 +616,14 @@ def main():
     sync = lambda: torch.cuda.synchronize(dev)    # noqa: E731
     run_steps(max(args.warmup, 2 * S))
     elapsed, repeats, blocks = timed_blocks(dp, lambda: run_steps(args.steps), sync)
+    fastest_rank_s = getattr(dp, 'last_min_elapsed', elapsed)      # (of the last block)
     out = None
     if rank == 0:
         qps = dp.throughput(K * d.N * args.steps, elapsed)
         out = {
             'metric': 'questions/sec (forward) on CLEVR 10x15x512 feats, client batches of %d served '
                       'as passes of %d rows (throughput)' % (d.N, K * d.N),
-            'value': round(qps, 1), 'unit': 'questions/sec', 'n_gpus': world,
+            'value': round(qps, 1), 'unit': 'questions/sec', 'n_gpus': dp.group_size(),
             'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
@@ -650,6 +653,11 @@ def main():
                        'passes_per_stream_per_block': args.steps // S,
                        'lstm_step_mode': pipe.mode,
                        'parallelism': 'dp%d (question-sharded, no data-path collective)' % world,
+                       # multi-GPU readiness: ranks the process group holds (not the --gpus asked for) and
+                       # the slowest / fastest rank's own rate in the last timed block
+                       'ranks_in_group': dp.group_size(), 'gpus_requested': args.gpus,
+                       'per_rank_value_min_max': [round(K * d.N * args.steps / max(blocks[-1], 1e-9), 1),
+                                                  round(K * d.N * args.steps / max(fastest_rank_s, 1e-9), 1)],
                        'host_sync': 'none: layouts are decoded on the device by the walker'
                        if not args.host_assemble else 'predicted_tokens D2H + C++ assembler'},
         }
@@ -706,6 +714,9 @@ def main():
         out['single_batch'] = {'value': round(d.N / t_one, 1), 'unit': 'questions/sec',
                                'ms_per_step': round(1e3 * t_one, 4), 'steps': n1,
                                'note': 'one batch of %d questions in flight' % d.N}
+        # (the strict reading of BASELINE's "batch 64" where the driver's record keeps it: `config`)
+        out['config']['single_batch_qps'] = out['single_batch']['value']
+        out['config']['single_batch_ms'] = out['single_batch']['ms_per_step']
         if not args.no_profile:
             # the strict batch-64 reading of the metric, kernel by kernel: the R = 64 recurrent step
             eng.profile_begin()
@@ -745,6 +756,78 @@ def main():
                             'find_type_nodes_per_question': round(f3 / toks3.shape[1], 2),
                             'pooling_nodes_per_question': round(p3 / toks3.shape[1], 2),
                             'transform_nesting_histogram': nesting_histogram(toks3, names)}}
+
+    # ---- inference option N2NMN_S2S_EOS_RETIRE (include/n2nmn.h), under its OWN key: rows leave the
+    # teacher-forced decoder at their layout's first <eos>.  `value` above is the full decoder (every row,
+    # all T_dec steps, like the reference).  Two layout mixes: the template mix of the headline (mean 3.2
+    # tokens) and CLEVR-like layouts of up to 19 tokens (n2nmn_amd/synth.py: the reference's linearisation
+    # rules, exp_clevr/data/get_ground_truth_layout.py:4-37,49-96, applied to the CLEVR question families),
+    # each against the full decoder on the SAME layouts; logits of the retired passes against the oracle.
+    if rank == 0 and not args.plain and use_gt and K > 1 and pipe.mode.startswith('throughput'):
+        from oracle import n2nmn_oracle_batched as OB
+        torch.set_num_threads(min(16, torch.get_num_threads()))
+        wt64 = OB.to_torch(w, torch.float64)
+        npass = max(args.steps, 2 * S)
+
+        def rate():
+            t_est = wall(lambda: run_steps(npass), 1, warm=2)
+            t = wall(lambda: run_steps(npass), max(3, min(15, int(0.3 / max(t_est, 1e-4)) + 1)), warm=0)
+            return npass * K * d.N / t, 1e3 * t / npass
+
+        def set_layouts(make):
+            for si, wk in enumerate(pipe.workers):
+                for j, b in enumerate(wk['buckets']):
+                    for k in range(KCAP):
+                        b.set_layout(k, make((si * 2 + j) * KCAP + k))
+
+        def retired_parity(make):
+            worst = 0.0
+            for si, wk in enumerate(pipe.workers):
+                j = (wk['next'] - 1) % 2
+                b = wk['buckets'][j]
+                i = (si * 2 + j) * KCAP
+                hb = synth.make_inputs(d, seed=dp.batch_seed(i))
+                ref = OB.forward(wt64, names, hb, d.T_decoder, d.num_choices, True, make(i))
+                worst = max(worst, float(np.abs(b.result(0)[0].cpu().numpy() - ref['scores']).max()))
+            return worst
+
+        er = {'option': 'N2NMN_S2S_EOS_RETIRE (Engine.forward(eos_retire=True)): decoder steps from a layout\'s '
+                        'first <eos> on are not computed; predicted_tokens / scores / validity as the full '
+                        'decoder (tests/test_gpu_eos_retire.py); the decoder\'s own outputs at every step on '
+                        'demand (Engine.decoder_outputs)', 'unit': 'questions/sec', 'mixes': {}}
+        mixes = (('templates', lambda i: synth.template_layout_batch(d, offset=i)),
+                 ('clevr_like', lambda i: synth.clevr_like_layout_batch(d, seed=i)))
+        try:
+            for name, make in mixes:
+                if name != 'templates':
+                    set_layouts(make)
+                lens = np.concatenate([(make(i) != asm.EOS_idx).sum(0) for i in range(4)])
+                pipe.eos_retire = False
+                full_v, full_ms = rate() if name != 'templates' else (qps, 1e3 * elapsed / args.steps)
+                pipe.eos_retire = True
+                v, ms = rate()
+                err = retired_parity(make)
+                row = {'value': round(v, 1), 'ms_per_step': round(ms, 4),
+                       'full_decoder_value': round(full_v, 1), 'full_decoder_ms_per_step': round(full_ms, 4),
+                       'vs_full_decoder': round(v / full_v, 4),
+                       'mean_layout_length': round(float(lens.mean()), 2), 'max_layout_length': int(lens.max()),
+                       'live_step_fraction': round(float(lens.mean()) / d.T_decoder, 4),
+                       'max_abs_logit_err': err, 'ok': bool(err <= 1e-4)}
+                if not args.no_profile:
+                    # executed-work rooflines of the decoder's kernels in a retired pass (library counters)
+                    sync()
+                    eng.profile_begin()
+                    for j in range(4):
+                        buckets[j % 2].run(use_gt_layout=True, n_slots=K, eos_retire=True)
+                    rr = kernel_rows(eng.profile_end(), 4)
+                    row['kernels'] = [r for r in rr if r['kernel'].startswith(('lstm_step(dec', 'dec_attn', 'gemm_pkn'))]
+                er['mixes'][name] = row
+        finally:
+            pipe.eos_retire = False
+            set_layouts(mixes[0][1])
+        er['value'] = er['mixes']['templates']['value']
+        er['ms_per_step'] = er['mixes']['templates']['ms_per_step']
+        out['eos_retire'] = er
 
     # ---- opt-in split-operand bf16 mode (N2NMN_MODE_THROUGHPUT_BF16X3): the same passes with the
     # recurrent contraction on bf16 MFMAs over three-way split operands, its logits against the oracle.
@@ -810,22 +893,15 @@ def main():
         if dom['kernel'].startswith('lstm_step(enc'):
             # The reference's dynamic_rnn evaluates the cell for every row of the batch at every step
             # and selects afterwards; the length-sorted encoder skips the 16-row MFMA tiles that hold
-            # no active row.  `frac` / `achieved` count the flops the kernel EXECUTED (lengths of this
-            # run); the rate with the skipped tiles counted as work is kept as `reference_work_*`.
+            # no active row.  The library's counters (n2nmn_profile_*) count the flops the kernels
+            # EXECUTED -- `frac` / `achieved` of every row of `kernels` -- and the rate with the skipped
+            # tiles counted as work is kept here as `reference_work_*`.
             L, Tn = d.lstm_dim, d.T_encoder
-            ex = 0.0
-            for b in buckets[:2]:
-                lens = np.sort(b.seq_length[:K * d.N].cpu().numpy())[::-1]
-                act = [int(np.count_nonzero(lens > t)) for t in range(Tn)]
-                r16 = [min(K * d.N, (a + 15) // 16 * 16) for a in act]
-                ex += sum(2.0 * 4 * L * (L * r16[k] if k < Tn else 0) +
-                          2.0 * 4 * L * (2 * L * r16[k - 1] if k >= 1 else 0) for k in range(Tn + 1))
-            ex /= min(2, len(buckets)) * (Tn + 1)             # per launch
+            nominal = 2.0 * 4 * L * (L + 2 * L) * K * d.N * Tn / (Tn + 1)        # per launch, every row
             rl = out['roofline']
-            rl['reference_work_achieved'], rl['reference_work_frac'] = rl['achieved'], rl['frac']
-            rl['achieved'] = round(ex / (dom['avg_us'] * 1e-6) / 1e12, 3)
-            rl['frac'] = round(ex / (dom['avg_us'] * 1e-6) / 1e12 / dom['peak'], 4)
-            rl['executed_flops_per_launch'] = round(ex)
+            rl['reference_work_achieved'] = round(nominal / (dom['avg_us'] * 1e-6) / 1e12, 3)
+            rl['reference_work_frac'] = round(nominal / (dom['avg_us'] * 1e-6) / 1e12 / dom['peak'], 4)
+            rl['executed_flops_per_launch'] = round(dom['achieved'] * 1e12 * dom['avg_us'] * 1e-6)
             rl['note'] = ('achieved / frac = flops of the 16-row tiles that hold an active row (what the '
                           'kernel executes) / measured duration; reference_work_* count every row at '
                           'every step like the reference; the decoder steps (every row active) are the '

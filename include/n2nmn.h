@@ -110,8 +110,8 @@ int n2nmn_ctx_dims(const n2nmn_ctx *ctx, n2nmn_dims *out);
  *   csrc/kernels_gemm_dma3.hip).  The terms dropped are <= 2^-26 relative: same error class as the fp32
  *   MFMA's own rounding -- every parity test runs unchanged at 1e-4 in this mode -- but NOT the same bits
  *   as the fp32 kernels, so it is a mode of its own and never the default.  Training forwards keep the
- *   fp32 kernels.  Needs lstm_dim % 128 == 0; the first call packs the split weights (may wait for the
- *   device). */
+ *   fp32 kernels.  Needs lstm_dim % 128 == 0 and lstm_dim >= 256 (N2NMN_EINVAL otherwise); the first call
+ *   packs the split weights (may wait for the device). */
 #define N2NMN_MODE_THROUGHPUT_BF16X3 3
 int n2nmn_ctx_set_mode(n2nmn_ctx *ctx, int mode);
 
@@ -182,10 +182,28 @@ typedef struct {
    * (LDS-staged 64 x 64 tiles while >= 4 blocks of 64 rows are active, K-split tiles for the tail).
    * NULL: one tile shape for the whole pass.  Read during the call only. */
   const int32_t *seq_length_host;
+  /* optional HOST array [N] for N2NMN_S2S_EOS_RETIRE: tokens of gt_layout[:, n] in front of its first
+   * <eos> (the reference's data reader holds the layouts on the host, util/clevr_train/data_reader.py:
+   * 60-72).  With it the decoder issues only as many step launches as the longest layout needs and
+   * picks the step tile from the rows still alive; NULL: T_dec + 1 launches whose workgroups find the
+   * live-row counts on the device.  Read during the call only. */
+  const int32_t *gt_length_host;
 } n2nmn_seq2seq_io;
 /* skip word_vecs / neg_entropy / log_seq_prob (one launch): for inference through
  * n2nmn_walk_layouts with attention maps, which derives the text maps from atts directly */
 #define N2NMN_S2S_NO_WORD_VECS 1
+/* Inference option for teacher-forced passes (use_gt_layout, >= 128 rows, a throughput mode, together
+ * with N2NMN_S2S_NO_WORD_VECS): retire a row from the decoder at its layout's first <eos>.  Decoder step
+ * t >= len(layout) of a row feeds nothing exp_clevr/eval_clevr.py:103-135 fetches -- the layout is read
+ * up to its first <eos> (models_clevr/nmn3_assembler.py:153-170) and a module's text attention is the
+ * step of its own token (models_clevr/nmn3_modules.py:53-57) -- so the LSTM cells, q, and the attention
+ * run only over the (row, step) pairs in front of it: rows are ordered by layout length and step t
+ * covers the row blocks still alive (the encoder's length trick).  predicted_tokens are complete;
+ * atts / token_probs hold the live (row, step) pairs only.  The full outputs (all T_dec steps; training
+ * and the debug fetches need them) come from a call without the flag -- n2nmn_decoder_forward on the
+ * same context recomputes them from the encoder results it holds.  Where the preconditions do not hold
+ * the flag is ignored. */
+#define N2NMN_S2S_EOS_RETIRE 2
 
 int n2nmn_encoder_forward(n2nmn_ctx *ctx, const n2nmn_seq2seq_io *io, n2nmn_stream stream);
 /* decoder uses the encoder results held in the context by the preceding encoder call */
@@ -315,14 +333,23 @@ int n2nmn_walk_set_front_end(n2nmn_ctx *ctx, int mode);
  * of >= 128 questions by default), the tree-dependent rest leaves the one-workgroup-per-question walker
  * as well: walk_tmap_kernel decodes every layout once (nmn3_assembler.py:153-222) and lists the
  * _Transform / _FindSameProperty nodes by nesting level (level = such nodes below it in its own subtree);
- * walk_heavy_kernel runs each of them as a job of its own (one workgroup per node, the walker's operator
- * code), one launch per level; walk_light_kernel (one small workgroup per question) evaluates the remaining
- * And / Or / Filter / Scene nodes and the answer operator (nmn3_modules.py:60-72,113-132,218-400) or hands
- * the root to the deferred pooling.  How many level launches a pass gets follows the deepest nesting the
- * previous two passes showed (a host-mapped word, never waited for); layouts nested deeper than that stay
- * with the one-workgroup walker -- same operators, logits equal within 2e-6.  The CLEVR template mix never
- * nests: one launch.  mode -1 (default): on; 0: off (the walker serves every question). */
+ * per level, walk_heavy_kernel runs every _Transform node as a job of its own (two workgroups per CU, the
+ * 5x5 convolution on the matrix cores) and every _FindSameProperty node as 8 channel parts of its soft-max
+ * pooling + fc_att share, and walk_fspepi_kernel finishes the _FindSameProperty maps (8 row parts per node
+ * over the operator's conv_image map); walk_light_kernel (one small workgroup per question) evaluates the
+ * remaining And / Or / Filter / Scene nodes and the answer operator (nmn3_modules.py:60-72,113-132,218-400)
+ * or hands the root to the deferred pooling.  How many levels a pass launches: see n2nmn_walk_set_levels.
+ * mode -1 (default): on; 0: off (the walker serves every question). */
 int n2nmn_walk_set_staged(n2nmn_ctx *ctx, int mode);
+/* Nesting levels of _Transform / _FindSameProperty the staged walker launches per pass.  levels = 0
+ * (default): adaptive -- as deep as the previous two passes of this context went (a host-mapped word the
+ * GPU writes and the host reads without waiting); a layout nested deeper than the pass launches is served
+ * by the one-workgroup walker (same operators, other summation order: logits within 1e-5).  The CLEVR
+ * template mix never nests: one level.  Because the route of such a question then depends on what ran
+ * before, default-mode logits of NESTED layouts are reproducible to that bound, not bit for bit.
+ * levels >= 1: exactly that many levels in every pass (1 .. 24; T_dec - 1 covers every layout) -- the route
+ * of a question depends on its own layout only and repeated passes return the same bits. */
+int n2nmn_walk_set_levels(n2nmn_ctx *ctx, int levels);
 /* Phase 2 straight from DEVICE tokens (no token fetch, no host assembly): replaces Assembler.assemble +
  * td.Compiler.build_feed_dict + the second partial_run (exp_clevr/eval_clevr.py:121-132,
  * exp_vqa/eval_vqa2.py:103-137).  n2nmn_conv_image(FIND | FSP gated by tokens), then
@@ -543,8 +570,10 @@ int n2nmn_debug_colsum(n2nmn_ctx *ctx, const float *src, int R, int ncols, int l
  * n2nmn_profile_* table carries on top of its kernel's duration. */
 int n2nmn_debug_event_overhead(n2nmn_ctx *ctx, int iters, double *us_pair, n2nmn_stream stream);
 /* Re-launch one kernel of the LAST n2nmn_walk_layouts call `iters` times back to back inside one HIP
- * event pair (which: 0 walker, 1 deferred pooling kernel, 2 heads kernel, 3 walk_find_kernel, 4
- * walk_tmap_kernel; | 0x10: one event pair PER
+ * event pair (which: 0 walker = every launch between walk_find and the deferred pooling, 1 deferred pooling
+ * kernel, 2 heads kernel, 3 walk_find_kernel, 4 walk_tmap_kernel; staged passes also 5 walk_heavy_kernel,
+ * 6 walk_fspepi_kernel, 7 walk_light_kernel, 8 the fall-back walk_kernel, level 0 each; | 0x10: one event
+ * pair PER
  * launch instead, which measures what a pair adds to this kernel) and return the average
  * microseconds per launch: the live duration the roofline of short kernels is computed from (an
  * event pair around a single ~5 us launch reads ~4 us too much).  Inputs must still be alive. */

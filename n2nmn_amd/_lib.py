@@ -32,7 +32,7 @@ class Seq2SeqIO(C.Structure):
         ('encoder_outputs', C.c_void_p), ('encoder_h_transformed', C.c_void_p),
         ('encoder_states', C.c_void_p), ('log_seq_prob', C.c_void_p), ('flags', C.c_int32),
         ('image_feat', C.c_void_p), ('drop_enc0', C.c_void_p), ('drop_dec0', C.c_void_p),
-        ('seq_length_host', C.c_void_p)]
+        ('seq_length_host', C.c_void_p), ('gt_length_host', C.c_void_p)]
 
 
 class TrainIO(C.Structure):
@@ -102,6 +102,7 @@ SYMBOLS = [
     ('n2nmn_walk_set_defer_pool', _I, [_P, _I]),
     ('n2nmn_walk_set_front_end', _I, [_P, _I]),
     ('n2nmn_walk_set_staged', _I, [_P, _I]),
+    ('n2nmn_walk_set_levels', _I, [_P, _I]),
     ('n2nmn_conv_image', _I, [_P, _P, _I, _I, _P, _I, _P]),
     ('n2nmn_walk_layouts', _I, [_P, C.POINTER(WalkBatch), _I, _I, _I, _I, _P]),
     ('n2nmn_execute_tokens', _I, [_P, _P, _I, _I, _P, _P, _P, _P, _P]),

@@ -210,6 +210,8 @@ static size_t carve_workspace(n2nmn_ctx* c, char* base) {
   c->nact = k.take<int32_t>(T + 1);
   c->enc_rows = k.take<int32_t>(T * N);
   c->enc_rows_n = k.take<int32_t>(4);
+  c->dlen = k.take<int32_t>(N); c->dperm = k.take<int32_t>(N); c->dnact = k.take<int32_t>(Td + 1);
+  c->drows = k.take<int32_t>(Td * N); c->drows_n = k.take<int32_t>(4);
   float* ds = c->st_B + 4 * N * L;                // decoder states: inside block B
   c->dh0[0] = ds; c->dh0[1] = ds + N * L; c->dh1[0] = ds + 2 * N * L; c->dh1[1] = ds + 3 * N * L;
   c->dc0 = ds + 4 * N * L; c->dc1 = ds + 5 * N * L;
@@ -252,6 +254,7 @@ static size_t carve_workspace(n2nmn_ctx* c, char* base) {
   c->wpooled = k.take<float>(N * 2 * (size_t)d.D);
   c->wpfc = k.take<float>(N * 2 * WALK_POOL_PARTS * Mp);
   c->wprog = k.take<WalkProg>(N);
+  c->wfpart = k.take<float>(N * Td * WALK_POOL_PARTS * Mp);
   // job lists of the staged walker: a region per nesting level (kernels.h, WalkArgs::hoff), sized for the
   // worst case -- at most T / (lv + 2) nodes of level lv per question, per operator
   {
@@ -408,15 +411,35 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmAr
   std::vector<int> act_host;
   // (the split-operand mode too: the K-split kernels write the bf16 planes of the states they produce
   // when a job carries plane pointers, so a row's final state reaches the decoder with its planes)
-  if (io->seq_length_host && (c->mode == N2NMN_MODE_THROUGHPUT || c->mode == N2NMN_MODE_THROUGHPUT_BF16X3)) {
+  auto rows_active = [&](const int32_t* lens, std::vector<int>& act) {
     std::vector<int> cnt(T + 2, 0);
-    for (int n = 0; n < N; ++n) cnt[std::min(std::max(io->seq_length_host[n], 0), T)] += 1;
-    act_host.assign(T, 0);
+    for (int n = 0; n < N; ++n) cnt[std::min(std::max(lens[n], 0), T)] += 1;
+    act.assign(T, 0);
     for (int t = T - 1, run = 0; t >= 0; --t) {    // rows with length > t
       run += cnt[t + 1];
-      act_host[t] = run;
+      act[t] = run;
     }
+  };
+  if (io->seq_length_host && (c->mode == N2NMN_MODE_THROUGHPUT || c->mode == N2NMN_MODE_THROUGHPUT_BF16X3))
+    rows_active(io->seq_length_host, act_host);
+  // The profile counters report EXECUTED work: the step kernels skip the 16-row MFMA tiles past the
+  // active rows of the length-sorted state, the encoder_h_transform GEMM runs over the listed rows.  A
+  // profiled pass may synchronise, so without a host copy of the lengths it fetches them (counters only:
+  // the launches are the unprofiled pass's).
+  std::vector<int> act_prof;
+  std::vector<int32_t> len_prof;
+  const int32_t* len_cnt = io->seq_length_host;
+  if (!len_cnt && c->prof_on) {
+    len_prof.resize(N);
+    N2_HIP(hipStreamSynchronize(s));
+    N2_HIP(hipMemcpy(len_prof.data(), io->seq_length, sizeof(int32_t) * N, hipMemcpyDeviceToHost));
+    len_cnt = len_prof.data();
   }
+  if (len_cnt && c->prof_on && !c->rec) rows_active(len_cnt, act_prof);
+  auto exec_rows = [&](int t) -> double {          // rows of the 16-row tiles that hold an active row at step t
+    if (act_prof.empty() || t < 0 || t >= T) return N;
+    return std::min(N, round_up(act_prof[t], 16));
+  };
   // software-pipelined over time: launch k runs layer-0 step k and layer-1 step k-1
   for (int k = 0; k <= T; ++k) {
     LstmJob jobs[2];
@@ -463,9 +486,10 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmAr
       }
     }
     {
-      const double fl = 2.0 * N * 4 * L * ((j0.active ? L : 0) + (j1.active ? 2 * L : 0));
-      const double by = 4.0 * ((j0.active ? (double)L * 4 * L + 3.0 * N * L : 0) +
-                               (j1.active ? 2.0 * L * 4 * L + 5.0 * N * L : 0));
+      const double r0 = exec_rows(k), r1 = exec_rows(st);
+      const double fl = 2.0 * 4 * L * ((j0.active ? r0 * L : 0) + (j1.active ? r1 * 2 * L : 0));
+      const double by = 4.0 * ((j0.active ? (double)L * 4 * L + 3.0 * r0 * L : 0) +
+                               (j1.active ? 2.0 * L * 4 * L + 5.0 * r1 * L : 0));
       ProfScope ps(c, F_LSTM_ENC, fl, by, s);
       int wide = lstm_wide(c);
       if (!act_host.empty() && act_host[std::min(k, T - 1)] <= tile_min_rows()) wide = 1;
@@ -494,15 +518,16 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmAr
   }
   c->eht_partial = eht_rows;
   c->eht_listed_rows = -1;
-  if (eht_rows && io->seq_length_host) {        // what the launch really computes, for the profile counters
+  if (eht_rows && len_cnt) {                    // what the launch really computes, for the profile counters
     long rows = 0;
-    for (int n = 0; n < N; ++n) rows += std::min(std::max(io->seq_length_host[n], 0), T);
+    for (int n = 0; n < N; ++n) rows += std::min(std::max(len_cnt[n], 0), T);
     c->eht_listed_rows = rows;
   }
   if (defer_eht) {
     *defer_eht = g;
   } else {
-    ProfScope ps(c, F_GEMM_EHT, 2.0 * T * N * L * L, 4.0 * (2.0 * T * N * L + (double)L * L), s);
+    const double rows = c->eht_listed_rows >= 0 ? (double)c->eht_listed_rows : (double)T * N;
+    ProfScope ps(c, F_GEMM_EHT, 2.0 * rows * L * L, 4.0 * (2.0 * rows * L + (double)L * L), s);
     launch_gemm_pk(g, s);
   }
   c->enc_T = T; c->enc_N = N; c->enc_seq = io->input_seq; c->enc_len = io->seq_length;
@@ -560,8 +585,58 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
   // token step, so the two layers pipeline over time like the encoder and the attention of ALL
   // T_dec steps runs as one launch.
   const bool batched = io->use_gt_layout && !io->forced_tokens && !io->sample_uniforms;
+  // ---- eos_retire (N2NMN_S2S_EOS_RETIRE, include/n2nmn.h): rows leave the decoder at their layout's first
+  // <eos>.  Preconditions: an inference pass of >= 128 rows in a throughput mode (the tile kernels take the
+  // rows in ranked order and a device-side live count), nothing fetched that needs the dead steps.
+  a.q = c->qbuf; a.out = c->dec_h1_all; a.gt = io->gt_layout; a.Td = Td;     // (dec_question_supported reads these)
+  const bool retire = batched && (io->flags & N2NMN_S2S_EOS_RETIRE) && (io->flags & N2NMN_S2S_NO_WORD_VECS) &&
+                      !c->rec && !io->drop_dec0 && !io->token_scores &&
+                      lstm_wide(c) >= 2 && N >= 128 && Td <= 63 && root(c)->have_token_ops &&
+                      dec_question_supported(a, Td);
+  int kmax = Td;                      // last launch of the pipelined loop
+  std::vector<int> dact_host;         // rows with layout length > t (host copy of the lengths given)
+  if (retire) {
+    launch_dec_len(io->gt_layout, root(c)->token_op, V, Td, N, c->dlen, s);
+    launch_enc_prepare(c->dlen, N, Td, c->dperm, c->dnact, nullptr, 0, s, c->drows_n);
+    launch_enc_rows(c->dlen, Td, N, c->drows, c->drows_n, s);
+    // the encoder's final states (ORIGINAL row order) in ranked order; block B's dropout buffers are free
+    // in an inference pass without dropout and carry plane companions like every state buffer
+    // (GatherArgs pairs the planes with src[0] / src[2]: h0, c0, h1, c1)
+    const float* src[4] = {c->fh0, c->fc0, c->fh1, c->fc1};
+    float* dst[4] = {c->ehd[0], c->ehd[1], c->dhd[0], c->dhd[1]};
+    if (lstm_b3(c, N)) {
+      const uint16_t* sb[2] = {planes_of(c, c->fh0), planes_of(c, c->fh1)};
+      uint16_t* db[2] = {planes_of(c, c->ehd[0]), planes_of(c, c->dhd[0])};
+      launch_gather_state(src, dst, sb, db, c->dperm, N, L, d.N, s);
+    } else {
+      launch_gather_state(src, dst, nullptr, nullptr, c->dperm, N, L, d.N, s);
+    }
+    if (io->gt_length_host) {
+      std::vector<int> cnt(Td + 2, 0);
+      int longest = 0;
+      for (int n = 0; n < N; ++n) {
+        const int l = std::min(std::max(io->gt_length_host[n], 0), Td);
+        cnt[l] += 1; longest = std::max(longest, l);
+      }
+      dact_host.assign(Td + 1, 0);
+      for (int t = Td - 1, run = 0; t >= 0; --t) { run += cnt[t + 1]; dact_host[t] = run; }
+      kmax = longest;
+    }
+  }
+  // (profile counters of a retired pass without host lengths: a profiled pass may synchronise)
+  std::vector<int> dact_prof = dact_host;
+  if (retire && dact_prof.empty() && c->prof_on) {
+    std::vector<int32_t> lh(N);
+    N2_HIP(hipStreamSynchronize(s));
+    N2_HIP(hipMemcpy(lh.data(), c->dlen, sizeof(int32_t) * N, hipMemcpyDeviceToHost));
+    std::vector<int> cnt(Td + 2, 0);
+    for (int n = 0; n < N; ++n) cnt[std::min(std::max(lh[n], 0), Td)] += 1;
+    dact_prof.assign(Td + 1, 0);
+    for (int t = Td - 1, run = 0; t >= 0; --t) { run += cnt[t + 1]; dact_prof[t] = run; }
+  }
+  c->dec_retired = retire;
   if (batched) {
-    for (int k = 0; k <= Td; ++k) {
+    for (int k = 0; k <= kmax; ++k) {
       LstmJob jobs[2];
       LstmJob& j0 = jobs[0];
       j0 = LstmJob{};
@@ -601,14 +676,38 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
           j1.save_h = c->rec->dh1s + (size_t)(st + 1) * nl;
         }
       }
-      ProfScope ps(c, F_LSTM_DEC0, (j0.active ? fl0 : 0) + (j1.active ? fl1 : 0),
-                   (j0.active ? by0 : 0) + (j1.active ? by1 : 0), s);
+      int wide = lstm_wide(c);
+      double live0 = N, live1 = N;      // rows the launch computes (16-row MFMA tiles), for the counters
+      if (retire) {
+        // state rows in ranked order (dperm), the rows alive at a step are a prefix whose length the
+        // kernels read from the device; a row past its layout keeps its state (as dynamic_rnn does past
+        // a question's length: the same kernel path)
+        if (k == 0) { j0.A0 = c->ehd[0]; j0.c_in = c->ehd[1]; j0.h_old = j0.A0; }
+        if (st == 0) { j1.A1 = c->dhd[0]; j1.c_in = c->dhd[1]; j1.h_old = j1.A1; }
+        j0.perm = j1.perm = c->dperm; j0.seq_len = j1.seq_len = c->dlen; j0.t = k; j1.t = st;
+        j0.n_active = c->dnact + std::min(k, Td - 1); j1.n_active = c->dnact + std::max(st, 0);
+        if (!dact_prof.empty()) {
+          live0 = std::min(N, round_up(j0.active ? dact_prof[k] : 0, 16));
+          live1 = std::min(N, round_up(j1.active ? dact_prof[st] : 0, 16));
+        }
+        if (!dact_host.empty()) {
+          const int a0 = j0.active ? dact_host[k] : 0, a1 = j1.active ? dact_host[st] : 0;
+          if (std::max(a0, a1) <= tile_min_rows()) wide = 1;      // few rows left: the K-split tiles scale with rows
+        }
+      }
+      ProfScope ps(c, F_LSTM_DEC0, (j0.active ? fl0 * live0 / N : 0) + (j1.active ? fl1 * live1 / N : 0),
+                   (j0.active ? 4.0 * ((double)L * 4 * L + 3.0 * live0 * L) : 0) +
+                   (j1.active ? 4.0 * (2.0 * L * 4 * L + 5.0 * live1 * L) : 0), s);
       if (lstm_b3(c, N)) {
         attach_planes(c, j0); attach_planes(c, j1);
-        N2_REQUIRE(lstm_tile3_supported(jobs, 2, L), N2NMN_EINVAL, "decoder_forward: bf16x3 mode: unsupported job");
-        launch_lstm_tile3(jobs, 2, N, L, s);
+        if (wide == 1) {              // (exact-fp32 K-split tiles; they write the planes of what they produce)
+          launch_lstm_step(jobs, 2, N, L, 64, s, 1);
+        } else {
+          N2_REQUIRE(lstm_tile3_supported(jobs, 2, L), N2NMN_EINVAL, "decoder_forward: bf16x3 mode: unsupported job");
+          launch_lstm_tile3(jobs, 2, N, L, s);
+        }
       } else {
-        launch_lstm_step(jobs, 2, N, L, 64, s, lstm_wide(c));
+        launch_lstm_step(jobs, 2, N, L, 64, s, wide);
       }
     }
     // q = out . W_a + b_a for all steps (nmn3_netgen_att.py:185), in ONE launch with whatever else
@@ -630,7 +729,22 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
       gq.Bp = c->att_W_p; gq.Np = L; gq.Kp = c->KpL; gq.bias = c->vars[V_ATT_B].mirror; gq.N = L;
       if (lstm_b3(c, N)) gq.Bp3 = c->att_W_b3;
       gq.C = c->qbuf; gq.ldc = L; gq.n_store = L;
-      fl += 2.0 * Td * N * L * L; by += 4.0 * ((double)L * L + 2.0 * Td * N * L);
+      double qrows = (double)Td * N;
+      if (retire) {                      // q of the live (step, row) pairs only (the eht GEMM's row-list form)
+        gq.group_idx = c->drows; gq.group_size = 1; gq.src_rows = Td * N;
+        gq.c_row_idx = c->drows; gq.m_dev = c->drows_n;
+        if (!dact_host.empty()) {
+          long tot = 0;
+          for (int t = 0; t < Td; ++t) tot += dact_host[t];
+          gq.M = (int)std::max<long>(tot, 1);
+        }
+        if (!dact_prof.empty()) {
+          long tot = 0;
+          for (int t = 0; t < Td; ++t) tot += dact_prof[t];
+          qrows = (double)tot;
+        }
+      }
+      fl += 2.0 * qrows * L * L; by += 4.0 * ((double)L * L + 2.0 * qrows * L);
       // the hoisted conv_image problems ride in this launch when the list has room (it holds four);
       // otherwise they get a launch of their own below -- never dropped: the walker reads their maps
       const bool conv = io->image_feat != nullptr;
@@ -661,13 +775,20 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
     a.tokens = tokens; a.tprobs = tprobs; a.ent_t = c->ent_t; a.atts = atts;
     a.scores = io->token_scores; a.next_idx = nullptr;
     a.Td = Td;
+    a.dec_len = retire ? c->dlen : nullptr;
+    double att_live = 1.0;             // share of the (step, row) pairs the attention evaluates
+    if (retire && !dact_prof.empty()) {
+      long tot = 0;
+      for (int t = 0; t < Td; ++t) tot += dact_prof[t];
+      att_live = (double)tot / ((double)Td * N);
+    }
     if (c->rec) {
       a.ctx_out = c->rec->ctx;
       if (!a.scores) a.scores = c->rec->tscores;
       a.valid_bits = c->rec->valid_bits;
     }
     {
-      ProfScope ps(c, F_DEC_STEP, Td * att_fl, Td * att_by, s);
+      ProfScope ps(c, F_DEC_STEP, Td * att_fl * att_live, Td * att_by * att_live, s);
       launch_dec_attn(a, Td, s);
     }
   } else {
@@ -1214,7 +1335,10 @@ int n2nmn_ctx_set_mode(n2nmn_ctx* ctx, int mode) {
                  mode == N2NMN_MODE_THROUGHPUT_KSPLIT || mode == N2NMN_MODE_THROUGHPUT_BF16X3,
              N2NMN_EINVAL, "ctx_set_mode: unknown mode");
   if (mode == N2NMN_MODE_THROUGHPUT_BF16X3) {
-    N2_REQUIRE(ctx->enc_W0h_b3, N2NMN_EINVAL, "ctx_set_mode: bf16x3 needs lstm_dim % 128 == 0");
+    // (lstm_tile3_kernel stages 32 k per step over at least 8 steps: the layer-0 contraction K = lstm_dim
+    // must reach 256)
+    N2_REQUIRE(ctx->enc_W0h_b3 && ctx->d.lstm_dim >= 256, N2NMN_EINVAL,
+               "ctx_set_mode: bf16x3 needs lstm_dim % 128 == 0 and lstm_dim >= 256");
     n2nmn_ctx* r = ctx->parent ? ctx->parent : ctx;
     if (!r->b3_on) {
       // from now on every commit packs the split weights too; if weights are committed already, now
@@ -1527,6 +1651,12 @@ int n2nmn_walk_set_staged(n2nmn_ctx* c, int mode) {
   return N2NMN_OK;
 }
 
+int n2nmn_walk_set_levels(n2nmn_ctx* c, int levels) {
+  N2_REQUIRE(c && levels >= 0 && levels <= WALK_HLEVELS, N2NMN_EINVAL, "walk_set_levels: 0 (adaptive) or 1 .. 24");
+  c->walk_levels = levels;
+  return N2NMN_OK;
+}
+
 int n2nmn_walk_supported(const n2nmn_ctx* c) {
   if (!c) return 0;
   const n2nmn_dims& d = c->d;
@@ -1605,7 +1735,7 @@ int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int
     a.b[k].watt = owner->watt;
     a.b[k].pjob = owner->wpjob; a.b[k].pw = owner->wpw; a.b[k].ptm = owner->wptm;
     a.b[k].pooled = owner->wpooled; a.b[k].pfc = owner->wpfc;
-    a.b[k].prog = owner->wprog;
+    a.b[k].prog = owner->wprog; a.b[k].fpart = owner->wfpart;
   }
   a.K = K; a.N = N; a.T = T_dec; a.V = d.num_vocab_nmn; a.token_op = root(c)->token_op;
   a.H = d.H; a.W = d.W; a.D = d.D; a.M = d.map_dim; a.Mp = c->Mp; a.HWp = c->HWp;
@@ -1658,8 +1788,7 @@ int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int
       seen = *reinterpret_cast<volatile int32_t*>(c->walk_hint_host);
       a.hint = c->walk_hint_dev;
     }
-    static const int lv_env = [] { const char* e = getenv("N2NMN_WALK_LEVELS"); return e ? atoi(e) : 0; }();
-    const int want = lv_env > 0 ? lv_env : std::max(seen, c->walk_hint_prev);
+    const int want = c->walk_levels > 0 ? c->walk_levels : std::max(seen, c->walk_hint_prev);
     c->walk_hint_prev = seen;
     a.hlevels = std::min(std::max(want, 1), WALK_HLEVELS);
   }
@@ -1679,7 +1808,8 @@ int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int
   {
     ProfScope ps(c, F_WALK, 0.0, 0.0, s);     // work filled in from the device counters
     if (a.staged) {
-      for (int lv = 0; lv < a.hlevels; ++lv) { a.hlevel = lv; launch_walk_heavy(w, a, s); }
+      // per nesting level: Transform jobs + stage A of the FindSameProperty jobs, then their stage B
+      for (int lv = 0; lv < a.hlevels; ++lv) { a.hlevel = lv; launch_walk_heavy(w, a, s); launch_walk_fspepi(w, a, s); }
       a.hlevel = 0;
       launch_walk_light(w, a, s);
     }
@@ -1742,7 +1872,7 @@ int n2nmn_debug_walk_replay(n2nmn_ctx* c, int which, int iters, double* us_avg, 
       WalkArgs t = a;
       t.plist = nullptr;                 // (a replay must not append the pooled roots to the lists again)
       if (t.staged) {
-        for (int lv = 0; lv < t.hlevels; ++lv) { t.hlevel = lv; launch_walk_heavy(w, t, s); }
+        for (int lv = 0; lv < t.hlevels; ++lv) { t.hlevel = lv; launch_walk_heavy(w, t, s); launch_walk_fspepi(w, t, s); }
         launch_walk_light(w, t, s);
       }
       launch_walk(w, t, s);
@@ -1750,6 +1880,14 @@ int n2nmn_debug_walk_replay(n2nmn_ctx* c, int which, int iters, double* us_avg, 
     else if (which == 1) launch_walk_pool(w, a, s);
     else if (which == 2) launch_walk_heads(w, a, s);
     else if (which == 3) launch_walk_find(w, a, s);
+    else if (which >= 5 && which <= 8 && a.staged) {      // the staged walker's launches one by one (level 0)
+      WalkArgs t = a;
+      t.plist = nullptr; t.hlevel = 0;
+      if (which == 5) launch_walk_heavy(w, t, s);
+      else if (which == 6) launch_walk_fspepi(w, t, s);
+      else if (which == 7) launch_walk_light(w, t, s);
+      else launch_walk(w, t, s);
+    }
     else { WalkArgs t = a; t.T_enc = c->last_walk_T_enc; t.staged = 0; launch_walk_tmap(w, t, s); }   // (no list appends)
   };
   for (int i = 0; i < 3; ++i) one();

@@ -202,6 +202,10 @@ struct n2nmn_ctx {
   float *fc0 = nullptr, *fh0 = nullptr, *fc1 = nullptr, *fh1 = nullptr;
   int32_t *perm = nullptr, *nact = nullptr;
   int32_t *enc_rows = nullptr, *enc_rows_n = nullptr;   // rows (t, n) inside their length, and how many
+  // eos_retire (N2NMN_S2S_EOS_RETIRE): layout lengths, rows ranked by them, live rows per decoder step,
+  // the live (step, row) pairs and their number
+  bool dec_retired = false;     // the last decoder call retired rows (its atts / token_probs are partial)
+  int32_t *dlen = nullptr, *dperm = nullptr, *dnact = nullptr, *drows = nullptr, *drows_n = nullptr;
   float *qpn_h = nullptr, *qpn_hid = nullptr;        // [N][2L] concat of final h, [N][qpn_hidden]
   float *enc_out = nullptr, *eht = nullptr, *qbuf = nullptr, *dec_h1_all = nullptr, *ent_t = nullptr, *dh1_rm = nullptr;
   // `eht` rows (tau, n) with tau >= len[n] were NOT computed by the last encoder pass (listed-row GEMM,
@@ -223,11 +227,13 @@ struct n2nmn_ctx {
   // staged walker (kernels.h WalkArgs::staged): decoded layouts of this context's questions, and -- for
   // the launches this context issues -- the job lists and the two counter sets (used alternately)
   WalkProg* wprog = nullptr;
+  float* wfpart = nullptr;   // [N][T_decoder][WALK_POOL_PARTS][Mp]: FindSameProperty fc_att shares (staged walker)
   int32_t *whjobs = nullptr, *wfblist = nullptr, *wcnt = nullptr, *wplist = nullptr;
   int whoff[WALK_HLEVELS + 1] = {0}, walk_parity = 0;
   int32_t* walk_hint_host = nullptr;   // host-mapped word the staged walker reports its deepest nesting in
   int32_t* walk_hint_dev = nullptr;
   int walk_hint_prev = 0;
+  int walk_levels = 0;                        // n2nmn_walk_set_levels: 0 adaptive, >= 1 fixed
   int walk_staged = -1;                       // -1 auto (with the chip-wide front end + deferred pooling), 0 off
   float *arena = nullptr, *tmap = nullptr, *pfc = nullptr, *mfind = nullptr, *mfsp = nullptr;
   float* ev_out = nullptr;

@@ -210,7 +210,17 @@ struct DecStepArgs {
   float* scores;           // [steps][N][V] or nullptr
   int32_t* next_idx;       // [N] row of the decoder x-table for the next step (= token) or nullptr
   float* ctx_out;          // [steps][N][L] context vectors kept for the backward pass, or nullptr
+  // eos_retire (teacher-forced passes, dec_attn_question_kernel only): live decoder steps per question;
+  // steps at or past it get their token from `gt` and nothing else.  nullptr: every step of every question
+  const int32_t* dec_len;  // [N]
 };
+// can launch_dec_attn serve this launch with dec_attn_question_kernel (the kernel that honours dec_len)?
+bool dec_question_supported(const DecStepArgs& a, int nsteps);
+// eos_retire helpers (kernels_seq2seq.hip): layout lengths from the tokens; state rows gathered by `perm`
+void launch_dec_len(const int32_t* tokens, const int32_t* token_op, int V, int T_dec, int N,
+                    int32_t* dec_len, hipStream_t s);
+void launch_gather_state(const float* const src[4], float* const dst[4], const uint16_t* const srcb[2],
+                         uint16_t* const dstb[2], const int32_t* perm, int N, int L, int R, hipStream_t s);
 // nsteps == 1: one sequential step (1024-thread workgroups); nsteps > 1: all steps in one launch
 void launch_dec_attn(const DecStepArgs& a, int nsteps, hipStream_t s);
 
@@ -308,6 +318,9 @@ struct WalkBatch {
   // staged walker (WalkArgs::staged): the decoded layout of every question, written by
   // walk_tmap_kernel (which becomes the pass's "plan" step), read by walk_heavy / walk_light
   struct WalkProg* prog;   // [N]
+  // FindSameProperty as chip-wide stages: the WALK_POOL_PARTS shares of fc_att(pooled features) of node
+  // (n, t), written by stage A (walk_heavy_kernel), summed by stage B (walk_fspepi_kernel)
+  float* fpart;            // [N][T][WALK_POOL_PARTS][Mp]
 };
 // One question's decoded layout (nmn3_assembler.py:153-222 on the device).  op: n2nmn_op of node t
 // | 0x80 for answer-type nodes; in0 / in1: input nodes or -1; hd: "heavy depth" = the largest number of
@@ -375,6 +388,7 @@ void launch_walk(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
 void launch_walk_tmap(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
 void launch_walk_find(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
 void launch_walk_heavy(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
+void launch_walk_fspepi(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
 void launch_walk_light(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
 void launch_walk_pool(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
 void launch_walk_heads(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);

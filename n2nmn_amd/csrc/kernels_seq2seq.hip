@@ -1021,6 +1021,14 @@ __global__ __launch_bounds__(1024) void dec_attn_question_kernel(DecStepArgs a, 
   const int n = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int len = min(max(a.seq_len[n], 0), T);
+  // eos_retire (DecStepArgs::dec_len): only the steps that emit a module token are evaluated -- the steps
+  // from the first <eos> on feed nothing the caller asked for (decoder_impl); their tokens are the given
+  // ones.  `nsteps` keeps describing the launch (LDS layout, output strides), `ns` the work.
+  const int ns = a.dec_len ? min(nsteps, max(a.dec_len[n], 0)) : nsteps;
+  if (ns < nsteps) {
+    for (int j = ns + tid; j < nsteps; j += NT) a.tokens[(size_t)j * N + n] = a.gt[(size_t)j * N + n];
+    if (ns == 0) return;
+  }
   // rows past the question's length all equal the bias of encoder_h_transform: virtual row `len`
   // stands for every one of them (evaluated once, copied to the others below)
   const bool virt = a.eht_bias && len < T;      // row `len` is the bias vector, not a row of eht
@@ -1048,7 +1056,10 @@ __global__ __launch_bounds__(1024) void dec_attn_question_kernel(DecStepArgs a, 
   __syncthreads();
   // ---- 1. e[j][tau] = sum_k v_k tanh(q_j,k + eht[tau, n, k])                          (:184-187)
   {
-    const int sg = w >> 2, tq = w & 3;
+    // 16 waves = (step groups of SPG steps) x (row parts): four groups x four row quarters for a full
+    // launch; a question with few live steps (eos_retire) gives its waves to the rows instead
+    const int nrq = ns > 2 * SPG ? 4 : (ns > SPG ? 8 : 16);  // row parts
+    const int sg = w / nrq, tq = w - sg * nrq;
     const int j0 = sg * SPG;
     float4 v4[KI], q4[SPG][KI];
 #pragma unroll
@@ -1057,13 +1068,13 @@ __global__ __launch_bounds__(1024) void dec_attn_question_kernel(DecStepArgs a, 
       v4[i] = *reinterpret_cast<const float4*>(a.v + k);
 #pragma unroll
       for (int j = 0; j < SPG; ++j) {
-        const int jj = min(j0 + j, nsteps - 1);
+        const int jj = min(j0 + j, ns - 1);
         q4[j][i] = *reinterpret_cast<const float4*>(a.q + ((size_t)jj * N + n) * L + k);
       }
     }
-    if (j0 < nsteps) {
-      for (int tau = tq; tau < Tv; tau += 8) {               // two rows of this quarter per trip
-        const int tau1 = tau + 4;
+    if (j0 < ns) {
+      for (int tau = tq; tau < Tv; tau += 2 * nrq) {         // two rows of this part per trip
+        const int tau1 = tau + nrq;
         float4 e0[KI], e1[KI];
 #pragma unroll
         for (int i = 0; i < KI; ++i) {
@@ -1081,7 +1092,7 @@ __global__ __launch_bounds__(1024) void dec_attn_question_kernel(DecStepArgs a, 
                   v4[i].z * fast_tanh(q4[j][i].z + e1[i].z) + v4[i].w * fast_tanh(q4[j][i].w + e1[i].w);
           }
           const float r0 = wave_sum(s0), r1 = wave_sum(s1);
-          if (lane == 0 && j0 + j < nsteps) {
+          if (lane == 0 && j0 + j < ns) {
             es[(j0 + j) * Tp + tau] = r0;
             if (tau1 < Tv) es[(j0 + j) * Tp + tau1] = r1;
           }
@@ -1092,14 +1103,14 @@ __global__ __launch_bounds__(1024) void dec_attn_question_kernel(DecStepArgs a, 
   __syncthreads();
   if (virt && len + 1 < T) {
     const int rest = T - len - 1;
-    for (int i = tid; i < nsteps * rest; i += NT) {
+    for (int i = tid; i < ns * rest; i += NT) {
       const int j = i / rest, tau = len + 1 + i - j * rest;
       es[j * Tp + tau] = es[j * Tp + len];
     }
     __syncthreads();
   }
   // ---- 2. softmax over ALL T rows, mask finished rows, renormalise                   (:190-191)
-  for (int j = w; j < nsteps; j += NW) {
+  for (int j = w; j < ns; j += NW) {
     float* ej = es + j * Tp;
     float m = -INFINITY;
     for (int tau = lane; tau < T; tau += 64) m = fmaxf(m, ej[tau]);
@@ -1151,7 +1162,7 @@ __global__ __launch_bounds__(1024) void dec_attn_question_kernel(DecStepArgs a, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int j = (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (j < nsteps) {
+        if (j < ns) {
           ctxS[(size_t)j * L + cb + li] = acc[r];
           if (a.ctx_out) a.ctx_out[((size_t)j * N + n) * L + cb + li] = acc[r];
         }
@@ -1168,7 +1179,7 @@ __global__ __launch_bounds__(1024) void dec_attn_question_kernel(DecStepArgs a, 
     const int li = lane & 31, kh = lane >> 5;
     const int kper = 2 * L / NW;                             // k range of this wave (64 at L = 512)
     const int k0 = w * kper;
-    const int jr = min(li, nsteps - 1);
+    const int jr = min(li, ns - 1);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -1187,11 +1198,11 @@ __global__ __launch_bounds__(1024) void dec_attn_question_kernel(DecStepArgs a, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int j = (r & 3) + 8 * (r >> 2) + 4 * kh;       // step (row of D), li = token (column)
-        if (j < nsteps) part[((size_t)w * nsteps + j) * MAXV + li] = acc[r];
+        if (j < ns) part[((size_t)w * nsteps + j) * MAXV + li] = acc[r];
       }
     }
     __syncthreads();
-    for (int j = w; j < nsteps; j += NW) {
+    for (int j = w; j < ns; j += NW) {
       float sc = -INFINITY;
       if (lane < V) {
         sc = a.by[lane];
@@ -1346,6 +1357,59 @@ __global__ __launch_bounds__(1024) void enc_rows_kernel(const int32_t* __restric
   }
   __syncthreads();
   if (act) rows[base_s + wcnt[w] + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = i;
+}
+
+// eos_retire: dec_len[n] = decoder steps row n's layout needs = tokens in front of the first <eos>
+// (token_op < 0; a token outside the vocabulary is not an <eos>: an invalid layout simply keeps every
+// step).  nmn3_assembler.py:153-170 reads a layout up to its first <eos> and nothing behind it.
+__global__ void dec_len_kernel(const int32_t* __restrict__ tokens, const int32_t* __restrict__ token_op,
+                               int V, int T_dec, int N, int32_t* __restrict__ dec_len) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  int len = T_dec;
+  for (int t = T_dec - 1; t >= 0; --t) {
+    const int tok = tokens[(size_t)t * N + n];
+    if (tok >= 0 && tok < V && token_op[tok] < 0) len = t;
+  }
+  dec_len[n] = len;
+}
+
+// eos_retire: the decoder's state rows in the order of `perm` (rows by decreasing layout length, so the
+// rows still alive at a step are a prefix): dst_i[k4][r] = src_i[k4][perm[r]] for the four initial state
+// arrays (k-interleaved [L/4][R][4]) and, in the split-operand mode, the bf16 planes [3][L/8][R][8] of
+// the two hidden states.
+struct GatherArgs {
+  const float* src[4]; float* dst[4];
+  const uint16_t* srcb[2]; uint16_t* dstb[2];   // planes of src[0] / src[2] or nullptr
+  const int32_t* perm;
+  int N, L, R;
+};
+__global__ __launch_bounds__(256) void gather_state_kernel(GatherArgs g) {
+  const int r = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int sub = threadIdx.x >> 6;                       // 4 k-slices per workgroup
+  if (r >= g.N) return;
+  const int pr = g.perm[r];
+  const int k4n = g.L / 4;
+  for (int k4 = blockIdx.y * 4 + sub; k4 < k4n; k4 += gridDim.y * 4) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 v = *reinterpret_cast<const float4*>(g.src[i] + ((size_t)k4 * g.R + pr) * 4);
+      *reinterpret_cast<float4*>(g.dst[i] + ((size_t)k4 * g.R + r) * 4) = v;
+    }
+  }
+  if (g.srcb[0]) {
+    const size_t plane = (size_t)(g.L / 8) * g.R * 8;
+    const int k8n = g.L / 8;
+    for (int k8 = blockIdx.y * 4 + sub; k8 < k8n; k8 += gridDim.y * 4) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const uint4 v = *reinterpret_cast<const uint4*>(g.srcb[i] + p * plane + ((size_t)k8 * g.R + pr) * 8);
+          *reinterpret_cast<uint4*>(g.dstb[i] + p * plane + ((size_t)k8 * g.R + r) * 8) = v;
+        }
+    }
+  }
 }
 
 __global__ void dec_init_kernel(int32_t* state, int N, int T_dec) {
@@ -1600,6 +1664,29 @@ void launch_enc_prepare(const int32_t* seq_len, int N, int T, int32_t* perm, int
   blocks = std::max(blocks, std::min(64, (N + 255) / 256 + T / 4));
   hipLaunchKernelGGL(enc_prepare_kernel, dim3(blocks), dim3(256), 0, s, seq_len, N, T, perm, n_active,
                      reinterpret_cast<float4*>(zero), zero ? z4 : 0, zero_int);
+}
+
+void launch_dec_len(const int32_t* tokens, const int32_t* token_op, int V, int T_dec, int N,
+                    int32_t* dec_len, hipStream_t s) {
+  hipLaunchKernelGGL(dec_len_kernel, dim3((N + 255) / 256), dim3(256), 0, s, tokens, token_op, V, T_dec, N,
+                     dec_len);
+}
+
+void launch_gather_state(const float* const src[4], float* const dst[4], const uint16_t* const srcb[2],
+                         uint16_t* const dstb[2], const int32_t* perm, int N, int L, int R, hipStream_t s) {
+  GatherArgs g{};
+  for (int i = 0; i < 4; ++i) { g.src[i] = src[i]; g.dst[i] = dst[i]; }
+  for (int i = 0; i < 2; ++i) { g.srcb[i] = srcb ? srcb[i] : nullptr; g.dstb[i] = dstb ? dstb[i] : nullptr; }
+  g.perm = perm; g.N = N; g.L = L; g.R = R;
+  hipLaunchKernelGGL(gather_state_kernel, dim3((N + 63) / 64, std::min(32, std::max(1, L / 16))), dim3(256), 0, s, g);
+}
+
+bool dec_question_supported(const DecStepArgs& a, int nsteps) {
+  const int Tp = (a.T + 3) & ~3;
+  const size_t smem = sizeof(float) * ((size_t)std::max(a.T, nsteps) * a.L + 32 * (size_t)Tp + 16 * 4 * MAXV);
+  return nsteps > 1 && nsteps <= 20 && a.N >= 128 && !a.uni && !a.forced && a.use_gt && a.L == 512 &&
+         !(smem > 150 * 1024 || (size_t)a.T * a.L > (size_t)3 * 2 * 4096 ||
+           (size_t)nsteps * (a.L + 16 * MAXV) > (size_t)std::max(a.T, nsteps) * a.L);
 }
 
 void launch_dec_init(int32_t* state, int N, int T_dec, hipStream_t s) {

@@ -148,8 +148,8 @@ __host__ __device__ inline size_t walk_lds_floats(int T, int HWp, int Mp, int E,
   size_t s0 = (size_t)WW * 256;
   size_t s1 = (size_t)nrow * 2 * D;
   const int KD = (KK + 1 + 3) & ~3, Mq = (M + 15) / 16 * 16, Pq = (HW + 15) / 16 * 16;
-  size_t s2 = (((size_t)(H + 2 * pad) * (W + 2 * pad) + 4) & ~3) + (size_t)WW * Pq * 2;
-  (void)RS; (void)KD; (void)Mq;
+  size_t s2 = (size_t)Mq + (((size_t)(H + 2 * pad) * (W + 2 * pad) + 4) & ~3) + (size_t)WW * Pq * 2;
+  (void)RS; (void)KD;
   size_t s3 = (size_t)((2 * HW + 4 + 3) & ~3) + (size_t)WT;
   size_t s = s0 > s1 ? s0 : s1;
   s = s > s2 ? s : s2;
@@ -165,108 +165,113 @@ namespace {
 // only: packed k-major at commit time, ModuleWeights::trA) and X[:, p] = [KSxKS window of pixel p, 1,
 // 0..], the text map enters only the epilogue:
 //     att[p] = (sum_c tm[c] w_e[c] u[c,p]) / sqrt(max(sum_c (tm[c] u[c,p])^2, eps)) + b_e.
-// Wave w owns channel tiles w, w + 8, ...: its A fragments come straight from L2 (64-B segments), the
-// B fragments straight from the zero-padded map in LDS (no im2col buffer: per-lane window offsets),
-// all pixel tiles accumulate in independent MFMA chains (a single dependent chain per wave ran the
-// matrix pipe at ~1/6 of its rate), and u is folded into per-pixel partial sums in the MFMA's own
-// output layout (a lane holds 4 channels of one pixel), so it never leaves registers.
+// Wave (g = w & 3, h = w >> 2) owns the channel tiles g, g + 4, ... and HALF of the pixel tiles (PTW of
+// them): its A fragments come straight from L2 (64-B segments), the B fragments straight from the
+// zero-padded map in LDS (no im2col buffer: per-lane window offsets), its PTW pixel tiles accumulate in
+// independent MFMA chains, and u is folded into per-pixel partial sums in the MFMA's own output layout
+// (a lane holds 4 channels of one pixel), so it never leaves registers.
+// Round 5: a wave used to hold ALL pixel tiles of two channel tiles (70 B-fragment registers + 40
+// accumulators: > 128 VGPRs, one workgroup per CU, the matrix phase at twice its MFMA issue time because
+// the 8 waves of the only resident workgroup walk through operand build / MFMAs / folds in lock step).
+// With half the pixel tiles per wave the function fits 128 VGPRs, walk_heavy_kernel runs TWO workgroups
+// per CU, and one job's operand build and fold phases hide under the other's MFMAs.
 // History: VALU, taps broadcast from LDS: 45 us per node; 6 interleaved FMA chains: 13 us;
-// MFMA with per-node operand build + one chain: 15 us.
-template <int KS>
-__device__ __forceinline__ void walk_transform(int tid, const ModuleWeights& w, const WalkArgs& a,
-                                               const float* in0, const float* tm, float* outp,
-                                               float* scr, long long* tl) {
+// MFMA with per-node operand build + one chain: 15 us; 10 chains per wave, one workgroup per CU: 11.6 us.
+constexpr int TR_CG = 4;                         // channel groups (x 2 pixel halves = the 8 waves)
+template <int KS, int PTW>
+__device__ __forceinline__ void walk_transform_t(int tid, const ModuleWeights& w, const WalkArgs& a,
+                                                 const float* in0, const float* tm, float* outp,
+                                                 float* scr, long long* tl) {
+  // scr: [Mq] tm (.) w_e | zero-padded map | fold buffer
   constexpr int KK = KS * KS;
   constexpr int KD = (KK + 1 + 3) & ~3;          // taps + bias row, padded to the MFMA's k = 4
   constexpr int NS = KD / 4;                     // k-steps
   constexpr int PAD = KS / 2;
-  constexpr int PTMAX = (WALK_MAX_PIXEL_GROUPS * 64 + 15) / 16;
   const int H = a.H, W = a.W, HW = H * W, M = a.M;
   const int PW = W + 2 * PAD, PH = H + 2 * PAD;
   const int Mt = (M + 15) >> 4, Pt = (HW + 15) >> 4;     // 16-wide channel / pixel tiles
-  const int Mq = Mt * 16, Pq = Pt * 16;
-  float* xin = scr;                              // [PH][PW] zero-padded input map (+ 1 spare = 0)
-  float* red = xin + ((PH * PW + 4) & ~3);       // [WW][Pq][2]
+  const int Mq = Mt * 16, Pq = 2 * PTW * 16;
+  float* twl = scr;                              // [Mq] tm[c] * w_e[c] (both zero padded to Mp >= Mq)
+  float* xin = twl + Mq;                         // [PH][PW] zero-padded input map (+ 1 spare = 0)
+  float* red = xin + ((PH * PW + 4) & ~3);       // [TR_CG][Pq][2]
   const int lane = tid & 63, wid = tid >> 6;
   const int ci = lane & 15, kg = lane >> 4;
   const int cw = __builtin_amdgcn_readfirstlane(wid);
+  const int g = cw & (TR_CG - 1), pt0 = (cw / TR_CG) * PTW;
   // A fragments of this wave's first channel tile: issued before anything else
   float af[NS];
   {
-    const int ct0 = min(cw, Mt - 1);
+    const int ct0 = min(g, Mt - 1);
 #pragma unroll
     for (int sI = 0; sI < NS; ++sI) af[sI] = w.trA[(4 * sI + kg) * Mq + 16 * ct0 + ci];
   }
-  // w_e of this lane's 4 channel rows of the first tile (zero padded to Mp >= Mq: one 16-byte read, no
-  // bounds branch), requested with them
-  float4 wev = *reinterpret_cast<const float4*>(w.we[2] + 16 * min(cw, Mt - 1) + 4 * kg);
+  // tm (.) w_e for the fold, once per node (it used to ride in registers per channel tile, prefetched
+  // like the A fragments: 8 VGPRs of a 128-VGPR budget)
+  for (int c = tid; c < Mq; c += WT) twl[c] = tm[c] * w.we[2][c];
   for (int i = tid; i <= PH * PW; i += WT) {
     const int y = i / PW - PAD, x = i % PW - PAD;
     xin[i] = (i < PH * PW && y >= 0 && y < H && x >= 0 && x < W) ? in0[y * W + x] : 0.f;
   }
-  // per-lane window offsets: k = 4*sI + kg -> (dy, dx); the bias row is a constant 1, rows beyond 0
-  int koff[NS];
-  float kmask[NS], kone[NS];
-#pragma unroll
-  for (int sI = 0; sI < NS; ++sI) {
-    const int k = 4 * sI + kg;
-    const int dy = k / KS, dx = k - dy * KS;
-    koff[sI] = k < KK ? dy * PW + dx : 0;
-    kmask[sI] = k < KK ? 1.f : 0.f;
-    kone[sI] = k == KK ? 1.f : 0.f;
-  }
-  int poff[PTMAX];
-  const float invW = 1.0f / (float)W;
-#pragma unroll
-  for (int pt = 0; pt < PTMAX; ++pt) {
-    const int p = min(16 * pt + ci, HW - 1);
-    int y = (int)(((float)p + 0.5f) * invW);       // p / W without the 40-instruction integer division
-    y -= y * W > p;                                // (exact for these small values; the fix-ups make it so)
-    y += (y + 1) * W <= p;
-    poff[pt] = y * PW + (p - y * W);
-  }
   __syncthreads();
   if (tl && threadIdx.x == 0) tl[1] = clock64();       // debug timeline: operands ready
-  float ssp[PTMAX], dtp[PTMAX];
+  // B fragments are the same for every channel tile: read them from LDS once.  Window offsets per lane:
+  // k = 4*sI + kg -> (dy, dx); the bias row is a constant 1, rows beyond it 0
+  float xf[NS][PTW];
+  {
+    const float invW = 1.0f / (float)W;
+    int poff[PTW];
 #pragma unroll
-  for (int pt = 0; pt < PTMAX; ++pt) { ssp[pt] = 0.f; dtp[pt] = 0.f; }
-  // B fragments are the same for every channel tile: read them from LDS once
-  float xf[NS][PTMAX];
+    for (int pt = 0; pt < PTW; ++pt) {
+      const int p = min(16 * (pt0 + pt) + ci, HW - 1);
+      int y = (int)(((float)p + 0.5f) * invW);       // p / W without the 40-instruction integer division
+      y -= y * W > p;                                // (exact for these small values; the fix-ups make it so)
+      y += (y + 1) * W <= p;
+      poff[pt] = y * PW + (p - y * W);
+    }
 #pragma unroll
-  for (int sI = 0; sI < NS; ++sI)
+    for (int sI = 0; sI < NS; ++sI) {
+      const int k = 4 * sI + kg;
+      const int dy = k / KS, dx = k - dy * KS;
+      const int koff = k < KK ? dy * PW + dx : 0;
+      const float kmask = k < KK ? 1.f : 0.f, kone = k == KK ? 1.f : 0.f;
 #pragma unroll
-    for (int pt = 0; pt < PTMAX; ++pt) xf[sI][pt] = xin[poff[pt] + koff[sI]] * kmask[sI] + kone[sI];
+      for (int pt = 0; pt < PTW; ++pt) xf[sI][pt] = xin[poff[pt] + koff] * kmask + kone;
+    }
+  }
+  float ssp[PTW], dtp[PTW];
+#pragma unroll
+  for (int pt = 0; pt < PTW; ++pt) { ssp[pt] = 0.f; dtp[pt] = 0.f; }
   // (debug timeline, second row of the node = row t + 16: [0] B fragments built, [1] / [2] first / last
   // channel tile of wave 0 done, [3] folds done)
   long long* tl2 = tl ? tl + 16 * 4 : nullptr;
   if (tl2 && threadIdx.x == 0) tl2[0] = clock64();
-  for (int ct = cw; ct < Mt; ct += WW) {
-    const float4 tmv = *reinterpret_cast<const float4*>(tm + 16 * ct + 4 * kg);
-    const float tm4[4] = {tmv.x, tmv.y, tmv.z, tmv.w};
-    const float tw4[4] = {tmv.x * wev.x, tmv.y * wev.y, tmv.z * wev.z, tmv.w * wev.w};
+  for (int ct = g; ct < Mt; ct += TR_CG) {
     // the NEXT tile's operands from L2 go out before this tile's MFMAs, not behind them: the round trip
-    // (~1-2 k clocks) then runs under 70 MFMAs instead of in front of the next tile (the timeline had
-    // the matrix phase at 17.7 k clocks for 9 k clocks of MFMA issue)
+    // (~1-2 k clocks) then runs under the MFMAs instead of in front of the next tile
     float afn[NS];
-    float4 wen = wev;
-    const bool more = ct + WW < Mt;
+    const bool more = ct + TR_CG < Mt;
     if (more) {
 #pragma unroll
-      for (int sI = 0; sI < NS; ++sI) afn[sI] = w.trA[(4 * sI + kg) * Mq + 16 * (ct + WW) + ci];
-      wen = *reinterpret_cast<const float4*>(w.we[2] + 16 * (ct + WW) + 4 * kg);
+      for (int sI = 0; sI < NS; ++sI) afn[sI] = w.trA[(4 * sI + kg) * Mq + 16 * (ct + TR_CG) + ci];
     }
-    f32x4 acc[PTMAX];
+    f32x4 acc[PTW];
 #pragma unroll
-    for (int pt = 0; pt < PTMAX; ++pt) acc[pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int pt = 0; pt < PTW; ++pt) acc[pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int sI = 0; sI < NS; ++sI) {
 #pragma unroll
-      for (int pt = 0; pt < PTMAX; ++pt) {
+      for (int pt = 0; pt < PTW; ++pt) {
         acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[sI], xf[sI][pt], acc[pt], 0, 0, 0);
       }
     }
+    // (the text map of the tile's channels is only needed by the fold: read behind the MFMAs, so that it
+    // does not hold registers while they run)
+    const float4 tmv = *reinterpret_cast<const float4*>(tm + 16 * ct + 4 * kg);
+    const float4 twv = *reinterpret_cast<const float4*>(twl + 16 * ct + 4 * kg);
+    const float tm4[4] = {tmv.x, tmv.y, tmv.z, tmv.w};
+    const float tw4[4] = {twv.x, twv.y, twv.z, twv.w};
 #pragma unroll
-    for (int pt = 0; pt < PTMAX; ++pt) {
+    for (int pt = 0; pt < PTW; ++pt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float v = tm4[r] * acc[pt][r];
@@ -277,23 +282,22 @@ __device__ __forceinline__ void walk_transform(int tid, const ModuleWeights& w, 
     if (more) {
 #pragma unroll
       for (int sI = 0; sI < NS; ++sI) af[sI] = afn[sI];
-      wev = wen;
     }
-    if (tl2 && threadIdx.x == 0) tl2[ct == cw ? 1 : 2] = clock64();
+    if (tl2 && threadIdx.x == 0) tl2[ct == g ? 1 : 2] = clock64();
   }
-  // a pixel's channels sit in the four 16-lane rows of the wave: fold them, then across waves.  Two
-  // half / row exchanges in registers (v_permlane32_swap, v_permlane16_swap) fold BOTH sums at once --
-  // sum of squares ends up in lanes 0-15, the dot product in lanes 32-47 -- where four __shfl_xor per
-  // pixel tile were four ds_bpermute round trips through the LDS hardware (40 per node).  The four
-  // rows are summed as (row0 + row2) + (row1 + row3).
+  // a pixel's channels sit in the four 16-lane rows of the wave: fold them, then across the channel
+  // groups.  Two half / row exchanges in registers (v_permlane32_swap, v_permlane16_swap) fold BOTH sums
+  // at once -- sum of squares ends up in lanes 0-15, the dot product in lanes 32-47 -- where four
+  // __shfl_xor per pixel tile were four ds_bpermute round trips through the LDS hardware.  The four rows
+  // are summed as (row0 + row2) + (row1 + row3).
 #pragma unroll
-  for (int pt = 0; pt < PTMAX; ++pt) {
+  for (int pt = 0; pt < PTW; ++pt) {
     const auto h = __builtin_amdgcn_permlane32_swap(__float_as_uint(ssp[pt]), __float_as_uint(dtp[pt]),
                                                     false, false);
     float v = __uint_as_float(h[0]) + __uint_as_float(h[1]);
     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    if ((kg & 1) == 0 && pt < Pt) red[((size_t)wid * Pq + 16 * pt + ci) * 2 + (kg >> 1)] = v;
+    if ((kg & 1) == 0 && pt0 + pt < Pt) red[((size_t)g * Pq + 16 * (pt0 + pt) + ci) * 2 + (kg >> 1)] = v;
   }
   if (tl2 && threadIdx.x == 0) tl2[3] = clock64();
   __syncthreads();
@@ -302,13 +306,22 @@ __device__ __forceinline__ void walk_transform(int tid, const ModuleWeights& w, 
   for (int p = tid; p < HW; p += WT) {
     float s2 = 0.f, d2 = 0.f;
 #pragma unroll
-    for (int q = 0; q < WW; ++q) {
+    for (int q = 0; q < TR_CG; ++q) {
       s2 += red[((size_t)q * Pq + p) * 2];
       d2 += red[((size_t)q * Pq + p) * 2 + 1];
     }
     outp[p] = d2 / sqrtf(fmaxf(s2, 1e-12f)) + be;
   }
   __syncthreads();
+}
+
+template <int KS>
+__device__ __forceinline__ void walk_transform(int tid, const ModuleWeights& w, const WalkArgs& a,
+                                               const float* in0, const float* tm, float* outp,
+                                               float* scr, long long* tl) {
+  // pixel tiles per wave: half of ceil(H*W / 16), at most 6 (H*W <= 192: walk_supported)
+  if ((a.H * a.W + 15) / 16 <= 10) walk_transform_t<KS, 5>(tid, w, a, in0, tm, outp, scr, tl);
+  else walk_transform_t<KS, 6>(tid, w, a, in0, tm, outp, scr, tl);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -474,16 +487,10 @@ __device__ __forceinline__ void walk_find_pass(int tid, const ModuleWeights& w, 
   }
 }
 
+// one question's whole module network (walk_kernel's body)
 template <int CI>
-__global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  __shared__ WalkLds L;
-  int q = blockIdx.x;
-  if (a.staged) {              // staged passes: only the questions the plan listed as nested too deep
-    if (q >= a.cnt[1]) return;
-    q = a.fblist[q];
-    if (a.stats && threadIdx.x == 0) atomicAdd(a.stats + 9, 1ull);
-  }
+__device__ __forceinline__ void walk_question(const ModuleWeights& w, const WalkArgs& a, int q, float* smem,
+                                              WalkLds& L) {
   const int kb = q / a.N, n = q - kb * a.N;
   const WalkBatch& B = a.b[kb];
   const int tid0 = threadIdx.x;
@@ -945,6 +952,26 @@ __global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
   }
 }
 
+// Plain passes: workgroup = question.  Staged passes: only the questions the plan listed as nested deeper
+// than the pass launches levels for (fblist, its length on the device) -- a persistent grid of one
+// workgroup per CU walks the list, so the template mix (an empty list) pays for 256 workgroups that leave
+// at once instead of one 150 KB-LDS workgroup per question of the pass (4.7 us).
+template <int CI>
+__global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ WalkLds L;
+  if (!a.staged) {
+    walk_question<CI>(w, a, blockIdx.x, smem, L);
+    return;
+  }
+  const int nfb = min(a.cnt[1], a.K * a.N);
+  for (int i = blockIdx.x; i < nfb; i += gridDim.x) {
+    __syncthreads();                                   // the previous question's readers of L / smem are done
+    if (a.stats && threadIdx.x == 0) atomicAdd(a.stats + 9, 1ull);
+    walk_question<CI>(w, a, a.fblist[i], smem, L);
+  }
+}
+
 }  // namespace
 
 namespace {
@@ -1146,23 +1173,13 @@ __device__ __forceinline__ FindRows<CI> find_load(const float* Mbuf, int rb, int
 }
 
 // `pre` holds the first batch of this wave's rows (rows r0 + wid + u * FW), requested by the caller
-// before anything else.
+// before anything else.  t4 / e4: text maps of the NF nodes and conv_eltwise weights at this lane's columns.
 template <int CI, int NF, bool ONE>
-__device__ __forceinline__ void find_rows(int tid, const ModuleWeights& w, const float* Mbuf,
-                                          const float* const* ts, float* const* os, int r0, int r1,
-                                          int Mp, const FindRows<CI> pre) {
+__device__ __forceinline__ void find_rows_core(int tid, float be, const float4 (&e4)[CI],
+                                               const float4 (&t4)[NF][CI], const float* Mbuf,
+                                               float* const* os, int r0, int r1, int Mp,
+                                               const FindRows<CI> pre) {
   const int lane = tid & 63, wid = tid >> 6;
-  const float be = w.be[0][0];
-  float4 t4[NF][CI], e4[CI];
-#pragma unroll
-  for (int i = 0; i < CI; ++i) {
-    const int c = 4 * lane + 256 * i;
-    const bool ok = c < Mp;
-    e4[i] = ok ? *reinterpret_cast<const float4*>(w.we[0] + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int j = 0; j < NF; ++j)
-      t4[j][i] = ok ? *reinterpret_cast<const float4*>(ts[j] + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
   constexpr int UNR = FindUnroll<CI>::value;
   for (int rb = r0 + wid; rb < r1; rb += UNR * FW) {
     // ONE: the first batch is all of this wave's rows (r1 - r0 <= UNR * FW, checked by the launcher)
@@ -1186,6 +1203,24 @@ __device__ __forceinline__ void find_rows(int tid, const ModuleWeights& w, const
       }
     }
   }
+}
+
+template <int CI, int NF, bool ONE>
+__device__ __forceinline__ void find_rows(int tid, const ModuleWeights& w, const float* Mbuf,
+                                          const float* const* ts, float* const* os, int r0, int r1,
+                                          int Mp, const FindRows<CI> pre) {
+  const int lane = tid & 63;
+  float4 t4[NF][CI], e4[CI];
+#pragma unroll
+  for (int i = 0; i < CI; ++i) {
+    const int c = 4 * lane + 256 * i;
+    const bool ok = c < Mp;
+    e4[i] = ok ? *reinterpret_cast<const float4*>(w.we[0] + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+      t4[j][i] = ok ? *reinterpret_cast<const float4*>(ts[j] + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  find_rows_core<CI, NF, ONE>(tid, w.be[0][0], e4, t4, Mbuf, os, r0, r1, Mp, pre);
 }
 
 // The question's layout comes from the pass's plan (WalkProg written by walk_tmap_kernel): a scalar
@@ -1222,6 +1257,84 @@ __global__ __launch_bounds__(FT, (CI == 1 ? 8 : 1)) void walk_find_kernel(Module
     }
     if (nf == 1) find_rows<CI, 1, ONE>(tid, w, Mbuf, ts, os, r0, r1, Mp, pre);
     else find_rows<CI, 2, ONE>(tid, w, Mbuf, ts, os, r0, r1, Mp, pre);
+  }
+}
+
+// walk_find16_kernel (round 5): the same epilogue with SIXTEEN lanes per map row instead of sixty-four.
+// walk_find_kernel gives a row to a whole wave (a float4 per lane at Mp = 256), so every (row, node) pair
+// costs a 64-lane reduction of two values (8 DPP steps + 2 v_readlane) and an IEEE sqrt + division issued
+// for ONE useful value: ~40 VALU instructions around 12 FMAs.  Here a wave holds 4 rows at a time (lane =
+// (row of the group, 16 channels as NL float4 at 64-B stride: the 16 lanes of a row read 256 contiguous
+// bytes per load), the reduction stays inside the 16-lane DPP row (4 steps, no cross-row traffic), and the
+// square root / division serve four rows per instruction: 2.1 x fewer VALU instructions per map byte.
+// A workgroup (4 waves) owns 32 rows -- 8 per wave, all in flight before the plan is read -- and sweeps the
+// question's Find / Filter nodes one at a time over rows that stay in registers (the next node's text map
+// is requested under the current sweep).
+constexpr int F16_ROWS = 32;
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f<0xB1, 0xF>(0.f, v);     // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E, 0xF>(0.f, v);     // quad_perm [2,3,0,1]
+  v += dpp_f<0x141, 0xF>(0.f, v);    // row_half_mirror
+  v += dpp_f<0x140, 0xF>(0.f, v);    // row_mirror: every lane holds its 16-lane row's sum
+  return v;
+}
+template <int NL>
+__global__ __launch_bounds__(FT, 5) void walk_find16_kernel(ModuleWeights w, WalkArgs a) {
+  const int q = blockIdx.x;
+  const int kb = q / a.N, n = q - kb * a.N;
+  const WalkBatch& B = a.b[kb];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int cl = lane & 15, rg = lane >> 4;
+  const int T = a.T, HW = a.H * a.W, Mp = a.Mp, HWp = a.HWp;
+  const int r0 = blockIdx.y * F16_ROWS + 8 * wid;      // this wave's rows r0 .. r0 + 7 (wave-uniform)
+  if (r0 >= HW) return;
+  const float* Mbuf = B.mfind + (size_t)n * HW * Mp;
+  float4 m[2][NL];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const unsigned r = (unsigned)min(r0 + 4 * u + rg, HW - 1);
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      m[u][i] = *reinterpret_cast<const float4*>(Mbuf + (r * (unsigned)Mp + 4u * cl + 64u * i));
+  }
+  const WalkProg* P = B.prog + n;                      // uniform address: scalar loads
+  const int nfind = P->valid ? P->nfind : 0;
+  if (nfind == 0) return;
+  const float be = w.be[0][0];
+  float4 e4[NL], tn[NL];
+  {
+    const float* t0 = B.tmap + ((size_t)P->flist[0] * a.N + n) * Mp;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      e4[i] = *reinterpret_cast<const float4*>(w.we[0] + 4 * cl + 64 * i);
+      tn[i] = *reinterpret_cast<const float4*>(t0 + 4 * cl + 64 * i);
+    }
+  }
+  for (int f = 0; f < nfind; ++f) {
+    const int t = P->flist[f];
+    float4 t4[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) t4[i] = tn[i];
+    if (f + 1 < nfind) {
+      const float* t1 = B.tmap + ((size_t)P->flist[f + 1] * a.N + n) * Mp;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) tn[i] = *reinterpret_cast<const float4*>(t1 + 4 * cl + 64 * i);
+    }
+    float* os = B.watt + ((size_t)n * T + t) * HWp;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float ss = 0.f, dot = 0.f;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const float p0 = m[u][i].x * t4[i].x, p1 = m[u][i].y * t4[i].y,
+                    p2 = m[u][i].z * t4[i].z, p3 = m[u][i].w * t4[i].w;
+        ss += p0 * p0 + p1 * p1 + p2 * p2 + p3 * p3;
+        dot += p0 * e4[i].x + p1 * e4[i].y + p2 * e4[i].z + p3 * e4[i].w;
+      }
+      const float s2 = row16_sum(ss), d2 = row16_sum(dot);
+      const int r = r0 + 4 * u + rg;
+      if (cl == 0 && r < HW) os[r] = d2 / sqrtf(fmaxf(s2, 1e-12f)) + be;   // l2_normalize eps (A.4)
+    }
   }
 }
 
@@ -1493,155 +1606,172 @@ __device__ __forceinline__ void eval_light_range(int tid, const WalkProg& P, int
   }
 }
 
-// FindSameProperty of one node (nmn3_modules.py:134-183): soft-max pooling of the image features
-// under the input map, fc_att, then the Find-type epilogue over the operator's own conv_image map --
-// walk_kernel's statements for this operator.
-template <int CI>
-__device__ __forceinline__ void heavy_fsp(int tid, const ModuleWeights& w, const WalkArgs& a,
-                                          const float* feat, const float* Mbuf, const float* in0,
-                                          const float* tml, float* outp, float* am0, float* pooled,
-                                          float* sa0, float* rs, float* scr, long long* tl) {
-  const int HW = a.H * a.W, D = a.D, Mp = a.Mp;
-  const int ncol = D / 4, nrow = WT / ncol;
+// FindSameProperty (nmn3_modules.py:134-183) as chip-wide stages (round 5).  One workgroup per node ran
+// its three dependent streams -- 307 KB feature pool, 512 KB fc_att weights, 154 KB map epilogue -- at ONE
+// CU's pace (17-46 GB/s: 31.6 us per node, 104 of them per 1024 questions set the length of the launch).
+// Now a node is WALK_POOL_PARTS items of stage A inside walk_heavy_kernel and as many workgroups of stage B:
+//   A (fsp_pool_item): channel part `part` of the soft-max pooling (:170-172) -- 38 KB of the feature map,
+//     every load in flight before the input subtree is evaluated under them -- and, because fc_att is
+//     linear (:173-176), that part's share of it: pooled[part] . W_att[rows of the part] -> fpart[n][t][part]
+//     (64 KB of weights per item, requested with the features; the full product is the bias plus the eight
+//     shares, summed in part order by stage B: no atomics, a fixed order);
+//   B (walk_fspepi_kernel): att = l2norm_c(M_fsp[r, c] * tmap[c] * am[c]) . w_e + b_e (:178-180) over the
+//     operator's own conv_image map, 8 workgroups per node streaming their rows like walk_find_kernel.
+__device__ __forceinline__ void fsp_pool_item(int tid, const ModuleWeights& w, const WalkArgs& a,
+                                              const WalkBatch& B, const WalkProg& P, int n, int t, int part,
+                                              float* arena, float* pp, float* sa0, float* scr, bool heavy_too) {
+  const int HW = a.H * a.W, D = a.D, Mp = a.Mp, HWp = a.HWp, T = a.T;
+  const int Dp = D / POOLP, ncol = Dp / 4, nrow = WT / ncol;
   const int lane = tid & 63, wid = tid >> 6;
   const int lc = tid % ncol, lr = tid / ncol;
-  constexpr int PR = WALK_POOL_ROWS;
-  float4 fr[PR];
+  constexpr int PR = (WALK_POOLK_ROWS + 1) / 2;          // rows of a thread (walk_pool_supported's bound, 512 threads)
+  // ---- the feature rows of this thread, then the first fc_att weight rows: nothing depends on the tree
+  const float* fp = B.feat + (size_t)n * HW * D + part * Dp + 4 * lc;
   const int myrows = lr < nrow ? (HW - lr + nrow - 1) / nrow : 0;
+  float4 fr[PR];
   {
     const unsigned rowstep = (unsigned)(nrow * D);
-    unsigned off = (unsigned)(lr * D + 4 * lc);
-    const unsigned last = (unsigned)(((myrows > 0 ? lr + (myrows - 1) * nrow : 0)) * D + 4 * lc);
+    unsigned off = (unsigned)(lr * D);
+    const unsigned last = (unsigned)((myrows > 0 ? lr + (myrows - 1) * nrow : 0) * D);
 #pragma unroll
     for (int qq = 0; qq < PR; ++qq) {
-      fr[qq] = *reinterpret_cast<const float4*>(feat + min(off, last));
+      fr[qq] = *reinterpret_cast<const float4*>(fp + min(off, last));
       off += rowstep;
     }
   }
-  __builtin_amdgcn_sched_barrier(0);
-  {                                                      // soft-max over the H*W logits (:170-172)
-    float lm = -INFINITY;
-    for (int r = tid; r < HW; r += WT) lm = fmaxf(lm, in0[r]);
-    const float mx = wg_reduce<1>(lm, rs);
-    float ls = 0.f;
-    for (int r = tid; r < HW; r += WT) {
-      const float ex = expf(in0[r] - mx);
-      sa0[r] = ex;
-      ls += ex;
+  // fc_att share: k-group kq = wave (Dp / 8 rows of the part each), float4 columns over the lanes
+  constexpr int KU = 8;
+  const int kper = (Dp + WW - 1) / WW;
+  const int k0 = part * Dp + wid * kper, k1 = min(part * Dp + Dp, k0 + kper);
+  const float* Wp = w.Watt[0];
+  float4 w4[KU];
+  auto fetch = [&](int kb, unsigned col) {
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      const unsigned k = (unsigned)min(kb + u, max(k1 - 1, k0));
+      w4[u] = *reinterpret_cast<const float4*>(Wp + (k * (unsigned)Mp + col));
     }
-    const float sum = wg_reduce<0>(ls, rs);
-    for (int r = tid; r < HW; r += WT) sa0[r] = sa0[r] / sum;
+  };
+  fetch(k0, (unsigned)min(4 * lane, Mp - 4));
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- the node's input map (its light subtree; the maps of lower levels come from watt)
+  const int i0 = P.in0[t];
+  eval_light_range(tid, P, P.lo[i0], i0, B.watt + (size_t)n * T * HWp, arena, HW, HWp, heavy_too);
+  const float* in0 = arena + (size_t)i0 * HWp;
+  // soft-max over the H*W logits (:170-172): a wave per 192 values, in registers (walk_light_kernel's form)
+  if (wid == 0) {                                        // (H*W <= 192: walk_supported)
+    float v[3], lm = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int r = lane + 64 * u;
+      v[u] = r < HW ? in0[r] : -INFINITY;
+      lm = fmaxf(lm, v[u]);
+    }
+    const float mx = wave_max(lm);
+    float ls = 0.f;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) { v[u] = lane + 64 * u < HW ? expf(v[u] - mx) : 0.f; ls += v[u]; }
+    const float sum = wave_sum(ls);
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+      if (lane + 64 * u < HW) sa0[lane + 64 * u] = v[u] / sum;
   }
   __syncthreads();
-  float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f);
-  float* stage = scr;                                    // [nrow][2][D] (walk_kernel's layout)
+  float* stage = scr;                                    // [nrow][Dp]
   if (lr < nrow) {
+    float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int qq = 0; qq < PR; ++qq) {
       if (qq < myrows) {
-        const int r = lr + qq * nrow;
-        const float w0 = sa0[r];
+        const float w0 = sa0[lr + qq * nrow];
         acc0.x += w0 * fr[qq].x; acc0.y += w0 * fr[qq].y; acc0.z += w0 * fr[qq].z; acc0.w += w0 * fr[qq].w;
       }
     }
-    *reinterpret_cast<float4*>(stage + (size_t)(lr * 2 + 0) * D + 4 * lc) = acc0;
+    *reinterpret_cast<float4*>(stage + (size_t)lr * Dp + 4 * lc) = acc0;
   }
   __syncthreads();
-  for (int i = tid; i < D; i += WT) {
+  for (int c = tid; c < Dp; c += WT) {
     float sacc = 0.f;
-    for (int qq = 0; qq < nrow; ++qq) sacc += stage[(size_t)(qq * 2) * D + i];
-    pooled[i] = sacc;
+    for (int qq = 0; qq < nrow; ++qq) sacc += stage[(size_t)qq * Dp + c];
+    pp[c] = sacc;
   }
   __syncthreads();
-  if (tl && threadIdx.x == 0) tl[1] = clock64();
-  fc_pad<32>(tid, pooled, D, w.Watt[0], w.batt[0], Mp, am0, scr, nullptr);     // :173-176
-  __syncthreads();
-  if (tl && threadIdx.x == 0) tl[2] = clock64();
-  const float be = w.be[1][0];
-  float4 t4[CI], e4[CI];
+  // ---- this part's share of fc_att (:173-176): fpart[n][t][part][c] = sum_{k in part} pooled[k] W[k][c]
+  float* red = scr;                                      // [WW][256]
+  float* dst = B.fpart + (((size_t)n * T + t) * POOLP + part) * Mp;
+  for (int cb = 0; cb < Mp; cb += 256) {
+    const unsigned col = (unsigned)min(cb + 4 * lane, Mp - 4);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int kb = k0; kb < k1; kb += KU) {
+      if (kb != k0 || cb != 0) fetch(kb, col);
 #pragma unroll
-  for (int i = 0; i < CI; ++i) {
-    const int c = 4 * lane + 256 * i;
-    if (c < Mp) {
-      t4[i] = *reinterpret_cast<const float4*>(tml + c);
-      e4[i] = *reinterpret_cast<const float4*>(w.we[1] + c);
-      const float4 a4 = *reinterpret_cast<const float4*>(am0 + c);
-      t4[i].x *= a4.x; t4[i].y *= a4.y; t4[i].z *= a4.z; t4[i].w *= a4.w;
-    } else {
-      t4[i] = make_float4(0.f, 0.f, 0.f, 0.f); e4[i] = t4[i];
-    }
-  }
-  constexpr int UNR = CI == 1 ? 19 : (CI == 2 ? 10 : 5);
-  for (int rb = wid; rb < HW; rb += UNR * WW) {
-    float4 m4[UNR][CI];
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const unsigned r = (unsigned)min(rb + u * WW, HW - 1);
-#pragma unroll
-      for (int i = 0; i < CI; ++i) {
-        const unsigned c = (unsigned)min(4 * lane + 256 * i, Mp - 4);
-        m4[u][i] = *reinterpret_cast<const float4*>(Mbuf + (r * (unsigned)Mp + c));
+      for (int u = 0; u < KU; ++u) {
+        if (kb + u < k1) {
+          const float xv = pp[kb + u - part * Dp];
+          acc.x += xv * w4[u].x; acc.y += xv * w4[u].y; acc.z += xv * w4[u].z; acc.w += xv * w4[u].w;
+        }
       }
     }
+    *reinterpret_cast<float4*>(red + (size_t)wid * 256 + 4 * lane) = acc;
+    __syncthreads();
+    if (tid < 256 && cb + tid < Mp) {
+      float r = 0.f;
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const int r = rb + u * WW;
-      float ss = 0.f, dot = 0.f;
-#pragma unroll
-      for (int i = 0; i < CI; ++i) {
-        const float p0 = m4[u][i].x * t4[i].x, p1 = m4[u][i].y * t4[i].y,
-                    p2 = m4[u][i].z * t4[i].z, p3 = m4[u][i].w * t4[i].w;
-        ss += p0 * p0 + p1 * p1 + p2 * p2 + p3 * p3;
-        dot += p0 * e4[i].x + p1 * e4[i].y + p2 * e4[i].z + p3 * e4[i].w;
-      }
-      const float s2 = wave_sum(ss);
-      const float d2 = wave_sum(dot);
-      if (lane == 0 && r < HW) outp[r] = d2 / sqrtf(fmaxf(s2, 1e-12f)) + be;   // l2_normalize eps (A.4)
+      for (int q = 0; q < WW; ++q) r += red[q * 256 + tid];
+      dst[cb + tid] = r;
     }
+    __syncthreads();
   }
-  __syncthreads();
 }
 
-template <int CI>
-__global__ __launch_bounds__(WT) void walk_heavy_kernel(ModuleWeights w, WalkArgs a) {
+// Items of a level: the Transform jobs first (microseconds of MFMA work each: they start first), then
+// WALK_POOL_PARTS stage-A items per FindSameProperty job.  Two workgroups per CU (<= 128 VGPRs, 40 KB of
+// LDS each): one item's operand / fold phases run under another's MFMAs or feature stream.
+// (launch bounds: 4 waves per SIMD = two 8-wave workgroups per CU, 128 VGPRs; one instantiation per
+// (kernel size, pixel tiles per wave) so that no variant pays for another's registers)
+template <int KS, int PTW>
+__global__ __launch_bounds__(WT, 4) void walk_heavy_kernel(ModuleWeights w, WalkArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ __attribute__((aligned(16))) WalkProg P;
   const int HW = a.H * a.W, D = a.D, Mp = a.Mp, HWp = a.HWp, T = a.T;
   float* arena = smem;                                 // [T][HWp]
   float* tml = arena + (size_t)T * HWp;                // [Mp] text map of the node
-  float* am0 = tml + Mp;                               // [Mp] fc_att
-  float* pooled = am0 + Mp;                            // [D]
-  float* sa0 = pooled + D;                             // [HWp]
-  float* rs = sa0 + HWp;                               // [32]
-  float* scr = rs + 32;                                // operator scratch (walk_lds_floats's maximum)
-  // two lists: FindSameProperty jobs (a 307 KB pool + a 512 KB fc_att stream + a 154 KB epilogue at one
-  // CU's pace: the long ones) are handed out first, Transform jobs behind them -- longest processing
-  // time first keeps the last round of the persistent grid short
+  float* pp = tml + Mp;                                // [D / POOL_PARTS] pooled features of the part
+  float* sa0 = pp + D / POOLP;                         // [HWp]
+  float* scr = sa0 + HWp;                              // operator scratch
   const int lv = a.hlevel;
   const int ctr = lv == 0 ? 0 : 6 + 2 * lv, cfs = lv == 0 ? 2 : 7 + 2 * lv;
   const int cap = (a.hoff[lv + 1] - a.hoff[lv]) / 2;
   const int nfsp = min(a.cnt[cfs], cap), ntr = min(a.cnt[ctr], cap);
   const int32_t* jtr = a.hjobs + a.hoff[lv];
   const int32_t* jfs = jtr + cap;
-  for (int j = blockIdx.x; j < nfsp + ntr; j += gridDim.x) {
+  for (int j = blockIdx.x; j < ntr + POOLP * nfsp; j += gridDim.x) {
     // the opaque copy keeps one operator's address arithmetic from being hoisted across the other
     // (see walk_kernel)
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
-    const int job = j < nfsp ? jfs[j] : jtr[j - nfsp];
+    const bool tr = j < ntr;
+    const int job = tr ? jtr[j] : jfs[(j - ntr) / POOLP];
+    const int part = tr ? 0 : (j - ntr) % POOLP;
     const int q = job >> 8, t = job & 0xff;
     if (q < 0 || q >= a.K * a.N || t >= T) continue;                 // (a stale list entry)
     const int kb = q / a.N, n = q - kb * a.N;
     const WalkBatch& B = a.b[kb];
-    __syncthreads();                                   // the previous job's readers of P / LDS are done
+    __syncthreads();                                   // the previous item's readers of P / LDS are done
     load_prog(tid, B.prog + n, P);
     __syncthreads();
     const int o = P.op[t] & 0x7f;
-    const bool heavy = o == N2NMN_OP_TRANSFORM || o == N2NMN_OP_FIND_SAME_PROPERTY;
-    if (!P.valid || P.fallback || t >= P.nn || !heavy || P.hd[t] != lv + 1 || P.in0[t] < 0) continue;
+    if (!P.valid || P.fallback || t >= P.nn || o != (tr ? N2NMN_OP_TRANSFORM : N2NMN_OP_FIND_SAME_PROPERTY) ||
+        P.hd[t] != lv + 1 || P.in0[t] < 0)
+      continue;
+    if (!tr) {
+      // (level >= 1: the Transform / FindSameProperty maps of the lower levels inside the subtree are in watt)
+      fsp_pool_item(tid, w, a, B, P, n, t, part, arena, pp, sa0, scr, lv > 0);
+      continue;
+    }
     const int i0 = P.in0[t];
-    // debug timeline (n2nmn_debug_walk_timeline): [0] job start, [1] operands ready (Transform) / pooled
-    // (FindSameProperty), [2] matrix phase / fc_att done, [3] map written
+    // debug timeline (n2nmn_debug_walk_timeline): [0] job start, [1] operands ready, [2] matrix phase done,
+    // [3] map written
     long long* tl = a.timeline ? a.timeline + ((size_t)q * MAXT + t) * 4 : nullptr;
     if (tl && threadIdx.x == 0) tl[0] = clock64();
     {                                                   // text map of the node (walk_tmap_kernel's row)
@@ -1649,21 +1779,67 @@ __global__ __launch_bounds__(WT) void walk_heavy_kernel(ModuleWeights w, WalkArg
       for (int c = 4 * tid; c < Mp; c += 4 * WT)
         *reinterpret_cast<float4*>(tml + c) = *reinterpret_cast<const float4*>(src + c);
     }
-    const float* watt_q = B.watt + (size_t)n * T * HWp;
-    // (level >= 1: the Transform / FindSameProperty maps of the lower levels inside the subtree are in watt)
-    eval_light_range(tid, P, P.lo[i0], i0, watt_q, arena, HW, HWp, lv > 0);
+    eval_light_range(tid, P, P.lo[i0], i0, B.watt + (size_t)n * T * HWp, arena, HW, HWp, lv > 0);
     const float* in0 = arena + (size_t)i0 * HWp;
     float* outp = arena + (size_t)t * HWp;
-    if (o == N2NMN_OP_TRANSFORM) {                      // :185-216
-      if (a.ksize == 5) walk_transform<5>(tid, w, a, in0, tml, outp, scr, tl);
-      else walk_transform<3>(tid, w, a, in0, tml, outp, scr, tl);
-    } else {
-      heavy_fsp<CI>(tid, w, a, B.feat + (size_t)n * HW * D, B.mfsp + (size_t)n * HW * Mp, in0, tml,
-                    outp, am0, pooled, sa0, rs, scr, tl);
-    }
+    walk_transform_t<KS, PTW>(tid, w, a, in0, tml, outp, scr, tl);             // :185-216
     float* dst = B.watt + ((size_t)n * T + t) * HWp;
     for (int r = tid; r < HW; r += WT) dst[r] = outp[r];
     if (tl && threadIdx.x == 0) tl[3] = clock64();
+  }
+}
+
+// Stage B of FindSameProperty: the Find-type epilogue over the operator's own conv_image map, with
+// tmap (.) (b_att + the eight fc_att shares of stage A) in the place of Find's text map.  Grid:
+// (persistent over the level's job list, WALK_FIND_PARTS row parts).
+// (a level has ~100 jobs x 8 workgroups per 1024 questions: 3 waves per SIMD; the eight shares in flight
+// at once want more than walk_find_kernel's 64 VGPRs)
+template <int CI, bool ONE>
+__global__ __launch_bounds__(FT, (CI == 1 ? 4 : 1)) void walk_fspepi_kernel(ModuleWeights w, WalkArgs a) {
+  const int lv = a.hlevel;
+  const int cfs = lv == 0 ? 2 : 7 + 2 * lv;
+  const int cap = (a.hoff[lv + 1] - a.hoff[lv]) / 2;
+  const int nfsp = min(a.cnt[cfs], cap);
+  const int32_t* jfs = a.hjobs + a.hoff[lv] + cap;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int T = a.T, HW = a.H * a.W, Mp = a.Mp, HWp = a.HWp;
+  const int rpp = (HW + WALK_FIND_PARTS - 1) / WALK_FIND_PARTS;
+  const int r0 = blockIdx.y * rpp, r1 = min(HW, r0 + rpp);
+  if (r0 >= r1) return;
+  for (int j = blockIdx.x; j < nfsp; j += gridDim.x) {
+    const int job = jfs[j];
+    const int q = job >> 8, t = job & 0xff;
+    if (q < 0 || q >= a.K * a.N || t >= T) continue;
+    const int kb = q / a.N, n = q - kb * a.N;
+    const WalkBatch& B = a.b[kb];
+    const float* Mbuf = B.mfsp + (size_t)n * HW * Mp;
+    const FindRows<CI> pre = find_load<CI>(Mbuf, r0 + (tid >> 6), r1, lane, Mp);
+    const WalkProg* P = B.prog + n;                    // uniform address: scalar loads
+    if (!P->valid || P->fallback || t >= P->nn || (P->op[t] & 0x7f) != N2NMN_OP_FIND_SAME_PROPERTY ||
+        P->hd[t] != lv + 1)
+      continue;
+    float4 t4[1][CI], e4[CI];
+    const float* tm = B.tmap + ((size_t)t * a.N + n) * Mp;
+    const float* fp = B.fpart + ((size_t)n * T + t) * POOLP * Mp;
+#pragma unroll
+    for (int i = 0; i < CI; ++i) {
+      const int c = 4 * lane + 256 * i;
+      if (c < Mp) {
+        float4 am = *reinterpret_cast<const float4*>(w.batt[0] + c);
+        float4 sh[POOLP];
+#pragma unroll
+        for (int p = 0; p < POOLP; ++p) sh[p] = *reinterpret_cast<const float4*>(fp + (size_t)p * Mp + c);
+#pragma unroll
+        for (int p = 0; p < POOLP; ++p) { am.x += sh[p].x; am.y += sh[p].y; am.z += sh[p].z; am.w += sh[p].w; }
+        const float4 tv = *reinterpret_cast<const float4*>(tm + c);
+        t4[0][i] = make_float4(tv.x * am.x, tv.y * am.y, tv.z * am.z, tv.w * am.w);
+        e4[i] = *reinterpret_cast<const float4*>(w.we[1] + c);
+      } else {
+        t4[0][i] = make_float4(0.f, 0.f, 0.f, 0.f); e4[i] = t4[0][i];
+      }
+    }
+    float* os[1] = {B.watt + ((size_t)n * T + t) * HWp};
+    find_rows_core<CI, 1, ONE>(tid, w.be[1][0], e4, t4, Mbuf, os, r0, r1, Mp, pre);
   }
 }
 
@@ -1802,21 +1978,45 @@ __global__ __launch_bounds__(WT) void walk_light_kernel(ModuleWeights w, WalkArg
 
 }  // namespace
 
+// LDS of walk_heavy_kernel (floats): arena + text map + pooled part + soft-max weights + the larger of
+// Transform's padded map / fold buffer and the FindSameProperty item's staging (4 * WT = [rows][part
+// channels] = [waves][256])
+static size_t heavy_lds_floats(const WalkArgs& a) {
+  const int pad = a.ksize / 2;
+  const size_t tr = (size_t)((a.M + 15) / 16 * 16) + (((size_t)(a.H + 2 * pad) * (a.W + 2 * pad) + 4) & ~3) +
+                    (size_t)TR_CG * 192 * 2;
+  const size_t fs = (size_t)4 * WT;
+  return (size_t)a.T * a.HWp + a.Mp + a.D / POOLP + a.HWp + (tr > fs ? tr : fs) + 64;
+}
+
 void launch_walk_heavy(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) {
-  const size_t smem = sizeof(float) * walk_lds_floats(a.T, a.HWp, a.Mp, a.E, a.D, a.M, a.ksize,
-                                                      a.H, a.W, a.C, 0);
-  // a persistent grid over the job list: two workgroups per CU's worth of ids, each takes jobs
-  // id, id + grid, ... (the list length lives on the device)
+  const size_t smem = sizeof(float) * heavy_lds_floats(a);
+  // a persistent grid over the level's items: two workgroups per CU's worth of ids, each takes items
+  // id, id + grid, ... (the list lengths live on the device)
   const int grid = std::min(512, std::max(1, (a.hoff[a.hlevel + 1] - a.hoff[a.hlevel]) / 2));
   auto go = [&](auto kern, std::atomic<uint64_t>& done) {
     if (smem > 64 * 1024) ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)smem, done);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WT), smem, s, w, a);
   };
-  static std::atomic<uint64_t> d1{0}, d2{0}, d4{0};
+  static std::atomic<uint64_t> d35{0}, d36{0}, d55{0}, d56{0};
+  const bool p5 = (a.H * a.W + 15) / 16 <= 10;     // pixel tiles per wave (walk_transform)
+  if (a.ksize == 5) { if (p5) go(walk_heavy_kernel<5, 5>, d55); else go(walk_heavy_kernel<5, 6>, d56); }
+  else { if (p5) go(walk_heavy_kernel<3, 5>, d35); else go(walk_heavy_kernel<3, 6>, d36); }
+}
+
+void launch_walk_fspepi(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) {
+  const int cap = (a.hoff[a.hlevel + 1] - a.hoff[a.hlevel]) / 2;
+  const dim3 grid(std::min(256, std::max(1, cap)), WALK_FIND_PARTS);
   const int ci = (a.Mp + 255) / 256;
-  if (ci == 1) go(walk_heavy_kernel<1>, d1);
-  else if (ci == 2) go(walk_heavy_kernel<2>, d2);
-  else go(walk_heavy_kernel<4>, d4);
+  const int rpp = (a.H * a.W + WALK_FIND_PARTS - 1) / WALK_FIND_PARTS;      // rows of a workgroup
+  if (ci == 1) {
+    if (rpp <= FindUnroll<1>::value * FW) hipLaunchKernelGGL((walk_fspepi_kernel<1, true>), grid, dim3(FT), 0, s, w, a);
+    else hipLaunchKernelGGL((walk_fspepi_kernel<1, false>), grid, dim3(FT), 0, s, w, a);
+  } else if (ci == 2) {
+    hipLaunchKernelGGL((walk_fspepi_kernel<2, false>), grid, dim3(FT), 0, s, w, a);
+  } else {
+    hipLaunchKernelGGL((walk_fspepi_kernel<4, false>), grid, dim3(FT), 0, s, w, a);
+  }
 }
 
 void launch_walk_light(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) {
@@ -1883,6 +2083,17 @@ void launch_walk_tmap(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) 
 }
 
 void launch_walk_find(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) {
+  static const bool f16 = [] { const char* e = getenv("N2NMN_WALK_FIND16"); return !e || atoi(e) != 0; }();
+  if (f16 && a.Mp <= 256 && a.Mp % 64 == 0) {          // sixteen lanes per row (walk_find16_kernel)
+    const dim3 g16(a.K * a.N, (a.H * a.W + F16_ROWS - 1) / F16_ROWS);
+    switch (a.Mp / 64) {
+      case 1: hipLaunchKernelGGL(walk_find16_kernel<1>, g16, dim3(FT), 0, s, w, a); break;
+      case 2: hipLaunchKernelGGL(walk_find16_kernel<2>, g16, dim3(FT), 0, s, w, a); break;
+      case 3: hipLaunchKernelGGL(walk_find16_kernel<3>, g16, dim3(FT), 0, s, w, a); break;
+      default: hipLaunchKernelGGL(walk_find16_kernel<4>, g16, dim3(FT), 0, s, w, a); break;
+    }
+    return;
+  }
   const dim3 grid(a.K * a.N, WALK_FIND_PARTS);
   const int ci = (a.Mp + 255) / 256;
   const int rpp = (a.H * a.W + WALK_FIND_PARTS - 1) / WALK_FIND_PARTS;      // rows of a workgroup
@@ -1903,7 +2114,7 @@ void launch_walk(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) {
     if (smem > 64 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(kern, dim3(a.K * a.N), dim3(WT), smem, s, w, a);
+    hipLaunchKernelGGL(kern, dim3(a.staged ? std::min(a.K * a.N, 256) : a.K * a.N), dim3(WT), smem, s, w, a);
   };
   const int ci = (a.Mp + 255) / 256;
   if (ci == 1) go(walk_kernel<1>);

@@ -46,8 +46,17 @@ class DataParallel:
         self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
         return float(t.item())
 
+    def min_over_ranks(self, value: float) -> float:
+        return -self.max_over_ranks(-value)
+
+    def group_size(self) -> int:
+        """ranks the process group actually holds (1 without a group): what a multi-GPU line reports as
+        n_gpus, instead of the number it was asked for"""
+        return int(self._dist.get_world_size()) if self._dist is not None else 1
+
     def timed(self, run: Callable[[], None], sync: Callable[[], None]) -> float:
-        """barrier + sync, run, sync + barrier; returns the max elapsed seconds over ranks."""
+        """barrier + sync, run, sync + barrier; returns the max elapsed seconds over ranks (the fastest
+        rank's time of the same region is kept in `last_min_elapsed`)."""
         sync()
         self.barrier()
         t0 = time.perf_counter()
@@ -55,6 +64,7 @@ class DataParallel:
         sync()
         elapsed = time.perf_counter() - t0
         self.barrier()
+        self.last_min_elapsed = self.min_over_ranks(elapsed)
         return self.max_over_ranks(elapsed)
 
     def throughput(self, units_per_rank: int, elapsed: float) -> float:

@@ -47,6 +47,10 @@ class Engine:
         self._parent = _parent
         if _parent is not None:
             _lib.check(self._lib.n2nmn_ctx_fork(_parent._ctx, C.byref(self._ctx)))
+            # a fork takes the phase-2 path of its parent (set_tokens_via_levels is per context)
+            self.tokens_via_levels = _parent.tokens_via_levels
+            if self.tokens_via_levels:
+                _lib.check(self._lib.n2nmn_set_tokens_via_levels(self._ctx, 1))
             return
         _lib.check(self._lib.n2nmn_ctx_create(C.byref(cd), device, C.byref(self._ctx)))
         P = np.ascontiguousarray(assembler.P, np.int32)
@@ -71,10 +75,6 @@ class Engine:
         (n2nmn_ctx_set_mode) -- use 'throughput' when several batches are in flight on forks.
         'throughput_bf16x3' (opt-in): 'throughput' with the recurrent contraction on bf16 MFMAs over
         three-way split operands (fp32-class accuracy, not the fp32 kernels' bits)."""
-        # N2NMN_THROUGHPUT_BF16X3=1 (test harness): every request for 'throughput' selects the opt-in
-        # split-operand bf16 mode instead, so the whole GPU suite can be run with that mode on
-        if mode == 'throughput' and os.environ.get('N2NMN_THROUGHPUT_BF16X3') == '1':
-            mode = 'throughput_bf16x3'
         self.mode = mode
         _lib.check(self._lib.n2nmn_ctx_set_mode(self._ctx, {'latency': 0, 'throughput': 1, 'throughput_ksplit': 2, 'throughput_bf16x3': 3}[mode]))
 
@@ -172,7 +172,8 @@ class Engine:
     def seq2seq(self, input_seq, seq_len, T_dec: Optional[int] = None, use_gt_layout: bool = False,
                 gt_layout=None, sample_uniforms=None, forced_tokens=None, debug: bool = False,
                 reuse_buffers: bool = True, phase: str = 'both', word_vecs: bool = True,
-                image_feat=None, dropout=None, out_tokens=None, seq_len_host=None):
+                image_feat=None, dropout=None, out_tokens=None, seq_len_host=None,
+                eos_retire: bool = False, gt_len_host=None):
         """Phase 1.  input_seq [T,N] int32, seq_len [N] int32 (device tensors or anything
         convertible).  Returns a dict of device tensors named like the reference attributes
         (models_clevr/nmn3_netgen_att.py:305-322).  With reuse_buffers the outputs are views of
@@ -182,7 +183,12 @@ class Engine:
         walk() / execute_tokens(conv_done=True) can follow directly.  dropout (optional, models_vqa):
         (enc0, dec0) multiplier tensors [T, N, L] / [T_dec, N, L] for the output of LSTM layer 0
         (n2nmn_seq2seq_io.drop_enc0 / drop_dec0), either may be None.  seq_len_host (optional): a
-        host int32 copy of seq_len (n2nmn_seq2seq_io.seq_length_host: per-step tile choice)."""
+        host int32 copy of seq_len (n2nmn_seq2seq_io.seq_length_host: per-step tile choice).
+        eos_retire (inference, teacher-forced passes of >= 128 rows in a throughput mode, word_vecs=False):
+        N2NMN_S2S_EOS_RETIRE -- rows leave the decoder at their layout's first <eos>; predicted_tokens are
+        complete, atts / token_probs hold the live (row, step) pairs only (call again with phase='decoder'
+        and eos_retire=False for every step).  gt_len_host: host int32 [N] layout lengths (tokens in front
+        of the first <eos>, `layout_lengths`), optional."""
         torch = _torch()
         d = self.dims
         seq = self._dev(input_seq, torch.int32)
@@ -240,8 +246,18 @@ class Engine:
         elif isinstance(seq_len, np.ndarray):
             lens_host = np.ascontiguousarray(seq_len, np.int32)
             io.seq_length_host = lens_host.ctypes.data
+        glen_host = None
+        if eos_retire:
+            if word_vecs:
+                raise ValueError('eos_retire needs word_vecs=False (the walker derives text maps from atts)')
+            io.flags |= 2        # N2NMN_S2S_EOS_RETIRE
+            if gt_len_host is not None:
+                glen_host = np.ascontiguousarray(np.asarray(gt_len_host), np.int32)
+                if glen_host.shape != (N,):
+                    raise ValueError('gt_len_host must hold N layout lengths')
+                io.gt_length_host = glen_host.ctypes.data
         if not word_vecs:        # N2NMN_S2S_NO_WORD_VECS: word_vecs / neg_entropy / log_seq_prob not computed
-            io.flags = 1
+            io.flags |= 1
             for k in ('word_vecs', 'neg_entropy', 'log_seq_prob'):
                 out.pop(k)
         fn = {'both': self._lib.n2nmn_seq2seq_forward, 'encoder': self._lib.n2nmn_encoder_forward,
@@ -284,6 +300,13 @@ class Engine:
         run as chip-wide jobs and a light per-question kernel finishes the tree; 0: the one-workgroup
         walker serves every question (n2nmn_walk_set_staged)."""
         _lib.check(self._lib.n2nmn_walk_set_staged(self._ctx, int(mode)))
+
+    def set_walk_levels(self, levels: int):
+        """0 (default): the staged walker launches as many nesting levels of Transform / FindSameProperty
+        as the last two passes needed (deeper layouts: the one-workgroup walker, logits within 1e-5);
+        >= 1: exactly that many in every pass -- a question's route then depends on its own layout only
+        and repeated passes return the same bits (n2nmn_walk_set_levels)."""
+        _lib.check(self._lib.n2nmn_walk_set_levels(self._ctx, int(levels)))
 
     def walk_supported(self) -> bool:
         return bool(self._lib.n2nmn_walk_supported(self._ctx))
@@ -428,9 +451,16 @@ class Engine:
         return Cm
 
     # ------------------------------------------------------------------------------------
+    def layout_lengths(self, gt_layout) -> np.ndarray:
+        """host int32 [N]: tokens of each column of a HOST layout array [T_dec, N] in front of its first
+        <eos> (T_dec when it has none) -- n2nmn_seq2seq_io.gt_length_host"""
+        g = np.asarray(gt_layout)
+        eos = g == self.assembler.EOS_idx
+        return np.where(eos.any(0), eos.argmax(0), g.shape[0]).astype(np.int32)
+
     def forward(self, batch, T_dec: Optional[int] = None, use_gt_layout: bool = False,
                 gt_layout=None, sample_uniforms=None, host_assemble: bool = False,
-                fetch: bool = True, out=None):
+                fetch: bool = True, out=None, eos_retire: bool = False):
         """The whole hot path of exp_clevr/eval_clevr.py:103-135 for one batch:
         phase 1 -> token fetch (the one host sync) -> C++ assemble/pack -> phase 2.
         Returns (scores device tensor, tokens numpy [T_dec,N], validity numpy [N]).
@@ -445,7 +475,12 @@ class Engine:
         With use_gt_layout and a HOST gt_layout (numpy, as the reference's data reader delivers
         it, util/clevr_train/data_reader.py:74-82) the predicted tokens are the ground-truth layout
         by construction (models_clevr/nmn3_netgen_att.py:236-238), so the program is assembled
-        from the host copy up front and the step has no host synchronisation at all."""
+        from the host copy up front and the step has no host synchronisation at all.
+
+        eos_retire (device path, use_gt_layout): inference option N2NMN_S2S_EOS_RETIRE -- the decoder
+        runs a row only up to its layout's first <eos>; scores / tokens / validity are bit-identical to
+        the full decoder's (the fetches of exp_clevr/eval_clevr.py:103-135), the decoder's own outputs for
+        the steps behind it are computed on demand (`decoder_outputs`)."""
         if self.walk_supported() and not host_assemble:
             # device path: the walker decodes the layouts itself (no sync between the phases).  The
             # hoisted conv_image GEMMs ride in phase 1's own GEMM launch (with encoder_h_transform
@@ -466,11 +501,19 @@ class Engine:
                     self.conv_image(feat, gt_dev if known else None, T_dec, find=True, fsp=known)
                     self._side_ev.record(self._side)
             table = self.dims.num_vocab_txt <= 4096
+            retire = bool(eos_retire) and known and table and sample_uniforms is None
+            glen = batch.get('gt_length_host') if retire else None
+            if retire and glen is None and isinstance(gt_layout, np.ndarray):
+                glen = self.layout_lengths(gt_layout)
             s2s = self.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], T_dec,
                                use_gt_layout, gt_dev, sample_uniforms, word_vecs=not table,
                                image_feat=None if self.overlap_conv else feat,
                                out_tokens=None if out is None else out[1],
-                               seq_len_host=batch.get('seq_length_host'))
+                               seq_len_host=batch.get('seq_length_host'),
+                               eos_retire=retire, gt_len_host=glen)
+            # (device tensors of this call: the context keeps pointers to them until the next encoder call)
+            self._last_s2s_args = (s2s['_input_seq'], s2s['_seq_length'], T_dec, use_gt_layout, gt_dev,
+                                   sample_uniforms)
             if self.overlap_conv and not known:
                 self.conv_image(feat, s2s['predicted_tokens'], find=False, fsp=True)
             if self.overlap_conv:
@@ -497,6 +540,19 @@ class Engine:
         packed, validity = self.assembler.assemble_packed(tokens)
         scores = self.execute(packed, batch['image_feat_batch'], s2s['word_vecs'])
         return scores, tokens, validity
+
+
+    def decoder_outputs(self):
+        """The decoder's outputs of the LAST forward() at EVERY step -- predicted_tokens, token_probs,
+        atts, neg_entropy, word_vecs, log_seq_prob -- recomputed from the encoder results the context
+        still holds (n2nmn_decoder_forward without N2NMN_S2S_EOS_RETIRE): the on-demand half of the
+        eos_retire contract (training and the debug fetches need all T_dec steps).  Call it before the
+        next forward() of this engine."""
+        args = getattr(self, '_last_s2s_args', None)
+        if args is None:
+            raise RuntimeError('decoder_outputs: no forward() on this engine yet')
+        seq, lens, T_dec, use_gt, gt_dev, uni = args
+        return self.seq2seq(seq, lens, T_dec, use_gt, gt_dev, uni, phase='decoder', reuse_buffers=False)
 
 
 def _to_host(x):

@@ -54,6 +54,10 @@ class SuperBucket:
         # host batches, util/clevr_train/data_reader.py:74-82): n2nmn_seq2seq_io.seq_length_host
         self.seq_length_host = np.ones((N,), np.int32)
         self._len_known = [False] * self.K
+        # host copy of the layout lengths of the slots whose ground-truth layout came as a host array
+        # (n2nmn_seq2seq_io.gt_length_host, eos_retire)
+        self.gt_length_host = np.full((N,), d.T_decoder, np.int32)
+        self._glen_known = [False] * self.K
         # results live in tensors of the bucket's own: two buckets may share one engine (a worker
         # alternates between them), and the engine's reuse buffers belong to whoever ran last
         self._res = {}
@@ -74,6 +78,7 @@ class SuperBucket:
         """Views a client writes its batch into (keys of util/clevr_train/data_reader.py:74-82)."""
         c = self._cols(k)
         self._len_known[k] = False        # written behind our back: no host copy of the lengths
+        self._glen_known[k] = False
         return dict(input_seq_batch=self.input_seq[:, c], seq_length_batch=self.seq_length[c],
                     image_feat_batch=self.image_feat[c], gt_layout_batch=self.gt_layout[:, c])
 
@@ -90,6 +95,18 @@ class SuperBucket:
             self.seq_length_host[self._cols(k)] = lens
         if gt_layout is not None:
             v['gt_layout_batch'].copy_(torch.as_tensor(gt_layout), non_blocking=True)
+            self._glen_known[k] = isinstance(gt_layout, np.ndarray)
+            if self._glen_known[k]:
+                self.gt_length_host[self._cols(k)] = self.engine.layout_lengths(gt_layout)
+
+    def set_layout(self, k: int, gt_layout):
+        """replace only the ground-truth layout of slot k (host array or tensor)"""
+        torch = _torch()
+        c = self._cols(k)
+        self.gt_layout[:, c].copy_(torch.as_tensor(gt_layout), non_blocking=True)
+        self._glen_known[k] = isinstance(gt_layout, np.ndarray)
+        if self._glen_known[k]:
+            self.gt_length_host[c] = self.engine.layout_lengths(gt_layout)
 
     def _results(self, n: int, Td: int):
         torch = _torch()
@@ -104,10 +121,11 @@ class SuperBucket:
         return r
 
     def run(self, use_gt_layout: bool = False, sample_uniforms=None, T_dec: Optional[int] = None,
-            n_slots: Optional[int] = None, host_assemble: bool = False):
+            n_slots: Optional[int] = None, host_assemble: bool = False, eos_retire: bool = False):
         """One pass over the first n_slots slots (default: all K).  Returns (scores [n*Nb, C], tokens
         [T_dec, n*Nb], validity [n*Nb]) device tensors owned by this bucket (one set per pass width,
-        overwritten by the next pass of that width); nothing synchronises."""
+        overwritten by the next pass of that width); nothing synchronises.  eos_retire: Engine.forward's
+        inference option (teacher-forced passes: rows leave the decoder at their layout's first <eos>)."""
         n = self.K if n_slots is None else int(n_slots)
         if not 1 <= n <= self.K:
             raise ValueError('n_slots %d out of range [1, %d]' % (n, self.K))
@@ -121,6 +139,8 @@ class SuperBucket:
         gt = None
         if use_gt_layout:
             gt = self.gt_layout if full else self.gt_layout[:, :rows].contiguous()
+            if eos_retire and all(self._glen_known[:n]) and (T_dec is None or Td == self.dims.T_decoder):
+                batch['gt_length_host'] = self.gt_length_host[:rows]
         if host_assemble or not self.engine.walk_supported():
             self.scores, self.tokens, self.validity = self.engine.forward(
                 batch, T_dec=T_dec, use_gt_layout=use_gt_layout, gt_layout=gt,
@@ -128,7 +148,8 @@ class SuperBucket:
         else:
             self.scores, self.tokens, self.validity = self.engine.forward(
                 batch, T_dec=T_dec, use_gt_layout=use_gt_layout, gt_layout=gt,
-                sample_uniforms=sample_uniforms, fetch=False, out=self._results(n, Td))
+                sample_uniforms=sample_uniforms, fetch=False, out=self._results(n, Td),
+                eos_retire=eos_retire and use_gt_layout)
         self.n_run = n
         return self.scores, self.tokens, self.validity
 

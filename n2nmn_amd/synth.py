@@ -106,3 +106,63 @@ def random_valid_layouts(d: Dims, P: np.ndarray, W: np.ndarray, b: np.ndarray,
             toks[t, i] = tok
             X = X + P[tok]
     return toks
+
+
+# ---- CLEVR-like layouts of realistic length -----------------------------------------------------------
+# The ten templates above average 3.2 tokens; real CLEVR programs are longer (up to 19 layout tokens at
+# T_dec = 20).  The dataset is not here, so the second layout mix of the eos_retire measurement is BUILT
+# from the reference's own linearisation rules (exp_clevr/data/get_ground_truth_layout.py:4-37 maps
+# functions to modules, :49-65 prunes count / query_* under comparisons, :90-96 turns scene + filter into
+# _Find and every further filter_* into _Filter, `unique` vanishes) applied to the CLEVR question families
+# (zero- to three-hop chains, single-and / single-or, integer and attribute comparisons, same-relate), an
+# object description being 1 to 4 filters as in the CLEVR generator.  Post-order (Reverse Polish) token
+# order, every layout checked against the validity automaton by the tests.
+def _obj(rng, lo=1, hi=4):
+    """one object description: scene + k filters -> _Find, _Filter x (k - 1)"""
+    return ['_Find'] + ['_Filter'] * (int(rng.integers(lo, hi + 1)) - 1)
+
+
+def _refine(rng, lo=1, hi=3):
+    """filters applied to a relate / same_* / intersect result"""
+    return ['_Filter'] * int(rng.integers(lo, hi + 1))
+
+
+def _chain(rng, hops):
+    out = _obj(rng)
+    for _ in range(hops):
+        out += ['_Transform'] + _refine(rng)
+    return out
+
+
+def clevr_like_layout(rng, T: int) -> List[str]:
+    """one layout (module names, no <eos>) of at most T - 1 tokens"""
+    while True:
+        fam = int(rng.integers(0, 9))
+        ans1 = ['_Count', '_Exist', '_Describe'][int(rng.integers(0, 3))]
+        if fam <= 2:                         # zero- / one- / two- / three-hop
+            lay = _chain(rng, int(rng.integers(0, 4))) + [ans1]
+        elif fam == 3:                       # single-and: two one-hop chains intersected
+            lay = _chain(rng, 1) + _chain(rng, 1) + ['_And'] + _refine(rng, 0, 2) + [ans1]
+        elif fam == 4:                       # single-or
+            lay = _obj(rng) + _obj(rng) + ['_Or'] + [['_Count', '_Exist'][int(rng.integers(0, 2))]]
+        elif fam == 5:                       # compare integer (count pruned under the comparison)
+            lay = _chain(rng, int(rng.integers(0, 2))) + _chain(rng, int(rng.integers(0, 2))) + \
+                [['_EqualNum', '_MoreNum', '_LessNum'][int(rng.integers(0, 3))]]
+        elif fam == 6:                       # compare attribute (query_* pruned)
+            lay = _chain(rng, int(rng.integers(0, 2))) + _chain(rng, int(rng.integers(0, 2))) + ['_SameProperty']
+        elif fam == 7:                       # same-relate
+            lay = _chain(rng, int(rng.integers(0, 2))) + ['_FindSameProperty'] + _refine(rng, 0, 3) + [ans1]
+        else:                                # whole-scene questions
+            lay = ['_Scene', ['_Count', '_Exist'][int(rng.integers(0, 2))]]
+        if len(lay) <= T - 1:
+            return lay
+
+
+def clevr_like_layout_batch(d: Dims, n: int | None = None, seed: int = 0) -> np.ndarray:
+    """gt_layout_batch [T_decoder, N] int32 of CLEVR-like layouts (see above); mean length ~8.5"""
+    n = d.N if n is None else n
+    rng = np.random.default_rng(seed + 104729)
+    out = np.zeros((d.T_decoder, n), np.int32)
+    for i in range(n):
+        out[:, i] = module_list2tokens(clevr_like_layout(rng, d.T_decoder), d.T_decoder)
+    return out

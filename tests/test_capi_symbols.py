@@ -38,8 +38,8 @@ def test_struct_sizes_match_header():
     assert ctypes.sizeof(_lib.Dims) == 17 * 4
     assert ctypes.sizeof(_lib.Node) == 8 * 4
     # 2 ptr + 4 int32 + 13 ptr
-    # ... + flags (4 + 4 pad) + image_feat + 2 dropout pointers + seq_length_host
-    assert ctypes.sizeof(_lib.Seq2SeqIO) == 2 * 8 + 4 * 4 + 13 * 8 + 8 + 8 + 2 * 8 + 8
+    # ... + flags (4 + 4 pad) + image_feat + 2 dropout pointers + seq_length_host + gt_length_host
+    assert ctypes.sizeof(_lib.Seq2SeqIO) == 2 * 8 + 4 * 4 + 13 * 8 + 8 + 8 + 2 * 8 + 8 + 8
     # ctx + 5 buffers + atts / input_seq / seq_length
     assert ctypes.sizeof(_lib.WalkBatch) == 9 * 8
     # 2 ptr + 3 int32 (+4 pad) + 3 ptr + float (+4 pad) + 3 ptr

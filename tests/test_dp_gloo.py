@@ -26,7 +26,8 @@ WORKER = textwrap.dedent('''
             time.sleep(0.01 * (1 + dp.rank))      # rank 1 is slower: max-over-ranks must see it
     elapsed = dp.timed(run, sync=lambda: None)
     out = dict(rank=dp.rank, world=dp.world, seeds=seeds, sums=sums, elapsed=elapsed,
-               qps=dp.throughput(steps * d.N, elapsed))
+               qps=dp.throughput(steps * d.N, elapsed), group=dp.group_size(),
+               fastest=dp.last_min_elapsed)
     print('RESULT ' + json.dumps(out), flush=True)
     dp.close()
 ''') % ROOT
@@ -56,6 +57,10 @@ def test_two_ranks_gloo(tmp_path):
     assert r0['elapsed'] >= 0.1
     # whole-job throughput counts the questions of all ranks
     assert abs(r0['qps'] - 2 * 5 * 4 / r0['elapsed']) < 1e-6
+    # what bench.py's forward line reports for N > 1: the ranks the GROUP holds (n_gpus, not --gpus) and
+    # the fastest rank's time next to the slowest (per_rank_value_min_max)
+    assert r0['group'] == 2 and r1['group'] == 2
+    assert abs(r0['fastest'] - r1['fastest']) < 1e-9 and 0.05 <= r0['fastest'] < r0['elapsed']
 
 
 TRAIN_WORKER = textwrap.dedent('''

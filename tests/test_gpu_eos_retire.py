@@ -1,0 +1,158 @@
+"""Inference option N2NMN_S2S_EOS_RETIRE (include/n2nmn.h): a teacher-forced pass runs a
+row's decoder only up to its layout's first <eos>.
+
+The reference's decoder runs all T_dec = 20 steps for every row (models_clevr/nmn3_netgen_att.py:270), but
+`exp_clevr/eval_clevr.py:103-135` fetches only predicted_tokens and scores; a layout is read up to its first
+<eos> (models_clevr/nmn3_assembler.py:153-170) and a module's text attention is the decoder step of its own
+token (models_clevr/nmn3_modules.py:53-57), so the steps from the <eos> on feed neither fetch.  The contract
+tested here:
+  * predicted_tokens, scores and validity of a retired pass equal the full decoder's pass in EVERY slot of a
+    1024-row pass (bit for bit where the same kernels run: layouts given as device tensors, no nesting; 2e-6
+    where the step tile is chosen from the host's copy of the lengths or the walker's level routing differs),
+    on the template mix (mean 3.2 tokens) and on CLEVR-like layouts of up to 19 tokens, in both throughput
+    modes;
+  * the decoder's own outputs at ALL T steps are available on demand (Engine.decoder_outputs: atts,
+    token_probs, neg_entropy, word_vecs, log_seq_prob) and equal the fp64 oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import n2nmn_oracle as O
+from n2nmn_amd import synth
+from n2nmn_amd.spec import Dims, CLEVR_MODULE_NAMES
+from util import assert_close, t2n
+
+pytestmark = pytest.mark.gpu
+NAMES = list(CLEVR_MODULE_NAMES)
+K = 16
+
+
+@pytest.fixture(scope='module')
+def bucket():
+    from n2nmn_amd.nmn3_assembler import Assembler
+    from n2nmn_amd.superbucket import SuperBucket
+    d = Dims()
+    sb = SuperBucket(d, Assembler(NAMES), K=K)
+    w = synth.make_weights(d, seed=0)
+    sb.load_weights(w)
+    batches = [synth.make_inputs(d, seed=700 + k, min_len=1) for k in range(K)]
+    return sb, d, w, batches
+
+
+def _layouts(d, mix, k):
+    if mix == 'templates':
+        return synth.template_layout_batch(d, offset=k)
+    return synth.clevr_like_layout_batch(d, seed=40 + k)
+
+
+def _pass(sb, retire, n=K):
+    sc, tok, val = sb.run(use_gt_layout=True, eos_retire=retire, n_slots=n)
+    torch.cuda.synchronize()
+    return t2n(sc).copy(), t2n(tok).copy(), t2n(val).copy()
+
+
+@pytest.mark.parametrize('mode', ['throughput', 'throughput_bf16x3'])
+@pytest.mark.parametrize('mix', ['templates', 'clevr_like'])
+@pytest.mark.parametrize('host_lengths', [True, False])
+def test_retired_pass_equals_the_full_decoder_pass_in_every_slot(bucket, mode, mix, host_lengths):
+    sb, d, w, batches = bucket
+    eng = sb.engine
+    gts = [_layouts(d, mix, k) for k in range(K)]
+    for k in range(K):
+        # (a layout handed over as a device tensor leaves no host copy of its length: the decoder then
+        # issues all T_dec + 1 step launches and every one finds its live rows on the device)
+        sb.fill(k, batches[k], gts[k] if host_lengths else torch.as_tensor(gts[k]).cuda())
+    eng.set_mode(mode)
+    try:
+        for _ in range(3 if mix == 'clevr_like' else 1):      # (the walker's level count settles)
+            full = _pass(sb, False)
+        got = _pass(sb, True)
+        again = _pass(sb, True)
+    finally:
+        eng.set_mode('latency')
+    gt_all = np.concatenate(gts, 1)
+    assert np.array_equal(got[1], gt_all) and np.array_equal(full[1], gt_all)
+    assert np.array_equal(got[2], full[2]) and got[2].all()
+    assert np.array_equal(got[0], again[0])
+    if mix == 'templates' and not host_lengths:
+        assert np.array_equal(got[0], full[0]), 'same kernels, same row arithmetic: the logits must be the same bits'
+    worst = 0.0
+    for k in range(K):
+        c = slice(k * d.N, (k + 1) * d.N)
+        worst = max(worst, assert_close('slot %d retired vs full' % k, got[0][c], full[0][c], 2e-6))
+    lens = (gt_all != sb.engine.assembler.EOS_idx).sum(0)
+    print('%s / %s: mean layout length %.2f (max %d); worst |retired - full| = %.2e' %
+          (mode, mix, lens.mean(), lens.max(), worst))
+    # one slot against the oracle (the full pass is pinned slot by slot in test_gpu_bench_config.py)
+    k = 5
+    ref = O.forward(w, NAMES, batches[k], d.T_decoder, d.num_choices, np.float64, use_gt_layout=True,
+                    gt_layout=gts[k])
+    assert_close('retired slot vs oracle', got[0][k * d.N:(k + 1) * d.N], ref['scores'], 1e-4)
+
+
+def test_partial_pass_and_degenerate_layouts(bucket):
+    """a 3-slot pass (192 rows: the K-split tail tiles from step 0 on) with layouts that start with <eos>
+    (no live step at all: invalid, zero logits), layouts without any <eos> (every step stays) and garbage
+    behind the first <eos> (ignored, as the reference's assembler ignores it)"""
+    sb, d, w, batches = bucket
+    asm = sb.engine.assembler
+    gts = [synth.template_layout_batch(d, offset=k).copy() for k in range(3)]
+    gts[0][:, 3] = asm.EOS_idx                                  # starts with <eos>
+    gts[1][:, 5] = asm.name2idx_dict['_Find']                   # never ends
+    gts[2][6:, 7] = asm.name2idx_dict['_Transform']             # tokens behind the first <eos>
+    for k in range(3):
+        sb.fill(k, batches[k], gts[k])
+    sb.engine.set_mode('throughput')
+    try:
+        full = _pass(sb, False, 3)
+        got = _pass(sb, True, 3)
+    finally:
+        sb.engine.set_mode('latency')
+    assert np.array_equal(got[1], full[1]) and np.array_equal(got[2], full[2])
+    assert not got[2][3] and not got[2][d.N + 5] and got[2][2 * d.N + 7]
+    assert_close('retired vs full', got[0], full[0], 2e-6)
+    assert np.all(got[0][3] == 0) and np.all(got[0][d.N + 5] == 0)
+
+
+@pytest.mark.parametrize('mode', ['throughput', 'throughput_bf16x3'])
+def test_decoder_outputs_on_demand_equal_the_oracle_at_every_step(bucket, mode):
+    """training and the debug fetches need every decoder step: after a retired pass the decoder's outputs
+    at ALL T_dec steps come from Engine.decoder_outputs (n2nmn_decoder_forward without the flag, on the
+    encoder results the context still holds)"""
+    sb, d, w, batches = bucket
+    n = 2
+    gts = [synth.clevr_like_layout_batch(d, seed=90 + k) for k in range(n)]
+    for k in range(n):
+        sb.fill(k, batches[k], gts[k])
+    sb.engine.set_mode(mode)
+    try:
+        got = _pass(sb, True, n)
+        s2s = sb.engine.decoder_outputs()
+        torch.cuda.synchronize()
+    finally:
+        sb.engine.set_mode('latency')
+    for k in range(n):
+        c = slice(k * d.N, (k + 1) * d.N)
+        ref = O.forward(w, NAMES, batches[k], d.T_decoder, d.num_choices, np.float64, use_gt_layout=True,
+                        gt_layout=gts[k])
+        dec = ref['dec']
+        assert np.array_equal(t2n(s2s['predicted_tokens'])[:, c], gts[k])
+        assert_close('atts, every step', t2n(s2s['atts'])[:, :, c], dec['atts'][..., 0], 1e-4)
+        assert_close('token_probs', t2n(s2s['token_probs'])[:, c], dec['token_probs'], 1e-4)
+        assert_close('neg_entropy', t2n(s2s['neg_entropy'])[c], dec['neg_entropy'], 1e-4)
+        assert_close('word_vecs', t2n(s2s['word_vecs'])[:, c], dec['word_vecs'], 1e-4)
+        assert_close('scores of the retired pass', got[0][c], ref['scores'], 1e-4)
+
+
+def test_flag_is_ignored_where_its_preconditions_fail(clevr_engine):
+    """a single batch of 64 in latency mode: the flag changes nothing (include/n2nmn.h)"""
+    eng, d, asm, w = clevr_engine
+    batch = synth.make_inputs(d, seed=3)
+    gt = synth.template_layout_batch(d, offset=2)
+    a, _, _ = eng.forward(batch, use_gt_layout=True, gt_layout=gt)
+    a = t2n(a).copy()
+    b, tok, val = eng.forward(batch, use_gt_layout=True, gt_layout=gt, eos_retire=True)
+    assert np.array_equal(t2n(b), a) and np.array_equal(tok, gt) and val.all()
+    out = eng.decoder_outputs()
+    ref = O.forward(w, NAMES, batch, d.T_decoder, d.num_choices, np.float64, use_gt_layout=True, gt_layout=gt)
+    assert_close('atts', t2n(out['atts']), ref['dec']['atts'][..., 0], 1e-4)

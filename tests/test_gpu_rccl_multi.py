@@ -72,6 +72,7 @@ WORKER = textwrap.dedent('''
         eg.load_weights(w)
         tg = Trainer(eg)
     err = err_torch = 0.0
+    err_step = {1: 0.0, 2: 0.0}
     for step in (1, 2):
         b, gt = shard(dp.rank, step)
         if step == 1:                      # (iv) the torch.distributed form of the same two buckets
@@ -94,8 +95,10 @@ WORKER = textwrap.dedent('''
             torch.cuda.synchronize(dev)
             ref = tg.grads.double().cpu().numpy()
             for name, (off, n, shape) in tr.layout.items():
-                err = max(err, float(np.abs(g[off:off + n] - ref[off:off + n]).max() /
-                                     (np.abs(ref[off:off + n]).max() + 1e-7)))
+                e1 = float(np.abs(g[off:off + n] - ref[off:off + n]).max() /
+                           (np.abs(ref[off:off + n]).max() + 1e-7))
+                err = max(err, e1)
+                err_step[step] = max(err_step[step], e1)
             tg.apply(1.0)
         tr.apply(scale)
     torch.cuda.synchronize(dev)
@@ -103,6 +106,7 @@ WORKER = textwrap.dedent('''
     for k, v in sorted(tr.get_weights().items()):
         h.update(v.cpu().numpy().tobytes())
     print('RESULT ' + json.dumps(dict(rank=dp.rank, world=dp.world, sha=h.hexdigest(), err=err,
+                                      err1=err_step[1], err2=err_step[2],
                                       err_torch=err_torch, comm_world=comm_world, verified=verified,
                                       default_is_rccl=default_is_rccl, device=lr)), flush=True)
     tr.buckets.close()
@@ -132,9 +136,13 @@ def test_c_abi_rccl_communicator_across_ranks(tmp_path):
     assert all(r['comm_world'] == n and r['verified'] == n for r in res), res       # (iii)
     assert all(r['default_is_rccl'] for r in res)       # the C-ABI communicator is what runs by default
     assert len({r['sha'] for r in res}) == 1, res                                   # (ii)
-    # (i): per variable, relative to its scale; the second step runs on weights that differ from the
-    # single-process trajectory by fp32 summation order amplified by Adam's lr-sized first step
-    assert res[0]['err'] < 5e-3, res
+    # (i): per variable, relative to its scale.  Step 1 runs on IDENTICAL weights: the only difference
+    # from the single-process gradient is fp32 summation order, so it holds the all-reduce path's own bound
+    # (a wrong 1/world fold or a dropped bucket tail of a few hundred elements cannot hide in it); the
+    # second step runs on weights that differ from the single-process trajectory by that summation order
+    # amplified by Adam's lr-sized first step and keeps the looser bound
+    assert res[0]['err1'] < 2e-5, res
+    assert res[0]['err2'] < 5e-3, res
     assert max(r['err_torch'] for r in res) < 1e-5, res                             # (iv)
 
 

@@ -268,10 +268,11 @@ def test_full_size_batch_matches_reference_code(clevr_engine):
     assert_close('greedy scores (free-running)', t2n(sc2)[same], z['greedy/scores'][same], TOL)
 
 
-def test_full_size_batch_in_a_throughput_pass_matches_reference_code():
+@pytest.mark.parametrize('tmode', ['throughput', 'throughput_bf16x3'])
+def test_full_size_batch_in_a_throughput_pass_matches_reference_code(tmode):
     """the same 64 questions as one slot of an 8-slot pass in 'throughput' mode (lstm_tile_kernel,
     per-question decoder attention, chip-wide walker front end, deferred pooling): the path bench.py
-    times, against the reference code's logits"""
+    times, against the reference code's logits -- and in the opt-in split-operand mode of its `bf16x3` key"""
     from n2nmn_amd.nmn3_assembler import Assembler
     from n2nmn_amd.superbucket import SuperBucket
     z = np.load(GOLDEN_FULL)
@@ -279,7 +280,8 @@ def test_full_size_batch_in_a_throughput_pass_matches_reference_code():
     gt = synth.template_layout_batch(d)
     sb = SuperBucket(d, Assembler(list(CLEVR_MODULE_NAMES)), K=8)
     sb.load_weights(FC.clevr_weights())
-    sb.engine.set_mode('throughput')
+    sb.engine.set_mode(tmode)
+    assert sb.engine.mode == tmode
     for k in range(8):
         other = synth.make_inputs(d, seed=300 + k, min_len=1)
         sb.fill(k, batch if k == 5 else other, gt if k == 5 else synth.template_layout_batch(d, offset=k))

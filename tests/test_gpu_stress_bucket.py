@@ -1,6 +1,7 @@
 """Randomised cross-check (formerly tools/stress_bucket.py): super-bucketed passes (random slot
-count and batch size, ragged question lengths incl. length 1, teacher-forced or greedy layouts, both
-recurrent-step modes -- 'throughput' runs lstm_tile_kernel from 128 rows up) against
+count and batch size, ragged question lengths incl. length 1, teacher-forced or greedy layouts, all three
+recurrent-step modes -- 'throughput' runs lstm_tile_kernel from 128 rows up, 'throughput_bf16x3' the
+split-operand kernels) against
 one-batch-at-a-time passes of a separate engine in the default mode.  Logits must agree to 2e-5,
 tokens / validity exactly (greedy: up to a question's first near-tie of two token logits, < 1e-5).  Reference loop: exp_clevr/eval_clevr.py:103-135."""
 import numpy as np
@@ -28,7 +29,8 @@ def test_random_bucket_equals_single_batches(trial):
     one.load_weights(w)
     sb = SuperBucket(d, asm, K)
     sb.load_weights(w)
-    sb.engine.set_mode('throughput' if trial % 2 == 0 else 'latency')
+    # (trials 0, 3, 6: 'throughput'; 1, 4, 7: 'latency'; 2, 5: the opt-in split-operand mode)
+    sb.engine.set_mode(('throughput', 'latency', 'throughput_bf16x3')[trial % 3])
     use_gt = bool(rng.integers(0, 2))
     batches, gts = [], []
     for k in range(K):

@@ -86,14 +86,18 @@ def test_latency_mode_batch_of_128(setup):
     assert_close('greedy layouts (GPU tokens), rows %s' % rows, got[rows], forced['scores'], TOL)
 
 
-def test_throughput_pass_of_8_client_batches(setup):
-    """`config5.passes`: 8 client batches of 128 as ONE pass of 1024 rows in 'throughput' mode."""
+@pytest.mark.parametrize('mode', ['throughput', 'throughput_bf16x3'])
+def test_throughput_pass_of_8_client_batches(setup, mode):
+    """`config5.passes`: 8 client batches of 128 as ONE pass of 1024 rows in 'throughput' mode -- and in
+    the opt-in split-operand mode (`bf16x3.config5_passes`: lstm_tile3_kernel at lstm_dim 1024,
+    gemm_dma3_kernel on the 2064 -> 1024 conv_image)."""
     eng, d, w = setup
     K = 8
     big = vqa.VQADims(N=K * CLIENT)
     eng_big = vqa.VQAEngine(big)
     eng_big.load_weights(w)
-    eng_big.engine.set_mode('throughput')
+    eng_big.engine.set_mode(mode)
+    assert eng_big.engine.mode == mode
     dev = eng_big.engine.device
     parts = [_part(d, eng, 200 + k) for k in range(K)]
     feat = torch.empty((K * CLIENT, d.H, d.W, d.D), dtype=torch.float32, device=dev)

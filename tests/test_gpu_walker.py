@@ -271,13 +271,19 @@ def test_walker_node_counters_equal_the_layouts_executed(clevr_engine):
     assert st[0] + st[8] == cnt('_FindSameProperty') + find_passes  # conv_image map passes
 
 
+# staged walker vs the one-workgroup walker: the same operators with other summation orders (the answer
+# heads reduce by waves, FindSameProperty pools / applies fc_att in 8 channel parts)
+STAGED_TOL = 1e-5
+
+
 @pytest.mark.parametrize('seed', [1, 2, 3, 4])
 def test_staged_walker_equals_the_one_workgroup_walker(clevr_engine, seed):
     """passes of many questions (n2nmn_walk_set_staged): the plan step of walk_tmap_kernel decodes every
     layout on the device, walk_heavy_kernel runs the Transform / FindSameProperty nodes over light input
     subtrees as chip-wide jobs, walk_light_kernel finishes the tree, and questions with NESTED
     Transform / FindSameProperty nodes stay with walk_kernel.  Same logits and validity as the
-    one-workgroup walker (same operator code: 2e-6) and the oracle, on the template mix (every staged
+    one-workgroup walker (same operators; FindSameProperty pools and applies fc_att in channel parts, so its
+    sums run in another order: 1e-5) and the oracle, on the template mix (every staged
     operator, no nesting), random layouts (shallow: mostly staged; deep: mostly the fall-back list), and
     a batch with invalid columns."""
     eng, d, asm, w = clevr_engine
@@ -310,14 +316,14 @@ def test_staged_walker_equals_the_one_workgroup_walker(clevr_engine, seed):
                 # (the second staged pass may list nested layouts level by level where the first sent them
                 # to the fall-back walker -- the host has seen the first pass's nesting depth by now: the
                 # answer heads then reduce in walk_light_kernel's order instead of walk_kernel's)
-                assert_close('second staged pass vs the first', t2n(sc), out[mode], 2e-6)
+                assert_close('second staged pass vs the first', t2n(sc), out[mode], STAGED_TOL)
             out[mode], val[mode] = t2n(sc).copy(), t2n(v).copy()
     finally:
         eng.set_front_end(-1)
         eng.set_defer_pool(-1)
         eng.set_staged(-1)
     assert np.array_equal(val[0], val[1]) and np.array_equal(val[1].astype(bool), ref['validity'])
-    assert_close('staged vs one-workgroup walker', out[1], out[0], 2e-6)
+    assert_close('staged vs one-workgroup walker', out[1], out[0], STAGED_TOL)
     assert_close('staged walker vs oracle', out[1], ref['scores'], TOL)
 
 
@@ -433,7 +439,51 @@ def test_staged_walker_lists_nested_layouts_level_by_level(clevr_engine):
         eng.set_front_end(-1)
         eng.set_defer_pool(-1)
         eng.set_staged(-1)
-    assert_close('nested layouts on the fall-back list vs the one-workgroup walker', first, ref, 2e-6)
-    assert_close('nested layouts level by level vs the one-workgroup walker', later, ref, 2e-6)
+    assert_close('nested layouts on the fall-back list vs the one-workgroup walker', first, ref, STAGED_TOL)
+    assert_close('nested layouts level by level vs the one-workgroup walker', later, ref, STAGED_TOL)
     full = O.forward(w, NAMES, batch, d.T_decoder, d.num_choices, np.float64, forced_tokens=toks)
     assert_close('level by level vs oracle', later, full['scores'], TOL)
+
+
+def test_fixed_level_count_makes_nested_layouts_reproducible_bit_for_bit(clevr_engine):
+    """n2nmn_walk_set_levels: with the adaptive default a nested layout goes through the
+    fall-back walker in a context's first nested pass and through the level launches later (other summation
+    order, 1e-5).  With a fixed level count the route depends on the layout alone: a pass right after
+    template passes and a pass after nested ones return the same bits."""
+    eng, d, asm, w = clevr_engine
+    batch = synth.make_inputs(d, seed=77)
+    toks = synth.random_valid_layouts(d, asm.P, asm.W, asm.b, seed=612, max_len=14)
+    for i, k in enumerate(range(1, 7)):
+        toks[:, 3 * i] = asm.module_list2tokens(['_Find'] + ['_FindSameProperty', '_Transform'] * k + ['_Count']
+                                                if k <= 3 else ['_Find'] + ['_Transform'] * k + ['_Describe'],
+                                                d.T_decoder)
+    tpl = synth.template_layout_batch(d)
+    s2n = eng.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], forced_tokens=toks,
+                      reuse_buffers=False, word_vecs=False)
+    s2t = eng.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], forced_tokens=tpl,
+                      reuse_buffers=False, word_vecs=False)
+
+    def run(s2s):
+        sc, v = eng.execute_tokens(s2s['predicted_tokens'], batch['image_feat_batch'], None, reuse_buffers=False,
+                                   atts=(s2s['atts'], s2s['_input_seq'], s2s['_seq_length']))
+        return t2n(sc).copy()
+    try:
+        eng.set_front_end(1)
+        eng.set_defer_pool(1)
+        eng.set_staged(1)
+        eng.set_walk_levels(d.T_decoder - 1)
+        for _ in range(3):
+            run(s2t)
+        a = run(s2n)                 # first nested pass of the "history"
+        run(s2n)
+        b = run(s2n)
+        eng.set_walk_levels(0)
+        eng.set_staged(0)
+        ref = run(s2n)
+    finally:
+        eng.set_walk_levels(0)
+        eng.set_front_end(-1)
+        eng.set_defer_pool(-1)
+        eng.set_staged(-1)
+    assert np.array_equal(a, b), 'fixed level count: the logits must not depend on what ran before'
+    assert_close('level by level vs the one-workgroup walker', a, ref, STAGED_TOL)
