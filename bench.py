@@ -88,11 +88,11 @@ if not os.path.exists(PMC_FILE):
     PMC_FILE = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
 PMC_FILE_TRAIN = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_train.json')
 PMC_KERNEL = {'lstm_step': 'lstm_tile_kernel', 'dec_attn': 'dec_attn_question_kernel',
-              'pool': 'walk_pool_kernel', 'walk_find': 'walk_find_kernel', 'walk_tmap': 'walk_tmap_kernel',
+              'pool': 'walk_pool_kernel', 'walk_find': 'walk_find', 'walk_tmap': 'walk_tmap_kernel',
               'gemm_pkn': 'gemm_dma_kernel', 'gemm_pk': 'gemm_pk', 'att_ops': 'att_ops_kernel',
               'textmap': 'walk_textmap_kernel', 'heads': 'heads_kernel', 'word_vecs': 'word_vecs_kernel',
               # the staged walker: Transform / FindSameProperty jobs + the per-question rest + the fall-back launch
-              'walk(': ('walk_heavy_kernel', 'walk_light_kernel', 'walk_kernel'),
+              'walk(': ('walk_fsppool_kernel', 'walk_heavy_kernel', 'walk_light_kernel', 'walk_kernel'),
               'lstm_bwd_step': 'lstm_bwd_step_kernel', 'gemm_tn': 'gemm_tn_kernel',
               'optimiser': 'adam_kernel'}
 
@@ -934,7 +934,7 @@ def main():
             us_walk = eng.walk_replay_us(0, 20)
             walk_bytes = wrow[0]['achieved'] * 1e9 * wrow[0]['avg_us'] * 1e-6 if wrow else 0.0
             frow = [r for r in rows if r['kernel'].startswith('walk_find')]
-            att.append({'kernel': 'walker = walk_heavy + walk_light + fall-back walk_kernel launches (%sfeatures and '
+            att.append({'kernel': 'walker = walk_fsppool + walk_heavy + walk_light + fall-back walk_kernel launches (%sfeatures and '
                                   'map under FindSameProperty%s; everything that depends on the tree)' %
                                   ('' if frow else 'conv_image maps under every Find-type node, ',
                                    '' if deferred else ' / Describe / SameProperty'),
@@ -949,8 +949,8 @@ def main():
                 us_find = eng.walk_replay_us(3, 50)
                 find_bytes = frow[0]['achieved'] * 1e9 * frow[0]['avg_us'] * 1e-6
                 att.insert(0, {
-                    'kernel': 'walk_find_kernel (Find / Filter epilogues: one read of the conv_image map '
-                              'per <= 4 nodes of a question)', 'bound': 'hbm', 'avg_us': round(us_find, 3),
+                    'kernel': 'walk_find16_kernel (Find / Filter epilogues: one read of the conv_image map '
+                              'per question)', 'bound': 'hbm', 'avg_us': round(us_find, 3),
                     'event_pair_us': frow[0]['avg_us'],
                     'algorithmic_bytes_per_launch': round(find_bytes),
                     'achieved': round(find_bytes / us_find / 1e3, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -996,7 +996,7 @@ def main():
                 'byte_weighted': {'bytes': round(path_bytes), 'us': round(path_us, 2),
                                   'achieved': round(path_bytes / path_us / 1e3, 1), 'unit': 'GB/s',
                                   'frac': round(path_bytes / path_us / 1e3 / HBM_PEAK_GBS, 4),
-                                  'kernels': 'walk_pool + walk_find + walker (walk_heavy + walk_light + fall-back walk_kernel)'},
+                                  'kernels': 'walk_pool + walk_find + walker (walk_fsppool + walk_heavy + walk_light + fall-back walk_kernel)'},
                 'measured': 'each kernel of the last pass replayed back to back inside one HIP event '
                             'pair, average per launch (inputs of one pass stay L2/MALL-warm across the '
                             'replays: see profiles/ for the cold rocprofv3 numbers)',

@@ -1698,6 +1698,16 @@ int n2nmn_conv_image(n2nmn_ctx* c, const float* image_feat, int N, int which,
   return check_launch("conv_image");
 }
 
+// The staged walker's launches between walk_find and the fall-back walker: per nesting level stage A of the
+// FindSameProperty nodes (pooling + fc_att shares), then the Transform nodes together with stage B (the map
+// epilogues); the light rest of every question at the end.  (One launch with device-side dependencies
+// between work items was built and measured slower: tools/rejected/walk_stage_single_launch.hip.txt.)
+static void walk_staged_launches(const ModuleWeights& w, WalkArgs& a, hipStream_t s) {
+  for (int lv = 0; lv < a.hlevels; ++lv) { a.hlevel = lv; launch_walk_fsppool(w, a, s); launch_walk_heavy(w, a, s); }
+  a.hlevel = 0;
+  launch_walk_light(w, a, s);
+}
+
 int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int T_dec, int T_enc,
                        int N, n2nmn_stream stream) {
   N2_REQUIRE(c && batches, N2NMN_EINVAL, "walk_layouts: null argument");
@@ -1807,12 +1817,7 @@ int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int
   }
   {
     ProfScope ps(c, F_WALK, 0.0, 0.0, s);     // work filled in from the device counters
-    if (a.staged) {
-      // per nesting level: Transform jobs + stage A of the FindSameProperty jobs, then their stage B
-      for (int lv = 0; lv < a.hlevels; ++lv) { a.hlevel = lv; launch_walk_heavy(w, a, s); launch_walk_fspepi(w, a, s); }
-      a.hlevel = 0;
-      launch_walk_light(w, a, s);
-    }
+    if (a.staged) walk_staged_launches(w, a, s);
     launch_walk(w, a, s);                     // staged: only the questions listed as nested too deep
   }
   c->last_walk = a;
@@ -1872,8 +1877,7 @@ int n2nmn_debug_walk_replay(n2nmn_ctx* c, int which, int iters, double* us_avg, 
       WalkArgs t = a;
       t.plist = nullptr;                 // (a replay must not append the pooled roots to the lists again)
       if (t.staged) {
-        for (int lv = 0; lv < t.hlevels; ++lv) { t.hlevel = lv; launch_walk_heavy(w, t, s); launch_walk_fspepi(w, t, s); }
-        launch_walk_light(w, t, s);
+        walk_staged_launches(w, t, s);
       }
       launch_walk(w, t, s);
     }
@@ -1884,7 +1888,7 @@ int n2nmn_debug_walk_replay(n2nmn_ctx* c, int which, int iters, double* us_avg, 
       WalkArgs t = a;
       t.plist = nullptr; t.hlevel = 0;
       if (which == 5) launch_walk_heavy(w, t, s);
-      else if (which == 6) launch_walk_fspepi(w, t, s);
+      else if (which == 6) launch_walk_fsppool(w, t, s);
       else if (which == 7) launch_walk_light(w, t, s);
       else launch_walk(w, t, s);
     }

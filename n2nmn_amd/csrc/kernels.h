@@ -319,7 +319,7 @@ struct WalkBatch {
   // walk_tmap_kernel (which becomes the pass's "plan" step), read by walk_heavy / walk_light
   struct WalkProg* prog;   // [N]
   // FindSameProperty as chip-wide stages: the WALK_POOL_PARTS shares of fc_att(pooled features) of node
-  // (n, t), written by stage A (walk_heavy_kernel), summed by stage B (walk_fspepi_kernel)
+  // (n, t), written by stage A (walk_fsppool_kernel), summed by stage B (an item of walk_heavy_kernel)
   float* fpart;            // [N][T][WALK_POOL_PARTS][Mp]
 };
 // One question's decoded layout (nmn3_assembler.py:153-222 on the device).  op: n2nmn_op of node t
@@ -388,7 +388,7 @@ void launch_walk(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
 void launch_walk_tmap(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
 void launch_walk_find(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
 void launch_walk_heavy(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
-void launch_walk_fspepi(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
+void launch_walk_fsppool(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
 void launch_walk_light(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
 void launch_walk_pool(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
 void launch_walk_heads(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);

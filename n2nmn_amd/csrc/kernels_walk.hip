@@ -46,6 +46,7 @@ struct WalkLds {
   int n_nodes, valid, n_find;
 };
 
+
 // block reductions through `scr` (>= 16 floats); every thread gets the result
 template <int OP>
 __device__ __forceinline__ float wg_reduce(float v, float* scr) {
@@ -98,21 +99,41 @@ __device__ __forceinline__ void fc_pad(int tid, const float* x, int K, const flo
 
 // scores[c] = b[c] + sum_f x[f] * Wm[f*C + c], x in LDS (F values), C <= WT.  Thread (slice, c)
 // takes f = slice, slice + nsl, ...: consecutive threads read consecutive floats of Wm.
-__device__ __forceinline__ void fc_out(int tid, const float* x, int F,
-                                       const float* __restrict__ Wm, const float* __restrict__ b,
-                                       int C, float* __restrict__ out, float* red) {
-  const int nsl = WT / C;
+// The thread's weights go out in groups of FC_FU loads before the first multiply (a loop that loads and
+// accumulates pays an L2 round trip per trip: 9 for CountModule's 152 features, a third of a question's
+// whole chain).  Even trips accumulate into s0, odd trips into s1.  The FIRST group can be requested by
+// the caller long before x exists (fc_out_first: walk_light_kernel asks for it as soon as the plan names
+// the root operator, the round trip then runs under the tree evaluation) -- same sums in the same order.
+constexpr int FC_FU = 10;
+struct FcFirst { float v[FC_FU]; };
+template <int NT = WT>
+__device__ __forceinline__ FcFirst fc_out_first(int tid, int F, const float* __restrict__ Wm, int C) {
+  const int nsl = NT / C;
+  const int c = tid % C, sl = tid / C;
+  FcFirst r;
+#pragma unroll
+  for (int u = 0; u < FC_FU; ++u)
+    r.v[u] = sl < nsl ? Wm[(size_t)min(sl + u * nsl, F - 1) * C + c] : 0.f;
+  return r;
+}
+template <bool PRE, int NT = WT>
+__device__ __forceinline__ void fc_out_t(int tid, const float* x, int F, const float* __restrict__ Wm,
+                                         const float* __restrict__ b, int C, float* __restrict__ out,
+                                         float* red, const FcFirst& pre) {
+  const int nsl = NT / C;
   const int c = tid % C, sl = tid / C;
   float s0 = 0.f, s1 = 0.f;
   if (sl < nsl) {
-    // the thread's weights go out in groups of FU loads before the first multiply (a loop that loads
-    // and accumulates pays an L2 round trip per trip: 9 for CountModule's 152 features, a third of a
-    // question's whole chain).  Same sums in the same order: even trips into s0, odd trips into s1.
-    constexpr int FU = 10;
+    constexpr int FU = FC_FU;
     for (int f0 = sl; f0 < F; f0 += FU * nsl) {
       float wv[FU];
+      if (PRE && f0 == sl) {
 #pragma unroll
-      for (int u = 0; u < FU; ++u) wv[u] = Wm[(size_t)min(f0 + u * nsl, F - 1) * C + c];
+        for (int u = 0; u < FU; ++u) wv[u] = pre.v[u];
+      } else {
+#pragma unroll
+        for (int u = 0; u < FU; ++u) wv[u] = Wm[(size_t)min(f0 + u * nsl, F - 1) * C + c];
+      }
 #pragma unroll
       for (int u = 0; u < FU; ++u) {
         const int f = f0 + u * nsl;
@@ -130,6 +151,12 @@ __device__ __forceinline__ void fc_out(int tid, const float* x, int F,
     out[tid] = r;
   }
   __syncthreads();
+}
+__device__ __forceinline__ void fc_out(int tid, const float* x, int F, const float* __restrict__ Wm,
+                                       const float* __restrict__ b, int C, float* __restrict__ out,
+                                       float* red) {
+  FcFirst none{};
+  fc_out_t<false>(tid, x, F, Wm, b, C, out, red, none);
 }
 
 }  // namespace
@@ -177,12 +204,16 @@ namespace {
 // per CU, and one job's operand build and fold phases hide under the other's MFMAs.
 // History: VALU, taps broadcast from LDS: 45 us per node; 6 interleaved FMA chains: 13 us;
 // MFMA with per-node operand build + one chain: 15 us; 10 chains per wave, one workgroup per CU: 11.6 us.
-constexpr int TR_CG = 4;                         // channel groups (x 2 pixel halves = the 8 waves)
-template <int KS, int PTW>
+// NW = 8: one workgroup owns the node (walk_kernel: wave = (channel group, pixel half)).  NW = 4: the
+// workgroup owns pixel half `half` of the node and its four waves are the channel groups
+// (walk_heavy_kernel: a node is two work items).  tw_ready: tm (.) w_e already in LDS (or nullptr).
+constexpr int TR_CG = 4;                         // channel groups
+template <int KS, int PTW, int NW>
 __device__ __forceinline__ void walk_transform_t(int tid, const ModuleWeights& w, const WalkArgs& a,
-                                                 const float* in0, const float* tm, float* outp,
-                                                 float* scr, long long* tl) {
-  // scr: [Mq] tm (.) w_e | zero-padded map | fold buffer
+                                                 const float* in0, const float* tm, const float* tw_ready,
+                                                 float* outp, float* scr, long long* tl, int half) {
+  // scr: [Mq] tm (.) w_e (unless tw_ready) | zero-padded map | fold buffer
+  constexpr int NT = NW * 64;
   constexpr int KK = KS * KS;
   constexpr int KD = (KK + 1 + 3) & ~3;          // taps + bias row, padded to the MFMA's k = 4
   constexpr int NS = KD / 4;                     // k-steps
@@ -190,14 +221,16 @@ __device__ __forceinline__ void walk_transform_t(int tid, const ModuleWeights& w
   const int H = a.H, W = a.W, HW = H * W, M = a.M;
   const int PW = W + 2 * PAD, PH = H + 2 * PAD;
   const int Mt = (M + 15) >> 4, Pt = (HW + 15) >> 4;     // 16-wide channel / pixel tiles
-  const int Mq = Mt * 16, Pq = 2 * PTW * 16;
+  const int Mq = Mt * 16;
+  constexpr int Pq = (NW / TR_CG) * PTW * 16;    // pixels the workgroup covers
   float* twl = scr;                              // [Mq] tm[c] * w_e[c] (both zero padded to Mp >= Mq)
-  float* xin = twl + Mq;                         // [PH][PW] zero-padded input map (+ 1 spare = 0)
+  float* xin = tw_ready ? scr : twl + Mq;        // [PH][PW] zero-padded input map (+ 1 spare = 0)
   float* red = xin + ((PH * PW + 4) & ~3);       // [TR_CG][Pq][2]
   const int lane = tid & 63, wid = tid >> 6;
   const int ci = lane & 15, kg = lane >> 4;
   const int cw = __builtin_amdgcn_readfirstlane(wid);
-  const int g = cw & (TR_CG - 1), pt0 = (cw / TR_CG) * PTW;
+  const int g = cw & (TR_CG - 1), pt0 = (NW == 8 ? cw / TR_CG : half) * PTW;
+  const int p_base = NW == 8 ? 0 : half * PTW * 16;
   // A fragments of this wave's first channel tile: issued before anything else
   float af[NS];
   {
@@ -207,8 +240,9 @@ __device__ __forceinline__ void walk_transform_t(int tid, const ModuleWeights& w
   }
   // tm (.) w_e for the fold, once per node (it used to ride in registers per channel tile, prefetched
   // like the A fragments: 8 VGPRs of a 128-VGPR budget)
-  for (int c = tid; c < Mq; c += WT) twl[c] = tm[c] * w.we[2][c];
-  for (int i = tid; i <= PH * PW; i += WT) {
+  if (tw_ready) twl = const_cast<float*>(tw_ready);
+  else for (int c = tid; c < Mq; c += NT) twl[c] = tm[c] * w.we[2][c];
+  for (int i = tid; i <= PH * PW; i += NT) {
     const int y = i / PW - PAD, x = i % PW - PAD;
     xin[i] = (i < PH * PW && y >= 0 && y < H && x >= 0 && x < W) ? in0[y * W + x] : 0.f;
   }
@@ -297,18 +331,20 @@ __device__ __forceinline__ void walk_transform_t(int tid, const ModuleWeights& w
     float v = __uint_as_float(h[0]) + __uint_as_float(h[1]);
     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    if ((kg & 1) == 0 && pt0 + pt < Pt) red[((size_t)g * Pq + 16 * (pt0 + pt) + ci) * 2 + (kg >> 1)] = v;
+    if ((kg & 1) == 0 && pt0 + pt < Pt) red[((size_t)g * Pq + 16 * (pt0 + pt) - p_base + ci) * 2 + (kg >> 1)] = v;
   }
   if (tl2 && threadIdx.x == 0) tl2[3] = clock64();
   __syncthreads();
   if (tl && threadIdx.x == 0) tl[2] = clock64();       // debug timeline: MFMA phase done
   const float be = w.be[2][0];
-  for (int p = tid; p < HW; p += WT) {
+  for (int pl = tid; pl < Pq; pl += NT) {
+    const int p = p_base + pl;
+    if (p >= HW) continue;
     float s2 = 0.f, d2 = 0.f;
 #pragma unroll
     for (int q = 0; q < TR_CG; ++q) {
-      s2 += red[((size_t)q * Pq + p) * 2];
-      d2 += red[((size_t)q * Pq + p) * 2 + 1];
+      s2 += red[((size_t)q * Pq + pl) * 2];
+      d2 += red[((size_t)q * Pq + pl) * 2 + 1];
     }
     outp[p] = d2 / sqrtf(fmaxf(s2, 1e-12f)) + be;
   }
@@ -320,8 +356,8 @@ __device__ __forceinline__ void walk_transform(int tid, const ModuleWeights& w, 
                                                const float* in0, const float* tm, float* outp,
                                                float* scr, long long* tl) {
   // pixel tiles per wave: half of ceil(H*W / 16), at most 6 (H*W <= 192: walk_supported)
-  if ((a.H * a.W + 15) / 16 <= 10) walk_transform_t<KS, 5>(tid, w, a, in0, tm, outp, scr, tl);
-  else walk_transform_t<KS, 6>(tid, w, a, in0, tm, outp, scr, tl);
+  if ((a.H * a.W + 15) / 16 <= 10) walk_transform_t<KS, 5, 8>(tid, w, a, in0, tm, nullptr, outp, scr, tl, 0);
+  else walk_transform_t<KS, 6, 8>(tid, w, a, in0, tm, nullptr, outp, scr, tl, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -953,9 +989,9 @@ __device__ __forceinline__ void walk_question(const ModuleWeights& w, const Walk
 }
 
 // Plain passes: workgroup = question.  Staged passes: only the questions the plan listed as nested deeper
-// than the pass launches levels for (fblist, its length on the device) -- a persistent grid of one
-// workgroup per CU walks the list, so the template mix (an empty list) pays for 256 workgroups that leave
-// at once instead of one 150 KB-LDS workgroup per question of the pass (4.7 us).
+// than the pass launches levels for (fblist, its length on the device) -- a persistent grid of 64
+// workgroups walks the list, so the template mix (an empty list) pays for 64 workgroups that leave at
+// once instead of one 150 KB-LDS workgroup per question of the pass (4.7 us).
 template <int CI>
 __global__ __launch_bounds__(WT) void walk_kernel(ModuleWeights w, WalkArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1269,7 +1305,9 @@ __global__ __launch_bounds__(FT, (CI == 1 ? 8 : 1)) void walk_find_kernel(Module
 // square root / division serve four rows per instruction: 2.1 x fewer VALU instructions per map byte.
 // A workgroup (4 waves) owns 32 rows -- 8 per wave, all in flight before the plan is read -- and sweeps the
 // question's Find / Filter nodes one at a time over rows that stay in registers (the next node's text map
-// is requested under the current sweep).
+// is requested under the current sweep).  Measured and not kept: the same without that prefetch (79 VGPRs, six
+// waves per SIMD: 26.0 vs 26.7 us warm, equal cold) and one workgroup per question walking its map in chunks
+// with a register double buffer (38.7 vs 36.7 us cold).
 constexpr int F16_ROWS = 32;
 __device__ __forceinline__ float row16_sum(float v) {
   v += dpp_f<0xB1, 0xF>(0.f, v);     // quad_perm [1,0,3,2]
@@ -1566,21 +1604,12 @@ __device__ __forceinline__ void load_prog(int tid, const WalkProg* src, WalkProg
   if (tid < (int)(sizeof(WalkProg) / 16)) d4[tid] = s4[tid];
 }
 
-// nodes [lo, hi] of a question into the LDS arena: rows that exist in `watt` (Find, Filter's
-// find_result, and -- when `heavy_too` -- the Transform / FindSameProperty maps walk_heavy_kernel wrote)
-// are fetched with every load in flight, then the light operators run in token order
-__device__ __forceinline__ void eval_light_range(int tid, const WalkProg& P, int lo, int hi,
-                                                 const float* watt_q, float* arena, int HW, int HWp,
-                                                 bool heavy_too) {
-  const int cnt = hi - lo + 1;
-  for (int i = tid; i < cnt * HWp; i += WT) {
-    const int t = lo + i / HWp, r = i - (i / HWp) * HWp;
-    const int o = P.op[t] & 0x7f;
-    const bool mat = o == N2NMN_OP_FIND || o == N2NMN_OP_FILTER ||
-                     (heavy_too && (o == N2NMN_OP_TRANSFORM || o == N2NMN_OP_FIND_SAME_PROPERTY));
-    if (mat && r < HW) arena[(size_t)t * HWp + r] = watt_q[(size_t)t * HWp + r];
-  }
-  __syncthreads();
+
+// the light operators of nodes [lo, hi] in token order, on maps that are already in the LDS arena (Find,
+// Filter's find_result, and the heavy nodes of lower levels): eval_light_range without its loads
+template <int NT>
+__device__ __forceinline__ void eval_light_ops(int tid, const WalkProg& P, int lo, int hi, float* arena,
+                                               int HW, int HWp) {
   for (int t = lo; t <= hi; ++t) {
     const int o = P.op[t] & 0x7f;
     float* outp = arena + (size_t)t * HWp;
@@ -1589,16 +1618,16 @@ __device__ __forceinline__ void eval_light_range(int tid, const WalkProg& P, int
     bool wrote = true;
     switch (o) {
       case N2NMN_OP_SCENE:                                       // :60-72
-        for (int r = tid; r < HW; r += WT) outp[r] = 3.0f;
+        for (int r = tid; r < HW; r += NT) outp[r] = 3.0f;
         break;
       case N2NMN_OP_AND:                                         // :218-236
-        for (int r = tid; r < HW; r += WT) outp[r] = fminf(in0[r], in1[r]);
+        for (int r = tid; r < HW; r += NT) outp[r] = fminf(in0[r], in1[r]);
         break;
       case N2NMN_OP_OR:                                          // :238-256
-        for (int r = tid; r < HW; r += WT) outp[r] = fmaxf(in0[r], in1[r]);
+        for (int r = tid; r < HW; r += NT) outp[r] = fmaxf(in0[r], in1[r]);
         break;
       case N2NMN_OP_FILTER:                                      // And(input_0, find_result) :129-130
-        for (int r = tid; r < HW; r += WT) outp[r] = fminf(in0[r], outp[r]);
+        for (int r = tid; r < HW; r += NT) outp[r] = fminf(in0[r], outp[r]);
         break;
       default: wrote = false; break;
     }
@@ -1609,57 +1638,63 @@ __device__ __forceinline__ void eval_light_range(int tid, const WalkProg& P, int
 // FindSameProperty (nmn3_modules.py:134-183) as chip-wide stages (round 5).  One workgroup per node ran
 // its three dependent streams -- 307 KB feature pool, 512 KB fc_att weights, 154 KB map epilogue -- at ONE
 // CU's pace (17-46 GB/s: 31.6 us per node, 104 of them per 1024 questions set the length of the launch).
-// Now a node is WALK_POOL_PARTS items of stage A inside walk_heavy_kernel and as many workgroups of stage B:
-//   A (fsp_pool_item): channel part `part` of the soft-max pooling (:170-172) -- 38 KB of the feature map,
-//     every load in flight before the input subtree is evaluated under them -- and, because fc_att is
+// Now a node is WALK_POOL_PARTS workgroups of stage A (walk_fsppool_kernel, launched first: it needs only the
+// Find / Filter logits) and as many stage-B items inside walk_heavy_kernel, next to the level's Transform
+// nodes (the matrix-core-bound Transform halves and the stream-bound epilogues share the CUs):
+//   A (fsp_pool_rest): channel part `part` of the soft-max pooling (:170-172) -- 38 KB of the feature map,
+//     every load in flight before the plan of the question has even arrived -- and, because fc_att is
 //     linear (:173-176), that part's share of it: pooled[part] . W_att[rows of the part] -> fpart[n][t][part]
-//     (64 KB of weights per item, requested with the features; the full product is the bias plus the eight
-//     shares, summed in part order by stage B: no atomics, a fixed order);
-//   B (walk_fspepi_kernel): att = l2norm_c(M_fsp[r, c] * tmap[c] * am[c]) . w_e + b_e (:178-180) over the
-//     operator's own conv_image map, 8 workgroups per node streaming their rows like walk_find_kernel.
-__device__ __forceinline__ void fsp_pool_item(int tid, const ModuleWeights& w, const WalkArgs& a,
-                                              const WalkBatch& B, const WalkProg& P, int n, int t, int part,
-                                              float* arena, float* pp, float* sa0, float* scr, bool heavy_too) {
-  const int HW = a.H * a.W, D = a.D, Mp = a.Mp, HWp = a.HWp, T = a.T;
-  const int Dp = D / POOLP, ncol = Dp / 4, nrow = WT / ncol;
+//     (64 KB of weights per item; the full product is the bias plus the eight shares, summed in part order
+//     by stage B: no atomics, a fixed order);
+//   B (fsp_epi_item): att = l2norm_c(M_fsp[r, c] * tmap[c] * am[c]) . w_e + b_e (:178-180) over the
+//     operator's own conv_image map, 8 row parts per node streaming their rows like walk_find_kernel.
+constexpr int HT = 256, HWV = HT / 64;                  // walk_heavy_kernel: 4 waves per work item
+constexpr int FSP_PR = WALK_POOLK_ROWS;                 // feature rows of a thread (walk_pool_supported's bound)
+constexpr int FSP_KU = 8;                               // fc_att weight rows in flight per thread
+struct FspLoads { float4 fr[FSP_PR]; float4 w4[FSP_KU]; };
+
+__device__ __forceinline__ void fsp_fetch_w(FspLoads& L, const float* Wp, int kb, int k0, int k1, int Mp,
+                                            unsigned col) {
+#pragma unroll
+  for (int u = 0; u < FSP_KU; ++u) {
+    const unsigned k = (unsigned)min(kb + u, max(k1 - 1, k0));
+    L.w4[u] = *reinterpret_cast<const float4*>(Wp + (k * (unsigned)Mp + col));
+  }
+}
+
+// the loads of a stage-A item that depend on nothing but (question, node, part)
+__device__ __forceinline__ void fsp_pool_loads(int tid, const ModuleWeights& w, const WalkArgs& a,
+                                               const WalkBatch& B, int n, int part, FspLoads& L) {
+  const int HW = a.H * a.W, D = a.D, Mp = a.Mp;
+  const int Dp = D / POOLP, ncol = Dp / 4, nrow = HT / ncol;
   const int lane = tid & 63, wid = tid >> 6;
   const int lc = tid % ncol, lr = tid / ncol;
-  constexpr int PR = (WALK_POOLK_ROWS + 1) / 2;          // rows of a thread (walk_pool_supported's bound, 512 threads)
-  // ---- the feature rows of this thread, then the first fc_att weight rows: nothing depends on the tree
   const float* fp = B.feat + (size_t)n * HW * D + part * Dp + 4 * lc;
   const int myrows = lr < nrow ? (HW - lr + nrow - 1) / nrow : 0;
-  float4 fr[PR];
-  {
-    const unsigned rowstep = (unsigned)(nrow * D);
-    unsigned off = (unsigned)(lr * D);
-    const unsigned last = (unsigned)((myrows > 0 ? lr + (myrows - 1) * nrow : 0) * D);
+  const unsigned rowstep = (unsigned)(nrow * D);
+  unsigned off = (unsigned)(lr * D);
+  const unsigned last = (unsigned)((myrows > 0 ? lr + (myrows - 1) * nrow : 0) * D);
 #pragma unroll
-    for (int qq = 0; qq < PR; ++qq) {
-      fr[qq] = *reinterpret_cast<const float4*>(fp + min(off, last));
-      off += rowstep;
-    }
+  for (int qq = 0; qq < FSP_PR; ++qq) {
+    L.fr[qq] = *reinterpret_cast<const float4*>(fp + min(off, last));
+    off += rowstep;
   }
-  // fc_att share: k-group kq = wave (Dp / 8 rows of the part each), float4 columns over the lanes
-  constexpr int KU = 8;
-  const int kper = (Dp + WW - 1) / WW;
+  const int kper = (Dp + HWV - 1) / HWV;
   const int k0 = part * Dp + wid * kper, k1 = min(part * Dp + Dp, k0 + kper);
-  const float* Wp = w.Watt[0];
-  float4 w4[KU];
-  auto fetch = [&](int kb, unsigned col) {
-#pragma unroll
-    for (int u = 0; u < KU; ++u) {
-      const unsigned k = (unsigned)min(kb + u, max(k1 - 1, k0));
-      w4[u] = *reinterpret_cast<const float4*>(Wp + (k * (unsigned)Mp + col));
-    }
-  };
-  fetch(k0, (unsigned)min(4 * lane, Mp - 4));
-  __builtin_amdgcn_sched_barrier(0);
-  // ---- the node's input map (its light subtree; the maps of lower levels come from watt)
-  const int i0 = P.in0[t];
-  eval_light_range(tid, P, P.lo[i0], i0, B.watt + (size_t)n * T * HWp, arena, HW, HWp, heavy_too);
-  const float* in0 = arena + (size_t)i0 * HWp;
-  // soft-max over the H*W logits (:170-172): a wave per 192 values, in registers (walk_light_kernel's form)
-  if (wid == 0) {                                        // (H*W <= 192: walk_supported)
+  fsp_fetch_w(L, w.Watt[0], k0, k0, k1, Mp, (unsigned)min(4 * lane, Mp - 4));
+}
+
+// the rest of the item, once the input map of the node is in the arena
+__device__ __forceinline__ void fsp_pool_rest(int tid, const ModuleWeights& w, const WalkArgs& a,
+                                              const WalkBatch& B, int n, int t, int part, const float* in0,
+                                              FspLoads& L, float* pp, float* sa0, float* scr) {
+  const int HW = a.H * a.W, D = a.D, Mp = a.Mp, T = a.T;
+  const int Dp = D / POOLP, ncol = Dp / 4, nrow = HT / ncol;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int lc = tid % ncol, lr = tid / ncol;
+  const int myrows = lr < nrow ? (HW - lr + nrow - 1) / nrow : 0;
+  // soft-max over the H*W logits (:170-172): ONE wave, in registers (walk_light_kernel's form; H*W <= 192)
+  if (wid == 0) {
     float v[3], lm = -INFINITY;
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
@@ -1681,175 +1716,283 @@ __device__ __forceinline__ void fsp_pool_item(int tid, const ModuleWeights& w, c
   if (lr < nrow) {
     float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int qq = 0; qq < PR; ++qq) {
+    for (int qq = 0; qq < FSP_PR; ++qq) {
       if (qq < myrows) {
         const float w0 = sa0[lr + qq * nrow];
-        acc0.x += w0 * fr[qq].x; acc0.y += w0 * fr[qq].y; acc0.z += w0 * fr[qq].z; acc0.w += w0 * fr[qq].w;
+        acc0.x += w0 * L.fr[qq].x; acc0.y += w0 * L.fr[qq].y; acc0.z += w0 * L.fr[qq].z; acc0.w += w0 * L.fr[qq].w;
       }
     }
     *reinterpret_cast<float4*>(stage + (size_t)lr * Dp + 4 * lc) = acc0;
   }
   __syncthreads();
-  for (int c = tid; c < Dp; c += WT) {
+  for (int c = tid; c < Dp; c += HT) {
     float sacc = 0.f;
     for (int qq = 0; qq < nrow; ++qq) sacc += stage[(size_t)qq * Dp + c];
     pp[c] = sacc;
   }
   __syncthreads();
-  // ---- this part's share of fc_att (:173-176): fpart[n][t][part][c] = sum_{k in part} pooled[k] W[k][c]
-  float* red = scr;                                      // [WW][256]
+  // ---- this part's share of fc_att (:173-176): fpart[n][t][part][c] = sum_{k in part} pooled[k] W[k][c];
+  // wave = k group, float4 columns over the lanes (the first FSP_KU weight rows were requested with the features)
+  const int kper = (Dp + HWV - 1) / HWV;
+  const int k0 = part * Dp + wid * kper, k1 = min(part * Dp + Dp, k0 + kper);
+  float* red = scr;                                      // [HWV][256]
   float* dst = B.fpart + (((size_t)n * T + t) * POOLP + part) * Mp;
   for (int cb = 0; cb < Mp; cb += 256) {
     const unsigned col = (unsigned)min(cb + 4 * lane, Mp - 4);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int kb = k0; kb < k1; kb += KU) {
-      if (kb != k0 || cb != 0) fetch(kb, col);
+    for (int kb = k0; kb < k1; kb += FSP_KU) {
+      if (kb != k0 || cb != 0) fsp_fetch_w(L, w.Watt[0], kb, k0, k1, Mp, col);
 #pragma unroll
-      for (int u = 0; u < KU; ++u) {
+      for (int u = 0; u < FSP_KU; ++u) {
         if (kb + u < k1) {
           const float xv = pp[kb + u - part * Dp];
-          acc.x += xv * w4[u].x; acc.y += xv * w4[u].y; acc.z += xv * w4[u].z; acc.w += xv * w4[u].w;
+          acc.x += xv * L.w4[u].x; acc.y += xv * L.w4[u].y; acc.z += xv * L.w4[u].z; acc.w += xv * L.w4[u].w;
         }
       }
     }
     *reinterpret_cast<float4*>(red + (size_t)wid * 256 + 4 * lane) = acc;
     __syncthreads();
-    if (tid < 256 && cb + tid < Mp) {
+    if (cb + tid < Mp) {
       float r = 0.f;
 #pragma unroll
-      for (int q = 0; q < WW; ++q) r += red[q * 256 + tid];
+      for (int q = 0; q < HWV; ++q) r += red[q * 256 + tid];
       dst[cb + tid] = r;
     }
     __syncthreads();
   }
 }
 
-// Items of a level: the Transform jobs first (microseconds of MFMA work each: they start first), then
-// WALK_POOL_PARTS stage-A items per FindSameProperty job.  Two workgroups per CU (<= 128 VGPRs, 40 KB of
-// LDS each): one item's operand / fold phases run under another's MFMAs or feature stream.
-// (launch bounds: 4 waves per SIMD = two 8-wave workgroups per CU, 128 VGPRs; one instantiation per
-// (kernel size, pixel tiles per wave) so that no variant pays for another's registers)
+// Items of a level, 4 waves each: two per Transform node (pixel halves: a node's 2.3 MFLOP of fp32 MFMA are
+// 9 k clocks of one CU's matrix pipe, and 300 nodes on 256 CUs leave a fifth of the CUs with two of them;
+// 600 half nodes spread), then WALK_POOL_PARTS stage-A items per FindSameProperty node.  <= 128 VGPRs and
+// 20 KB of LDS: four items per CU, so one item's dependent chain (list entry -> plan -> operators) runs
+// under the others' MFMAs / feature streams.  Everything an item reads that does not depend on the plan
+// -- ALL attention rows of the question (12.8 KB; the plan only says which are used), the text map, the
+// features and fc_att weights -- is requested before the plan has arrived.
+// (launch bounds: 4 waves per SIMD; one instantiation per (kernel size, pixel tiles per wave) so that no
+// variant pays for another's registers)
+struct HeavyLds { float *arena, *tml, *twl, *pp, *sa0, *scr; };
+constexpr int HEAVY_NQ = (WALK_MAX_T * 192 / 4 + HT - 1) / HT;   // float4 of the arena per thread (T * HWp <= 32 * 192)
+
+// the attention rows in FRONT of a node (its subtree is a token range that ends right before it), requested
+// before the question's plan is known -- the plan only says which of them are used; kept in registers
+// across the barrier that guards the plan's LDS copy
+struct HeavyRows { float4 v0, v1, v2, v3, v4, v5; };
+static_assert(HEAVY_NQ == 6, "HeavyRows holds HEAVY_NQ float4");
+__device__ __forceinline__ HeavyRows heavy_rows_load(int tid, const float* watt_q, int nq4) {
+  const float4* wq4 = reinterpret_cast<const float4*>(watt_q);
+  HeavyRows r;
+  r.v0 = wq4[min(tid, nq4 - 1)];          r.v1 = wq4[min(tid + HT, nq4 - 1)];
+  r.v2 = wq4[min(tid + 2 * HT, nq4 - 1)]; r.v3 = wq4[min(tid + 3 * HT, nq4 - 1)];
+  r.v4 = wq4[min(tid + 4 * HT, nq4 - 1)]; r.v5 = wq4[min(tid + 5 * HT, nq4 - 1)];
+  return r;
+}
+__device__ __forceinline__ void heavy_rows_store(int tid, float* arena, int nq4, const HeavyRows& r) {
+  float4* a4 = reinterpret_cast<float4*>(arena);
+  if (tid < nq4) a4[tid] = r.v0;
+  if (tid + HT < nq4) a4[tid + HT] = r.v1;
+  if (tid + 2 * HT < nq4) a4[tid + 2 * HT] = r.v2;
+  if (tid + 3 * HT < nq4) a4[tid + 3 * HT] = r.v3;
+  if (tid + 4 * HT < nq4) a4[tid + 4 * HT] = r.v4;
+  if (tid + 5 * HT < nq4) a4[tid + 5 * HT] = r.v5;
+}
+// is node t of the plan a node of this operator at this level (a stale or foreign list entry is skipped)?
+__device__ __forceinline__ bool heavy_node_ok(const WalkProg& P, int t, int op, int lv) {
+  return P.valid && !P.fallback && t < P.nn && (P.op[t] & 0x7f) == op && P.hd[t] == lv + 1 && P.in0[t] >= 0;
+}
+
+// pixel half `half` of Transform node (n, t)
 template <int KS, int PTW>
-__global__ __launch_bounds__(WT, 4) void walk_heavy_kernel(ModuleWeights w, WalkArgs a) {
+__device__ __forceinline__ void heavy_transform_item(int tid, const ModuleWeights& w, const WalkArgs& a,
+                                                     const WalkBatch& B, WalkProg& P, int q, int n, int t,
+                                                     int half, int lv, const HeavyLds& S) {
+  const int HW = a.H * a.W, Mp = a.Mp, HWp = a.HWp, T = a.T;
+  const int nq4 = t * HWp / 4;                          // rows [0, t)  (HWp % 4 == 0; t >= 1: the node has an input)
+  const HeavyRows wq = heavy_rows_load(tid, B.watt + (size_t)n * T * HWp, nq4);
+  float4 tmv = make_float4(0.f, 0.f, 0.f, 0.f), wev = tmv;
+  if (4 * tid < Mp) {                                   // (Mp <= 4 * HT = 1024: MAXCI)
+    tmv = *reinterpret_cast<const float4*>(B.tmap + ((size_t)t * a.N + n) * Mp + 4 * tid);
+    wev = *reinterpret_cast<const float4*>(w.we[2] + 4 * tid);
+  }
+  __syncthreads();                                     // the previous item's readers of P / LDS are done
+  load_prog(tid, B.prog + n, P);
+  heavy_rows_store(tid, S.arena, nq4, wq);
+  if (4 * tid < Mp) {
+    *reinterpret_cast<float4*>(S.tml + 4 * tid) = tmv;
+    *reinterpret_cast<float4*>(S.twl + 4 * tid) =
+        make_float4(tmv.x * wev.x, tmv.y * wev.y, tmv.z * wev.z, tmv.w * wev.w);
+  }
+  __syncthreads();
+  if (!heavy_node_ok(P, t, N2NMN_OP_TRANSFORM, lv)) return;
+  const int i0 = P.in0[t];
+  // the node's input map: its light subtree (level >= 1: the Transform / FindSameProperty maps of the lower
+  // levels inside the subtree came from watt with the rest)
+  eval_light_ops<HT>(tid, P, P.lo[i0], i0, S.arena, HW, HWp);
+  // debug timeline (n2nmn_debug_walk_timeline), first half only: [0] operands in LDS, [1] padded map built,
+  // [2] matrix phase done, [3] map written
+  long long* tl = (a.timeline && half == 0) ? a.timeline + ((size_t)q * MAXT + t) * 4 : nullptr;
+  if (tl && threadIdx.x == 0) tl[0] = clock64();
+  float* outp = S.arena + (size_t)t * HWp;
+  walk_transform_t<KS, PTW, HWV>(tid, w, a, S.arena + (size_t)i0 * HWp, S.tml, S.twl, outp, S.scr, tl, half);   // :185-216
+  float* dst = B.watt + ((size_t)n * T + t) * HWp;
+  for (int pl = tid; pl < PTW * 16; pl += HT) {
+    const int pxl = half * PTW * 16 + pl;
+    if (pxl < HW) dst[pxl] = outp[pxl];
+  }
+  if (tl && threadIdx.x == 0) tl[3] = clock64();
+}
+
+// Stage B of FindSameProperty node (n, t), row part `part`: the Find-type epilogue over the operator's own
+// conv_image map, with tmap (.) (b_att + the eight fc_att shares of stage A) in the place of Find's text map
+template <int CI>
+__device__ __forceinline__ void fsp_epi_item(int tid, const ModuleWeights& w, const WalkArgs& a,
+                                             const WalkBatch& B, int n, int t, int part, int lv) {
+  const int lane = tid & 63;
+  const int T = a.T, HW = a.H * a.W, Mp = a.Mp, HWp = a.HWp;
+  const int rpp = (HW + WALK_FIND_PARTS - 1) / WALK_FIND_PARTS;
+  const int r0 = part * rpp, r1 = min(HW, r0 + rpp);
+  if (r0 >= r1) return;
+  const float* Mbuf = B.mfsp + (size_t)n * HW * Mp;
+  const FindRows<CI> pre = find_load<CI>(Mbuf, r0 + (tid >> 6), r1, lane, Mp);
+  const WalkProg* P = B.prog + n;                      // uniform address: scalar loads
+  if (!P->valid || P->fallback || t >= P->nn || (P->op[t] & 0x7f) != N2NMN_OP_FIND_SAME_PROPERTY ||
+      P->hd[t] != lv + 1)
+    return;
+  float4 t4[1][CI], e4[CI];
+  const float* tm = B.tmap + ((size_t)t * a.N + n) * Mp;
+  const float* fp = B.fpart + ((size_t)n * T + t) * POOLP * Mp;
+#pragma unroll
+  for (int i = 0; i < CI; ++i) {
+    const int c = 4 * lane + 256 * i;
+    if (c < Mp) {
+      float4 am = *reinterpret_cast<const float4*>(w.batt[0] + c);
+      float4 sh[POOLP];
+#pragma unroll
+      for (int p = 0; p < POOLP; ++p) sh[p] = *reinterpret_cast<const float4*>(fp + (size_t)p * Mp + c);
+#pragma unroll
+      for (int p = 0; p < POOLP; ++p) { am.x += sh[p].x; am.y += sh[p].y; am.z += sh[p].z; am.w += sh[p].w; }
+      const float4 tv = *reinterpret_cast<const float4*>(tm + c);
+      t4[0][i] = make_float4(tv.x * am.x, tv.y * am.y, tv.z * am.z, tv.w * am.w);
+      e4[i] = *reinterpret_cast<const float4*>(w.we[1] + c);
+    } else {
+      t4[0][i] = make_float4(0.f, 0.f, 0.f, 0.f); e4[i] = t4[0][i];
+    }
+  }
+  float* os[1] = {B.watt + ((size_t)n * T + t) * HWp};
+  if (rpp <= FindUnroll<CI>::value * FW) find_rows_core<CI, 1, true>(tid, w.be[1][0], e4, t4, Mbuf, os, r0, r1, Mp, pre);
+  else find_rows_core<CI, 1, false>(tid, w.be[1][0], e4, t4, Mbuf, os, r0, r1, Mp, pre);
+}
+
+// channel part `part` of stage A of FindSameProperty node (q, t)
+__device__ __forceinline__ void fsp_pool_item(int tid, const ModuleWeights& w, const WalkArgs& a, WalkProg& P,
+                                              int q, int t, int part, int lv, float* arena, float* pp,
+                                              float* sa0, float* scr) {
+  const int HW = a.H * a.W, HWp = a.HWp, T = a.T;
+  const int kb = q / a.N, n = q - kb * a.N;
+  const WalkBatch& B = a.b[kb];
+  FspLoads FL;
+  fsp_pool_loads(tid, w, a, B, n, part, FL);
+  // rows [0, t): the node's subtree lies in front of it.  The first HT float4 (6 rows of 160) ride in
+  // registers across the plan's barrier; a deeper subtree's remaining rows are fetched behind it
+  const int nq4 = t * HWp / 4;
+  const float4* wq4 = reinterpret_cast<const float4*>(B.watt + (size_t)n * T * HWp);
+  const float4 wr0 = wq4[min(tid, nq4 - 1)];
+  __syncthreads();                                     // the previous item's readers of P / LDS are done
+  load_prog(tid, B.prog + n, P);
+  {
+    float4* a4 = reinterpret_cast<float4*>(arena);
+    if (tid < nq4) a4[tid] = wr0;
+    for (int i = tid + HT; i < nq4; i += HT) a4[i] = wq4[i];
+  }
+  __syncthreads();
+  if (!heavy_node_ok(P, t, N2NMN_OP_FIND_SAME_PROPERTY, lv)) return;
+  const int i0 = P.in0[t];
+  // (level >= 1: the Transform / FindSameProperty maps of the lower levels inside the subtree came from watt)
+  eval_light_ops<HT>(tid, P, P.lo[i0], i0, arena, HW, HWp);
+  fsp_pool_rest(tid, w, a, B, n, t, part, arena + (size_t)i0 * HWp, FL, pp, sa0, scr);
+}
+
+// Stage A of the FindSameProperty nodes of a level: walk_fsppool_kernel, WALK_POOL_PARTS workgroups per
+// node (persistent over the level's list).  Launched before the level's walk_heavy_kernel.
+__global__ __launch_bounds__(HT, 4) void walk_fsppool_kernel(ModuleWeights w, WalkArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ __attribute__((aligned(16))) WalkProg P;
-  const int HW = a.H * a.W, D = a.D, Mp = a.Mp, HWp = a.HWp, T = a.T;
+  const int HWp = a.HWp, T = a.T;
   float* arena = smem;                                 // [T][HWp]
-  float* tml = arena + (size_t)T * HWp;                // [Mp] text map of the node
-  float* pp = tml + Mp;                                // [D / POOL_PARTS] pooled features of the part
-  float* sa0 = pp + D / POOLP;                         // [HWp]
-  float* scr = sa0 + HWp;                              // operator scratch
+  float* pp = arena + (size_t)T * HWp;                 // [D / POOL_PARTS] pooled features of the part
+  float* sa0 = pp + a.D / POOLP;                       // [HWp]
+  float* scr = sa0 + HWp;                              // [4 * HT]
+  const int lv = a.hlevel;
+  const int cfs = lv == 0 ? 2 : 7 + 2 * lv;
+  const int cap = (a.hoff[lv + 1] - a.hoff[lv]) / 2;
+  const int nfsp = min(a.cnt[cfs], cap);
+  const int32_t* jfs = a.hjobs + a.hoff[lv] + cap;
+  for (int j = blockIdx.x; j < POOLP * nfsp; j += gridDim.x) {
+    // (an opaque copy per item: the per-thread addresses of one item's 18 loads must not be hoisted out of
+    // the loop, where they would stay live across everything else -- see walk_kernel)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int job = jfs[j / POOLP], part = j % POOLP;
+    const int q = job >> 8, t = job & 0xff;
+    if (q < 0 || q >= a.K * a.N || t >= T || t < 1) continue;        // (a stale list entry)
+    fsp_pool_item(tid, w, a, P, q, t, part, lv, arena, pp, sa0, scr);
+  }
+}
+
+// Items of a level, 4 waves each: two per Transform node (pixel halves: a node's 2.3 MFLOP of fp32 MFMA are
+// 9 k clocks of one CU's matrix pipe, and 300 nodes on 256 CUs leave a fifth of the CUs with two of them;
+// 600 half nodes spread), then WALK_FIND_PARTS stage-B items per FindSameProperty node (their stage A ran in
+// the launch before).  <= 128 VGPRs and 20 KB of LDS: four items per CU, so one item's dependent chain (list
+// entry -> plan -> operators) runs under the others' MFMAs / map streams.  Everything an item reads that
+// does not depend on the plan -- the attention rows in front of the node, its text map, the rows of the
+// conv_image map -- is requested before the plan has arrived.
+// (launch bounds: 4 waves per SIMD; one instantiation per (kernel size, pixel tiles per wave, map width) so
+// that no variant pays for another's registers)
+template <int KS, int PTW, int CI>
+__global__ __launch_bounds__(HT, 4) void walk_heavy_kernel(ModuleWeights w, WalkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ __attribute__((aligned(16))) WalkProg P;
+  const int T = a.T;
+  HeavyLds S;
+  S.arena = smem;                                      // [T][HWp]
+  S.tml = S.arena + (size_t)T * a.HWp;                 // [Mp] text map of the node
+  S.twl = S.tml + a.Mp;                                // [Mp] text map (.) w_e
+  S.pp = nullptr; S.sa0 = nullptr;
+  S.scr = S.twl + a.Mp;                                // Transform's padded map + fold buffer
   const int lv = a.hlevel;
   const int ctr = lv == 0 ? 0 : 6 + 2 * lv, cfs = lv == 0 ? 2 : 7 + 2 * lv;
   const int cap = (a.hoff[lv + 1] - a.hoff[lv]) / 2;
   const int nfsp = min(a.cnt[cfs], cap), ntr = min(a.cnt[ctr], cap);
   const int32_t* jtr = a.hjobs + a.hoff[lv];
   const int32_t* jfs = jtr + cap;
-  for (int j = blockIdx.x; j < ntr + POOLP * nfsp; j += gridDim.x) {
+  const int nB = WALK_FIND_PARTS * nfsp;
+  for (int j = blockIdx.x; j < nB + 2 * ntr; j += gridDim.x) {
     // the opaque copy keeps one operator's address arithmetic from being hoisted across the other
     // (see walk_kernel)
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
-    const bool tr = j < ntr;
-    const int job = tr ? jtr[j] : jfs[(j - ntr) / POOLP];
-    const int part = tr ? 0 : (j - ntr) % POOLP;
+    // stage-B items first: short streams (3 - 4 us) that free their slots for the Transform halves behind
+    // them; with the Transform halves first, 400 of the 800 epilogues only started when a 10 us half left
+    const bool tr = j >= nB;
+    const int job = tr ? jtr[(j - nB) >> 1] : jfs[j / WALK_FIND_PARTS];
+    const int part = tr ? ((j - nB) & 1) : j % WALK_FIND_PARTS;
     const int q = job >> 8, t = job & 0xff;
-    if (q < 0 || q >= a.K * a.N || t >= T) continue;                 // (a stale list entry)
+    if (q < 0 || q >= a.K * a.N || t >= T || t < 1) continue;        // (a stale list entry)
     const int kb = q / a.N, n = q - kb * a.N;
-    const WalkBatch& B = a.b[kb];
-    __syncthreads();                                   // the previous item's readers of P / LDS are done
-    load_prog(tid, B.prog + n, P);
-    __syncthreads();
-    const int o = P.op[t] & 0x7f;
-    if (!P.valid || P.fallback || t >= P.nn || o != (tr ? N2NMN_OP_TRANSFORM : N2NMN_OP_FIND_SAME_PROPERTY) ||
-        P.hd[t] != lv + 1 || P.in0[t] < 0)
-      continue;
-    if (!tr) {
-      // (level >= 1: the Transform / FindSameProperty maps of the lower levels inside the subtree are in watt)
-      fsp_pool_item(tid, w, a, B, P, n, t, part, arena, pp, sa0, scr, lv > 0);
-      continue;
-    }
-    const int i0 = P.in0[t];
-    // debug timeline (n2nmn_debug_walk_timeline): [0] job start, [1] operands ready, [2] matrix phase done,
-    // [3] map written
-    long long* tl = a.timeline ? a.timeline + ((size_t)q * MAXT + t) * 4 : nullptr;
-    if (tl && threadIdx.x == 0) tl[0] = clock64();
-    {                                                   // text map of the node (walk_tmap_kernel's row)
-      const float* src = B.tmap + ((size_t)t * a.N + n) * Mp;
-      for (int c = 4 * tid; c < Mp; c += 4 * WT)
-        *reinterpret_cast<float4*>(tml + c) = *reinterpret_cast<const float4*>(src + c);
-    }
-    eval_light_range(tid, P, P.lo[i0], i0, B.watt + (size_t)n * T * HWp, arena, HW, HWp, lv > 0);
-    const float* in0 = arena + (size_t)i0 * HWp;
-    float* outp = arena + (size_t)t * HWp;
-    walk_transform_t<KS, PTW>(tid, w, a, in0, tml, outp, scr, tl);             // :185-216
-    float* dst = B.watt + ((size_t)n * T + t) * HWp;
-    for (int r = tid; r < HW; r += WT) dst[r] = outp[r];
-    if (tl && threadIdx.x == 0) tl[3] = clock64();
+    if (tr) heavy_transform_item<KS, PTW>(tid, w, a, a.b[kb], P, q, n, t, part, lv, S);
+    else fsp_epi_item<CI>(tid, w, a, a.b[kb], n, t, part, lv);
   }
 }
 
-// Stage B of FindSameProperty: the Find-type epilogue over the operator's own conv_image map, with
-// tmap (.) (b_att + the eight fc_att shares of stage A) in the place of Find's text map.  Grid:
-// (persistent over the level's job list, WALK_FIND_PARTS row parts).
-// (a level has ~100 jobs x 8 workgroups per 1024 questions: 3 waves per SIMD; the eight shares in flight
-// at once want more than walk_find_kernel's 64 VGPRs)
-template <int CI, bool ONE>
-__global__ __launch_bounds__(FT, (CI == 1 ? 4 : 1)) void walk_fspepi_kernel(ModuleWeights w, WalkArgs a) {
-  const int lv = a.hlevel;
-  const int cfs = lv == 0 ? 2 : 7 + 2 * lv;
-  const int cap = (a.hoff[lv + 1] - a.hoff[lv]) / 2;
-  const int nfsp = min(a.cnt[cfs], cap);
-  const int32_t* jfs = a.hjobs + a.hoff[lv] + cap;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int T = a.T, HW = a.H * a.W, Mp = a.Mp, HWp = a.HWp;
-  const int rpp = (HW + WALK_FIND_PARTS - 1) / WALK_FIND_PARTS;
-  const int r0 = blockIdx.y * rpp, r1 = min(HW, r0 + rpp);
-  if (r0 >= r1) return;
-  for (int j = blockIdx.x; j < nfsp; j += gridDim.x) {
-    const int job = jfs[j];
-    const int q = job >> 8, t = job & 0xff;
-    if (q < 0 || q >= a.K * a.N || t >= T) continue;
-    const int kb = q / a.N, n = q - kb * a.N;
-    const WalkBatch& B = a.b[kb];
-    const float* Mbuf = B.mfsp + (size_t)n * HW * Mp;
-    const FindRows<CI> pre = find_load<CI>(Mbuf, r0 + (tid >> 6), r1, lane, Mp);
-    const WalkProg* P = B.prog + n;                    // uniform address: scalar loads
-    if (!P->valid || P->fallback || t >= P->nn || (P->op[t] & 0x7f) != N2NMN_OP_FIND_SAME_PROPERTY ||
-        P->hd[t] != lv + 1)
-      continue;
-    float4 t4[1][CI], e4[CI];
-    const float* tm = B.tmap + ((size_t)t * a.N + n) * Mp;
-    const float* fp = B.fpart + ((size_t)n * T + t) * POOLP * Mp;
-#pragma unroll
-    for (int i = 0; i < CI; ++i) {
-      const int c = 4 * lane + 256 * i;
-      if (c < Mp) {
-        float4 am = *reinterpret_cast<const float4*>(w.batt[0] + c);
-        float4 sh[POOLP];
-#pragma unroll
-        for (int p = 0; p < POOLP; ++p) sh[p] = *reinterpret_cast<const float4*>(fp + (size_t)p * Mp + c);
-#pragma unroll
-        for (int p = 0; p < POOLP; ++p) { am.x += sh[p].x; am.y += sh[p].y; am.z += sh[p].z; am.w += sh[p].w; }
-        const float4 tv = *reinterpret_cast<const float4*>(tm + c);
-        t4[0][i] = make_float4(tv.x * am.x, tv.y * am.y, tv.z * am.z, tv.w * am.w);
-        e4[i] = *reinterpret_cast<const float4*>(w.we[1] + c);
-      } else {
-        t4[0][i] = make_float4(0.f, 0.f, 0.f, 0.f); e4[i] = t4[0][i];
-      }
-    }
-    float* os[1] = {B.watt + ((size_t)n * T + t) * HWp};
-    find_rows_core<CI, 1, ONE>(tid, w.be[1][0], e4, t4, Mbuf, os, r0, r1, Mp, pre);
-  }
-}
-
-__global__ __launch_bounds__(WT) void walk_light_kernel(ModuleWeights w, WalkArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  __shared__ __attribute__((aligned(16))) WalkProg P;
-  const int q = blockIdx.x;
+// One workgroup per question: every node that is not a Transform / FindSameProperty, the answer operator
+// or the hand-over of a pooling root.  The question's chain is a sequence of dependent round trips (plan ->
+// maps -> answer weights); the last one leaves the chain: the first group of the answer fc's weights / the
+// root's text map is requested as soon as the plan names the root operator, under the tree evaluation.
+template <int NT>
+__device__ __forceinline__ void light_item(int tid, const ModuleWeights& w, const WalkArgs& a, WalkProg& P,
+                                           int q, float* smem) {
   const int kb = q / a.N, n = q - kb * a.N;
   const WalkBatch& B = a.b[kb];
-  const int tid = threadIdx.x;
   const int HW = a.H * a.W, Mp = a.Mp, HWp = a.HWp, T = a.T, C = a.C;
   float* arena = smem;                                 // [T][HWp]
   float* rs = arena + (size_t)T * HWp;                 // [32]
@@ -1864,14 +2007,27 @@ __global__ __launch_bounds__(WT) void walk_light_kernel(ModuleWeights w, WalkArg
   if (tid == 0 && B.validity) B.validity[n] = P.valid;
   if (tid == 0) B.pjob[n] = 0;
   if (!P.valid) {                                      // INVALID_EXPR: zero logits (nmn3_model.py:146,155)
-    for (int c = tid; c < C; c += WT) srow[c] = 0.f;
+    for (int c = tid; c < C; c += NT) srow[c] = 0.f;
     return;
   }
   const int nn = P.nn;
+  const int t = nn - 1;
+  const int op = P.op[t] & 0x7f;
+  const bool pool_root = op == N2NMN_OP_DESCRIBE || op == N2NMN_OP_SAME_PROPERTY;
+  // ---- what the root needs from memory, requested now
+  int F = 0, wi = 0;
+  if (op == N2NMN_OP_EXIST) { F = 3; wi = 0; }
+  else if (op == N2NMN_OP_COUNT) { F = HW + 2; wi = 1; }
+  else if (!pool_root) { F = 2 * HW + 4; wi = op == N2NMN_OP_EQUAL_NUM ? 2 : (op == N2NMN_OP_MORE_NUM ? 3 : 4); }
+  FcFirst pre{};
+  float4 tm4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* tsrc = B.tmap + ((size_t)t * a.N + n) * Mp;
+  if (pool_root) { if (4 * tid < Mp) tm4 = *reinterpret_cast<const float4*>(tsrc + 4 * tid); }
+  else pre = fc_out_first<NT>(tid, F, w.Wans[wi], C);
   if (a.stats && tid == 0) {                           // the counters walk_kernel keeps (profiling only)
     unsigned long long cf = 0, cpi = 0, cp = 0, ct = 0, ctr = 0, nfind = 0;
-    for (int t = 0; t < nn; ++t) {
-      const int o = P.op[t] & 0x7f;
+    for (int tt = 0; tt < nn; ++tt) {
+      const int o = P.op[tt] & 0x7f;
       const bool f = o == N2NMN_OP_FIND || o == N2NMN_OP_FILTER || o == N2NMN_OP_FIND_SAME_PROPERTY;
       const bool p = o == N2NMN_OP_FIND_SAME_PROPERTY || o == N2NMN_OP_SAME_PROPERTY || o == N2NMN_OP_DESCRIBE;
       cf += o == N2NMN_OP_FIND_SAME_PROPERTY; cp += p;
@@ -1882,20 +2038,32 @@ __global__ __launch_bounds__(WT) void walk_light_kernel(ModuleWeights w, WalkArg
     atomicAdd(a.stats + 8, (nfind + 3) / 4);
     atomicAdd(a.stats + 0, cf); atomicAdd(a.stats + 1, cpi); atomicAdd(a.stats + 2, cp);
     atomicAdd(a.stats + 3, ct); atomicAdd(a.stats + 4, ctr); atomicAdd(a.stats + 5, 1ull);
-    const int ro = P.op[nn - 1] & 0x7f;
-    if (ro == N2NMN_OP_DESCRIBE || ro == N2NMN_OP_SAME_PROPERTY) {
-      atomicAdd(a.stats + 6, 1ull); atomicAdd(a.stats + 7, ro == N2NMN_OP_SAME_PROPERTY ? 2ull : 1ull);
+    if (pool_root) {
+      atomicAdd(a.stats + 6, 1ull); atomicAdd(a.stats + 7, op == N2NMN_OP_SAME_PROPERTY ? 2ull : 1ull);
     }
   }
-  // every attention node of the tree: the root is the only answer node (a valid layout)
-  eval_light_range(tid, P, 0, nn - 2, B.watt + (size_t)n * T * HWp, arena, HW, HWp, true);
+  // every attention node of the tree (the root is the only answer node of a valid layout): the rows that
+  // exist in `watt` -- Find / Filter logits (walk_find), Transform / FindSameProperty maps (walk_heavy) --
+  // with every load in flight, then the light operators in token order.  (Requesting ALL T rows before the
+  // plan arrives, as the heavy items do for the rows in front of their node, was measured slower here: 12.8
+  // KB per question where the template mix needs 0.6 - 1.8.)
+  {
+    const float* watt_q = B.watt + (size_t)n * T * HWp;
+    for (int i = tid; i < (nn - 1) * HWp; i += NT) {
+      const int tt = i / HWp, r = i - tt * HWp;
+      const int o = P.op[tt] & 0x7f;
+      const bool mat = o == N2NMN_OP_FIND || o == N2NMN_OP_FILTER || o == N2NMN_OP_TRANSFORM ||
+                       o == N2NMN_OP_FIND_SAME_PROPERTY;
+      if (mat && r < HW) arena[(size_t)tt * HWp + r] = watt_q[(size_t)tt * HWp + r];
+    }
+    __syncthreads();
+  }
+  eval_light_ops<NT>(tid, P, 0, nn - 2, arena, HW, HWp);
   if (tl && tid == 0) tl[1] = clock64();
-  const int t = nn - 1;
-  const int op = P.op[t] & 0x7f;
   const float* in0 = P.in0[t] >= 0 ? arena + (size_t)P.in0[t] * HWp : nullptr;
   const float* in1 = P.in1[t] >= 0 ? arena + (size_t)P.in1[t] * HWp : nullptr;
   const int lane = tid & 63, wid = tid >> 6;
-  if (op == N2NMN_OP_DESCRIBE || op == N2NMN_OP_SAME_PROPERTY) {
+  if (pool_root) {
     // deferred pooling root: soft-max weights, text map and job code for walk_pool / walk_heads
     // (:432-437,482-484).  A map has H*W = 150 values: ONE wave reduces it in registers (three values
     // per lane, DPP wave reductions) -- the block-wide reductions of walk_kernel cost two barriers and
@@ -1921,8 +2089,9 @@ __global__ __launch_bounds__(WT) void walk_light_kernel(ModuleWeights w, WalkArg
         if (lane + 64 * u < HW) pw[wid * HWp + lane + 64 * u] = v[u] / sum;
     }
     float* ptm = B.ptm + (size_t)n * Mp;
-    const float* tsrc = B.tmap + ((size_t)t * a.N + n) * Mp;
-    for (int c = tid; c < Mp; c += WT) ptm[c] = tsrc[c];
+    if (4 * tid < Mp) *reinterpret_cast<float4*>(ptm + 4 * tid) = tm4;
+    for (int c = 4 * (tid + NT); c < Mp; c += 4 * NT)      // (Mp > 4 * NT: not at CLEVR dimensions)
+      *reinterpret_cast<float4*>(ptm + c) = *reinterpret_cast<const float4*>(tsrc + c);
     if (tid == 0) {
       B.pjob[n] = op;
       if (a.plist) {                                   // the job lists walk_fcatt_kernel works from
@@ -1955,74 +2124,72 @@ __global__ __launch_bounds__(WT) void walk_light_kernel(ModuleWeights w, WalkArg
     if (lane == 0) { rs[4 * wid] = mn; rs[4 * wid + 1] = mx; rs[4 * wid + 2] = sm; }
   }
   __syncthreads();
-  int F, wi;
   if (op == N2NMN_OP_EXIST) {
     if (tid == 0) { const float mn = rs[0], mx = rs[1], sm = rs[2]; x[0] = mn; x[1] = sm / (float)HW; x[2] = mx; }
-    F = 3; wi = 0;
   } else if (op == N2NMN_OP_COUNT) {
     if (tid == 0) { x[HW] = rs[0]; x[HW + 1] = rs[1]; }
-    F = HW + 2; wi = 1;
   } else {
     if (tid == 0) {
       x[HW] = rs[0]; x[HW + 1] = rs[1];
       x[2 * HW + 2] = rs[4]; x[2 * HW + 3] = rs[5];
     }
-    F = 2 * HW + 4;
-    wi = op == N2NMN_OP_EQUAL_NUM ? 2 : (op == N2NMN_OP_MORE_NUM ? 3 : 4);
   }
   __syncthreads();
   if (tl && tid == 0) tl[2] = clock64();
-  fc_out(tid, x, F, w.Wans[wi], w.bans[wi], C, srow, red);
+  fc_out_t<true, NT>(tid, x, F, w.Wans[wi], w.bans[wi], C, srow, red, pre);
   if (tl && tid == 0) tl[3] = clock64();
+}
+
+
+__global__ __launch_bounds__(HT) void walk_light_kernel(ModuleWeights w, WalkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ __attribute__((aligned(16))) WalkProg P;
+  light_item<HT>(threadIdx.x, w, a, P, blockIdx.x, smem);
 }
 
 }  // namespace
 
-// LDS of walk_heavy_kernel (floats): arena + text map + pooled part + soft-max weights + the larger of
-// Transform's padded map / fold buffer and the FindSameProperty item's staging (4 * WT = [rows][part
-// channels] = [waves][256])
+// LDS of walk_heavy_kernel (floats): arena + text map (twice) + Transform's padded map / fold buffer
 static size_t heavy_lds_floats(const WalkArgs& a) {
   const int pad = a.ksize / 2;
-  const size_t tr = (size_t)((a.M + 15) / 16 * 16) + (((size_t)(a.H + 2 * pad) * (a.W + 2 * pad) + 4) & ~3) +
-                    (size_t)TR_CG * 192 * 2;
-  const size_t fs = (size_t)4 * WT;
-  return (size_t)a.T * a.HWp + a.Mp + a.D / POOLP + a.HWp + (tr > fs ? tr : fs) + 64;
+  const size_t tr = (((size_t)(a.H + 2 * pad) * (a.W + 2 * pad) + 4) & ~3) + (size_t)TR_CG * 96 * 2;
+  return (size_t)a.T * a.HWp + 2 * (size_t)a.Mp + tr + 64;
 }
 
 void launch_walk_heavy(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) {
   const size_t smem = sizeof(float) * heavy_lds_floats(a);
-  // a persistent grid over the level's items: two workgroups per CU's worth of ids, each takes items
+  // a persistent grid over the level's items: four workgroups per CU's worth of ids, each takes items
   // id, id + grid, ... (the list lengths live on the device)
-  const int grid = std::min(512, std::max(1, (a.hoff[a.hlevel + 1] - a.hoff[a.hlevel]) / 2));
+  const int grid = std::min(1024, std::max(1, a.hoff[a.hlevel + 1] - a.hoff[a.hlevel]));
   auto go = [&](auto kern, std::atomic<uint64_t>& done) {
     if (smem > 64 * 1024) ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)smem, done);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WT), smem, s, w, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(HT), smem, s, w, a);
   };
-  static std::atomic<uint64_t> d35{0}, d36{0}, d55{0}, d56{0};
+  static std::atomic<uint64_t> dn[8];
   const bool p5 = (a.H * a.W + 15) / 16 <= 10;     // pixel tiles per wave (walk_transform)
-  if (a.ksize == 5) { if (p5) go(walk_heavy_kernel<5, 5>, d55); else go(walk_heavy_kernel<5, 6>, d56); }
-  else { if (p5) go(walk_heavy_kernel<3, 5>, d35); else go(walk_heavy_kernel<3, 6>, d36); }
+  const bool c1 = a.Mp <= 256;                     // float4 column groups per lane of the stage-B epilogue
+  if (a.ksize == 5) {
+    if (p5) { if (c1) go(walk_heavy_kernel<5, 5, 1>, dn[0]); else go(walk_heavy_kernel<5, 5, 4>, dn[1]); }
+    else { if (c1) go(walk_heavy_kernel<5, 6, 1>, dn[2]); else go(walk_heavy_kernel<5, 6, 4>, dn[3]); }
+  } else {
+    if (p5) { if (c1) go(walk_heavy_kernel<3, 5, 1>, dn[4]); else go(walk_heavy_kernel<3, 5, 4>, dn[5]); }
+    else { if (c1) go(walk_heavy_kernel<3, 6, 1>, dn[6]); else go(walk_heavy_kernel<3, 6, 4>, dn[7]); }
+  }
 }
 
-void launch_walk_fspepi(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) {
+void launch_walk_fsppool(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) {
   const int cap = (a.hoff[a.hlevel + 1] - a.hoff[a.hlevel]) / 2;
-  const dim3 grid(std::min(256, std::max(1, cap)), WALK_FIND_PARTS);
-  const int ci = (a.Mp + 255) / 256;
-  const int rpp = (a.H * a.W + WALK_FIND_PARTS - 1) / WALK_FIND_PARTS;      // rows of a workgroup
-  if (ci == 1) {
-    if (rpp <= FindUnroll<1>::value * FW) hipLaunchKernelGGL((walk_fspepi_kernel<1, true>), grid, dim3(FT), 0, s, w, a);
-    else hipLaunchKernelGGL((walk_fspepi_kernel<1, false>), grid, dim3(FT), 0, s, w, a);
-  } else if (ci == 2) {
-    hipLaunchKernelGGL((walk_fspepi_kernel<2, false>), grid, dim3(FT), 0, s, w, a);
-  } else {
-    hipLaunchKernelGGL((walk_fspepi_kernel<4, false>), grid, dim3(FT), 0, s, w, a);
-  }
+  const size_t smem = sizeof(float) * ((size_t)a.T * a.HWp + a.D / POOLP + a.HWp + (size_t)4 * HT + 64);
+  static std::atomic<uint64_t> done{0};
+  if (smem > 64 * 1024) ensure_dynamic_lds(reinterpret_cast<const void*>(walk_fsppool_kernel), (int)smem, done);
+  const int grid = (int)std::min<long>(1024, std::max<long>(1, (long)cap * POOLP));
+  hipLaunchKernelGGL(walk_fsppool_kernel, dim3(grid), dim3(HT), smem, s, w, a);
 }
 
 void launch_walk_light(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) {
   const int HW = a.H * a.W;
-  const size_t smem = sizeof(float) * ((size_t)a.T * a.HWp + 32 + (size_t)((2 * HW + 4 + 3) & ~3) + WT);
-  hipLaunchKernelGGL(walk_light_kernel, dim3(a.K * a.N), dim3(WT), smem, s, w, a);
+  const size_t smem = sizeof(float) * ((size_t)a.T * a.HWp + 32 + (size_t)((2 * HW + 4 + 3) & ~3) + HT);
+  hipLaunchKernelGGL(walk_light_kernel, dim3(a.K * a.N), dim3(HT), smem, s, w, a);
 }
 
 void launch_walk_pool(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) {
@@ -2083,8 +2250,7 @@ void launch_walk_tmap(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) 
 }
 
 void launch_walk_find(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) {
-  static const bool f16 = [] { const char* e = getenv("N2NMN_WALK_FIND16"); return !e || atoi(e) != 0; }();
-  if (f16 && a.Mp <= 256 && a.Mp % 64 == 0) {          // sixteen lanes per row (walk_find16_kernel)
+  if (a.Mp <= 256 && a.Mp % 64 == 0) {                 // sixteen lanes per row (walk_find16_kernel)
     const dim3 g16(a.K * a.N, (a.H * a.W + F16_ROWS - 1) / F16_ROWS);
     switch (a.Mp / 64) {
       case 1: hipLaunchKernelGGL(walk_find16_kernel<1>, g16, dim3(FT), 0, s, w, a); break;
@@ -2114,7 +2280,7 @@ void launch_walk(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) {
     if (smem > 64 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(kern, dim3(a.staged ? std::min(a.K * a.N, 256) : a.K * a.N), dim3(WT), smem, s, w, a);
+    hipLaunchKernelGGL(kern, dim3(a.staged ? std::min(a.K * a.N, 64) : a.K * a.N), dim3(WT), smem, s, w, a);
   };
   const int ci = (a.Mp + 255) / 256;
   if (ci == 1) go(walk_kernel<1>);

@@ -487,3 +487,4 @@ def test_fixed_level_count_makes_nested_layouts_reproducible_bit_for_bit(clevr_e
         eng.set_staged(-1)
     assert np.array_equal(a, b), 'fixed level count: the logits must not depend on what ran before'
     assert_close('level by level vs the one-workgroup walker', a, ref, STAGED_TOL)
+

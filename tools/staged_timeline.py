@@ -48,7 +48,7 @@ def main():
             print('  %s med %6.0f p90 %6.0f' % (lab, np.median(rows[:, j]), np.percentile(rows[:, j], 90)), end='')
         print()
 
-    for op, labels in (('_Transform', ('operands', 'mfma', 'fold+write', 'total')),
+    for op, labels in (('_Transform', ('padded map', 'mfma', 'fold+write', 'total (from operands in LDS)')),
                        ('_FindSameProperty', ('subtree+pool', 'fc_att', 'epilogue', 'total'))):
         rows = []
         for q in range(Q):

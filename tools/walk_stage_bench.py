@@ -30,11 +30,11 @@ def main():
         sb.run(use_gt_layout=True)
     torch.cuda.synchronize()
     eng = sb.engine
-    names = {0: 'walker (heavy + fspepi per level + light + fall-back)', 5: '  walk_heavy (level 0)',
-             6: '  walk_fspepi (level 0)', 7: '  walk_light', 8: '  walk_kernel (fall-back list)',
+    names = {0: 'walker (fsppool + heavy per level, light, fall-back)', 5: '  walk_heavy (level 0: Transform + FSP stage B)',
+             6: '  walk_fsppool (level 0: FSP stage A)', 7: '  walk_light', 8: '  walk_kernel (fall-back list)',
              3: 'walk_find', 1: 'walk_pool', 2: 'walk_fcatt + walk_heads', 4: 'walk_tmap'}
     tot = 0.0
-    for which in (4, 3, 0, 5, 6, 7, 8, 1, 2):
+    for which in (4, 3, 0, 6, 5, 7, 8, 1, 2):
         us = min(eng.walk_replay_us(which, 50) for _ in range(3))
         print('%-56s %8.2f us' % (names[which], us), flush=True)
         if which in (3, 0, 1):
