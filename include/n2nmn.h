@@ -584,6 +584,12 @@ int n2nmn_debug_walk_replay(n2nmn_ctx *ctx, int which, int iters, double *us_avg
 int n2nmn_debug_walk_timeline(n2nmn_ctx *ctx, long long *timeline_dev);
 int n2nmn_debug_gemm(n2nmn_ctx *ctx, const float *A, const float *B, const float *bias,
                      float *C, int M, int N, int K, n2nmn_stream stream);
+/* out[M,N] = (relu ? max(0, .) : .)(A[M,K] . W[K,N] + bias[N]), row-major fp32, K % 4 == 0:
+ * util/cnn.py:87-126 (fc_layer / fc_relu_layer) and -- on im2col rows -- the VALID strided convolutions of
+ * models_shapes/shapes_convnet.py:8-17 (BASELINE.json configs[0]; not on the CLEVR hot path).  Packs W per
+ * call and synchronises `stream`. */
+int n2nmn_fc_forward(n2nmn_ctx *ctx, const float *A, const float *W, const float *bias, float *out,
+                     int M, int N, int K, int relu, n2nmn_stream stream);
 
 #ifdef __cplusplus
 }

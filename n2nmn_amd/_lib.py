@@ -142,6 +142,7 @@ SYMBOLS = [
     ('n2nmn_debug_walk_replay', _I, [_P, _I, _I, C.POINTER(C.c_double), _P]),
     ('n2nmn_debug_walk_timeline', _I, [_P, _P]),
     ('n2nmn_debug_gemm', _I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    ('n2nmn_fc_forward', _I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
 ]
 
 

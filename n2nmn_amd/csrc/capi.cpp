@@ -2137,4 +2137,26 @@ int n2nmn_debug_gemm(n2nmn_ctx* ctx, const float* A, const float* B, const float
   return check_launch("debug_gemm");
 }
 
+// out = [relu](A . W + bias): util/cnn.py:87-126 (fc_layer / fc_relu_layer) and, on im2col rows, the VALID
+// strided convolutions of models_shapes/shapes_convnet.py:8-17 (conv_relu_layer).  W is packed per call (a
+// small operator of the SHAPES plumbing, BASELINE configs[0]; the hot-path GEMMs use commit-time packs).
+int n2nmn_fc_forward(n2nmn_ctx* ctx, const float* A, const float* W, const float* bias, float* out,
+                     int M, int N, int K, int relu, n2nmn_stream stream) {
+  N2_REQUIRE(ctx && A && W && out, N2NMN_EINVAL, "fc_forward: null argument");
+  N2_REQUIRE(M > 0 && N > 0 && K > 0 && K % 4 == 0, N2NMN_EINVAL,
+             "fc_forward: K must be a positive multiple of 4");
+  const int Kp = round_up(K, 32), Np = round_up(N, 64);
+  float* Bp = nullptr;
+  N2_HIP(hipMalloc(reinterpret_cast<void**>(&Bp), sizeof(float) * (size_t)Kp * Np));
+  hipStream_t s = S(stream);
+  launch_pack_pk(W, N, K, N, Bp, Kp, Np, s);
+  GemmArgs g{};
+  g.A = A; g.lda = K; g.M = M; g.K = K; g.group_size = 1; g.Bp = Bp; g.Np = Np; g.Kp = Kp;
+  g.bias = bias; g.N = N; g.C = out; g.ldc = N; g.n_store = N; g.relu = relu ? 1 : 0;
+  launch_gemm_pk(g, s);
+  N2_HIP(hipStreamSynchronize(s));       // (the pack is freed right away)
+  N2_HIP(hipFree(Bp));
+  return check_launch("fc_forward");
+}
+
 }  // extern "C"

@@ -493,6 +493,8 @@ int n2nmn_train_enable(n2nmn_ctx* c) {
   {
     int lo = 0, hi = 0;
     N2_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));      // lo = lowest priority (largest number)
+    // (measured and rejected, round 5: a CU-masked side stream -- hipExtStreamCreateWithCUMask with 32 .. 192 of
+    // the 256 CUs -- doubles the step, 2.58 -> 5.16 ms, whatever the mask: profiles/r05_notes.md)
     N2_HIP(hipStreamCreateWithPriority(&t->side, hipStreamNonBlocking, lo));
     for (int i = 0; i < TrainState::kForkEvents; ++i)
       N2_HIP(hipEventCreateWithFlags(&t->ev_fork[i], hipEventDisableTiming));

@@ -438,6 +438,27 @@ class Engine:
                             flops=fl.value, bytes=by.value))
         return out
 
+    def fc(self, A, W, bias=None, relu: bool = False):
+        """out = [relu](A . W + bias) through n2nmn_fc_forward (util/cnn.py:87-126; on im2col rows the
+        VALID strided convolutions of models_shapes/shapes_convnet.py).  Device tensor [M, N]."""
+        torch = _torch()
+        A = self._dev(A, torch.float32); W = self._dev(W, torch.float32)
+        bias = self._dev(bias, torch.float32)
+        M, K = A.shape
+        N = W.shape[1]
+        out = torch.empty((M, N), dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.n2nmn_fc_forward(self._ctx, A.data_ptr(), W.data_ptr(),
+                                              bias.data_ptr() if bias is not None else None,
+                                              out.data_ptr(), M, N, K, 1 if relu else 0, self.stream()))
+        return out
+
+    def set_validity_tables(self, P, W, b):
+        """replace the decoder's validity automaton (n2nmn_set_validity_tables): all-zero tables make every
+        token valid at every step -- the decoder of models_shapes/nmn3_netgen_att.py has no automaton"""
+        P = np.ascontiguousarray(P, np.int32); W = np.ascontiguousarray(W, np.int32)
+        b = np.ascontiguousarray(b, np.int32)
+        _lib.check(self._lib.n2nmn_set_validity_tables(self._ctx, P.ctypes.data, W.ctypes.data, b.ctypes.data))
+
     def gemm(self, A, B, bias=None):
         torch = _torch()
         A = self._dev(A, torch.float32); B = self._dev(B, torch.float32)

@@ -79,6 +79,8 @@ class Session:
         return out[0] if single else out
 
     def run(self, fetches, feed_dict=None):
+        if isinstance(fetches, _NoOp):        # sess.run(tf.global_variables_initializer()): nothing to do,
+            return None                       # variables live in the engine and are set by Saver.restore
         h = self.partial_run_setup(fetches, list((feed_dict or {}).keys()))
         return self.partial_run(h, fetches, feed_dict)
 
@@ -123,6 +125,10 @@ class _Namespace:
         self.__dict__.update(kw)
 
 
+class _NoOp:
+    """tf.global_variables_initializer() (exp_shapes/eval_shapes.py:135)"""
+
+
 def _config(**kwargs):
     return _Namespace(**kwargs)
 
@@ -133,6 +139,7 @@ tf = _Namespace(
     placeholder=placeholder,
     int32='int32', int64='int64', float32='float32', float64='float64', bool='bool',
     train=_Namespace(Saver=_Saver),
+    global_variables_initializer=lambda: _NoOp(),
 )
 
 

@@ -200,6 +200,13 @@ class VQAEngine:
                                            e.stream()))
         return self._feat_c
 
+    def add_question_prior(self, scores):
+        """scores += question_prior_net(encoder states of the last phase 1)  (models_vqa/nmn3_model.py:106-114,
+        question_prior_net.py:10-28), in place; returns scores"""
+        e = self.engine
+        _lib.check(e._lib.n2nmn_question_prior_add(e._ctx, scores.shape[0], scores.data_ptr(), e.stream()))
+        return scores
+
     def forward(self, batch, use_gt_layout: bool = False, gt_layout=None, forced_tokens=None,
                 use_qpn: bool = True, host_assemble: bool = False, fetch: bool = True):
         """phase 1 -> phase 2 (+ question prior).  Returns (scores device tensor [N, num_choices], tokens,
@@ -234,8 +241,7 @@ class VQAEngine:
             scores, validity = e.execute_tokens(s2s['predicted_tokens'], feat_c, s2s['word_vecs'])
             tokens = s2s['predicted_tokens']
         if use_qpn and self.dims.qpn_hidden > 0:
-            _lib.check(e._lib.n2nmn_question_prior_add(e._ctx, scores.shape[0], scores.data_ptr(),
-                                                       e.stream()))
+            self.add_question_prior(scores)
         if not (known or host_assemble) and fetch:
             tokens = tokens.cpu().numpy()
             validity = validity.cpu().numpy().astype(bool)

@@ -98,6 +98,7 @@ def decoder_forward(w, enc, T_dec, eos_idx, dtype=np.float64, use_gt_layout=Fals
     scores_all = np.zeros((T_dec, N, demb.shape[0]), dtype)
     neg_ent = np.zeros(N, dtype)
     is_eos = np.zeros(N, bool)
+    feats = np.zeros((T_dec, N, Wy.shape[0]), dtype)       # [h1, ctx]: what token_prediction sees (fixtures)
     for t in range(T_dec):
         c0, h0 = O._lstm_cell(x, c0, h0, W0, b0)
         c1, h1 = O._lstm_cell(h0, c1, h1, W1, b1)
@@ -106,7 +107,8 @@ def decoder_forward(w, enc, T_dec, eos_idx, dtype=np.float64, use_gt_layout=Fals
         att = O._softmax(e, axis=0) * nf
         att = att / np.sum(att, axis=0, keepdims=True)
         ctx = np.sum(att * eout, axis=0)
-        sc = np.concatenate([h1, ctx], axis=1) @ Wy + by
+        feats[t] = np.concatenate([h1, ctx], axis=1)
+        sc = feats[t] @ Wy + by
         tok = np.argmax(sc, axis=1).astype(np.int32)                     # :193
         if use_gt_layout:
             tok = np.asarray(gt_layout[t], np.int32)                     # :194-196
@@ -123,7 +125,7 @@ def decoder_forward(w, enc, T_dec, eos_idx, dtype=np.float64, use_gt_layout=Fals
         tokens[t] = tok; tprobs[t] = tp; atts[t] = att; scores_all[t] = sc
     word_vecs = np.sum(atts * enc['embedded'][None], axis=1)
     return dict(predicted_tokens=tokens, token_probs=tprobs, neg_entropy=neg_ent, atts=atts,
-                word_vecs=word_vecs, token_scores=scores_all)
+                word_vecs=word_vecs, token_scores=scores_all, token_features=feats)
 
 
 def assemble(tokens):

@@ -81,8 +81,14 @@ class SessionRecorder:
     runs: what the script ASKED of the drop-in (constructor keywords, every partial_run with its feeds)
     and what it got back.  Placeholders are recorded by name; image features by question index."""
 
-    def __init__(self, d: Dims):
+    def __init__(self, d: Dims = None, model_cls=None, feature_fn=None, n_questions=N_QUESTIONS):
+        """model_cls: the drop-in model class whose constructor the script calls (default: the models_clevr
+        NMN3Model); feature_fn(i) -> the image feed row(s) of question i, [1, ...] (default: feature_of);
+        None: image feeds are recorded as arrays"""
         self.d = d
+        self.model_cls = model_cls
+        self.feature_fn = feature_fn if feature_fn is not None else ((lambda i: feature_of(i, d)) if d is not None else None)
+        self.n_questions = n_questions
         self.model_kwargs = None
         self.calls = []
         self.setups = {}
@@ -91,7 +97,7 @@ class SessionRecorder:
 
     def _image_ids(self, feat):
         if self._feats is None:
-            self._feats = [feature_of(i, self.d)[0] for i in range(N_QUESTIONS)]
+            self._feats = [self.feature_fn(i)[0] for i in range(self.n_questions)]
         ids = []
         for row in np.asarray(feat):
             hit = [i for i, f in enumerate(self._feats) if np.array_equal(f, row)]
@@ -111,7 +117,8 @@ class SessionRecorder:
         from n2nmn_amd import nmn3_model, runtime
         from n2nmn_amd.nmn3_assembler import PackedLayouts
         rec = self
-        init0 = nmn3_model.NMN3Model.__init__
+        model_cls = self.model_cls if self.model_cls is not None else nmn3_model.NMN3Model
+        init0 = model_cls.__init__
         run0 = runtime.Session.partial_run
         setup0 = runtime.Session.partial_run_setup
 
@@ -137,14 +144,15 @@ class SessionRecorder:
                 role = rec.role(k)
                 if isinstance(v, PackedLayouts):
                     feeds[role] = ('packed', v)
-                elif role == 'image_feat_grid':
+                elif role == 'image_feat_grid' and rec.feature_fn is not None:
                     feeds[role] = ('image_ids', rec._image_ids(v))
                 else:
                     feeds[role] = ('array', np.asarray(v))
-            rec.calls.append(dict(fetch=fetches.name, feeds=feeds, handle=id(handle), result=np.asarray(out)))
+            # (a copy: exp_vqa/eval_vqa2.py:137 writes into the array it got back)
+            rec.calls.append(dict(fetch=fetches.name, feeds=feeds, handle=id(handle), result=np.array(out, copy=True)))
             return out
 
-        monkeypatch.setattr(nmn3_model.NMN3Model, '__init__', init)
+        monkeypatch.setattr(model_cls, '__init__', init)
         monkeypatch.setattr(runtime.Session, 'partial_run', partial_run)
         monkeypatch.setattr(runtime.Session, 'partial_run_setup', partial_run_setup)
 

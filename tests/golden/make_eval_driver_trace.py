@@ -58,8 +58,9 @@ class _Patch:
             f()
 
 
-def pack_trace(rec, answers_written, answers):
-    """recorder -> dict of arrays for np.savez"""
+def pack_trace(rec, answers_written, answers, result_dtype=None):
+    """recorder -> dict of arrays for np.savez (answers_written: words of `answers`, or indices already;
+    result_dtype: store the returned values in this type -- float32 keeps the 3001-answer VQA logits small)"""
     out, calls, handles, setups = {}, [], {}, []
     for k, c in enumerate(rec.calls):
         feeds = {}
@@ -74,7 +75,8 @@ def pack_trace(rec, answers_written, answers):
             else:
                 out[key] = v
                 feeds[name] = dict(kind='array', key=key)
-        out['c%d_result' % k] = c['result']
+        out['c%d_result' % k] = c['result'] if (result_dtype is None or c['result'].dtype.kind != 'f') \
+            else c['result'].astype(result_dtype)
         if c['handle'] not in handles:
             handles[c['handle']] = len(handles)
             setups.append({k: v for k, v in rec.setups[c['handle']].items() if k != 'keep'})
@@ -83,7 +85,7 @@ def pack_trace(rec, answers_written, answers):
                 placeholders={k: [str(v[1]), list(v[2])] for k, v in rec.placeholders.items()},
                 setups=setups, calls=calls)
     out['meta'] = np.frombuffer(json.dumps(meta, sort_keys=True).encode(), np.uint8)
-    out['answers_written'] = np.asarray([answers.index(a) for a in answers_written], np.int32)
+    out['answers_written'] = np.asarray([a if answers is None else answers.index(a) for a in answers_written], np.int32)
     return out
 
 
@@ -102,6 +104,52 @@ def record():
     return pack_trace(rec, written, answers)
 
 
+OUT_VQA = os.path.join(HERE, 'eval_driver_trace_vqa2.npz')
+OUT_SHAPES = os.path.join(HERE, 'eval_driver_trace_shapes.npz')
+
+
+def record_vqa():
+    """exp_vqa/eval_vqa2.py (tests/eval_driver_more.py): the answers it wrote come from its results json"""
+    import json as _json
+    import eval_driver_common as EC
+    import eval_driver_more as EM
+    from oracle_engine import OracleVQAEngine
+    from n2nmn_amd import models_vqa
+    mp = _Patch()
+    rec = EC.SessionRecorder(None, model_cls=models_vqa.NMN3Model, feature_fn=EM.vqa_feature_of,
+                             n_questions=EM.VQA_N)
+    with tempfile.TemporaryDirectory() as tmp:
+        try:
+            g, data, words, answers, w = EM.run_vqa_script(Path(tmp), mp, OracleVQAEngine, rec)
+            res = _json.load(open(Path(tmp) / 'exp_vqa' / 'eval_outputs' / 'exp0' /
+                                  'vqa_OpenEnded_mscoco_syn_exp0_00040000_results.json'))
+        finally:
+            mp.undo()
+    assert [r['question_id'] for r in res] == [1000 + i for i in range(EM.VQA_N)]
+    return pack_trace(rec, [r['answer'] for r in res], answers, result_dtype=np.float32)
+
+
+def record_shapes():
+    """exp_shapes/eval_shapes.py: it writes accuracies, not answers -- its per-question predictions are
+    the arg max of the scores it fetched (`predictions`, :166)"""
+    import eval_driver_common as EC
+    import eval_driver_more as EM
+    from oracle_engine import OracleShapesEngine
+    from n2nmn_amd import models_shapes
+    mp = _Patch()
+    rec = EC.SessionRecorder(None, model_cls=models_shapes.NMN3ModelAtt, feature_fn=None)
+    with tempfile.TemporaryDirectory() as tmp:
+        try:
+            g, w = EM.run_shapes_script(Path(tmp), mp, OracleShapesEngine, rec)
+            summary = open(Path(tmp) / 'exp_shapes' / 'results' / 'exp0' / '00040000.train.tiny.txt').read()
+        finally:
+            mp.undo()
+    preds = np.concatenate([np.argmax(c['result'], axis=1) for c in rec.calls if c['fetch'] == 'scores'])
+    t = pack_trace(rec, list(preds), None)
+    t['summary'] = np.frombuffer(summary.encode(), np.uint8)
+    return t
+
+
 def same(a, b):
     if set(a) != set(b):
         return 'keys differ: %s' % sorted(set(a) ^ set(b))
@@ -118,11 +166,15 @@ def same(a, b):
 
 
 if __name__ == '__main__':
-    t = record()
-    if '--check' in sys.argv:
-        z = np.load(OUT)
-        err = same(t, {k: z[k] for k in z.files})
-        print('eval_driver_trace.npz:', err or 'reproduced')
-        sys.exit(1 if err else 0)
-    np.savez_compressed(OUT, **t)
-    print('wrote', OUT, '%d calls, %.0f KB' % (len(json.loads(bytes(t['meta']))['calls']), os.path.getsize(OUT) / 1e3))
+    bad = 0
+    for out, rec_fn in ((OUT, record), (OUT_VQA, record_vqa), (OUT_SHAPES, record_shapes)):
+        t = rec_fn()
+        if '--check' in sys.argv:
+            z = np.load(out)
+            err = same(t, {k: z[k] for k in z.files})
+            print(os.path.basename(out) + ':', err or 'reproduced')
+            bad += bool(err)
+            continue
+        np.savez_compressed(out, **t)
+        print('wrote', out, '%d calls, %.0f KB' % (len(json.loads(bytes(t['meta']))['calls']), os.path.getsize(out) / 1e3))
+    sys.exit(1 if bad else 0)

@@ -68,3 +68,154 @@ class OracleEngine:
                 scores[nodes[i].out_row] = O.eval_expr(self.weights, expr(i), feat, wv,
                                                        self.dims.num_choices, np.float64)
         return torch.as_tensor(scores)
+
+
+# ---- models_vqa: the double behind n2nmn_amd.models_vqa.NMN3Model (exp_vqa/eval_vqa2.py) -------------------
+class _OracleVQASeq2Seq:
+    """the slice of n2nmn_amd.engine.Engine the models_vqa face uses: seq2seq / execute, with the VQA oracle"""
+
+    def __init__(self, owner):
+        self.o = owner
+        self.device = torch.device('cpu')
+
+    def seq2seq(self, input_seq, seq_len, T_dec=None, use_gt_layout=False, gt_layout=None, *a, **kw):
+        o = self.o
+        o.calls['seq2seq'] += 1
+        seq, lens = np.asarray(input_seq, np.int32), np.asarray(seq_len, np.int32)
+        P, W, b = O.build_validity_mats(list(O.VQA_MODULE_NAMES))
+        o.enc = O.encoder_forward(o.weights, seq, lens, np.float64)
+        dec = O.decoder_forward(o.weights, o.enc, P, W, b, T_dec or o.dims.T_decoder, np.float64,
+                                use_gt_layout=use_gt_layout, gt_layout=gt_layout)
+        out = {k: torch.as_tensor(np.asarray(dec[k])) for k in
+               ('predicted_tokens', 'token_probs', 'neg_entropy', 'word_vecs')}
+        out['atts'] = torch.as_tensor(dec['atts'][..., 0])
+        out['log_seq_prob'] = torch.as_tensor(np.sum(np.log(dec['token_probs']), axis=0))
+        out['predicted_tokens'] = out['predicted_tokens'].to(torch.int32)
+        return out
+
+    def execute(self, packed, feat_c, word_vecs, reuse_buffers=True):
+        o = self.o
+        o.calls['execute'] += 1
+        n = packed.num_nodes
+        nodes = (_lib.Node * max(n, 1))()
+        _lib.check(_lib.lib().n2nmn_program_get_nodes(packed.handle, nodes, n))
+        feat = np.asarray(feat_c, np.float64)
+        wv = np.asarray(word_vecs, np.float64)
+        names = {1: '_Find', 3: '_Transform', 5: '_And', 13: '_Describe'}       # n2nmn_amd.vqa.VQA_OP_CODE
+
+        def expr(i):
+            nd = nodes[i]
+            e = dict(module=names[nd.op], time_idx=nd.time_idx, batch_idx=nd.batch_idx)
+            if nd.in0 >= 0:
+                e['input_0'] = expr(nd.in0)
+            if nd.in1 >= 0:
+                e['input_1'] = expr(nd.in1)
+            return e
+        scores = np.zeros((packed.num_rows, o.dims.num_choices))
+        for i in range(n):
+            if nodes[i].out_row >= 0:
+                scores[nodes[i].out_row] = O.eval_expr_vqa(o.weights, expr(i), feat, wv, o.dims.num_choices,
+                                                           np.float64)
+        return torch.as_tensor(scores)
+
+
+class OracleVQAEngine:
+    """n2nmn_amd.vqa.VQAEngine's interface as the models_vqa face uses it"""
+
+    def __init__(self, dims, device=0):
+        from n2nmn_amd.vqa import VQA_OP_CODE
+        assert VQA_OP_CODE == {'_Find': 1, '_Transform': 3, '_And': 5, '_Describe': 13}
+        self.dims = dims
+        self.engine = _OracleVQASeq2Seq(self)
+        self.weights = None
+        self.enc = None
+        self.calls = dict(seq2seq=0, execute=0)
+
+    def load_weights(self, weights):
+        self.weights = {k: np.asarray(v, np.float64) for k, v in weights.items()}
+
+    def features_with_coords(self, image_feat):
+        return O.add_spatial_coordinate_map(np.asarray(image_feat, np.float64))
+
+    def add_question_prior(self, scores):
+        return scores + torch.as_tensor(O.question_prior_net(self.weights, self.enc['states']))
+
+
+# ---- models_shapes: the double behind n2nmn_amd.models_shapes.NMN3ModelAtt (exp_shapes/eval_shapes.py) ------
+class OracleShapesEngine:
+    """the slice of Engine the models_shapes face uses (seq2seq, execute, fc, set_validity_tables,
+    load_weights with ENGINE-side names), computing with oracle/n2nmn_oracle_shapes.py"""
+
+    def __init__(self, dims, assembler, device=0, _parent=None):
+        from oracle import n2nmn_oracle_shapes as S
+        self.S = S
+        self.dims, self.assembler = dims, assembler
+        self.device = torch.device('cpu')
+        self.weights = None
+        self.calls = dict(seq2seq=0, execute=0, fc=0)
+        self.tables = None
+
+    def set_validity_tables(self, P, W, b):
+        self.tables = (np.asarray(P), np.asarray(W), np.asarray(b))
+
+    def _dev(self, x, dtype):
+        return None if x is None else torch.as_tensor(np.asarray(x)).to(dtype)
+
+    def load_weights(self, weights, strict=True):
+        # engine-side names -> the models_shapes names the oracle reads
+        S, w = self.S, {}
+        mv = S._MOD + 'module_variables/'
+        for k, v in weights.items():
+            v = np.asarray(v, np.float64)
+            if k.startswith(mv):
+                scope, rest = k[len(mv):].split('/', 1)
+                scope = scope.replace('ExistModule', 'AnswerModule')
+                if scope in ('FindModule', 'TransformModule', 'AnswerModule'):
+                    w[S._MOD + scope + '/' + scope + '/' + rest] = v
+            else:
+                w[k] = v
+        self.weights = w
+
+    def fc(self, A, W, bias=None, relu=False):
+        self.calls['fc'] += 1
+        out = np.asarray(A, np.float64) @ np.asarray(W, np.float64)
+        if bias is not None:
+            out = out + np.asarray(bias, np.float64)
+        return torch.as_tensor(np.maximum(out, 0) if relu else out)
+
+    def seq2seq(self, input_seq, seq_len, T_dec=None, use_gt_layout=False, gt_layout=None, *a, **kw):
+        self.calls['seq2seq'] += 1
+        assert self.tables is not None and not any(t.any() for t in self.tables), 'all-valid tables expected'
+        S = self.S
+        enc = O.encoder_forward(self.weights, np.asarray(input_seq, np.int32), np.asarray(seq_len, np.int32),
+                                np.float64)
+        dec = S.decoder_forward(self.weights, enc, T_dec, self.assembler.EOS_idx, np.float64, use_gt_layout,
+                                gt_layout)
+        out = dict(predicted_tokens=torch.as_tensor(dec['predicted_tokens']).to(torch.int32),
+                   word_vecs=torch.as_tensor(dec['word_vecs']), atts=torch.as_tensor(dec['atts'][..., 0]))
+        return out
+
+    def execute(self, packed, image_feat, word_vecs, reuse_buffers=True):
+        self.calls['execute'] += 1
+        S = self.S
+        n = packed.num_nodes
+        nodes = (_lib.Node * max(n, 1))()
+        _lib.check(_lib.lib().n2nmn_program_get_nodes(packed.handle, nodes, n))
+        names = {1: '_Find', 4: '_Transform', 5: '_And', 7: '_Answer'}
+        feat = np.asarray(image_feat, np.float64)
+        wv = np.asarray(word_vecs, np.float64)
+        mw = S._mw(self.weights)
+
+        def expr(i):
+            nd = nodes[i]
+            e = dict(module=names[nd.op], time_idx=nd.time_idx, batch_idx=nd.batch_idx)
+            if nd.in0 >= 0:
+                e['input_0'] = expr(nd.in0)
+            if nd.in1 >= 0:
+                e['input_1'] = expr(nd.in1)
+            return e
+        scores = np.zeros((packed.num_rows, self.dims.num_choices))
+        for i in range(n):
+            if nodes[i].out_row >= 0:
+                scores[nodes[i].out_row] = S.eval_expr(mw, expr(i), feat, wv, self.dims.num_choices, np.float64)
+        return torch.as_tensor(scores)

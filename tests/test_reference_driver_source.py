@@ -72,3 +72,78 @@ def test_eval_clevr_script_runs_unmodified_against_the_drop_in(tmp_path, monkeyp
     import make_eval_driver_trace as MT
     z = np.load(MT.OUT)
     assert MT.same(MT.pack_trace(rec, written, answers), {k: z[k] for k in z.files}) is None
+
+
+# ---- the reference's other two inference drivers (tests/eval_driver_more.py) -------------------------------
+def test_eval_vqa2_script_runs_unmodified_against_the_drop_in(tmp_path, monkeypatch):
+    """/root/reference/exp_vqa/eval_vqa2.py, every line of it (BASELINE.json configs[4]): models_vqa's
+    Assembler / NMN3Model (use_qpn, qpn_dropout, reduce_visfeat_dim keywords) / the VQA DataReader / tf names
+    answered by n2nmn_amd.models_vqa and n2nmn_amd.runtime; 53 synthetic questions over the reference's own
+    vocabulary files; the `scores_val[:, 0] = -1e10` step (:137) and the results json are the script's."""
+    import json
+    import eval_driver_more as EM
+    from n2nmn_amd import models_vqa
+    from oracle_engine import OracleVQAEngine
+    rec = EC.SessionRecorder(None, model_cls=models_vqa.NMN3Model, feature_fn=EM.vqa_feature_of,
+                             n_questions=EM.VQA_N)
+    g, data, words, answers, w = EM.run_vqa_script(tmp_path, monkeypatch, OracleVQAEngine, rec)
+    model, asm = g['nmn3_model_tst'], g['assembler']
+    assert model.vqa.calls == dict(seq2seq=2, execute=2)            # a batch of 50 and one of 3, two phases each
+    res = json.load(open(tmp_path / 'exp_vqa' / 'eval_outputs' / 'exp0' /
+                         'vqa_OpenEnded_mscoco_syn_exp0_00040000_results.json'))
+    assert [r['question_id'] for r in res] == [1000 + i for i in range(EM.VQA_N)]
+    # the oracle on the same questions, batch by batch like the reader delivers them
+    reader = models_vqa.DataReader(str(data / 'imdb_vqa_v2' / 'imdb_syn.npy'), shuffle=False, one_pass=True,
+                                   batch_size=50, T_encoder=26, T_decoder=13, assembler=asm,
+                                   vocab_question_file=str(data / 'vocabulary_vqa.txt'),
+                                   vocab_answer_file=str(data / 'answers_vqa.txt'))
+    w64 = {k: v.astype(np.float64) for k, v in w.items()}
+    want, valid = [], 0
+    for batch in reader.batches():
+        ref = O.forward_vqa(w64, batch, 13, len(answers), np.float64)
+        sc = ref['scores'].copy()
+        sc[:, 0] = -1e10                                             # eval_vqa2.py:137
+        want += [answers[p] for p in np.argmax(sc, axis=1)]
+        valid += int(np.sum(ref['validity']))
+    assert [r['answer'] for r in res] == want and '<unk>' not in want
+    summary = open(tmp_path / 'exp_vqa' / 'results' / 'exp0' / '00040000.syn.txt').read()
+    assert 'layout validity = %f (%d / %d)' % (valid / EM.VQA_N, valid, EM.VQA_N) in summary
+    # the committed recording (replayed over the HIP engine: tests/test_gpu_eval_driver_trace.py)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import make_eval_driver_trace as MT
+    z = np.load(MT.OUT_VQA)
+    fresh = MT.pack_trace(rec, [r['answer'] for r in res], answers, result_dtype=np.float32)
+    assert MT.same(fresh, {k: z[k] for k in z.files}) is None
+
+
+def test_eval_shapes_script_runs_unmodified_against_the_drop_in(tmp_path, monkeypatch):
+    """/root/reference/exp_shapes/eval_shapes.py, every line of it (BASELINE.json configs[0]) on the reference's
+    own `train.tiny` files: models_shapes' Assembler / NMN3ModelAtt (EOS_idx instead of an assembler, no
+    validity automaton), tf.global_variables_initializer / sess.run, the inline data plumbing with
+    np.random.seed(3).  Weights: seeded, token classifier fitted so that greedy layouts are valid
+    (eval_driver_more.shapes_weights)."""
+    import eval_driver_more as EM
+    from n2nmn_amd import models_shapes
+    from oracle import n2nmn_oracle_shapes as S
+    from oracle_engine import OracleShapesEngine
+    rec = EC.SessionRecorder(None, model_cls=models_shapes.NMN3ModelAtt, feature_fn=None)
+    g, w = EM.run_shapes_script(tmp_path, monkeypatch, OracleShapesEngine, rec)
+    model = g['nmn3_model']
+    assert model.engine.calls == dict(seq2seq=1, execute=1, fc=2)   # one batch of 64; the convnet = two GEMMs
+    d = S.load_split(EC.REF, 'train.tiny')
+    batch = dict(image_batch=(d['images_u8'] - d['image_mean']).astype(np.float32), text_seq_batch=d['text_seq'],
+                 seq_length_batch=d['seq_length'])
+    ref = S.forward({k: v.astype(np.float64) for k, v in w.items()}, batch)
+    assert np.array_equal(g['tokens'], ref['dec']['predicted_tokens'])
+    assert np.abs(g['scores_val'] - ref['scores']).max() < 1e-9
+    acc = float(np.mean(ref['validity'] & (np.argmax(ref['scores'], 1) == d['labels'])))
+    summary = open(tmp_path / 'exp_shapes' / 'results' / 'exp0' / '00040000.train.tiny.txt').read()
+    assert summary.splitlines()[0] == 'answer accuracy = %s on train.tiny' % acc
+    assert 'layout validity = 1.0' in summary and 'layout accuracy = 1.0' in summary
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import make_eval_driver_trace as MT
+    z = np.load(MT.OUT_SHAPES)
+    preds = np.concatenate([np.argmax(c['result'], axis=1) for c in rec.calls if c['fetch'] == 'scores'])
+    fresh = MT.pack_trace(rec, list(preds), None)
+    fresh['summary'] = np.frombuffer(summary.encode(), np.uint8)
+    assert MT.same(fresh, {k: z[k] for k in z.files}) is None
