@@ -312,7 +312,7 @@ def bench_vqa(args, dp, local_rank):
 
 
 def vqa_numbers(args, dp, local_rank, steps, warmup, profile=True, batches_per_pass=1, lstm_mode=None,
-                device_layouts=False):
+                device_layouts=False, eos_retire=False):
     """BASELINE.json configs[4]: models_vqa forward (exp_vqa/eval_vqa2.py:103-137) -- seq2seq with
     the 17742-word vocabulary and lstm_dim 1000, coordinate map, the 4-module network at map_dim
     1024 on 14x14x2048 features, question prior net -- batch 128 per GPU, ground-truth layouts from
@@ -356,9 +356,10 @@ def vqa_numbers(args, dp, local_rank, steps, warmup, profile=True, batches_per_p
     def run_steps(first, count):
         for i in range(first, first + count):
             if device_layouts:
-                eng.forward(batches[i % 3], use_gt_layout=True, gt_layout=gts_dev[i % 3], fetch=False)
+                eng.forward(batches[i % 3], use_gt_layout=True, gt_layout=gts_dev[i % 3], fetch=False,
+                            eos_retire=eos_retire)
             else:
-                eng.forward(batches[i % 3], use_gt_layout=True, gt_layout=gts[i % 3])
+                eng.forward(batches[i % 3], use_gt_layout=True, gt_layout=gts[i % 3], eos_retire=eos_retire)
 
     run_steps(0, warmup)
     elapsed = dp.timed(lambda: run_steps(warmup, steps),
@@ -519,7 +520,7 @@ def timed_blocks(dp, run, sync, min_window_s=0.3, max_repeats=15):
 
 def nesting_histogram(tokens, names):
     """how deep Transform / FindSameProperty nodes nest per layout (index = depth, value = layouts): the
-    staged walker lists up to four levels, deeper layouts go to its one-workgroup fall-back"""
+    staged walker lists up to WALK_HLEVELS = 24 levels, as many as the previous passes needed; deeper layouts go to its one-workgroup fall-back"""
     import numpy as np
     from n2nmn_amd.spec import MODULE_INPUT_NUM
     idx = {n: i for i, n in enumerate(names)}
@@ -1038,6 +1039,13 @@ def main():
             out['config5']['device_layouts']['passes']['kernels'] = c5dp['kernels'][:6]
         del c5dp
         torch.cuda.empty_cache()
+        if 'eos_retire' in out:      # the inference option on the models_vqa passes (mean layout 3.0 of T_dec = 13)
+            c5r = vqa_numbers(args, dp, local_rank, 4, 2, profile=False, batches_per_pass=8, eos_retire=True)
+            out['eos_retire']['config5_passes'] = {
+                'value': c5r['value'], 'ms_per_step': c5r['ms_per_step'],
+                'vs_full_decoder': round(c5r['value'] / out['config5']['passes']['value'], 4)}
+            del c5r
+            torch.cuda.empty_cache()
         if 'bf16x3' in out:          # the opt-in split-operand mode on the models_vqa passes (lstm_dim 1024)
             c5b = vqa_numbers(args, dp, local_rank, 4, 2, profile=False, batches_per_pass=8,
                               lstm_mode='throughput_bf16x3')

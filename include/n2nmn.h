@@ -192,14 +192,15 @@ typedef struct {
 /* skip word_vecs / neg_entropy / log_seq_prob (one launch): for inference through
  * n2nmn_walk_layouts with attention maps, which derives the text maps from atts directly */
 #define N2NMN_S2S_NO_WORD_VECS 1
-/* Inference option for teacher-forced passes (use_gt_layout, >= 128 rows, a throughput mode, together
- * with N2NMN_S2S_NO_WORD_VECS): retire a row from the decoder at its layout's first <eos>.  Decoder step
+/* Inference option for teacher-forced passes (use_gt_layout, >= 128 rows, a throughput mode): retire a row
+ * from the decoder at its layout's first <eos>.  Decoder step
  * t >= len(layout) of a row feeds nothing exp_clevr/eval_clevr.py:103-135 fetches -- the layout is read
  * up to its first <eos> (models_clevr/nmn3_assembler.py:153-170) and a module's text attention is the
  * step of its own token (models_clevr/nmn3_modules.py:53-57) -- so the LSTM cells, q, and the attention
  * run only over the (row, step) pairs in front of it: rows are ordered by layout length and step t
  * covers the row blocks still alive (the encoder's length trick).  predicted_tokens are complete;
- * atts / token_probs hold the live (row, step) pairs only.  The full outputs (all T_dec steps; training
+ * atts / token_probs / word_vecs hold the live (row, step) pairs only, neg_entropy / log_seq_prob (sums
+ * over all steps) are not meaningful.  The full outputs (all T_dec steps; training
  * and the debug fetches need them) come from a call without the flag -- n2nmn_decoder_forward on the
  * same context recomputes them from the encoder results it holds.  Where the preconditions do not hold
  * the flag is ignored. */

@@ -589,10 +589,10 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
   // <eos>.  Preconditions: an inference pass of >= 128 rows in a throughput mode (the tile kernels take the
   // rows in ranked order and a device-side live count), nothing fetched that needs the dead steps.
   a.q = c->qbuf; a.out = c->dec_h1_all; a.gt = io->gt_layout; a.Td = Td;     // (dec_question_supported reads these)
-  const bool retire = batched && (io->flags & N2NMN_S2S_EOS_RETIRE) && (io->flags & N2NMN_S2S_NO_WORD_VECS) &&
+  const bool retire = batched && (io->flags & N2NMN_S2S_EOS_RETIRE) &&
                       !c->rec && !io->drop_dec0 && !io->token_scores &&
                       lstm_wide(c) >= 2 && N >= 128 && Td <= 63 && root(c)->have_token_ops &&
-                      dec_question_supported(a, Td);
+                      dec_len_supported(a, Td);
   int kmax = Td;                      // last launch of the pipelined loop
   std::vector<int> dact_host;         // rows with layout length > t (host copy of the lengths given)
   if (retire) {
@@ -1265,7 +1265,12 @@ int n2nmn_ctx_create(const n2nmn_dims* dims, int device, n2nmn_ctx** out) {
   c->max_nodes = d.N * std::max(d.T_decoder, 4);
   c->max_text = c->max_nodes;
   c->max_pool = c->max_nodes;
-  c->max_tab = c->max_nodes * 28 + 4096;      // A: 16 + B: 8 + C: 1 + text-map groups: 10/8 ints per node at most
+  // work tables per node at most: stage A 4 ints x FIND_PARTS (Find epilogues are split in row parts) = 16,
+  // stage B 2 ints x POOL_PARTS / ... = 8, stage C 1, text-map groups (2 + TM_GROUP) / TM_GROUP <= 2: 28
+  // with these constants (sched_kernel flags an overflow as validity 0, never as silent zero logits)
+  static_assert(4 * FIND_PARTS <= 16 && 2 * POOL_PARTS <= 16 && (2 + TM_GROUP + TM_GROUP - 1) / TM_GROUP <= 3,
+                "max_tab: 28 ints per node no longer bound the work tables");
+  c->max_tab = c->max_nodes * 28 + 4096;
   c->big_heads = (size_t)d.map_dim * d.num_choices > 65536;
   c->big_vocab = d.num_vocab_txt > 4096;
   int rc = finish_create(c, nullptr);

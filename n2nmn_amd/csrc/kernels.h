@@ -210,12 +210,13 @@ struct DecStepArgs {
   float* scores;           // [steps][N][V] or nullptr
   int32_t* next_idx;       // [N] row of the decoder x-table for the next step (= token) or nullptr
   float* ctx_out;          // [steps][N][L] context vectors kept for the backward pass, or nullptr
-  // eos_retire (teacher-forced passes, dec_attn_question_kernel only): live decoder steps per question;
+  // eos_retire (teacher-forced passes: dec_attn_question_kernel / dec_attn_multi_kernel): live decoder steps per question;
   // steps at or past it get their token from `gt` and nothing else.  nullptr: every step of every question
   const int32_t* dec_len;  // [N]
 };
 // can launch_dec_attn serve this launch with dec_attn_question_kernel (the kernel that honours dec_len)?
 bool dec_question_supported(const DecStepArgs& a, int nsteps);
+bool dec_len_supported(const DecStepArgs& a, int nsteps);
 // eos_retire helpers (kernels_seq2seq.hip): layout lengths from the tokens; state rows gathered by `perm`
 void launch_dec_len(const int32_t* tokens, const int32_t* token_op, int V, int T_dec, int N,
                     int32_t* dec_len, hipStream_t s);

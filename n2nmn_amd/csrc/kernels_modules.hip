@@ -788,7 +788,13 @@ __global__ __launch_bounds__(SCHED_THREADS) void sched_kernel(SchedArgs a) {
       }
   }
   __syncthreads();
-  if (!fits) return;
+  if (!fits) {
+    // the tables do not fit (unreachable with the context's worst-case sizing, capi.cpp max_tab): nothing is
+    // launched, so no question of the launch has an answer -- say so instead of returning zero logits as valid
+    if (a.validity)
+      for (int n = tid; n < a.N; n += SCHED_THREADS) a.validity[n] = 0;
+    return;
+  }
   // ---- pass 2: place ----------------------------------------------------------------------------------------
   for (int n = tid; n < a.N; n += SCHED_THREADS) {
     if (a.N > SCHED_THREADS) sched_decode(a, n, q);       // (one question per thread: still in registers)

@@ -835,9 +835,18 @@ __global__ __launch_bounds__(256) void dec_attn_multi_kernel(DecStepArgs a, int 
   float* es = ctxp + (size_t)nsplit * TS * L;       // [TS][Tp]
   float* red = es + (size_t)TS * Tp;                // [NW][TS][MAXV]
   const int n = blockIdx.x, ts0 = blockIdx.y * TS;
-  const int nts = min(TS, nsteps - ts0);
+  int nts = min(TS, nsteps - ts0);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int len = min(max(a.seq_len[n], 0), T);
+  if (a.dec_len) {
+    // eos_retire (DecStepArgs::dec_len): the steps from the layout's first <eos> on only get their (given)
+    // token; a step group that lies behind it entirely leaves at once
+    const int live = min(nsteps, max(a.dec_len[n], 0));
+    for (int j = max(live - ts0, 0) + tid; j < nts; j += NT)
+      a.tokens[(size_t)(ts0 + j) * N + n] = a.gt[(size_t)(ts0 + j) * N + n];
+    nts = min(nts, live - ts0);
+    if (nts <= 0) return;
+  }
 
   for (int i = tid; i < TS * L; i += NT) {
     const int j = i / L, k = i - j * L;
@@ -1679,6 +1688,13 @@ void launch_gather_state(const float* const src[4], float* const dst[4], const u
   for (int i = 0; i < 2; ++i) { g.srcb[i] = srcb ? srcb[i] : nullptr; g.dstb[i] = dstb ? dstb[i] : nullptr; }
   g.perm = perm; g.N = N; g.L = L; g.R = R;
   hipLaunchKernelGGL(gather_state_kernel, dim3((N + 63) / 64, std::min(32, std::max(1, L / 16))), dim3(256), 0, s, g);
+}
+
+// teacher-forced launches whose attention kernel honours DecStepArgs::dec_len: dec_attn_question_kernel
+// (lstm_dim 512) or dec_attn_multi_kernel (launch_dec_attn's choice for every other lstm_dim % 256 == 0)
+bool dec_len_supported(const DecStepArgs& a, int nsteps) {
+  return dec_question_supported(a, nsteps) ||
+         (nsteps > 1 && a.L % 256 == 0 && a.L <= 1024 && !a.uni && !a.forced && a.use_gt);
 }
 
 bool dec_question_supported(const DecStepArgs& a, int nsteps) {

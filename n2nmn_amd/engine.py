@@ -184,7 +184,7 @@ class Engine:
         (enc0, dec0) multiplier tensors [T, N, L] / [T_dec, N, L] for the output of LSTM layer 0
         (n2nmn_seq2seq_io.drop_enc0 / drop_dec0), either may be None.  seq_len_host (optional): a
         host int32 copy of seq_len (n2nmn_seq2seq_io.seq_length_host: per-step tile choice).
-        eos_retire (inference, teacher-forced passes of >= 128 rows in a throughput mode, word_vecs=False):
+        eos_retire (inference, teacher-forced passes of >= 128 rows in a throughput mode):
         N2NMN_S2S_EOS_RETIRE -- rows leave the decoder at their layout's first <eos>; predicted_tokens are
         complete, atts / token_probs hold the live (row, step) pairs only (call again with phase='decoder'
         and eos_retire=False for every step).  gt_len_host: host int32 [N] layout lengths (tokens in front
@@ -248,9 +248,7 @@ class Engine:
             io.seq_length_host = lens_host.ctypes.data
         glen_host = None
         if eos_retire:
-            if word_vecs:
-                raise ValueError('eos_retire needs word_vecs=False (the walker derives text maps from atts)')
-            io.flags |= 2        # N2NMN_S2S_EOS_RETIRE
+            io.flags |= 2        # N2NMN_S2S_EOS_RETIRE (word_vecs: rows of live steps only; no neg_entropy / log_seq_prob)
             if gt_len_host is not None:
                 glen_host = np.ascontiguousarray(np.asarray(gt_len_host), np.int32)
                 if glen_host.shape != (N,):

@@ -208,7 +208,8 @@ class VQAEngine:
         return scores
 
     def forward(self, batch, use_gt_layout: bool = False, gt_layout=None, forced_tokens=None,
-                use_qpn: bool = True, host_assemble: bool = False, fetch: bool = True):
+                use_qpn: bool = True, host_assemble: bool = False, fetch: bool = True,
+                eos_retire: bool = False):
         """phase 1 -> phase 2 (+ question prior).  Returns (scores device tensor [N, num_choices], tokens,
         validity) -- scores = scores_nmn + scores_qpn (models_vqa/nmn3_model.py:106-114); the eval
         script's `scores[:, 0] = -1e10` is the caller's.
@@ -222,15 +223,21 @@ class VQAEngine:
         With use_gt_layout and a HOST gt_layout (numpy, as the reference's data reader delivers it,
         util/vqa_train/data_reader.py) the predicted tokens ARE the ground-truth layout
         (models_vqa/nmn3_netgen_att.py: teacher forcing), so the program is assembled from the host
-        copy up front and the call has no host synchronisation either."""
+        copy up front and the call has no host synchronisation either.
+
+        eos_retire (teacher-forced passes of >= 128 rows in a throughput mode): N2NMN_S2S_EOS_RETIRE -- rows
+        leave the decoder at their layout's first <eos> (include/n2nmn.h); scores / tokens / validity as the
+        full decoder's."""
         e = self.engine
         known = use_gt_layout and isinstance(gt_layout, np.ndarray) and forced_tokens is None
         if known:
             tokens = np.ascontiguousarray(gt_layout, np.int32)
             packed, validity = self.assembler.assemble_packed(tokens)
             gt_dev = e.upload_i32(tokens)
+        retire = bool(eos_retire) and use_gt_layout and forced_tokens is None
         s2s = e.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], self.dims.T_decoder,
-                        use_gt_layout, gt_dev if known else gt_layout, None, forced_tokens)
+                        use_gt_layout, gt_dev if known else gt_layout, None, forced_tokens,
+                        eos_retire=retire, gt_len_host=e.layout_lengths(tokens) if (retire and known) else None)
         feat_c = self.features_with_coords(batch['image_feat_batch'])
         if known or host_assemble:
             if not known:

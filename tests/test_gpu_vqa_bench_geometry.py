@@ -158,3 +158,34 @@ def test_throughput_pass_of_8_client_batches(setup, mode):
             dec = O.decoder_forward(w, enc, P, Wv, bv, d.T_decoder, np.float64)
             _check_greedy_tokens(d, tokens[:, c][:, diff], dec, 'pass, slot %d' % k)
             _check_greedy_tokens(d, tok1[:, diff], dec, 'alone, slot %d' % k)
+
+
+def test_eos_retire_on_a_models_vqa_pass(setup):
+    """N2NMN_S2S_EOS_RETIRE at lstm_dim 1024 (dec_attn_multi_kernel honours the live steps; the level path
+    reads word_vecs of live steps only): a pass of 4 x 128 rows with host layouts (K-split tail tiles) and with
+    device layouts (every launch finds its live rows on the device) equals the full decoder's pass."""
+    eng, d, w = setup
+    K = 4
+    big = vqa.VQADims(N=K * CLIENT)
+    eb = vqa.VQAEngine(big)
+    eb.load_weights(w)
+    eb.engine.set_mode('throughput')
+    dev = eb.engine.device
+    parts = [_part(d, eng, 300 + k) for k in range(K)]
+    cat = dict(input_seq_batch=np.concatenate([p['input_seq_batch'] for p, _ in parts], 1),
+               seq_length_batch=np.concatenate([p['seq_length_batch'] for p, _ in parts]),
+               image_feat_batch=torch.as_tensor(np.concatenate([p['image_feat_batch'] for p, _ in parts])).to(dev))
+    gt = np.ascontiguousarray(np.concatenate([g for _, g in parts], 1))
+    full, tok, val = eb.forward(cat, use_gt_layout=True, gt_layout=gt)
+    full = t2n(full).copy()
+    assert val.all() and np.array_equal(tok, gt)
+    got, tok2, val2 = eb.forward(cat, use_gt_layout=True, gt_layout=gt, eos_retire=True)
+    assert val2.all() and np.array_equal(tok2, gt)
+    assert_close('retired pass (host layouts) vs full', t2n(got), full, 2e-5)
+    gd, tok3, val3 = eb.forward(cat, use_gt_layout=True, gt_layout=torch.as_tensor(gt).to(dev), eos_retire=True)
+    assert np.asarray(val3).all() and np.array_equal(np.asarray(tok3), gt)
+    assert_close('retired pass (device layouts) vs full', t2n(gd), full, 2e-5)
+    rows = [0, 127, 128, 300, 511]
+    sub, gts = _rows(dict(cat, image_feat_batch=np.concatenate([p['image_feat_batch'] for p, _ in parts])), gt, rows)
+    ref = O.forward_vqa(w, sub, d.T_decoder, d.num_choices, np.float64, use_gt_layout=True, gt_layout=gts)
+    assert_close('retired pass vs oracle, rows %s' % rows, t2n(got)[rows], ref['scores'], TOL)
