@@ -92,7 +92,7 @@ PMC_KERNEL = {'lstm_step': 'lstm_tile_kernel', 'dec_attn': 'dec_attn_question_ke
               'gemm_pkn': 'gemm_dma_kernel', 'gemm_pk': 'gemm_pk', 'att_ops': 'att_ops_kernel',
               'textmap': 'walk_textmap_kernel', 'heads': 'heads_kernel', 'word_vecs': 'word_vecs_kernel',
               # the staged walker: Transform / FindSameProperty jobs + the per-question rest + the fall-back launch
-              'walk(': ('walk_fsppool_kernel', 'walk_heavy_kernel', 'walk_light_kernel', 'walk_kernel'),
+              'walk(': ('walk_heavy_kernel', 'walk_fspepi_kernel', 'walk_light_kernel', 'walk_kernel'),
               'lstm_bwd_step': 'lstm_bwd_step_kernel', 'gemm_tn': 'gemm_tn_kernel',
               'optimiser': 'adam_kernel'}
 
@@ -935,7 +935,7 @@ def main():
             us_walk = eng.walk_replay_us(0, 20)
             walk_bytes = wrow[0]['achieved'] * 1e9 * wrow[0]['avg_us'] * 1e-6 if wrow else 0.0
             frow = [r for r in rows if r['kernel'].startswith('walk_find')]
-            att.append({'kernel': 'walker = walk_fsppool + walk_heavy + walk_light + fall-back walk_kernel launches (%sfeatures and '
+            att.append({'kernel': 'walker = walk_heavy + walk_fspepi + walk_light (+ the fall-back walk_kernel when the layouts are not known on the host) launches (%sfeatures and '
                                   'map under FindSameProperty%s; everything that depends on the tree)' %
                                   ('' if frow else 'conv_image maps under every Find-type node, ',
                                    '' if deferred else ' / Describe / SameProperty'),
@@ -997,7 +997,7 @@ def main():
                 'byte_weighted': {'bytes': round(path_bytes), 'us': round(path_us, 2),
                                   'achieved': round(path_bytes / path_us / 1e3, 1), 'unit': 'GB/s',
                                   'frac': round(path_bytes / path_us / 1e3 / HBM_PEAK_GBS, 4),
-                                  'kernels': 'walk_pool + walk_find + walker (walk_fsppool + walk_heavy + walk_light + fall-back walk_kernel)'},
+                                  'kernels': 'walk_pool + walk_find + walker (walk_heavy + walk_fspepi + walk_light)'},
                 'measured': 'each kernel of the last pass replayed back to back inside one HIP event '
                             'pair, average per launch (inputs of one pass stay L2/MALL-warm across the '
                             'replays: see profiles/ for the cold rocprofv3 numbers)',

@@ -334,8 +334,8 @@ int n2nmn_walk_set_front_end(n2nmn_ctx *ctx, int mode);
  * of >= 128 questions by default), the tree-dependent rest leaves the one-workgroup-per-question walker
  * as well: walk_tmap_kernel decodes every layout once (nmn3_assembler.py:153-222) and lists the
  * _Transform / _FindSameProperty nodes by nesting level (level = such nodes below it in its own subtree);
- * per level, walk_heavy_kernel runs every _Transform node as a job of its own (two workgroups per CU, the
- * 5x5 convolution on the matrix cores) and every _FindSameProperty node as 8 channel parts of its soft-max
+ * per level, walk_heavy_kernel runs every _Transform node as two jobs (pixel halves, four workgroups per CU,
+ * the 5x5 convolution on the matrix cores) and every _FindSameProperty node as 8 channel parts of its soft-max
  * pooling + fc_att share, and walk_fspepi_kernel finishes the _FindSameProperty maps (8 row parts per node
  * over the operator's conv_image map); walk_light_kernel (one small workgroup per question) evaluates the
  * remaining And / Or / Filter / Scene nodes and the answer operator (nmn3_modules.py:60-72,113-132,218-400)
@@ -351,6 +351,14 @@ int n2nmn_walk_set_staged(n2nmn_ctx *ctx, int mode);
  * levels >= 1: exactly that many levels in every pass (1 .. 24; T_dec - 1 covers every layout) -- the route
  * of a question depends on its own layout only and repeated passes return the same bits. */
 int n2nmn_walk_set_levels(n2nmn_ctx *ctx, int levels);
+/* A promise for the NEXT n2nmn_walk_layouts / n2nmn_execute_tokens call of this context only: no layout of
+ * that pass nests _Transform / _FindSameProperty deeper than `bound` levels (0: none has such a node).  A
+ * caller that holds the layouts on the host -- ground-truth layouts from the data reader,
+ * util/clevr_train/data_reader.py:74-82 -- knows this before the pass; the staged walker then launches
+ * exactly max(bound, 1) levels and NO fall-back walker (an empty launch of it is 4 - 5 us of a 1024-question
+ * pass), whatever n2nmn_walk_set_levels says.  A layout that breaks the promise is reported INVALID
+ * (validity 0, zero logits), never evaluated wrongly.  bound = -1 withdraws the promise. */
+int n2nmn_walk_set_nesting_bound(n2nmn_ctx *ctx, int bound);
 /* Phase 2 straight from DEVICE tokens (no token fetch, no host assembly): replaces Assembler.assemble +
  * td.Compiler.build_feed_dict + the second partial_run (exp_clevr/eval_clevr.py:121-132,
  * exp_vqa/eval_vqa2.py:103-137).  n2nmn_conv_image(FIND | FSP gated by tokens), then

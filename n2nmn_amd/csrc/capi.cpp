@@ -1662,6 +1662,12 @@ int n2nmn_walk_set_levels(n2nmn_ctx* c, int levels) {
   return N2NMN_OK;
 }
 
+int n2nmn_walk_set_nesting_bound(n2nmn_ctx* c, int bound) {
+  N2_REQUIRE(c && bound >= -1 && bound <= WALK_MAX_T, N2NMN_EINVAL, "walk_set_nesting_bound: -1 (none) or 0 .. 32");
+  c->walk_nesting_bound = bound;
+  return N2NMN_OK;
+}
+
 int n2nmn_walk_supported(const n2nmn_ctx* c) {
   if (!c) return 0;
   const n2nmn_dims& d = c->d;
@@ -1703,12 +1709,14 @@ int n2nmn_conv_image(n2nmn_ctx* c, const float* image_feat, int N, int which,
   return check_launch("conv_image");
 }
 
-// The staged walker's launches between walk_find and the fall-back walker: per nesting level stage A of the
-// FindSameProperty nodes (pooling + fc_att shares), then the Transform nodes together with stage B (the map
-// epilogues); the light rest of every question at the end.  (One launch with device-side dependencies
-// between work items was built and measured slower: tools/rejected/walk_stage_single_launch.hip.txt.)
+// The staged walker's launches between walk_find and the fall-back walker: per nesting level walk_heavy_kernel
+// (stage A of the FindSameProperty nodes -- pooling + fc_att shares -- and the Transform halves), then
+// walk_fspepi_kernel (stage B: the FindSameProperty map epilogues); the light rest of every question at the
+// end.  (Built and measured slower: one launch with device-side dependencies between work items,
+// tools/rejected/walk_stage_single_launch.hip.txt; level 0 at the tail of the Find launch,
+// tools/rejected/walk_front_kernel.diff.txt.)
 static void walk_staged_launches(const ModuleWeights& w, WalkArgs& a, hipStream_t s) {
-  for (int lv = 0; lv < a.hlevels; ++lv) { a.hlevel = lv; launch_walk_fsppool(w, a, s); launch_walk_heavy(w, a, s); }
+  for (int lv = 0; lv < a.hlevels; ++lv) { a.hlevel = lv; launch_walk_heavy(w, a, s); launch_walk_fspepi(w, a, s); }
   a.hlevel = 0;
   launch_walk_light(w, a, s);
 }
@@ -1777,7 +1785,7 @@ int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int
   const int pf_env = c->walk_pre_find;
   const bool pre = use_table && (pf_env < 0 ? K * N >= 128 : pf_env > 0);
   // staged walker: with both of the above the tree-dependent work leaves the one-workgroup-per-question
-  // chain too (kernels_walk.hip: walk_heavy_kernel / walk_light_kernel); N2NMN_WALK_STAGED=0 keeps the
+  // chain too (kernels_walk.hip: walk_heavy_kernel / walk_fspepi_kernel / walk_light_kernel); N2NMN_WALK_STAGED=0 keeps the
   // round-3 walker
   static const bool staged_env = [] { const char* e = getenv("N2NMN_WALK_STAGED"); return !e || atoi(e) != 0; }();
   const bool staged = pre && a.defer_pool && staged_env && c->walk_staged != 0 &&
@@ -1806,7 +1814,14 @@ int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int
     const int want = c->walk_levels > 0 ? c->walk_levels : std::max(seen, c->walk_hint_prev);
     c->walk_hint_prev = seen;
     a.hlevels = std::min(std::max(want, 1), WALK_HLEVELS);
+    // the caller knows this pass's layouts (host copies of ground-truth layouts): exactly as many levels
+    // as they nest, and no launch of the fall-back walker (an empty one costs 4 - 5 us of the pass)
+    if (c->walk_nesting_bound >= 0 && c->walk_nesting_bound <= WALK_HLEVELS) {
+      a.hlevels = std::max(c->walk_nesting_bound, 1);
+      a.no_fallback = 1;
+    }
   }
+  c->walk_nesting_bound = -1;     // (a promise covers one call)
   if (pre) {
     a.pre_find = 1;
     {
@@ -1823,7 +1838,7 @@ int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int
   {
     ProfScope ps(c, F_WALK, 0.0, 0.0, s);     // work filled in from the device counters
     if (a.staged) walk_staged_launches(w, a, s);
-    launch_walk(w, a, s);                     // staged: only the questions listed as nested too deep
+    if (!a.no_fallback) launch_walk(w, a, s); // staged: only the questions listed as nested too deep
   }
   c->last_walk = a;
   c->have_last_walk = true;
@@ -1884,7 +1899,7 @@ int n2nmn_debug_walk_replay(n2nmn_ctx* c, int which, int iters, double* us_avg, 
       if (t.staged) {
         walk_staged_launches(w, t, s);
       }
-      launch_walk(w, t, s);
+      if (!t.no_fallback) launch_walk(w, t, s);
     }
     else if (which == 1) launch_walk_pool(w, a, s);
     else if (which == 2) launch_walk_heads(w, a, s);
@@ -1893,9 +1908,9 @@ int n2nmn_debug_walk_replay(n2nmn_ctx* c, int which, int iters, double* us_avg, 
       WalkArgs t = a;
       t.plist = nullptr; t.hlevel = 0;
       if (which == 5) launch_walk_heavy(w, t, s);
-      else if (which == 6) launch_walk_fsppool(w, t, s);
+      else if (which == 6) launch_walk_fspepi(w, t, s);
       else if (which == 7) launch_walk_light(w, t, s);
-      else launch_walk(w, t, s);
+      else if (!t.no_fallback) launch_walk(w, t, s);
     }
     else { WalkArgs t = a; t.T_enc = c->last_walk_T_enc; t.staged = 0; launch_walk_tmap(w, t, s); }   // (no list appends)
   };

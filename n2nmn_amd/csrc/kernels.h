@@ -320,7 +320,7 @@ struct WalkBatch {
   // walk_tmap_kernel (which becomes the pass's "plan" step), read by walk_heavy / walk_light
   struct WalkProg* prog;   // [N]
   // FindSameProperty as chip-wide stages: the WALK_POOL_PARTS shares of fc_att(pooled features) of node
-  // (n, t), written by stage A (walk_fsppool_kernel), summed by stage B (an item of walk_heavy_kernel)
+  // (n, t), written by stage A (items of walk_heavy_kernel), summed by stage B (walk_fspepi_kernel)
   float* fpart;            // [N][T][WALK_POOL_PARTS][Mp]
 };
 // One question's decoded layout (nmn3_assembler.py:153-222 on the device).  op: n2nmn_op of node t
@@ -366,6 +366,7 @@ struct WalkArgs {
   int hoff[WALK_HLEVELS + 1];
   int hlevels, hlevel;     // levels listed by this pass's plan (deeper nesting: fall-back list); level of this launch
   int32_t* hint;           // host-mapped word: deepest nesting of the pass (written once, by walk_fcatt_kernel)
+  int no_fallback;         // the host vouches that no layout nests deeper than hlevels: no fall-back launch follows
   // deferred pooling (defer_pool): the questions whose root pools, listed per operator by whoever
   // writes pjob (walk_light_kernel / walk_kernel): plist[0 .. pcap) Describe, plist[pcap ..) SameProperty
   int32_t* plist;
@@ -389,7 +390,7 @@ void launch_walk(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
 void launch_walk_tmap(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
 void launch_walk_find(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
 void launch_walk_heavy(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
-void launch_walk_fsppool(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
+void launch_walk_fspepi(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
 void launch_walk_light(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
 void launch_walk_pool(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);
 void launch_walk_heads(const ModuleWeights& w, const WalkArgs& a, hipStream_t s);

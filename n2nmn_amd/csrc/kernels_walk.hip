@@ -1121,6 +1121,9 @@ __global__ __launch_bounds__(FT) void walk_tmap_kernel(ModuleWeights w, WalkArgs
       // level; deeper layouts go to the one-workgroup walker (and the host, told through cnt[11], launches
       // more levels for the passes that follow)
       P.fallback = P.valid && deepest > max(a.hlevels, 1);
+      // (n2nmn_walk_set_nesting_bound: the host vouched that this cannot happen and launches no fall-back
+      // walker; a layout that breaks the promise is reported invalid -- zero logits -- not served wrongly)
+      if (a.no_fallback && P.fallback) { P.valid = 0; P.fallback = 0; }
       if (a.staged && deepest >= 2) atomicMax(a.cnt + 5, deepest);
     }
   }
@@ -1169,7 +1172,7 @@ __global__ __launch_bounds__(FT) void walk_tmap_kernel(ModuleWeights w, WalkArgs
   }
   // the chip-wide job lists of the staged walker (WalkArgs::staged) -- last, so that the returning
   // atomics (an L2 round trip each) delay nothing: one list per (nesting level, operator); a level's
-  // FindSameProperty jobs (the long ones) are handed out first by walk_heavy_kernel
+  // FindSameProperty jobs are handed out first by walk_heavy_kernel
   if (a.staged && tid == 0 && P.valid) {
     if (P.fallback) {
       a.fblist[atomicAdd(a.cnt + 1, 1)] = q;
@@ -1638,9 +1641,10 @@ __device__ __forceinline__ void eval_light_ops(int tid, const WalkProg& P, int l
 // FindSameProperty (nmn3_modules.py:134-183) as chip-wide stages (round 5).  One workgroup per node ran
 // its three dependent streams -- 307 KB feature pool, 512 KB fc_att weights, 154 KB map epilogue -- at ONE
 // CU's pace (17-46 GB/s: 31.6 us per node, 104 of them per 1024 questions set the length of the launch).
-// Now a node is WALK_POOL_PARTS workgroups of stage A (walk_fsppool_kernel, launched first: it needs only the
-// Find / Filter logits) and as many stage-B items inside walk_heavy_kernel, next to the level's Transform
-// nodes (the matrix-core-bound Transform halves and the stream-bound epilogues share the CUs):
+// Now a node is WALK_POOL_PARTS stage-A items in the level's walk_heavy_kernel launch (next to the level's
+// Transform halves: both need only maps of lower levels, and the stream-bound pooling parts and the
+// matrix-core-bound Transform halves share the CUs) and WALK_FIND_PARTS stage-B items in the
+// walk_fspepi_kernel launch behind it:
 //   A (fsp_pool_rest): channel part `part` of the soft-max pooling (:170-172) -- 38 KB of the feature map,
 //     every load in flight before the plan of the question has even arrived -- and, because fc_att is
 //     linear (:173-176), that part's share of it: pooled[part] . W_att[rows of the part] -> fpart[n][t][part]
@@ -1912,43 +1916,20 @@ __device__ __forceinline__ void fsp_pool_item(int tid, const ModuleWeights& w, c
   fsp_pool_rest(tid, w, a, B, n, t, part, arena + (size_t)i0 * HWp, FL, pp, sa0, scr);
 }
 
-// Stage A of the FindSameProperty nodes of a level: walk_fsppool_kernel, WALK_POOL_PARTS workgroups per
-// node (persistent over the level's list).  Launched before the level's walk_heavy_kernel.
-__global__ __launch_bounds__(HT, 4) void walk_fsppool_kernel(ModuleWeights w, WalkArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  __shared__ __attribute__((aligned(16))) WalkProg P;
-  const int HWp = a.HWp, T = a.T;
-  float* arena = smem;                                 // [T][HWp]
-  float* pp = arena + (size_t)T * HWp;                 // [D / POOL_PARTS] pooled features of the part
-  float* sa0 = pp + a.D / POOLP;                       // [HWp]
-  float* scr = sa0 + HWp;                              // [4 * HT]
-  const int lv = a.hlevel;
-  const int cfs = lv == 0 ? 2 : 7 + 2 * lv;
-  const int cap = (a.hoff[lv + 1] - a.hoff[lv]) / 2;
-  const int nfsp = min(a.cnt[cfs], cap);
-  const int32_t* jfs = a.hjobs + a.hoff[lv] + cap;
-  for (int j = blockIdx.x; j < POOLP * nfsp; j += gridDim.x) {
-    // (an opaque copy per item: the per-thread addresses of one item's 18 loads must not be hoisted out of
-    // the loop, where they would stay live across everything else -- see walk_kernel)
-    int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));
-    const int job = jfs[j / POOLP], part = j % POOLP;
-    const int q = job >> 8, t = job & 0xff;
-    if (q < 0 || q >= a.K * a.N || t >= T || t < 1) continue;        // (a stale list entry)
-    fsp_pool_item(tid, w, a, P, q, t, part, lv, arena, pp, sa0, scr);
-  }
-}
-
-// Items of a level, 4 waves each: two per Transform node (pixel halves: a node's 2.3 MFLOP of fp32 MFMA are
-// 9 k clocks of one CU's matrix pipe, and 300 nodes on 256 CUs leave a fifth of the CUs with two of them;
-// 600 half nodes spread), then WALK_FIND_PARTS stage-B items per FindSameProperty node (their stage A ran in
-// the launch before).  <= 128 VGPRs and 20 KB of LDS: four items per CU, so one item's dependent chain (list
-// entry -> plan -> operators) runs under the others' MFMAs / map streams.  Everything an item reads that
-// does not depend on the plan -- the attention rows in front of the node, its text map, the rows of the
-// conv_image map -- is requested before the plan has arrived.
-// (launch bounds: 4 waves per SIMD; one instantiation per (kernel size, pixel tiles per wave, map width) so
-// that no variant pays for another's registers)
-template <int KS, int PTW, int CI>
+// First launch of a nesting level: walk_heavy_kernel, a persistent grid (4 workgroups of 4 waves per CU) over
+// WALK_POOL_PARTS stage-A items per FindSameProperty node of the level, then two items per Transform node
+// (pixel halves: a node's 2.3 MFLOP of fp32 MFMA are 9 k clocks of one CU's matrix pipe; 600 half nodes
+// spread where 300 nodes left a fifth of the CUs with two).  Everything in it needs only the Find / Filter
+// logits and the maps of lower levels.  <= 128 VGPRs and 20 KB of LDS per item: one item's dependent chain
+// (list entry -> plan -> operators) runs under the others' MFMAs / feature streams, and everything an item
+// reads that does not depend on the plan -- the attention rows in front of the node, its text map, the
+// features and fc_att weights of its part -- is requested before the plan has arrived.
+// Order and split were measured (profiles/r05_notes.md): with the Transform halves in the SECOND launch next
+// to stage B (round 5's first arrangement) the level cost 30.7 us of back-to-back replays, this way 28.8;
+// Transform halves in front of the stage-A items 29.4.
+// (launch bounds: 4 waves per SIMD; one instantiation per (kernel size, pixel tiles per wave) so that no
+// variant pays for another's registers)
+template <int KS, int PTW>
 __global__ __launch_bounds__(HT, 4) void walk_heavy_kernel(ModuleWeights w, WalkArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ __attribute__((aligned(16))) WalkProg P;
@@ -1957,30 +1938,51 @@ __global__ __launch_bounds__(HT, 4) void walk_heavy_kernel(ModuleWeights w, Walk
   S.arena = smem;                                      // [T][HWp]
   S.tml = S.arena + (size_t)T * a.HWp;                 // [Mp] text map of the node
   S.twl = S.tml + a.Mp;                                // [Mp] text map (.) w_e
-  S.pp = nullptr; S.sa0 = nullptr;
-  S.scr = S.twl + a.Mp;                                // Transform's padded map + fold buffer
+  S.pp = S.twl + a.Mp;                                 // [D / POOL_PARTS] pooled features of the part
+  S.sa0 = S.pp + a.D / POOLP;                          // [HWp]
+  S.scr = S.sa0 + a.HWp;                               // operator scratch
   const int lv = a.hlevel;
   const int ctr = lv == 0 ? 0 : 6 + 2 * lv, cfs = lv == 0 ? 2 : 7 + 2 * lv;
   const int cap = (a.hoff[lv + 1] - a.hoff[lv]) / 2;
   const int nfsp = min(a.cnt[cfs], cap), ntr = min(a.cnt[ctr], cap);
   const int32_t* jtr = a.hjobs + a.hoff[lv];
   const int32_t* jfs = jtr + cap;
-  const int nB = WALK_FIND_PARTS * nfsp;
-  for (int j = blockIdx.x; j < nB + 2 * ntr; j += gridDim.x) {
-    // the opaque copy keeps one operator's address arithmetic from being hoisted across the other
-    // (see walk_kernel)
+  const int nA = POOLP * nfsp, nT = 2 * ntr;
+  for (int j = blockIdx.x; j < nA + nT; j += gridDim.x) {
+    // (an opaque copy per item: the per-thread addresses of one item's 18 loads must not be hoisted out of
+    // the loop, where they would stay live across everything else -- see walk_kernel)
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
-    // stage-B items first: short streams (3 - 4 us) that free their slots for the Transform halves behind
-    // them; with the Transform halves first, 400 of the 800 epilogues only started when a 10 us half left
-    const bool tr = j >= nB;
-    const int job = tr ? jtr[(j - nB) >> 1] : jfs[j / WALK_FIND_PARTS];
-    const int part = tr ? ((j - nB) & 1) : j % WALK_FIND_PARTS;
+    const bool tr = j >= nA;
+    const int jj = tr ? j - nA : j;
+    const int job = tr ? jtr[jj >> 1] : jfs[jj / POOLP];
+    const int part = tr ? (jj & 1) : jj % POOLP;
     const int q = job >> 8, t = job & 0xff;
     if (q < 0 || q >= a.K * a.N || t >= T || t < 1) continue;        // (a stale list entry)
     const int kb = q / a.N, n = q - kb * a.N;
     if (tr) heavy_transform_item<KS, PTW>(tid, w, a, a.b[kb], P, q, n, t, part, lv, S);
-    else fsp_epi_item<CI>(tid, w, a, a.b[kb], n, t, part, lv);
+    else fsp_pool_item(tid, w, a, P, q, t, part, lv, S.arena, S.pp, S.sa0, S.scr);
+  }
+}
+
+// Second launch of a nesting level: stage B of its FindSameProperty nodes, WALK_FIND_PARTS row parts per node
+// streaming the operator's own conv_image map like walk_find_kernel (persistent grid; the eight fc_att
+// shares of stage A came from the launch before).
+template <int CI>
+__global__ __launch_bounds__(HT, CI == 1 ? 4 : 2) void walk_fspepi_kernel(ModuleWeights w, WalkArgs a) {
+  const int lv = a.hlevel;
+  const int cfs = lv == 0 ? 2 : 7 + 2 * lv;
+  const int cap = (a.hoff[lv + 1] - a.hoff[lv]) / 2;
+  const int nfsp = min(a.cnt[cfs], cap);
+  const int32_t* jfs = a.hjobs + a.hoff[lv] + cap;
+  for (int j = blockIdx.x; j < WALK_FIND_PARTS * nfsp; j += gridDim.x) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));                        // (see walk_kernel)
+    const int job = jfs[j / WALK_FIND_PARTS], part = j % WALK_FIND_PARTS;
+    const int q = job >> 8, t = job & 0xff;
+    if (q < 0 || q >= a.K * a.N || t >= a.T || t < 1) continue;      // (a stale list entry)
+    const int kb = q / a.N, n = q - kb * a.N;
+    fsp_epi_item<CI>(tid, w, a, a.b[kb], n, t, part, lv);
   }
 }
 
@@ -2043,7 +2045,7 @@ __device__ __forceinline__ void light_item(int tid, const ModuleWeights& w, cons
     }
   }
   // every attention node of the tree (the root is the only answer node of a valid layout): the rows that
-  // exist in `watt` -- Find / Filter logits (walk_find), Transform / FindSameProperty maps (walk_heavy) --
+  // exist in `watt` -- Find / Filter logits (walk_find), Transform / FindSameProperty maps (walk_heavy / walk_fspepi) --
   // with every load in flight, then the light operators in token order.  (Requesting ALL T rows before the
   // plan arrives, as the heavy items do for the rows in front of their node, was measured slower here: 12.8
   // KB per question where the template mix needs 0.6 - 1.8.)
@@ -2149,41 +2151,34 @@ __global__ __launch_bounds__(HT) void walk_light_kernel(ModuleWeights w, WalkArg
 
 }  // namespace
 
-// LDS of walk_heavy_kernel (floats): arena + text map (twice) + Transform's padded map / fold buffer
-static size_t heavy_lds_floats(const WalkArgs& a) {
-  const int pad = a.ksize / 2;
-  const size_t tr = (((size_t)(a.H + 2 * pad) * (a.W + 2 * pad) + 4) & ~3) + (size_t)TR_CG * 96 * 2;
-  return (size_t)a.T * a.HWp + 2 * (size_t)a.Mp + tr + 64;
-}
-
+// First launch of level a.hlevel: FindSameProperty stage A + Transform halves
 void launch_walk_heavy(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) {
-  const size_t smem = sizeof(float) * heavy_lds_floats(a);
+  const int cap = (a.hoff[a.hlevel + 1] - a.hoff[a.hlevel]) / 2;
+  const int pad = a.ksize / 2;
+  // LDS (floats): arena + text map (twice) + pooled part + soft-max row + the larger of Transform's padded
+  // map / fold buffer and the pooling scratch
+  const size_t tr = (((size_t)(a.H + 2 * pad) * (a.W + 2 * pad) + 4) & ~3) + (size_t)TR_CG * 96 * 2;
+  const size_t smem = sizeof(float) * ((size_t)a.T * a.HWp + 2 * (size_t)a.Mp + a.D / POOLP + a.HWp +
+                                       std::max<size_t>(tr, (size_t)4 * HT) + 64);
   // a persistent grid over the level's items: four workgroups per CU's worth of ids, each takes items
   // id, id + grid, ... (the list lengths live on the device)
-  const int grid = std::min(1024, std::max(1, a.hoff[a.hlevel + 1] - a.hoff[a.hlevel]));
+  const int grid = (int)std::min<long>(1024, std::max<long>(1, (long)cap * (POOLP + 2)));
   auto go = [&](auto kern, std::atomic<uint64_t>& done) {
     if (smem > 64 * 1024) ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)smem, done);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(HT), smem, s, w, a);
   };
-  static std::atomic<uint64_t> dn[8];
+  static std::atomic<uint64_t> dn[4];
   const bool p5 = (a.H * a.W + 15) / 16 <= 10;     // pixel tiles per wave (walk_transform)
-  const bool c1 = a.Mp <= 256;                     // float4 column groups per lane of the stage-B epilogue
-  if (a.ksize == 5) {
-    if (p5) { if (c1) go(walk_heavy_kernel<5, 5, 1>, dn[0]); else go(walk_heavy_kernel<5, 5, 4>, dn[1]); }
-    else { if (c1) go(walk_heavy_kernel<5, 6, 1>, dn[2]); else go(walk_heavy_kernel<5, 6, 4>, dn[3]); }
-  } else {
-    if (p5) { if (c1) go(walk_heavy_kernel<3, 5, 1>, dn[4]); else go(walk_heavy_kernel<3, 5, 4>, dn[5]); }
-    else { if (c1) go(walk_heavy_kernel<3, 6, 1>, dn[6]); else go(walk_heavy_kernel<3, 6, 4>, dn[7]); }
-  }
+  if (a.ksize == 5) { if (p5) go(walk_heavy_kernel<5, 5>, dn[0]); else go(walk_heavy_kernel<5, 6>, dn[1]); }
+  else { if (p5) go(walk_heavy_kernel<3, 5>, dn[2]); else go(walk_heavy_kernel<3, 6>, dn[3]); }
 }
 
-void launch_walk_fsppool(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) {
+// Second launch of level a.hlevel: FindSameProperty stage B
+void launch_walk_fspepi(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) {
   const int cap = (a.hoff[a.hlevel + 1] - a.hoff[a.hlevel]) / 2;
-  const size_t smem = sizeof(float) * ((size_t)a.T * a.HWp + a.D / POOLP + a.HWp + (size_t)4 * HT + 64);
-  static std::atomic<uint64_t> done{0};
-  if (smem > 64 * 1024) ensure_dynamic_lds(reinterpret_cast<const void*>(walk_fsppool_kernel), (int)smem, done);
-  const int grid = (int)std::min<long>(1024, std::max<long>(1, (long)cap * POOLP));
-  hipLaunchKernelGGL(walk_fsppool_kernel, dim3(grid), dim3(HT), smem, s, w, a);
+  const int grid = (int)std::min<long>(1024, std::max<long>(1, (long)cap * WALK_FIND_PARTS));
+  if (a.Mp <= 256) hipLaunchKernelGGL(walk_fspepi_kernel<1>, dim3(grid), dim3(HT), 0, s, w, a);
+  else hipLaunchKernelGGL(walk_fspepi_kernel<4>, dim3(grid), dim3(HT), 0, s, w, a);
 }
 
 void launch_walk_light(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) {

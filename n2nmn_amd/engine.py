@@ -306,6 +306,49 @@ class Engine:
         and repeated passes return the same bits (n2nmn_walk_set_levels)."""
         _lib.check(self._lib.n2nmn_walk_set_levels(self._ctx, int(levels)))
 
+    def set_nesting_bound(self, bound: int):
+        """promise for the NEXT walker pass only: no layout nests Transform / FindSameProperty deeper than
+        `bound` levels -> exactly that many level launches and no fall-back walker launch; -1: none
+        (n2nmn_walk_set_nesting_bound).  `layout_nesting` computes it from a host layout array."""
+        _lib.check(self._lib.n2nmn_walk_set_nesting_bound(self._ctx, int(bound)))
+
+    def layout_nesting(self, gt_layout) -> int:
+        """deepest nesting of _Transform / _FindSameProperty nodes in a HOST layout array [T_dec, N]: the
+        stack machine of models_clevr/nmn3_assembler.py:153-222 on nesting depths only (a node's depth = the
+        deepest of its inputs', + 1 if it is one of the two), all columns at once.  Columns that run out
+        of stack stop counting; type errors are ignored, so the result is an upper bound of what the
+        device's decoder (plan_layout, kernels_walk.hip) finds for the VALID layouts."""
+        g = np.asarray(gt_layout)
+        T, N = g.shape
+        tok_op = np.asarray(self.assembler._token_op, np.int64)
+        ok_tok = (g >= 0) & (g < tok_op.shape[0])
+        ops = np.where(ok_tok, tok_op[np.clip(g, 0, tok_op.shape[0] - 1)], -2)
+        OP_ARITY_MAX = 64
+        arity = np.full(OP_ARITY_MAX, -1, np.int64)
+        for code, name in self.assembler._op_name.items():
+            arity[code] = self.assembler._input_num[name]
+        heavy_codes = (OP_CODE['_Transform'], OP_CODE['_FindSameProperty'])
+        stack = np.zeros((N, T + 2), np.int64)
+        sp = np.zeros(N, np.int64)
+        live = np.ones(N, bool)
+        deepest = np.zeros(N, np.int64)
+        cols = np.arange(N)
+        for t in range(T):
+            op = ops[t]
+            live &= op >= 0
+            k = np.where(live, arity[np.clip(op, 0, OP_ARITY_MAX - 1)], 0)
+            live &= (k >= 0) & (sp >= k)
+            k = np.where(live, k, 0)
+            top = stack[cols, np.maximum(sp - 1, 0)]
+            sec = stack[cols, np.maximum(sp - 2, 0)]
+            hd = np.where(k >= 1, top, 0)
+            hd = np.where(k >= 2, np.maximum(hd, sec), hd) + np.isin(op, heavy_codes)
+            nsp = sp - k
+            stack[cols[live], nsp[live]] = hd[live]
+            sp = np.where(live, nsp + 1, sp)
+            deepest = np.where(live, np.maximum(deepest, hd), deepest)
+        return int(deepest.max()) if N else 0
+
     def walk_supported(self) -> bool:
         return bool(self._lib.n2nmn_walk_supported(self._ctx))
 
@@ -537,6 +580,13 @@ class Engine:
                 self.conv_image(feat, s2s['predicted_tokens'], find=False, fsp=True)
             if self.overlap_conv:
                 cur.wait_event(self._side_ev)
+            # layouts held on the host: the walker is told how deep they nest (exact level launches, no
+            # fall-back launch); a SuperBucket passes the figure it computed when its slots were filled
+            nest = batch.get('gt_nesting_host') if known else None
+            if nest is None and known and isinstance(gt_layout, np.ndarray):
+                nest = self.layout_nesting(gt_layout)
+            if nest is not None:
+                self.set_nesting_bound(int(nest))
             scores, validity = self.execute_tokens(
                 s2s['predicted_tokens'], feat, s2s.get('word_vecs'), conv_done=True,
                 atts=(s2s['atts'], s2s['_input_seq'], s2s['_seq_length']) if table else None,

@@ -58,6 +58,9 @@ class SuperBucket:
         # (n2nmn_seq2seq_io.gt_length_host, eos_retire)
         self.gt_length_host = np.full((N,), d.T_decoder, np.int32)
         self._glen_known = [False] * self.K
+        # ... and how deep each such slot's layouts nest Transform / FindSameProperty (Engine.layout_nesting):
+        # the walker then launches exactly that many levels and no fall-back walker
+        self.gt_nesting_host = [0] * self.K
         # results live in tensors of the bucket's own: two buckets may share one engine (a worker
         # alternates between them), and the engine's reuse buffers belong to whoever ran last
         self._res = {}
@@ -98,6 +101,7 @@ class SuperBucket:
             self._glen_known[k] = isinstance(gt_layout, np.ndarray)
             if self._glen_known[k]:
                 self.gt_length_host[self._cols(k)] = self.engine.layout_lengths(gt_layout)
+                self.gt_nesting_host[k] = self.engine.layout_nesting(gt_layout)
 
     def set_layout(self, k: int, gt_layout):
         """replace only the ground-truth layout of slot k (host array or tensor)"""
@@ -107,6 +111,7 @@ class SuperBucket:
         self._glen_known[k] = isinstance(gt_layout, np.ndarray)
         if self._glen_known[k]:
             self.gt_length_host[c] = self.engine.layout_lengths(gt_layout)
+            self.gt_nesting_host[k] = self.engine.layout_nesting(gt_layout)
 
     def _results(self, n: int, Td: int):
         torch = _torch()
@@ -141,6 +146,8 @@ class SuperBucket:
             gt = self.gt_layout if full else self.gt_layout[:, :rows].contiguous()
             if eos_retire and all(self._glen_known[:n]) and (T_dec is None or Td == self.dims.T_decoder):
                 batch['gt_length_host'] = self.gt_length_host[:rows]
+            if all(self._glen_known[:n]) and (T_dec is None or Td == self.dims.T_decoder):
+                batch['gt_nesting_host'] = max(self.gt_nesting_host[:n])
         if host_assemble or not self.engine.walk_supported():
             self.scores, self.tokens, self.validity = self.engine.forward(
                 batch, T_dec=T_dec, use_gt_layout=use_gt_layout, gt_layout=gt,

@@ -488,3 +488,48 @@ def test_fixed_level_count_makes_nested_layouts_reproducible_bit_for_bit(clevr_e
     assert np.array_equal(a, b), 'fixed level count: the logits must not depend on what ran before'
     assert_close('level by level vs the one-workgroup walker', a, ref, STAGED_TOL)
 
+
+
+def test_nesting_bound_from_host_layouts_launches_exact_levels_and_no_fallback(clevr_engine):
+    """n2nmn_walk_set_nesting_bound: a caller that holds the layouts on the host tells the walker how deep
+    they nest -> exactly that many level launches, no fall-back launch.  Same bits as a pass with a fixed
+    level count that covers every layout; the promise covers ONE pass; a layout that breaks it comes back
+    INVALID (validity 0, zero logits), the others are unaffected."""
+    eng, d, asm, w = clevr_engine
+    batch = synth.make_inputs(d, seed=31)
+    toks = synth.random_valid_layouts(d, asm.P, asm.W, asm.b, seed=77, max_len=14)
+    toks[:, 1] = asm.module_list2tokens(['_Find'] + ['_FindSameProperty', '_Transform'] * 2 + ['_Count'], d.T_decoder)
+    toks[:, 2] = asm.module_list2tokens(['_Find', '_Transform', '_Exist'], d.T_decoder)
+    nest = eng.layout_nesting(toks)
+    assert nest >= 4
+    s2s = eng.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], forced_tokens=toks,
+                      reuse_buffers=False, word_vecs=False)
+
+    def run(bound=None):
+        if bound is not None:
+            eng.set_nesting_bound(bound)
+        sc, v = eng.execute_tokens(s2s['predicted_tokens'], batch['image_feat_batch'], None, reuse_buffers=False,
+                                   atts=(s2s['atts'], s2s['_input_seq'], s2s['_seq_length']))
+        return t2n(sc).copy(), t2n(v).copy()
+    try:
+        eng.set_front_end(1)
+        eng.set_defer_pool(1)
+        eng.set_staged(1)
+        eng.set_walk_levels(d.T_decoder - 1)
+        ref = run()
+        got = run(nest)
+        after = run()                                # the promise is spent: the fixed level count again
+        broken = run(1)
+    finally:
+        eng.set_walk_levels(0)
+        eng.set_front_end(-1)
+        eng.set_defer_pool(-1)
+        eng.set_staged(-1)
+    assert ref[1].all()
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    assert np.array_equal(after[0], ref[0])
+    # bound 1: every layout nested deeper than one level is reported invalid, nothing else changes
+    deep = np.array([eng.layout_nesting(toks[:, i:i + 1]) > 1 for i in range(d.N)])
+    assert deep[1] and not deep[2] and 0 < deep.sum() < d.N
+    assert np.array_equal(broken[1].astype(bool), ~deep)
+    assert np.all(broken[0][deep] == 0) and np.array_equal(broken[0][~deep], ref[0][~deep])
