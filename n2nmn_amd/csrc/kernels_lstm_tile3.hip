@@ -349,539 +349,6 @@ __global__ __launch_bounds__(T3<RG>::THREADS, RG == 4 ? 2 : 1) void lstm_tile3_k
   }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// lstm_tile3w_kernel: the same step with 128 rows x 128 gate columns (32 hidden units) per workgroup.
-// Measured on the 64- / 128-row x 64-column tiles above (profiles/r04_notes.md): the LDS-DMA stream is
-// the limit, not the matrix pipe -- 24 (36) KiB per stage for 64 (128) rows, 17.6 TB/s chip-wide at
-// best, and the waves' LDS reads (9 KiB per 12 MFMAs) compete with it for the LDS port.  Here
-//   * a stage is 24 KiB of h planes (128 rows) + 24 KiB of weight planes (two 16-unit tiles): 48 KiB
-//     for FOUR 64 x 64 blocks, half the DMA bytes per MFMA of the 128 x 64 tile;
-//   * a wave owns 32 rows x 16 units x all four gates: 18 ds_read_b128 per 48 MFMAs (0.375 KiB per MFMA
-//     instead of 0.75), eight independent accumulators, and every gate of a unit in its own registers:
-//     no exchange between waves before the cell update;
-//   * 8 waves = 4 row groups of 32 x 2 unit tiles; ring of 3 stages (144 KiB); 6 LDS-DMA pieces per wave
-//     and stage.
-// Grid: (job, 128-row block, 32-unit tile), the K = 2L job first, the tile index fastest.
-// ---------------------------------------------------------------------------------------------------
-constexpr int TW_ROWS = 128, TW_UNITS = 32, TW_WAVES = 8, TW_THREADS = TW_WAVES * 64;
-constexpr int TW_H_IMAGE = 3 * 8 * 1024, TW_W_IMAGE = 2 * T3_W_IMAGE, TW_STAGE = TW_H_IMAGE + TW_W_IMAGE;
-constexpr int TW_PIECES = (TW_STAGE / 1024) / TW_WAVES;       // 6
-
-template <int NS, int VAR = 0>
-__global__ __launch_bounds__(TW_THREADS, 1) void lstm_tile3w_kernel(LstmJobs3 jobs, int N, int L, int nrb,
-                                                                    int njobs) {
-  extern __shared__ __attribute__((aligned(1024))) char smem[];
-  const int ntile = L / TW_UNITS;
-  int nab[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const LstmJob& jq = jobs.j[j];
-    int n = 0;
-    if (j < njobs && jq.active) {
-      const int na = jq.n_active ? *jq.n_active : N;
-      n = (min(max(na, 0), N) + TW_ROWS - 1) / TW_ROWS;
-    }
-    nab[j] = n;
-  }
-  int rem = blockIdx.x / ntile;
-  const int ct = blockIdx.x - rem * ntile;
-  int jsel = -1, rb = 0;
-  bool zero_fill = false;
-#pragma unroll
-  for (int j = 1; j >= 0; --j)
-    if (jsel < 0) { if (rem < nab[j]) { jsel = j; rb = rem; } else rem -= nab[j]; }
-#pragma unroll
-  for (int j = 1; j >= 0; --j)
-    if (jsel < 0 && j < njobs && jobs.j[j].active && jobs.j[j].out_seq) {
-      if (rem < nrb - nab[j]) { jsel = j; rb = nab[j] + rem; zero_fill = true; } else rem -= nrb - nab[j];
-    }
-  if (jsel < 0) return;
-  const LstmJob& jb = jobs.j[jsel];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = w & 3, ut = w >> 2;                // 32-row group of the wave, and its 16-unit tile
-  const int row0 = rb * TW_ROWS;
-  const int R = jb.hp_R;
-  const int nact = jb.n_active ? *jb.n_active : N;
-  const int lr = lane & 15, q = lane >> 4;
-  const int t4 = 4 * (2 * ct + ut) + q;              // 4-unit group = float4 element of the state
-  if (zero_fill) {
-#pragma unroll
-    for (int rs = 0; rs < 2; ++rs) {
-      const int gr = row0 + 32 * wr + 16 * rs + lr;
-      if (gr < N) {
-        const int zr = jb.perm ? jb.perm[gr] : gr;
-        *reinterpret_cast<float4*>(jb.out_seq + (size_t)zr * L + 4 * t4) = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-    return;
-  }
-
-  // ---- operand stream: 48 pieces of 1 KiB per stage, wave w moves pieces w, w + 8, ... -----------
-  //   pc < 24: h plane pc / 8 of 16-row group pc % 8;  pc >= 24: weight tile (pc - 24) / 12, plane, gate
-  const int K = jb.K, nst = K / T3_BK;
-  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-  const uint32_t plane_bytes = (uint32_t)(L / 8) * (uint32_t)R * 16u;
-  uint32_t pbase[TW_PIECES], pstep[TW_PIECES], plds[TW_PIECES];
-  bool pish[TW_PIECES];
-#pragma unroll
-  for (int i = 0; i < TW_PIECES; ++i) {
-    const int pc = w + TW_WAVES * i;
-    pish[i] = pc < 24;
-    if (pc < 24) {
-      const int p = pc >> 3, rg = pc & 7;
-      const int arow = min(row0 + 16 * rg + (lane & 15), N - 1);
-      pbase[i] = (uint32_t)p * plane_bytes + ((uint32_t)(lane >> 4) * (uint32_t)R + (uint32_t)arow) * 16u;
-      pstep[i] = 4u * (uint32_t)R * 16u;
-      plds[i] = (uint32_t)pc * 1024u;
-    } else {
-      const int idx = pc - 24, tile = idx / 12, rest = idx - 12 * tile;      // rest = plane * 4 + gate
-      pbase[i] = (uint32_t)(2 * ct + tile) * (uint32_t)nst * (uint32_t)T3_W_IMAGE + (uint32_t)rest * 1024u +
-                 (uint32_t)lane * 16u;
-      pstep[i] = (uint32_t)T3_W_IMAGE;
-      plds[i] = (uint32_t)TW_H_IMAGE + (uint32_t)idx * 1024u;
-    }
-  }
-  const uint16_t* const A0p = jb.A0b;
-  const uint16_t* const A1p = jb.A1b;
-  const uint16_t* const Wp = jb.Wb3;
-  const int sL = L / T3_BK;
-  auto issue = [&](int s) {
-    const uint32_t slot = lds0 + (uint32_t)(s % NS) * TW_STAGE;
-    const bool lo = s < sL;
-    const uint32_t sh = (uint32_t)(lo ? s : s - sL);
-#pragma unroll
-    for (int i = 0; i < TW_PIECES; ++i) {
-      if (pish[i]) glds16b(lo ? A0p : A1p, pbase[i] + sh * pstep[i], slot + plds[i]);
-      else glds16b(Wp, pbase[i] + (uint32_t)s * pstep[i], slot + plds[i]);
-    }
-  };
-#pragma unroll
-  for (int s = 0; s < NS - 1; ++s)
-    if (VAR != 1) issue(s);
-
-  f32x4 acc[2][4];
-#pragma unroll
-  for (int rs = 0; rs < 2; ++rs)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) acc[rs][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const bool wact = row0 + 32 * wr < nact;          // wave-uniform: any active row in this wave?
-
-  const uint4* const S0 = reinterpret_cast<const uint4*>(smem) + lane;
-  // Operands of a stage in registers: 2 row halves x 3 h planes + 4 gates x 3 weight planes (72 VGPRs),
-  // double-buffered: while the 48 MFMAs of stage i run from P, the wave reads stage i + 1 from LDS into
-  // Q (single-buffered, both waves of a SIMD read right behind the barrier and the 576 LDS clocks of a
-  // stage stand in front of its 1536 MFMA clocks: 36 us without any DMA against 24 of matrix work)
-  struct Ops { uint4 hq[2][3]; uint4 wq[4][3]; };
-  auto fetch = [&](Ops& o, int slot) {
-    const uint4* st = S0 + slot * (TW_STAGE / 16);
-#pragma unroll
-    for (int rs = 0; rs < 2; ++rs)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) o.hq[rs][p] = st[(p * 8 + 2 * wr + rs) * 64];
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) o.wq[g][p] = st[(TW_H_IMAGE / 16) + (ut * 12 + p * 4 + g) * 64];
-  };
-  // the six products, small terms first; the 8 accumulators (2 row halves x 4 gates) interleave
-  auto mma = [&](const Ops& o, int t) {
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // weight plane, h plane
-    if (VAR == 2) {
-      asm volatile("" ::"v"(o.hq[0][0].x), "v"(o.hq[1][2].w), "v"(o.wq[0][0].x), "v"(o.wq[3][2].w),
-                   "v"(o.wq[1][1].y), "v"(o.wq[2][1].z));
-      return;
-    }
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int rs = 0; rs < 2; ++rs)
-        acc[rs][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, o.wq[g][PA[t]]),
-                                                             __builtin_bit_cast(bf16x8, o.hq[rs][PB[t]]),
-                                                             acc[rs][g], 0, 0, 0);
-  };
-  // before stage `next` is read: this wave's pieces of it have landed (the stages issued behind it may
-  // stay in flight: NS - 3 of them, the refill goes out behind this barrier), then every wave's have
-  auto sync_stage = [&](int next) {
-    const int behind = nst - 1 - next;
-    if (behind >= NS - 3) wait_vm3<TW_PIECES * (NS - 3)>();
-    else wait_vm3<0>();
-    __builtin_amdgcn_s_barrier();
-  };
-#define NW_PIN() __builtin_amdgcn_sched_barrier(0)
-  auto step = [&](auto work_tag, const Ops& cur, Ops& nxt, int next, bool more) {
-    constexpr bool WORK = decltype(work_tag)::value;
-    const int refill = next + NS - 2;
-    const bool dma = more && refill < nst && VAR != 1;
-    if (more) sync_stage(next);       // stage `next` visible; every wave holds stage `cur` in registers
-    if (WORK) { mma(cur, 0); NW_PIN(); }
-    if (dma) issue(refill);
-    if (WORK) {
-      NW_PIN();
-      if (more) fetch(nxt, next % NS);
-      NW_PIN();
-#pragma unroll
-      for (int t = 1; t < 6; ++t) mma(cur, t);
-    }
-  };
-  auto stages = [&](auto work_tag) {
-    constexpr bool WORK = decltype(work_tag)::value;
-    wait_vm3<TW_PIECES * (NS - 2)>();              // stage 0 (the oldest of the NS - 1 in flight)
-    __builtin_amdgcn_s_barrier();
-    Ops P{}, Q{};
-    if (WORK) fetch(P, 0);
-    int i = 0;
-    for (; i + 2 < nst; i += 2) {                  // nst is even: two stages per trip, P / Q static
-      step(work_tag, P, Q, i + 1, true);
-      step(work_tag, Q, P, i + 2, true);
-    }
-    step(work_tag, P, Q, i + 1, true);             // the last two stages
-    step(work_tag, Q, P, 0, false);
-  };
-#undef NW_PIN
-  if (wact && VAR != 3) stages(std::true_type{});
-  else stages(std::false_type{});
-
-  // ---- cell update: lane = (row, 4 units) for each of the wave's two 16-row halves ----------------
-#pragma unroll
-  for (int rs = 0; rs < 2; ++rs) {
-    const int gr = row0 + 32 * wr + 16 * rs + lr;
-    if (gr >= N) continue;
-    const int orow = jb.perm ? jb.perm[gr] : gr;
-    const float* ar;
-    if (jb.xtab) {
-      const int xi = jb.xidx ? jb.xidx[orow] : jb.xidx_const;
-      ar = jb.xtab + (size_t)xi * 4 * L + 16 * t4;
-    } else {
-      ar = jb.bias + 16 * t4;
-    }
-    float4 add[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) add[g] = *reinterpret_cast<const float4*>(ar + 4 * g);
-    const size_t sidx = ((size_t)t4 * R + gr) * 4;
-    const float4 c_old = *reinterpret_cast<const float4*>(jb.c_in + sidx);
-    const bool masked = jb.seq_len && jb.t >= jb.seq_len[orow];      // dynamic_rnn past the length (A.2)
-    float4 h_prev = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (masked) h_prev = *reinterpret_cast<const float4*>(jb.h_old + sidx);
-    float cn[4], hn[4];
-    const float co[4] = {c_old.x, c_old.y, c_old.z, c_old.w};
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float zi = acc[rs][0][r] + (r == 0 ? add[0].x : r == 1 ? add[0].y : r == 2 ? add[0].z : add[0].w);
-      const float zj = acc[rs][1][r] + (r == 0 ? add[1].x : r == 1 ? add[1].y : r == 2 ? add[1].z : add[1].w);
-      const float zf = acc[rs][2][r] + (r == 0 ? add[2].x : r == 1 ? add[2].y : r == 2 ? add[2].z : add[2].w);
-      const float zo = acc[rs][3][r] + (r == 0 ? add[3].x : r == 1 ? add[3].y : r == 2 ? add[3].z : add[3].w);
-      const float gi = fast_sigmoid(zi), gj = fast_tanh(zj), gf = fast_sigmoid(zf + 1.0f), go = fast_sigmoid(zo);
-      cn[r] = co[r] * gf + gi * gj;
-      hn[r] = fast_tanh(cn[r]) * go;
-    }
-    float4 c4 = make_float4(cn[0], cn[1], cn[2], cn[3]);
-    float4 h4 = make_float4(hn[0], hn[1], hn[2], hn[3]);
-    float4 o4 = h4;
-    if (masked) { c4 = c_old; h4 = h_prev; o4 = make_float4(0.f, 0.f, 0.f, 0.f); }
-    *reinterpret_cast<float4*>(jb.c_out + sidx) = c4;
-    *reinterpret_cast<float4*>(jb.h_new + sidx) = h4;
-    const size_t plane_elems = (size_t)(L / 8) * R * 8;
-    const size_t poff = ((size_t)(t4 >> 1) * R + gr) * 8 + (size_t)(t4 & 1) * 4;
-    if (jb.h_new_b) store_planes(jb.h_new_b, plane_elems, poff, h4);
-    const size_t oidx = (size_t)orow * L + 4 * t4;
-    if (jb.out_seq) *reinterpret_cast<float4*>(jb.out_seq + oidx) = o4;
-    if (jb.h_drop) {
-      const float4 dm = *reinterpret_cast<const float4*>(jb.drop + oidx);
-      const float4 hd = make_float4(h4.x * dm.x, h4.y * dm.y, h4.z * dm.z, h4.w * dm.w);
-      *reinterpret_cast<float4*>(jb.h_drop + sidx) = hd;
-      if (jb.h_drop_b) store_planes(jb.h_drop_b, plane_elems, poff, hd);
-    }
-    if (jb.fin_c && jb.seq_len && jb.t == jb.seq_len[orow] - 1) {   // the row's last valid step
-      const size_t fidx = ((size_t)t4 * R + orow) * 4;
-      *reinterpret_cast<float4*>(jb.fin_c + fidx) = c4;
-      *reinterpret_cast<float4*>(jb.fin_h + fidx) = h4;
-      if (jb.fin_h_b)
-        store_planes(jb.fin_h_b, plane_elems, ((size_t)(t4 >> 1) * R + orow) * 8 + (size_t)(t4 & 1) * 4, h4);
-    }
-  }
-}
-
-template <int NS, int VAR = 0>
-void launch_tile3w(const LstmJobs3& js, int njobs, int N, int L, hipStream_t s) {
-  static std::atomic<uint64_t> attr{0};
-  const int lds = NS * TW_STAGE;
-  ensure_dynamic_lds(reinterpret_cast<const void*>(&lstm_tile3w_kernel<NS, VAR>), lds, attr);
-  const int nrb = (N + TW_ROWS - 1) / TW_ROWS;
-  const int grid = njobs * nrb * (L / TW_UNITS);
-  hipLaunchKernelGGL((lstm_tile3w_kernel<NS, VAR>), dim3(grid), dim3(TW_THREADS), lds, s, js, N, L, nrb,
-                     njobs);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// lstm_tile3r_kernel: 128 rows x 64 gate columns per workgroup, h read as fp32 and split IN REGISTERS.
-// What the variants above measured: with h travelling as three bf16 planes (6 bytes per element) the
-// L2 -> LDS stream and the waves' LDS reads are as long as the matrix work, and the two do not overlap
-// well enough.  A wave that owns 16 rows and ALL FOUR gates of the tile's 16 units is the only consumer
-// of its rows' h inside the workgroup, so it can split them itself without doing anybody else's work:
-//   * h comes in as the fp32 state it already is ([L/4][R][4]: 4 bytes per element, 16 KiB per stage of
-//     128 rows instead of 24) -- a stage is 28 KiB instead of 36, the state planes in HBM are not needed;
-//   * per stage a lane splits its 8 values (44 VALU instructions, under 24 MFMAs = 384 matrix clocks);
-//   * 2 + 12 ds_read_b128 per 24 MFMAs (0.58 KiB per MFMA instead of 0.75), no gate exchange;
-//   * 8 waves, ring of 5 stages (140 KiB): three stages of look-ahead instead of two.
-// ---------------------------------------------------------------------------------------------------
-constexpr int TR_ROWS = 128, TR_WAVES = 8, TR_THREADS = TR_WAVES * 64;
-constexpr int TR_H_IMAGE = 8 * TR_ROWS * 16;                  // [k4 = 8][row][4 floats] = 16 KiB
-constexpr int TR_STAGE = TR_H_IMAGE + T3_W_IMAGE;              // 28 KiB
-constexpr int TR_NPIECE = TR_STAGE / 1024, TR_PBASE = TR_NPIECE / TR_WAVES, TR_PEXTRA = TR_NPIECE % TR_WAVES;
-
-// 8 fp32 values (two float4 = k 8 kq .. 8 kq + 7 of one row) -> the three bf16 planes of an MFMA operand
-__device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& hi, uint4& mid, uint4& lo) {
-  split3(a.x, a.y, hi.x, mid.x, lo.x);
-  split3(a.z, a.w, hi.y, mid.y, lo.y);
-  split3(b.x, b.y, hi.z, mid.z, lo.z);
-  split3(b.z, b.w, hi.w, mid.w, lo.w);
-}
-
-template <int NS, int VAR = 0>
-__global__ __launch_bounds__(TR_THREADS, 1) void lstm_tile3r_kernel(LstmJobs3 jobs, int N, int L, int nrb,
-                                                                    int njobs) {
-  extern __shared__ __attribute__((aligned(1024))) char smem[];
-  constexpr int PMAX = TR_PBASE + (TR_PEXTRA ? 1 : 0);
-  const int ntile = L / T3_UNITS;
-  int nab[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const LstmJob& jq = jobs.j[j];
-    int n = 0;
-    if (j < njobs && jq.active) {
-      const int na = jq.n_active ? *jq.n_active : N;
-      n = (min(max(na, 0), N) + TR_ROWS - 1) / TR_ROWS;
-    }
-    nab[j] = n;
-  }
-  int rem = blockIdx.x / ntile;
-  const int ct = blockIdx.x - rem * ntile;
-  int jsel = -1, rb = 0;
-  bool zero_fill = false;
-#pragma unroll
-  for (int j = 1; j >= 0; --j)
-    if (jsel < 0) { if (rem < nab[j]) { jsel = j; rb = rem; } else rem -= nab[j]; }
-#pragma unroll
-  for (int j = 1; j >= 0; --j)
-    if (jsel < 0 && j < njobs && jobs.j[j].active && jobs.j[j].out_seq) {
-      if (rem < nrb - nab[j]) { jsel = j; rb = nab[j] + rem; zero_fill = true; } else rem -= nrb - nab[j];
-    }
-  if (jsel < 0) return;
-  const LstmJob& jb = jobs.j[jsel];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // = 16-row group of the wave
-  const int row0 = rb * TR_ROWS;
-  const int R = jb.hp_R;
-  const int nact = jb.n_active ? *jb.n_active : N;
-  const int lr = lane & 15, q = lane >> 4;
-  const int gr = row0 + 16 * w + lr;
-  const bool eact = gr < N;
-  const int grc = eact ? gr : N - 1;
-  const int t4 = 4 * ct + q;
-  if (zero_fill) {
-    if (eact) {
-      const int zr = jb.perm ? jb.perm[grc] : grc;
-      *reinterpret_cast<float4*>(jb.out_seq + (size_t)zr * L + 4 * t4) = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    return;
-  }
-
-  // ---- operand stream: 28 pieces of 1 KiB per stage; wave w moves pieces w, w + 8, ... ---------------
-  //   pc < 16: k4 slab pc / 2 of the h stage, rows 64 (pc % 2) ..;  pc >= 16: weight plane, gate
-  const int K = jb.K, nst = K / T3_BK;
-  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-  uint32_t pbase[PMAX], pstep[PMAX], plds[PMAX];
-  bool pish[PMAX];
-  const uint32_t wtile = (uint32_t)ct * (uint32_t)nst * (uint32_t)T3_W_IMAGE;
-#pragma unroll
-  for (int i = 0; i < PMAX; ++i) {
-    const int pc = min(w + TR_WAVES * i, TR_NPIECE - 1);
-    pish[i] = pc < 16;
-    if (pc < 16) {
-      const int s4 = pc >> 1, rh = pc & 1;
-      const int arow = min(row0 + 64 * rh + lane, N - 1);
-      pbase[i] = ((uint32_t)s4 * (uint32_t)R + (uint32_t)arow) * 16u;
-      pstep[i] = 8u * (uint32_t)R * 16u;                        // eight k4 slabs per stage
-      plds[i] = ((uint32_t)s4 * TR_ROWS + 64u * (uint32_t)rh) * 16u;
-    } else {
-      const int idx = pc - 16;
-      pbase[i] = wtile + (uint32_t)idx * 1024u + (uint32_t)lane * 16u;
-      pstep[i] = (uint32_t)T3_W_IMAGE;
-      plds[i] = (uint32_t)TR_H_IMAGE + (uint32_t)idx * 1024u;
-    }
-  }
-  const float* const A0p = jb.A0;
-  const float* const A1p = jb.A1;
-  const uint16_t* const Wp = jb.Wb3;
-  const int sL = L / T3_BK;
-  auto issue = [&](auto np_tag, int s) {
-    constexpr int NP = decltype(np_tag)::value;
-    const uint32_t slot = lds0 + (uint32_t)(s % NS) * TR_STAGE;
-    const bool lo = s < sL;
-    const uint32_t sh = (uint32_t)(lo ? s : s - sL);
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      if (pish[i]) glds16b(lo ? A0p : A1p, pbase[i] + sh * pstep[i], slot + plds[i]);
-      else glds16b(Wp, pbase[i] + (uint32_t)s * pstep[i], slot + plds[i]);
-    }
-  };
-  const bool extra = w < TR_PEXTRA;
-#pragma unroll
-  for (int s = 0; s < NS - 1; ++s) {
-    if (VAR != 1) {
-      if (extra) issue(std::integral_constant<int, PMAX>{}, s);
-      else issue(std::integral_constant<int, TR_PBASE>{}, s);
-    }
-  }
-
-  // ---- epilogue operands: fetched under the DMA prologue -------------------------------------------
-  int orow = grc;
-  if (jb.perm) orow = jb.perm[grc];
-  const float* ar;
-  if (jb.xtab) {
-    const int xi = jb.xidx ? jb.xidx[orow] : jb.xidx_const;
-    ar = jb.xtab + (size_t)xi * 4 * L + 16 * t4;
-  } else {
-    ar = jb.bias + 16 * t4;
-  }
-  float4 add[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) add[g] = *reinterpret_cast<const float4*>(ar + 4 * g);
-  const size_t sidx = ((size_t)t4 * R + grc) * 4;
-  const float4 c_old = *reinterpret_cast<const float4*>(jb.c_in + sidx);
-  const bool masked = jb.seq_len && jb.t >= jb.seq_len[orow];      // dynamic_rnn past the length (A.2)
-  float4 h_prev = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (masked) h_prev = *reinterpret_cast<const float4*>(jb.h_old + sidx);
-
-  f32x4 acc[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const bool wact = row0 + 16 * w < nact;
-
-  // raw operands of a stage: the lane's 8 fp32 h values + 4 gates x 3 weight planes (56 VGPRs)
-  struct Raw { float4 ha, hb; uint4 wq[4][3]; };
-  const char* const S0 = smem;
-  auto fetch = [&](Raw& o, int slot) {
-    const char* st = S0 + (size_t)slot * TR_STAGE;
-    const float4* hs = reinterpret_cast<const float4*>(st) + 16 * w + lr;
-    o.ha = hs[(2 * q) * TR_ROWS];
-    o.hb = hs[(2 * q + 1) * TR_ROWS];
-    const uint4* ws = reinterpret_cast<const uint4*>(st + TR_H_IMAGE) + lane;
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) o.wq[g][p] = ws[(p * 4 + g) * 64];
-  };
-  auto mma = [&](const Raw& o, const uint4 (&hq)[3], int t) {
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // weight plane, h plane
-    if (VAR == 2) {
-      asm volatile("" ::"v"(o.wq[0][0].x), "v"(o.wq[3][2].w), "v"(o.wq[1][1].y), "v"(o.wq[2][1].z),
-                   "v"(hq[0].x), "v"(hq[2].w));
-      return;
-    }
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-      acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, o.wq[g][PA[t]]),
-                                                       __builtin_bit_cast(bf16x8, hq[PB[t]]), acc[g], 0, 0, 0);
-  };
-#define NR_PIN() __builtin_amdgcn_sched_barrier(0)
-  auto stages = [&](auto work_tag, auto np_tag) {
-    constexpr bool WORK = decltype(work_tag)::value;
-    constexpr int NP = decltype(np_tag)::value;
-    auto sync_stage = [&](int next) {
-      const int behind = nst - 1 - next;             // stages after `next`
-      if (behind >= NS - 3) wait_vm3<NP * (NS - 3)>();
-      else if (NS > 4 && behind == NS - 4) wait_vm3<NP * (NS > 4 ? NS - 4 : 0)>();
-      else if (NS > 5 && behind == NS - 5) wait_vm3<NP * (NS > 5 ? NS - 5 : 0)>();
-      else wait_vm3<0>();
-      __builtin_amdgcn_s_barrier();
-    };
-    // `hq` = the split planes of stage `cur`'s h (made while the PREVIOUS stage's MFMAs ran)
-    auto step = [&](const Raw& cur, const uint4 (&hq)[3], Raw& nxt, uint4 (&hqn)[3], int next, bool more) {
-      const int refill = next + NS - 2;
-      const bool dma = more && refill < nst && VAR != 1;
-      if (more) sync_stage(next);
-      if (WORK) { mma(cur, hq, 0); NR_PIN(); }
-      if (dma) issue(np_tag, refill);
-      if (WORK) {
-        NR_PIN();
-        if (more) fetch(nxt, next % NS);
-        NR_PIN();
-        mma(cur, hq, 1); mma(cur, hq, 2);
-        if (more) split8(nxt.ha, nxt.hb, hqn[0], hqn[1], hqn[2]);      // VALU under the MFMAs
-        mma(cur, hq, 3); mma(cur, hq, 4); mma(cur, hq, 5);
-      }
-    };
-    wait_vm3<NP * (NS - 2)>();                     // stage 0 (the oldest of the NS - 1 in flight)
-    __builtin_amdgcn_s_barrier();
-    Raw P{}, Q{};
-    uint4 hp[3] = {}, hqq[3] = {};
-    if (WORK) { fetch(P, 0); split8(P.ha, P.hb, hp[0], hp[1], hp[2]); }
-    int i = 0;
-    for (; i + 2 < nst; i += 2) {                  // nst is even: two stages per trip, P / Q static
-      step(P, hp, Q, hqq, i + 1, true);
-      step(Q, hqq, P, hp, i + 2, true);
-    }
-    step(P, hp, Q, hqq, i + 1, true);              // the last two stages
-    step(Q, hqq, P, hp, 0, false);
-  };
-#undef NR_PIN
-  const bool work = wact && VAR != 3;
-  if (extra) {
-    if (work) stages(std::true_type{}, std::integral_constant<int, PMAX>{});
-    else stages(std::false_type{}, std::integral_constant<int, PMAX>{});
-  } else {
-    if (work) stages(std::true_type{}, std::integral_constant<int, TR_PBASE>{});
-    else stages(std::false_type{}, std::integral_constant<int, TR_PBASE>{});
-  }
-  if (!eact) return;
-
-  // ---- cell update: lane = (row, 4 units), acc[g][r] = z of gate g, unit 4q + r ------------------
-  float cn[4], hn[4];
-  const float co[4] = {c_old.x, c_old.y, c_old.z, c_old.w};
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const float zi = acc[0][r] + (r == 0 ? add[0].x : r == 1 ? add[0].y : r == 2 ? add[0].z : add[0].w);
-    const float zj = acc[1][r] + (r == 0 ? add[1].x : r == 1 ? add[1].y : r == 2 ? add[1].z : add[1].w);
-    const float zf = acc[2][r] + (r == 0 ? add[2].x : r == 1 ? add[2].y : r == 2 ? add[2].z : add[2].w);
-    const float zo = acc[3][r] + (r == 0 ? add[3].x : r == 1 ? add[3].y : r == 2 ? add[3].z : add[3].w);
-    const float gi = fast_sigmoid(zi), gj = fast_tanh(zj), gf = fast_sigmoid(zf + 1.0f), go = fast_sigmoid(zo);
-    cn[r] = co[r] * gf + gi * gj;
-    hn[r] = fast_tanh(cn[r]) * go;
-  }
-  float4 c4 = make_float4(cn[0], cn[1], cn[2], cn[3]);
-  float4 h4 = make_float4(hn[0], hn[1], hn[2], hn[3]);
-  float4 o4 = h4;
-  if (masked) { c4 = c_old; h4 = h_prev; o4 = make_float4(0.f, 0.f, 0.f, 0.f); }
-  *reinterpret_cast<float4*>(jb.c_out + sidx) = c4;
-  *reinterpret_cast<float4*>(jb.h_new + sidx) = h4;
-  const size_t oidx = (size_t)orow * L + 4 * t4;
-  if (jb.out_seq) *reinterpret_cast<float4*>(jb.out_seq + oidx) = o4;
-  if (jb.h_drop) {
-    const float4 dm = *reinterpret_cast<const float4*>(jb.drop + oidx);
-    *reinterpret_cast<float4*>(jb.h_drop + sidx) = make_float4(h4.x * dm.x, h4.y * dm.y, h4.z * dm.z, h4.w * dm.w);
-  }
-  if (jb.fin_c && jb.seq_len && jb.t == jb.seq_len[orow] - 1) {   // the row's last valid step
-    const size_t fidx = ((size_t)t4 * R + orow) * 4;
-    *reinterpret_cast<float4*>(jb.fin_c + fidx) = c4;
-    *reinterpret_cast<float4*>(jb.fin_h + fidx) = h4;
-  }
-}
-
-template <int NS, int VAR = 0>
-void launch_tile3r(const LstmJobs3& js, int njobs, int N, int L, hipStream_t s) {
-  static std::atomic<uint64_t> attr{0};
-  const int lds = NS * TR_STAGE;
-  ensure_dynamic_lds(reinterpret_cast<const void*>(&lstm_tile3r_kernel<NS, VAR>), lds, attr);
-  const int nrb = (N + TR_ROWS - 1) / TR_ROWS;
-  const int grid = njobs * nrb * (L / T3_UNITS);
-  hipLaunchKernelGGL((lstm_tile3r_kernel<NS, VAR>), dim3(grid), dim3(TR_THREADS), lds, s, js, N, L, nrb,
-                     njobs);
-}
-
 // weights -> three bf16 planes in fragment order (see the header): one thread per 16-byte fragment
 __global__ __launch_bounds__(256) void pack_tiles64_b3_kernel(const float* __restrict__ W, int ld, int row0,
                                                               int K, int L, uint16_t* __restrict__ dst) {
@@ -960,24 +427,16 @@ void launch_lstm_tile3(const LstmJob* jobs, int njobs, int N, int L, hipStream_t
   // 128-row blocks per job; variants (n2nmn_debug_lstm_bench): 4xx = 64-row workgroups
   static const int dflt = [] { const char* e = getenv("N2NMN_TILE3_VARIANT"); return e ? atoi(e) : 0; }();
   // shipped: 128-row x 64-column workgroups of 16 waves (4 x 36 KiB) from 256 rows on, 64-row workgroups
-  // below.  Measured and kept as variants only (profiles/r04_notes.md section 2): 128 x 128 (903) and the
-  // register-split form (705) -- both run 8 waves per CU and lose to two-waves-per-SIMD bubbles what
-  // their smaller streams gain.
+  // below.  Measured and rejected (tools/rejected/lstm_tile3_variants.hip.txt has the kernels and numbers):
+  // 128 x 128 workgroups and the register-split form -- both run 8 waves per CU and lose to
+  // two-waves-per-SIMD bubbles what their smaller streams gain; s_setprio around the MFMA groups (no
+  // change); the two gates' MFMA chains interleaved (slower: the LDS reads no longer sit between them).
   if (variant == 0) variant = dflt ? dflt : (N >= 256 ? 804 : 403);
   switch (variant) {
     case 404: launch_tile3<4, 4>(js, njobs, N, L, s); break;
     case 413: launch_tile3<3, 4, 1>(js, njobs, N, L, s); break;     // debug variants: no DMA
     case 423: launch_tile3<3, 4, 2>(js, njobs, N, L, s); break;     // no MFMA
     case 433: launch_tile3<3, 4, 3>(js, njobs, N, L, s); break;     // DMA + barriers only
-    case 705: launch_tile3r<5>(js, njobs, N, L, s); break;          // 128 x 64, fp32 h split in registers
-    case 704: launch_tile3r<4>(js, njobs, N, L, s); break;
-    case 715: launch_tile3r<5, 1>(js, njobs, N, L, s); break;
-    case 725: launch_tile3r<5, 2>(js, njobs, N, L, s); break;
-    case 735: launch_tile3r<5, 3>(js, njobs, N, L, s); break;
-    case 903: launch_tile3w<3>(js, njobs, N, L, s); break;          // 128 x 128 workgroups
-    case 913: launch_tile3w<3, 1>(js, njobs, N, L, s); break;
-    case 923: launch_tile3w<3, 2>(js, njobs, N, L, s); break;
-    case 933: launch_tile3w<3, 3>(js, njobs, N, L, s); break;
     case 803: launch_tile3<3, 8>(js, njobs, N, L, s); break;
     case 804: launch_tile3<4, 8>(js, njobs, N, L, s); break;
     case 814: launch_tile3<4, 8, 1>(js, njobs, N, L, s); break;

@@ -20,17 +20,13 @@ names = {24: 'fp32 LDS tile, 4 stages', 34: 'fp32 tile, no DMA', 44: 'fp32 tile,
          1403: 'bf16x3 64 rows, 3 stages', 1404: 'bf16x3 64 rows, 4 stages', 1413: 'bf16x3 64 rows, no DMA',
          1423: 'bf16x3 64 rows, no MFMA', 1433: 'bf16x3 64 rows, DMA only',
          1803: 'bf16x3 128 rows, 3 stages', 1804: 'bf16x3 128 rows, 4 stages', 1814: 'bf16x3 128 rows, no DMA',
-         1824: 'bf16x3 128 rows, no MFMA', 1834: 'bf16x3 128 rows, DMA only',
-         1903: 'bf16x3 128x128, 3 stages', 1913: 'bf16x3 128x128, no DMA', 1923: 'bf16x3 128x128, no MFMA',
-         1933: 'bf16x3 128x128, DMA only',
-         1705: 'bf16x3 128x64 reg-split, 5 st', 1704: 'bf16x3 128x64 reg-split, 4 st',
-         1715: 'reg-split, no DMA', 1725: 'reg-split, no MFMA', 1735: 'reg-split, DMA only'}
+         1824: 'bf16x3 128 rows, no MFMA', 1834: 'bf16x3 128 rows, DMA only'}
 VARIANTS = [int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else \
-    [24, 1804, 1903, 1913, 1923, 1933, 24, 1804, 1903]
+    [24, 1804, 1814, 1824, 1834, 1404, 24, 1804]
 GF = {N: 2.0 * N * 4 * 512 * (512 + 1024) / 1e9 for N in (128, 256, 512, 1024)}
 for N in ([int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else (1024, 512, 256)):
     for v in VARIANTS:
         us = C.c_double()
         _lib.check(eng._lib.n2nmn_debug_lstm_bench(eng._ctx, v, 64, 2, N, 200, C.byref(us), eng.stream()))
         print('N=%4d %-28s %7.2f us/launch  %6.1f TFLOP/s fp32-equivalent' %
-              (N, names.get(v, str(v)), us.value, GF[N] / us.value * 1e-3 * 1e3), flush=True)
+              (N, names.get(v, str(v)), us.value, GF[N] / us.value * 1e3), flush=True)
