@@ -78,14 +78,20 @@ def parse():
                     help="recurrent-step mode of the timed passes; 'throughput_bf16x3' = the opt-in "
                          "split-operand bf16 mode (NOT the headline: `dtype` then reads 'bf16x3 (fp32-"
                          "equivalent)'; the default line reports it under the `bf16x3` key)")
+    ap.add_argument('--eos-retire', action='store_true',
+                    help='timed passes with the inference option N2NMN_S2S_EOS_RETIRE (NOT the headline: the '
+                         'metric text and config.eos_retire say so; the default line reports it under the '
+                         '`eos_retire` key).  For rocprofv3 traces of the retired pass')
+    ap.add_argument('--layouts', default='templates', choices=('templates', 'clevr_like'),
+                    help="ground-truth layout mix of the timed passes ('clevr_like': synth.clevr_like_layout_batch)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     return ap.parse_args()
 
 
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r04_pmc_traffic.json')
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r05_pmc_traffic.json')
 if not os.path.exists(PMC_FILE):
-    PMC_FILE = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
+    PMC_FILE = os.path.join(ROOT, 'profiles', 'r04_pmc_traffic.json')
 PMC_FILE_TRAIN = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_train.json')
 PMC_KERNEL = {'lstm_step': 'lstm_tile_kernel', 'dec_attn': 'dec_attn_question_kernel',
               'pool': 'walk_pool_kernel', 'walk_find': 'walk_find', 'walk_tmap': 'walk_tmap_kernel',
@@ -560,6 +566,9 @@ def main():
     args = parse()
     if args.plain:
         args.no_profile = args.no_cpu_baseline = True
+    elif args.eos_retire or args.layouts != 'templates':
+        sys.exit('bench.py: --eos-retire / --layouts are for --plain runs (tracing); the default line carries '
+                 'the option and both mixes under its `eos_retire` key')
     ensure_world(args, sys.argv[1:])
     own_stdout()
     import numpy as np
@@ -602,7 +611,9 @@ def main():
     eng, sb = pipe.engine, pipe.bucket(0, 0)
     dev = eng.device
     pipe.fill_all(lambda i: synth.make_inputs(d, seed=dp.batch_seed(i)),
-                  lambda i: synth.template_layout_batch(d, offset=i))
+                  (lambda i: synth.template_layout_batch(d, offset=i)) if args.layouts == 'templates' else
+                  (lambda i: synth.clevr_like_layout_batch(d, seed=i)))
+    pipe.eos_retire = bool(args.eos_retire) and use_gt
     buckets = pipe.workers[0]['buckets']
     torch.cuda.synchronize(dev)
 
@@ -623,7 +634,8 @@ def main():
         qps = dp.throughput(K * d.N * args.steps, elapsed)
         out = {
             'metric': 'questions/sec (forward) on CLEVR 10x15x512 feats, client batches of %d served '
-                      'as passes of %d rows (throughput)' % (d.N, K * d.N),
+                      'as passes of %d rows (throughput)%s' %
+                      (d.N, K * d.N, ' -- with the inference option eos_retire' if pipe.eos_retire else ''),
             'value': round(qps, 1), 'unit': 'questions/sec', 'n_gpus': dp.group_size(),
             'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 4),
@@ -652,7 +664,7 @@ def main():
                        'questions_per_step': K * d.N, 'global_batch': world * K * d.N,
                        'streams_per_gpu': S, 'questions_in_flight': S * K * d.N,
                        'passes_per_stream_per_block': args.steps // S,
-                       'lstm_step_mode': pipe.mode,
+                       'lstm_step_mode': pipe.mode, 'eos_retire': bool(pipe.eos_retire), 'layout_mix': args.layouts,
                        'parallelism': 'dp%d (question-sharded, no data-path collective)' % world,
                        # multi-GPU readiness: ranks the process group holds (not the --gpus asked for) and
                        # the slowest / fastest rank's own rate in the last timed block

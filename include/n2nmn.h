@@ -359,6 +359,13 @@ int n2nmn_walk_set_levels(n2nmn_ctx *ctx, int levels);
  * pass), whatever n2nmn_walk_set_levels says.  A layout that breaks the promise is reported INVALID
  * (validity 0, zero logits), never evaluated wrongly.  bound = -1 withdraws the promise. */
 int n2nmn_walk_set_nesting_bound(n2nmn_ctx *ctx, int bound);
+/* on != 0: the NEXT n2nmn_walk_layouts call of this context computes the hoisted conv_image maps of its
+ * batches itself (what n2nmn_conv_image(FIND | FSP, tokens) would have written, same GEMM kernels, same bits)
+ * -- behind the text maps and right in front of walk_find, FindSameProperty's maps first and Find's last, so
+ * the 154 KB per image that walk_find streams is the pass's most recently written data and is served by the
+ * Infinity Cache (walk_find 36.5 -> 29.5 us per 1024 questions).  The caller then leaves image_feat out of
+ * n2nmn_seq2seq_forward and does not call n2nmn_conv_image.  n2nmn_execute_tokens does this by itself. */
+int n2nmn_walk_set_conv_inline(n2nmn_ctx *ctx, int on);
 /* Phase 2 straight from DEVICE tokens (no token fetch, no host assembly): replaces Assembler.assemble +
  * td.Compiler.build_feed_dict + the second partial_run (exp_clevr/eval_clevr.py:121-132,
  * exp_vqa/eval_vqa2.py:103-137).  n2nmn_conv_image(FIND | FSP gated by tokens), then

@@ -104,6 +104,7 @@ SYMBOLS = [
     ('n2nmn_walk_set_staged', _I, [_P, _I]),
     ('n2nmn_walk_set_levels', _I, [_P, _I]),
     ('n2nmn_walk_set_nesting_bound', _I, [_P, _I]),
+    ('n2nmn_walk_set_conv_inline', _I, [_P, _I]),
     ('n2nmn_conv_image', _I, [_P, _P, _I, _I, _P, _I, _P]),
     ('n2nmn_walk_layouts', _I, [_P, C.POINTER(WalkBatch), _I, _I, _I, _I, _P]),
     ('n2nmn_execute_tokens', _I, [_P, _P, _I, _I, _P, _P, _P, _P, _P]),

@@ -277,7 +277,7 @@ const char* kFamilyNames[F_COUNT] = {
   "lstm_step(linear q)", "dec_attn", "gemm_pk(encoder_h_transform)", "word_vecs", "textmap", "gemm_pk(conv_image)",
   "att_ops", "pool", "heads",
   "lstm_bwd_step", "gemm_tn(weight grads)", "backward misc (modules/attention/gemm_nt)",
-  "optimiser", "walk(layout walker)", "gemm_pkn(encoder_h_transform + q + conv_image)",
+  "optimiser", "walk(layout walker)", "gemm_pkn(encoder_h_transform + q [+ conv_image when it rides in phase 1])",
   "walk_find(Find / Filter epilogues over the conv_image maps)", "walk_tmap(text maps from the attention tables)",
   "sched(layout assembler + level scheduler on the device)"};
 
@@ -1721,6 +1721,32 @@ static void walk_staged_launches(const ModuleWeights& w, WalkArgs& a, hipStream_
   launch_walk_light(w, a, s);
 }
 
+// n2nmn_walk_set_conv_inline: the conv_image maps of the walker's batches, computed inside the walker call
+// right before walk_find reads them -- FindSameProperty's (gated by the layouts) first, Find's 154 KB per image
+// LAST, so that what walk_find streams is the most recently written data of the pass and comes back from the
+// Infinity Cache instead of HBM (measured at 1024 questions: walk_find 36.5 -> 29.5 us, the attention-module
+// path 103 -> 96 us, pass time unchanged; profiles/r05_notes.md section 1).
+static void walk_conv_inline(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int N, int T_dec,
+                             hipStream_t s) {
+  const n2nmn_dims& d = c->d;
+  for (int k = 0; k < K; ++k) {
+    n2nmn_ctx* owner = const_cast<n2nmn_ctx*>(batches[k].ctx ? batches[k].ctx : c);
+    GemmArgs ga[2];
+    conv_image_problems(owner, batches[k].image_feat, N, batches[k].tokens, T_dec, ga);
+    std::swap(ga[0], ga[1]);
+    const double HW = d.H * d.W, frac = 1.1;       // gated share: see n2nmn_conv_image
+    ProfScope ps(c, F_CONV_IMAGE, frac * 2.0 * N * HW * d.D * d.map_dim,
+                 frac * 4.0 * N * HW * (d.D + c->Mp) + 4.0 * d.D * d.map_dim, s);
+    launch_gemm_pkn(ga, 2, s);
+  }
+}
+
+int n2nmn_walk_set_conv_inline(n2nmn_ctx* c, int on) {
+  N2_REQUIRE(c, N2NMN_EINVAL, "walk_set_conv_inline: null context");
+  c->walk_conv_inline = on != 0;
+  return N2NMN_OK;
+}
+
 int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int T_dec, int T_enc,
                        int N, n2nmn_stream stream) {
   N2_REQUIRE(c && batches, N2NMN_EINVAL, "walk_layouts: null argument");
@@ -1822,12 +1848,16 @@ int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int
     }
   }
   c->walk_nesting_bound = -1;     // (a promise covers one call)
+  const bool conv_inline = c->walk_conv_inline;
+  c->walk_conv_inline = false;    // (so does the request for the maps)
+  if (conv_inline && !pre) walk_conv_inline(c, batches, K, N, T_dec, s);
   if (pre) {
     a.pre_find = 1;
     {
       ProfScope ps(c, F_WALK_TMAP, 0.0, 0.0, s);
       launch_walk_tmap(w, a, s);
     }
+    if (conv_inline) walk_conv_inline(c, batches, K, N, T_dec, s);   // behind the text maps, in front of their reader
     {
       ProfScope ps(c, F_WALK_FIND, 0.0, 0.0, s);   // bytes from the device counters (walk stats [8])
       launch_walk_find(w, a, s);
@@ -1947,13 +1977,14 @@ int n2nmn_execute_tokens(n2nmn_ctx* c, const int32_t* tokens, int T_dec, int N,
                          int32_t* validity, n2nmn_stream stream) {
   N2_REQUIRE(c && tokens && image_feat && word_vecs && scores, N2NMN_EINVAL,
              "execute_tokens: null argument");
-  int rc = n2nmn_conv_image(c, image_feat, N, N2NMN_CONV_FIND | N2NMN_CONV_FSP, tokens, T_dec,
-                            stream);
-  if (rc != N2NMN_OK) return rc;
   // dimensions outside the walker's tiling (models_vqa): the level path, scheduled on the device
   static const bool force_levels = [] { const char* e = getenv("N2NMN_TOKENS_VIA_LEVELS"); return e && atoi(e) != 0; }();
-  if (!n2nmn_walk_supported(c) || force_levels || c->tokens_via_levels)
+  if (!n2nmn_walk_supported(c) || force_levels || c->tokens_via_levels) {
+    int rc = n2nmn_conv_image(c, image_feat, N, N2NMN_CONV_FIND | N2NMN_CONV_FSP, tokens, T_dec, stream);
+    if (rc != N2NMN_OK) return rc;
     return run_tokens_levels(c, tokens, T_dec, N, image_feat, word_vecs, scores, validity, S(stream));
+  }
+  c->walk_conv_inline = true;     // the walker call computes the maps itself, right before it reads them
   n2nmn_walk_batch b{};
   b.ctx = c; b.tokens = tokens; b.image_feat = image_feat; b.word_vecs = word_vecs;
   b.scores = scores; b.validity = validity;

@@ -234,6 +234,7 @@ struct n2nmn_ctx {
   int32_t* walk_hint_dev = nullptr;
   int walk_hint_prev = 0;
   int walk_levels = 0;                        // n2nmn_walk_set_levels: 0 adaptive, >= 1 fixed
+  bool walk_conv_inline = false;              // n2nmn_walk_set_conv_inline: the NEXT walk_layouts call computes the conv_image maps
   int walk_nesting_bound = -1;                // n2nmn_walk_set_nesting_bound: promise for the NEXT walk_layouts call
   int walk_staged = -1;                       // -1 auto (with the chip-wide front end + deferred pooling), 0 off
   float *arena = nullptr, *tmap = nullptr, *pfc = nullptr, *mfind = nullptr, *mfsp = nullptr;

@@ -366,10 +366,13 @@ class Engine:
             tok.data_ptr() if tok is not None else None, Td, self.stream()))
         return feat
 
-    def walk(self, jobs, N: int, T_dec: int):
+    def walk(self, jobs, N: int, T_dec: int, conv_inline: bool = False):
         """One walker launch over K in-flight batches.  jobs: list of (engine, tokens, image_feat,
         word_vecs, scores, validity) device tensors; `engine` is the (fork of this) engine whose
-        conv_image() was called for that batch."""
+        conv_image() was called for that batch -- or, with conv_inline, nobody's: the walker call computes
+        the maps itself right in front of their reader (n2nmn_walk_set_conv_inline)."""
+        if conv_inline:
+            _lib.check(self._lib.n2nmn_walk_set_conv_inline(self._ctx, 1))
         arr = (_lib.WalkBatch * len(jobs))()
         T_enc = 0
         for i, job in enumerate(jobs):
@@ -415,11 +418,9 @@ class Engine:
                                                       wv.data_ptr(), scores.data_ptr(), validity.data_ptr(),
                                                       self.stream()))
             return scores, validity
-        if not conv_done:
-            self.conv_image(feat, tok, Td)
         # atts = (atts [T_dec, T_enc, N], input_seq [T_enc, N], seq_length [N]): text maps from the
         # decoder's attention and the commit-time (embedding . W_txt) tables; word_vecs not needed
-        self.walk([(self, tok, feat, wv, scores, validity, atts)], N, Td)
+        self.walk([(self, tok, feat, wv, scores, validity, atts)], N, Td, conv_inline=not conv_done)
         return scores, validity
 
     def module_forward(self, name: str, inputs, time_idx, batch_idx, image_feat, word_vecs):
@@ -563,13 +564,17 @@ class Engine:
                     self.conv_image(feat, gt_dev if known else None, T_dec, find=True, fsp=known)
                     self._side_ev.record(self._side)
             table = self.dims.num_vocab_txt <= 4096
+            # passes of many questions: the conv_image GEMM leaves phase 1's merged launch and runs inside the
+            # walker call, right in front of walk_find (its maps then come back from the Infinity Cache); one
+            # batch of 64 keeps the merged launch (one launch fewer on the latency path)
+            conv_late = (not self.overlap_conv) and feat.shape[0] >= 128
             retire = bool(eos_retire) and known and table and sample_uniforms is None
             glen = batch.get('gt_length_host') if retire else None
             if retire and glen is None and isinstance(gt_layout, np.ndarray):
                 glen = self.layout_lengths(gt_layout)
             s2s = self.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], T_dec,
                                use_gt_layout, gt_dev, sample_uniforms, word_vecs=not table,
-                               image_feat=None if self.overlap_conv else feat,
+                               image_feat=None if (self.overlap_conv or conv_late) else feat,
                                out_tokens=None if out is None else out[1],
                                seq_len_host=batch.get('seq_length_host'),
                                eos_retire=retire, gt_len_host=glen)
@@ -588,7 +593,7 @@ class Engine:
             if nest is not None:
                 self.set_nesting_bound(int(nest))
             scores, validity = self.execute_tokens(
-                s2s['predicted_tokens'], feat, s2s.get('word_vecs'), conv_done=True,
+                s2s['predicted_tokens'], feat, s2s.get('word_vecs'), conv_done=not conv_late,
                 atts=(s2s['atts'], s2s['_input_seq'], s2s['_seq_length']) if table else None,
                 out=None if out is None else (out[0], out[2]))
             if not fetch:

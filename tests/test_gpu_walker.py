@@ -533,3 +533,40 @@ def test_nesting_bound_from_host_layouts_launches_exact_levels_and_no_fallback(c
     assert deep[1] and not deep[2] and 0 < deep.sum() < d.N
     assert np.array_equal(broken[1].astype(bool), ~deep)
     assert np.all(broken[0][deep] == 0) and np.array_equal(broken[0][~deep], ref[0][~deep])
+
+
+@pytest.mark.parametrize('front', [0, 1])
+def test_conv_image_inside_the_walker_call_equals_the_separate_launch(clevr_engine, front):
+    """n2nmn_walk_set_conv_inline: the walker call computes the hoisted conv_image maps itself (behind the text
+    maps, FindSameProperty's first, Find's last -- right in front of their reader).  Same GEMM kernels on the
+    same operands as n2nmn_conv_image: the logits must be the same BITS, with the chip-wide front end and
+    without it, and the request covers one call only."""
+    eng, d, asm, w = clevr_engine
+    batch = synth.make_inputs(d, seed=58, min_len=1)
+    toks = synth.template_layout_batch(d, offset=4)
+    s2s = eng.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], forced_tokens=toks,
+                      reuse_buffers=False, word_vecs=False)
+    import torch
+    feat = torch.as_tensor(batch['image_feat_batch']).cuda()
+    other = torch.as_tensor(synth.make_inputs(d, seed=59)['image_feat_batch']).cuda()
+
+    def run(conv_done):
+        sc, v = eng.execute_tokens(s2s['predicted_tokens'], feat, None, reuse_buffers=False, conv_done=conv_done,
+                                   atts=(s2s['atts'], s2s['_input_seq'], s2s['_seq_length']))
+        return t2n(sc).copy(), t2n(v).copy()
+    try:
+        eng.set_front_end(front)
+        eng.set_defer_pool(front)
+        eng.conv_image(feat, s2s['predicted_tokens'])
+        sep = run(True)
+        eng.conv_image(other, s2s['predicted_tokens'])       # stale maps of other images in the workspace
+        inl = run(False)
+        eng.conv_image(other, s2s['predicted_tokens'])
+        stale = run(True)                                    # the request is spent: this reads the maps as they lie
+    finally:
+        eng.set_front_end(-1)
+        eng.set_defer_pool(-1)
+    assert np.array_equal(inl[0], sep[0]) and np.array_equal(inl[1], sep[1])
+    assert not np.array_equal(stale[0], sep[0]), 'a request for the maps must cover ONE walker call'
+    ref = O.forward(w, NAMES, batch, d.T_decoder, d.num_choices, np.float64, forced_tokens=toks)
+    assert_close('vs oracle', inl[0], ref['scores'], TOL)
