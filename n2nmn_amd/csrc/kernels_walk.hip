@@ -2176,7 +2176,7 @@ void launch_walk_heavy(const ModuleWeights& w, const WalkArgs& a, hipStream_t s)
 // Second launch of level a.hlevel: FindSameProperty stage B
 void launch_walk_fspepi(const ModuleWeights& w, const WalkArgs& a, hipStream_t s) {
   const int cap = (a.hoff[a.hlevel + 1] - a.hoff[a.hlevel]) / 2;
-  const int grid = (int)std::min<long>(1024, std::max<long>(1, (long)cap * WALK_FIND_PARTS));
+  const int grid = (int)std::min<long>(1024, std::max<long>(1, (long)cap * WALK_FIND_PARTS));   // (768: +1.2 us; 1536 / 2048: no change)
   if (a.Mp <= 256) hipLaunchKernelGGL(walk_fspepi_kernel<1>, dim3(grid), dim3(HT), 0, s, w, a);
   else hipLaunchKernelGGL(walk_fspepi_kernel<4>, dim3(grid), dim3(HT), 0, s, w, a);
 }
