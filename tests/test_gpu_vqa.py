@@ -115,3 +115,26 @@ def test_vqa_pass_of_several_batches_equals_single_batches(vqa_setup):
     ref = O.forward_vqa(w, parts[0], d.T_decoder, d.num_choices, np.float64, use_gt_layout=True,
                         gt_layout=gts[0])
     assert_close('slot 0 vs oracle', got[:d.N], ref['scores'], TOL)
+
+
+def test_resident_feature_slab_equals_add_coords_per_pass(vqa_setup):
+    """VQAEngine.feature_slab: the input slab [N, 14, 14, 2064] carries the two coordinate channels of
+    add_spatial_coordinate_map (models_vqa/nmn3_modules.py:11-31; constants) and the zero padding, written once;
+    a client fills the 2048 image channels.  A pass on the slab is bit-identical to a pass that appends the
+    coordinates itself (n2nmn_add_coords per call), for two different batches written into the same slab, and a
+    tensor of slab width that is not a slab is refused."""
+    import torch
+    eng, d, w = vqa_setup
+    gt = _gt(eng, d)
+    slab = eng.feature_slab(d.N)
+    for seed in (3, 4):
+        batch = _batch(d, seed)
+        want, _, _ = eng.forward(batch, use_gt_layout=True, gt_layout=gt)
+        want = t2n(want).copy()
+        slab[..., :d.D].copy_(torch.as_tensor(batch['image_feat_batch']).to(slab.device))
+        with_c = t2n(eng.features_with_coords(batch['image_feat_batch'])).copy()
+        assert np.array_equal(t2n(slab), with_c), 'slab layout differs from n2nmn_add_coords'
+        got, tokens, validity = eng.forward(dict(batch, image_feat_batch=slab), use_gt_layout=True, gt_layout=gt)
+        assert validity.all() and np.array_equal(t2n(got), want)
+    with pytest.raises(ValueError):
+        eng.forward(dict(batch, image_feat_batch=torch.zeros_like(slab)), use_gt_layout=True, gt_layout=gt)
