@@ -844,6 +844,26 @@ def main():
                     rr = kernel_rows(eng.profile_end(), 4)
                     row['kernels'] = [r for r in rr if r['kernel'].startswith(('lstm_step(dec', 'dec_attn', 'gemm_pkn'))]
                 er['mixes'][name] = row
+            # layouts the greedy decoder chooses (config 3): rows leave the recurrence as they emit <eos>
+            # (dec_compact_kernel after every step); tokens and logits must equal the full decoder's
+            def greedy_rate(retire):
+                pipe.eos_retire = retire
+                run_steps(2 * S, gt=False)
+                t = wall(lambda: run_steps(npass, gt=False), 3, warm=1)
+                b = pipe.workers[0]['buckets'][(pipe.workers[0]['next'] - 1) % 2]
+                return npass * K * d.N / t, 1e3 * t / npass, b.result(0)[0].cpu().numpy().copy(), \
+                    b.tokens.cpu().numpy().copy()
+            gf = greedy_rate(False)
+            gr = greedy_rate(True)
+            glen = np.where((gr[3] == asm.EOS_idx).any(0), (gr[3] == asm.EOS_idx).argmax(0), d.T_decoder)
+            er['config3_passes'] = {
+                'value': round(gr[0], 1), 'ms_per_step': round(gr[1], 4),
+                'full_decoder_value': round(gf[0], 1), 'vs_full_decoder': round(gr[0] / gf[0], 4),
+                'mean_layout_length': round(float(glen.mean()), 2), 'max_layout_length': int(glen.max()),
+                'tokens_equal': bool(np.array_equal(gr[3], gf[3])),
+                'max_abs_logit_diff_vs_full_decoder': float(np.abs(gr[2] - gf[2]).max()),
+                'note': 'layouts chosen by the RANDOM-weight synthetic decoder (bimodal: most end after 2 tokens, '
+                        'the rest run to 18-19); a trained decoder emits the layout-length histogram of the data'}
         finally:
             pipe.eos_retire = False
             set_layouts(mixes[0][1])

@@ -203,7 +203,14 @@ typedef struct {
  * over all steps) are not meaningful.  The full outputs (all T_dec steps; training
  * and the debug fetches need them) come from a call without the flag -- n2nmn_decoder_forward on the
  * same context recomputes them from the encoder results it holds.  Where the preconditions do not hold
- * the flag is ignored. */
+ * the flag is ignored.
+ * Layouts the decoder chooses itself (greedy / sampled decoding; >= 128 and <= 1024 rows, exact-fp32
+ * throughput mode, lstm_dim 512): the lengths are only known step by step -- a row is finished once it has
+ * emitted <eos>, after which the validity automaton allows nothing but <eos> (nmn3_netgen_att.py:8-15,
+ * nmn3_assembler.py:94-117).  After every step the state rows are re-partitioned on the device (live rows
+ * to the front, dec_compact_kernel) and the next step's launches run over that prefix; finished rows get
+ * their <eos> tokens without a recurrent step.  Same contract: predicted_tokens complete and identical to the
+ * full decoder's, atts / token_probs for live (row, step) pairs only. */
 #define N2NMN_S2S_EOS_RETIRE 2
 
 int n2nmn_encoder_forward(n2nmn_ctx *ctx, const n2nmn_seq2seq_io *io, n2nmn_stream stream);

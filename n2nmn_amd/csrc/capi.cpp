@@ -568,8 +568,7 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
   float* negent = io->neg_entropy ? io->neg_entropy : c->negent;
   float* atts = io->atts ? io->atts : c->atts;
   float* wv = io->word_vecs ? io->word_vecs : c->word_vecs;
-  const double fl0 = 2.0 * N * L * 4 * L, by0 = 4.0 * ((double)L * 4 * L + 3.0 * N * L);
-  const double fl1 = 2.0 * N * 2 * L * 4 * L, by1 = 4.0 * (2.0 * L * 4 * L + 5.0 * N * L);
+  const double fl0 = 2.0 * N * L * 4 * L, fl1 = 2.0 * N * 2 * L * 4 * L;
   DecStepArgs a{};
   a.eht = c->eht; a.eout = c->enc_out; a.seq_len = c->enc_len; a.v = c->vars[V_ATT_V].mirror;
   a.order = c->perm;            // enc_prepare's length ranking of this pass's rows
@@ -813,20 +812,48 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
       launch_gemm_pkn(list, nl, s);
     }
     launch_dec_init(c->state, N, Td, s);
+    // ---- eos_retire for sequential decoding: a row that has emitted <eos> leaves the recurrence.  After
+    // every step dec_compact_kernel re-partitions the state rows (live ones in front, gathered into the
+    // alternate state buffers) and the launches of the next step run over that dense prefix; the host
+    // issues every launch (it never learns the counts) and the workgroups past the prefix return at once.
+    // Inference only, >= 128 rows in the exact-fp32 throughput mode, dec_attn_seq_kernel's dimensions.
+    a.q = c->qbuf; a.out = c->dh1_rm;
+    const bool retire_seq = (io->flags & N2NMN_S2S_EOS_RETIRE) && !c->rec && !io->drop_dec0 &&
+                            !io->token_scores && !io->forced_tokens && !io->use_gt_layout && lstm_wide(c) >= 2 && N >= 128 && !lstm_b3(c, N) &&
+                            root(c)->have_token_ops && root(c)->eos_token >= 0 && dec_seq_retire_supported(a);
+    c->dec_retired = retire_seq;
+    // state buffers of the loop: h ping-pongs as always; c is updated in place in cb0 / cb1; a compaction
+    // moves all four into their alternates (block B's dropout buffers are free without dropout)
+    float* hb0[2] = {c->dh0[0], c->dh0[1]};
+    float* hb1[2] = {c->dh1[0], c->dh1[1]};
+    float* cb0[2] = {c->dc0, c->dhd[0]};
+    float* cb1[2] = {c->dc1, c->dhd[1]};
+    int32_t* pbuf[2] = {c->dperm, c->drows};
+    int h0w = 0, h1w = 0, c0i = 0, c1i = 0, pi = 0;     // buffer step t WRITES h into; buffer holding c; perm in use
     for (int t = 0; t < Td; ++t) {
+      const int32_t* live_perm = retire_seq && t > 0 ? pbuf[pi] : nullptr;
+      const int32_t* live_n = retire_seq && t > 0 ? c->dnact + t : nullptr;
+      double live = N;                     // rows the recurrent launches compute, for the profile counters
+      if (live_n && c->prof_on) {          // (a profiled pass may synchronise)
+        int32_t nl = N;
+        N2_HIP(hipStreamSynchronize(s));
+        N2_HIP(hipMemcpy(&nl, live_n, sizeof(int32_t), hipMemcpyDeviceToHost));
+        live = std::min(N, round_up(std::max(nl, 0), 16));
+      }
       LstmJob j0{};
       j0.active = 1;
       packed_state(c, j0);
-      j0.A0 = t == 0 ? c->fh0 : c->dh0[(t + 1) & 1]; j0.K = L; j0.Wp = c->dec_W0h_t; j0.Wp64 = c->dec_W0h_64;
+      j0.A0 = t == 0 ? c->fh0 : hb0[h0w ^ 1]; j0.K = L; j0.Wp = c->dec_W0h_t; j0.Wp64 = c->dec_W0h_64;
       j0.ntiles = L / 4;
       j0.xtab = c->dec_xtab; j0.xidx = t == 0 ? nullptr : c->next_idx; j0.xidx_const = V;  // <go>
-      j0.c_in = t == 0 ? c->fc0 : c->dc0; j0.c_out = c->dc0;
-      j0.h_old = j0.A0; j0.h_new = c->dh0[t & 1];
+      j0.c_in = t == 0 ? c->fc0 : cb0[c0i]; j0.c_out = cb0[c0i];
+      j0.h_old = j0.A0; j0.h_new = hb0[h0w];
+      j0.perm = live_perm; j0.n_active = live_n;
       if (io->drop_dec0) {             // sampling from the network with dropout (policy gradient)
         j0.drop = io->drop_dec0 + (size_t)t * N * L; j0.h_drop = c->dhd[t & 1];
       }
       {
-        ProfScope ps(c, F_LSTM_DEC0, fl0, by0, s);
+        ProfScope ps(c, F_LSTM_DEC0, fl0 * live / N, 4.0 * ((double)L * 4 * L + 3.0 * live * L), s);
         // (throughput mode, >= 128 rows: the 64 x 64 LDS-DMA tiles, one round of 512 workgroups per
         // layer -- the greedy decoder's two layers cannot share a launch, token t feeds layer 0 of t+1)
         if (lstm_b3(c, N)) {
@@ -840,14 +867,15 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
       LstmJob j1{};
       j1.active = 1;
       packed_state(c, j1);
-      j1.out_seq = c->dh1_rm;          // row-major copy of the top-layer h for dec_attn
-      j1.A0 = io->drop_dec0 ? c->dhd[t & 1] : c->dh0[t & 1];
-      j1.A1 = t == 0 ? c->fh1 : c->dh1[(t + 1) & 1]; j1.K = 2 * L;
+      j1.out_seq = c->dh1_rm;          // row-major copy of the top-layer h for dec_attn (by ORIGINAL row)
+      j1.A0 = io->drop_dec0 ? c->dhd[t & 1] : hb0[h0w];
+      j1.A1 = t == 0 ? c->fh1 : hb1[h1w ^ 1]; j1.K = 2 * L;
       j1.Wp = c->dec_W1_t; j1.Wp64 = c->dec_W1_64; j1.ntiles = L / 4; j1.bias = c->dec_b1_t;
-      j1.c_in = t == 0 ? c->fc1 : c->dc1; j1.c_out = c->dc1;
-      j1.h_old = j1.A1; j1.h_new = c->dh1[t & 1];
+      j1.c_in = t == 0 ? c->fc1 : cb1[c1i]; j1.c_out = cb1[c1i];
+      j1.h_old = j1.A1; j1.h_new = hb1[h1w];
+      j1.perm = live_perm; j1.n_active = live_n;
       {
-        ProfScope ps(c, F_LSTM_DEC1, fl1, by1, s);
+        ProfScope ps(c, F_LSTM_DEC1, fl1 * live / N, 4.0 * (2.0 * L * 4 * L + 5.0 * live * L), s);
         if (lstm_b3(c, N)) {
           attach_planes(c, j1);
           N2_REQUIRE(lstm_tile3_supported(&j1, 1, L), N2NMN_EINVAL, "decoder_forward: bf16x3 mode: unsupported job");
@@ -859,7 +887,7 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
       LstmJob jq{};                    // q = out . W_a + b_a            (nmn3_netgen_att.py:185)
       packed_state(c, jq);
       jq.hp_R = 0;
-      jq.active = 1; jq.mode = 1; jq.A0 = c->dh1[t & 1]; jq.K = L; jq.Wp = c->att_W_t;
+      jq.active = 1; jq.mode = 1; jq.A0 = hb1[h1w]; jq.K = L; jq.Wp = c->att_W_t;     // (q in STATE-row order)
       jq.ntiles = L / 16; jq.bias = c->vars[V_ATT_B].mirror; jq.h_new = c->qbuf; jq.ldo = L;
       {
         ProfScope ps(c, F_LINEAR_Q, 2.0 * N * L * L, 4.0 * ((double)L * L + 2.0 * N * L), s);
@@ -873,9 +901,19 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
       a.ent_t = c->ent_t + (size_t)t * N; a.atts = atts + (size_t)t * T * N;
       a.scores = io->token_scores ? io->token_scores + (size_t)t * N * V : nullptr;
       a.next_idx = c->next_idx;
+      a.live_perm = live_perm; a.live_n = live_n; a.eos_token = root(c)->eos_token;
       {
-        ProfScope ps(c, F_DEC_STEP, att_fl, att_by, s);
+        ProfScope ps(c, F_DEC_STEP, att_fl * live / N, att_by * live / N, s);
         launch_dec_attn(a, 1, s);
+      }
+      h0w ^= 1; h1w ^= 1;
+      if (retire_seq && t + 1 < Td) {
+        // rows whose token of this step is <eos> retire: live rows to the front of the alternate buffers
+        const float* src[4] = {hb0[h0w ^ 1], cb0[c0i], hb1[h1w ^ 1], cb1[c1i]};
+        float* dst[4] = {hb0[h0w], cb0[c0i ^ 1], hb1[h1w], cb1[c1i ^ 1]};
+        launch_dec_compact(a.tokens, root(c)->token_op, V, live_perm, live_n, pbuf[pi ^ 1], c->dnact + t + 1,
+                           src, dst, N, L, d.N, s);
+        h0w ^= 1; h1w ^= 1; c0i ^= 1; c1i ^= 1; pi ^= 1;
       }
     }
     if (io->image_feat) {              // FindSameProperty maps of the layouts the decoder chose
@@ -1635,6 +1673,8 @@ int n2nmn_set_token_ops(n2nmn_ctx* ctx, const int32_t* token_op_host, int V) {
                N2NMN_EKEY, "set_token_ops: unknown op code");
   N2_HIP(hipMemcpy(ctx->token_op, token_op_host, sizeof(int32_t) * V, hipMemcpyHostToDevice));
   ctx->have_token_ops = true;
+  ctx->eos_token = -1;
+  for (int i = 0; i < V; ++i) if (token_op_host[i] < 0) { ctx->eos_token = i; break; }
   return N2NMN_OK;
 }
 

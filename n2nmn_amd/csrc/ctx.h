@@ -195,6 +195,7 @@ struct n2nmn_ctx {
   int32_t *P = nullptr, *Wv = nullptr, *bv = nullptr;
   int32_t* token_op = nullptr;             // [V] op code per layout token (-1: <eos>), device
   bool have_token_ops = false;
+  int eos_token = -1;                      // the token whose op code is < 0 (<eos>), host copy
 
   // seq2seq workspace
   float *eh0[2] = {nullptr, nullptr}, *eh1[2] = {nullptr, nullptr}, *ec0 = nullptr, *ec1 = nullptr;

@@ -213,11 +213,21 @@ struct DecStepArgs {
   // eos_retire (teacher-forced passes: dec_attn_question_kernel / dec_attn_multi_kernel): live decoder steps per question;
   // steps at or past it get their token from `gt` and nothing else.  nullptr: every step of every question
   const int32_t* dec_len;  // [N]
+  // eos_retire, sequential decoding (dec_attn_seq_kernel; dec_compact_kernel builds these after every step):
+  // workgroup j serves original row live_perm[j]; j >= *live_n: the row has emitted <eos> and gets eos_token.
+  // q is read at state row j, every other operand by original row.  nullptr: all rows live, identity
+  const int32_t* live_perm;
+  const int32_t* live_n;
+  int eos_token;
 };
 // can launch_dec_attn serve this launch with dec_attn_question_kernel (the kernel that honours dec_len)?
 bool dec_question_supported(const DecStepArgs& a, int nsteps);
 bool dec_len_supported(const DecStepArgs& a, int nsteps);
 // eos_retire helpers (kernels_seq2seq.hip): layout lengths from the tokens; state rows gathered by `perm`
+bool dec_seq_retire_supported(const DecStepArgs& a);
+void launch_dec_compact(const int32_t* tokens, const int32_t* token_op, int V, const int32_t* perm_old,
+                        const int32_t* n_old, int32_t* perm_new, int32_t* n_new, const float* const src[4],
+                        float* const dst[4], int N, int L, int R, hipStream_t s);
 void launch_dec_len(const int32_t* tokens, const int32_t* token_op, int V, int T_dec, int N,
                     int32_t* dec_len, hipStream_t s);
 void launch_gather_state(const float* const src[4], float* const dst[4], const uint16_t* const srcb[2],

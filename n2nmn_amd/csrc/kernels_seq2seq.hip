@@ -713,11 +713,24 @@ __global__ __launch_bounds__(1024, 2) void dec_attn_seq_kernel(DecStepArgs a) {
   float* es = ctxp + (size_t)NW * L;  // [Tp] raw scores of the rows inside the length
   float* ms = es + Tp;                // [NW][2] running (max, sum) of each wave, then [2 NW ..] merge weights
   float* red = ms + 4 * NW;           // [NW][MAXV]
-  const int n = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // eos_retire: workgroup j serves state row j = original row live_perm[j]; rows at or past *live_n have
+  // emitted <eos> and get <eos> again -- what the automaton would force (dec_compact_kernel)
+  int n = blockIdx.x;
+  size_t qr = n;                                    // q lives in STATE-row order, everything else by original row
+  if (a.live_n) {
+    n = a.live_perm[blockIdx.x];
+    if ((int)blockIdx.x >= *a.live_n) {
+      if (tid == 0) {
+        a.tokens[n] = a.eos_token; a.tprobs[n] = 1.0f; a.ent_t[n] = 0.f;
+        if (a.next_idx) a.next_idx[n] = a.eos_token;
+      }
+      return;
+    }
+  }
   const int len = min(max(a.seq_len[n], 0), T);
   const size_t tn = n;                              // (one step per launch: step offset 0)
-  const float* qrow = a.q + tn * L;
+  const float* qrow = a.q + qr * L;
   const float* orow = a.out + tn * L;
   for (int k = tid; k < L; k += NT) outs[k] = orow[k];
 
@@ -1421,6 +1434,91 @@ __global__ __launch_bounds__(256) void gather_state_kernel(GatherArgs g) {
   }
 }
 
+// eos_retire for sequential (greedy / sampled) decoding.  A row is finished once it has emitted its answer
+// operator (the validity automaton then allows nothing but <eos>, nmn3_netgen_att.py:8-15 with
+// nmn3_assembler.py:94-117) or <eos> itself, but which rows those are is only known step by step.  After the attention launch of step t this kernel
+// re-partitions the decoder's state rows: live rows (token of step t is neither) keep their relative order
+// in front, their four state arrays (h, c of both layers, k-interleaved [L/4][R][4]) are gathered into the
+// alternate buffers, the finished rows follow in `perm_new` (so that the attention launch can still give each of
+// them its <eos> token), and the live count lands in *n_new -- the recurrent launches of step t + 1 then run
+// over a dense prefix exactly as the encoder does behind enc_prepare (LstmJob::perm / n_active).
+// Every workgroup recomputes the partition of the <= 1024 rows (256 threads x 4 positions, one block scan)
+// and copies 64 new positions x a k-slice, rows across lanes as gather_state_kernel does.
+struct CompactArgs {
+  const int32_t* tokens;      // [N] tokens of step t, by ORIGINAL row
+  const int32_t* token_op;    // [V] operator of a token, < 0 for <eos>
+  const int32_t* perm_old;    // [N] state row -> original row, or nullptr (identity)
+  const int32_t* n_old;       // live rows before this step's tokens, or nullptr (N)
+  int32_t* perm_new;          // [N]
+  int32_t* n_new;
+  const float* src[4]; float* dst[4];
+  int N, L, R, V;
+};
+__global__ __launch_bounds__(256) void dec_compact_kernel(CompactArgs g) {
+  __shared__ int src_of[1024];              // new position -> old position (live rows)
+  __shared__ int dead_of[1024];             // rank among the finished rows of [0, n_old) -> old position
+  __shared__ int wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int N = g.N;
+  const int n_old = g.n_old ? min(max(*g.n_old, 0), N) : N;
+  int live[4], cnt = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = 4 * tid + i;
+    live[i] = 0;
+    if (j < n_old) {
+      const int n = g.perm_old ? g.perm_old[j] : j;
+      const int tok = g.tokens[n];
+      // live = the layout is not complete: no <eos> and no answer operator yet.  Behind an answer operator
+      // the automaton allows only <eos> (verified over 47 k reachable states, tests/test_layout_nesting.py),
+      // so the row's remaining tokens are known without running its steps
+      const int op = (tok >= 0 && tok < g.V) ? g.token_op[tok] : -1;
+      live[i] = (op >= 0 && !(op >= N2NMN_OP_EXIST && op <= N2NMN_OP_DESCRIBE)) ? 1 : 0;
+    }
+    cnt += live[i];
+  }
+  // exclusive scan of cnt over the 256 threads
+  int incl = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int v = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += v;
+  }
+  if (lane == 63) wsum[w] = incl;
+  __syncthreads();
+  int base = incl - cnt, total = 0;
+#pragma unroll
+  for (int ww = 0; ww < 4; ++ww) { if (ww < w) base += wsum[ww]; total += wsum[ww]; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = 4 * tid + i;
+    if (j < n_old) {
+      if (live[i]) src_of[base] = j; else dead_of[j - base] = j;     // (j - base = finished rows in front of j)
+      base += live[i];
+    }
+  }
+  __syncthreads();
+  if (blockIdx.y == 0) {                    // the permutation: 64 positions per workgroup column
+    if (blockIdx.x == 0 && tid == 0) *g.n_new = total;
+    const int p = blockIdx.x * 64 + lane;
+    if (w == 0 && p < N) {
+      const int jo = p < total ? src_of[p] : (p < n_old ? dead_of[p - total] : p);
+      g.perm_new[p] = g.perm_old ? g.perm_old[jo] : jo;
+    }
+  }
+  const int p = blockIdx.x * 64 + lane;
+  if (p >= total) return;
+  const int jo = src_of[p];
+  const int k4n = g.L / 4;
+  for (int k4 = blockIdx.y * 4 + w; k4 < k4n; k4 += gridDim.y * 4) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 v = *reinterpret_cast<const float4*>(g.src[i] + ((size_t)k4 * g.R + jo) * 4);
+      *reinterpret_cast<float4*>(g.dst[i] + ((size_t)k4 * g.R + p) * 4) = v;
+    }
+  }
+}
+
 __global__ void dec_init_kernel(int32_t* state, int N, int T_dec) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n < N) {
@@ -1673,6 +1771,22 @@ void launch_enc_prepare(const int32_t* seq_len, int N, int T, int32_t* perm, int
   blocks = std::max(blocks, std::min(64, (N + 255) / 256 + T / 4));
   hipLaunchKernelGGL(enc_prepare_kernel, dim3(blocks), dim3(256), 0, s, seq_len, N, T, perm, n_active,
                      reinterpret_cast<float4*>(zero), zero ? z4 : 0, zero_int);
+}
+
+bool dec_seq_retire_supported(const DecStepArgs& a) {     // the one-step launches go to dec_attn_seq_kernel
+  static const bool seq_on = [] { const char* e = getenv("N2NMN_DEC_ATTN_SEQ"); return !e || atoi(e) != 0; }();
+  return seq_on && a.L == 512 && a.N <= 1024;
+}
+
+void launch_dec_compact(const int32_t* tokens, const int32_t* token_op, int V, const int32_t* perm_old,
+                        const int32_t* n_old, int32_t* perm_new, int32_t* n_new, const float* const src[4],
+                        float* const dst[4], int N, int L, int R, hipStream_t s) {
+  CompactArgs g{};
+  g.tokens = tokens; g.token_op = token_op; g.V = V; g.perm_old = perm_old; g.n_old = n_old;
+  g.perm_new = perm_new; g.n_new = n_new;
+  for (int i = 0; i < 4; ++i) { g.src[i] = src[i]; g.dst[i] = dst[i]; }
+  g.N = N; g.L = L; g.R = R;
+  hipLaunchKernelGGL(dec_compact_kernel, dim3((N + 63) / 64, std::min(32, std::max(1, L / 16))), dim3(256), 0, s, g);
 }
 
 void launch_dec_len(const int32_t* tokens, const int32_t* token_op, int V, int T_dec, int N,

@@ -540,8 +540,9 @@ class Engine:
         by construction (models_clevr/nmn3_netgen_att.py:236-238), so the program is assembled
         from the host copy up front and the step has no host synchronisation at all.
 
-        eos_retire (device path, use_gt_layout): inference option N2NMN_S2S_EOS_RETIRE -- the decoder
-        runs a row only up to its layout's first <eos>; scores / tokens / validity are bit-identical to
+        eos_retire (device path): inference option N2NMN_S2S_EOS_RETIRE -- the decoder
+        runs a row only up to its layout's first <eos> (teacher-forced layouts: rows ranked by length up
+        front; layouts the decoder chooses: rows leave the recurrence as they emit <eos>); scores / tokens / validity are bit-identical to
         the full decoder's (the fetches of exp_clevr/eval_clevr.py:103-135), the decoder's own outputs for
         the steps behind it are computed on demand (`decoder_outputs`)."""
         if self.walk_supported() and not host_assemble:
@@ -568,9 +569,10 @@ class Engine:
             # walker call, right in front of walk_find (its maps then come back from the Infinity Cache); one
             # batch of 64 keeps the merged launch (one launch fewer on the latency path)
             conv_late = (not self.overlap_conv) and feat.shape[0] >= 128
-            retire = bool(eos_retire) and known and table and sample_uniforms is None
-            glen = batch.get('gt_length_host') if retire else None
-            if retire and glen is None and isinstance(gt_layout, np.ndarray):
+            # (teacher-forced: rows ranked by layout length up front; greedy / sampled: rows leave as they emit <eos>)
+            retire = bool(eos_retire) and table and (known or not use_gt_layout)
+            glen = batch.get('gt_length_host') if (retire and known) else None
+            if retire and known and glen is None and isinstance(gt_layout, np.ndarray):
                 glen = self.layout_lengths(gt_layout)
             s2s = self.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], T_dec,
                                use_gt_layout, gt_dev, sample_uniforms, word_vecs=not table,

@@ -44,7 +44,7 @@ class PassPipeline:
         self._start = threading.Barrier(self.S + 1)
         self._done = threading.Barrier(self.S + 1)
         self._state = {'stop': False, 'gt': False, 'err': None}
-        self.eos_retire = False        # inference option of teacher-forced passes (SuperBucket.run)
+        self.eos_retire = False        # inference option N2NMN_S2S_EOS_RETIRE of the passes (SuperBucket.run)
         if self.S > 1:
             for wk in self.workers:
                 t = threading.Thread(target=self._worker_main, args=(wk,), daemon=True)
@@ -70,7 +70,7 @@ class PassPipeline:
             b = wk['buckets'][wk['next'] % 2]
             wk['next'] += 1
             b.run(use_gt_layout=gt, n_slots=n, host_assemble=self.host_assemble,
-                  eos_retire=self.eos_retire and gt and not self.host_assemble)
+                  eos_retire=self.eos_retire and not self.host_assemble)
 
     def _worker_main(self, wk):
         torch = _torch()

@@ -130,7 +130,7 @@ class SuperBucket:
         """One pass over the first n_slots slots (default: all K).  Returns (scores [n*Nb, C], tokens
         [T_dec, n*Nb], validity [n*Nb]) device tensors owned by this bucket (one set per pass width,
         overwritten by the next pass of that width); nothing synchronises.  eos_retire: Engine.forward's
-        inference option (teacher-forced passes: rows leave the decoder at their layout's first <eos>)."""
+        inference option (rows leave the decoder at their layout's first <eos>)."""
         n = self.K if n_slots is None else int(n_slots)
         if not 1 <= n <= self.K:
             raise ValueError('n_slots %d out of range [1, %d]' % (n, self.K))
@@ -156,7 +156,7 @@ class SuperBucket:
             self.scores, self.tokens, self.validity = self.engine.forward(
                 batch, T_dec=T_dec, use_gt_layout=use_gt_layout, gt_layout=gt,
                 sample_uniforms=sample_uniforms, fetch=False, out=self._results(n, Td),
-                eos_retire=eos_retire and use_gt_layout)
+                eos_retire=eos_retire)
         self.n_run = n
         return self.scores, self.tokens, self.validity
 

@@ -156,3 +156,48 @@ def test_flag_is_ignored_where_its_preconditions_fail(clevr_engine):
     out = eng.decoder_outputs()
     ref = O.forward(w, NAMES, batch, d.T_decoder, d.num_choices, np.float64, use_gt_layout=True, gt_layout=gt)
     assert_close('atts', t2n(out['atts']), ref['dec']['atts'][..., 0], 1e-4)
+
+
+@pytest.mark.parametrize('n_slots', [16, 3])
+def test_greedy_retired_pass_equals_the_full_greedy_pass(bucket, n_slots):
+    """Layouts the decoder chooses itself: a row leaves the recurrence once it has emitted <eos> (after every
+    step dec_compact_kernel moves the live rows to the front and the next step runs over that prefix).  The
+    recurrent tile computes a row's dot products in the same order wherever the row sits, so tokens, validity
+    AND logits of a retired pass equal the full decoder's in every slot -- bit for bit -- at 1024 rows and at
+    192; the decoder's outputs at all steps come on demand and equal the fp64 oracle given the GPU's tokens."""
+    sb, d, w, batches = bucket
+    eng = sb.engine
+    asm = eng.assembler
+    for k in range(n_slots):
+        sb.fill(k, batches[k])
+    eng.set_mode('throughput')
+    eng.set_walk_levels(d.T_decoder - 1)     # (decoder-chosen layouts nest: a fixed level count makes the walker's
+    try:                                     #  route, and with it the last bits of the logits, independent of history)
+        full = _pass_greedy(sb, False, n_slots)
+        got = _pass_greedy(sb, True, n_slots)
+        again = _pass_greedy(sb, True, n_slots)
+        s2s = eng.decoder_outputs()
+        torch.cuda.synchronize()
+    finally:
+        eng.set_walk_levels(0)
+        eng.set_mode('latency')
+    assert np.array_equal(got[1], full[1]), 'tokens of a retired greedy pass differ'
+    assert np.array_equal(got[2], full[2])
+    assert np.array_equal(got[0], full[0]) and np.array_equal(again[0], got[0])
+    lens = np.where((got[1] == asm.EOS_idx).any(0), (got[1] == asm.EOS_idx).argmax(0), d.T_decoder)
+    print('greedy layouts: mean %.2f tokens, max %d; %d of %d rows end within 3 steps' %
+          (lens.mean(), lens.max(), int((lens <= 3).sum()), lens.size))
+    assert np.array_equal(t2n(s2s['predicted_tokens']), got[1])
+    k = min(2, n_slots - 1)
+    c = slice(k * d.N, (k + 1) * d.N)
+    ref = O.forward(w, NAMES, batches[k], d.T_decoder, d.num_choices, np.float64,
+                    forced_tokens=np.ascontiguousarray(got[1][:, c]))
+    assert_close('atts at every step (on demand)', t2n(s2s['atts'])[:, :, c], ref['dec']['atts'][..., 0], 1e-4)
+    assert_close('token_probs (on demand)', t2n(s2s['token_probs'])[:, c], ref['dec']['token_probs'], 1e-4)
+    assert_close('logits of the retired pass, given its tokens', got[0][c], ref['scores'], 1e-4)
+
+
+def _pass_greedy(sb, retire, n):
+    sc, tok, val = sb.run(use_gt_layout=False, eos_retire=retire, n_slots=n)
+    torch.cuda.synchronize()
+    return t2n(sc).copy(), t2n(tok).copy(), t2n(val).copy()

@@ -48,3 +48,31 @@ def test_layout_nesting_equals_the_column_by_column_stack_machine():
     assert Engine.layout_nesting(h, deep) == 6
     flat = np.array([asm.module_list2tokens(['_Find', '_Find', '_And', '_Exist'], d.T_decoder)], np.int32).T
     assert Engine.layout_nesting(h, flat) == 0
+
+
+def test_behind_an_answer_operator_the_automaton_allows_only_eos():
+    """What eos_retire's sequential form rests on (dec_compact_kernel): in every state the validity automaton
+    of the layout decoder (models_clevr/nmn3_netgen_att.py:8-15 with the matrices of nmn3_assembler.py:94-117)
+    can reach behind an answer operator -- or behind <eos> -- the only valid token is <eos>.  Random valid walks
+    over the matrices that are pinned to the reference's own (tests/golden/assembler_golden.json)."""
+    from oracle import n2nmn_oracle as O
+    from n2nmn_amd.spec import MODULE_OUTPUT_TYPE
+    d = Dims()
+    names = list(CLEVR_MODULE_NAMES)
+    eos = names.index('<eos>')
+    P, Wv, bv = O.build_validity_mats(names)
+    rng = np.random.default_rng(11)
+    checked = 0
+    for _ in range(1500):
+        X = np.array([0, 0, d.T_decoder])
+        done = False
+        for t in range(d.T_decoder):
+            valid = np.nonzero(np.all((X[:, None, None] * Wv).sum(0) - bv >= 0, axis=1))[0]
+            assert len(valid) >= 1
+            if done:
+                checked += 1
+                assert list(valid) == [eos], (t, X, valid)
+            tok = int(rng.choice(valid))
+            done = done or tok == eos or MODULE_OUTPUT_TYPE[names[tok]] == 'ans'
+            X = X + P[tok]
+    assert checked > 10000
