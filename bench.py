@@ -622,7 +622,7 @@ def main():
     pipe.fill_all(lambda i: synth.make_inputs(d, seed=dp.batch_seed(i)),
                   (lambda i: synth.template_layout_batch(d, offset=i)) if args.layouts == 'templates' else
                   (lambda i: synth.clevr_like_layout_batch(d, seed=i)))
-    pipe.eos_retire = bool(args.eos_retire) and use_gt
+    pipe.eos_retire = bool(args.eos_retire)
     buckets = pipe.workers[0]['buckets']
     torch.cuda.synchronize(dev)
 
