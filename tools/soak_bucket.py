@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak of the super-bucket vs single-batch cross-check (tests/test_gpu_stress_bucket.py's body with
-fresh random shapes every trial): hunts rare mismatches.  Usage: soak_bucket.py [trials] (GPU only)"""
+fresh random shapes every trial, the eos_retire option on in half of them): hunts rare mismatches.  Usage: soak_bucket.py [trials] (GPU only)"""
 import os
 import sys
 import numpy as np
@@ -20,9 +20,10 @@ def main(trials):
     bad = 0
     for trial in range(trials):
         Nb = int(rng.choice([16, 40, 64]))
-        K = int(rng.choice([2, 4, 8]))
+        K = int(rng.choice([2, 4, 8, 16]))
         mode = str(rng.choice(['throughput', 'latency']))
         use_gt = bool(rng.integers(0, 2))
+        retire = bool(rng.integers(0, 2))     # N2NMN_S2S_EOS_RETIRE (ignored where its preconditions fail)
         key = (Nb, K)
         if key not in engines:
             d = Dims(N=Nb)
@@ -38,7 +39,7 @@ def main(trials):
             batches.append(b)
             gts.append(synth.template_layout_batch(d, offset=int(rng.integers(0, 10))))
             sb.fill(k, b, gts[-1] if use_gt else None)
-        sb.run(use_gt_layout=use_gt)
+        sb.run(use_gt_layout=use_gt, eos_retire=retire)
         for k in range(K):
             s1, t1, v1 = one.forward(batches[k], use_gt_layout=use_gt, gt_layout=gts[k] if use_gt else None)
             s2, t2, v2 = sb.result(k)
@@ -48,9 +49,9 @@ def main(trials):
             err = float(np.abs(s1 - s2)[same_cols].max()) if same_cols.any() else 0.0
             if err > 2e-5 or not tok_same:
                 bad += 1
-                print('trial %d slot %d Nb=%d K=%d %s gt=%s: tokens equal %s (%d of %d columns differ), '
+                print('trial %d slot %d Nb=%d K=%d %s gt=%s retire=%s: tokens equal %s (%d of %d columns differ), '
                       'max |dlogit| on equal-token columns %.3e' %
-                      (trial, k, Nb, K, mode, use_gt, tok_same, int((~same_cols).sum()), Nb, err), flush=True)
+                      (trial, k, Nb, K, mode, use_gt, retire, tok_same, int((~same_cols).sum()), Nb, err), flush=True)
     print('soak: %d trials, %d mismatching slots' % (trials, bad))
 
 
