@@ -204,8 +204,8 @@ typedef struct {
  * and the debug fetches need them) come from a call without the flag -- n2nmn_decoder_forward on the
  * same context recomputes them from the encoder results it holds.  Where the preconditions do not hold
  * the flag is ignored.
- * Layouts the decoder chooses itself (greedy / sampled decoding; >= 128 and <= 1024 rows, exact-fp32
- * throughput mode, lstm_dim 512): the lengths are only known step by step -- a row is finished once it has
+ * Layouts the decoder chooses itself (greedy / sampled decoding; >= 128 and <= 1024 rows, a throughput
+ * mode, lstm_dim 512): the lengths are only known step by step -- a row is finished once it has
  * emitted <eos>, after which the validity automaton allows nothing but <eos> (nmn3_netgen_att.py:8-15,
  * nmn3_assembler.py:94-117).  After every step the state rows are re-partitioned on the device (live rows
  * to the front, dec_compact_kernel) and the next step's launches run over that prefix; finished rows get

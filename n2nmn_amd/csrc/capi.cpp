@@ -816,10 +816,11 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
     // every step dec_compact_kernel re-partitions the state rows (live ones in front, gathered into the
     // alternate state buffers) and the launches of the next step run over that dense prefix; the host
     // issues every launch (it never learns the counts) and the workgroups past the prefix return at once.
-    // Inference only, >= 128 rows in the exact-fp32 throughput mode, dec_attn_seq_kernel's dimensions.
+    // Inference only, >= 128 rows in a throughput mode, dec_attn_seq_kernel's dimensions.
     a.q = c->qbuf; a.out = c->dh1_rm;
     const bool retire_seq = (io->flags & N2NMN_S2S_EOS_RETIRE) && !c->rec && !io->drop_dec0 &&
-                            !io->token_scores && !io->forced_tokens && !io->use_gt_layout && lstm_wide(c) >= 2 && N >= 128 && !lstm_b3(c, N) &&
+                            !io->token_scores && !io->forced_tokens && !io->use_gt_layout &&
+                            lstm_wide(c) >= 2 && N >= 128 &&
                             root(c)->have_token_ops && root(c)->eos_token >= 0 && dec_seq_retire_supported(a);
     c->dec_retired = retire_seq;
     // state buffers of the loop: h ping-pongs as always; c is updated in place in cb0 / cb1; a compaction
@@ -911,8 +912,15 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
         // rows whose token of this step is <eos> retire: live rows to the front of the alternate buffers
         const float* src[4] = {hb0[h0w ^ 1], cb0[c0i], hb1[h1w ^ 1], cb1[c1i]};
         float* dst[4] = {hb0[h0w], cb0[c0i ^ 1], hb1[h1w], cb1[c1i ^ 1]};
-        launch_dec_compact(a.tokens, root(c)->token_op, V, live_perm, live_n, pbuf[pi ^ 1], c->dnact + t + 1,
-                           src, dst, N, L, d.N, s);
+        if (lstm_b3(c, N)) {               // the split planes of the two hidden states move with them
+          const uint16_t* sb[2] = {planes_of(c, src[0]), planes_of(c, src[2])};
+          uint16_t* db[2] = {planes_of(c, dst[0]), planes_of(c, dst[2])};
+          launch_dec_compact(a.tokens, root(c)->token_op, V, live_perm, live_n, pbuf[pi ^ 1], c->dnact + t + 1,
+                             src, dst, sb, db, N, L, d.N, s);
+        } else {
+          launch_dec_compact(a.tokens, root(c)->token_op, V, live_perm, live_n, pbuf[pi ^ 1], c->dnact + t + 1,
+                             src, dst, nullptr, nullptr, N, L, d.N, s);
+        }
         h0w ^= 1; h1w ^= 1; c0i ^= 1; c1i ^= 1; pi ^= 1;
       }
     }

@@ -227,7 +227,8 @@ bool dec_len_supported(const DecStepArgs& a, int nsteps);
 bool dec_seq_retire_supported(const DecStepArgs& a);
 void launch_dec_compact(const int32_t* tokens, const int32_t* token_op, int V, const int32_t* perm_old,
                         const int32_t* n_old, int32_t* perm_new, int32_t* n_new, const float* const src[4],
-                        float* const dst[4], int N, int L, int R, hipStream_t s);
+                        float* const dst[4], const uint16_t* const srcb[2], uint16_t* const dstb[2], int N, int L,
+                        int R, hipStream_t s);
 void launch_dec_len(const int32_t* tokens, const int32_t* token_op, int V, int T_dec, int N,
                     int32_t* dec_len, hipStream_t s);
 void launch_gather_state(const float* const src[4], float* const dst[4], const uint16_t* const srcb[2],

@@ -1452,6 +1452,7 @@ struct CompactArgs {
   int32_t* perm_new;          // [N]
   int32_t* n_new;
   const float* src[4]; float* dst[4];
+  const uint16_t* srcb[2]; uint16_t* dstb[2];   // bf16x3 mode: planes [3][L/8][R][8] of src[0] / src[2], or nullptr
   int N, L, R, V;
 };
 __global__ __launch_bounds__(256) void dec_compact_kernel(CompactArgs g) {
@@ -1515,6 +1516,19 @@ __global__ __launch_bounds__(256) void dec_compact_kernel(CompactArgs g) {
     for (int i = 0; i < 4; ++i) {
       const float4 v = *reinterpret_cast<const float4*>(g.src[i] + ((size_t)k4 * g.R + jo) * 4);
       *reinterpret_cast<float4*>(g.dst[i] + ((size_t)k4 * g.R + p) * 4) = v;
+    }
+  }
+  if (g.srcb[0]) {
+    const size_t plane = (size_t)(g.L / 8) * g.R * 8;
+    const int k8n = g.L / 8;
+    for (int k8 = blockIdx.y * 4 + w; k8 < k8n; k8 += gridDim.y * 4) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          const uint4 v = *reinterpret_cast<const uint4*>(g.srcb[i] + pl * plane + ((size_t)k8 * g.R + jo) * 8);
+          *reinterpret_cast<uint4*>(g.dstb[i] + pl * plane + ((size_t)k8 * g.R + p) * 8) = v;
+        }
     }
   }
 }
@@ -1780,8 +1794,10 @@ bool dec_seq_retire_supported(const DecStepArgs& a) {     // the one-step launch
 
 void launch_dec_compact(const int32_t* tokens, const int32_t* token_op, int V, const int32_t* perm_old,
                         const int32_t* n_old, int32_t* perm_new, int32_t* n_new, const float* const src[4],
-                        float* const dst[4], int N, int L, int R, hipStream_t s) {
+                        float* const dst[4], const uint16_t* const srcb[2], uint16_t* const dstb[2], int N, int L,
+                        int R, hipStream_t s) {
   CompactArgs g{};
+  for (int i = 0; i < 2; ++i) { g.srcb[i] = srcb ? srcb[i] : nullptr; g.dstb[i] = dstb ? dstb[i] : nullptr; }
   g.tokens = tokens; g.token_op = token_op; g.V = V; g.perm_old = perm_old; g.n_old = n_old;
   g.perm_new = perm_new; g.n_new = n_new;
   for (int i = 0; i < 4; ++i) { g.src[i] = src[i]; g.dst[i] = dst[i]; }

@@ -158,8 +158,9 @@ def test_flag_is_ignored_where_its_preconditions_fail(clevr_engine):
     assert_close('atts', t2n(out['atts']), ref['dec']['atts'][..., 0], 1e-4)
 
 
+@pytest.mark.parametrize('mode', ['throughput', 'throughput_bf16x3'])
 @pytest.mark.parametrize('n_slots', [16, 3])
-def test_greedy_retired_pass_equals_the_full_greedy_pass(bucket, n_slots):
+def test_greedy_retired_pass_equals_the_full_greedy_pass(bucket, n_slots, mode):
     """Layouts the decoder chooses itself: a row leaves the recurrence once it has emitted <eos> (after every
     step dec_compact_kernel moves the live rows to the front and the next step runs over that prefix).  The
     recurrent tile computes a row's dot products in the same order wherever the row sits, so tokens, validity
@@ -170,7 +171,7 @@ def test_greedy_retired_pass_equals_the_full_greedy_pass(bucket, n_slots):
     asm = eng.assembler
     for k in range(n_slots):
         sb.fill(k, batches[k])
-    eng.set_mode('throughput')
+    eng.set_mode(mode)
     eng.set_walk_levels(d.T_decoder - 1)     # (decoder-chosen layouts nest: a fixed level count makes the walker's
     try:                                     #  route, and with it the last bits of the logits, independent of history)
         full = _pass_greedy(sb, False, n_slots)
