@@ -17,7 +17,9 @@ context each, shared weights; n2nmn_amd/pipeline.py -- the object tests/test_gpu
 checks against the oracle) run passes concurrently, each alternating two buckets of distinct inputs;
 exactly `--steps` passes are timed, split evenly over the workers; value = K * 64 * steps / time.
 `config` says what a launch carried (`rows_per_launch`, `questions_in_flight`).  Default: 2 streams,
-K = 16 (1024 rows per launch).  `parity_check`: logits of the timed passes against the oracle.
+K = 16 (1024 rows per launch; round 5's sweep: 2 / 3 / 4 streams = 311 / 316 / 301 k questions/s -- 3 is not
+the default because the 3-worker form of tests/test_gpu_bench_config.py failed once in three runs in the bf16x3
+mode and the failure did not reproduce in isolation: profiles/r05_notes.md section 8).  `parity_check`: logits of the timed passes against the oracle.
 Latency number (`single_batch`): one batch of 64 in flight (the strict reading of "batch 64").
 `config3`: the same with layouts chosen by the greedy decoder (BASELINE.json configs[2]).
 `config4` / `config5`: the training step and the models_vqa forward (BASELINE.json configs[3], [4]),
@@ -848,6 +850,8 @@ def main():
             # (dec_compact_kernel after every step); tokens and logits must equal the full decoder's
             def greedy_rate(retire):
                 pipe.eos_retire = retire
+                for wk in pipe.workers:          # (both measurements end on the same bucket of every worker)
+                    wk['next'] = 0
                 run_steps(2 * S, gt=False)
                 t = wall(lambda: run_steps(npass, gt=False), 3, warm=1)
                 b = pipe.workers[0]['buckets'][(pipe.workers[0]['next'] - 1) % 2]
