@@ -18,8 +18,8 @@ checks against the oracle) run passes concurrently, each alternating two buckets
 exactly `--steps` passes are timed, split evenly over the workers; value = K * 64 * steps / time.
 `config` says what a launch carried (`rows_per_launch`, `questions_in_flight`).  Default: 2 streams,
 K = 16 (1024 rows per launch; round 5's sweep: 2 / 3 / 4 streams = 311 / 316 / 301 k questions/s -- 3 is not
-the default because the 3-worker form of tests/test_gpu_bench_config.py failed once in three runs in the bf16x3
-mode and the failure did not reproduce in isolation: profiles/r05_notes.md section 8).  `parity_check`: logits of the timed passes against the oracle.
+the default because the 3-worker form of tests/test_gpu_bench_config.py failed in 2 of 5 runs in the bf16x3
+mode -- a 3e-4 logit error on one worker's pass, not reproduced in isolation: profiles/r05_notes.md section 8).  `parity_check`: logits of the timed passes against the oracle.
 Latency number (`single_batch`): one batch of 64 in flight (the strict reading of "batch 64").
 `config3`: the same with layouts chosen by the greedy decoder (BASELINE.json configs[2]).
 `config4` / `config5`: the training step and the models_vqa forward (BASELINE.json configs[3], [4]),
