@@ -103,11 +103,13 @@ int n2nmn_ctx_dims(const n2nmn_ctx *ctx, n2nmn_dims *out);
 #define N2NMN_MODE_LATENCY    0
 #define N2NMN_MODE_THROUGHPUT 1
 #define N2NMN_MODE_THROUGHPUT_KSPLIT 2
-/* N2NMN_MODE_THROUGHPUT_BF16X3  (opt-in) N2NMN_MODE_THROUGHPUT with the recurrent contraction and the dense
- *   contractions (encoder_h_transform, W_a, conv_image) of passes of >= 128 rows on the bf16 matrix cores
- *   over three-way split operands: w = wh + wm + wl, h = hh + hm + hl (bf16 each, exact sums), six cross
- *   products per 16 x 16 x 32 block with fp32 accumulation (csrc/kernels_lstm_tile3.hip,
- *   csrc/kernels_gemm_dma3.hip).  The terms dropped are <= 2^-26 relative: same error class as the fp32
+/* N2NMN_MODE_THROUGHPUT_BF16X3  (opt-in) N2NMN_MODE_THROUGHPUT with the recurrent contraction of passes of
+ *   >= 128 rows on the bf16 matrix cores over three-way split operands: w = wh + wm + wl, h = hh + hm + hl
+ *   (bf16 each, exact sums), six cross products per 16 x 16 x 32 block with fp32 accumulation
+ *   (csrc/kernels_lstm_tile3.hip).  The dense contractions (encoder_h_transform, W_a, conv_image) have the
+ *   same form in csrc/kernels_gemm_dma3.hip, but that kernel left the product path at the end of round 5:
+ *   with a second stream running passes concurrently it returned intermittent wrong tiles (cause unknown;
+ *   N2NMN_GEMM_DMA3=1 brings it back for investigation).  The terms dropped are <= 2^-26 relative: same error class as the fp32
  *   MFMA's own rounding -- every parity test runs unchanged at 1e-4 in this mode -- but NOT the same bits
  *   as the fp32 kernels, so it is a mode of its own and never the default.  Training forwards keep the
  *   fp32 kernels.  Needs lstm_dim % 128 == 0 and lstm_dim >= 256 (N2NMN_EINVAL otherwise); the first call

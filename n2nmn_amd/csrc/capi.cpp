@@ -2229,7 +2229,13 @@ int n2nmn_debug_gemm(n2nmn_ctx* ctx, const float* A, const float* B, const float
     g.Bp3 = Bp3;
   }
   const int reps = e3 && atoi(e3) < 0 ? -atoi(e3) : 1;       // (negative: fp32 form, that many launches)
-  for (int i = 0; i < (b3 ? atoi(e3) : reps); ++i) launch_gemm_pk(g, s);
+  // (the split-operand kernel is off in the product path, kernels_gemm.hip use_gemm_dma3; this debug entry
+  // keeps exercising it directly -- single-stream accuracy and timing)
+  for (int i = 0; i < (b3 ? atoi(e3) : reps); ++i) {
+    const int tiles3 = ((g.M + 63) / 64) * ((g.n_store + 127) / 128);      // (the product path's old threshold)
+    if (b3 && gemm_dma3_supported(g) && tiles3 >= 256) launch_gemm_dma3(&g, 1, s);
+    else launch_gemm_pk(g, s);
+  }
   N2_HIP(hipStreamSynchronize(s));       // debug entry only: Bp is freed right away
   N2_HIP(hipFree(Bp));
   if (Bp3) N2_HIP(hipFree(Bp3));

@@ -384,8 +384,17 @@ static bool use_gemm_dma(const GemmArgs* a, int n) {
 
 // split-operand bf16 form of a launch: every problem carries its weight planes (the caller sets Bp3 only in
 // the opt-in mode) and fits the kernel
+// gemm_dma3_kernel (the dense contractions of the opt-in bf16x3 mode on split operands) is OFF unless
+// N2NMN_GEMM_DMA3=1.  Found at the end of round 5 (tools/diag/three_stream_repro.py, profiles/r05_notes.md
+// section 8): with a second stream running passes concurrently, launches on this kernel returned intermittent
+// wrong tiles -- logit errors of 1e-5 .. 1e-2 in 30 - 40 % of the rounds at two streams, the conv_image launch
+// most of all -- while the same passes with the contractions on the exact-fp32 kernels (and the recurrent step
+// still on lstm_tile3_kernel) were bit-identical to the passes run alone in 100 of 100 rounds, as was every
+// fp32-mode pass at three streams.  Not an LDS-ring hazard (a build that restaged only behind a full barrier
+// failed the same way), not the token gate, not the tile height; cause unknown.  The mode's claim is fp32
+// accuracy, so it runs without this kernel (377 -> ~366 k questions/s) until the cause is found.
 static bool use_gemm_dma3(const GemmArgs* a, int n) {
-  static const int on = [] { const char* e = getenv("N2NMN_GEMM_DMA3"); return e ? atoi(e) : 1; }();
+  static const int on = [] { const char* e = getenv("N2NMN_GEMM_DMA3"); return e ? atoi(e) : 0; }();
   if (!on) return false;
   int tiles = 0;
   for (int i = 0; i < n; ++i) {
