@@ -127,7 +127,8 @@ def test_bf16x3_encoder_states_and_decoder_outputs():
 
 @pytest.mark.parametrize('M,N,K', [(1000, 250, 300), (4096, 512, 512), (2500, 1024, 2064)])
 def test_split_operand_gemm_is_as_accurate_as_the_fp32_gemm(clevr_engine, M, N, K):
-    """gemm_dma3_kernel (the mode's dense contractions: fp32 activations split in registers, weights split
+    """gemm_dma3_kernel (the split-operand form of the dense contractions -- out of the product path since the
+    end of round 5, DESIGN.md 2.1, exercised here through the debug entry: fp32 activations split in registers, weights split
     at commit, 6 bf16 products, fp32 accumulate) through n2nmn_debug_gemm: against torch fp64, and against
     the error of the exact-fp32 kernels on the same operands (ragged sizes, K not a multiple of 32, the
     models_vqa conv_image shape)."""

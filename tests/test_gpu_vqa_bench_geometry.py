@@ -90,7 +90,7 @@ def test_latency_mode_batch_of_128(setup):
 def test_throughput_pass_of_8_client_batches(setup, mode):
     """`config5.passes`: 8 client batches of 128 as ONE pass of 1024 rows in 'throughput' mode -- and in
     the opt-in split-operand mode (`bf16x3.config5_passes`: lstm_tile3_kernel at lstm_dim 1024,
-    gemm_dma3_kernel on the 2064 -> 1024 conv_image)."""
+    the dense contractions on the exact-fp32 kernels since gemm_dma3_kernel left the product path)."""
     eng, d, w = setup
     K = 8
     big = vqa.VQADims(N=K * CLIENT)
