@@ -616,6 +616,14 @@ int n2nmn_debug_gemm(n2nmn_ctx *ctx, const float *A, const float *B, const float
 int n2nmn_fc_forward(n2nmn_ctx *ctx, const float *A, const float *W, const float *bias, float *out,
                      int M, int N, int K, int relu, n2nmn_stream stream);
 
+/* ------------------------------------------------------------------------------------------
+ * (8) snapshot I/O helper (host): CRC-32C (Castagnoli, polynomial 0x1EDC6F41 reflected) of `n` bytes,
+ *     continuing from `crc` (0 to start) -- the checksum of TensorFlow's tensor-bundle checkpoints
+ *     (tf.train.Saver.restore / .save: exp_clevr/eval_clevr.py:88-91, train_clevr_gt_layout.py:221-223;
+ *     tensorflow/core/lib/hash/crc32c.h, restated).  n2nmn_amd/tf_checkpoint.py checksums tensors with it.
+ * ---------------------------------------------------------------------------------------- */
+uint32_t n2nmn_crc32c(uint32_t crc, const void *data, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,9 @@ template <int MT> struct G3 {
 
 __device__ __forceinline__ void glds16_3(const void* base, uint32_t voff, uint32_t lds) {
   uint32_t keep;
+#ifdef N2NMN_DIAG_TWICE
+  lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds);   // (the pass loop leaves the address in a VGPR)
+#endif
   asm volatile(
       "s_mov_b32 %0, m0\n\t"
       "s_mov_b32 m0, %3\n\t"
@@ -50,8 +53,57 @@ __device__ __forceinline__ void glds16_3(const void* base, uint32_t voff, uint32
       : "memory");
 }
 
+
+#ifdef N2NMN_DIAG
+// ---- diagnostic build only (tools/diag/build_diag.py, -DN2NMN_DIAG): in-kernel verification of what the
+// LDS-DMA left in LDS against a direct global read of the same bytes, with the workgroup's LDS allocation and
+// hardware ids recorded per anomaly (profiles/r06_notes.md section 1).  Nothing of this is in the product .so.
+struct DiagRec { uint32_t w[16]; };
+__device__ DiagRec* g_diag_rec = nullptr;
+__device__ uint32_t g_diag_cap = 0;
+__device__ uint32_t* g_diag_cnt = nullptr;        // [0] records wanted, [1] workgroups seen, [2..] misc
+__device__ uint32_t g_diag_level = 0;
+__device__ uint32_t* g_diag_wg = nullptr;         // optional: per-workgroup {lds_alloc, hw_id, xcc_id, tile}
+__device__ uint32_t g_diag_wg_cap = 0;
+
+__device__ __forceinline__ uint32_t diag_lds_alloc() {
+  uint32_t v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC)" : "=s"(v)); return v;
+}
+__device__ __forceinline__ uint32_t diag_hw_id() {
+  uint32_t v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(v)); return v;
+}
+__device__ __forceinline__ uint32_t diag_xcc_id() {
+  uint32_t v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v;
+}
+typedef uint32_t diag_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 diag_lds_read(uint32_t lds_addr) {      // (an LDS read the compiler cannot move)
+  diag_u32x4 v;
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_addr) : "memory");
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ bool diag_ne(const uint4& a, const uint4& b) {
+  return a.x != b.x || a.y != b.y || a.z != b.z || a.w != b.w;
+}
+// kind: 1 = own piece wrong right behind this wave's vmcnt(0); 2 = another wave's piece wrong behind the
+// barrier; 3 = the two redundant accumulator chains differ
+__device__ __forceinline__ void diag_record(uint32_t kind, uint32_t tile, uint32_t stage, uint32_t wave,
+                                            uint32_t piece, uint64_t mask, uint32_t got, uint32_t exp,
+                                            uint32_t lds_off, uint32_t reread_ok, uint32_t stale_match,
+                                            uint32_t extra) {
+  if (!g_diag_cnt) return;
+  const uint32_t i = atomicAdd(&g_diag_cnt[0], 1u);
+  if (i >= g_diag_cap) return;
+  DiagRec r;
+  r.w[0] = kind; r.w[1] = tile; r.w[2] = stage; r.w[3] = wave; r.w[4] = piece;
+  r.w[5] = (uint32_t)mask; r.w[6] = (uint32_t)(mask >> 32); r.w[7] = got; r.w[8] = exp; r.w[9] = lds_off;
+  r.w[10] = reread_ok; r.w[11] = stale_match; r.w[12] = diag_lds_alloc(); r.w[13] = diag_hw_id();
+  r.w[14] = diag_xcc_id(); r.w[15] = extra;
+  g_diag_rec[i] = r;
+}
+#endif
+
 template <int MT>
-__device__ __forceinline__ void gemm_dma3_body(const GemmArgs& a, const int bx, const int by) {
+__device__ __forceinline__ void gemm_dma3_body(const GemmArgs& a, const int bx, const int by, const int tile_id) {
   constexpr int M3 = G3<MT>::M, A3_IMAGE = G3<MT>::A_IMAGE, G3_STAGE = G3<MT>::STAGE;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -96,6 +148,9 @@ __device__ __forceinline__ void gemm_dma3_body(const GemmArgs& a, const int bx, 
   const uint32_t b_slab = (uint32_t)(a.Np / N3) * (uint32_t)B3_IMAGE;       // bytes per 32 k of B planes
   const int Klast = a.K - 4;
   auto issue = [&](int s) {
+#ifdef N2NMN_DIAG_TWICE
+    s = __builtin_amdgcn_readfirstlane(s);       // (inside the pass loop hipcc keeps the stage index in a VGPR)
+#endif
     const uint32_t st = lds0 + (uint32_t)(s & 1) * G3_STAGE;
     // columns past K (Kp padding) meet zero weights: any finite in-bounds value will do
 #pragma unroll
@@ -108,6 +163,77 @@ __device__ __forceinline__ void gemm_dma3_body(const GemmArgs& a, const int bx, 
       glds16_3(Bp, b_tile + (uint32_t)s * b_slab + (uint32_t)u * 1024u,
                st + A3_IMAGE + (uint32_t)(3 * w + u) * 1024u);
   };
+
+#if defined(N2NMN_DIAG_WG) || defined(N2NMN_DIAG_VERIFY) || defined(N2NMN_DIAG_ACC2)
+  const uint32_t dlvl = g_diag_level;
+#endif
+#ifdef N2NMN_DIAG_WG
+  if ((dlvl & 8u) && tid == 0 && g_diag_wg) {
+    const uint32_t i = atomicAdd(&g_diag_cnt[1], 1u);
+    if (i < g_diag_wg_cap) {
+      g_diag_wg[4 * i + 0] = diag_lds_alloc(); g_diag_wg[4 * i + 1] = diag_hw_id();
+      g_diag_wg[4 * i + 2] = diag_xcc_id(); g_diag_wg[4 * i + 3] = (uint32_t)tile_id;
+    }
+  }
+#endif
+#ifdef N2NMN_DIAG_VERIFY
+  // where wave w2's piece pc of stage s2 comes from (byte offset from Ap / Bp, per lane) and where it lands
+  auto d_src = [&](int w2, int pc, int s2) -> uint32_t {
+    if (pc < MT) {
+      const int row = 8 * (w2 + 8 * pc) + (lane >> 3);
+      int gm = m0 + row;
+      gm = gm < M ? gm : M - 1;
+      if (a.group_idx) {
+        const int g = gm / a.group_size;
+        gm = a.group_idx[g] * a.group_size + (gm - g * a.group_size);
+      }
+      const int sw = (lane & 7) ^ ((row >> 1) & 7);
+      const int k = min(s2 * K3 + 4 * sw, Klast);
+      return (uint32_t)gm * (uint32_t)a.lda * 4u + (uint32_t)k * 4u;
+    }
+    return (uint32_t)bx * (uint32_t)B3_IMAGE + (uint32_t)(3 * w2 + (pc - MT)) * 1024u + (uint32_t)lane * 16u +
+           (uint32_t)s2 * b_slab;
+  };
+  auto d_lds = [&](int w2, int pc, int s2) -> uint32_t {
+    const uint32_t st = (uint32_t)(s2 & 1) * G3_STAGE + (uint32_t)lane * 16u;
+    return pc < MT ? st + (uint32_t)(8 * (w2 + 8 * pc)) * 128u
+                   : st + A3_IMAGE + (uint32_t)(3 * w2 + (pc - MT)) * 1024u;
+  };
+  auto d_verify = [&](uint32_t kind, int w2, int s2) {
+    for (int pc = 0; pc < MT + 3; ++pc) {
+      const char* gbase = pc < MT ? reinterpret_cast<const char*>(Ap) : reinterpret_cast<const char*>(Bp);
+      const uint4 g = *reinterpret_cast<const uint4*>(gbase + d_src(w2, pc, s2));
+      const uint32_t lo = d_lds(w2, pc, s2);
+      const uint4 l = diag_lds_read(lds0 + lo);
+      const bool bad = diag_ne(g, l);
+      const uint64_t mask = __ballot(bad);
+      if (mask) {
+        for (int i = 0; i < 8; ++i) __builtin_amdgcn_s_sleep(127);
+        const uint4 l2 = diag_lds_read(lds0 + lo);
+        const uint64_t mask2 = __ballot(diag_ne(g, l2));
+        uint32_t stale = 0xffffu;
+        if (s2 >= 2) {
+          const uint4 g2 = *reinterpret_cast<const uint4*>(gbase + d_src(w2, pc, s2 - 2));
+          stale = (uint32_t)__popcll(__ballot(bad && !diag_ne(g2, l)));
+        }
+        const int fl = __ffsll((long long)mask) - 1;
+        const uint32_t got = (uint32_t)__builtin_amdgcn_readlane((int)l.x, fl);
+        const uint32_t exp = (uint32_t)__builtin_amdgcn_readlane((int)g.x, fl);
+        if (lane == 0)
+          diag_record(kind, (uint32_t)tile_id, (uint32_t)s2, (uint32_t)w | ((uint32_t)w2 << 8), (uint32_t)pc, mask,
+                      got, exp, lds0 + lo - (uint32_t)lane * 16u, mask2 == 0 ? 1u : 0u, stale,
+                      (uint32_t)__popcll(mask) | ((uint32_t)MT << 16));
+      }
+    }
+  };
+#endif
+#ifdef N2NMN_DIAG_ACC2
+  f32x4 acc2[MT][4];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc2[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#endif
 
   // ---- fragment addressing: MFMA 16x16x32 -- lane holds 8 consecutive k (k group lane >> 4) of row /
   // column lane & 15 ----------------------------------------------------------------------------------
@@ -137,12 +263,45 @@ __device__ __forceinline__ void gemm_dma3_body(const GemmArgs& a, const int bx, 
     return f;
   };
 
+#ifdef N2NMN_DIAG_TWICE
+  // the whole K loop a second time over the same operands (the SAME instructions: the pass loop is not
+  // unrolled): accumulators that differ between the passes = a transient fault between LDS and the
+  // accumulators; equal accumulators with a wrong result = the kernel's inputs differed at the time
+  f32x4 accA[MT][4];
+  const int npass = (dlvl & 16u) ? 2 : 1;
+  uint4 a_sum0 = make_uint4(0u, 0u, 0u, 0u);
+  if (dlvl & 32u)
+    for (int s2 = 0; s2 < nst; ++s2)
+      for (int pc = 0; pc < MT + 3; ++pc) {
+        const char* gbase = pc < MT ? reinterpret_cast<const char*>(Ap) : reinterpret_cast<const char*>(Bp);
+        const uint4 g = *reinterpret_cast<const uint4*>(gbase + d_src(w, pc, s2));
+        a_sum0.x ^= g.x; a_sum0.y += g.y; a_sum0.z ^= g.z; a_sum0.w += g.w;
+      }
+#pragma unroll 1
+  for (int pass = 0; pass < npass; ++pass) {
+    if (pass == 1) {
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { accA[t][c] = acc[t][c]; acc[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+      __syncthreads();
+    }
+#endif
   issue(0);
   for (int s = 0; s < nst; ++s) {
     // this wave's pieces of stage s have landed; after the barrier everyone's have, and everyone is
     // done reading stage s - 1, whose buffer the DMA of stage s + 1 refills under this stage's MFMAs
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef N2NMN_DIAG_VERIFY
+    if (dlvl & 1u) d_verify(1u, w, s);
+#endif
     __builtin_amdgcn_s_barrier();
+#ifdef N2NMN_DIAG_VERIFY
+    if (dlvl & 2u) {
+      d_verify(2u, (w + 1) & 7, s);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+#endif
     if (s + 1 < nst) issue(s + 1);
     const char* st = smem + (size_t)(s & 1) * G3_STAGE;
     float4 x0[MT], x1[MT];
@@ -183,11 +342,85 @@ __device__ __forceinline__ void gemm_dma3_body(const GemmArgs& a, const int bx, 
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[t], Bm, c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[t], Bh, c, 0, 0, 0);
         acc[t][ct] = c;
+#ifdef N2NMN_DIAG_ACC2
+        if (dlvl & 4u) {
+          f32x4 c2 = acc2[t][ct];
+          c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al[t], Bh, c2, 0, 0, 0);
+          c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[t], Bl, c2, 0, 0, 0);
+          c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am[t], Bm, c2, 0, 0, 0);
+          c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am[t], Bh, c2, 0, 0, 0);
+          c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[t], Bm, c2, 0, 0, 0);
+          c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[t], Bh, c2, 0, 0, 0);
+          acc2[t][ct] = c2;
+        }
+#endif
       }
       if (ct + 1 < 4) P = Q;
     }
   }
+#ifdef N2NMN_DIAG_TWICE
+  }
+  if (npass == 2) {
+    int first = -1, nbad = 0;
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (__float_as_uint(acc[t][c][r]) != __float_as_uint(accA[t][c][r])) {
+            if (first < 0) first = t * 16 + c * 4 + r;
+            ++nbad;
+          }
+    const uint64_t mask = __ballot(nbad > 0);
+    if (mask) {
+      const int fl = __ffsll((long long)mask) - 1;
+      uint32_t got = 0, exp = 0;
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (first == t * 16 + c * 4 + r) { got = __float_as_uint(acc[t][c][r]); exp = __float_as_uint(accA[t][c][r]); }
+      const uint32_t f1 = (uint32_t)__builtin_amdgcn_readlane(first, fl), n1 = (uint32_t)__builtin_amdgcn_readlane(nbad, fl);
+      got = (uint32_t)__builtin_amdgcn_readlane((int)got, fl);
+      exp = (uint32_t)__builtin_amdgcn_readlane((int)exp, fl);
+      if (lane == 0)
+        diag_record(4u, (uint32_t)tile_id, (uint32_t)fl, (uint32_t)w, n1, mask, got, exp, f1, 0u, 0u,
+                    (uint32_t)__popcll(mask) | ((uint32_t)MT << 16));
+    }
+  }
+  if (dlvl & 32u) {
+    uint4 a_sum1 = make_uint4(0u, 0u, 0u, 0u);
+    for (int s2 = 0; s2 < nst; ++s2)
+      for (int pc = 0; pc < MT + 3; ++pc) {
+        const char* gbase = pc < MT ? reinterpret_cast<const char*>(Ap) : reinterpret_cast<const char*>(Bp);
+        const uint4 g = *reinterpret_cast<const uint4*>(gbase + d_src(w, pc, s2));
+        a_sum1.x ^= g.x; a_sum1.y += g.y; a_sum1.z ^= g.z; a_sum1.w += g.w;
+      }
+    const uint64_t mask = __ballot(diag_ne(a_sum0, a_sum1));
+    const int M1 = a.m_dev ? min(a.M, *reinterpret_cast<const volatile int*>(a.m_dev)) : a.M;
+    if ((mask || M1 != M) && lane == 0)
+      diag_record(6u, (uint32_t)tile_id, 0u, (uint32_t)w, 0u, mask, (uint32_t)M1, (uint32_t)M, 0u, 0u, 0u,
+                  (uint32_t)__popcll(mask) | ((uint32_t)MT << 16));
+  }
+#endif
 
+#ifdef N2NMN_DIAG_ACC2
+  if (dlvl & 4u) {
+    bool bad = false;
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bad |= __float_as_uint(acc[t][c][r]) != __float_as_uint(acc2[t][c][r]);
+    const uint64_t mask = __ballot(bad);
+    if (mask && lane == 0)
+      diag_record(3u, (uint32_t)tile_id, 0u, (uint32_t)w, 0u, mask, 0u, 0u, 0u, 0u, 0u, (uint32_t)MT << 16);
+  }
+#endif
   // ---- epilogue: C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + r -----------------
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) {
@@ -214,8 +447,11 @@ __device__ __forceinline__ void gemm_dma3_body(const GemmArgs& a, const int bx, 
   }
 }
 
+#ifndef N2NMN_DIAG_WAVES_PER_EU
+#define N2NMN_DIAG_WAVES_PER_EU 4
+#endif
 template <int MT>
-__global__ __launch_bounds__(G3_THREADS, 4) void gemm_dma3_kernel(GemmBatch b) {
+__global__ __launch_bounds__(G3_THREADS, N2NMN_DIAG_WAVES_PER_EU) void gemm_dma3_kernel(GemmBatch b) {
   // consecutive workgroup ids go round-robin over the 8 XCDs: runs of 8 consecutive list positions
   // (column tiles of neighbouring row tiles, which share their A rows) execute on ONE XCD, the runs rotate
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -225,7 +461,7 @@ __global__ __launch_bounds__(G3_THREADS, 4) void gemm_dma3_kernel(GemmBatch b) {
   const GemmArgs& a = b.a[p];
   const int local = t - b.start[p];
   const int gx = (a.n_store + N3 - 1) / N3;
-  gemm_dma3_body<MT>(a, local % gx, local / gx);
+  gemm_dma3_body<MT>(a, local % gx, local / gx, t);
 }
 
 // PK pack [Kp/4][Np][4] fp32 (zero padded) -> planes [Kp/32][Np/128][3][8][64][8] bf16
@@ -264,6 +500,9 @@ bool gemm_dma3_supported(const GemmArgs& a) {
          (size_t)a.Kp * a.Np * 6 < ((size_t)1 << 32) && (!a.gate_tokens || a.gate_T <= 64);
 }
 
+#ifdef N2NMN_DIAG
+static int g_diag_lds_pad = 0;       // extra dynamic LDS per workgroup (bytes): changes how workgroups share a CU
+#endif
 template <int MT>
 static void launch3(const GemmArgs* a, int n, hipStream_t s) {
   constexpr int M3 = G3<MT>::M;
@@ -278,6 +517,13 @@ static void launch3(const GemmArgs* a, int n, hipStream_t s) {
   }
   if (!np) return;
   for (int i = np; i <= 4; ++i) b.start[i] = tiles;
+#ifdef N2NMN_DIAG_LAUNCH
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma3_kernel<MT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G3<MT>::STAGE + g_diag_lds_pad);
+  hipLaunchKernelGGL(gemm_dma3_kernel<MT>, dim3((tiles + 63) / 64 * 64), dim3(G3_THREADS),
+                     2 * G3<MT>::STAGE + g_diag_lds_pad, s, b);
+  return;
+#endif
   static std::atomic<uint64_t> attr{0};
   ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_dma3_kernel<MT>), 2 * G3<MT>::STAGE, attr);
   hipLaunchKernelGGL(gemm_dma3_kernel<MT>, dim3((tiles + 63) / 64 * 64), dim3(G3_THREADS), 2 * G3<MT>::STAGE, s, b);
@@ -300,3 +546,99 @@ void launch_pack_pk_b3(const float* Bp, int Kp, int Np, uint16_t* dst, hipStream
 }
 
 }  // namespace n2nmn
+
+#ifdef N2NMN_DIAG
+// ---- diagnostic exports (diag build only; bound by tools/diag/dma3_fault.py with ctypes, not in n2nmn.h) ----
+namespace n2nmn {
+namespace {
+// A co-resident "foreign" workgroup for the concurrency experiments.  mode 0: holds `lds` bytes of LDS and
+// sleeps; 1: rewrites and re-reads its own LDS all the time; 2: streams `buf` from HBM (no LDS traffic);
+// 3: LDS-DMA from `buf` into its own LDS all the time.
+__global__ __launch_bounds__(256) void diag_aggressor_kernel(int mode, int iters, int lds_bytes, const float* buf,
+                                                             size_t nfloat, float* sink) {
+  extern __shared__ __attribute__((aligned(1024))) char dsm[];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float acc = 0.f;
+  if (lds_bytes >= 4) reinterpret_cast<volatile float*>(dsm)[0] = 1.f;
+  if (mode == 0) {
+    for (int i = 0; i < iters; ++i) __builtin_amdgcn_s_sleep(127);
+  } else if (mode == 1) {
+    const int nw = lds_bytes / 4;
+    for (int i = 0; i < iters; ++i) {
+      for (int j = tid; j < nw; j += 256) reinterpret_cast<volatile uint32_t*>(dsm)[j] = 0xdead0000u + (uint32_t)i;
+      __syncthreads();
+      for (int j = tid; j < nw; j += 256) acc += (float)(reinterpret_cast<volatile uint32_t*>(dsm)[j] & 1u);
+      __syncthreads();
+    }
+  } else if (mode == 2) {
+    const size_t n4 = nfloat / 4;
+    size_t j = ((size_t)blockIdx.x * 256 + tid) % n4;
+    for (int i = 0; i < iters; ++i) {
+      const float4 v = reinterpret_cast<const float4*>(buf)[j];
+      acc += v.x + v.y + v.z + v.w;
+      j += (size_t)gridDim.x * 256;
+      if (j >= n4) j -= n4;
+    }
+  } else {
+    const uint32_t l0 = (uint32_t)(uintptr_t)dsm;
+    const int pieces = lds_bytes / 1024;
+    const size_t nb = nfloat * 4;
+    size_t off = ((size_t)blockIdx.x * 4 + w) * 1024 % (nb - 2048);
+    for (int i = 0; i < iters; ++i) {
+      for (int pc = w; pc < pieces; pc += 4) {
+        glds16_3(buf, (uint32_t)(off + (size_t)lane * 16),
+                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(l0 + (uint32_t)pc * 1024u)));
+        off += (size_t)gridDim.x * 4096;
+        if (off >= nb - 2048) off -= nb - 2048;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    acc += reinterpret_cast<volatile float*>(dsm)[tid];
+  }
+  if (acc == 12345.678f) sink[0] = acc;
+}
+}  // namespace
+}  // namespace n2nmn
+
+extern "C" {
+int n2nmn_diag_config(unsigned level, void* rec, unsigned rec_cap, void* cnt, void* wg, unsigned wg_cap,
+                      int lds_pad) {
+  using namespace n2nmn;
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_diag_level), &level, sizeof(level));
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_diag_rec), &rec, sizeof(rec));
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_diag_cap), &rec_cap, sizeof(rec_cap));
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_diag_cnt), &cnt, sizeof(cnt));
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_diag_wg), &wg, sizeof(wg));
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_diag_wg_cap), &wg_cap, sizeof(wg_cap));
+  g_diag_lds_pad = lds_pad;
+  return e == hipSuccess ? 0 : -(int)e;
+}
+// PK pack [Kp/4][Np][4] of a row-major B[K][N], then its bf16 planes
+int n2nmn_diag_pack3(const float* B, int K, int N, float* Bp, void* Bp3, int Kp, int Np, void* stream) {
+  n2nmn::launch_pack_pk(B, N, K, N, Bp, Kp, Np, (hipStream_t)stream);
+  n2nmn::launch_pack_pk_b3(Bp, Kp, Np, (uint16_t*)Bp3, (hipStream_t)stream);
+  return 0;
+}
+// one launch, no synchronisation; mt = 1 / 2: gemm_dma3_kernel<mt>, mt = 0: the exact-fp32 gemm_dma_kernel
+int n2nmn_diag_gemm(const float* A, const float* Bp, const void* Bp3, const float* bias, float* C, int M, int N,
+                    int K, int Kp, int Np, int mt, void* stream) {
+  using namespace n2nmn;
+  GemmArgs g{};
+  g.A = A; g.lda = K; g.M = M; g.K = K; g.group_size = 1; g.Bp = Bp; g.Np = Np; g.Kp = Kp;
+  g.Bp3 = (const uint16_t*)Bp3; g.bias = bias; g.N = N; g.C = C; g.ldc = N; g.n_store = N;
+  if (mt == 0) { if (!gemm_dma_supported(g)) return -1; launch_gemm_dma(&g, 1, (hipStream_t)stream); }
+  else { if (!gemm_dma3_supported(g)) return -1; if (mt == 2) launch3<2>(&g, 1, (hipStream_t)stream); else launch3<1>(&g, 1, (hipStream_t)stream); }
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+int n2nmn_diag_aggressor(int mode, int iters, int lds_bytes, int grid, const float* buf, size_t nfloat, float* sink,
+                         void* stream) {
+  using namespace n2nmn;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(diag_aggressor_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  hipLaunchKernelGGL(diag_aggressor_kernel, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, mode, iters,
+                     lds_bytes, buf, nfloat, sink);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+}  // extern "C"
+#endif
+

@@ -410,4 +410,46 @@ int n2nmn_program_status(const n2nmn_program* p, int example, int32_t* kind, int
   return N2NMN_OK;
 }
 
+
+// CRC-32C of the tensor-bundle checkpoints (include/n2nmn.h section 8).  The x86 crc32 instruction computes
+// exactly this polynomial; without SSE4.2 a byte table.
+namespace {
+struct Crc32cTable {
+  uint32_t t[256];
+  Crc32cTable() {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0x82f63b78u : c >> 1;
+      t[i] = c;
+    }
+  }
+};
+#if defined(__x86_64__)
+__attribute__((target("sse4.2"))) uint32_t crc32c_hw(uint32_t c, const unsigned char* p, size_t n) {
+  uint64_t c64 = c;
+  while (n && (reinterpret_cast<uintptr_t>(p) & 7u)) { c64 = __builtin_ia32_crc32qi((uint32_t)c64, *p++); --n; }
+  for (; n >= 8; n -= 8, p += 8) {
+    uint64_t v;
+    std::memcpy(&v, p, 8);
+    c64 = __builtin_ia32_crc32di(c64, v);
+  }
+  while (n--) c64 = __builtin_ia32_crc32qi((uint32_t)c64, *p++);
+  return (uint32_t)c64;
+}
+#endif
+}  // namespace
+
+uint32_t n2nmn_crc32c(uint32_t crc, const void* data, size_t n) {
+  const unsigned char* p = static_cast<const unsigned char*>(data);
+  uint32_t c = crc ^ 0xffffffffu;
+  if (!p || !n) return crc;
+#if defined(__x86_64__)
+  static const bool hw = __builtin_cpu_supports("sse4.2");
+  if (hw) return crc32c_hw(c, p, n) ^ 0xffffffffu;
+#endif
+  static const Crc32cTable tab;
+  while (n--) c = tab.t[(c ^ *p++) & 0xffu] ^ (c >> 8);
+  return c ^ 0xffffffffu;
+}
+
 }  // extern "C"

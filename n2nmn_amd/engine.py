@@ -120,6 +120,17 @@ class Engine:
         torch.cuda.synchronize(self.device)
         _lib.check(self._lib.n2nmn_commit_weights(self._ctx, self.stream()))
 
+    def get_weights(self) -> Dict[str, object]:
+        """reference variable name -> device tensor holding the current value (n2nmn_get_weight)"""
+        torch = _torch()
+        out = {}
+        for name, shape in self.variable_names().items():
+            t = torch.empty(shape, dtype=torch.float32, device=self.device)
+            _lib.check(self._lib.n2nmn_get_weight(self._ctx, name.encode(), t.data_ptr(), self.stream()))
+            out[name] = t
+        torch.cuda.synchronize(self.device)
+        return out
+
     def load_tf_checkpoint(self, prefix: str, verify: bool = True):
         """Load a TF V2 checkpoint (`<prefix>.index` + `.data-*`, README.md:75-79 of the reference)
         reading ONLY this model's variables (not the optimiser slots).  Returns the names found."""

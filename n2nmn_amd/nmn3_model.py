@@ -70,10 +70,29 @@ class NMN3Model:
         self.modules = Modules(image_feat_grid, None, num_choices, engine=engine)
         self.compiler = Compiler(assembler)
         self.scores = Fetch(self, 'scores', 2)
+        # nmn3_model.py:33-34,161-166: entropy_reg = mean(neg_entropy) (phase 1); l2_reg = sum of l2_loss over
+        # the weight matrices (a term of the training loss: n2nmn_amd.runtime_train)
+        self.entropy_reg = Fetch(self, 'entropy_reg', 1)
+        self.l2_reg = Fetch(self, 'l2_reg', 2)
+        self._has_weights = False
         register_model(self)
 
     def load_weights(self, weights):
         self.engine.load_weights(weights)
+        self._has_weights = True
+
+    def get_weights(self):
+        return self.engine.get_weights()
+
+    def variable_shapes(self):
+        """reference variable name -> shape, in graph order (what tf.trainable_variables() lists)"""
+        return self.engine.variable_names()
+
+    def initialize_variables(self, seed: int = 0):
+        """sess.run(tf.global_variables_initializer()): the reference's declared initial values
+        (runtime_train.initial_weights)"""
+        from .runtime_train import initial_weights
+        self.load_weights(initial_weights(self.variable_shapes(), seed))
 
     # -- eager execution --------------------------------------------------------------------
     def run_phase1(self, feeds=None, **kw):
@@ -85,8 +104,18 @@ class NMN3Model:
     def _fetch(self, f, handle):
         if handle.phase1 is None:
             handle.phase1 = self.run_phase1(handle.feeds)
+        if f.name == 'entropy_reg':
+            import numpy as np
+            return np.float32(np.mean(to_numpy(handle.phase1['neg_entropy']), dtype=np.float32))
         if f.phase == 1:
             return to_numpy(handle.phase1[f.name])
+        if f.name == 'l2_reg':
+            if 'l2_reg' not in handle.results:
+                import numpy as np
+                handle.results['l2_reg'] = np.float32(sum(
+                    0.5 * float((to_numpy(v).astype(np.float64) ** 2).sum())
+                    for k, v in self.get_weights().items() if k.endswith('/weights')))
+            return handle.results['l2_reg']
         if 'scores' not in handle.results:
             packed = resolve(self.compiler.loom_input_tensor, handle.feeds)
             feat = resolve(self.image_feat_grid, handle.feeds)

@@ -79,11 +79,13 @@ class AttentionSeq2Seq:
         uni = None
         if self.decoder_sampling:
             # stand-in for tf.multinomial's private RNG stream (nmn3_netgen_att.py:216-217)
+            # drawn on the host generator (640 floats a batch), so that a seed names the same layouts on every
+            # device -- the recorded training-driver runs are replayed on another box
             if self._gen is None:
-                self._gen = torch.Generator(device=self.engine.device)
+                self._gen = torch.Generator(device='cpu')
                 self._gen.manual_seed(self._seed)
             n = torch.as_tensor(seq).shape[1]
-            uni = torch.rand((self.T_decoder, n), generator=self._gen, device=self.engine.device)
+            uni = torch.rand((self.T_decoder, n), generator=self._gen).to(self.engine.device)
         drop = None
         if self.encoder_dropout or self.decoder_dropout:
             T, n = torch.as_tensor(seq).shape

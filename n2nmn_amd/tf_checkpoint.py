@@ -1,7 +1,7 @@
-"""Reader for TensorFlow V2 checkpoints ("tensor bundles": `<prefix>.index` +
+"""Reader and writer for TensorFlow V2 checkpoints ("tensor bundles": `<prefix>.index` +
 `<prefix>.data-NNNNN-of-MMMMM`) without TensorFlow, so that the snapshots the reference writes
 (`tf.train.Saver`, exp_clevr/train_clevr_gt_layout.py:147,221-223; README.md:75-79) can be loaded by
-variable name:
+variable name, and the drop-in's own `Saver.save` (n2nmn_amd.runtime) leaves files of the same format:
 
     from n2nmn_amd.tf_checkpoint import read_checkpoint
     engine.load_weights(read_checkpoint('exp_clevr/tfmodel/clevr_gt_layout/00050000'),
@@ -56,11 +56,37 @@ def _make_crc_table():
 _CRC_TABLE = _make_crc_table()
 
 
-def crc32c(data: bytes, crc: int = 0) -> int:
+_NATIVE = [None]        # n2nmn_crc32c of the shared library, once it is loaded (False: not available)
+
+
+def _native_crc():
+    if _NATIVE[0] is None:
+        _NATIVE[0] = False
+        try:
+            from . import _lib
+            fn = _lib.lib().n2nmn_crc32c
+            _NATIVE[0] = fn
+        except Exception:
+            pass
+    return _NATIVE[0]
+
+
+def crc32c_py(data: bytes, crc: int = 0) -> int:
+    """table-driven byte loop (the definition; small inputs and boxes without the library)"""
     c = crc ^ 0xffffffff
     for b in data:
         c = _CRC_TABLE[(c ^ b) & 0xff] ^ (c >> 8)
     return c ^ 0xffffffff
+
+
+def crc32c(data: bytes, crc: int = 0) -> int:
+    """CRC-32C (Castagnoli) of `data`, continuing from `crc`.  Tensors (megabytes) go through the library's
+    n2nmn_crc32c (SSE4.2 crc32 instruction / slicing tables, include/n2nmn.h section 8) when it is loaded."""
+    if len(data) >= 4096:
+        fn = _native_crc()
+        if fn:
+            return int(fn(crc, bytes(data) if not isinstance(data, bytes) else data, len(data)))
+    return crc32c_py(data, crc)
 
 
 def mask_crc(crc: int) -> int:
@@ -221,6 +247,9 @@ def read_index(path: str, verify: bool = True) -> Tuple[dict, Dict[str, dict]]:
         for key, val in _block_entries(_read_block(data, boff, bsize, verify)):
             if key == b'':
                 header = _parse_header(val)
+            elif key[:1] == b'\x00':
+                continue        # data of one slice of a partitioned variable (checkpoint::EncodeTensorNameSlice
+                #                 keys start with the ordered code of 0); the full tensor's own entry says `sliced`
             else:
                 entries[key.decode('utf-8')] = _parse_entry(val)
     if header is None:
@@ -265,3 +294,116 @@ def read_checkpoint(prefix: str, names=None, verify: bool = True,
             raise ValueError('tf_checkpoint: data checksum mismatch for %r' % name)
         out[name] = np.frombuffer(raw, dtype=dt.newbyteorder('<')).astype(dt).reshape(e['shape'])
     return out
+
+
+# ---- writer ------------------------------------------------------------------------------------
+_DTYPE_CODES = {np.dtype(v): k for k, v in DTYPES.items()}
+
+
+def _enc_varint(v: int) -> bytes:
+    out = bytearray()
+    v &= (1 << 64) - 1
+    while v >= 0x80:
+        out.append((v & 0x7f) | 0x80)
+        v >>= 7
+    out.append(v)
+    return bytes(out)
+
+
+def _enc_field(num: int, wire: int, payload) -> bytes:
+    tag = _enc_varint((num << 3) | wire)
+    if wire == 0:
+        return tag + _enc_varint(payload)
+    if wire == 2:
+        return tag + _enc_varint(len(payload)) + payload
+    if wire == 5:
+        return tag + struct.pack('<I', payload)
+    raise ValueError(wire)
+
+
+class _TableBuilder:
+    """LevelDB table (tensorflow/core/lib/io/table_builder.cc): data blocks of about `block_size` bytes with
+    prefix-compressed keys and a restart point every 16 entries, one index block, an empty metaindex block,
+    every block followed by its compression type byte (0) and masked CRC32C, then the 48-byte footer."""
+
+    def __init__(self, block_size: int = 4096, restart_interval: int = 16):
+        self.block_size, self.restart_interval = block_size, restart_interval
+        self.out = bytearray()
+        self.index = []            # (last key of the block, handle)
+        self._reset()
+
+    def _reset(self):
+        self.buf, self.restarts, self.count, self.last = bytearray(), [0], 0, b''
+
+    def add(self, key: bytes, value: bytes):
+        if self.count and key <= self.last:
+            raise ValueError('table keys must be added in increasing order')
+        shared = 0
+        if self.count % self.restart_interval == 0:
+            if self.count:
+                self.restarts.append(len(self.buf))
+        else:
+            n = min(len(key), len(self.last))
+            while shared < n and key[shared] == self.last[shared]:
+                shared += 1
+        self.buf += _enc_varint(shared) + _enc_varint(len(key) - shared) + _enc_varint(len(value)) + key[shared:] + value
+        self.last = key
+        self.count += 1
+        if len(self.buf) >= self.block_size:
+            self._flush()
+
+    def _emit(self, block: bytes) -> bytes:
+        off = len(self.out)
+        body = block + b'\x00'
+        self.out += body + struct.pack('<I', mask_crc(crc32c_py(body)))
+        return _enc_varint(off) + _enc_varint(len(block))
+
+    @staticmethod
+    def _finish_block(buf, restarts) -> bytes:
+        return bytes(buf) + b''.join(struct.pack('<I', r) for r in restarts) + struct.pack('<I', len(restarts))
+
+    def _flush(self):
+        if not self.count:
+            return
+        self.index.append((self.last, self._emit(self._finish_block(self.buf, self.restarts))))
+        self._reset()
+
+    def finish(self) -> bytes:
+        self._flush()
+        meta = self._emit(self._finish_block(b'', [0]))
+        ib = bytearray()
+        rs = []
+        for key, handle in self.index:           # the index block restarts at every entry
+            rs.append(len(ib))
+            ib += _enc_varint(0) + _enc_varint(len(key)) + _enc_varint(len(handle)) + key + handle
+        idx = self._emit(self._finish_block(ib, rs or [0]))
+        footer = meta + idx
+        footer += b'\x00' * (40 - len(footer)) + struct.pack('<Q', TABLE_MAGIC)
+        return bytes(self.out) + footer
+
+
+def write_checkpoint(prefix: str, tensors: Dict[str, np.ndarray]) -> None:
+    """`<prefix>.index` + `<prefix>.data-00000-of-00001` holding `tensors` (name -> array) as a one-shard
+    tensor bundle: header entry under the empty key (num_shards 1, little endian, version producer 1), one
+    BundleEntryProto per tensor in key order (dtype, shape, offset, size, masked crc32c of the bytes)."""
+    data = bytearray()
+    tb = _TableBuilder()
+    tb.add(b'', _enc_field(1, 0, 1) + _enc_field(3, 2, _enc_field(1, 0, 1)))
+    for name in sorted(tensors, key=lambda k: k.encode('utf-8')):
+        a = np.asarray(tensors[name])
+        if a.dtype not in _DTYPE_CODES:
+            raise NotImplementedError('tf_checkpoint: cannot store dtype %s of %r' % (a.dtype, name))
+        raw = np.ascontiguousarray(a).astype(a.dtype.newbyteorder('<'), copy=False).tobytes()
+        shape = b''.join(_enc_field(2, 2, _enc_field(1, 0, int(d))) for d in a.shape)
+        entry = _enc_field(1, 0, _DTYPE_CODES[a.dtype]) + _enc_field(2, 2, shape)
+        if len(data):
+            entry += _enc_field(4, 0, len(data))
+        entry += _enc_field(5, 0, len(raw)) + _enc_field(6, 5, mask_crc(crc32c(raw)))
+        tb.add(name.encode('utf-8'), entry)
+        data += raw
+    index = tb.finish()
+    os.makedirs(os.path.dirname(os.path.abspath(prefix)), exist_ok=True)
+    with open(prefix + '.data-00000-of-00001', 'wb') as f:
+        f.write(bytes(data))
+    with open(prefix + '.index', 'wb') as f:
+        f.write(index)

@@ -180,6 +180,7 @@ class Trainer:
         self.baseline = torch.full((1,), self.rl['invalid_expr_loss'], dtype=torch.float32,
                                    device=engine.device)
         self.scores = None
+        self.last_validity = None
         if rccl is None:
             rccl = default_rccl(dist)
         self.buckets = RcclBuckets(engine, self.grads, dist) if rccl else \
@@ -233,6 +234,7 @@ class Trainer:
             io.baseline_decay = self.rl['baseline_decay']
             io.baseline = self.baseline.data_ptr()
         self._keep = (seq, lens, feat, labels, gt, packed, val)
+        self.last_validity = np.asarray(validity, bool)
         return io, packed, validity
 
     def forward_backward(self, batch, gt_layout, reduce: bool = True, objective: int = 0) -> float:
@@ -258,6 +260,13 @@ class Trainer:
             self.buckets.reduce_early()
             return self.buckets.wait()
         return 1.0
+
+    def set_baseline(self, value: float):
+        """the REINFORCE baseline (train_clevr_rl_gt_layout.py:120: tf.Variable(invalid_expr_loss))"""
+        self.baseline.fill_(float(value))
+
+    def get_baseline(self) -> float:
+        return float(self.baseline.item())
 
     def apply(self, scale: float = 1.0):
         self.iteration += 1

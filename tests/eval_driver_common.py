@@ -76,6 +76,18 @@ def import_map():
     }
 
 
+def fetch_name(f):
+    """a fetched graph node by the name the reference's scripts give it"""
+    from n2nmn_amd import runtime, runtime_train
+    if isinstance(f, runtime.Fetch):
+        return f.name
+    if isinstance(f, runtime_train.Const):
+        return 'train_step' if f.deps else 'const'
+    if isinstance(f, runtime_train.Op):
+        return 'avg_sample_loss' if f.kind == 'mean' else f.kind
+    return type(f).__name__
+
+
 class SessionRecorder:
     """Wraps n2nmn_amd.runtime.Session.partial_run and NMN3Model.__init__ while the reference's script
     runs: what the script ASKED of the drop-in (constructor keywords, every partial_run with its feeds)
@@ -133,7 +145,7 @@ class SessionRecorder:
 
         def partial_run_setup(self, fetches, feeds=None):
             h = setup0(self, fetches, feeds)
-            rec.setups[id(h)] = dict(fetches=[f.name for f in h.allowed_fetches],
+            rec.setups[id(h)] = dict(fetches=[fetch_name(f) for f in h.allowed_fetches],
                                      feeds=[rec.role(p) for p in h.allowed_feeds], keep=h)   # (keeps id(h) unique)
             return h
 
@@ -149,7 +161,11 @@ class SessionRecorder:
                 else:
                     feeds[role] = ('array', np.asarray(v))
             # (a copy: exp_vqa/eval_vqa2.py:137 writes into the array it got back)
-            rec.calls.append(dict(fetch=fetches.name, feeds=feeds, handle=id(handle), result=np.array(out, copy=True)))
+            if isinstance(fetches, (list, tuple)):     # the training drivers fetch tuples (train_clevr_gt_layout.py:171,190)
+                rec.calls.append(dict(fetch='(%s)' % ', '.join(fetch_name(f) for f in fetches), feeds=feeds,
+                                      handle=id(handle), result_list=[np.array(o, copy=True) for o in out]))
+            else:
+                rec.calls.append(dict(fetch=fetches.name, feeds=feeds, handle=id(handle), result=np.array(out, copy=True)))
             return out
 
         monkeypatch.setattr(model_cls, '__init__', init)

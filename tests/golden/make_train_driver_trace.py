@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Recorded runs of the reference's TRAINING drivers against the drop-in:
+exp_clevr/train_clevr_gt_layout.py and exp_clevr/train_clevr_rl_gt_layout.py, executed unmodified in the
+scratch tree of tests/train_driver_common.py over the CPU oracle doubles (OracleEngine + OracleTrainer, fp64).
+
+Recorded per script: the batches its reader delivered (text, lengths, labels, layouts, image features by question
+index), what the model constructor and the matched loss graph asked of the Trainer (objective, weight decay,
+Adam hyper-parameters, clip norm, REINFORCE constants), and per iteration what its two partial_run calls
+returned (tokens, entropy_reg; scores, avg_sample_loss), plus probes of every variable after the last step.
+tests/test_gpu_train_driver_trace.py rebuilds the same graph through n2nmn_amd.runtime.tf on the GPU box and
+replays the batches over the HIP engine and the HIP Trainer.
+
+    python tests/golden/make_train_driver_trace.py [--check]
+"""
+import json
+import os
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests'), HERE]
+OUT_GT = os.path.join(HERE, 'train_driver_trace_gt.npz')
+OUT_RL = os.path.join(HERE, 'train_driver_trace_rl.npz')
+PROBES = 8                     # elements per variable compared after the last step
+
+
+def probe_indices(name, size):
+    rng = np.random.default_rng(abs(hash_name(name)) % (2 ** 32))
+    return np.sort(rng.choice(size, size=min(PROBES, size), replace=False))
+
+
+def hash_name(name):
+    h = 0
+    for ch in name.encode():
+        h = (h * 131 + ch) % (2 ** 31 - 1)
+    return h
+
+
+def pack(rec, batches, trainer):
+    out = {}
+    iters = []
+    p1 = [c for c in rec.calls if c['fetch'].startswith('(predicted_tokens')]
+    p2 = [c for c in rec.calls if c['fetch'] == '(scores, avg_sample_loss, train_step)']
+    assert len(p1) == len(p2) == len(batches)
+    for i, (b, c1, c2) in enumerate(zip(batches, p1, p2)):
+        out['b%d_input_seq' % i] = np.asarray(b['input_seq_batch'], np.int32)
+        out['b%d_seq_length' % i] = np.asarray(b['seq_length_batch'], np.int32)
+        out['b%d_labels' % i] = np.asarray(b['answer_label_batch'], np.int32)
+        if 'gt_layout_batch' in b:
+            out['b%d_gt_layout' % i] = np.asarray(b['gt_layout_batch'], np.int32)
+        kind, ids = c1['feeds']['image_feat_grid']
+        assert kind == 'image_ids' and min(ids) >= 0
+        out['b%d_image_ids' % i] = np.asarray(ids, np.int32)
+        out['r%d_tokens' % i] = np.asarray(c1['result_list'][0], np.int32)
+        out['r%d_entropy_reg' % i] = np.asarray(c1['result_list'][1], np.float64)
+        out['r%d_scores' % i] = np.asarray(c2['result_list'][0], np.float64)
+        out['r%d_avg_sample_loss' % i] = np.asarray(c2['result_list'][1], np.float64)
+        iters.append(dict(feeds1=sorted(c1['feeds']), feeds2=sorted(c2['feeds'])))
+    for name, v in trainer.engine.weights.items():
+        flat = np.asarray(v, np.float64).reshape(-1)
+        out['w_' + name] = flat[probe_indices(name, flat.size)]
+    meta = dict(model_kwargs=rec.model_kwargs, iterations=iters, weight_decay=trainer.weight_decay, hyper=trainer.hyper,
+                rl=trainer.rl, objectives=[o for o, _ in trainer.history],
+                setups=[{k: v for k, v in s.items() if k != 'keep'} for s in list(rec.setups.values())[:1]])
+    out['meta'] = np.frombuffer(json.dumps(meta, sort_keys=True).encode(), np.uint8)
+    return out
+
+
+def same(a, b):
+    """None if the two packed traces agree (floats to 1e-9: fp64 oracle, thread-count dependent sums), else why"""
+    if set(a) != set(b):
+        return 'keys differ: %s' % sorted(set(a) ^ set(b))
+    for k in a:
+        x, y = np.asarray(a[k]), np.asarray(b[k])
+        if x.shape != y.shape:
+            return '%s: shape %s vs %s' % (k, x.shape, y.shape)
+        if x.dtype.kind == 'f':
+            if not np.allclose(x, y, rtol=0, atol=1e-9):
+                return '%s: max |diff| %.3e' % (k, float(np.abs(x - y).max()))
+        elif not np.array_equal(x, y):
+            return '%s differs' % k
+    return None
+
+
+def record(which):
+    import eval_driver_common as EC
+    import train_driver_common as TC
+    from make_eval_driver_trace import _Patch
+    from oracle_engine import OracleEngine, OracleTrainer
+    mp = _Patch()
+    OracleTrainer.made.clear()
+    rec = EC.SessionRecorder(TC.train_dims(), n_questions=TC.N_QUESTIONS)
+    with tempfile.TemporaryDirectory() as tmp:
+        try:
+            if which == 'gt':
+                g, d, batches, w = TC.run_train_script(TC.SCRIPT_GT, Path(tmp), mp, OracleEngine, OracleTrainer, rec)
+            else:
+                g, d, batches, w = TC.run_train_script(TC.SCRIPT_RL, Path(tmp), mp, OracleEngine, OracleTrainer, rec,
+                                                       with_snapshot=True, seed_weights=False)
+        finally:
+            mp.undo()
+    return pack(rec, batches, OracleTrainer.made[0])
+
+
+if __name__ == '__main__':
+    for which, path in (('gt', OUT_GT), ('rl', OUT_RL)):
+        fresh = record(which)
+        if '--check' in sys.argv:
+            z = np.load(path)
+            why = same(fresh, {k: z[k] for k in z.files})
+            print(path, 'matches the reference script run' if why is None else 'DIFFERS: ' + why)
+            if why is not None:
+                sys.exit(1)
+        else:
+            np.savez_compressed(path, **fresh)
+            print('wrote', path, os.path.getsize(path), 'bytes')

@@ -30,6 +30,13 @@ class OracleEngine:
     def load_weights(self, weights, strict=True):
         self.weights = {k: np.asarray(v, np.float64) for k, v in weights.items()}
 
+    def variable_names(self):
+        from n2nmn_amd.spec import variable_shapes
+        return dict(variable_shapes(self.dims))
+
+    def get_weights(self):
+        return {k: np.asarray(v, np.float32) for k, v in self.weights.items()}
+
     def seq2seq(self, input_seq, seq_len, T_dec=None, use_gt_layout=False, gt_layout=None,
                 sample_uniforms=None, forced_tokens=None, debug=False, **kw):
         self.calls['seq2seq'] += 1
@@ -68,6 +75,95 @@ class OracleEngine:
                 scores[nodes[i].out_row] = O.eval_expr(self.weights, expr(i), feat, wv,
                                                        self.dims.num_choices, np.float64)
         return torch.as_tensor(scores)
+
+
+# ---- the training step behind n2nmn_amd.runtime_train.TrainStep (exp_clevr/train_clevr*_gt_layout.py) -------
+class OracleTrainer:
+    """n2nmn_amd.train.Trainer's interface as runtime_train.TrainStep uses it, computing with the fp64 autograd
+    oracle (oracle/n2nmn_oracle_grad.py): forward_backward -> losses / scores / gradients, apply -> per-tensor
+    clip-by-norm + Adam on the OracleEngine's weights."""
+
+    made = []            # every trainer built (tests look at the hyper-parameters the script's graph produced)
+
+    def __init__(self, engine, weight_decay=5e-6, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8,
+                 max_grad_l2_norm=10.0, dist=None, rccl=None):
+        from oracle import n2nmn_oracle_grad as G
+        self.G = G
+        self.engine = engine
+        self.weight_decay = weight_decay
+        self.hyper = dict(lr=lr, beta1=beta1, beta2=beta2, eps=eps, max_grad_l2_norm=max_grad_l2_norm)
+        self.rl = dict(invalid_expr_loss=0.5, lambda_entropy=0.005, baseline_decay=0.99)
+        self._baseline = self.rl['invalid_expr_loss']
+        self.iteration = 0
+        self.m = self.v = None
+        self.grads = None
+        self.losses = np.zeros(8, np.float32)
+        self.scores = None
+        self.last_validity = None
+        self.history = []          # (objective, losses dict) per step
+        OracleTrainer.made.append(self)
+
+    def set_baseline(self, value):
+        self._baseline = float(value)
+
+    def get_baseline(self):
+        return float(self._baseline)
+
+    def _token_validity(self, tokens, T_dec):
+        """[T_dec, N, V] masks of the automaton along the given token sequences (nmn3_netgen_att.py:8-15,200-203)"""
+        a = self.engine.assembler
+        Td, N = tokens.shape
+        X = np.tile(np.array([[0, 0, T_dec]], np.int64), (N, 1))
+        out = np.zeros((Td, N, a.P.shape[0]), bool)
+        for t in range(Td):
+            out[t] = O.valid_tokens(X, a.W, a.b)
+            X = X + a.P[tokens[t]]
+        return out
+
+    def forward_backward(self, batch, gt_layout, reduce=True, objective=0):
+        G, e = self.G, self.engine
+        tokens = np.asarray(gt_layout, np.int32)
+        names = list(e.assembler.module_names)
+        b = {k: np.asarray(v) for k, v in batch.items()}
+        if objective == 0:
+            L, g, ex = G.loss_and_grads(e.weights, names, b, tokens.shape[0], e.dims.num_choices, tokens,
+                                        weight_decay=self.weight_decay)
+            self.losses[:4] = [L['avg_sample_loss'], L['seq_likelihood_loss'], L['l2_reg'], L['total_loss']]
+            self.last_validity = np.ones(tokens.shape[1], bool)
+        else:
+            tv = self._token_validity(tokens, tokens.shape[0])
+            L, g, ex = G.loss_and_grads_rl(e.weights, names, b, tokens.shape[0], e.dims.num_choices, tokens, tv,
+                                           self._baseline, self.rl['invalid_expr_loss'], self.rl['lambda_entropy'],
+                                           self.weight_decay, self.rl['baseline_decay'])
+            self.losses[:5] = [L['avg_sample_loss'], L['policy_gradient_loss'], L['l2_reg'], L['total_loss'],
+                               L['entropy_reg']]
+            self._baseline = L['new_baseline']
+            self.last_validity = ex['validity']
+        self.grads, self.scores = g, ex['scores']
+        self.history.append((objective, dict(L)))
+        return 1.0
+
+    def apply(self, scale=1.0):
+        """per-tensor tf.clip_by_norm, then tf.train.AdamOptimizer's update (TF 1.0.0: lr_t = lr sqrt(1 - b2^t) /
+        (1 - b1^t); w -= lr_t m / (sqrt(v) + eps)) -- in torch fp64 (oracle_grad.adam_step is the numpy statement
+        of the same step; tests/test_reference_train_driver_source.py checks one against the other)"""
+        e, h = self.engine, self.hyper
+        self.iteration += 1
+        t = self.iteration
+        if self.m is None:
+            self.m = {k: torch.zeros(v.shape, dtype=torch.float64) for k, v in e.weights.items()}
+            self.v = {k: torch.zeros(v.shape, dtype=torch.float64) for k, v in e.weights.items()}
+        clip = h['max_grad_l2_norm'] if h['max_grad_l2_norm'] and h['max_grad_l2_norm'] > 0 else None
+        lr_t = h['lr'] * np.sqrt(1.0 - h['beta2'] ** t) / (1.0 - h['beta1'] ** t)
+        new = {}
+        for k, w in e.weights.items():
+            g = torch.as_tensor(np.asarray(self.grads[k], np.float64)) * scale
+            if clip is not None:
+                g = g * (clip / max(float(torch.linalg.vector_norm(g)), clip))
+            self.m[k].mul_(h['beta1']).add_(g, alpha=1.0 - h['beta1'])
+            self.v[k].mul_(h['beta2']).addcmul_(g, g, value=1.0 - h['beta2'])
+            new[k] = (torch.as_tensor(np.asarray(w, np.float64)) - lr_t * self.m[k] / (self.v[k].sqrt() + h['eps'])).numpy()
+        e.weights = new
 
 
 # ---- models_vqa: the double behind n2nmn_amd.models_vqa.NMN3Model (exp_vqa/eval_vqa2.py) -------------------

@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""Root-cause harness for the concurrent-stream wrong-tile fault of gemm_dma3_kernel (profiles/r05_notes.md
+section 8, profiles/r06_notes.md section 1).  Runs on the DIAGNOSTIC library (tools/diag/build_diag.py).
+
+Part A (standalone): the conv_image contraction of one pass (153600 x 512 x 250) on stream 1 -- the victim --
+against itself run alone (bit-reproducible), while stream 2 runs one "aggressor" at a time: nothing, a clone of
+the victim, the exact-fp32 LDS-DMA GEMM, workgroups that only HOLD 20 / 48 / 80 KiB of LDS, workgroups that
+rewrite their own LDS, an HBM streamer without LDS, workgroups that LDS-DMA into their own LDS.  Wrong tiles are
+listed with their position inside the tile; with --verify the kernel checks every LDS-DMA piece in LDS against a
+direct global read and records the workgroup's LDS allocation register, CU / SE / XCC ids for every anomaly.
+
+Part B (pipeline): the round-5 reproducer (two PassPipeline workers, bf16x3 mode, N2NMN_GEMM_DMA3=1) with the
+same in-kernel verification.
+
+    python tools/diag/dma3_fault.py [--rounds 100] [--part A|B|AB] [--verify]
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, HERE)
+import build_diag  # noqa: E402
+
+P = C.c_void_p
+
+
+def diag_lib(which='full'):
+    build_diag.use_diag_lib(which)
+    from n2nmn_amd import _lib
+    L = _lib.lib()
+    L.n2nmn_diag_config.restype = C.c_int
+    L.n2nmn_diag_config.argtypes = [C.c_uint, P, C.c_uint, P, P, C.c_uint, C.c_int]
+    L.n2nmn_diag_pack3.restype = C.c_int
+    L.n2nmn_diag_pack3.argtypes = [P, C.c_int, C.c_int, P, P, C.c_int, C.c_int, P]
+    L.n2nmn_diag_gemm.restype = C.c_int
+    L.n2nmn_diag_gemm.argtypes = [P, P, P, P, P] + [C.c_int] * 6 + [P]
+    L.n2nmn_diag_aggressor.restype = C.c_int
+    L.n2nmn_diag_aggressor.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, P, C.c_size_t, P, P]
+    return L
+
+
+class Diag:
+    """record buffers on the device + decoding"""
+    CAP, WGCAP = 4096, 1 << 16
+
+    def __init__(self, L):
+        self.L = L
+        self.rec = torch.zeros(self.CAP * 16, dtype=torch.int32, device='cuda')
+        self.cnt = torch.zeros(16, dtype=torch.int32, device='cuda')
+        self.wg = torch.zeros(self.WGCAP * 4, dtype=torch.int32, device='cuda')
+
+    def config(self, level, lds_pad=0):
+        torch.cuda.synchronize()
+        self.cnt.zero_()
+        torch.cuda.synchronize()
+        rc = self.L.n2nmn_diag_config(level, self.rec.data_ptr(), self.CAP, self.cnt.data_ptr(), self.wg.data_ptr(),
+                                      self.WGCAP, lds_pad)
+        assert rc == 0, rc
+
+    def records(self):
+        torch.cuda.synchronize()
+        n = int(self.cnt[0].item())
+        r = self.rec.cpu().numpy().view(np.uint32).reshape(-1, 16)[:min(n, self.CAP)]
+        return n, r
+
+    def workgroups(self):
+        torch.cuda.synchronize()
+        n = min(int(self.cnt[1].item()), self.WGCAP)
+        return self.wg.cpu().numpy().view(np.uint32).reshape(-1, 4)[:n]
+
+
+def decode_hw(lds_alloc, hw_id, xcc):
+    # HW_REG_LDS_ALLOC: LDS_BASE [7:0] (+ [8] on gfx950?), LDS_SIZE [20:12], VGPR_SHARED_SIZE [27:24] (granules)
+    # HW_REG_HW_ID (gfx9): WAVE_ID [3:0], SIMD_ID [5:4], PIPE_ID [7:6], CU_ID [11:8], SH_ID [12], SE_ID [15:13],
+    # TG_ID [19:16], VM_ID [23:20], QUEUE_ID [26:24], STATE_ID [29:27], ME_ID [31:30]
+    return dict(lds_base=lds_alloc & 0xfff, lds_size=(lds_alloc >> 12) & 0x1ff, raw='%08x' % lds_alloc,
+                simd=(hw_id >> 4) & 3, pipe=(hw_id >> 6) & 3, cu=(hw_id >> 8) & 15, sh=(hw_id >> 12) & 1,
+                se=(hw_id >> 13) & 7, tg=(hw_id >> 16) & 15, queue=(hw_id >> 24) & 7, me=(hw_id >> 30) & 3,
+                xcc=xcc & 0xf)
+
+
+def print_records(tag, diag, limit=24):
+    n, r = diag.records()
+    print('%s: %d anomaly records' % (tag, n), flush=True)
+    kinds = {1: 'own piece wrong behind vmcnt(0)', 2: "neighbour's piece wrong behind the barrier",
+             3: 'redundant accumulators differ', 4: 'second pass of the K loop gave other accumulators',
+             6: 'operand bytes (or the device row count) changed while the kernel ran'}
+    for row in r[:limit]:
+        hw = decode_hw(int(row[12]), int(row[13]), int(row[14]))
+        print('  kind %d (%s) tile %d stage %d wave %d (checked wave %d) piece %d mt %d bad lanes %d mask %08x%08x '
+              'got %08x exp %08x lds_off %d reread_ok %d stale_match %d | %s' % (
+                  row[0], kinds.get(int(row[0]), '?'), row[1], row[2], row[3] & 0xff, (row[3] >> 8) & 0xff, row[4],
+                  row[15] >> 16, row[15] & 0xffff, row[6], row[5], row[7], row[8], row[9], row[10], row[11], hw),
+              flush=True)
+    if len(r):
+        from collections import Counter
+        print('  by kind:', dict(Counter(int(x) for x in r[:, 0])))
+        print('  by piece:', dict(Counter(int(x) for x in r[:, 4])))
+        print('  by stage parity:', dict(Counter(int(x) & 1 for x in r[:, 2])))
+        print('  reread_ok:', dict(Counter(int(x) for x in r[:, 10])), ' stale_match:',
+              dict(Counter(int(x) for x in r[:, 11])))
+        print('  lds_alloc raw:', dict(Counter('%08x' % int(x) for x in r[:, 12])))
+        print('  xcc:', dict(Counter(int(x) & 0xf for x in r[:, 14])))
+    return n
+
+
+def lds_alloc_histogram(tag, diag):
+    from collections import Counter
+    w = diag.workgroups()
+    c = Counter('%08x' % int(x) for x in w[:, 0])
+    print('%s: LDS_ALLOC of %d recorded workgroups: %s' % (tag, len(w), dict(c.most_common(24))), flush=True)
+
+
+# ------------------------------------------------------------------------------------------------ part A
+def part_a(L, diag, rounds, verify):
+    dev = 'cuda'
+    M, N, K = 16 * 64 * 150, 250, 512
+    Kp, Np = 512, 256
+    g = torch.Generator(device='cpu').manual_seed(1)
+    A = torch.clamp(torch.randn(M, K, generator=g), min=0).to(dev)
+    B = (torch.randn(K, N, generator=g) * 0.05).to(dev)
+    bias = (torch.rand(N, generator=g) * 0.2 - 0.1).to(dev)
+    Bp = torch.zeros(Kp * Np, device=dev)
+    Bp3 = torch.zeros(3 * Kp * Np, dtype=torch.int16, device=dev)
+    L.n2nmn_diag_pack3(B.data_ptr(), K, N, Bp.data_ptr(), Bp3.data_ptr(), Kp, Np, None)
+    torch.cuda.synchronize()
+    A2 = torch.clamp(torch.randn(M, K, generator=g), min=0).to(dev)       # the aggressor clone's operands
+    C2 = torch.zeros(M, N, device=dev)
+    NV = 4
+    Cs = [torch.zeros(M, N, device=dev) for _ in range(NV)]
+    big = torch.randn(64 << 20, device=dev)                               # 256 MiB for the streamers
+    sink = torch.zeros(4, device=dev)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def gemm(Am, Cm, mt, stream):
+        rc = L.n2nmn_diag_gemm(Am.data_ptr(), Bp.data_ptr(), Bp3.data_ptr(), bias.data_ptr(), Cm.data_ptr(), M, N, K,
+                               Kp, Np, mt, stream.cuda_stream)
+        assert rc == 0, rc
+
+    def aggr(mode, iters, lds, grid, stream):
+        rc = L.n2nmn_diag_aggressor(mode, iters, lds, grid, big.data_ptr(), big.numel(), sink.data_ptr(),
+                                    stream.cuda_stream)
+        assert rc == 0, rc
+
+    aggressors = [
+        ('none', None),
+        ('clone of the victim (other operands)', lambda mt: [gemm(A2, C2, mt, s2) for _ in range(NV)]),
+        ('fp32 gemm_dma_kernel', lambda mt: [gemm(A2, C2, 0, s2) for _ in range(NV)]),
+        ('hold 20 KiB LDS, sleep', lambda mt: aggr(0, 300, 20 << 10, 2048, s2)),
+        ('hold 48 KiB LDS, sleep', lambda mt: aggr(0, 300, 48 << 10, 1024, s2)),
+        ('hold 80 KiB LDS, sleep', lambda mt: aggr(0, 300, 80 << 10, 512, s2)),
+        ('rewrite own 20 KiB LDS', lambda mt: aggr(1, 400, 20 << 10, 2048, s2)),
+        ('HBM streamer, no LDS', lambda mt: aggr(2, 400, 0, 4096, s2)),
+        ('LDS-DMA into own 32 KiB', lambda mt: aggr(3, 200, 32 << 10, 1024, s2)),
+    ]
+    summary = []
+    for mt in (1, 2, 0):
+        name = {0: 'fp32 gemm_dma_kernel (control)', 1: 'gemm_dma3_kernel<1> (64-row tiles)',
+                2: 'gemm_dma3_kernel<2> (128-row tiles)'}[mt]
+        diag.config(0)
+        with torch.cuda.stream(s1):
+            gemm(A, Cs[0], mt, s1)
+        torch.cuda.synchronize()
+        C0 = Cs[0].clone()
+        gemm(A, Cs[1], mt, s1)
+        torch.cuda.synchronize()
+        assert torch.equal(C0, Cs[1]), 'alone vs alone differs'
+        ref = (A.double() @ B.double() + bias.double())
+        print('\n=== victim %s: alone max |err| vs fp64 = %.3e' % (name, float((C0.double() - ref).abs().max())), flush=True)
+        del ref
+        th = 64 * mt if mt else 128
+        for aname, afn in aggressors:
+            for level in ([0, 3] if (verify and mt) else [0]):
+                diag.config(level | 8 if level else 0)
+                bad_launches, bad_tiles_total, examples = 0, 0, []
+                for r in range(rounds):
+                    if afn is not None:
+                        afn(mt)
+                    for i in range(NV):
+                        gemm(A, Cs[i], mt, s1)
+                    torch.cuda.synchronize()
+                    for i in range(NV):
+                        if not torch.equal(Cs[i], C0):
+                            bad_launches += 1
+                            d = (Cs[i] != C0)
+                            rows, cols = torch.nonzero(d, as_tuple=True)
+                            tiles = torch.unique((rows // th) * 2 + cols // 128)
+                            bad_tiles_total += int(tiles.numel())
+                            if len(examples) < 6:
+                                t0 = int(tiles[0].item())
+                                sel = ((rows // th) * 2 + cols // 128) == t0
+                                rr, cc = rows[sel] % th, cols[sel] % 128
+                                err = (Cs[i] - C0)[rows[sel], cols[sel]].abs()
+                                rel = err / C0[rows[sel], cols[sel]].abs().clamp(min=1e-6)
+                                examples.append('tile %d (row tile %d, col tile %d): %d wrong elements, rows %s, cols %d..%d, '
+                                                'max abs %.2e, max rel %.2e, nan %d' % (
+                                                    t0, t0 // 2, t0 % 2, int(sel.sum()), sorted(set(rr.tolist()))[:40],
+                                                    int(cc.min()), int(cc.max()), float(err.max()), float(rel.max()),
+                                                    int(torch.isnan(Cs[i]).sum())))
+                line = 'victim mt=%d | aggressor %-40s | level %d | %d of %d launches wrong, %d wrong tiles' % (
+                    mt, aname, level, bad_launches, rounds * NV, bad_tiles_total)
+                print(line, flush=True)
+                summary.append(line)
+                for e in examples:
+                    print('     ', e, flush=True)
+                if level:
+                    print_records('      records', diag)
+                    lds_alloc_histogram('      ', diag)
+    print('\n==== part A summary')
+    for s in summary:
+        print(s)
+
+
+# ------------------------------------------------------------------------------------------------ part B
+def part_b(L, diag, rounds, levels):
+    os.environ['N2NMN_GEMM_DMA3'] = '1'
+    from n2nmn_amd import synth
+    from n2nmn_amd.nmn3_assembler import Assembler
+    from n2nmn_amd.pipeline import PassPipeline
+    from n2nmn_amd.spec import Dims, CLEVR_MODULE_NAMES
+    S = 2
+    d = Dims()
+    p = PassPipeline(d, Assembler(list(CLEVR_MODULE_NAMES)), synth.make_weights(d, seed=0), streams=S, kcap=16,
+                     mode='throughput_bf16x3')
+    p.fill_all(lambda i: synth.make_inputs(d, seed=500 + i, min_len=1), lambda i: synth.template_layout_batch(d, offset=i))
+    torch.cuda.synchronize()
+    widths = [[8, 10], [16, 8]]
+    diag.config(0)
+    p.run(widths, gt=True)
+    p.run(widths, gt=False)
+
+    def alone(si, n):
+        for wk in p.workers:
+            wk['next'] = 0
+        p.run([[n] if k == si else [] for k in range(S)], gt=True)
+        return p.bucket(si, 0).scores.cpu().numpy().copy()
+
+    ref = [alone(si, 10) for si in range(S)]
+    again = [alone(si, 10) for si in range(S)]
+    print('\n=== part B (pipeline, bf16x3 mode, gemm_dma3 on): alone vs alone', [float(np.abs(a - b).max()) for a, b in zip(ref, again)],
+          flush=True)
+    for level in levels:
+        diag.config(level)
+        bad = 0
+        for it in range(rounds):
+            for wk in p.workers:
+                wk['next'] = 0
+            p.run([[10]] * S, gt=True)
+            diffs = [float(np.abs(p.bucket(si, 0).scores.cpu().numpy() - ref[si]).max()) for si in range(S)]
+            if max(diffs) > 0:
+                bad += 1
+                if bad <= 10:
+                    print('  level %d round %d: max |concurrent - alone| per worker %s' % (level, it, ['%.2e' % x for x in diffs]),
+                          flush=True)
+        print('part B level %d: %d of %d concurrent rounds differ (bitwise) from the passes run alone' % (level, bad, rounds),
+              flush=True)
+        if level:
+            print_records('  records', diag)
+            if level & 8:
+                lds_alloc_histogram('  ', diag)
+    p.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--rounds', type=int, default=60)
+    ap.add_argument('--part', default='AB')
+    ap.add_argument('--verify', action='store_true')
+    ap.add_argument('--levels', default='0,3,11,4')
+    ap.add_argument('--lib', default='full')
+    a = ap.parse_args()
+    L = diag_lib(a.lib)
+    print('library:', a.lib, flush=True)
+    diag = Diag(L)
+    if 'B' in a.part:
+        part_b(L, diag, a.rounds, [int(x) for x in a.levels.split(',')])
+    if 'A' in a.part:
+        part_a(L, diag, a.rounds, a.verify)
+
+
+if __name__ == '__main__':
+    main()

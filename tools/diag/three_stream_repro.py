@@ -7,6 +7,10 @@ import sys
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+if os.environ.get('N2NMN_DIAG_LIB'):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import build_diag
+    print('library:', build_diag.use_diag_lib(os.environ['N2NMN_DIAG_LIB']), flush=True)
 from n2nmn_amd import synth
 from n2nmn_amd.nmn3_assembler import Assembler
 from n2nmn_amd.pipeline import PassPipeline
