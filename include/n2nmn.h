@@ -609,6 +609,18 @@ int n2nmn_debug_walk_replay(n2nmn_ctx *ctx, int which, int iters, double *us_avg
 int n2nmn_debug_walk_timeline(n2nmn_ctx *ctx, long long *timeline_dev);
 int n2nmn_debug_gemm(n2nmn_ctx *ctx, const float *A, const float *B, const float *bias,
                      float *C, int M, int N, int K, n2nmn_stream stream);
+/* A/B switches of ONE context (a fork without its own entry uses its parent's); value NULL removes the entry.
+ * The library reads no environment variable: these are the only run-time switches, they are per context, and
+ * none of them changes what is computed -- only which launch schedule / tile computes it (the tests run every
+ * setting against the oracle).  Unknown key: N2NMN_EKEY.  Keys (values are decimal strings):
+ *   "tile_min_rows"  encoder steps with at most this many live rows use the K-split tiles (default 192)
+ *   "eht_rows"       0: encoder_h_transform over all T N rows instead of the rows inside their length (default 1)
+ *   "debug_gemm_b3"  n2nmn_debug_gemm: n < 0 = -n launches per call (timing loops); n > 0 (n launches on the
+ *                    split-operand bf16 GEMM) is refused: that kernel exists in the diagnostic library only
+ *   before n2nmn_train_enable -- where the weight-gradient GEMMs of a training step run:
+ *   "train_overlap"  0: no side stream (default 1)      "train_schedule" 0: every leaf after its recurrence
+ *   "train_bg_wgs"   cap on background workgroups, 0 = unbounded     "train_chunks" "p0,p1,p2" time-chunk split */
+int n2nmn_debug_set(n2nmn_ctx *ctx, const char *key, const char *value);
 /* out[M,N] = (relu ? max(0, .) : .)(A[M,K] . W[K,N] + bias[N]), row-major fp32, K % 4 == 0:
  * util/cnn.py:87-126 (fc_layer / fc_relu_layer) and -- on im2col rows -- the VALID strided convolutions of
  * models_shapes/shapes_convnet.py:8-17 (BASELINE.json configs[0]; not on the CLEVR hot path).  Packs W per

@@ -139,11 +139,13 @@ static size_t carve_weights(n2nmn_ctx* c, char* base) {
     c->dec_W0h_64 = k.take<float>(L * 4 * L); c->dec_W1_64 = k.take<float>(2 * L * 4 * L);
     c->enc_W0h_b3 = k.take<uint16_t>(3 * L * 4 * L); c->enc_W1_b3 = k.take<uint16_t>(3 * 2 * L * 4 * L);
     c->dec_W0h_b3 = k.take<uint16_t>(3 * L * 4 * L); c->dec_W1_b3 = k.take<uint16_t>(3 * 2 * L * 4 * L);
+#ifdef N2NMN_DIAG      // (operand planes of gemm_dma3_kernel: diagnostic library only, kernels_gemm.hip)
     c->eht_W_b3 = k.take<uint16_t>(3 * (size_t)c->KpL * L); c->att_W_b3 = k.take<uint16_t>(3 * (size_t)c->KpL * L);
     if (Mp % 128 == 0) {
       c->find_img_b3 = k.take<uint16_t>(3 * (size_t)c->KpD * Mp);
       c->fsp_img_b3 = k.take<uint16_t>(3 * (size_t)c->KpD * Mp);
     }
+#endif
   }
   c->eht_W_p = k.take<float>((size_t)c->KpL * L);
   c->att_W_t = k.take<float>(L * L);
@@ -316,11 +318,21 @@ static int lstm_wide(const n2nmn_ctx* c) {
          : c->mode == N2NMN_MODE_THROUGHPUT_KSPLIT ? 1 : 0;
 }
 
-// encoder steps with at most this many active rows use the K-split tiles (needs the host lengths)
-static int tile_min_rows() {
-  static const int v = [] { const char* e = getenv("N2NMN_TILE_MIN_ROWS"); return e ? atoi(e) : 192; }();
-  return v;
+// a switch of n2nmn_debug_set: this context's entry, else its parent's, else the default
+const char* knob_str(const n2nmn_ctx* c, const char* key) {
+  for (const n2nmn_ctx* p = c; p; p = p->parent) {
+    auto it = p->knobs.find(key);
+    if (it != p->knobs.end()) return it->second.c_str();
+  }
+  return nullptr;
 }
+int knob_int(const n2nmn_ctx* c, const char* key, int dflt) {
+  const char* v = knob_str(c, key);
+  return v ? atoi(v) : dflt;
+}
+
+// encoder steps with at most this many active rows use the K-split tiles (needs the host lengths)
+static int tile_min_rows(const n2nmn_ctx* c) { return knob_int(c, "tile_min_rows", 192); }
 
 // state buffers (eh0/eh1/dh0/dh1) are k-interleaved [L/4][R][4] with R = capacity N
 // split-operand bf16 mode of a pass of N rows (a training forward keeps the exact kernels)
@@ -386,8 +398,7 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmAr
   // encoder_h_transform over the rows inside their question's length only (44 % of T*N are past it at
   // the eval mix; every reader of `eht` takes the bias vector for those: DecStepArgs::eht_bias) -- when
   // the GEMM rides in the decoder's launch of a large pass and nobody was promised the full matrix
-  static const bool eht_rows_on = [] { const char* e = getenv("N2NMN_EHT_ROWS"); return !e || atoi(e) != 0; }();
-  const bool eht_rows = eht_rows_on && defer_eht && !c->rec && (size_t)T * N >= 8192;
+  const bool eht_rows = knob_int(c, "eht_rows", 1) != 0 && defer_eht && !c->rec && (size_t)T * N >= 8192;
   const bool b3 = lstm_b3(c, N);      // (with the planes of block A behind it, see carve_workspace)
   launch_enc_prepare(io->seq_length, N, T, c->perm, c->nact, c->eh0[0], (b3 ? 25 : 10) * (size_t)d.N * L, s,
                      eht_rows ? c->enc_rows_n : nullptr);
@@ -492,7 +503,7 @@ int encoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, GemmAr
                                (j1.active ? 2.0 * L * 4 * L + 5.0 * r1 * L : 0));
       ProfScope ps(c, F_LSTM_ENC, fl, by, s);
       int wide = lstm_wide(c);
-      if (!act_host.empty() && act_host[std::min(k, T - 1)] <= tile_min_rows()) wide = 1;
+      if (!act_host.empty() && act_host[std::min(k, T - 1)] <= tile_min_rows(c)) wide = 1;
       if (b3) {
         attach_planes(c, j0); attach_planes(c, j1);
         if (wide == 1) {              // tail of the length-sorted encoder: exact-fp32 K-split tiles (+ planes)
@@ -691,7 +702,7 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
         }
         if (!dact_host.empty()) {
           const int a0 = j0.active ? dact_host[k] : 0, a1 = j1.active ? dact_host[st] : 0;
-          if (std::max(a0, a1) <= tile_min_rows()) wide = 1;      // few rows left: the K-split tiles scale with rows
+          if (std::max(a0, a1) <= tile_min_rows(c)) wide = 1;      // few rows left: the K-split tiles scale with rows
         }
       }
       ProfScope ps(c, F_LSTM_DEC0, (j0.active ? fl0 * live0 / N : 0) + (j1.active ? fl1 * live1 / N : 0),
@@ -1859,10 +1870,9 @@ int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int
   const int pf_env = c->walk_pre_find;
   const bool pre = use_table && (pf_env < 0 ? K * N >= 128 : pf_env > 0);
   // staged walker: with both of the above the tree-dependent work leaves the one-workgroup-per-question
-  // chain too (kernels_walk.hip: walk_heavy_kernel / walk_fspepi_kernel / walk_light_kernel); N2NMN_WALK_STAGED=0 keeps the
-  // round-3 walker
-  static const bool staged_env = [] { const char* e = getenv("N2NMN_WALK_STAGED"); return !e || atoi(e) != 0; }();
-  const bool staged = pre && a.defer_pool && staged_env && c->walk_staged != 0 &&
+  // chain too (kernels_walk.hip: walk_heavy_kernel / walk_fspepi_kernel / walk_light_kernel); n2nmn_walk_set_staged(ctx, 0)
+  // keeps the round-3 walker
+  const bool staged = pre && a.defer_pool && c->walk_staged != 0 &&
                       K * N < (1 << 22) && T_dec <= 255;
   if (a.defer_pool) {
     // the per-pass counters (two sets, used alternately: walk_fcatt_kernel clears the other one) and the
@@ -2026,8 +2036,7 @@ int n2nmn_execute_tokens(n2nmn_ctx* c, const int32_t* tokens, int T_dec, int N,
   N2_REQUIRE(c && tokens && image_feat && word_vecs && scores, N2NMN_EINVAL,
              "execute_tokens: null argument");
   // dimensions outside the walker's tiling (models_vqa): the level path, scheduled on the device
-  static const bool force_levels = [] { const char* e = getenv("N2NMN_TOKENS_VIA_LEVELS"); return e && atoi(e) != 0; }();
-  if (!n2nmn_walk_supported(c) || force_levels || c->tokens_via_levels) {
+  if (!n2nmn_walk_supported(c) || c->tokens_via_levels) {
     int rc = n2nmn_conv_image(c, image_feat, N, N2NMN_CONV_FIND | N2NMN_CONV_FSP, tokens, T_dec, stream);
     if (rc != N2NMN_OK) return rc;
     return run_tokens_levels(c, tokens, T_dec, N, image_feat, word_vecs, scores, validity, S(stream));
@@ -2206,14 +2215,35 @@ int n2nmn_debug_lstm_bench(n2nmn_ctx* c, int variant, int rows_per_wg, int njobs
   return check_launch("debug_lstm_bench");
 }
 
+int n2nmn_debug_set(n2nmn_ctx* ctx, const char* key, const char* value) {
+  N2_REQUIRE(ctx && key, N2NMN_EINVAL, "debug_set: null argument");
+  static const char* const known[] = {"tile_min_rows", "eht_rows", "debug_gemm_b3", "train_overlap", "train_bg_wgs",
+                                      "train_schedule", "train_chunks"};
+  bool ok = false;
+  for (const char* k : known) ok = ok || strcmp(k, key) == 0;
+  if (!ok) {
+    set_last_error(std::string("debug_set: unknown key '") + key + "'");
+    return N2NMN_EKEY;
+  }
+  if (value) ctx->knobs[key] = value; else ctx->knobs.erase(key);
+  return N2NMN_OK;
+}
+
 int n2nmn_debug_gemm(n2nmn_ctx* ctx, const float* A, const float* B, const float* bias, float* C,
                      int M, int N, int K, n2nmn_stream stream) {
   N2_REQUIRE(ctx && A && B && C, N2NMN_EINVAL, "debug_gemm: null argument");
   N2_REQUIRE(M > 0 && N > 0 && K > 0 && K % 4 == 0, N2NMN_EINVAL,
              "debug_gemm: K must be a positive multiple of 4");
-  // N2NMN_DEBUG_GEMM_B3=1 (read per call): the split-operand bf16 form (gemm_dma3_kernel)
-  const char* e3 = getenv("N2NMN_DEBUG_GEMM_B3");
+  // n2nmn_debug_set(ctx, "debug_gemm_b3", "n") (read per call): n < 0: -n launches (timing loops); n > 0: n launches
+  // in the split-operand bf16 form -- gemm_dma3_kernel, which only the diagnostic library has (kernels_gemm.hip)
+  const char* e3 = knob_str(ctx, "debug_gemm_b3");
+#ifdef N2NMN_DIAG
   const bool b3 = e3 && atoi(e3) > 0;
+#else
+  N2_REQUIRE(!(e3 && atoi(e3) > 0), N2NMN_EINVAL,
+             "debug_gemm: the split-operand GEMM is not part of this library (tools/diag/build_diag.py)");
+  const bool b3 = false;
+#endif
   const int Kp = round_up(K, 32), Np = round_up(N, b3 ? 128 : 64);
   float* Bp = nullptr;
   uint16_t* Bp3 = nullptr;

@@ -500,14 +500,15 @@ int n2nmn_train_enable(n2nmn_ctx* c) {
       N2_HIP(hipEventCreateWithFlags(&t->ev_fork[i], hipEventDisableTiming));
     N2_HIP(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
     N2_HIP(hipEventCreateWithFlags(&t->infer_ev, hipEventDisableTiming));
-    const char* env = getenv("N2NMN_TRAIN_OVERLAP");
-    t->overlap = !(env && env[0] == '0');
+    // schedule switches (n2nmn_debug_set before n2nmn_train_enable; tests/test_gpu_train.py runs every schedule
+    // against the oracle): "train_overlap", "train_bg_wgs", "train_schedule", "train_chunks"
+    t->overlap = knob_int(c, "train_overlap", 1) != 0;
     // models_vqa (lstm_dim 1024, 32-row backward tiles, GEMMs several times the size): its step
     // measured 7.93 ms with unbounded background launches against 8.14 bounded (same box)
     if (vqa_variant) t->bg_wgs = 0;
-    if (const char* e = getenv("N2NMN_TRAIN_BG_WGS")) t->bg_wgs = std::max(0, atoi(e));
-    if (const char* e = getenv("N2NMN_TRAIN_SCHEDULE")) t->schedule = atoi(e) != 0;
-    if (const char* e = getenv("N2NMN_TRAIN_CHUNKS")) {
+    if (const char* e = knob_str(c, "train_bg_wgs")) t->bg_wgs = std::max(0, atoi(e));
+    if (const char* e = knob_str(c, "train_schedule")) t->schedule = atoi(e) != 0;
+    if (const char* e = knob_str(c, "train_chunks")) {
       int v[3] = {0, 0, 0};
       const int got = sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]);
       for (int i = 0; i < 3; ++i) {

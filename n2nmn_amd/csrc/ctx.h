@@ -127,6 +127,9 @@ struct n2nmn_ctx {
   std::vector<Var> vars;                   // indexed by VarId (absent ones have numel 0)
   std::vector<int> pub;                    // VarIds of the variables of this variant, in order
   std::unordered_map<std::string, int> index;
+  // n2nmn_debug_set(ctx, key, value): A/B switches of this context (a fork without its own entry asks its
+  // parent); the keys are listed in include/n2nmn.h section 7.  Never read from the environment.
+  std::unordered_map<std::string, std::string> knobs;
   bool committed = false;
   bool have_tables = false;
   int mode = 0;                            // N2NMN_MODE_*: tile shape of the recurrent step kernels
@@ -320,6 +323,9 @@ struct ProfScope {
 };
 
 const n2nmn_ctx* root(const n2nmn_ctx* c);
+// switches of n2nmn_debug_set (capi.cpp): this context's entry, else its parent's, else nullptr / the default
+const char* knob_str(const n2nmn_ctx* c, const char* key);
+int knob_int(const n2nmn_ctx* c, const char* key, int dflt);
 bool is_committed(const n2nmn_ctx* c);
 bool has_tables(const n2nmn_ctx* c);
 hipStream_t S(n2nmn_stream s);

@@ -15,6 +15,17 @@ inline void ensure_dynamic_lds(const void* kernel, int bytes, std::atomic<uint64
   done.fetch_or(bit, std::memory_order_release);
 }
 
+// A/B switches of the launchers.  The product library reads NO environment variable: each switch is its
+// default, fixed at compile time.  Only the diagnostic build (tools/diag/build_diag.py, -DN2NMN_DIAG) looks
+// the name up in the environment (once, on first use).  Per-context switches that tests need at run time go
+// through n2nmn_debug_set (include/n2nmn.h section 7).
+#ifdef N2NMN_DIAG
+#include <cstdlib>
+#define N2NMN_KNOB_INT(name, dflt) ([] { const char* e_ = std::getenv(name); return e_ ? std::atoi(e_) : (dflt); }())
+#else
+#define N2NMN_KNOB_INT(name, dflt) (dflt)
+#endif
+
 namespace n2nmn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -370,8 +370,8 @@ void launch_gemm_pk2(const GemmArgs& a0, const GemmArgs& a1, hipStream_t s) {
 // 64 x 64 tiles of gemm_pk / gemm_pkn spread the same work over four times as many workgroups (a
 // training step's encoder_h_transform, 2880 x 512 x 512 = 92 big tiles: 39.6 us against 27.8).
 static bool use_gemm_dma(const GemmArgs* a, int n) {
-  static const int on = [] { const char* e = getenv("N2NMN_GEMM_DMA"); return e ? atoi(e) : 1; }();
-  static const int min_tiles = [] { const char* e = getenv("N2NMN_GEMM_DMA_MIN_TILES"); return e ? atoi(e) : 192; }();
+  static const int on = N2NMN_KNOB_INT("N2NMN_GEMM_DMA", 1);
+  static const int min_tiles = N2NMN_KNOB_INT("N2NMN_GEMM_DMA_MIN_TILES", 192);
   if (!on) return false;
   int tiles = 0;
   for (int i = 0; i < n; ++i) {
@@ -382,19 +382,17 @@ static bool use_gemm_dma(const GemmArgs* a, int n) {
   return tiles >= min_tiles;
 }
 
-// split-operand bf16 form of a launch: every problem carries its weight planes (the caller sets Bp3 only in
-// the opt-in mode) and fits the kernel
-// gemm_dma3_kernel (the dense contractions of the opt-in bf16x3 mode on split operands) is OFF unless
-// N2NMN_GEMM_DMA3=1.  Found at the end of round 5 (tools/diag/three_stream_repro.py, profiles/r05_notes.md
-// section 8): with a second stream running passes concurrently, launches on this kernel returned intermittent
-// wrong tiles -- logit errors of 1e-5 .. 1e-2 in 30 - 40 % of the rounds at two streams, the conv_image launch
-// most of all -- while the same passes with the contractions on the exact-fp32 kernels (and the recurrent step
-// still on lstm_tile3_kernel) were bit-identical to the passes run alone in 100 of 100 rounds, as was every
-// fp32-mode pass at three streams.  Not an LDS-ring hazard (a build that restaged only behind a full barrier
-// failed the same way), not the token gate, not the tile height; cause unknown.  The mode's claim is fp32
-// accuracy, so it runs without this kernel (377 -> ~366 k questions/s) until the cause is found.
+// gemm_dma3_kernel (the dense contractions of the opt-in bf16x3 mode on split operands, rounds 4 - 5) is NOT part of
+// this library.  With a second stream running passes concurrently, passes whose conv_image launch ran on it returned
+// wrong logits (1e-5 .. 1e-2, 30 - 50 % of the rounds).  Round 6 (profiles/r06_notes.md section 1) cleared the kernel's
+// own data path -- every LDS-DMA piece verified in LDS, inputs and the output buffer checksummed right -- and found the
+// fault between the launch and its consumer: a kernel launched directly behind it computes from wrong values, a ~40 us
+// idle gap behind it removes the fault, a release fence or a drained store queue at the end of the kernel does not.
+// Unexplained at that level, so the kernel left the product; it lives in tools/diag/csrc/ and is compiled only into
+// the diagnostic library (tools/diag/build_diag.py, -DN2NMN_DIAG), where N2NMN_GEMM_DMA3=1 routes launches to it.
+#ifdef N2NMN_DIAG
 static bool use_gemm_dma3(const GemmArgs* a, int n) {
-  static const int on = [] { const char* e = getenv("N2NMN_GEMM_DMA3"); return e ? atoi(e) : 0; }();
+  static const int on = N2NMN_KNOB_INT("N2NMN_GEMM_DMA3", 0);
   if (!on) return false;
   int tiles = 0;
   for (int i = 0; i < n; ++i) {
@@ -404,6 +402,12 @@ static bool use_gemm_dma3(const GemmArgs* a, int n) {
   }
   return tiles >= 256;
 }
+#else
+static bool use_gemm_dma3(const GemmArgs*, int) { return false; }
+bool gemm_dma3_supported(const GemmArgs&) { return false; }
+void launch_gemm_dma3(const GemmArgs*, int, hipStream_t) {}
+void launch_pack_pk_b3(const float*, int, int, uint16_t*, hipStream_t) {}
+#endif
 
 void launch_gemm_pkn(const GemmArgs* a, int n, hipStream_t s) {
   if (use_gemm_dma3(a, n)) { launch_gemm_dma3(a, n, s); return; }

@@ -425,7 +425,7 @@ void launch_lstm_tile3(const LstmJob* jobs, int njobs, int N, int L, hipStream_t
   }
   // default: 128-row workgroups (16 waves, 4 stages of 36 KiB) when the launch has at least two
   // 128-row blocks per job; variants (n2nmn_debug_lstm_bench): 4xx = 64-row workgroups
-  static const int dflt = [] { const char* e = getenv("N2NMN_TILE3_VARIANT"); return e ? atoi(e) : 0; }();
+  static const int dflt = N2NMN_KNOB_INT("N2NMN_TILE3_VARIANT", 0);
   // shipped: 128-row x 64-column workgroups of 16 waves (4 x 36 KiB) from 256 rows on, 64-row workgroups
   // below.  Measured and rejected (tools/rejected/lstm_tile3_variants.hip.txt has the kernels and numbers):
   // 128 x 128 workgroups and the register-split form -- both run 8 waves per CU and lose to

@@ -1614,7 +1614,7 @@ void launch_lstm_step(const LstmJob* jobs, int njobs, int N, int L, int rows_per
             jobs[i].K % (LSTM_WAVES * 16) == 0;
   }
   if (wide >= 2 && N >= 128 && lstm_tile_supported(jobs, njobs, L)) {
-    static const int stages = [] { const char* e = getenv("N2NMN_TILE_STAGES"); return e ? atoi(e) : 4; }();
+    static const int stages = N2NMN_KNOB_INT("N2NMN_TILE_STAGES", 4);
     launch_lstm_tile(jobs, njobs, N, L, wide >= 3 ? wide : stages, s);
     return;
   }
@@ -1726,7 +1726,7 @@ static bool launch_dec_question(const DecStepArgs& a, int nsteps, hipStream_t s)
 void launch_dec_attn(const DecStepArgs& a, int nsteps, hipStream_t s) {
   // every step of a question in one workgroup: needs <= 20 steps (4 groups of 5), enough questions to
   // fill the chip with one workgroup each, and the question's rows in LDS
-  static const int qk = [] { const char* e = getenv("N2NMN_DEC_ATTN_Q"); return e ? atoi(e) : 1; }();
+  static const int qk = N2NMN_KNOB_INT("N2NMN_DEC_ATTN_Q", 1);
   if (qk && nsteps > 1 && nsteps <= 20 && a.N >= 128 && !a.uni && !a.forced && a.use_gt) {
     if (a.L == 512 && launch_dec_question<2>(a, nsteps, s)) return;
   }
@@ -1755,7 +1755,7 @@ void launch_dec_attn(const DecStepArgs& a, int nsteps, hipStream_t s) {
   }
   // one step per launch (greedy / sampled decoding): the one-pass form; N2NMN_DEC_ATTN_SEQ=0 keeps the
   // three-pass kernel
-  static const bool seq_on = [] { const char* e = getenv("N2NMN_DEC_ATTN_SEQ"); return !e || atoi(e) != 0; }();
+  static const bool seq_on = N2NMN_KNOB_INT("N2NMN_DEC_ATTN_SEQ", 1) != 0;
   if (seq_on && a.L == 512) {       // (lstm_dim 1024 needs 128 VGPRs in this form: one workgroup per CU)
     const size_t sm = sizeof(float) * ((2 + 16) * (size_t)a.L + ((a.T + 3) & ~3) + 4 * 16 + 16 * MAXV + 16);
     hipLaunchKernelGGL(dec_attn_seq_kernel<2>, dim3(a.N), dim3(1024), sm, s, a);
@@ -1773,7 +1773,7 @@ void launch_enc_rows(const int32_t* seq_len, int T, int N, int32_t* rows, int32_
 void launch_enc_prepare(const int32_t* seq_len, int N, int T, int32_t* perm, int32_t* n_active,
                         float* zero, size_t zero_floats, hipStream_t s, int32_t* zero_int) {
   const size_t z4 = zero_floats / 4;             // the state block is a multiple of 4 floats
-  static const bool sort_on = [] { const char* e = getenv("N2NMN_ENC_PREPARE_SORT"); return !e || atoi(e) != 0; }();
+  static const bool sort_on = N2NMN_KNOB_INT("N2NMN_ENC_PREPARE_SORT", 1) != 0;
   if (sort_on && N <= 1024 && T <= 63) {
     // block 0 ranks, the others clear the state block (16 KB per workgroup and trip)
     const int zb = zero ? (int)std::min<size_t>(255, (z4 + 4095) / 4096) : 0;
@@ -1788,7 +1788,7 @@ void launch_enc_prepare(const int32_t* seq_len, int N, int T, int32_t* perm, int
 }
 
 bool dec_seq_retire_supported(const DecStepArgs& a) {     // the one-step launches go to dec_attn_seq_kernel
-  static const bool seq_on = [] { const char* e = getenv("N2NMN_DEC_ATTN_SEQ"); return !e || atoi(e) != 0; }();
+  static const bool seq_on = N2NMN_KNOB_INT("N2NMN_DEC_ATTN_SEQ", 1) != 0;
   return seq_on && a.L == 512 && a.N <= 1024;
 }
 

@@ -1132,10 +1132,7 @@ void launch_lstm_bwd_step(const LstmBwdJob* jobs, int njobs, int N, int L, hipSt
     dim3 grid(L / 16, njobs, (N + 31) / 32);
     hipLaunchKernelGGL((lstm_bwd_step_kernel<2, 8>), grid, dim3(512), 0, s, js, N, L);
   } else {
-    static const int waves = [] {
-      const char* e = std::getenv("N2NMN_BWD_WAVES");
-      return e && std::atoi(e) == 16 ? 16 : 8;
-    }();
+    static const int waves = N2NMN_KNOB_INT("N2NMN_BWD_WAVES", 8) == 16 ? 16 : 8;
     dim3 grid(L / 16, njobs, (N + 15) / 16);
     if (waves == 16)
       hipLaunchKernelGGL((lstm_bwd_step_kernel<1, 16>), grid, dim3(1024), 0, s, js, N, L);

@@ -78,6 +78,10 @@ class Engine:
         self.mode = mode
         _lib.check(self._lib.n2nmn_ctx_set_mode(self._ctx, {'latency': 0, 'throughput': 1, 'throughput_ksplit': 2, 'throughput_bf16x3': 3}[mode]))
 
+    def debug_set(self, key: str, value=None):
+        """an A/B switch of this context (include/n2nmn.h section 7: n2nmn_debug_set); None removes it"""
+        _lib.check(self._lib.n2nmn_debug_set(self._ctx, key.encode(), None if value is None else str(value).encode()))
+
     def set_tokens_via_levels(self, on: bool):
         """execute_tokens through the device-scheduled level path even where the layout walker applies."""
         self.tokens_via_levels = bool(on)

@@ -246,13 +246,13 @@ def test_training_api_errors(trainer_setup):
         tr.forward_backward(batch, gt_small, reduce=False)
 
 
-SCHEDULES = {
+SCHEDULES = {          # keys of n2nmn_debug_set (include/n2nmn.h section 7), set before n2nmn_train_enable
     # the round-2 schedule: every weight gradient after its recurrence, on the caller's stream
-    'leaves_after_recurrence': {'N2NMN_TRAIN_SCHEDULE': '0'},
+    'leaves_after_recurrence': {'train_schedule': '0'},
     # as many time chunks as the encoder's backward takes, unbounded background launches
-    'four_chunks_unbounded': {'N2NMN_TRAIN_CHUNKS': '60,40,20', 'N2NMN_TRAIN_BG_WGS': '0'},
+    'four_chunks_unbounded': {'train_chunks': '60,40,20', 'train_bg_wgs': '0'},
     # no side stream at all
-    'single_stream': {'N2NMN_TRAIN_OVERLAP': '0'},
+    'single_stream': {'train_overlap': '0'},
 }
 
 
@@ -260,16 +260,18 @@ SCHEDULES = {
 def test_every_backward_schedule_gives_the_same_gradients(monkeypatch, name):
     """The weight-gradient GEMMs are leaves of the backward graph; where they run (side stream under
     the encoder's reverse-time pass, chunk by chunk, or after it) is a schedule, not arithmetic.
-    Each schedule the library can be switched to (read at n2nmn_train_enable) against the oracle,
+    Each schedule the library can be switched to (n2nmn_debug_set, read at n2nmn_train_enable) against the oracle,
     on the configuration-4 batch and on a ragged one (short questions: chunks without rows)."""
     from n2nmn_amd.nmn3_assembler import Assembler
     from n2nmn_amd.engine import Engine
     from n2nmn_amd.train import Trainer
-    for k, v in SCHEDULES[name].items():
-        monkeypatch.setenv(k, v)
     d = Dims(T_decoder=10)
     asm = Assembler(NAMES)
     eng = Engine(d, asm)
+    for k, v in SCHEDULES[name].items():
+        eng.debug_set(k, v)
+    with pytest.raises(KeyError):
+        eng.debug_set('no_such_switch', '1')
     w = synth.make_weights(d, seed=0)
     eng.load_weights(w)
     tr = Trainer(eng, weight_decay=WD)

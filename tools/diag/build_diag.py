@@ -29,6 +29,11 @@ VARIANTS = {
     'verify': ['-DN2NMN_DIAG_VERIFY'],            # LDS contents against a direct global read
     'lb2': ['-DN2NMN_DIAG_WAVES_PER_EU=2'],       # __launch_bounds__(512, 2)
     'twice': ['-DN2NMN_DIAG_VERIFY', '-DN2NMN_DIAG_TWICE'],   # the K loop twice over the same operands; input stability
+    'sums': ['-DN2NMN_DIAG_SUMS'],                # per-launch checksums of A / tokens / C (which launch differs)
+    'endwait': ['-DN2NMN_DIAG_END=1'],            # s_waitcnt vmcnt(0) behind the epilogue stores
+    'endfence': ['-DN2NMN_DIAG_END=2'],           # __threadfence() behind the epilogue stores
+    'endsleep': ['-DN2NMN_DIAG_END=3'],           # control: a delay of the same order, no memory effect
+    'epilds': ['-DN2NMN_DMA3_EPI_LDS'],           # epilogue staged through LDS: whole 128-byte lines per store
     'nop': ['-DN2NMN_DIAG_NOP'],                  # (experiments: see kernels_gemm_dma3.hip)
 }
 
@@ -39,7 +44,7 @@ def lib_of(variant):
 
 def _cc(b, src, obj, extra):
     return [b.hipcc(), '--offload-arch=' + b.ARCH, '-O3', '-std=c++17', '-fPIC', '-x', 'hip', '-DN2NMN_DIAG=1',
-            '-Wall', '-Wno-unused-function'] + extra + ['-c', src, '-o', obj]
+            '-Wall', '-Wno-unused-function', '-I' + b.CSRC] + extra + ['-c', src, '-o', obj]
 
 
 def build(variants=None, verbose=True):
@@ -48,10 +53,8 @@ def build(variants=None, verbose=True):
     objdir = os.path.join(LIBDIR, 'obj')
     os.makedirs(objdir, exist_ok=True)
     procs, common = [], []
-    special = [s for s in b.sources() if s.endswith('kernels_gemm_dma3.hip')][0]
+    special = os.path.join(HERE, 'csrc', 'kernels_gemm_dma3.hip')     # (not a source of the product library)
     for src in b.sources():
-        if src == special:
-            continue
         obj = os.path.join(objdir, os.path.basename(src) + '.o')
         common.append(obj)
         procs.append((src, subprocess.Popen(_cc(b, src, obj, []), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

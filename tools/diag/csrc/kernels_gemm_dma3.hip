@@ -16,6 +16,10 @@
 //     per 32 k.
 // Gather / scatter / device row count / token gate as in gemm_dma_kernel.
 #include <algorithm>
+#ifdef N2NMN_DIAG_SUMS
+#include <mutex>
+#include <vector>
+#endif
 
 #include "device_utils.h"
 #include "kernels.h"
@@ -421,6 +425,54 @@ __device__ __forceinline__ void gemm_dma3_body(const GemmArgs& a, const int bx, 
       diag_record(3u, (uint32_t)tile_id, 0u, (uint32_t)w, 0u, mask, 0u, 0u, 0u, 0u, 0u, (uint32_t)MT << 16);
   }
 #endif
+#ifdef N2NMN_DMA3_EPI_LDS
+  // ---- epilogue through LDS: the 16x16 MFMA C layout (col = lane & 15, row = 4 (lane >> 4) + r) gives 64-byte
+  // row pieces per store instruction; staged as a row-major tile the workgroup writes 16 B per lane, 512 contiguous
+  // bytes per row -- whole 128-byte lines, as the fp32 kernel's 32x32 layout does by itself --------------------
+  {
+    constexpr int LDT = N3 + 4;                                 // row stride of the staged tile (floats)
+    float* const tile = reinterpret_cast<float*>(smem);
+    __syncthreads();                                            // (every wave is done with the last stage)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          tile[((wm * MT + t) * 16 + 4 * kg + r) * LDT + wn * 64 + 16 * ct + li] = acc[t][ct][r];
+    __syncthreads();
+    for (int idx = tid; idx < M3 * (N3 / 4); idx += G3_THREADS) {
+      const int trow = idx / (N3 / 4), c4 = idx - trow * (N3 / 4);
+      const int row = m0 + trow, col = n0 + 4 * c4;
+      if (row >= M || col >= a.n_store) continue;
+      int orow = row;
+      if (a.c_row_idx) {
+        orow = a.c_row_idx[row];
+        if (orow < 0) continue;
+      }
+      const float4 v = *reinterpret_cast<const float4*>(tile + trow * LDT + 4 * c4);
+      float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int cj = col + j;
+        float val = cj < a.N ? o[j] + (a.bias ? a.bias[cj] : 0.f) : 0.f;
+        if (a.relu) val = fmaxf(val, 0.f);
+        o[j] = val;
+      }
+      float* dst = a.C + (size_t)orow * a.ldc + col;
+      if (col + 3 < a.n_store && (a.ldc & 3) == 0) {
+        float4 w4 = make_float4(o[0], o[1], o[2], o[3]);
+        if (a.accumulate) {
+          const float4 old = *reinterpret_cast<const float4*>(dst);
+          w4.x += old.x; w4.y += old.y; w4.z += old.z; w4.w += old.w;
+        }
+        *reinterpret_cast<float4*>(dst) = w4;
+      } else {
+        for (int j = 0; j < 4 && col + j < a.n_store; ++j) dst[j] = a.accumulate ? dst[j] + o[j] : o[j];
+      }
+    }
+  }
+#else
   // ---- epilogue: C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + r -----------------
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) {
@@ -445,6 +497,15 @@ __device__ __forceinline__ void gemm_dma3_body(const GemmArgs& a, const int bx, 
         }
       }
   }
+#endif
+#if defined(N2NMN_DIAG_END) && N2NMN_DIAG_END == 1
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the wave ends only after its stores were acknowledged
+#elif defined(N2NMN_DIAG_END) && N2NMN_DIAG_END == 2
+  __threadfence();                                            // agent-scope release: L2 write-back of this XCD
+#elif defined(N2NMN_DIAG_END) && N2NMN_DIAG_END == 3
+  __builtin_amdgcn_s_sleep(127);                              // (control: the same delay without any memory effect)
+  __builtin_amdgcn_s_sleep(127);
+#endif
 }
 
 #ifndef N2NMN_DIAG_WAVES_PER_EU
@@ -503,6 +564,35 @@ bool gemm_dma3_supported(const GemmArgs& a) {
 #ifdef N2NMN_DIAG
 static int g_diag_lds_pad = 0;       // extra dynamic LDS per workgroup (bytes): changes how workgroups share a CU
 #endif
+#ifdef N2NMN_DIAG_SUMS
+// position-sensitive checksums of what a launch READS (A, gate tokens) and of what it WROTE (C), per problem:
+// which launch of a pass differs from the same pass run alone, and whether its inputs already did
+namespace {
+struct SumRec { const void* C; const void* A; int M, n_store, gated, mt; int slot; };
+static std::mutex g_sum_mu;
+static std::vector<SumRec> g_sum_recs;
+static unsigned long long* g_sum_dev = nullptr;          // [cap][4]: A, tokens, C, -
+static const int SUM_CAP = 1 << 14;
+__global__ void diag_empty_kernel() {}
+__global__ void diag_delay_kernel(int n) { for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127); }
+__global__ __launch_bounds__(256) void diag_sum_kernel(const uint32_t* p, size_t rows, size_t row_words,
+                                                       size_t ld_words, unsigned long long* out) {
+  unsigned long long h = 0;
+  const size_t total = rows * row_words;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / row_words, c = i - r * row_words;
+    h += (unsigned long long)p[r * ld_words + c] * (2ull * i + 1ull);
+  }
+  atomicAdd(out, h);
+}
+static void diag_sum(const void* p, size_t rows, size_t row_words, size_t ld_words, unsigned long long* out,
+                     hipStream_t s) {
+  const size_t total = rows * row_words;
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 1024);
+  hipLaunchKernelGGL(diag_sum_kernel, dim3(blocks), dim3(256), 0, s, (const uint32_t*)p, rows, row_words, ld_words, out);
+}
+}  // namespace
+#endif
 template <int MT>
 static void launch3(const GemmArgs* a, int n, hipStream_t s) {
   constexpr int M3 = G3<MT>::M;
@@ -517,6 +607,30 @@ static void launch3(const GemmArgs* a, int n, hipStream_t s) {
   }
   if (!np) return;
   for (int i = np; i <= 4; ++i) b.start[i] = tiles;
+#ifdef N2NMN_DIAG_SUMS
+  // N2NMN_DIAG_SUMS_MODE (diagnostic build only): 1 checksum of the inputs in front of the launch, 2 checksum of
+  // the output behind it, 4 / 8 an EMPTY kernel in front / behind instead (which neighbour hides the fault?)
+  static const int sums_mode = N2NMN_KNOB_INT("N2NMN_DIAG_SUMS_MODE", 3);
+  if (sums_mode & 4) hipLaunchKernelGGL(diag_empty_kernel, dim3(1), dim3(64), 0, s);
+  if (sums_mode & 128) hipLaunchKernelGGL(diag_delay_kernel, dim3(1), dim3(64), 0, s, 12);     // ~40 us in FRONT of the launch
+  int slots[4] = {-1, -1, -1, -1};
+  if (g_sum_dev) {
+    std::lock_guard<std::mutex> lk(g_sum_mu);
+    for (int i = 0; i < np; ++i) {
+      const GemmArgs& g = b.a[i];
+      if (g.c_row_idx || g.group_idx || g.m_dev || (int)g_sum_recs.size() >= SUM_CAP) continue;
+      slots[i] = (int)g_sum_recs.size();
+      g_sum_recs.push_back(SumRec{g.C, g.A, g.M, g.n_store, g.gate_tokens != nullptr, MT, slots[i]});
+    }
+  }
+  for (int i = 0; i < np; ++i)
+    if (slots[i] >= 0 && (sums_mode & 1)) {
+      const GemmArgs& g = b.a[i];
+      diag_sum(g.A, (size_t)g.M, (size_t)g.K, (size_t)g.lda, g_sum_dev + 4 * (size_t)slots[i], s);
+      if (g.gate_tokens)
+        diag_sum(g.gate_tokens, (size_t)g.gate_T, (size_t)g.gate_N, (size_t)g.gate_N, g_sum_dev + 4 * (size_t)slots[i] + 1, s);
+    }
+#endif
 #ifdef N2NMN_DIAG_LAUNCH
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma3_kernel<MT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G3<MT>::STAGE + g_diag_lds_pad);
@@ -527,11 +641,25 @@ static void launch3(const GemmArgs* a, int n, hipStream_t s) {
   static std::atomic<uint64_t> attr{0};
   ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_dma3_kernel<MT>), 2 * G3<MT>::STAGE, attr);
   hipLaunchKernelGGL(gemm_dma3_kernel<MT>, dim3((tiles + 63) / 64 * 64), dim3(G3_THREADS), 2 * G3<MT>::STAGE, s, b);
+#ifdef N2NMN_DIAG_SUMS
+  if (sums_mode & 8) hipLaunchKernelGGL(diag_empty_kernel, dim3(1), dim3(64), 0, s);
+  if (sums_mode & 16) hipLaunchKernelGGL(diag_delay_kernel, dim3(1), dim3(64), 0, s, 12);      // ~40 us, no memory access
+  if (sums_mode & 64) hipLaunchKernelGGL(diag_delay_kernel, dim3(2048), dim3(256), 0, s, 6);   // ~20 us on every CU
+  if (sums_mode & 32)                                  // reads one row in 16 of every output
+    for (int i = 0; i < np; ++i)
+      if (slots[i] >= 0 && !b.a[i].gate_tokens)
+        diag_sum(b.a[i].C, (size_t)b.a[i].M / 16, (size_t)b.a[i].n_store, (size_t)b.a[i].ldc * 16,
+                 g_sum_dev + 4 * (size_t)slots[i] + 3, s);
+  for (int i = 0; i < np; ++i)
+    if (slots[i] >= 0 && (sums_mode & 2) && !b.a[i].gate_tokens)   // (a gated problem leaves the rows of skipped tiles as they were)
+      diag_sum(b.a[i].C, (size_t)b.a[i].M, (size_t)b.a[i].n_store, (size_t)b.a[i].ldc,
+               g_sum_dev + 4 * (size_t)slots[i] + 2, s);
+#endif
 }
 
 void launch_gemm_dma3(const GemmArgs* a, int n, hipStream_t s) {
   // 128-row tiles when they still cover the chip a few times over (N2NMN_GEMM_DMA3_MT overrides)
-  static const int mt_env = [] { const char* e = getenv("N2NMN_GEMM_DMA3_MT"); return e ? atoi(e) : 0; }();
+  static const int mt_env = N2NMN_KNOB_INT("N2NMN_GEMM_DMA3_MT", 0);
   int tiles128 = 0;
   for (int i = 0; i < n; ++i)
     if (a[i].M > 0) tiles128 += ((a[i].n_store + N3 - 1) / N3) * ((a[i].M + 127) / 128);
@@ -630,6 +758,37 @@ int n2nmn_diag_gemm(const float* A, const float* Bp, const void* Bp3, const floa
   else { if (!gemm_dma3_supported(g)) return -1; if (mt == 2) launch3<2>(&g, 1, (hipStream_t)stream); else launch3<1>(&g, 1, (hipStream_t)stream); }
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+#ifdef N2NMN_DIAG_SUMS
+// start / read the per-launch checksum records: out[i] = {C pointer, A pointer, M | n_store << 32, gated | mt << 8,
+// sum(A), sum(tokens), sum(C), 0}; returns the number of records
+int n2nmn_diag_sums_reset() {
+  using namespace n2nmn;
+  std::lock_guard<std::mutex> lk(g_sum_mu);
+  if (!g_sum_dev && hipMalloc(reinterpret_cast<void**>(&g_sum_dev), sizeof(unsigned long long) * 4 * SUM_CAP) != hipSuccess)
+    return -1;
+  (void)hipDeviceSynchronize();
+  (void)hipMemset(g_sum_dev, 0, sizeof(unsigned long long) * 4 * SUM_CAP);
+  (void)hipDeviceSynchronize();
+  g_sum_recs.clear();
+  return 0;
+}
+int n2nmn_diag_sums_get(unsigned long long* out, int cap) {
+  using namespace n2nmn;
+  std::lock_guard<std::mutex> lk(g_sum_mu);
+  (void)hipDeviceSynchronize();
+  const int n = std::min<int>((int)g_sum_recs.size(), cap);
+  std::vector<unsigned long long> dev(4 * (size_t)std::max(n, 1));
+  if (n) (void)hipMemcpy(dev.data(), g_sum_dev, sizeof(unsigned long long) * 4 * n, hipMemcpyDeviceToHost);
+  for (int i = 0; i < n; ++i) {
+    const SumRec& r = g_sum_recs[i];
+    out[8 * i + 0] = (unsigned long long)(uintptr_t)r.C; out[8 * i + 1] = (unsigned long long)(uintptr_t)r.A;
+    out[8 * i + 2] = (unsigned long long)(unsigned)r.M | ((unsigned long long)(unsigned)r.n_store << 32);
+    out[8 * i + 3] = (unsigned long long)r.gated | ((unsigned long long)r.mt << 8);
+    out[8 * i + 4] = dev[4 * i]; out[8 * i + 5] = dev[4 * i + 1]; out[8 * i + 6] = dev[4 * i + 2]; out[8 * i + 7] = 0;
+  }
+  return n;
+}
+#endif
 int n2nmn_diag_aggressor(int mode, int iters, int lds_bytes, int grid, const float* buf, size_t nfloat, float* sink,
                          void* stream) {
   using namespace n2nmn;

@@ -267,6 +267,150 @@ def part_b(L, diag, rounds, levels):
     p.close()
 
 
+# ------------------------------------------------------------------------------------------------ part C
+def part_c(L, rounds):
+    """pipeline as in part B on the `sums` library: every plain gemm_dma3 launch (the conv_image launches) leaves a
+    checksum of what it read (A, gate tokens) and of what it wrote (C).  The records of a concurrent round are
+    compared with the same worker's records of its pass run alone, keyed by the C buffer."""
+    os.environ['N2NMN_GEMM_DMA3'] = '1'
+    from n2nmn_amd import synth
+    from n2nmn_amd.nmn3_assembler import Assembler
+    from n2nmn_amd.pipeline import PassPipeline
+    from n2nmn_amd.spec import Dims, CLEVR_MODULE_NAMES
+    L.n2nmn_diag_sums_reset.restype = C.c_int
+    L.n2nmn_diag_sums_get.restype = C.c_int
+    L.n2nmn_diag_sums_get.argtypes = [P, C.c_int]
+    S = 2
+    d = Dims()
+    p = PassPipeline(d, Assembler(list(CLEVR_MODULE_NAMES)), synth.make_weights(d, seed=0), streams=S, kcap=16,
+                     mode='throughput_bf16x3')
+    p.fill_all(lambda i: synth.make_inputs(d, seed=500 + i, min_len=1), lambda i: synth.template_layout_batch(d, offset=i))
+    torch.cuda.synchronize()
+    p.run([[8, 10], [16, 8]], gt=True)
+
+    def sums():
+        buf = np.zeros((1 << 14, 8), np.uint64)
+        n = L.n2nmn_diag_sums_get(buf.ctypes.data, buf.shape[0])
+        out = {}
+        for r in buf[:n]:
+            out.setdefault(int(r[0]), []).append(tuple(int(x) for x in r[1:7]))
+        return out
+
+    def alone(si, n):
+        for wk in p.workers:
+            wk['next'] = 0
+        assert L.n2nmn_diag_sums_reset() == 0
+        p.run([[n] if k == si else [] for k in range(S)], gt=True)
+        return p.bucket(si, 0).scores.cpu().numpy().copy(), sums()
+
+    ref = [alone(si, 10) for si in range(S)]
+    again = [alone(si, 10) for si in range(S)]
+    print('\n=== part C: alone vs alone: logits', [float(np.abs(a[0] - b[0]).max()) for a, b in zip(ref, again)],
+          'checksum records equal:', [a[1] == b[1] for a, b in zip(ref, again)],
+          'records per pass:', [sum(len(v) for v in a[1].values()) for a in ref], flush=True)
+    want = {}
+    for si in range(S):
+        want.update(ref[si][1])
+    bad_rounds, shown = 0, 0
+    stats = dict(out_only=0, inputs_differ=0, rounds_with_logit_diff_but_equal_sums=0)
+    for it in range(rounds):
+        for wk in p.workers:
+            wk['next'] = 0
+        assert L.n2nmn_diag_sums_reset() == 0
+        p.run([[10]] * S, gt=True)
+        diffs = [float(np.abs(p.bucket(si, 0).scores.cpu().numpy() - ref[si][0]).max()) for si in range(S)]
+        got = sums()
+        differing = []
+        for cptr, recs in got.items():
+            w = want.get(cptr)
+            if w is None or len(w) != len(recs):
+                differing.append((cptr, 'record count', len(recs), None if w is None else len(w)))
+                continue
+            for k, (a, b) in enumerate(zip(recs, w)):
+                if a != b:
+                    differing.append((cptr, k, a, b))
+        if max(diffs) > 0:
+            bad_rounds += 1
+            if not differing:
+                stats['rounds_with_logit_diff_but_equal_sums'] += 1
+        for cptr, k, a, b in differing:
+            if isinstance(k, str):
+                continue
+            same_in = a[3] == b[3] and a[4] == b[4]
+            stats['out_only' if same_in else 'inputs_differ'] += 1
+            if shown < 12:
+                shown += 1
+                print('  round %d (logit diffs %s): C %x launch %d M %d mt %d gated %d: A sum %s, token sum %s, C sum %s'
+                      % (it, ['%.1e' % x for x in diffs], cptr, k, a[1] & 0xffffffff, a[2] >> 8, a[2] & 1,
+                         'same' if a[3] == b[3] else 'DIFFERS', 'same' if a[4] == b[4] else 'DIFFERS',
+                         'same' if a[5] == b[5] else 'DIFFERS'), flush=True)
+    print('part C: %d of %d concurrent rounds differ in the logits; launches whose OUTPUT checksum differs with equal '
+          'input checksums: %d, with differing input checksums: %d; rounds with wrong logits but equal checksums of '
+          'every recorded launch: %d' % (bad_rounds, rounds, stats['out_only'], stats['inputs_differ'],
+                                         stats['rounds_with_logit_diff_but_equal_sums']), flush=True)
+    p.close()
+
+
+# ------------------------------------------------------------------------------------------------ part D
+def part_d(L, rounds):
+    """which half of a pass diverges: the engine-owned outputs of phase 1 (decoder attention, token probabilities, word
+    vectors, ...: Engine._bufs) and the logits of a concurrent round against the same pass run alone"""
+    os.environ['N2NMN_GEMM_DMA3'] = '1'
+    from collections import Counter
+    from n2nmn_amd import synth
+    from n2nmn_amd.nmn3_assembler import Assembler
+    from n2nmn_amd.pipeline import PassPipeline
+    from n2nmn_amd.spec import Dims, CLEVR_MODULE_NAMES
+    S = 2
+    d = Dims()
+    p = PassPipeline(d, Assembler(list(CLEVR_MODULE_NAMES)), synth.make_weights(d, seed=0), streams=S, kcap=16,
+                     mode='throughput_bf16x3')
+    p.fill_all(lambda i: synth.make_inputs(d, seed=500 + i, min_len=1), lambda i: synth.template_layout_batch(d, offset=i))
+    torch.cuda.synchronize()
+    p.run([[8, 10], [16, 8]], gt=True)
+
+    def snap(si):
+        torch.cuda.synchronize()
+        e = p.workers[si]['engine']
+        out = {'scores': p.bucket(si, 0).scores.cpu().numpy().copy()}
+        for (key, shape, dt), t in e._bufs.items():
+            if shape and shape[-1] != 0:
+                out['%s%s' % (key, list(shape))] = t.cpu().numpy().copy()
+        return out
+
+    def alone(si, n):
+        for wk in p.workers:
+            wk['next'] = 0
+        p.run([[n] if k == si else [] for k in range(S)], gt=True)
+        return snap(si)
+
+    ref = [alone(si, 10) for si in range(S)]
+    again = [alone(si, 10) for si in range(S)]
+    print('\n=== part D: engine buffers:', sorted(ref[0]), flush=True)
+    for si in range(S):
+        unstable = [k for k in ref[si] if not np.array_equal(ref[si][k], again[si][k], equal_nan=True)]
+        print('  worker %d: buffers that differ between two runs alone (not outputs of the pass): %s' % (si, unstable))
+        for k in unstable:
+            ref[si].pop(k)
+    first = Counter()
+    bad = 0
+    for it in range(rounds):
+        for wk in p.workers:
+            wk['next'] = 0
+        p.run([[10]] * S, gt=True)
+        for si in range(S):
+            cur = snap(si)
+            diff = {k: float(np.nanmax(np.abs(cur[k].astype(np.float64) - ref[si][k].astype(np.float64))))
+                    for k in ref[si] if not np.array_equal(cur[k], ref[si][k], equal_nan=True)}
+            if diff:
+                bad += 1
+                first[tuple(sorted(diff))] += 1
+                if bad <= 12:
+                    print('  round %d worker %d differs in: %s' % (it, si, {k: '%.1e' % v for k, v in diff.items()}), flush=True)
+    print('part D: %d worker-rounds of %d differ; sets of differing buffers: %s' % (bad, rounds * S, dict(first)), flush=True)
+    p.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--rounds', type=int, default=60)
@@ -278,6 +422,10 @@ def main():
     L = diag_lib(a.lib)
     print('library:', a.lib, flush=True)
     diag = Diag(L)
+    if 'D' in a.part:
+        part_d(L, a.rounds)
+    if 'C' in a.part:
+        part_c(L, a.rounds)
     if 'B' in a.part:
         part_b(L, diag, a.rounds, [int(x) for x in a.levels.split(',')])
     if 'A' in a.part:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """gemm_dma3_kernel (split-operand bf16, opt-in mode) against gemm_dma_kernel (exact fp32) on the dense
-contractions of a pass, through n2nmn_debug_gemm (N2NMN_DEBUG_GEMM_B3 = launches in the bf16x3 form,
-negative = launches in the fp32 form): max error against torch fp64, us per launch, TFLOP/s."""
+contractions of a pass, through n2nmn_debug_gemm (n2nmn_debug_set "debug_gemm_b3" = launches in the bf16x3
+form, negative = launches in the fp32 form): max error against torch fp64, us per launch, TFLOP/s."""
 import ctypes as C
 import os
 import sys
@@ -34,7 +34,7 @@ for name, M, N, K in SHAPES:
         Cbuf = torch.zeros((M, N), device=dev)
 
         def call(n):
-            os.environ['N2NMN_DEBUG_GEMM_B3'] = str(n if mode == 'bf16x3' else -n)
+            eng.debug_set('debug_gemm_b3', n if mode == 'bf16x3' else -n)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             _lib.check(L.n2nmn_debug_gemm(eng._ctx, A.data_ptr(), B.data_ptr(), bias.data_ptr(),
@@ -51,4 +51,4 @@ for name, M, N, K in SHAPES:
         print('%-34s %-7s M=%6d N=%4d K=%4d  %8.1f us  %6.1f TFLOP/s  max |err| vs fp64 %.2e' %
               (name, mode, M, N, K, us, 2.0 * M * N * K / us / 1e6, err))
     print('    bf16x3 / fp32 time: %.2f' % (out['bf16x3'][0] / out['fp32'][0]))
-os.environ.pop('N2NMN_DEBUG_GEMM_B3', None)
+eng.debug_set('debug_gemm_b3', None)

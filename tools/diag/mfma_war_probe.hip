@@ -52,13 +52,14 @@ __global__ __launch_bounds__(64) void probe(int iters, int every, unsigned* bad,
   __syncthreads();
   const uint32_t lds = (uint32_t)(uintptr_t)frag + lane * 16;
   const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};   // eight bf16 1.0
-  unsigned nbad = 0;
+  unsigned nbad = 0, nread = 0, h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int i = 0; i < iters; ++i) {
     u32x4 A = ones, B = ones;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     // (one asm block: the order below is the order on the chip)
     if (MODE == 0) {
       asm volatile(
+          "s_nop 15\n\t"         // (the operand set-up in front is VALU: hipcc cannot see the MFMA in here)
           ".rept %4\n\t"
           "v_mfma_f32_16x16x32_bf16 %0, %2, %1, %0\n\t"
           ".endr\n\t"
@@ -71,6 +72,7 @@ __global__ __launch_bounds__(64) void probe(int iters, int every, unsigned* bad,
     } else {
       // control: the read is issued only after the chain's result has been consumed
       asm volatile(
+          "s_nop 15\n\t"         // (the operand set-up in front is VALU: hipcc cannot see the MFMA in here)
           ".rept %4\n\t"
           "v_mfma_f32_16x16x32_bf16 %0, %2, %1, %0\n\t"
           ".endr\n\t"
@@ -84,14 +86,82 @@ __global__ __launch_bounds__(64) void probe(int iters, int every, unsigned* bad,
     const float want = 32.0f * CHAIN;
     bool wrong = false;
     for (int r = 0; r < 4; ++r) wrong |= acc[r] != want;
-    if (B[0] != 0x40004000u) wrong = true;                 // (the read itself must have happened)
+    nread += B[0] == 0x40004000u;                          // (the read itself happened)
     if (wrong) {
       ++nbad;
       const int k = (int)((acc[0] - want) / 32.0f);        // how many MFMAs saw the new fragment
-      atomicAdd(&hist[k < 0 ? 15 : (k > 14 ? 14 : k)], 1u);
+      ++h[k < 0 ? 7 : (k > 6 ? 6 : k)];
     }
   }
-  if (nbad) atomicAdd(bad, nbad);
+  // (one set of atomics per wave, at the end: lane 0's view)
+  if (lane == 0) atomicAdd(&hist[8], nread);
+  if (lane == 0 && nbad) {
+    atomicAdd(bad, nbad);
+    for (int k = 0; k < 8; ++k)
+      if (h[k]) atomicAdd(&hist[k], h[k]);
+  }
+}
+
+
+// ---- second question: how many wait states does the chip need between a VALU write of an MFMA source register and
+// the MFMA?  (hipcc pads what it knows of; kernels_gemm_dma3.hip produces its A fragments with v_cvt_pk_bf16_f32
+// right in front of the MFMAs.)  One asm block on fixed registers: A dword 0 holds two bf16 2.0, is rewritten to
+// two 1.0 by v_cvt_pk_bf16_f32, N x s_nop 0 (and, VIA = 1, one independent MFMA) later the MFMA reads it: 32 if it
+// saw the new value, 34 if the old one.
+template <int N, int VIA, int W = 0>
+__global__ __launch_bounds__(64) void hazard(int iters, int every, unsigned* bad, float* sink) {
+  if (every > 0 && (blockIdx.x % (every + 1)) != 0) {
+    f32x16 a0 = {0}, a1 = {0};
+    const float x = 1.0f + threadIdx.x, y = 0.5f;
+    for (int i = 0; i < iters * 2; ++i) {
+      a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a1, 0, 0, 0);
+    }
+    if (a0[0] + a1[1] == 12345.f) sink[0] = a0[0];
+    return;
+  }
+  unsigned nbad = 0;
+  const uint32_t ones = 0x3f803f80u;
+  const float f1 = 1.0f;
+  for (int i = 0; i < iters; ++i) {
+    float r;
+    asm volatile(
+        "v_mov_b32 v100, 0x40004000\n\tv_mov_b32 v101, %1\n\tv_mov_b32 v102, %1\n\tv_mov_b32 v103, %1\n\t"
+        "v_mov_b32 v104, %1\n\tv_mov_b32 v105, %1\n\tv_mov_b32 v106, %1\n\tv_mov_b32 v107, %1\n\t"
+        "v_mov_b32 v108, 0\n\tv_mov_b32 v109, 0\n\tv_mov_b32 v110, 0\n\tv_mov_b32 v111, 0\n\t"
+        "v_mov_b32 v112, 0\n\tv_mov_b32 v113, 0\n\tv_mov_b32 v114, 0\n\tv_mov_b32 v115, 0\n\t"
+        "s_nop 15\n\ts_nop 15\n\t"
+        "v_cvt_pk_bf16_f32 v100, %2, %2\n\t"
+        ".rept %5\n\ts_waitcnt lgkmcnt(0)\n\t.endr\n\t"     // (nothing outstanding: the wait is satisfied at once)
+        ".rept %3\n\ts_nop 0\n\t.endr\n\t"
+        ".rept %4\n\tv_mfma_f32_16x16x32_bf16 v[112:115], v[104:107], v[104:107], v[112:115]\n\t.endr\n\t"
+        "v_mfma_f32_16x16x32_bf16 v[108:111], v[100:103], v[104:107], v[108:111]\n\t"
+        "s_nop 15\n\ts_nop 15\n\ts_nop 15\n\t"
+        "v_mov_b32 %0, v108"
+        : "=v"(r)
+        : "v"(ones), "v"(f1), "n"(N), "n"(VIA), "n"(W)
+        : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112",
+          "v113", "v114", "v115", "memory");
+    nbad += r != 32.0f;
+  }
+  if (threadIdx.x == 0 && nbad) atomicAdd(bad, nbad);
+}
+
+template <int N, int VIA, int W = 0>
+static void run_hazard(int iters, int every, int grid) {
+  unsigned* bad;
+  float* sink;
+  CHECK(hipMalloc(&bad, 4));
+  CHECK(hipMalloc(&sink, 16));
+  CHECK(hipMemset(bad, 0, 4));
+  hipLaunchKernelGGL((hazard<N, VIA, W>), dim3(grid), dim3(64), 0, 0, iters, every, bad, sink);
+  CHECK(hipDeviceSynchronize());
+  unsigned hb = 0;
+  CHECK(hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost));
+  const long victims = every > 0 ? (grid + every) / (every + 1) : grid;
+  printf("v_cvt_pk_bf16_f32 -> %d x satisfied s_waitcnt + %d x s_nop 0%s -> MFMA reading it, %d aggressor workgroup(s) per victim: %u of %ld used the OLD value\n",
+         W, N, VIA ? " + one independent MFMA" : "", every, hb, victims * iters);
+  CHECK(hipFree(bad)); CHECK(hipFree(sink));
 }
 
 template <int CHAIN>
@@ -114,7 +184,8 @@ static void run(int iters, int every, int grid) {
     printf("chain %d, %d aggressor workgroup(s) per victim, %s: %u wrong of %ld chains; extra products per wrong chain:",
            CHAIN, every, mode == 0 ? "read issued right behind the chain" : "control (read behind the result)", hb,
            victims * iters);
-    for (int k = 0; k < 16; ++k)
+    printf(" (reads seen %u)", hh[8]);
+    for (int k = 0; k < 8; ++k)
       if (hh[k]) printf(" [%d]=%u", k, hh[k]);
     printf("\n");
   }
@@ -122,6 +193,7 @@ static void run(int iters, int every, int grid) {
 }
 
 int main(int argc, char** argv) {
+  setvbuf(stdout, nullptr, _IONBF, 0);
   const int iters = argc > 1 ? atoi(argv[1]) : 20000;
   const int grid = argc > 2 ? atoi(argv[2]) : 256 * 16;
   for (int every : {0, 1, 3, 7}) {
@@ -129,6 +201,20 @@ int main(int argc, char** argv) {
     run<2>(iters, every, grid);
     run<6>(iters, every, grid);
     run<12>(iters, every, grid);
+  }
+  for (int every : {0, 3}) {
+    run_hazard<0, 0>(iters, every, grid);
+    run_hazard<1, 0>(iters, every, grid);
+    run_hazard<2, 0>(iters, every, grid);
+    run_hazard<3, 0>(iters, every, grid);
+    run_hazard<4, 0>(iters, every, grid);
+    run_hazard<0, 1>(iters, every, grid);
+    run_hazard<1, 1>(iters, every, grid);
+    run_hazard<0, 0, 1>(iters, every, grid);
+    run_hazard<1, 0, 1>(iters, every, grid);
+    run_hazard<0, 0, 2>(iters, every, grid);
+    run_hazard<0, 0, 3>(iters, every, grid);
+    run_hazard<2, 0, 1>(iters, every, grid);
   }
   return 0;
 }

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Decoder attention / word vectors of one 192-row pass with and without the row-listed
-encoder_h_transform GEMM (N2NMN_EHT_ROWS): run twice, second run compares with the first's dump."""
+encoder_h_transform GEMM (n2nmn_debug_set "eht_rows"; `--full` = the GEMM over all T N rows): run twice, the second
+run compares with the first's dump."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,13 +16,15 @@ d = Dims(N=192)
 eng = Engine(d, Assembler(list(CLEVR_MODULE_NAMES)))
 eng.load_weights(synth.make_weights(d, seed=0))
 eng.set_mode('throughput')
+if '--full' in sys.argv:
+    eng.debug_set('eht_rows', '0')
 b = synth.make_inputs(d, seed=70)
 g = np.concatenate([synth.template_layout_batch(Dims(), offset=1)] * 3, axis=1)
 out = eng.seq2seq(b['input_seq_batch'], b['seq_length_batch'], use_gt_layout=True, gt_layout=g)
 torch.cuda.synchronize()
 cur = {k: out[k].cpu().numpy() for k in ('atts', 'word_vecs', 'token_probs')}
 path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'eht_diag.npz')
-if os.path.exists(path) and len(sys.argv) > 1:
+if os.path.exists(path) and '--compare' in sys.argv:
     ref = np.load(path)
     lens = b['seq_length_batch']
     for k in cur:
