@@ -133,6 +133,13 @@ int n2nmn_commit_weights(n2nmn_ctx *ctx, n2nmn_stream stream);
 int n2nmn_set_validity_tables(n2nmn_ctx *ctx, const int32_t *P_host, const int32_t *W_host,
                               const int32_t *b_host);
 /* Number of expected variables and the i-th expected name/shape (introspection for loaders). */
+/* Host only (no device, no context): 1 if the automaton P [V,3], W [3,V,4], b [V,4] (models_clevr/nmn3_assembler.py:
+ * 50-135; token s valid in state x iff all_c (x . W[:, s, c] - b[s, c] >= 0), x += P[token]) allows nothing but <eos>
+ * behind <eos> and behind every answer operator (token_op [V]: n2nmn_op codes, < 0 = <eos>), in every state reachable
+ * from (0, 0, T), T = 1 .. T_decoder; 0 otherwise.  n2nmn_set_validity_tables / n2nmn_set_token_ops evaluate this for
+ * the installed tables: N2NMN_S2S_EOS_RETIRE retires decoder-chosen layouts only if it is 1. */
+int n2nmn_automaton_forces_eos(const int32_t *P_host, const int32_t *W_host, const int32_t *b_host,
+                               const int32_t *token_op_host, int V, int T_decoder);
 int n2nmn_num_variables(const n2nmn_ctx *ctx);
 int n2nmn_variable_info(const n2nmn_ctx *ctx, int i, const char **name, int64_t shape[4],
                         int *ndim);
@@ -207,12 +214,14 @@ typedef struct {
  * same context recomputes them from the encoder results it holds.  Where the preconditions do not hold
  * the flag is ignored.
  * Layouts the decoder chooses itself (greedy / sampled decoding; >= 128 and <= 1024 rows, a throughput
- * mode, lstm_dim 512): the lengths are only known step by step -- a row is finished once it has
- * emitted <eos>, after which the validity automaton allows nothing but <eos> (nmn3_netgen_att.py:8-15,
- * nmn3_assembler.py:94-117).  After every step the state rows are re-partitioned on the device (live rows
- * to the front, dec_compact_kernel) and the next step's launches run over that prefix; finished rows get
- * their <eos> tokens without a recurrent step.  Same contract: predicted_tokens complete and identical to the
- * full decoder's, atts / token_probs for live (row, step) pairs only. */
+ * mode): a row is finished once it has emitted <eos> OR an answer operator (Exist .. Describe) -- behind either
+ * the reference's automaton allows nothing but <eos> (models_clevr/nmn3_assembler.py:94-117) -- and the
+ * finished rows are compacted out of the state after every step; they get their <eos> tokens (probability 1)
+ * without a recurrent step.  This is exact only for an automaton with that property, so it is PROVEN when the
+ * tables are installed: n2nmn_set_validity_tables / n2nmn_set_token_ops search every state reachable from
+ * (0, 0, T), T = 1 .. T_decoder, and the flag is ignored on this path unless no finished row can ever emit
+ * another token (all-zero tables -- every token always valid, models_shapes -- do not qualify).  Same contract:
+ * predicted_tokens complete and identical to the full decoder's, atts / token_probs for live (row, step) pairs only. */
 #define N2NMN_S2S_EOS_RETIRE 2
 
 int n2nmn_encoder_forward(n2nmn_ctx *ctx, const n2nmn_seq2seq_io *io, n2nmn_stream stream);

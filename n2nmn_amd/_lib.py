@@ -147,6 +147,7 @@ SYMBOLS = [
     ('n2nmn_fc_forward', _I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     ('n2nmn_crc32c', C.c_uint32, [C.c_uint32, C.c_char_p, C.c_size_t]),
     ('n2nmn_debug_set', _I, [_P, C.c_char_p, C.c_char_p]),
+    ('n2nmn_automaton_forces_eos', _I, [_P, _P, _P, _P, _I, _I]),
 ]
 
 

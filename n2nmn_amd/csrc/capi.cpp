@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <array>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -832,7 +833,8 @@ int decoder_impl(n2nmn_ctx* c, const n2nmn_seq2seq_io* io, hipStream_t s, const 
     const bool retire_seq = (io->flags & N2NMN_S2S_EOS_RETIRE) && !c->rec && !io->drop_dec0 &&
                             !io->token_scores && !io->forced_tokens && !io->use_gt_layout &&
                             lstm_wide(c) >= 2 && N >= 128 &&
-                            root(c)->have_token_ops && root(c)->eos_token >= 0 && dec_seq_retire_supported(a);
+                            root(c)->have_token_ops && root(c)->eos_token >= 0 && root(c)->retire_ok &&
+                            dec_seq_retire_supported(a);
     c->dec_retired = retire_seq;
     // state buffers of the loop: h ping-pongs as always; c is updated in place in cb0 / cb1; a compaction
     // moves all four into their alternates (block B's dropout buffers are free without dropout)
@@ -1464,6 +1466,71 @@ int n2nmn_set_weight(n2nmn_ctx* ctx, const char* name, const float* data, const 
 
 /* validity automaton of the layout vocabulary: Assembler.P [V,3], .W [3,V,4], .b [V,4]
  * (models_clevr/nmn3_assembler.py:50-119 -> nmn3_netgen_att.py:59-62), host int32 pointers */
+// Does the installed automaton (nmn3_netgen_att.py:8-15: token s is valid in state x iff all_c (x . W[:, s, c] - b[s, c]
+// >= 0); x += P[token]) force <eos> for ever behind <eos> and behind every answer operator?  Breadth-first over
+// every state reachable from (0, 0, T) for T = 1 .. T_decoder (47 k states for the reference's automaton,
+// nmn3_assembler.py:50-135; all-zero tables -- models_shapes -- fail at the first state).  The retirement of
+// finished rows by dec_compact_kernel is exact only if it holds.
+static bool automaton_forces_eos(const int32_t* P, const int32_t* W, const int32_t* b, const int32_t* token_op, int V,
+                                 int T_decoder) {
+  int eos = -1;
+  for (int i = 0; i < V; ++i) if (token_op[i] < 0) { eos = i; break; }
+  if (eos < 0 || V <= 0 || T_decoder <= 0) return false;
+  auto valid = [&](const int x[3], int s) {
+    for (int c = 0; c < 4; ++c) {
+      long v = -(long)b[s * 4 + c];
+      for (int k = 0; k < 3; ++k) v += (long)x[k] * W[(k * V + s) * 4 + c];
+      if (v < 0) return false;
+    }
+    return true;
+  };
+  auto finishing = [&](int s) {
+    const int op = token_op[s];
+    return op < 0 || (op >= N2NMN_OP_EXIST && op <= N2NMN_OP_DESCRIBE);
+  };
+  const int lim = 4 * T_decoder + 8;                   // states outside [-lim, lim]^3 are not reachable in T steps
+  auto key = [&](const int x[3]) {
+    return ((long)(x[0] + lim) * (2 * lim + 1) + (x[1] + lim)) * (2 * lim + 1) + (x[2] + lim);
+  };
+  // (state, steps left, reached behind a finishing token): a pass decodes T_decoder tokens, so T steps from (0, 0, T)
+  std::unordered_map<long, bool> seen;
+  std::vector<std::array<int, 5>> todo;                // x0, x1, x2, steps left, finished
+  for (int T = 1; T <= T_decoder; ++T) todo.push_back({0, 0, T, T, 0});
+  size_t steps = 0;
+  while (!todo.empty()) {
+    const auto cur = todo.back();
+    todo.pop_back();
+    if (cur[3] == 0) continue;
+    const int x[3] = {cur[0], cur[1], cur[2]};
+    for (int k = 0; k < 3; ++k) if (x[k] < -lim || x[k] > lim) return false;
+    const long kx = (key(x) * (T_decoder + 1) + cur[3]) * 2 + cur[4];
+    if (seen.count(kx)) continue;
+    seen[kx] = true;
+    if (++steps > 4000000) return false;               // (not an automaton of this family: do not retire)
+    for (int s = 0; s < V; ++s) {
+      if (!valid(x, s)) continue;
+      if (cur[4] && s != eos) return false;            // a finished row could emit something else
+      todo.push_back({x[0] + P[s * 3 + 0], x[1] + P[s * 3 + 1], x[2] + P[s * 3 + 2], cur[3] - 1,
+                      (cur[4] || finishing(s)) ? 1 : 0});
+    }
+  }
+  return true;
+}
+
+static void refresh_retire_ok(n2nmn_ctx* r) {
+  const int V = r->d.num_vocab_nmn;
+  r->retire_ok = r->have_tables && r->have_token_ops && (int)r->P_host.size() == V * 3 &&
+                 (int)r->token_op_host.size() == V &&
+                 automaton_forces_eos(r->P_host.data(), r->W_host.data(), r->b_host.data(), r->token_op_host.data(), V,
+                                      r->d.T_decoder);
+}
+
+int n2nmn_automaton_forces_eos(const int32_t* P_host, const int32_t* W_host, const int32_t* b_host,
+                               const int32_t* token_op_host, int V, int T_decoder) {
+  N2_REQUIRE(P_host && W_host && b_host && token_op_host, N2NMN_EINVAL, "automaton_forces_eos: null argument");
+  return automaton_forces_eos(P_host, W_host, b_host, token_op_host, V, T_decoder) ? 1 : 0;
+}
+
 int n2nmn_set_validity_tables(n2nmn_ctx* ctx, const int32_t* P_host, const int32_t* W_host,
                               const int32_t* b_host) {
   N2_REQUIRE(ctx && P_host && W_host && b_host, N2NMN_EINVAL, "set_validity_tables: null argument");
@@ -1473,6 +1540,10 @@ int n2nmn_set_validity_tables(n2nmn_ctx* ctx, const int32_t* P_host, const int32
   N2_HIP(hipMemcpy(ctx->Wv, W_host, sizeof(int32_t) * 3 * V * 4, hipMemcpyHostToDevice));
   N2_HIP(hipMemcpy(ctx->bv, b_host, sizeof(int32_t) * V * 4, hipMemcpyHostToDevice));
   ctx->have_tables = true;
+  ctx->P_host.assign(P_host, P_host + V * 3);
+  ctx->W_host.assign(W_host, W_host + 3 * V * 4);
+  ctx->b_host.assign(b_host, b_host + V * 4);
+  refresh_retire_ok(ctx);
   return N2NMN_OK;
 }
 
@@ -1694,6 +1765,8 @@ int n2nmn_set_token_ops(n2nmn_ctx* ctx, const int32_t* token_op_host, int V) {
   ctx->have_token_ops = true;
   ctx->eos_token = -1;
   for (int i = 0; i < V; ++i) if (token_op_host[i] < 0) { ctx->eos_token = i; break; }
+  ctx->token_op_host.assign(token_op_host, token_op_host + V);
+  refresh_retire_ok(ctx);
   return N2NMN_OK;
 }
 

@@ -199,6 +199,11 @@ struct n2nmn_ctx {
   int32_t* token_op = nullptr;             // [V] op code per layout token (-1: <eos>), device
   bool have_token_ops = false;
   int eos_token = -1;                      // the token whose op code is < 0 (<eos>), host copy
+  // host copies of the automaton and the token -> op table, and what they prove (refresh_retire_ok, capi.cpp):
+  // from every state the automaton can reach, a row that has emitted <eos> or an answer operator may only emit
+  // <eos> from then on.  Only then may the sequential decoder retire such rows (N2NMN_S2S_EOS_RETIRE).
+  std::vector<int32_t> P_host, W_host, b_host, token_op_host;
+  bool retire_ok = false;
 
   // seq2seq workspace
   float *eh0[2] = {nullptr, nullptr}, *eh1[2] = {nullptr, nullptr}, *ec0 = nullptr, *ec1 = nullptr;

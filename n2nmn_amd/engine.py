@@ -39,11 +39,11 @@ class Engine:
         self._ring_i = 0
         self._side = None             # side stream + event for the hoisted conv_image GEMMs
         self._side_ev = None
-        # N2NMN_OVERLAP_CONV=1: hoisted conv_image GEMMs on a side stream beside phase 1.  Off by
-        # default: measured on MI355X the chip-filling recurrent steps slow down by more than the
-        # GEMMs take (0.882 ms per batch overlapped vs 0.812 ms in line, profiles/r02_notes.md)
-        self.overlap_conv = os.environ.get('N2NMN_OVERLAP_CONV', '0') == '1'
-        self.tokens_via_levels = os.environ.get('N2NMN_TOKENS_VIA_LEVELS', '0') not in ('', '0')
+        # overlap_conv = True: hoisted conv_image GEMMs on a side stream beside phase 1.  Off: measured on
+        # MI355X the chip-filling recurrent steps slow down by more than the GEMMs take (0.882 ms per batch
+        # overlapped vs 0.812 ms in line, profiles/r02_notes.md).  (An attribute, not an environment switch.)
+        self.overlap_conv = False
+        self.tokens_via_levels = False      # set_tokens_via_levels()
         self._parent = _parent
         if _parent is not None:
             _lib.check(self._lib.n2nmn_ctx_fork(_parent._ctx, C.byref(self._ctx)))
@@ -515,6 +515,7 @@ class Engine:
         P = np.ascontiguousarray(P, np.int32); W = np.ascontiguousarray(W, np.int32)
         b = np.ascontiguousarray(b, np.int32)
         _lib.check(self._lib.n2nmn_set_validity_tables(self._ctx, P.ctypes.data, W.ctypes.data, b.ctypes.data))
+        self.all_tokens_valid = not (P.any() or W.any() or b.any())
 
     def gemm(self, A, B, bias=None):
         torch = _torch()

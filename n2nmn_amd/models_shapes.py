@@ -80,11 +80,16 @@ class NMN3ModelAtt:
                         num_choices=num_choices, T_encoder=T_encoder, T_decoder=T_decoder, N=max_batch,
                         kernel_size=kernel_size)
             engine = Engine(dims, self.assembler, device)
+            # models_shapes' decoder has no validity automaton: every token is valid at every step
+            V = num_vocab_nmn
+            engine.set_validity_tables(np.zeros((V, 3), np.int32), np.zeros((3, V, 4), np.int32),
+                                       np.zeros((V, 4), np.int32))
+        elif not getattr(engine, 'all_tokens_valid', False):
+            # (a caller's engine keeps the tables it was given: installing the all-valid tables behind its back
+            # would change what its other users decode)
+            raise ValueError('models_shapes decodes without a validity automaton: give it an engine whose '
+                             'set_validity_tables() installed all-zero tables, or let it build its own')
         self.engine = engine
-        # models_shapes' decoder has no validity automaton: every token is valid at every step
-        V = num_vocab_nmn
-        engine.set_validity_tables(np.zeros((V, 3), np.int32), np.zeros((3, V, 4), np.int32),
-                                   np.zeros((V, 4), np.int32))
         self.EOS_idx = EOS_idx
         self.T_decoder = T_decoder
         self.hidden_dim = hidden_dim

@@ -202,3 +202,45 @@ def _pass_greedy(sb, retire, n):
     sc, tok, val = sb.run(use_gt_layout=False, eos_retire=retire, n_slots=n)
     torch.cuda.synchronize()
     return t2n(sc).copy(), t2n(tok).copy(), t2n(val).copy()
+
+
+def test_sequential_retirement_needs_an_automaton_that_forces_eos():
+    """dec_compact_kernel retires a row at its answer operator or <eos> and hands it <eos> with probability 1
+    from then on -- exact only if the installed automaton allows nothing else there.  n2nmn_set_validity_tables /
+    n2nmn_set_token_ops prove that over every reachable state; with tables that do not have the property (all-zero =
+    every token always valid, what models_shapes installs) the flag must be ignored: a greedy pass with it returns what
+    the pass without it returns, INCLUDING the tokens behind the first <eos> / answer operator (the full decoder keeps
+    choosing by its logits there)."""
+    from n2nmn_amd.nmn3_assembler import Assembler
+    from n2nmn_amd.superbucket import SuperBucket
+    d = Dims()
+    asm = Assembler(NAMES)
+    sb = SuperBucket(d, asm, K=3)
+    w = synth.make_weights(d, seed=0)
+    sb.load_weights(w)
+    eng = sb.engine
+    V = d.num_vocab_nmn
+    eng.set_validity_tables(np.zeros((V, 3), np.int32), np.zeros((3, V, 4), np.int32), np.zeros((V, 4), np.int32))
+    assert eng.all_tokens_valid
+    for k in range(3):
+        sb.fill(k, synth.make_inputs(d, seed=900 + k, min_len=1))
+    eng.set_mode('throughput')
+    eng.set_walk_levels(d.T_decoder - 1)
+    try:
+        full = _pass_greedy(sb, False, 3)
+        got = _pass_greedy(sb, True, 3)
+    finally:
+        eng.set_walk_levels(0)
+        eng.set_mode('latency')
+    # without an automaton the free-running decoder emits tokens behind an <eos> / answer operator in some row:
+    # exactly the rows a wrongly enabled retirement would have overwritten with <eos>
+    tok = full[1]
+    fin = np.isin(tok, [asm.EOS_idx] + [i for i, nme in enumerate(NAMES) if nme in
+                                        ('_Exist', '_Count', '_EqualNum', '_MoreNum', '_LessNum', '_SameProperty', '_Describe')])
+    first = np.where(fin.any(0), fin.argmax(0), d.T_decoder)
+    behind = np.arange(d.T_decoder)[:, None] > first[None, :]
+    assert (behind & (tok != asm.EOS_idx)).any(), 'the case does not exercise the difference'
+    assert np.array_equal(got[1], full[1]) and np.array_equal(got[2], full[2]) and np.array_equal(got[0], full[0])
+    # and the reference automaton does qualify (the speed-up of the tests above is real): same engine, tables back
+    eng.set_validity_tables(asm.P, asm.W, asm.b)
+    assert not eng.all_tokens_valid
