@@ -360,14 +360,18 @@ int n2nmn_walk_set_front_end(n2nmn_ctx *ctx, int mode);
  * or hands the root to the deferred pooling.  How many levels a pass launches: see n2nmn_walk_set_levels.
  * mode -1 (default): on; 0: off (the walker serves every question). */
 int n2nmn_walk_set_staged(n2nmn_ctx *ctx, int mode);
-/* Nesting levels of _Transform / _FindSameProperty the staged walker launches per pass.  levels = 0
- * (default): adaptive -- as deep as the previous two passes of this context went (a host-mapped word the
- * GPU writes and the host reads without waiting); a layout nested deeper than the pass launches is served
- * by the one-workgroup walker (same operators, other summation order: logits within 1e-5).  The CLEVR
- * template mix never nests: one level.  Because the route of such a question then depends on what ran
- * before, default-mode logits of NESTED layouts are reproducible to that bound, not bit for bit.
- * levels >= 1: exactly that many levels in every pass (1 .. 24; T_dec - 1 covers every layout) -- the route
- * of a question depends on its own layout only and repeated passes return the same bits. */
+/* Nesting levels of _Transform / _FindSameProperty the staged walker launches per pass.  A question is served
+ * either by the level launches or -- nested deeper than the pass launches -- by the one-workgroup walker: same
+ * operators, other summation order in the answer head (logits within 1e-5 of each other).
+ * levels = 0 (default): every level a layout of T_dec tokens can reach (T_dec - 1 launches pairs; the level kernels
+ * are persistent grids that leave at once when their list is empty) and no fall-back launch: the route of a question
+ * depends on nothing but its own layout, repeated passes return the same bits whatever ran before
+ * (Fold's result does not depend on batching).  A pass whose caller promised a nesting bound
+ * (n2nmn_walk_set_nesting_bound: ground-truth layouts) launches exactly that many instead.
+ * levels >= 1: exactly that many levels in every pass (1 .. 24), deeper layouts on the fall-back walker.
+ * levels = -1: adaptive -- as deep as the previous two passes of this context went (a host-mapped word the GPU
+ * writes and the host reads without waiting).  Saves the empty launches of the default (~0.1 ms of a 1024-question
+ * pass of decoder-chosen layouts); the logits of NESTED layouts are then reproducible to 1e-5, not bit for bit. */
 int n2nmn_walk_set_levels(n2nmn_ctx *ctx, int levels);
 /* A promise for the NEXT n2nmn_walk_layouts / n2nmn_execute_tokens call of this context only: no layout of
  * that pass nests _Transform / _FindSameProperty deeper than `bound` levels (0: none has such a node).  A
@@ -628,7 +632,8 @@ int n2nmn_debug_gemm(n2nmn_ctx *ctx, const float *A, const float *B, const float
  *                    split-operand bf16 GEMM) is refused: that kernel exists in the diagnostic library only
  *   before n2nmn_train_enable -- where the weight-gradient GEMMs of a training step run:
  *   "train_overlap"  0: no side stream (default 1)      "train_schedule" 0: every leaf after its recurrence
- *   "train_bg_wgs"   cap on background workgroups, 0 = unbounded     "train_chunks" "p0,p1,p2" time-chunk split */
+ *   "train_bg_wgs"   cap on background workgroups, 0 = unbounded     "train_chunks" "p0,p1,p2" time-chunk split
+ *   "train_bwd_ksplit" (read per step) 0: the reverse-time step without the K split over workgroups (default 1) */
 int n2nmn_debug_set(n2nmn_ctx *ctx, const char *key, const char *value);
 /* out[M,N] = (relu ? max(0, .) : .)(A[M,K] . W[K,N] + bias[N]), row-major fp32, K % 4 == 0:
  * util/cnn.py:87-126 (fc_layer / fc_relu_layer) and -- on im2col rows -- the VALID strided convolutions of

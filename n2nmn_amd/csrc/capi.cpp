@@ -1282,6 +1282,16 @@ static int finish_create(n2nmn_ctx* c, n2nmn_ctx* parent) {
 
 }  // namespace n2nmn
 
+namespace {
+// a device allocation that is freed on EVERY exit of the debug / plumbing entries below (N2_HIP returns early)
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+  template <class T> T* as() const { return static_cast<T*>(p); }
+};
+}  // namespace
+
 // =============================================================================================
 extern "C" {
 
@@ -1789,7 +1799,8 @@ int n2nmn_walk_set_staged(n2nmn_ctx* c, int mode) {
 }
 
 int n2nmn_walk_set_levels(n2nmn_ctx* c, int levels) {
-  N2_REQUIRE(c && levels >= 0 && levels <= WALK_HLEVELS, N2NMN_EINVAL, "walk_set_levels: 0 (adaptive) or 1 .. 24");
+  N2_REQUIRE(c && levels >= -1 && levels <= WALK_HLEVELS, N2NMN_EINVAL,
+             "walk_set_levels: 0 (every reachable level), -1 (adaptive) or 1 .. 24");
   c->walk_levels = levels;
   return N2NMN_OK;
 }
@@ -1882,6 +1893,12 @@ int n2nmn_walk_set_conv_inline(n2nmn_ctx* c, int on) {
 int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int T_dec, int T_enc,
                        int N, n2nmn_stream stream) {
   N2_REQUIRE(c && batches, N2NMN_EINVAL, "walk_layouts: null argument");
+  // the two one-call promises (n2nmn_walk_set_nesting_bound / _conv_inline) are consumed HERE, whichever way
+  // this call ends: a rejected argument further down must not leave them standing for some later pass
+  const int nesting_bound = c->walk_nesting_bound;
+  const bool conv_inline = c->walk_conv_inline;
+  c->walk_nesting_bound = -1;
+  c->walk_conv_inline = false;
   N2_REQUIRE(is_committed(c), N2NMN_ENOWEIGHT, "walk_layouts: weights not committed");
   N2_REQUIRE(root(c)->have_token_ops, N2NMN_EINVAL, "walk_layouts: call n2nmn_set_token_ops first");
   N2_REQUIRE(n2nmn_walk_supported(c), N2NMN_EINVAL,
@@ -1958,29 +1975,33 @@ int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int
     a.staged = 1;
     a.hjobs = c->whjobs; a.fblist = c->wfblist;
     for (int i = 0; i <= WALK_HLEVELS; ++i) a.hoff[i] = c->whoff[i];
-    // How many nesting levels of Transform / FindSameProperty get a launch of their own: as deep as the
-    // last two passes went (the kernels leave that in a host-mapped word; whatever has arrived is read,
-    // nothing waits).  A layout nested deeper than this pass launches is served by the one-workgroup
-    // walker -- same logits -- so the hint steers speed only.  The CLEVR template mix never nests:
-    // one launch.
+    // How many nesting levels of Transform / FindSameProperty get a launch of their own.  The route of a
+    // question (a level launch or the one-workgroup fall-back) decides the summation order of its answer head,
+    // i.e. the last bits of its logits, so by DEFAULT it must depend on nothing but the pass itself
+    // (models_clevr/nmn3_model.py:134-159: Fold's result does not depend on batching): every
+    // level a layout of T_dec tokens can reach gets its launch (T_dec - 1; the level kernels are persistent
+    // grids that leave at once when their list is empty) and the fall-back is not needed.
+    // n2nmn_walk_set_levels(ctx, -1) opts into the adaptive form instead: as deep as the last two passes went
+    // (a host-mapped word the kernels write and the host reads without waiting) -- fewer empty launches,
+    // history-dependent last bits for nested layouts.
     int seen = 0;
     if (c->walk_hint_host) {
       seen = *reinterpret_cast<volatile int32_t*>(c->walk_hint_host);
       a.hint = c->walk_hint_dev;
     }
-    const int want = c->walk_levels > 0 ? c->walk_levels : std::max(seen, c->walk_hint_prev);
+    const int full = std::max(T_dec - 1, 1);
+    const int want = c->walk_levels > 0 ? c->walk_levels
+                     : c->walk_levels < 0 ? std::max(seen, c->walk_hint_prev) : full;
     c->walk_hint_prev = seen;
     a.hlevels = std::min(std::max(want, 1), WALK_HLEVELS);
+    if (c->walk_levels == 0 && full <= WALK_HLEVELS) a.no_fallback = 1;     // (no layout can nest deeper)
     // the caller knows this pass's layouts (host copies of ground-truth layouts): exactly as many levels
     // as they nest, and no launch of the fall-back walker (an empty one costs 4 - 5 us of the pass)
-    if (c->walk_nesting_bound >= 0 && c->walk_nesting_bound <= WALK_HLEVELS) {
-      a.hlevels = std::max(c->walk_nesting_bound, 1);
+    if (nesting_bound >= 0 && nesting_bound <= WALK_HLEVELS) {
+      a.hlevels = std::max(nesting_bound, 1);
       a.no_fallback = 1;
     }
   }
-  c->walk_nesting_bound = -1;     // (a promise covers one call)
-  const bool conv_inline = c->walk_conv_inline;
-  c->walk_conv_inline = false;    // (so does the request for the maps)
   if (conv_inline && !pre) walk_conv_inline(c, batches, K, N, T_dec, s);
   if (pre) {
     a.pre_find = 1;
@@ -2110,6 +2131,8 @@ int n2nmn_execute_tokens(n2nmn_ctx* c, const int32_t* tokens, int T_dec, int N,
              "execute_tokens: null argument");
   // dimensions outside the walker's tiling (models_vqa): the level path, scheduled on the device
   if (!n2nmn_walk_supported(c) || c->tokens_via_levels) {
+    c->walk_nesting_bound = -1;   // (the level path has no use for the walker's one-call promises: drop them)
+    c->walk_conv_inline = false;
     int rc = n2nmn_conv_image(c, image_feat, N, N2NMN_CONV_FIND | N2NMN_CONV_FSP, tokens, T_dec, stream);
     if (rc != N2NMN_OK) return rc;
     return run_tokens_levels(c, tokens, T_dec, N, image_feat, word_vecs, scores, validity, S(stream));
@@ -2291,7 +2314,7 @@ int n2nmn_debug_lstm_bench(n2nmn_ctx* c, int variant, int rows_per_wg, int njobs
 int n2nmn_debug_set(n2nmn_ctx* ctx, const char* key, const char* value) {
   N2_REQUIRE(ctx && key, N2NMN_EINVAL, "debug_set: null argument");
   static const char* const known[] = {"tile_min_rows", "eht_rows", "debug_gemm_b3", "train_overlap", "train_bg_wgs",
-                                      "train_schedule", "train_chunks"};
+                                      "train_schedule", "train_chunks", "train_bwd_ksplit"};
   bool ok = false;
   for (const char* k : known) ok = ok || strcmp(k, key) == 0;
   if (!ok) {
@@ -2318,16 +2341,18 @@ int n2nmn_debug_gemm(n2nmn_ctx* ctx, const float* A, const float* B, const float
   const bool b3 = false;
 #endif
   const int Kp = round_up(K, 32), Np = round_up(N, b3 ? 128 : 64);
-  float* Bp = nullptr;
+  DevBuf pack, pack3;                     // (freed on every exit)
   uint16_t* Bp3 = nullptr;
-  N2_HIP(hipMalloc(reinterpret_cast<void**>(&Bp), sizeof(float) * (size_t)Kp * Np));
+  N2_HIP(pack.alloc(sizeof(float) * (size_t)Kp * Np));
+  float* Bp = pack.as<float>();
   hipStream_t s = S(stream);
   launch_pack_pk(B, N, K, N, Bp, Kp, Np, s);
   GemmArgs g{};
   g.A = A; g.lda = K; g.M = M; g.K = K; g.group_size = 1; g.Bp = Bp; g.Np = Np; g.Kp = Kp;
   g.bias = bias; g.N = N; g.C = C; g.ldc = N; g.n_store = N;
   if (b3) {
-    N2_HIP(hipMalloc(reinterpret_cast<void**>(&Bp3), sizeof(uint16_t) * 3 * (size_t)Kp * Np));
+    N2_HIP(pack3.alloc(sizeof(uint16_t) * 3 * (size_t)Kp * Np));
+    Bp3 = pack3.as<uint16_t>();
     launch_pack_pk_b3(Bp, Kp, Np, Bp3, s);
     g.Bp3 = Bp3;
   }
@@ -2339,9 +2364,7 @@ int n2nmn_debug_gemm(n2nmn_ctx* ctx, const float* A, const float* B, const float
     if (b3 && gemm_dma3_supported(g) && tiles3 >= 256) launch_gemm_dma3(&g, 1, s);
     else launch_gemm_pk(g, s);
   }
-  N2_HIP(hipStreamSynchronize(s));       // debug entry only: Bp is freed right away
-  N2_HIP(hipFree(Bp));
-  if (Bp3) N2_HIP(hipFree(Bp3));
+  N2_HIP(hipStreamSynchronize(s));       // debug entry only: the packs are freed right away
   return check_launch("debug_gemm");
 }
 
@@ -2354,16 +2377,17 @@ int n2nmn_fc_forward(n2nmn_ctx* ctx, const float* A, const float* W, const float
   N2_REQUIRE(M > 0 && N > 0 && K > 0 && K % 4 == 0, N2NMN_EINVAL,
              "fc_forward: K must be a positive multiple of 4");
   const int Kp = round_up(K, 32), Np = round_up(N, 64);
-  float* Bp = nullptr;
-  N2_HIP(hipMalloc(reinterpret_cast<void**>(&Bp), sizeof(float) * (size_t)Kp * Np));
+  DevBuf pack;                            // (freed on every exit, after the stream has drained)
+  N2_HIP(pack.alloc(sizeof(float) * (size_t)Kp * Np));
+  float* Bp = pack.as<float>();
   hipStream_t s = S(stream);
   launch_pack_pk(W, N, K, N, Bp, Kp, Np, s);
   GemmArgs g{};
   g.A = A; g.lda = K; g.M = M; g.K = K; g.group_size = 1; g.Bp = Bp; g.Np = Np; g.Kp = Kp;
   g.bias = bias; g.N = N; g.C = out; g.ldc = N; g.n_store = N; g.relu = relu ? 1 : 0;
   launch_gemm_pk(g, s);
-  N2_HIP(hipStreamSynchronize(s));       // (the pack is freed right away)
-  N2_HIP(hipFree(Bp));
+  const hipError_t done = hipStreamSynchronize(s);       // the pack may go only behind the GEMM that reads it
+  N2_HIP(done);
   return check_launch("fc_forward");
 }
 

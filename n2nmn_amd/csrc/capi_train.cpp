@@ -415,6 +415,8 @@ int run_bptt(n2nmn_ctx* c, const BpttArgs& a, hipStream_t s,
                              (j0.active ? 8.0 * L * L + 8.0 * N * L : 0) + 20.0 * N * L);
     {
       ProfScope ps(c, F_LSTM_BWD, fl, by, s);
+      // (the contraction split over workgroups as well was measured and rejected in round 6: 15.7 us per launch
+      // against 15.0, tools/rejected/lstm_bwd_step_ksplit.hip.txt)
       launch_lstm_bwd_step(jobs, 2, N, L, s);
     }
     if (after_step && k >= 1 && t0 >= 0 && t0 < a.T) (*after_step)(t0);

@@ -22,6 +22,12 @@ def _torch():
 
 
 class Engine:
+    _latest = None          # weak reference to the most recently built root engine (Modules() without engine=)
+
+    @classmethod
+    def latest(cls):
+        return cls._latest() if cls._latest is not None else None
+
     def __init__(self, dims: Dims, assembler: Assembler, device: int = 0, _parent=None):
         torch = _torch()
         if not torch.cuda.is_available():
@@ -61,6 +67,9 @@ class Engine:
         tok_op = np.ascontiguousarray(assembler._token_op, np.int32)
         _lib.check(self._lib.n2nmn_set_token_ops(self._ctx, tok_op.ctypes.data, tok_op.shape[0]))
         self._bufs: Dict[tuple, object] = {}
+        self.all_tokens_valid = not (P.any() or W.any() or b.any())
+        import weakref
+        Engine._latest = weakref.ref(self)
 
     def __del__(self):
         ctx, self._ctx = getattr(self, '_ctx', None), None
@@ -315,10 +324,11 @@ class Engine:
         _lib.check(self._lib.n2nmn_walk_set_staged(self._ctx, int(mode)))
 
     def set_walk_levels(self, levels: int):
-        """0 (default): the staged walker launches as many nesting levels of Transform / FindSameProperty
-        as the last two passes needed (deeper layouts: the one-workgroup walker, logits within 1e-5);
-        >= 1: exactly that many in every pass -- a question's route then depends on its own layout only
-        and repeated passes return the same bits (n2nmn_walk_set_levels)."""
+        """0 (default): the staged walker launches every nesting level of Transform / FindSameProperty a layout
+        of T_dec tokens can reach (empty level launches leave at once) -- a question's route depends on its own
+        layout only and repeated passes return the same bits; >= 1: exactly that many, deeper layouts on the
+        one-workgroup walker (logits within 1e-5); -1: adaptive, as many as the last two passes needed: fewer
+        empty launches, history-dependent last bits for nested layouts (n2nmn_walk_set_levels)."""
         _lib.check(self._lib.n2nmn_walk_set_levels(self._ctx, int(levels)))
 
     def set_nesting_bound(self, bound: int):

@@ -17,8 +17,12 @@ from .engine import Engine
 class Modules:
     def __init__(self, image_feat_grid, word_vecs, num_choices, engine: Engine = None):
         if engine is None:
-            raise ValueError('Modules needs the Engine holding the committed weights '
-                             '(engine=...)')
+            # the reference's positional form (models_clevr/nmn3_modules.py:11, exp_shapes/visualize_shapes.ipynb
+            # cell 6): the weights are "the graph's"; here, those of the most recently built root Engine
+            engine = Engine.latest()
+            if engine is None:
+                raise ValueError('Modules(image_feat_grid, word_vecs, num_choices): no Engine has been built yet -- '
+                                 'build the model (NMN3Model / Engine) first or pass engine=')
         if num_choices != engine.dims.num_choices:
             raise ValueError('num_choices differs from the committed model')
         self.engine = engine

@@ -173,7 +173,7 @@ class VQAEngine:
         self.assembler = Assembler(list(VQA_MODULE_NAMES), op_code=VQA_OP_CODE)
         self.engine = Engine(self.idims, self.assembler, device=device)
         self._feat_c = None
-        self._slabs = {}           # data_ptr -> shape of the resident input slabs (feature_slab)
+        self._slabs = []           # weak references to the resident input slabs (feature_slab)
 
     def load_weights(self, weights: Dict[str, object]):
         shapes = vqa_variable_shapes(self.dims)
@@ -204,8 +204,26 @@ class VQAEngine:
         one = torch.empty((1, di.H, di.W, di.D), dtype=torch.float32, device=e.device)
         _lib.check(e._lib.n2nmn_add_coords(e._ctx, zero.data_ptr(), 1, d.D, one.data_ptr(), e.stream()))
         slab.copy_(one.expand_as(slab))
-        self._slabs[slab.data_ptr()] = tuple(slab.shape)
+        # remembered by a WEAK reference and recognised by storage identity (features_with_coords): once the caller
+        # drops the slab the entry dies with it, so an unrelated tensor that the allocator later places at the same
+        # address is never mistaken for one that already carries the coordinate channels
+        import weakref
+        self._slabs = [r for r in self._slabs if r() is not None]
+        self._slabs.append(weakref.ref(slab))
         return slab
+
+    def _slab_of(self, t):
+        """the live feature_slab() tensor `t` is a row-aligned contiguous view of, or None"""
+        sp = t.untyped_storage().data_ptr()
+        for r in self._slabs:
+            base = r()
+            if base is None or base.untyped_storage().data_ptr() != sp:
+                continue
+            row = base.shape[1] * base.shape[2] * base.shape[3]
+            if t.is_contiguous() and tuple(t.shape[1:]) == tuple(base.shape[1:]) and t.storage_offset() % row == 0 and \
+                    t.storage_offset() // row + t.shape[0] <= base.shape[0]:
+                return base
+        return None
 
     def features_with_coords(self, image_feat):
         """[N,H,W,D] image features -> [N,H,W,Dp] with the coordinate map appended (on the GPU); a slab
@@ -213,10 +231,9 @@ class VQAEngine:
         import torch
         e, d, di = self.engine, self.dims, self.idims
         if hasattr(image_feat, 'data_ptr') and image_feat.dim() == 4 and image_feat.shape[-1] == di.D != d.D:
-            base = self._slabs.get(image_feat.data_ptr())
-            if base is None or image_feat.shape[0] > base[0] or not image_feat.is_contiguous():
-                raise ValueError('a [N, H, W, %d] tensor must be (the first rows of) a slab of feature_slab(); '
-                                 'raw image features are [N, H, W, %d]' % (di.D, d.D))
+            if self._slab_of(image_feat) is None:
+                raise ValueError('a [N, H, W, %d] tensor must be a slab of feature_slab() that is still alive (or whole '
+                                 'rows of one); raw image features are [N, H, W, %d]' % (di.D, d.D))
             return image_feat
         feat = e._dev(image_feat, torch.float32)
         n = feat.shape[0]

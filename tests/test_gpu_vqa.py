@@ -138,3 +138,30 @@ def test_resident_feature_slab_equals_add_coords_per_pass(vqa_setup):
         assert validity.all() and np.array_equal(t2n(got), want)
     with pytest.raises(ValueError):
         eng.forward(dict(batch, image_feat_batch=torch.zeros_like(slab)), use_gt_layout=True, gt_layout=gt)
+
+
+def test_feature_slab_is_recognised_by_identity_not_by_address(vqa_setup):
+    """the slab registry used to be data_ptr -> shape with no reference to the slab.  A slab the caller has
+    dropped must stop being accepted even if the allocator hands its address to the next tensor of the same shape;
+    whole rows of a live slab (slab[k:]) are a slab too."""
+    import gc
+    import torch
+    eng, d, w = vqa_setup
+    gt = _gt(eng, d)
+    batch = _batch(d, 5)
+    slab = eng.feature_slab(d.N)
+    slab[..., :d.D].copy_(torch.as_tensor(batch['image_feat_batch']).to(slab.device))
+    full, _, _ = eng.forward(dict(batch, image_feat_batch=slab), use_gt_layout=True, gt_layout=gt)
+    full = t2n(full).copy()
+    k = 3                                            # the last N - k questions as a view of the slab
+    part = {kk: (v[:, k:] if kk in ('input_seq_batch',) else v[k:]) for kk, v in batch.items() if kk != 'image_feat_batch'}
+    got, _, _ = eng.forward(dict(part, image_feat_batch=slab[k:]), use_gt_layout=True, gt_layout=gt[:, k:])
+    assert np.abs(t2n(got) - full[k:]).max() <= 1e-5
+    ptr, shape = slab.data_ptr(), tuple(slab.shape)
+    del slab, got
+    gc.collect()
+    torch.cuda.synchronize()
+    other = torch.zeros(shape, dtype=torch.float32, device=eng.engine.device)      # (usually the very same address)
+    print('the freed slab address was %s' % ('reused' if other.data_ptr() == ptr else 'not reused'))
+    with pytest.raises(ValueError, match='still alive'):
+        eng.forward(dict(batch, image_feat_batch=other), use_gt_layout=True, gt_layout=gt)
