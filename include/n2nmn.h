@@ -632,8 +632,7 @@ int n2nmn_debug_gemm(n2nmn_ctx *ctx, const float *A, const float *B, const float
  *                    split-operand bf16 GEMM) is refused: that kernel exists in the diagnostic library only
  *   before n2nmn_train_enable -- where the weight-gradient GEMMs of a training step run:
  *   "train_overlap"  0: no side stream (default 1)      "train_schedule" 0: every leaf after its recurrence
- *   "train_bg_wgs"   cap on background workgroups, 0 = unbounded     "train_chunks" "p0,p1,p2" time-chunk split
- *   "train_bwd_ksplit" (read per step) 0: the reverse-time step without the K split over workgroups (default 1) */
+ *   "train_bg_wgs"   cap on background workgroups, 0 = unbounded     "train_chunks" "p0,p1,p2" time-chunk split */
 int n2nmn_debug_set(n2nmn_ctx *ctx, const char *key, const char *value);
 /* out[M,N] = (relu ? max(0, .) : .)(A[M,K] . W[K,N] + bias[N]), row-major fp32, K % 4 == 0:
  * util/cnn.py:87-126 (fc_layer / fc_relu_layer) and -- on im2col rows -- the VALID strided convolutions of

@@ -2314,7 +2314,7 @@ int n2nmn_debug_lstm_bench(n2nmn_ctx* c, int variant, int rows_per_wg, int njobs
 int n2nmn_debug_set(n2nmn_ctx* ctx, const char* key, const char* value) {
   N2_REQUIRE(ctx && key, N2NMN_EINVAL, "debug_set: null argument");
   static const char* const known[] = {"tile_min_rows", "eht_rows", "debug_gemm_b3", "train_overlap", "train_bg_wgs",
-                                      "train_schedule", "train_chunks", "train_bwd_ksplit"};
+                                      "train_schedule", "train_chunks"};
   bool ok = false;
   for (const char* k : known) ok = ok || strcmp(k, key) == 0;
   if (!ok) {

@@ -7,8 +7,10 @@
 busy.db: --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE
 mops.db: --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 (either may be absent)
 
-mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs) -- the counter sums busy cycles over the
-256 CUs x 4 SIMDs of the device (MI355X_MICROARCH.md: it counts cycles, 32 per 32x32x16 bf16 MFMA).
+mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs): the SQ counter sums busy cycles over the
+256 CUs x 4 SIMDs of the device, the GRBM counter sums active cycles over the 8 XCDs.  Calibrated on this box with
+tools/microbench/mfma_peak (nothing but fp32 MFMAs, 143 - 153 TFLOP/s = 0.91 - 0.97 of peak by its own clock): that
+kernel reads 0.119 - 0.123 before the factor of 8, 0.95 - 0.98 with it (profiles/r06_pmc_mfma_calibration.txt).
 counter flops = 512 x SQ_INSTS_VALU_MFMA_MOPS_* (one MOP = 512 flops)."""
 import json
 import sqlite3
@@ -33,7 +35,7 @@ def main(busy_db, mops_db, out=None):
         gui, mf = v.get('GRBM_GUI_ACTIVE'), v.get('SQ_VALU_MFMA_BUSY_CYCLES')
         if not gui or not mf:
             continue
-        r = dict(launches=v['launches'], gui_cycles=gui, mfma_busy_cycles=mf, mfma_busy=mf / (gui * 1024.0))
+        r = dict(launches=v['launches'], gui_cycles=gui, mfma_busy_cycles=mf, mfma_busy=mf / (gui / 8.0 * 1024.0))
         if v.get('SQ_BUSY_CU_CYCLES'):
             r['cu_busy_cycles'] = v['SQ_BUSY_CU_CYCLES']
         m = mops.get(k, {})
