@@ -436,6 +436,7 @@ def test_staged_walker_lists_nested_layouts_level_by_level(clevr_engine):
         later, fb_later = one_pass(True)
         assert fb_later == 0                            # one walk_heavy launch per nesting level seen
     finally:
+        eng.set_walk_levels(0)
         eng.set_front_end(-1)
         eng.set_defer_pool(-1)
         eng.set_staged(-1)
@@ -446,10 +447,11 @@ def test_staged_walker_lists_nested_layouts_level_by_level(clevr_engine):
 
 
 def test_fixed_level_count_makes_nested_layouts_reproducible_bit_for_bit(clevr_engine):
-    """n2nmn_walk_set_levels: with the adaptive default a nested layout goes through the
+    """n2nmn_walk_set_levels: in the adaptive form (levels = -1) a nested layout goes through the
     fall-back walker in a context's first nested pass and through the level launches later (other summation
-    order, 1e-5).  With a fixed level count the route depends on the layout alone: a pass right after
-    template passes and a pass after nested ones return the same bits."""
+    order, 1e-5).  With a fixed level count -- and with the default, which launches every reachable level
+    (round 6) -- the route depends on the layout alone: a pass right after template passes and a pass after
+    nested ones return the same bits, and the default returns the bits of levels = T_dec - 1."""
     eng, d, asm, w = clevr_engine
     batch = synth.make_inputs(d, seed=77)
     toks = synth.random_valid_layouts(d, asm.P, asm.W, asm.b, seed=612, max_len=14)
@@ -477,7 +479,10 @@ def test_fixed_level_count_makes_nested_layouts_reproducible_bit_for_bit(clevr_e
         a = run(s2n)                 # first nested pass of the "history"
         run(s2n)
         b = run(s2n)
-        eng.set_walk_levels(0)
+        eng.set_walk_levels(0)       # the default: every reachable level
+        for _ in range(2):
+            run(s2t)
+        c = run(s2n)
         eng.set_staged(0)
         ref = run(s2n)
     finally:
@@ -486,6 +491,7 @@ def test_fixed_level_count_makes_nested_layouts_reproducible_bit_for_bit(clevr_e
         eng.set_defer_pool(-1)
         eng.set_staged(-1)
     assert np.array_equal(a, b), 'fixed level count: the logits must not depend on what ran before'
+    assert np.array_equal(a, c), 'the default route is the route of levels = T_dec - 1'
     assert_close('level by level vs the one-workgroup walker', a, ref, STAGED_TOL)
 
 
