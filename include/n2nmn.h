@@ -106,10 +106,10 @@ int n2nmn_ctx_dims(const n2nmn_ctx *ctx, n2nmn_dims *out);
 /* N2NMN_MODE_THROUGHPUT_BF16X3  (opt-in) N2NMN_MODE_THROUGHPUT with the recurrent contraction of passes of
  *   >= 128 rows on the bf16 matrix cores over three-way split operands: w = wh + wm + wl, h = hh + hm + hl
  *   (bf16 each, exact sums), six cross products per 16 x 16 x 32 block with fp32 accumulation
- *   (csrc/kernels_lstm_tile3.hip).  The dense contractions (encoder_h_transform, W_a, conv_image) have the
- *   same form in csrc/kernels_gemm_dma3.hip, but that kernel left the product path at the end of round 5:
- *   with a second stream running passes concurrently it returned intermittent wrong tiles (cause unknown;
- *   N2NMN_GEMM_DMA3=1 brings it back for investigation).  The terms dropped are <= 2^-26 relative: same error class as the fp32
+ *   (csrc/kernels_lstm_tile3.hip).  The dense contractions (encoder_h_transform, W_a, conv_image) stay on the
+ *   exact-fp32 kernels: their split-operand form is not part of this library (a pass whose conv_image launch ran
+ *   on it returned wrong logits while another stream ran passes; DESIGN.md 2.1, profiles/r06_notes.md section 1).
+ *   The terms dropped are <= 2^-26 relative: same error class as the fp32
  *   MFMA's own rounding -- every parity test runs unchanged at 1e-4 in this mode -- but NOT the same bits
  *   as the fp32 kernels, so it is a mode of its own and never the default.  Training forwards keep the
  *   fp32 kernels.  Needs lstm_dim % 128 == 0 and lstm_dim >= 256 (N2NMN_EINVAL otherwise); the first call
@@ -395,8 +395,8 @@ int n2nmn_walk_set_conv_inline(n2nmn_ctx *ctx, int on);
  *   - any other (models_vqa): the level path of n2nmn_execute_program with the program assembled and
  *     level-scheduled ON THE DEVICE (sched_kernel): every level of the capacity T_dec gets its three
  *     persistent-grid launches, which read their work tables and lengths from HBM; nothing is read back.
- *     (n2nmn_set_tokens_via_levels(ctx, 1) or N2NMN_TOKENS_VIA_LEVELS=1 forces this form for every
- *     variant: the scheduler's cross-check against the walker and the host assembler.)
+ *     (n2nmn_set_tokens_via_levels(ctx, 1) forces this form for every variant: the scheduler's cross-check
+ *     against the walker and the host assembler.)
  * scores [N][num_choices] (INVALID_EXPR rows zero), validity [N] (expr_validity_array) or NULL. */
 int n2nmn_execute_tokens(n2nmn_ctx *ctx, const int32_t *tokens, int T_dec, int N,
                          const float *image_feat, const float *word_vecs, float *scores,
@@ -628,6 +628,8 @@ int n2nmn_debug_gemm(n2nmn_ctx *ctx, const float *A, const float *B, const float
  * setting against the oracle).  Unknown key: N2NMN_EKEY.  Keys (values are decimal strings):
  *   "tile_min_rows"  encoder steps with at most this many live rows use the K-split tiles (default 192)
  *   "eht_rows"       0: encoder_h_transform over all T N rows instead of the rows inside their length (default 1)
+ *   "profile_walk_stats" 0: profiled passes keep their event pairs but the walker kernels do not count nodes (default 1:
+ *                    the counts are the families' algorithmic bytes; the atomics slow the tree-dependent launches 3 x)
  *   "debug_gemm_b3"  n2nmn_debug_gemm: n < 0 = -n launches per call (timing loops); n > 0 (n launches on the
  *                    split-operand bf16 GEMM) is refused: that kernel exists in the diagnostic library only
  *   before n2nmn_train_enable -- where the weight-gradient GEMMs of a training step run:

@@ -1938,7 +1938,10 @@ int n2nmn_walk_layouts(n2nmn_ctx* c, const n2nmn_walk_batch* batches, int K, int
   a.K = K; a.N = N; a.T = T_dec; a.V = d.num_vocab_nmn; a.token_op = root(c)->token_op;
   a.H = d.H; a.W = d.W; a.D = d.D; a.M = d.map_dim; a.Mp = c->Mp; a.HWp = c->HWp;
   a.E = d.embed_dim_txt; a.C = d.num_choices; a.ksize = d.kernel_size;
-  a.stats = c->prof_on ? c->walk_stats : nullptr;
+  // (profile mode: the walker kernels count their nodes into device words -- the source of the families' algorithmic
+  // bytes, and a few hundred contended atomics that triple the tree-dependent launches' time; "profile_walk_stats" = 0
+  // keeps the event pairs and drops the counting, for the passes whose DURATIONS are read)
+  a.stats = c->prof_on && knob_int(c, "profile_walk_stats", 1) != 0 ? c->walk_stats : nullptr;
   a.timeline = c->walk_timeline;
   a.T_enc = use_table ? T_enc : 0;
   for (int i = 0; i < 5; ++i) a.ew[i] = root(c)->ew[i];
@@ -2314,7 +2317,7 @@ int n2nmn_debug_lstm_bench(n2nmn_ctx* c, int variant, int rows_per_wg, int njobs
 int n2nmn_debug_set(n2nmn_ctx* ctx, const char* key, const char* value) {
   N2_REQUIRE(ctx && key, N2NMN_EINVAL, "debug_set: null argument");
   static const char* const known[] = {"tile_min_rows", "eht_rows", "debug_gemm_b3", "train_overlap", "train_bg_wgs",
-                                      "train_schedule", "train_chunks"};
+                                      "train_schedule", "train_chunks", "profile_walk_stats"};
   bool ok = false;
   for (const char* k : known) ok = ok || strcmp(k, key) == 0;
   if (!ok) {

@@ -96,7 +96,7 @@ struct TrainState {
   int bg_wgs = 768;
   // 1: the recurrences' weight gradients follow them on the side stream (decoder: after its last
   // step, under the encoder's pass; encoder: chunk by chunk); 0: on the caller's stream after each
-  // recurrence (round 2's schedule).  N2NMN_TRAIN_SCHEDULE
+  // recurrence (round 2's schedule).  n2nmn_debug_set "train_schedule"
   int schedule = 1;
   int chunk_pct[3] = {33, 0, 0};
   int bg(hipStream_t s) const { return overlap && side && s == side ? bg_wgs : 0; }
@@ -866,7 +866,7 @@ int n2nmn_train_backward(n2nmn_ctx* c, const n2nmn_train_io* io, n2nmn_program* 
     // gradient (here the embedding gradient through word_vecs; in phase 1 the LSTM's)
     // chunk starts of the encoder's reverse-time pass (descending).  Every chunk is a launch that
     // updates all of dW (fixed cost ~70 us whatever its rows), so there are few: by default
-    // [T/3, T) under the last third of the recurrence and [0, T/3) after it (N2NMN_TRAIN_CHUNKS =
+    // [T/3, T) under the last third of the recurrence and [0, T/3) after it (n2nmn_debug_set "train_chunks" =
     // up to three descending percentages of T)
     for (int i = 0; i < 4; ++i) t->chunk_start[i] = i < 3 ? T * t->chunk_pct[i] / 100 : 0;
     launch_active_rows(io->seq_length, T, N, t->act_rows, t->act_count, t->act_rows_ch,

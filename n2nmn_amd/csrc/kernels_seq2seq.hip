@@ -1753,7 +1753,7 @@ void launch_dec_attn(const DecStepArgs& a, int nsteps, hipStream_t s) {
     hipLaunchKernelGGL(dec_attn_kernel<256>, dim3(a.N, nsteps), dim3(256), smem, s, a);
     return;
   }
-  // one step per launch (greedy / sampled decoding): the one-pass form; N2NMN_DEC_ATTN_SEQ=0 keeps the
+  // one step per launch (greedy / sampled decoding): the one-pass form; the diagnostic build's N2NMN_DEC_ATTN_SEQ=0 keeps the
   // three-pass kernel
   static const bool seq_on = N2NMN_KNOB_INT("N2NMN_DEC_ATTN_SEQ", 1) != 0;
   if (seq_on && a.L == 512) {       // (lstm_dim 1024 needs 128 VGPRs in this form: one workgroup per CU)

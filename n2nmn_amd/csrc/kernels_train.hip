@@ -393,7 +393,7 @@ __global__ void pack_tiles_t_kernel(const float* __restrict__ W, int ld, int row
 // BW_WAVES = waves that split K (template parameter).  A step moves 96 MB from L2 to the CUs at
 // lstm_dim 512 / 64 rows (every workgroup streams its 16 rows x K of dz and its K x 16 weight tile: 4
 // flops per byte), which is what bounds it -- not the bytes in flight: 16 waves (256 KiB in flight per
-// CU) measured 12.3 us per step against 11.7 for 8 (round 3, N2NMN_BWD_WAVES).
+// CU) measured 12.3 us per step against 11.7 for 8 (round 3; the 16-wave form stays behind the diagnostic build's N2NMN_BWD_WAVES).
 struct LstmBwdJobs {
   LstmBwdJob j[2];
 };

@@ -574,7 +574,7 @@ class Engine:
         if self.walk_supported() and not host_assemble:
             # device path: the walker decodes the layouts itself (no sync between the phases).  The
             # hoisted conv_image GEMMs ride in phase 1's own GEMM launch (with encoder_h_transform
-            # and q); N2NMN_OVERLAP_CONV=1 puts them on a side stream beside the recurrent chain
+            # and q); engine.overlap_conv = True puts them on a side stream beside the recurrent chain
             # instead (measured slower: they take CUs from the chip-filling step kernels)
             torch = _torch()
             gt_dev = self.upload_i32(gt_layout) if isinstance(gt_layout, np.ndarray) else \

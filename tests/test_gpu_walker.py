@@ -423,6 +423,14 @@ def test_staged_walker_lists_nested_layouts_level_by_level(clevr_engine):
         eng.set_staged(0)
         ref, _ = one_pass(False)                        # the one-workgroup walker
         eng.set_staged(1)
+        # (round 6) the DEFAULT launches every reachable nesting level: no layout reaches the fall-back list, and
+        # the logits do not depend on what the context ran before -- bit for bit
+        d0, fb_d0 = one_pass(True)
+        d1, _ = one_pass(False)
+        assert fb_d0 == 0 and np.array_equal(d0, d1)
+        assert_close('default route vs the one-workgroup walker', d0, ref, STAGED_TOL)
+        # the ADAPTIVE form (n2nmn_walk_set_levels(ctx, -1)): as many level launches as the last two passes needed
+        eng.set_walk_levels(-1)
         # template passes first: the hint of earlier tests in this process must have decayed
         tpl = synth.template_layout_batch(d)
         s2t = eng.seq2seq(batch['input_seq_batch'], batch['seq_length_batch'], forced_tokens=tpl,
