@@ -408,7 +408,9 @@ __global__ __launch_bounds__(BW_WAVES * 64) void lstm_bwd_step_kernel(LstmBwdJob
   constexpr int ROWS = 16 * BW_MT;
   const int tile = blockIdx.x;
   const int row0 = blockIdx.z * ROWS;
-  if (jb.n_act && row0 >= *jb.n_act) return;     // no row of this block is inside its length at step t
+  // (the active-row count of step t is a dependent scalar load: requested here, tested only after the epilogue
+  // operands and the first operand sets have been requested, so its round trip runs under theirs)
+  const int32_t* const nact_p = jb.n_act;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int ci = lane & 15, kg = lane >> 4;
 
@@ -475,20 +477,12 @@ __global__ __launch_bounds__(BW_WAVES * 64) void lstm_bwd_step_kernel(LstmBwdJob
 #ifndef BWS_NS
 #define BWS_NS 4
 #endif
-#ifndef BWS_NT
-#define BWS_NT 0
-#endif
     constexpr int UN = BW_MT == 1 ? BWS_UN : (BWS_UN + 1) / 2;   // chunks per set (NS x UN x (1 + BW_MT) float4 registers)
     constexpr int NS = BWS_NS;
     f32x4 bq[NS][UN];
     f32x4 aq[NS][UN][BW_MT];
-    auto ld = [&](const char* ptr) -> f32x4 {
-#if BWS_NT
-      return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ptr));
-#else
-      return *reinterpret_cast<const f32x4*>(ptr);
-#endif
-    };
+    // (plain loads: non-temporal ones cost 0.34 ms per step -- the four row blocks of a column tile share its lines)
+    auto ld = [&](const char* ptr) -> f32x4 { return *reinterpret_cast<const f32x4*>(ptr); };
     auto load_set = [&](int s, int q0) {           // (s is a compile-time constant wherever this is called)
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
@@ -516,6 +510,8 @@ __global__ __launch_bounds__(BW_WAVES * 64) void lstm_bwd_step_kernel(LstmBwdJob
       // keep the compiler from sinking a set's loads below the MFMAs they are meant to run under
 #pragma unroll
       for (int s = 0; s < NS - 1; ++s) load_set(s, s * UN);
+      __builtin_amdgcn_sched_barrier(0);
+      if (nact_p && row0 >= *nact_p) return;       // no row of this block is inside its length at step t
       int q0 = 0;
       for (; q0 + NS * UN < nch; q0 += NS * UN) {
 #pragma unroll
@@ -531,12 +527,14 @@ __global__ __launch_bounds__(BW_WAVES * 64) void lstm_bwd_step_kernel(LstmBwdJob
 #pragma unroll
       for (int s = 0; s < NS; ++s) mfma_set(s, UN);
     } else {
+      if (nact_p && row0 >= *nact_p) return;
       for (int q0 = 0; q0 < nch; q0 += UN) {       // any other size: one set at a time
         load_set(0, q0);
         mfma_set(0, nch - q0);
       }
     }
   }
+  else if (nact_p && row0 >= *nact_p) return;
   // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
   for (int m = 0; m < BW_MT; ++m)
@@ -1184,7 +1182,10 @@ void launch_lstm_bwd_step(const LstmBwdJob* jobs, int njobs, int N, int L, hipSt
     dim3 grid(L / 16, njobs, (N + 31) / 32);
     hipLaunchKernelGGL((lstm_bwd_step_kernel<2, 8>), grid, dim3(512), 0, s, js, N, L);
   } else {
-    static const int waves = N2NMN_KNOB_INT("N2NMN_BWD_WAVES", 8) == 16 ? 16 : 8;
+#ifndef BWS_WAVES
+#define BWS_WAVES 8
+#endif
+    static const int waves = N2NMN_KNOB_INT("N2NMN_BWD_WAVES", BWS_WAVES) == 16 ? 16 : 8;
     dim3 grid(L / 16, njobs, (N + 15) / 16);
     if (waves == 16)
       hipLaunchKernelGGL((lstm_bwd_step_kernel<1, 16>), grid, dim3(1024), 0, s, js, N, L);
