@@ -12,9 +12,12 @@ from n2nmn_amd.engine import Engine
 from n2nmn_amd.train import Trainer
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+knobs = dict(kv.split('=', 1) for kv in sys.argv[2:])      # e.g. train_chunks=25 train_bg_wgs=512
 d = Dims(N=64, T_decoder=10)
 eng = Engine(d, Assembler(list(CLEVR_MODULE_NAMES)), device=0)
 eng.load_weights(synth.make_weights(d, seed=0))
+for k, v in knobs.items():
+    eng.debug_set(k, v)
 tr = Trainer(eng)
 dev = eng.device
 batches = [{k: torch.as_tensor(v).to(dev) for k, v in synth.make_inputs(d, seed=i).items()} for i in range(4)]
@@ -32,6 +35,9 @@ t1 = time.perf_counter()
 torch.cuda.synchronize(dev)
 t2 = time.perf_counter()
 host = np.array(host) * 1e3
+if knobs:
+    print('knobs', knobs, 'wall %.4f ms/step' % ((t2 - t0) / steps * 1e3))
+    sys.exit(0)
 print('steps %d: wall %.3f ms/step; host loop %.3f ms/step (median call %.3f, p10 %.3f, p90 %.3f); drain after the loop %.3f ms'
       % (steps, (t2 - t0) / steps * 1e3, (t1 - t0) / steps * 1e3, np.median(host), np.percentile(host, 10),
          np.percentile(host, 90), (t2 - t1) * 1e3))
