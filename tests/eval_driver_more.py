@@ -46,9 +46,10 @@ def vqa_weights():
     return synth.make_weights_from_shapes(vqa_variable_shapes(vqa_dims()), seed=0)
 
 
-def build_vqa_scratch(tmp_path):
+def build_vqa_scratch(tmp_path, imdb_dir='imdb_vqa_v2'):
+    """imdb_dir: 'imdb_vqa_v2' for eval_vqa2.py (:51), 'imdb' for eval_vqa.py (:51) -- all the two scripts differ in"""
     data = tmp_path / 'exp_vqa' / 'data'
-    (data / 'imdb_vqa_v2').mkdir(parents=True)
+    (data / imdb_dir).mkdir(parents=True)
     for f in ('vocabulary_vqa.txt', 'vocabulary_layout.txt', 'answers_vqa.txt'):
         shutil.copy(os.path.join(REF, 'exp_vqa', 'data', f), data / f)          # data files, scratch only
     words = [l.strip() for l in open(data / 'vocabulary_vqa.txt')]
@@ -66,7 +67,7 @@ def build_vqa_scratch(tmp_path):
                          question_str='synthetic question %d' % i,
                          question_tokens=[words[int(rng.integers(0, len(words)))] for _ in range(L)],
                          gt_layout_tokens=list(layouts[i % 3])))
-    np.save(data / 'imdb_vqa_v2' / 'imdb_syn.npy', np.array(imdb, dtype=object), allow_pickle=True)
+    np.save(data / imdb_dir / 'imdb_syn.npy', np.array(imdb, dtype=object), allow_pickle=True)
     w = vqa_weights()
     snap = tmp_path / 'exp_vqa' / 'tfmodel' / 'exp0'
     snap.mkdir(parents=True)
@@ -86,21 +87,22 @@ def vqa_import_map():
     }
 
 
-def run_vqa_script(tmp_path, monkeypatch, engine_cls, recorder=None):
-    """exp_vqa/eval_vqa2.py, every line of it; `engine_cls` replaces n2nmn_amd.vqa.VQAEngine behind the face"""
+def run_vqa_script(tmp_path, monkeypatch, engine_cls, recorder=None, script='eval_vqa2.py'):
+    """exp_vqa/eval_vqa2.py (or eval_vqa.py, the VQAv1 form), every line of it; `engine_cls` replaces
+    n2nmn_amd.vqa.VQAEngine behind the face"""
     import runpy
     from n2nmn_amd import models_vqa, runtime
     sys.dont_write_bytecode = True
-    data, words, answers, w = build_vqa_scratch(tmp_path)
+    data, words, answers, w = build_vqa_scratch(tmp_path, 'imdb_vqa_v2' if script == 'eval_vqa2.py' else 'imdb')
     monkeypatch.setattr(models_vqa, 'VQAEngine', engine_cls)
     monkeypatch.setattr(runtime, '_MODELS', [])
     if recorder is not None:
         recorder.install(monkeypatch)
     for name, mod in vqa_import_map().items():
         monkeypatch.setitem(sys.modules, name, mod)
-    monkeypatch.setattr(sys, 'argv', list(VQA_ARGV))
+    monkeypatch.setattr(sys, 'argv', [script] + list(VQA_ARGV[1:]))
     monkeypatch.chdir(tmp_path)
-    g = runpy.run_path(VQA_SCRIPT, run_name='__main__')
+    g = runpy.run_path(os.path.join(REF, 'exp_vqa', script), run_name='__main__')
     return g, data, words, answers, w
 
 

@@ -116,6 +116,33 @@ def test_eval_vqa2_script_runs_unmodified_against_the_drop_in(tmp_path, monkeypa
     assert MT.same(fresh, {k: z[k] for k in z.files}) is None
 
 
+def test_eval_vqa_v1_script_runs_unmodified_and_issues_the_recorded_vqa2_session(tmp_path, monkeypatch):
+    """/root/reference/exp_vqa/eval_vqa.py (the VQAv1 driver; VERDICT r5 "missing" #6), every line of it.  It
+    differs from eval_vqa2.py in ONE line -- the imdb it reads (:51, ./exp_vqa/data/imdb/ instead of
+    imdb_vqa_v2/) -- so on the same synthetic questions it must issue exactly the session that is committed for
+    eval_vqa2.py (tests/golden/eval_driver_trace_vqa2.npz, replayed on the HIP engine by
+    tests/test_gpu_eval_driver_trace.py) and write the same answers."""
+    import json
+    import eval_driver_more as EM
+    from n2nmn_amd import models_vqa
+    from oracle_engine import OracleVQAEngine
+    ref = os.path.join(EC.REF, 'exp_vqa')
+    a, b = open(os.path.join(ref, 'eval_vqa.py')).read().splitlines(), open(os.path.join(ref, 'eval_vqa2.py')).read().splitlines()
+    assert len(a) == len(b) and [i for i in range(len(a)) if a[i] != b[i]] == [50]      # line 51, the imdb path
+    rec = EC.SessionRecorder(None, model_cls=models_vqa.NMN3Model, feature_fn=EM.vqa_feature_of,
+                             n_questions=EM.VQA_N)
+    g, data, words, answers, w = EM.run_vqa_script(tmp_path, monkeypatch, OracleVQAEngine, rec, script='eval_vqa.py')
+    assert g['nmn3_model_tst'].vqa.calls == dict(seq2seq=2, execute=2)
+    res = json.load(open(tmp_path / 'exp_vqa' / 'eval_outputs' / 'exp0' /
+                         'vqa_OpenEnded_mscoco_syn_exp0_00040000_results.json'))
+    assert [r['question_id'] for r in res] == [1000 + i for i in range(EM.VQA_N)]
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import make_eval_driver_trace as MT
+    z = np.load(MT.OUT_VQA)
+    fresh = MT.pack_trace(rec, [r['answer'] for r in res], answers, result_dtype=np.float32)
+    assert MT.same(fresh, {k: z[k] for k in z.files}) is None
+
+
 def test_eval_shapes_script_runs_unmodified_against_the_drop_in(tmp_path, monkeypatch):
     """/root/reference/exp_shapes/eval_shapes.py, every line of it (BASELINE.json configs[0]) on the reference's
     own `train.tiny` files: models_shapes' Assembler / NMN3ModelAtt (EOS_idx instead of an assembler, no
