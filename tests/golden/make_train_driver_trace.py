@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Recorded runs of the reference's TRAINING drivers against the drop-in:
-exp_clevr/train_clevr_gt_layout.py and exp_clevr/train_clevr_rl_gt_layout.py, executed unmodified in the
+exp_clevr/train_clevr_gt_layout.py, exp_clevr/train_clevr_rl_gt_layout.py and exp_clevr/train_clevr_scratch.py
+(policy gradient from random weights: no ground-truth layouts are even loaded), executed unmodified in the
 scratch tree of tests/train_driver_common.py over the CPU oracle doubles (OracleEngine + OracleTrainer, fp64).
 
 Recorded per script: the batches its reader delivered (text, lengths, labels, layouts, image features by question
@@ -25,6 +26,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests'), HERE]
 OUT_GT = os.path.join(HERE, 'train_driver_trace_gt.npz')
 OUT_RL = os.path.join(HERE, 'train_driver_trace_rl.npz')
+OUT_SCRATCH = os.path.join(HERE, 'train_driver_trace_scratch.npz')
 PROBES = 8                     # elements per variable compared after the last step
 
 
@@ -93,11 +95,15 @@ def record(which):
     from oracle_engine import OracleEngine, OracleTrainer
     mp = _Patch()
     OracleTrainer.made.clear()
-    rec = EC.SessionRecorder(TC.train_dims(), n_questions=TC.N_QUESTIONS)
+    rec = EC.SessionRecorder(TC.train_dims(TC.T_DECODER_SCRATCH if which == 'scratch' else None),
+                             n_questions=TC.N_QUESTIONS)
     with tempfile.TemporaryDirectory() as tmp:
         try:
             if which == 'gt':
                 g, d, batches, w = TC.run_train_script(TC.SCRIPT_GT, Path(tmp), mp, OracleEngine, OracleTrainer, rec)
+            elif which == 'scratch':
+                g, d, batches, w = TC.run_train_script(TC.SCRIPT_SCRATCH, Path(tmp), mp, OracleEngine, OracleTrainer,
+                                                       rec, t_decoder=TC.T_DECODER_SCRATCH)
             else:
                 g, d, batches, w = TC.run_train_script(TC.SCRIPT_RL, Path(tmp), mp, OracleEngine, OracleTrainer, rec,
                                                        with_snapshot=True, seed_weights=False)
@@ -107,7 +113,7 @@ def record(which):
 
 
 if __name__ == '__main__':
-    for which, path in (('gt', OUT_GT), ('rl', OUT_RL)):
+    for which, path in (('gt', OUT_GT), ('rl', OUT_RL), ('scratch', OUT_SCRATCH)):
         fresh = record(which)
         if '--check' in sys.argv:
             z = np.load(path)

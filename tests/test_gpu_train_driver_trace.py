@@ -1,8 +1,8 @@
 """The reference's TRAINING drivers driving the HIP engine and the HIP Trainer, as far as that can be arranged
 when the reference checkout and the GPU never meet.
 
-tests/golden/train_driver_trace_{gt,rl}.npz record what exp_clevr/train_clevr_gt_layout.py and
-exp_clevr/train_clevr_rl_gt_layout.py, executed UNMODIFIED on the CPU box, asked of the drop-in and got back from
+tests/golden/train_driver_trace_{gt,rl,scratch}.npz record what exp_clevr/train_clevr_gt_layout.py,
+exp_clevr/train_clevr_rl_gt_layout.py and exp_clevr/train_clevr_scratch.py, executed UNMODIFIED on the CPU box, asked of the drop-in and got back from
 the fp64 oracle doubles (tests/golden/make_train_driver_trace.py; re-recorded and compared on every CPU run by
 tests/test_reference_train_driver_source.py).  Here the scripts' graph-building statements are issued to the same
 `n2nmn_amd.runtime.tf` names in the same order (train_clevr_gt_layout.py:84-130 / rl :82-132 -- the lines are cited
@@ -146,19 +146,23 @@ def test_replay_of_train_clevr_gt_layout_on_the_hip_trainer(tmp_path):
     tf.train.Saver().restore(sess, snapshot_file)               # (eval_clevr.py:90-91 on the file just written)
 
 
-def test_replay_of_train_clevr_rl_gt_layout_on_the_hip_trainer(tmp_path):
+def _replay_policy_gradient(trace, tmp_path, scratch):
+    """train_clevr_rl_gt_layout.py (scratch=False) or train_clevr_scratch.py (scratch=True: T_decoder 6, Adam at its
+    default learning rate, no snapshot restored -- the run starts from the initializer, whose draws the recording
+    replaced with seeded weights)"""
     from n2nmn_amd.nmn3_assembler import Assembler
     from n2nmn_amd.nmn3_model import NMN3Model
     from n2nmn_amd.runtime import tf
     from n2nmn_amd import runtime, runtime_train, tf_checkpoint
-    z, meta = _load('train_driver_trace_rl.npz')
-    d = TC.train_dims()
+    z, meta = _load(trace)
+    d = TC.train_dims(TC.T_DECODER_SCRATCH if scratch else None)
     runtime._MODELS.clear()
     runtime_train._GLOBALS.clear()
     kw = dict(meta['model_kwargs'])
     assert kw.pop('assembler') == 'Assembler' and 'use_gt_layout' not in kw
+    assert kw['T_decoder'] == d.T_decoder
     rl = meta['rl']
-    # ---- the script's graph (train_clevr_rl_gt_layout.py) ------------------------------------------------------
+    # ---- the script's graph (train_clevr_rl_gt_layout.py; train_clevr_scratch.py is the same block 3 lines up) ----
     sess = tf.Session(config=tf.ConfigProto(gpu_options=tf.GPUOptions(allow_growth=True)))
     assembler = Assembler(list(synth.CLEVR_MODULE_NAMES))
     input_seq_batch = tf.placeholder(tf.int32, [None, None])                                          # :82-86
@@ -178,18 +182,24 @@ def test_replay_of_train_clevr_rl_gt_layout_on_the_hip_trainer(tmp_path):
     total_training_loss = policy_gradient_loss + avg_sample_loss
     total_loss = tf.add_n([total_training_loss, rl['lambda_entropy'] * model.entropy_reg,
                            meta['weight_decay'] * model.l2_reg])                                      # :127-129
-    solver = tf.train.AdamOptimizer(learning_rate=meta['hyper']['lr'])                                # :132
+    if scratch:
+        solver = tf.train.AdamOptimizer()                                                             # scratch :127
+    else:
+        solver = tf.train.AdamOptimizer(learning_rate=meta['hyper']['lr'])                            # :132
     gradients = solver.compute_gradients(total_loss)
     gradients = [(tf.clip_by_norm(g, meta['hyper']['max_grad_l2_norm']), v) for g, v in gradients]
     solver_op = solver.apply_gradients(gradients)
     with tf.control_dependencies([solver_op, baseline_update_op]):                                    # :144-145
         train_step = tf.constant(0)
     sess.run(tf.global_variables_initializer())                                                       # :165
-    # `snapshot_loader.restore(sess, pretrained_model)` (:168-169): a TensorFlow-format checkpoint of the weights
-    # the recording's scratch tree held
-    tf_checkpoint.write_checkpoint(str(tmp_path / '00050000'), synth.make_weights(d, seed=3))
-    snapshot_loader = tf.train.Saver([v for v in tf.global_variables() if v != baseline])
-    snapshot_loader.restore(sess, str(tmp_path / '00050000'))
+    if scratch:
+        model.load_weights(synth.make_weights(d, seed=3))       # (the recording started from these: run_train_script)
+    else:
+        # `snapshot_loader.restore(sess, pretrained_model)` (:168-169): a TensorFlow-format checkpoint of the weights
+        # the recording's scratch tree held
+        tf_checkpoint.write_checkpoint(str(tmp_path / '00050000'), synth.make_weights(d, seed=3))
+        snapshot_loader = tf.train.Saver([v for v in tf.global_variables() if v != baseline])
+        snapshot_loader.restore(sess, str(tmp_path / '00050000'))
     n_iter = len(meta['iterations'])
     same_tokens, compared = True, 0
     for i in range(n_iter):
@@ -199,6 +209,7 @@ def test_replay_of_train_clevr_rl_gt_layout_on_the_hip_trainer(tmp_path):
         tokens, entropy_reg_val = sess.partial_run(h, (model.predicted_tokens, model.entropy_reg), feed_dict={
             input_seq_batch: z['b%d_input_seq' % i], seq_length_batch: z['b%d_seq_length' % i],
             image_feat_batch: _features(z['b%d_image_ids' % i], d)})
+        assert tokens.shape[0] == d.T_decoder
         expr_list, expr_validity_array = assembler.assemble(tokens)
         assert np.all(expr_validity_array)                       # (the script asserts it too, :194)
         expr_feed = compiler.build_feed_dict(expr_list)
@@ -218,9 +229,19 @@ def test_replay_of_train_clevr_rl_gt_layout_on_the_hip_trainer(tmp_path):
             assert es <= (1e-4 if i == 0 else 5e-3) and el <= (1e-4 if i == 0 else 2e-3), (i, es, el)
     step = train_step._step
     assert step.plan.objective == 1 and type(step.trainer).__module__ == 'n2nmn_amd.train'
-    assert step.trainer.rl == rl and step.trainer.hyper['lr'] == meta['hyper']['lr']
-    print('train_clevr_rl_gt_layout replay: %d of %d iterations sampled the recorded layouts and were compared'
-          % (compared, n_iter))
+    assert step.trainer.hyper['lr'] == meta['hyper']['lr'] and step.trainer.weight_decay == meta['weight_decay']
+    for k in rl:
+        assert abs(step.trainer.rl[k] - rl[k]) < 1e-6, k
+    print('%s replay: %d of %d iterations sampled the recorded layouts and were compared' % (trace, compared, n_iter))
     assert compared >= 3
     b = float(sess.run(baseline))
     assert 0.5 < b < 4.0 and abs(b - step.trainer.get_baseline()) < 1e-7
+
+
+def test_replay_of_train_clevr_rl_gt_layout_on_the_hip_trainer(tmp_path):
+    _replay_policy_gradient('train_driver_trace_rl.npz', tmp_path, scratch=False)
+
+
+def test_replay_of_train_clevr_scratch_on_the_hip_trainer(tmp_path):
+    """tests/golden/train_driver_trace_scratch.npz: exp_clevr/train_clevr_scratch.py, UNMODIFIED, on the CPU box"""
+    _replay_policy_gradient('train_driver_trace_scratch.npz', tmp_path, scratch=True)

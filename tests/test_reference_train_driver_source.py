@@ -1,8 +1,8 @@
 """The reference's own TRAINING drivers, UNMODIFIED, against the drop-in (VERDICT r5 "missing" #1; SURVEY 8(b):
 "what calls it: ... train scripts train_clevr_gt_layout.py:60-223").
 
-`/root/reference/exp_clevr/train_clevr_gt_layout.py` and `.../train_clevr_rl_gt_layout.py` are executed as
-scripts (runpy, `__main__`); their imports are answered by the drop-in --
+`/root/reference/exp_clevr/train_clevr_gt_layout.py`, `.../train_clevr_rl_gt_layout.py` and
+`.../train_clevr_scratch.py` are executed as scripts (runpy, `__main__`); their imports are answered by the drop-in --
 
     import tensorflow as tf  -> n2nmn_amd.runtime.tf: placeholder, constant, nn.sparse_softmax_cross_entropy_with_logits,
                                 reduce_mean, where, ones_like, stop_gradient, add_n, Variable, assign_add,
@@ -126,6 +126,39 @@ def test_train_clevr_rl_gt_layout_script_runs_unmodified_against_the_drop_in(tmp
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
     import make_train_driver_trace as MT
     z = np.load(MT.OUT_RL)
+    assert MT.same(MT.pack(rec, batches, tr), {k: z[k] for k in z.files}) is None
+
+
+def test_train_clevr_scratch_script_runs_unmodified_against_the_drop_in(tmp_path, monkeypatch, capsys):
+    """/root/reference/exp_clevr/train_clevr_scratch.py, every line of it: policy gradient from freshly initialised
+    weights, T_decoder = 6, no ground-truth layouts loaded (load_gt_layout=False, :71-72), invalid_expr_loss = ln 28,
+    lambda_entropy = 0.01, weight_decay = 0, Adam at its default learning rate, no snapshot restored."""
+    from oracle_engine import OracleEngine, OracleTrainer
+    OracleTrainer.made.clear()
+    d = TC.train_dims(TC.T_DECODER_SCRATCH)
+    rec = _recorder(d)
+    g, d, batches, w = TC.run_train_script(TC.SCRIPT_SCRATCH, tmp_path, monkeypatch, OracleEngine, OracleTrainer, rec,
+                                           t_decoder=TC.T_DECODER_SCRATCH)
+    assert g['T_decoder'] == 6 and all('gt_layout_batch' not in b for b in batches)
+    assert len(OracleTrainer.made) == 1
+    tr = OracleTrainer.made[0]
+    assert tr.hyper == dict(lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, max_grad_l2_norm=10.0)
+    assert tr.weight_decay == 0.0 and tr.rl['lambda_entropy'] == 0.01 and tr.rl['baseline_decay'] == 0.99
+    assert abs(tr.rl['invalid_expr_loss'] - np.log(28)) < 1e-6          # (the graph holds it as a float32 constant)
+    assert [o for o, _ in tr.history] == [1] * TC.N_ITERS
+    plan = g['train_step']._step.plan
+    assert plan.objective == 1 and plan.baseline is g['baseline'] and plan.weight_decay == 0.0
+    # sampled layouts: at most 6 tokens, valid, not all alike
+    first_tokens = [c for c in rec.calls if c['fetch'].startswith('(predicted_tokens')][0]['result_list'][0]
+    assert first_tokens.shape[0] == 6 and len({tuple(c) for c in first_tokens.T}) > 1
+    b = float(np.log(28))
+    for _, L in tr.history:
+        b = b + (1 - 0.99) * (L['avg_sample_loss'] - b)
+    assert abs(tr.get_baseline() - b) < 1e-6
+    assert 'iter = 20\n\tloss = ' in capsys.readouterr().out
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import make_train_driver_trace as MT
+    z = np.load(MT.OUT_SCRATCH)
     assert MT.same(MT.pack(rec, batches, tr), {k: z[k] for k in z.files}) is None
 
 

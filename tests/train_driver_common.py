@@ -21,14 +21,16 @@ from n2nmn_amd.spec import Dims
 REF = EC.REF
 SCRIPT_GT = os.path.join(REF, 'exp_clevr', 'train_clevr_gt_layout.py')
 SCRIPT_RL = os.path.join(REF, 'exp_clevr', 'train_clevr_rl_gt_layout.py')
+SCRIPT_SCRATCH = os.path.join(REF, 'exp_clevr', 'train_clevr_scratch.py')
 N_QUESTIONS = 24
 BATCH = 6                  # questions per batch delivered to the script
 N_ITERS = 21               # log_interval = 20: iteration 20 writes the TensorBoard summary
 T_DECODER = 10             # train_clevr_gt_layout.py:35
+T_DECODER_SCRATCH = 6       # train_clevr_scratch.py:35
 
 
-def train_dims():
-    return Dims(T_decoder=T_DECODER)
+def train_dims(t_decoder=None):
+    return Dims(T_decoder=t_decoder or T_DECODER)
 
 
 def build_scratch(tmp_path, d: Dims, with_snapshot=False):
@@ -84,7 +86,7 @@ def short_reader(batches_seen):
 
 
 def run_train_script(script, tmp_path, monkeypatch, engine_cls, trainer_cls, recorder=None, argv=None,
-                     with_snapshot=False, seed_weights=True):
+                     with_snapshot=False, seed_weights=True, t_decoder=None):
     """Executes the reference's training script, every line of it, in a scratch tree.  engine_cls / trainer_cls
     replace n2nmn_amd.engine.Engine / n2nmn_amd.train.Trainer behind the drop-in's Python face (None: the HIP
     ones).  seed_weights: `sess.run(tf.global_variables_initializer())` loads the scratch's seeded weights
@@ -92,7 +94,7 @@ def run_train_script(script, tmp_path, monkeypatch, engine_cls, trainer_cls, rec
     import runpy
     from n2nmn_amd import nmn3_model, runtime, runtime_train, train
     sys.dont_write_bytecode = True
-    d = train_dims()
+    d = train_dims(t_decoder)
     data, words, answers, w = build_scratch(tmp_path, d, with_snapshot)
     if engine_cls is not None:
         monkeypatch.setattr(nmn3_model, 'Engine', engine_cls)
