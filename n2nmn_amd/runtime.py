@@ -58,6 +58,18 @@ class _Handle:
         self.phase1 = None      # results of phase 1 (device tensors)
         self.results = {}
         self.env = {}           # id(graph node) -> value computed by this run (runtime_train.evaluate)
+        # the `train_step` constant among the declared fetches, if any: a model face that trains under dropout
+        # draws ONE set of masks per handle, in phase 1, for the step that runs in phase 2 (TensorFlow evaluates
+        # a dropout op once per partial_run handle)
+        self.train_const = next((f for f in self.allowed_fetches if isinstance(f, _rt.Const) and f.deps), None)
+
+    def train_step(self):
+        c = self.train_const
+        if c is None:
+            return None
+        if getattr(c, '_step', None) is None:
+            c._step = _rt.TrainStep(c)
+        return c._step
 
 
 class Session:
@@ -138,6 +150,18 @@ class Session:
                                      for p in fetches.parts})
         if isinstance(fetches, _rt.Variable):
             return np.float32(fetches.read())
+        if isinstance(fetches, _rt.Op) and fetches.kind == 'assign':
+            # sess.run(tf.assign(embedding_mat, glove_mat)) (exp_vqa/train_vqa2_gt_layout.py:166-169)
+            var, value = fetches.args
+            if not isinstance(var, _rt.ModelVariable):
+                raise NotImplementedError('tf.assign: model variables only')
+            value = np.asarray(resolve(value, feed_dict or {}), np.float32)
+            if tuple(value.shape) != tuple(var.shape):
+                raise ValueError('tf.assign(%s): shape %s, the variable is %s' % (var.name, value.shape, var.shape))
+            w = {k: to_numpy(v) for k, v in var.model.get_weights().items()}
+            w[var.name] = value
+            var.model.load_weights(w)
+            return value
         h = self.partial_run_setup(fetches, list((feed_dict or {}).keys()))
         return self.partial_run(h, fetches, feed_dict)
 
@@ -228,7 +252,36 @@ def _softmax_ce(_sentinel=None, labels=None, logits=None, name=None):
     return _rt.Op('softmax_ce', logits, labels)
 
 
+_SCOPE = []
+
+
+class _VariableScope:
+    """tf.variable_scope(name, reuse=True): a prefix for tf.get_variable (train_vqa2_gt_layout.py:166-167)"""
+
+    def __init__(self, name, reuse=None, **kw):
+        self.name = name if isinstance(name, str) else getattr(name, 'name', str(name))
+
+    def __enter__(self):
+        _SCOPE.append(self.name.strip('/'))
+        return self
+
+    def __exit__(self, *exc):
+        _SCOPE.pop()
+        return False
+
+
+def _get_variable(name, *args, **kwargs):
+    """an EXISTING variable of a model built so far, by its scoped name (reuse=True: nothing is ever created here)"""
+    full = '/'.join(_SCOPE + [name])
+    for v in _rt.global_variables():
+        if getattr(v, 'name', None) == full:
+            return v
+    raise ValueError('Variable %s does not exist (tf.get_variable under reuse=True)' % full)
+
+
 tf = _Namespace(
+    variable_scope=_VariableScope, get_variable=_get_variable,
+    assign=lambda ref, value, **kw: _rt.Op('assign', ref, value),
     Session=lambda config=None, **kw: Session(),
     ConfigProto=_config, GPUOptions=_config,
     placeholder=placeholder,

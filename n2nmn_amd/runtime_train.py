@@ -448,6 +448,8 @@ def evaluate(e, env):
 # ---------------------------------------------------------------------------------------------------
 def _new_trainer(model, plan: LossPlan, op: TrainOp):
     from .train import Trainer
+    if hasattr(model, 'new_trainer'):             # a face with its own Trainer (models_vqa: dropout)
+        return model.new_trainer(plan, op)
     h = op.optimizer.hyper
     return Trainer(model.engine, weight_decay=plan.weight_decay, lr=h['lr'], beta1=h['beta1'], beta2=h['beta2'],
                    eps=h['eps'], max_grad_l2_norm=op.clip_norm if op.clip_norm is not None else 0.0)
@@ -472,21 +474,27 @@ class TrainStep:
             raise NotImplementedError('the policy-gradient step updates its baseline in the same run (rl :131-132)')
         self.trainer = None
 
-    def run(self, handle):
-        """forward + backward + clip + Adam on the feeds of this partial_run handle; fills handle.results"""
-        from .runtime import resolve, to_numpy
-        m, plan = self.model, self.plan
+    def ensure_trainer(self):
         if self.trainer is None:
-            self.trainer = _new_trainer(m, plan, self.op)
+            plan = self.plan
+            self.trainer = _new_trainer(self.model, plan, self.op)
             if plan.objective == 1:
                 self.trainer.rl.update(invalid_expr_loss=plan.invalid_expr_loss, lambda_entropy=plan.lambda_entropy,
                                        baseline_decay=self.baseline_decay)
                 self.trainer.set_baseline(float(plan.baseline.read()))
                 plan.baseline._reader = self.trainer.get_baseline
+        return self.trainer
+
+    def run(self, handle):
+        """forward + backward + clip + Adam on the feeds of this partial_run handle; fills handle.results"""
+        from .runtime import resolve, to_numpy
+        m, plan = self.model, self.plan
+        self.ensure_trainer()
         if handle.phase1 is None:
-            handle.phase1 = m.run_phase1(handle.feeds)
+            handle.phase1 = m.run_phase1_training(handle) if hasattr(m, 'run_phase1_training') else \
+                m.run_phase1(handle.feeds)
         tokens = to_numpy(handle.phase1['predicted_tokens'])
-        s2s = m.att_seq2seq._inputs
+        s2s = getattr(m, 'att_seq2seq', m)._inputs
         batch = dict(input_seq_batch=resolve(s2s['input_seq'], handle.feeds),
                      seq_length_batch=resolve(s2s['seq_len'], handle.feeds),
                      image_feat_batch=resolve(m.image_feat_grid, handle.feeds),

@@ -174,7 +174,10 @@ def _lstm_w(w, which, layer):
 # ----------------------------------------------------------------------------------------
 # encoder -- models_clevr/nmn3_netgen_att.py:73-113
 # ----------------------------------------------------------------------------------------
-def encoder_forward(w, input_seq, seq_len, dtype=np.float64):
+def encoder_forward(w, input_seq, seq_len, dtype=np.float64, drop0=None):
+    """drop0 [T, N, L] of {0, 1} keep masks (encoder_dropout=True, models_vqa/nmn3_netgen_att.py:17-44: the
+    DropoutWrapper(output_keep_prob=0.5) around layer 0 scales what FEEDS layer 1 by mask / 0.5; the recurrent state
+    is not touched) -- the same statement as oracle/n2nmn_oracle_grad.py:encoder_forward"""
     w = _cast(w, dtype)
     T, N = input_seq.shape
     emb = w[_ENC + 'embedding_mat']
@@ -188,7 +191,7 @@ def encoder_forward(w, input_seq, seq_len, dtype=np.float64):
     for t in range(T):                                   # dynamic_rnn(sequence_length) A.2
         act = (t < seq_len)[:, None]
         nc0, nh0 = _lstm_cell(E[t], c0, h0, W0, b0)
-        nc1, nh1 = _lstm_cell(nh0, c1, h1, W1, b1)
+        nc1, nh1 = _lstm_cell(nh0 if drop0 is None else nh0 * (np.asarray(drop0[t], dtype) * dtype(2.0)), c1, h1, W1, b1)
         outs[t] = np.where(act, nh1, 0)                  # zero output past the length
         c0 = np.where(act, nc0, c0); h0 = np.where(act, nh0, h0)   # state carried through
         c1 = np.where(act, nc1, c1); h1 = np.where(act, nh1, h1)
@@ -204,7 +207,7 @@ def encoder_forward(w, input_seq, seq_len, dtype=np.float64):
 # decoder -- models_clevr/nmn3_netgen_att.py:115-322
 # ----------------------------------------------------------------------------------------
 def decoder_forward(w, enc, P, Wv, bv, T_dec, dtype=np.float64, use_gt_layout=False,
-                    gt_layout=None, sample_uniforms=None, forced_tokens=None):
+                    gt_layout=None, sample_uniforms=None, forced_tokens=None, drop0=None):
     """Greedy (default), teacher-forced (use_gt_layout + gt_layout[T_dec,N]) or sampled decoding.
 
     sample_uniforms[T_dec, N] in [0,1): replaces tf.multinomial (:216-217), whose RNG stream is
@@ -212,7 +215,8 @@ def decoder_forward(w, enc, P, Wv, bv, T_dec, dtype=np.float64, use_gt_layout=Fa
     to the greedy token when the sample is invalid (:219-232) is kept.
     forced_tokens[T_dec, N]: parity-protocol hook -- overrides the chosen token AFTER
     validity/probabilities are computed with the normal rules (unlike use_gt_layout it does not
-    change the validity mask)."""
+    change the validity mask).
+    drop0 [T_dec, N, L] of {0, 1}: decoder_dropout=True, as in encoder_forward."""
     w = _cast(w, dtype)
     (c0, h0), (c1, h1) = enc['states']                   # :177 initial state = encoder state
     N, L = h0.shape
@@ -236,7 +240,7 @@ def decoder_forward(w, enc, P, Wv, bv, T_dec, dtype=np.float64, use_gt_layout=Fa
     one = dtype(1.0)
     for t in range(T_dec):                               # raw_rnn: exactly T_dec cell calls (A.3)
         c0, h0 = _lstm_cell(x, c0, h0, W0, b0)
-        c1, h1 = _lstm_cell(h0, c1, h1, W1, b1)
+        c1, h1 = _lstm_cell(h0 if drop0 is None else h0 * (np.asarray(drop0[t], dtype) * dtype(2.0)), c1, h1, W1, b1)
         out = h1
         q = out @ Wa + ba                                # :184-187
         e = np.sum(np.tanh(q[None] + eht) * v, axis=2, keepdims=True)       # [T_enc, N, 1]

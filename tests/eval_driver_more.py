@@ -106,6 +106,110 @@ def run_vqa_script(tmp_path, monkeypatch, engine_cls, recorder=None, script='eva
     return g, data, words, answers, w
 
 
+# ---- models_vqa TRAINING drivers (exp_vqa/train_vqa2_gt_layout.py, train_vqa2_rl_gt_layout.py, and the VQAv1 forms) ----
+VQA_TRAIN_N = 24            # questions in the scratch imdb
+VQA_TRAIN_BATCH = 6         # questions per batch the reader delivers (the scripts ask for N = 64)
+VQA_TRAIN_ITERS = 21        # log_interval = 20: iteration 20 writes the summary
+
+
+def vqa_train_dims():
+    from n2nmn_amd.vqa import VQADims
+    return VQADims(N=64, lstm_dim=1000)          # exp_vqa/train_vqa2_gt_layout.py:29: lstm_dim = 1000
+
+
+def vqa_train_weights():
+    from n2nmn_amd import synth
+    from n2nmn_amd.vqa import vqa_variable_shapes
+    return synth.make_weights_from_shapes(vqa_variable_shapes(vqa_train_dims()), seed=5)
+
+
+def build_vqa_train_scratch(tmp_path, imdb_dir='imdb_vqa_v2', snapshot=None):
+    """exp_vqa/data/{vocabulary files, vocabulary_vqa_glove.npy, <imdb_dir>/imdb_trainval2014.npy}, feature files;
+    snapshot: '<experiment>/<iteration>' under exp_vqa/tfmodel/ that gets a TensorFlow-format checkpoint of the seeded
+    weights (the RL scripts' --pretrained_model defaults: vqa2_gt_layout/00080000, vqa_gt_layout/00040000)."""
+    data = tmp_path / 'exp_vqa' / 'data'
+    (data / imdb_dir).mkdir(parents=True)
+    for f in ('vocabulary_vqa.txt', 'vocabulary_layout.txt', 'answers_vqa.txt'):
+        shutil.copy(os.path.join(REF, 'exp_vqa', 'data', f), data / f)          # data files, scratch only
+    words = [l.strip() for l in open(data / 'vocabulary_vqa.txt')]
+    answers = [l.strip() for l in open(data / 'answers_vqa.txt')]
+    rng = np.random.default_rng(23)
+    # (the real file holds GloVe rows; any [num_vocab_txt, 300] array exercises `tf.assign(embedding_mat, glove_mat)`)
+    glove = (0.1 * rng.standard_normal((len(words), 300))).astype(np.float32)
+    np.save(data / 'vocabulary_vqa_glove.npy', glove)
+    feat_dir = tmp_path / 'feat'
+    feat_dir.mkdir()
+    layouts = (['_Find', '_Describe'], ['_Find', '_Find', '_And', '_Describe'], ['_Find', '_Transform', '_Describe'])
+    imdb = []
+    for i in range(VQA_TRAIN_N):
+        fp = str(feat_dir / ('%03d.npy' % i))
+        np.save(fp, vqa_feature_of(i))
+        L = int(rng.integers(2, 27))
+        imdb.append(dict(image_path='COCO_syn_%06d.jpg' % i, feature_path=fp, question_id=2000 + i,
+                         question_str='synthetic question %d' % i,
+                         question_tokens=[words[int(rng.integers(0, len(words)))] for _ in range(L)],
+                         # ONE valid answer per question: the reader's np.random.choice among them is then deterministic
+                         valid_answers=[answers[1 + int(rng.integers(0, len(answers) - 1))]],
+                         gt_layout_tokens=list(layouts[i % 3])))
+    np.save(data / imdb_dir / 'imdb_trainval2014.npy', np.array(imdb, dtype=object), allow_pickle=True)
+    w = vqa_train_weights()
+    if snapshot:
+        from n2nmn_amd import tf_checkpoint
+        snap = tmp_path / 'exp_vqa' / 'tfmodel' / snapshot
+        snap.parent.mkdir(parents=True)
+        tf_checkpoint.write_checkpoint(str(snap), w)
+    return data, words, answers, w, glove
+
+
+def vqa_short_reader(batches_seen):
+    from n2nmn_amd import models_vqa
+
+    class ShortReader(models_vqa.DataReader):
+        def __init__(self, imdb_file, **kw):
+            kw['batch_size'] = VQA_TRAIN_BATCH
+            kw['shuffle'] = False
+            super().__init__(imdb_file, **kw)
+
+        def batches(self):
+            for i, b in enumerate(super().batches()):
+                if i >= VQA_TRAIN_ITERS:
+                    return
+                batches_seen.append({k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v)
+                                     for k, v in b.items()})
+                yield b
+    return ShortReader
+
+
+def run_vqa_train_script(script, tmp_path, monkeypatch, engine_cls, trainer_cls, recorder=None, snapshot=None,
+                         seed_weights=True):
+    """exp_vqa/<script>, every line of it, in a scratch tree; engine_cls / trainer_cls replace VQAEngine / VQATrainer
+    behind the face (None: the HIP ones)"""
+    import runpy
+    from n2nmn_amd import models_vqa, runtime, runtime_train, vqa
+    sys.dont_write_bytecode = True
+    data, words, answers, w, glove = build_vqa_train_scratch(
+        tmp_path, 'imdb_vqa_v2' if 'vqa2' in script else 'imdb', snapshot)
+    if engine_cls is not None:
+        monkeypatch.setattr(models_vqa, 'VQAEngine', engine_cls)
+    if trainer_cls is not None:
+        monkeypatch.setattr(vqa, 'VQATrainer', trainer_cls)
+    monkeypatch.setattr(runtime, '_MODELS', [])
+    monkeypatch.setattr(runtime_train, '_GLOBALS', [])
+    if seed_weights:
+        monkeypatch.setattr(runtime_train, 'initial_weights', lambda shapes, seed=0: {k: w[k] for k in shapes})
+    if recorder is not None:
+        recorder.install(monkeypatch)
+    seen = []
+    mods = vqa_import_map()
+    mods['util.vqa_train.data_reader'] = EC.module('util.vqa_train.data_reader', DataReader=vqa_short_reader(seen))
+    for name, mod in mods.items():
+        monkeypatch.setitem(sys.modules, name, mod)
+    monkeypatch.setattr(sys, 'argv', [script])
+    monkeypatch.chdir(tmp_path)
+    g = runpy.run_path(os.path.join(REF, 'exp_vqa', script), run_name='__main__')
+    return g, seen, w, glove, answers
+
+
 # ---- SHAPES ---------------------------------------------------------------------------------------------
 def shapes_weights():
     """Seeded weights whose GREEDY layouts are valid.  models_shapes' decoder has no validity automaton, so
