@@ -1,3 +1,4 @@
+# (the "head" leg needs a copy of the previous commit's source at tools/diag/csrc/*_head.*.tmp -- not kept in the tree)
 # reverse-time step: operand sets in flight (UN chunks per set, one or two sets), whole training step each
 set -x
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06fwd1; mkdir -p $O

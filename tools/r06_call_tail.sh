@@ -1,3 +1,5 @@
+# (the "head" leg needs a copy of the previous commit's source at tools/diag/csrc/*_head.*.tmp:
+#  git show HEAD~1:n2nmn_amd/csrc/<file> > tools/diag/csrc/<file>_head.tmp -- not kept in the tree)
 # training step: the last chunk's x-table path on the caller's stream beside the side stream's weight gradients
 set -x
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06tail; mkdir -p $O
