@@ -422,6 +422,16 @@ def vqa_numbers(args, dp, local_rank, steps, warmup, profile=True, batches_per_p
     run_steps(0, warmup)
     elapsed = dp.timed(lambda: run_steps(warmup, steps),
                        sync=lambda: torch.cuda.synchronize(dev))
+    # the same passes with the features as plain [N, 14, 14, 2048] tensors: add_spatial_coordinate_map's work
+    # (models_vqa/nmn3_modules.py:11-31, inside the reference's graph) is then done per pass by n2nmn_add_coords --
+    # the figure comparable with rounds 1-4
+    elapsed_coords = None
+    if batches_per_pass == 1 and not device_layouts and not eos_retire:
+        slabs = batches
+        batches = [dict(b, image_feat_batch=b['image_feat_batch'][..., :d.D].contiguous()) for b in slabs]
+        run_steps(0, warmup)
+        elapsed_coords = dp.timed(lambda: run_steps(warmup, steps), sync=lambda: torch.cuda.synchronize(dev))
+        batches = slabs
     out = None
     if rank == 0:
         label = 'batch %d per GPU' % d.N if batches_per_pass == 1 else \
@@ -445,6 +455,12 @@ def vqa_numbers(args, dp, local_rank, steps, warmup, profile=True, batches_per_p
                           'parallelism': 'dp%d (question-sharded)' % world},
                'host_sync': 'none: tokens never leave the GPU between the phases (n2nmn_execute_tokens)'
                if device_layouts else 'none: gt_layout_batch is a host array, the program is assembled before phase 1'}
+        if elapsed_coords is not None:
+            out['with_per_pass_add_coords'] = {
+                'value': round(dp.throughput(d.N * steps, elapsed_coords), 1), 'unit': 'questions/sec',
+                'ms_per_step': round(1e3 * elapsed_coords / steps, 4),
+                'input_layout': 'features as [N, 14, 14, 2048] tensors; the coordinate channels are appended per pass '
+                                '(n2nmn_add_coords), as the reference does inside its graph'}
         if profile:
             ksteps = min(steps, 10)
             eng.engine.profile_begin()

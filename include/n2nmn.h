@@ -103,7 +103,7 @@ int n2nmn_ctx_dims(const n2nmn_ctx *ctx, n2nmn_dims *out);
 #define N2NMN_MODE_LATENCY    0
 #define N2NMN_MODE_THROUGHPUT 1
 #define N2NMN_MODE_THROUGHPUT_KSPLIT 2
-/* N2NMN_MODE_THROUGHPUT_BF16X3  (opt-in) N2NMN_MODE_THROUGHPUT with the recurrent contraction of passes of
+/* N2NMN_MODE_THROUGHPUT_BF16X3  (opt-in, experimental) N2NMN_MODE_THROUGHPUT with the recurrent contraction of passes of
  *   >= 128 rows on the bf16 matrix cores over three-way split operands: w = wh + wm + wl, h = hh + hm + hl
  *   (bf16 each, exact sums), six cross products per 16 x 16 x 32 block with fp32 accumulation
  *   (csrc/kernels_lstm_tile3.hip).  The dense contractions (encoder_h_transform, W_a, conv_image) stay on the
