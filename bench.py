@@ -1182,7 +1182,8 @@ def main():
         if 'kernels' in c4:
             out['config4']['kernels'] = c4['kernels'][:4]
         c5 = vqa_numbers(args, dp, local_rank, 10, 3, profile=True)
-        out['config5'] = {k: c5[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'config', 'host_sync')}
+        out['config5'] = {k: c5[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'config', 'host_sync',
+                                             'with_per_pass_add_coords') if k in c5}
         if 'kernels' in c5:
             out['config5']['kernels'] = c5['kernels'][:4]
         del c5
